@@ -1,0 +1,1115 @@
+// Per-seed consensus engine (host side).
+//
+// Everything the reference does inside nextCorrect() (lib/nextcorrect.c:2219-2305)
+// EXCEPT the pairwise O(ND) alignments, which are requested as AlnJob batches and
+// executed by the HIP kernels (csrc/ond_kernels.hip).  The logic here reproduces
+// the reference's observable behaviour bit for bit (tie-breaks, integer/float
+// conversions, first-seen ordering) but on our own data layout:
+//   * alignments arrive as column-kind streams (match / query-only / target-only)
+//     instead of two gapped strings,
+//   * the MSA link graph is one flat cell table + one link arena per pile
+//     (index-linked lists) instead of per-column malloc blocks,
+//   * low-quality regions keep std::string sequences instead of 10 kB slots,
+//   * sorting uses std::stable_sort, which yields the same permutation as glibc's
+//     merge-sort qsort() on the reference's comparators.
+// Reference locations are cited at each step.
+#include "nd_host.h"
+
+#include <algorithm>
+#include <cctype>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace ndgpu {
+
+ConsensusTrimed *make_error_seed(unsigned len) {
+    // lib/nextcorrect.c:261-266.  The reference leaves the buffer uninitialised;
+    // callers only look at `len` (lib/nextcorrect.py:236,255).  We zero it.
+    ConsensusTrimed *c = (ConsensusTrimed *)malloc(sizeof(ConsensusTrimed));
+    c->len = len;
+    c->identity = 0;
+    c->seq = (char *)calloc(len + 1, 1);
+    return c;
+}
+
+namespace {
+
+// lib/nextcorrect.c:42-62
+const unsigned char kIntToBase[7] = {'A', 'T', 'G', 'C', '-', 'N', 'M'};
+struct BaseLut {
+    uint8_t v[256];
+    BaseLut() {
+        memset(v, 4, sizeof(v));
+        v['A'] = v['a'] = 0;
+        v['T'] = v['t'] = 1;
+        v['G'] = v['g'] = 2;
+        v['C'] = v['c'] = 3;
+        v['N'] = 5;
+        v['M'] = 6;
+    }
+};
+const BaseLut kLut;
+inline uint8_t base_code(char c) { return kLut.v[(unsigned char)c]; }
+
+struct Tag {
+    int32_t t_pos;
+    uint16_t delta;
+    uint8_t base;
+};
+
+struct TagList {
+    unsigned aln_t_s = 0;
+    std::vector<Tag> tags;
+};
+
+struct Link {
+    int32_t pp_t;
+    int32_t ppp_t;
+    uint16_t pp_d;
+    uint16_t ppp_d;
+    uint8_t pp_b;
+    uint8_t ppp_b;
+    uint16_t count;
+    int32_t next;
+    int64_t score;
+};
+
+struct Cell {
+    int32_t head = -1, tail = -1;
+    uint32_t len = 0;
+    int64_t best_score = 0;
+    int32_t best_t = 0;  // calloc-zero initial state (lib/nextcorrect.c:181)
+    uint16_t best_d = 0;
+    uint8_t best_b = 0;
+    uint16_t best_link = 0;
+};
+
+struct Pos {
+    int32_t t;
+    uint16_t d;
+    uint8_t b;
+};
+
+// Flat MSA link graph of one (pseudo-)seed.
+struct Msa {
+    std::vector<uint16_t> max_size, coverage;
+    std::vector<uint32_t> cell_base;
+    std::vector<Cell> cells;
+    std::vector<Link> links;
+
+    explicit Msa(size_t ncol) : max_size(ncol, 0), coverage(ncol, 0) {}
+    size_t ncol() const { return max_size.size(); }
+    Cell &cell(int32_t t, unsigned d, unsigned b) { return cells[cell_base[t] + d * 6 + b]; }
+
+    // lib/nextcorrect.c:175-198
+    void allocate() {
+        cell_base.resize(ncol() + 1);
+        uint32_t acc = 0;
+        for (size_t p = 0; p < ncol(); p++) {
+            cell_base[p] = acc;
+            acc += (uint32_t)max_size[p] * 6;
+        }
+        cell_base[ncol()] = acc;
+        cells.assign(acc, Cell());
+    }
+
+    // lib/nextcorrect.c:212-250: count (pp,ppp) predecessor pairs per cell,
+    // keeping first-seen order inside each cell.
+    void count_links(const std::vector<TagList> &reads) {
+        size_t total = 0;
+        for (const TagList &r : reads) total += r.tags.size();
+        links.reserve(total / 4 + 16);
+        const Tag head{-1, 0, 0};
+        for (const TagList &r : reads) {
+            const size_t n = r.tags.size();
+            for (size_t i = 0; i < n; i++) {
+                const Tag &cur = r.tags[i];
+                const Tag &pp = i > 0 ? r.tags[i - 1] : head;
+                const Tag &ppp = i > 1 ? r.tags[i - 2] : head;
+                if (cur.base == 6 || pp.base == 6) continue;
+                Cell &c = cell(cur.t_pos, cur.delta, cur.base);
+                int32_t at = c.head;
+                while (at != -1) {
+                    Link &l = links[at];
+                    if (l.pp_t == pp.t_pos && l.pp_d == pp.delta && l.pp_b == pp.base && l.ppp_t == ppp.t_pos &&
+                        l.ppp_d == ppp.delta && l.ppp_b == ppp.base) {
+                        l.count++;
+                        break;
+                    }
+                    at = l.next;
+                }
+                if (at == -1) {
+                    Link l;
+                    l.pp_t = pp.t_pos; l.pp_d = pp.delta; l.pp_b = pp.base;
+                    l.ppp_t = ppp.t_pos; l.ppp_d = ppp.delta; l.ppp_b = ppp.base;
+                    l.count = 1; l.score = 0; l.next = -1;
+                    int32_t id = (int32_t)links.size();
+                    links.push_back(l);
+                    if (c.tail == -1) c.head = id;
+                    else links[c.tail].next = id;
+                    c.tail = id;
+                    c.len++;
+                }
+            }
+        }
+    }
+
+    // lib/nextcorrect.c:2149-2202 (main MSA).  Returns the backtrack origin.
+    Pos score_main(int factor) {
+        int64_t global_best = -10;
+        Pos origin{-1, 0, 0};
+        const int ncols = (int)ncol();
+        for (int p = 0; p < ncols; p++) {
+            const int64_t penalty = (int64_t)factor * coverage[p];
+            for (unsigned d = 0; d < max_size[p]; d++) {
+                for (unsigned b = 0; b < 5; b++) {
+                    Cell &c = cell(p, d, b);
+                    c.best_score = -10;
+                    c.best_t = -1;
+                    int64_t via = INT64_MIN, via_pending = INT64_MIN;
+                    for (int32_t m = c.head; m != -1; m = links[m].next) {
+                        Link &lm = links[m];
+                        if (lm.pp_t == -1) {
+                            lm.score = 10 * (int64_t)lm.count - penalty;
+                        } else {
+                            const Cell &pc = cell(lm.pp_t, lm.pp_d, lm.pp_b);
+                            for (int32_t n = pc.head; n != -1; n = links[n].next) {
+                                const Link &ln = links[n];
+                                if (ln.pp_t != lm.ppp_t || ln.pp_d != lm.ppp_d || ln.pp_b != lm.ppp_b) continue;
+                                int64_t s = ln.score + 10 * (int64_t)lm.count - penalty;
+                                if (s > lm.score) {
+                                    lm.score = s;
+                                    via_pending = ln.score;
+                                }
+                                if (ln.score > via && (lm.pp_b == 4 || lm.pp_b == b)) {
+                                    via = ln.score;
+                                    c.best_score = lm.score;
+                                    c.best_t = lm.pp_t; c.best_d = lm.pp_d; c.best_b = lm.pp_b;
+                                    c.best_link = lm.count;
+                                }
+                            }
+                        }
+                        if (lm.score > c.best_score || (lm.score == c.best_score && lm.pp_b != 4)) {
+                            via = via_pending;
+                            c.best_score = lm.score;
+                            c.best_t = lm.pp_t; c.best_d = lm.pp_d; c.best_b = lm.pp_b;
+                            c.best_link = lm.count;
+                        }
+                    }
+                    if (c.best_score >= global_best - 3000) {
+                        origin = Pos{p, (uint16_t)d, (uint8_t)b};
+                        if (c.best_score > global_best) global_best = c.best_score;
+                    }
+                }
+            }
+        }
+        return origin;
+    }
+
+    // lib/nextcorrect.c:1263-1300 (second, low-quality-region MSA): 6 symbols,
+    // plain max, origin = last cell.
+    Pos score_lq(int factor) {
+        Pos origin{-1, 0, 0};
+        const int ncols = (int)ncol();
+        for (int p = 0; p < ncols; p++) {
+            const int64_t penalty = (int64_t)factor * coverage[p];
+            for (unsigned d = 0; d < max_size[p]; d++) {
+                for (unsigned b = 0; b < 6; b++) {
+                    Cell &c = cell(p, d, b);
+                    c.best_score = -10;
+                    c.best_t = -1;
+                    for (int32_t m = c.head; m != -1; m = links[m].next) {
+                        Link &lm = links[m];
+                        if (lm.pp_t == -1) {
+                            lm.score = 10 * (int64_t)lm.count - penalty;
+                        } else {
+                            const Cell &pc = cell(lm.pp_t, lm.pp_d, lm.pp_b);
+                            for (int32_t n = pc.head; n != -1; n = links[n].next) {
+                                const Link &ln = links[n];
+                                if (ln.pp_t != lm.ppp_t || ln.pp_d != lm.ppp_d || ln.pp_b != lm.ppp_b) continue;
+                                int64_t s = ln.score + 10 * (int64_t)lm.count - penalty;
+                                if (s > lm.score) lm.score = s;
+                            }
+                        }
+                        if (lm.score > c.best_score || (lm.score == c.best_score && lm.pp_b != 4)) {
+                            c.best_score = lm.score;
+                            c.best_t = lm.pp_t; c.best_d = lm.pp_d; c.best_b = lm.pp_b;
+                            c.best_link = lm.count;
+                        }
+                    }
+                    origin = Pos{p, (uint16_t)d, (uint8_t)b};
+                }
+            }
+        }
+        return origin;
+    }
+};
+
+// get_align_tags (lib/nextcorrect.c:1485-1536) for an explicit pair of gapped strings.
+void tags_from_strings(const std::string &t_str, const std::string &q_str, unsigned aln_t_s, TagList &out, Msa &msa) {
+    const size_t n = t_str.size();
+    out.aln_t_s = aln_t_s;
+    out.tags.resize(n);
+    int32_t t = (int32_t)aln_t_s - 1;
+    uint16_t delta = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (t_str[i] != '-') {
+            t++;
+            delta = 0;
+        }
+        Tag &g = out.tags[i];
+        g.t_pos = t;
+        g.delta = delta++;
+        g.base = base_code(q_str[i]);
+        if (g.delta == 0 && q_str[i] != 'M') msa.coverage[t]++;
+        if (g.delta >= msa.max_size[t]) msa.max_size[t] = g.delta + 1;
+    }
+}
+
+struct LqSeq {
+    uint16_t order = 0, kscore = 0, len = 0;
+    std::string seq;
+};
+
+struct LqRegion {
+    unsigned start = 0, end = 0;
+    int len = 0;
+    uint8_t indexs = 0, indexe = 0;
+    unsigned lqcount = 0;
+    unsigned sudoseed_len = 0;
+    bool has_seed = false;
+    std::string sudoseed;  // sudoseed_len valid bytes
+    std::vector<LqSeq> seqs;
+};
+
+struct CnsBase {
+    unsigned pos;
+    char base;
+};
+
+struct CnsData {
+    unsigned len = 0, uncorrected_len = 0, lstrip = 0, rstrip = 0;
+    std::vector<CnsBase> bases;
+};
+
+struct LqReg {
+    unsigned start = 0, end = 0, lqlen = 0, lq_total_len = 0;
+};
+constexpr int kLqRegMax = 10;  // LQREG_MAX_COUNT
+
+// lib/nextcorrect.c:1340-1363
+int update_lqreg(LqReg *lq, const std::string &seq, unsigned p, int i, unsigned *hq_m, unsigned *lq_m) {
+    if (seq[p] >= 'a') {
+        if (!lq[i].lqlen) lq[i].start = p;
+        if ((*lq_m)++ > 2) *hq_m = 0;
+        lq[i].end = p;
+        lq[i].lqlen++;
+        lq[i].lq_total_len++;
+    } else {
+        if (lq[i].lqlen && lq[i].start == 0) {
+            i++;
+            *hq_m = 0;
+        } else if (*hq_m + lq[i].start > lq[i].end || (*hq_m)++ > 10) {
+            if (lq[i].end > lq[i].start + 100) i++;
+            else lq[i].lqlen = lq[i].end = 0;
+            *hq_m = 0;
+        } else if (*hq_m >= lq[i].lqlen) {
+            lq[i].lqlen = lq[i].end = 0;
+            *hq_m = 0;
+        }
+        *lq_m = 0;
+    }
+    return i;
+}
+
+// ---- 8-mer ranking of low-quality-region candidates (lib/nextcorrect.c:281-337)
+constexpr int kKmerLen = 8, kKmerRange = 40, kKmerBins = 65536, kKmerMaxSeq = 10;
+constexpr int kLqCanMax = 40, kLqSeqMax = 30, kLqRevLen = 2000;
+
+void count_kmers(const LqRegion &lq, uint16_t *bins, int c, int from_tail) {
+    memset(bins, 0, sizeof(uint16_t) * kKmerBins);
+    const int lim = std::min(lq.len, c);
+    for (int j = 0; j < lim; j++) {
+        const LqSeq &s = lq.seqs[j];
+        if (s.len < kKmerLen) continue;
+        const int off = from_tail && s.len > kKmerRange ? s.len - kKmerRange : 0;
+        const int n = std::min<int>(s.len, kKmerRange) - kKmerLen;
+        uint16_t km = 0;
+        for (int k = 0; k < n; k++) {
+            if (k) km = (uint16_t)(km << 2 | base_code(s.seq[off + k + kKmerLen - 1]));
+            else
+                for (int x = 0; x < kKmerLen; x++) km = (uint16_t)(km << 2 | base_code(s.seq[off + x]));
+            bins[km]++;
+        }
+    }
+}
+
+void count_kscore(LqRegion &lq, const uint16_t *bins, int from_tail) {
+    for (int j = 0; j < lq.len; j++) {
+        LqSeq &s = lq.seqs[j];
+        s.kscore = 0;
+        if (s.len < kKmerLen) continue;
+        const int off = from_tail && s.len > kKmerRange ? s.len - kKmerRange : 0;
+        const int n = std::min<int>(s.len, kKmerRange) - kKmerLen;
+        uint16_t km = 0;
+        for (int k = 0; k < n; k++) {
+            if (k) km = (uint16_t)(km << 2 | base_code(s.seq[off + k + kKmerLen - 1]));
+            else
+                for (int x = 0; x < kKmerLen; x++) km = (uint16_t)(km << 2 | base_code(s.seq[off + x]));
+            s.kscore = (uint16_t)(s.kscore + bins[km]);
+        }
+    }
+}
+
+void sort_by_kscore_desc(LqRegion &lq) {
+    // qsort(compare_seq_by_kscore) (lib/nextcorrect.c:254-258,413); glibc qsort is a
+    // stable merge sort, so the permutation equals std::stable_sort's.
+    std::stable_sort(lq.seqs.begin(), lq.seqs.begin() + lq.len,
+                     [](const LqSeq &a, const LqSeq &b) { return a.kscore > b.kscore; });
+}
+
+// ---- terminal SSR clipping (lib/nextcorrect.c:2008-2128)
+int terminal_ssr(int *bins, int range, int klen, const char *seq, int s) {
+    memset(bins, 0, sizeof(int) * 256);
+    uint8_t km = 0;
+    for (int i = 0; i < range; i++) {
+        if (i) km = (uint8_t)(km << 2 | base_code(seq[s + i + klen - 1]));
+        else
+            for (int k = 0; k < klen; k++) km = (uint8_t)(km << 2 | base_code(seq[s + k]));
+        bins[km]++;
+    }
+    int best = 0;
+    for (int i = 0; i < 256; i++)
+        if (bins[i] > best) {
+            best = bins[i];
+            km = (uint8_t)i;
+        }
+    return km;
+}
+
+int clip_ssr(const char *seq, int seq_len, int klen, int kmer, int from_end) {
+    const int gap = 20;
+    int i, p = 0, p1 = 0, p2 = 0;
+    uint8_t cur = 0;
+    if (from_end) {
+        uint8_t rk = 0;
+        for (i = 0; i < 8; i += 2) rk = (uint8_t)(rk << 2 | (kmer >> i & 3));
+        seq_len--;
+        kmer = rk;
+        for (i = 0; i < seq_len - klen; i++) {
+            if (i) cur = (uint8_t)(cur << 2 | base_code(seq[seq_len - i - klen + 1]));
+            else
+                for (int k = 0; k < klen; k++) cur = (uint8_t)(cur << 2 | base_code(seq[seq_len - k]));
+            if (cur != kmer) {
+                if (i - p > gap) {
+                    if (!p1) p1 = p;
+                    else if (p2) {
+                        if (i - p2 < 100) { p = p1; break; }
+                        else p1 = p2 = 0;
+                    }
+                }
+            } else {
+                p = i;
+                if (p1 && p2 == 0) p2 = p;
+            }
+        }
+    } else {
+        for (i = 0; i < seq_len - klen; i++) {
+            if (i) cur = (uint8_t)(cur << 2 | base_code(seq[i + klen - 1]));
+            else
+                for (int k = 0; k < klen; k++) cur = (uint8_t)(cur << 2 | base_code(seq[k]));
+            if (cur != kmer) {
+                if (i - p > gap) {
+                    if (!p1) p1 = p;
+                    else if (p2) {
+                        if (i - p2 < 100) { p = p1; break; }
+                        else p1 = p2 = 0;
+                    }
+                }
+            } else {
+                p = i;
+                if (p1 && p2 == 0) p2 = p;
+            }
+        }
+    }
+    return p > 100 ? p + klen : 0;
+}
+
+struct Result {
+    unsigned len = 0;
+    float identity = 0;
+    std::string seq;
+};
+
+void trim_terminal_ssr(Result &r) {
+    int bins[256];
+    const int range = 24, klen = 4;
+    int clip_s = 0, clip_e = 0;
+    const int L = (int)r.len;
+    int km = terminal_ssr(bins, range, klen, r.seq.c_str(), 0);
+    if (bins[km] >= 4) {
+        clip_s = clip_ssr(r.seq.c_str(), L, klen, km, 0);
+        while (clip_s < L && r.seq[clip_s] >= 'a') clip_s++;
+    }
+    km = terminal_ssr(bins, range, klen, r.seq.c_str(), L - range - klen + 1);
+    if (bins[km] >= 4) {
+        clip_e = clip_ssr(r.seq.c_str(), L, klen, km, 1);
+        while (clip_e < L && r.seq[L - clip_e - 1] >= 'a') clip_e++;
+    }
+    if (clip_s + clip_e < L - 10) {
+        r.seq = r.seq.substr(clip_s, L - clip_s - clip_e);
+        r.len = (unsigned)(L - clip_s - clip_e);
+    } else {
+        r.len = 4;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+
+class PileImpl {
+  public:
+    enum Phase { MAIN, LQ_ROUND, DONE };
+
+    CorrectParams prm;
+    unsigned lq_max_len;
+    std::vector<std::string> seqs;
+    std::vector<unsigned> aln_start, aln_end;
+    int seed_len;
+    Phase phase = MAIN;
+    std::vector<AlnJob> jobs;
+    Result result;
+    bool error2 = false;
+
+    // state carried through the low-quality-region rounds
+    std::vector<LqRegion> regions;
+    CnsData cns;
+    int lq_iter = 0;          // 1-based round being aligned
+    int lq_max_aln_length = 0;
+    int lq_max_dif_len = 0;
+    struct LqSlot { int i, j, job; };  // (row, region) -> job index or -1 ('M' fill)
+    std::vector<LqSlot> lq_slots;
+
+    PileImpl(const char *const *s, const unsigned *st, const unsigned *en, unsigned n, const CorrectParams &p)
+        : prm(p) {
+        lq_max_len = p.lqseq_max_length > 10000 ? 10000 : p.lqseq_max_length;  // DAG_MAX_LENGTH, nextcorrect.c:2231
+        seqs.reserve(n);
+        for (unsigned i = 0; i < n; i++) seqs.emplace_back(s[i]);
+        aln_start.assign(st, st + n);
+        aln_end.assign(en, en + n);
+        seed_len = n ? (int)en[0] + 1 : 0;
+        if (n == 0) { finish_error(2); return; }
+        // nextcorrect.c:2271-2293: every non-seed read is aligned to its seed window
+        jobs.resize(n > 0 ? n - 1 : 0);
+        for (unsigned i = 1; i < n; i++) {
+            AlnJob &j = jobs[i - 1];
+            j.q = seqs[i].c_str();
+            j.q_len = (int)seqs[i].size();
+            j.t = seqs[0].c_str() + aln_start[i];
+            j.t_len = (int)(aln_end[i] - aln_start[i] + 1);
+            j.hq = prm.read_type == 3;
+        }
+    }
+
+    void finish_error(unsigned code) {
+        result = Result();
+        result.len = code;
+        error2 = true;
+        phase = DONE;
+    }
+
+    void collect(std::vector<AlnJob *> &out) {
+        if (phase == DONE) return;
+        for (AlnJob &j : jobs) out.push_back(&j);
+    }
+
+    void advance() {
+        if (phase == MAIN) after_main();
+        else if (phase == LQ_ROUND) after_lq_round();
+    }
+
+    // -- main phase ----------------------------------------------------------------
+    std::vector<TagList> reads;  // accepted alignments in pile order
+
+    // get_align_shift(aln, 8) + get_align_tags on a column-kind stream
+    // (lib/nextcorrect.c:102-154, 1485-1536)
+    bool tags_from_ops(const AlnJob &job, unsigned t_s, unsigned t_e, Msa &msa, int &total_cov) {
+        if (job.status != ALN_OK) return false;
+        const std::vector<uint8_t> &ops = job.ops;
+        const int n = (int)ops.size();
+        int run = 0, i, tcols = 0;
+        for (i = 0; i < n; i++) {
+            run = ops[i] == OP_MATCH ? run + 1 : 0;
+            if (ops[i] != OP_QONLY) tcols++;
+            if (run == 8) break;
+        }
+        if (i >= n) return false;
+        const int shift = i - 7;
+        t_s += (unsigned)(tcols - 8);
+        run = 0;
+        int tc = 0;
+        for (i = n - 1; i >= 0; i--) {
+            run = ops[i] == OP_MATCH ? run + 1 : 0;
+            if (ops[i] != OP_QONLY) tc++;
+            if (run == 8) break;
+        }
+        t_e = t_e - (unsigned)tc + 8;
+        const int last = i + 7;
+        const unsigned aln_len = (unsigned)(last - shift + 1);
+        if (aln_len < prm.min_len_aln) return false;
+        total_cov += (int)(t_e - t_s + 1);
+
+        reads.emplace_back();
+        TagList &tl = reads.back();
+        tl.aln_t_s = t_s;
+        tl.tags.resize(aln_len);
+        // query offset of column `shift`
+        int qi = 0;
+        for (int c = 0; c < shift; c++) qi += ops[c] != OP_TONLY;
+        int32_t t = (int32_t)t_s - 1;
+        uint16_t delta = 0;
+        const char *q = job.q;
+        for (unsigned c = 0; c < aln_len; c++) {
+            const uint8_t op = ops[shift + c];
+            if (op != OP_QONLY) {
+                t++;
+                delta = 0;
+            }
+            Tag &g = tl.tags[c];
+            g.t_pos = t;
+            g.delta = delta++;
+            g.base = op == OP_TONLY ? 4 : base_code(q[qi++]);
+            if (g.delta == 0) msa.coverage[t]++;
+            if (g.delta >= msa.max_size[t]) msa.max_size[t] = g.delta + 1;
+        }
+        return true;
+    }
+
+    void after_main() {
+        Msa msa((size_t)seed_len);
+        int total_cov = 0;
+        const unsigned n = (unsigned)seqs.size();
+        for (unsigned i = 0; i < n && (unsigned)(total_cov / seed_len) <= prm.max_cov_aln; i++) {
+            if (i == 0) {
+                // the seed is its own alignment (nextcorrect.c:2279-2282)
+                const unsigned L = (unsigned)seqs[0].size();
+                if (L >= prm.min_len_aln) {
+                    total_cov += (int)(aln_end[0] - aln_start[0] + 1);
+                    reads.emplace_back();
+                    tags_from_strings(seqs[0], seqs[0], aln_start[0], reads.back(), msa);
+                }
+            } else {
+                tags_from_ops(jobs[i - 1], aln_start[i], aln_end[i], msa, total_cov);
+            }
+        }
+        jobs.clear();
+        jobs.shrink_to_fit();
+
+        // get_cns_from_align_tags (nextcorrect.c:2130-2217)
+        msa.allocate();
+        msa.count_links(reads);
+        const int factor = prm.read_type == 3 ? 4 : 3;
+        Pos origin = msa.score_main(factor);
+
+        if (prm.fast) {
+            cns_fast(msa, origin);
+            phase = DONE;
+            return;
+        }
+        if (prm.read_type == 3) {
+            fprintf(stderr, "[ndgpu] read_type=hifi consensus is not implemented in this build\n");
+            finish_error(2);
+            return;
+        }
+        if (!cns_from_best_score(msa, origin)) {
+            finish_error(2);
+            return;
+        }
+        // continue with the low-quality-region rounds
+        lq_iter = 0;
+        lq_max_dif_len = 0;
+        start_lq_round();
+    }
+
+    // lib/nextcorrect.c:1717-1784
+    void cns_fast(Msa &msa, Pos cur) {
+        std::string out;
+        LqReg lq[kLqRegMax];
+        int lq_i = 0;
+        const int min_cov = (int)prm.min_cov;
+        while (true) {
+            if (cur.b != 4) {
+                if ((int)msa.coverage[cur.t] > min_cov) {
+                    out.push_back((char)kIntToBase[cur.b]);
+                    if (lq[lq_i].end >= lq[lq_i].start + 50 || !lq_i) {
+                        if (++lq_i >= kLqRegMax) break;
+                    } else lq[lq_i].end = 0;
+                } else {
+                    out.push_back((char)tolower(kIntToBase[cur.b]));
+                    if (!lq[lq_i].end) {
+                        lq[lq_i].start = (unsigned)out.size() - 1;
+                        lq[lq_i].lqlen = 0;
+                    }
+                    lq[lq_i].end = (unsigned)out.size() - 1;
+                    lq[lq_i].lq_total_len++;
+                    lq[lq_i].lqlen++;
+                }
+            }
+            const Cell &c = msa.cell(cur.t, cur.d, cur.b);
+            cur = Pos{c.best_t, c.best_d, c.best_b};
+            if (cur.t == -1) break;
+        }
+        int i, lq_m = 0, hq_m = (int)lq[0].start, l = hq_m;
+        unsigned lq_total_len = lq[0].lq_total_len - lq[0].lqlen;
+        for (i = 1; i < kLqRegMax && lq[i].end; i++) {
+            if (lq[i].start - lq[i - 1].end > (unsigned)l) {
+                lq_m = (int)lq[i - 1].end + 1;
+                hq_m = (int)lq[i].start;
+                lq_total_len = lq[i].lq_total_len - lq[i].lqlen;
+                l = hq_m - lq_m;
+            }
+        }
+        if (i < kLqRegMax && (unsigned)out.size() - lq[i - 1].end > (unsigned)l) {
+            lq_m = (int)lq[i - 1].end + 1;
+            hq_m = (int)out.size();
+            lq_total_len = lq[i].lq_total_len;
+        }
+        result.len = (unsigned)(hq_m - lq_m);
+        result.identity = 1 - (float)lq_total_len / result.len;
+        result.seq = out.substr((size_t)lq_m, result.len);
+        std::reverse(result.seq.begin(), result.seq.end());
+    }
+
+    // lib/nextcorrect.c:1885-2006.  Returns false for the error_seed(2) outcome.
+    bool cns_from_best_score(Msa &msa, Pos cur) {
+        int p = 0, lable = 1;
+        const int lq_min_length = 8;
+        int qv = 0, pqv, hq = 0, lq = 0, lq_l = 0, lq_s = -1, lq_e = -1;
+        int lqseq_total_length = 0;
+        const int min_cov = (int)prm.min_cov;
+        cns = CnsData();
+        cns.bases.reserve((size_t)seed_len + seed_len / 8 + 16);
+        regions.clear();
+        while (true) {
+            if (cur.b != 4) {
+                cns.bases.push_back(CnsBase{(unsigned)cur.t, 0});
+                const Cell &c = msa.cell(cur.t, cur.d, cur.b);
+                const int cov = msa.coverage[cur.t];
+                pqv = 100 * (int)c.best_link / cov;
+                if (pqv > 40) hq++;
+                else {
+                    hq = 0;
+                    lqseq_total_length++;
+                }
+                if (hq > lq_min_length / 2 && lq_e - lq_s < lq_min_length / 2) {
+                    qv = lq_l = lq = 0;
+                    lq_s = -1;
+                }
+                if ((qv + pqv) / (lq_l + 1) < 40) {
+                    if (lq_s == -1) lq_s = p;
+                    lq_e = p;
+                    lq = 1;
+                    lq_l++;
+                    qv += pqv;
+                } else if (lq && p - lq_e > 2 * lq_min_length && cns.bases[p].pos != cns.bases[p - 1].pos) {
+                    if (lq_e - lq_s + 1 > lq_min_length && (unsigned)(lq_e - lq_s + 1) < lq_max_len) {
+                        lq_e = p - lq_min_length - 1;
+                        lq_s = lq_s > lq_min_length ? lq_s - lq_min_length : 1;
+                        LqRegion r;
+                        r.end = cns.bases[lq_s].pos;
+                        r.start = cns.bases[lq_e].pos;
+                        if (!regions.empty() && r.end == regions.back().start) {
+                            while (r.end == regions.back().start && lq_s < p - 4) r.end = cns.bases[++lq_s].pos;
+                        }
+                        regions.push_back(std::move(r));
+                    }
+                    qv = lq_l = lq = 0;
+                    lq_s = -1;
+                } else if (lq && cns.bases[p].pos != cns.bases[p - 1].pos) {
+                    qv = lq_l = 0;
+                }
+                if (cov > min_cov && pqv > 20) {
+                    cns.bases[p].base = (char)kIntToBase[cur.b];
+                    lable = 0;
+                    cns.lstrip = 0;
+                } else {
+                    cns.bases[p].base = (char)tolower(kIntToBase[cur.b]);
+                    cns.uncorrected_len++;
+                    cns.lstrip++;
+                    if (lable) cns.rstrip++;
+                }
+                p++;
+            }
+            const Cell &c = msa.cell(cur.t, cur.d, cur.b);
+            cur = Pos{c.best_t, c.best_d, c.best_b};
+            if (cur.t == -1) break;
+        }
+        cns.len = (unsigned)p;
+        const float lhs = (float)(cns.uncorrected_len - cns.lstrip - cns.rstrip);
+        const float rhs = (float)(cns.len - cns.lstrip - cns.rstrip) * (1 - prm.min_error_corrected_ratio);
+        if (!(cns.len > 2 && (double)lqseq_total_length < cns.len * 0.8 && lhs < rhs)) return false;
+        std::reverse(cns.bases.begin(), cns.bases.end());
+        lq_max_aln_length = lqseqs_from_tags();
+        reads.clear();
+        reads.shrink_to_fit();
+        return true;
+    }
+
+    // lib/nextcorrect.c:356-510
+    int lqseqs_from_tags() {
+        int max_aln_length = 0;
+        std::vector<uint16_t> bins(kKmerBins);
+        for (LqRegion &lq : regions) {
+            int max_len_here = 0, large_seq = 0;
+            const int start = (int)lq.start, end = (int)lq.end;
+            lq.len = 0;
+            lq.seqs.clear();
+            lq.has_seed = false;
+            for (const TagList &tl : reads) {
+                const std::vector<Tag> &tg = tl.tags;
+                if (!(tg.front().t_pos <= start && tg.back().t_pos >= end)) continue;
+                bool too_long = false;
+                std::string s;
+                for (size_t k = (size_t)(start - tg.front().t_pos); k < tg.size() && tg[k].t_pos <= end; k++) {
+                    if (tg[k].t_pos >= start && tg[k].base != 4) {
+                        s.push_back((char)kIntToBase[tg[k].base]);
+                        if (s.size() > lq_max_len - 1) {
+                            large_seq++;
+                            too_long = true;
+                            break;
+                        }
+                    }
+                }
+                if (!s.empty() && !too_long) {
+                    LqSeq q;
+                    q.len = (uint16_t)s.size();
+                    q.order = (uint16_t)lq.len;
+                    if ((int)s.size() > max_len_here) max_len_here = (int)s.size();
+                    q.seq = std::move(s);
+                    lq.seqs.push_back(std::move(q));
+                    lq.len++;
+                }
+                if (lq.len >= kLqCanMax) break;
+            }
+            if ((float)large_seq / (lq.len + large_seq) > 1.0 / 3 || lq.len <= 4 || (prm.split && lq.len < 10)) {
+                lq.len = 0;
+                continue;
+            }
+            count_kmers(lq, bins.data(), 1, 0);
+            count_kscore(lq, bins.data(), 0);
+            sort_by_kscore_desc(lq);
+            count_kmers(lq, bins.data(), kKmerMaxSeq, 0);
+            count_kscore(lq, bins.data(), 0);
+            unsigned klastscore, kmaxscore = lq.seqs[0].kscore;
+            unsigned kmaxlen = lq.seqs[0].len, kminlen;
+            if (kmaxlen > 500 || (kmaxlen > 200 && kmaxscore < 200)) {
+                uint16_t saved[kLqCanMax];
+                if (lq.seqs[0].order) {
+                    for (int j = 1; j < lq.len; j++)
+                        if (!lq.seqs[j].order) {
+                            std::swap(lq.seqs[0], lq.seqs[j]);
+                            break;
+                        }
+                }
+                for (int j = 0; j < lq.len; j++) saved[lq.seqs[j].order] = lq.seqs[j].kscore;
+                count_kmers(lq, bins.data(), 1, 1);
+                count_kscore(lq, bins.data(), 1);
+                sort_by_kscore_desc(lq);
+                count_kmers(lq, bins.data(), kKmerMaxSeq, 1);
+                count_kscore(lq, bins.data(), 1);
+                for (int j = 0; j < lq.len; j++)
+                    lq.seqs[j].kscore = (uint16_t)(lq.seqs[j].kscore + saved[lq.seqs[j].order]);
+            }
+            sort_by_kscore_desc(lq);
+            kminlen = kmaxlen = lq.seqs[0].len;
+            klastscore = kmaxscore = lq.seqs[0].kscore;
+            int j, k;
+            for (k = j = 0; j < lq.len; j++) {
+                const unsigned ks = lq.seqs[j].kscore;
+                if (ks * 10 < kmaxscore || j >= kLqSeqMax || ks * 2 < klastscore ||
+                    (j > 4 && kmaxlen > 200 && ks < kmaxscore * 0.6 && lq.seqs[j].len < kminlen * 0.8))
+                    break;
+                klastscore = ks;
+                if (j < kKmerMaxSeq && ks > kmaxscore * 0.8) {
+                    if (lq.seqs[j].len > kmaxlen) kmaxlen = lq.seqs[j].len;
+                    else if (lq.seqs[j].len < kminlen) kminlen = lq.seqs[j].len;
+                }
+            }
+            lq.indexs = 0;
+            lq.indexe = (uint8_t)(kmaxlen > (unsigned)kLqRevLen && j > 6 ? 5 : j - 1);
+            if ((int)lq.indexe - (int)lq.indexs <= 3) {
+                lq.len = 0;
+                continue;
+            }
+            j = lq.indexs;
+            if (lq.seqs[0].len < 3000) k = j + 6 < lq.indexe ? 6 : lq.indexe - j + 1;
+            else k = j + 2 < lq.indexe ? 2 : lq.indexe - j + 1;
+            {
+                std::vector<std::string> in;
+                for (int x = 0; x < k; x++) in.push_back(lq.seqs[j + x].seq);
+                lq.sudoseed = poa_consensus(in);
+            }
+            lq.has_seed = true;
+            lq.sudoseed_len = (unsigned)lq.sudoseed.size();
+            if (lq.sudoseed_len > 500) {
+                int kmax, kmin;
+                k = kmax = kmin = lq.seqs[lq.indexs].len;
+                for (j = lq.indexs + 1; j <= lq.indexe && j <= lq.indexs + 4; j++) {
+                    k += lq.seqs[j].len;
+                    if (lq.seqs[j].len > kmax) kmax = lq.seqs[j].len;
+                    else if (lq.seqs[j].len < kmin) kmin = lq.seqs[j].len;
+                }
+                k = kmax != kmin ? (k - kmax - kmin) / (j - lq.indexs - 2) : k / (j - lq.indexs);
+                if (lq.sudoseed_len > (unsigned)(k + k / 10)) {
+                    for (kmin = k, k = lq.indexs; k < j; k++)
+                        if (lq.seqs[k].len != kmax && lq.seqs[k].len >= kmin) break;
+                    if (j == k)
+                        for (k = 0; k < lq.len && lq.seqs[k].order; k++) {}
+                    if (k >= lq.len) k = 0;  // unreachable: order 0 always survives
+                    lq.sudoseed = lq.seqs[k].seq;
+                    lq.sudoseed_len = lq.seqs[k].len;
+                }
+            }
+            if (max_len_here + (int)lq.sudoseed_len > max_aln_length) max_aln_length = max_len_here + (int)lq.sudoseed_len;
+        }
+        return max_aln_length;
+    }
+
+    // -- low-quality-region rounds (lib/nextcorrect.c:1671-1715, 1538-1669) ----------
+    void start_lq_round() {
+        lq_iter++;
+        lq_max_aln_length += lq_max_dif_len;
+        jobs.clear();
+        lq_slots.clear();
+        const int count = (int)regions.size();
+        for (int i = 0; i < kLqSeqMax; i++) {
+            for (int j = count - 1; j >= 0; j--) {
+                LqRegion &r = regions[j];
+                if (r.len <= 0) continue;
+                const int sl = (int)r.sudoseed_len;
+                const bool past = i + r.indexs > r.indexe;
+                const int ql = past ? sl : r.seqs[i + r.indexs].len;
+                LqSlot slot{i, j, -1};
+                if (!(past || (i && (ql < sl * 0.5 || ql > sl * 1.3)))) {
+                    AlnJob job;
+                    job.q = r.seqs[i + r.indexs].seq.c_str();
+                    job.q_len = ql;
+                    job.t = r.sudoseed.c_str();
+                    job.t_len = sl;
+                    job.hq = prm.read_type == 3;
+                    slot.job = (int)jobs.size();
+                    jobs.push_back(std::move(job));
+                }
+                lq_slots.push_back(slot);
+            }
+        }
+        phase = LQ_ROUND;
+        if (jobs.empty()) after_lq_round();  // nothing to align: still run the round
+    }
+
+    void after_lq_round() {
+        // generate_consensus_trimed: build the 30 linked rows, second MSA, backtrack
+        const int count = (int)regions.size();
+        size_t link_len = 1;
+        for (int j = count - 1; j >= 0; j--)
+            if (regions[j].len > 0) link_len += regions[j].sudoseed_len + 1;
+        Msa msa(link_len);
+        std::vector<TagList> rows(kLqSeqMax);
+        size_t slot_at = 0;
+        std::string t_str, q_str;
+        for (int i = 0; i < kLqSeqMax; i++) {
+            t_str.clear();
+            q_str.clear();
+            for (int j = count - 1; j >= 0; j--) {
+                LqRegion &r = regions[j];
+                if (r.len <= 0) continue;
+                const LqSlot &slot = lq_slots[slot_at++];
+                const int sl = (int)r.sudoseed_len;
+                t_str.push_back('N');
+                q_str.push_back('N');
+                const AlnJob *job = slot.job >= 0 ? &jobs[slot.job] : nullptr;
+                if (job && job->status == ALN_OK && job->ops.size() > 2) {
+                    const char *q = job->q, *t = job->t;
+                    int qi = 0, ti = 0;
+                    for (uint8_t op : job->ops) {
+                        if (op == OP_MATCH) { t_str.push_back(t[ti++]); q_str.push_back(q[qi++]); }
+                        else if (op == OP_QONLY) { t_str.push_back('-'); q_str.push_back(q[qi++]); }
+                        else { t_str.push_back(t[ti++]); q_str.push_back('-'); }
+                    }
+                    int tl = job->t_used, ql = job->q_used;
+                    while (tl < sl) { t_str.push_back(r.sudoseed[tl++]); q_str.push_back('-'); }
+                    int delta = 0;
+                    const LqSeq &qs = r.seqs[slot.i + r.indexs];
+                    while (ql < qs.len && delta++ < 250) { q_str.push_back(qs.seq[ql++]); t_str.push_back('-'); }
+                } else {
+                    t_str.append((size_t)sl, 'M');
+                    q_str.append((size_t)sl, 'M');
+                }
+            }
+            t_str.push_back('N');
+            q_str.push_back('N');
+            tags_from_strings(t_str, q_str, 0, rows[i], msa);
+        }
+        jobs.clear();
+        lq_slots.clear();
+
+        // get_lqseqs_from_align_tags (nextcorrect.c:1250-1338)
+        msa.allocate();
+        msa.count_links(rows);
+        rows.clear();
+        Pos cur = msa.score_lq(prm.read_type == 3 ? 4 : 2);
+        const int min_qv_factor = prm.read_type == 3 ? 2 : 5;
+        std::string lqc;
+        while (true) {
+            if (cur.b != 4) {
+                const Cell &c = msa.cell(cur.t, cur.d, cur.b);
+                const char ch = (char)kIntToBase[cur.b];
+                lqc.push_back((int)c.best_link * min_qv_factor > (int)msa.coverage[cur.t] || ch == 'N' ? ch : (char)tolower(ch));
+            }
+            const Cell &c = msa.cell(cur.t, cur.d, cur.b);
+            cur = Pos{c.best_t, c.best_d, c.best_b};
+            if (cur.t == -1) break;
+        }
+
+        // iterate_generate_consensus_trimed body (nextcorrect.c:1684-1710)
+        int j = count;
+        int psed_len = 0;
+        lq_max_dif_len = 0;
+        for (size_t k = lqc.size(); k; k--) {
+            const char ch = lqc[k - 1];
+            if (ch != 'N') {
+                if (j < 0 || j >= count) { finish_error(2); return; }  // reference: out-of-bounds write
+                LqRegion &r = regions[j];
+                if (r.sudoseed.size() <= r.sudoseed_len) r.sudoseed.resize(r.sudoseed_len + 1);
+                if (ch < 'a') r.sudoseed[r.sudoseed_len++] = ch;
+                else {
+                    r.sudoseed[r.sudoseed_len++] = (char)toupper(ch);
+                    r.lqcount++;
+                }
+            } else {
+                if (j != count && j >= 0) {
+                    LqRegion &r = regions[j];
+                    r.sudoseed.resize(r.sudoseed_len);
+                    if ((int)r.sudoseed_len > psed_len + lq_max_dif_len) lq_max_dif_len = (int)r.sudoseed_len - psed_len;
+                    if (r.lqcount > r.sudoseed_len * 4 / 5) r.len = -1;
+                }
+                j--;
+                while (j >= 0 && regions[j].len <= 0) j--;
+                if (j < 0) continue;
+                psed_len = (int)regions[j].sudoseed_len;
+                regions[j].sudoseed_len = regions[j].lqcount = 0;
+            }
+        }
+        if (lq_iter < 2) {
+            start_lq_round();
+            return;
+        }
+        splice();
+    }
+
+    // update_consensus_trimed (lib/nextcorrect.c:1365-1482), non-HiFi branch, then
+    // trim_terminal_ssr (nextcorrect.c:2214)
+    void splice() {
+        std::string out;
+        out.reserve((size_t)seed_len * 2 + 1);
+        unsigned p = 0, i = cns.lstrip;
+        int update = 1;
+        int idx = (int)regions.size() - 1;
+        LqReg lq[kLqRegMax + 1];  // +1 guard slot (the reference indexes lq[10] in one corner case)
+        unsigned lq_m = 0, hq_m = 0;
+        int lq_i = 0;
+        auto usable = [&](int k) { return regions[k].len > 0 || regions[k].len == -2; };
+        bool stop = false;
+        while (!stop && i < cns.len - cns.rstrip) {
+            p = cns.bases[i].pos;
+            if (idx >= 0 && (!usable(idx) || p > regions[idx].end)) {
+                idx--;
+                update = 1;
+            }
+            if (idx >= 0 && usable(idx) && p >= regions[idx].start && p <= regions[idx].end) {
+                if (update) {
+                    const LqRegion &r = regions[idx];
+                    for (unsigned j = 0; j < r.sudoseed_len; j++) {
+                        out.push_back(r.sudoseed[j]);
+                        lq_i = update_lqreg(lq, out, (unsigned)out.size() - 1, lq_i, &hq_m, &lq_m);
+                        if (lq_i >= kLqRegMax) { stop = true; break; }
+                    }
+                    update = 0;
+                }
+            } else {
+                out.push_back(cns.bases[i].base);
+                update = 1;
+                lq_i = update_lqreg(lq, out, (unsigned)out.size() - 1, lq_i, &hq_m, &lq_m);
+                if (lq_i >= kLqRegMax) break;
+            }
+            i++;
+        }
+        unsigned olen = (unsigned)out.size();
+        if (lq_i < kLqRegMax + 1 && lq[lq_i].end == olen - 1) lq_i++;
+
+        if (lq_i) {
+            lq_m = 0;
+            hq_m = lq[0].start;
+            p = lq[0].start;
+            unsigned lq_total_len = lq[0].lq_total_len - lq[0].lqlen;
+            for (i = 1; i < (unsigned)kLqRegMax && lq[i].end; i++) {
+                if (lq[i].start - lq[i - 1].end > p) {
+                    lq_m = lq[i - 1].end + 1;
+                    hq_m = lq[i].start;
+                    lq_total_len = lq[i].lq_total_len - lq[i].lqlen;
+                    p = lq[i].start - lq[i - 1].end;
+                }
+            }
+            if (i < (unsigned)kLqRegMax && olen - lq[i - 1].end > p) {
+                lq_m = lq[i - 1].end + 1;
+                hq_m = olen;
+                lq_total_len = lq[i].lq_total_len;
+            }
+            result.len = hq_m - lq_m;
+            result.seq = lq_m <= out.size() ? out.substr(lq_m, result.len) : std::string();
+            result.identity = 1 - (float)lq_total_len / result.len;
+        } else {
+            if (!out.empty() && out[0] >= 'a') {
+                unsigned k = 0;
+                while (k < out.size() && out[k] >= 'a') k++;
+                out.erase(0, k);
+                lq[0].lq_total_len -= k;
+            }
+            result.len = (unsigned)out.size();
+            result.seq = out;
+            result.identity = 1 - (float)lq[0].lq_total_len / result.len;
+        }
+        if (result.len > 1000 && result.identity > 0.8) trim_terminal_ssr(result);
+        phase = DONE;
+    }
+
+    ConsensusTrimed *take() {
+        if (error2 || result.len <= 4) {
+            ConsensusTrimed *c = make_error_seed(result.len < 2 ? result.len : result.len);
+            c->identity = result.identity;
+            if (!error2 && result.len == 4) memcpy(c->seq, result.seq.data(), std::min<size_t>(4, result.seq.size()));
+            return c;
+        }
+        ConsensusTrimed *c = (ConsensusTrimed *)malloc(sizeof(ConsensusTrimed));
+        c->len = result.len;
+        c->identity = result.identity;
+        c->seq = (char *)malloc((size_t)result.len + 1);
+        memcpy(c->seq, result.seq.data(), result.len);
+        c->seq[result.len] = '\0';
+        return c;
+    }
+};
+
+PileEngine::PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
+                       const CorrectParams &prm)
+    : impl_(new PileImpl(seqs, aln_start, aln_end, seq_count, prm)) {}
+PileEngine::~PileEngine() { delete impl_; }
+bool PileEngine::done() const { return impl_->phase == PileImpl::DONE; }
+void PileEngine::collect_jobs(std::vector<AlnJob *> &out) { impl_->collect(out); }
+void PileEngine::advance() { impl_->advance(); }
+ConsensusTrimed *PileEngine::take_result() { return impl_->take(); }
+
+}  // namespace ndgpu

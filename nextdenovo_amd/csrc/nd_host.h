@@ -1,0 +1,81 @@
+// Host-side declarations of the MI355X read-correction engine (internal; the
+// public C ABI is include/ndgpu_nextcorrect.h).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace ndgpu {
+
+// ABI-compatible with the reference's `consensus_trimed` (lib/nextcorrect.h:70-74).
+struct ConsensusTrimed {
+    unsigned int len;
+    float identity;
+    char *seq;
+};
+
+// Column kinds of a pairwise alignment, as produced by the HIP traceback kernel.
+enum : uint8_t { OP_MATCH = 0, OP_QONLY = 1, OP_TONLY = 2 };
+
+enum : int { ALN_NONE = 0, ALN_OK = 1, ALN_GAP_ABORT = 2 };
+
+// One query-vs-target alignment request.  Sequences are ASCII on the host side;
+// the device runtime packs them to 2 bit.  `hq` selects the align_hq
+// thresholds (lib/align.c:563-570) instead of align (:572-578).
+struct AlnJob {
+    const char *q = nullptr;
+    int q_len = 0;
+    const char *t = nullptr;
+    int t_len = 0;
+    int hq = 0;
+    // results
+    int status = ALN_NONE;
+    int q_used = 0;            // aln_q_len
+    int t_used = 0;            // aln_t_len
+    std::vector<uint8_t> ops;  // forward column kinds (empty unless ALN_OK)
+};
+
+// Backend that executes a batch of alignments (the HIP runtime in the product;
+// tests may plug the CPU oracle to exercise the host logic without a GPU).
+typedef void (*AlignBatchFn)(AlnJob **jobs, size_t n, void *ctx);
+
+struct CorrectParams {
+    unsigned max_mem_len = 0;
+    unsigned min_len_aln = 500;
+    unsigned max_cov_aln = 130;
+    unsigned min_cov = 4;
+    unsigned lqseq_max_length = 10000;
+    float min_error_corrected_ratio = 0.8f;
+    unsigned split = 0;
+    unsigned fast = 0;
+    int read_type = 1;  // 1 ont, 2 clr, 3 hifi
+};
+
+std::string poa_consensus(const std::vector<std::string> &seqs);
+
+class PileImpl;
+
+// Per-seed consensus state machine.  Alignment work is exposed as batches of
+// AlnJob so that many piles can share one device launch:
+//     while (!done()) { collect_jobs(v); <run v on the device>; advance(); }
+class PileEngine {
+  public:
+    PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
+               const CorrectParams &prm);
+    ~PileEngine();
+    PileEngine(const PileEngine &) = delete;
+    PileEngine &operator=(const PileEngine &) = delete;
+
+    bool done() const;
+    void collect_jobs(std::vector<AlnJob *> &out);
+    void advance();
+    ConsensusTrimed *take_result();  // malloc'd, caller frees with free_consensus_trimed
+
+  private:
+    PileImpl *impl_;
+};
+
+ConsensusTrimed *make_error_seed(unsigned len);
+
+}  // namespace ndgpu
