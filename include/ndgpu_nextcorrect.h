@@ -1,0 +1,103 @@
+/* ndgpu_nextcorrect.h -- C ABI of the MI355X-native read-correction engine.
+ *
+ * Drop-in boundary: the symbols below are exactly what NextDenovo's correction
+ * stage binds through ctypes (reference lib/nextcorrect.py:56-59) and what
+ * minimap2-nd / ctg_cns link against (reference lib/align.h:45-62).  Build
+ * product: nextdenovo_amd/libndgpu_nextcorrect.so (install it as lib/nextcorrect.so
+ * next to lib/nextcorrect.py).
+ *
+ * All compute behind these entry points runs in hand-written HIP kernels on
+ * gfx950; there is no CPU fallback: the first call aborts with a message if no
+ * HIP device is visible.
+ */
+#ifndef NDGPU_NEXTCORRECT_H
+#define NDGPU_NEXTCORRECT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* replaces: reference lib/nextcorrect.h:70-74 (`consensus_trimed`), mirrored by
+ * lib/nextcorrect.py:19-24.  `seq` is malloc'd, NUL-terminated, mixed case
+ * (lower case = low confidence).  len 2 = uncorrectable, 3 = out of memory,
+ * 4 = everything clipped (lib/nextcorrect.c:2254-2261, 1999, 2126). */
+typedef struct {
+    unsigned int len;
+    float identity;
+    char *seq;
+} consensus_trimed;
+
+/* replaces: reference lib/nextcorrect.h:161-162 / lib/nextcorrect.c:2219-2305.
+ * seqs[0] = full seed, seqs[i>0] = strand-corrected overlapping substrings (ASCII,
+ * upper-case ACGT, NUL-terminated); aln_start/aln_end = inclusive seed coordinates.
+ * read_type: 1 ont, 2 clr, 3 hifi. */
+consensus_trimed *nextCorrect(char **seqs, unsigned int *aln_start, unsigned int *aln_end, unsigned int seq_count,
+                              unsigned int max_mem_len, unsigned int min_len_aln, unsigned int max_cov_aln,
+                              unsigned int min_cov, unsigned int lqseq_max_length, float min_error_corrected_ratio,
+                              unsigned int split, unsigned int fast, int read_type);
+
+/* replaces: reference lib/nextcorrect.h:164 / lib/nextcorrect.c:2307-2310 */
+void free_consensus_trimed(consensus_trimed *c);
+
+/* ---- lib/align.h family (short `alignment` layout, i.e. without -DLGS_CORRECT,
+ *      reference lib/align.h:21-32 / lib/nextcorrect.h:120-129) ---- */
+typedef struct {
+    unsigned int shift;
+    unsigned int aln_len;
+    unsigned int aln_t_s;
+    unsigned int aln_t_e;
+    unsigned int aln_t_len;
+    unsigned int aln_q_len;
+    char *q_aln_str;
+    char *t_aln_str;
+} alignment;
+
+/* replaces: reference lib/align.h:61-62 / lib/align.c:572-578.  V and D are accepted
+ * for signature compatibility and ignored (the device keeps its own state). */
+void align(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *V, uint8_t **D);
+/* replaces: reference lib/align.h:59-60 / lib/align.c:563-570 */
+void align_hq(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *V, uint8_t **D);
+/* replaces: reference lib/align.h:45-50 / lib/align.c:22-78 (host-only helpers) */
+void malloc_vd(int **V, uint8_t ***D, uint64_t max_mem_d);
+void clean_V(int *V, int max_mem_d);
+void destory_vd(int *V, uint8_t **D);
+void revcomp_bseq(char *str, int len);
+void reverse_str(char *str, int len);
+void str_tolower(char *p);
+void str_toupper(char *p);
+/* replaces: reference lib/nextcorrect.h:166 / lib/dag.c:658-694.  `seqs` points at
+ * `seq_count` records laid out as the reference's `struct seq_`
+ * (lib/nextcorrect.h:63-68: u16 order, u16 kscore, u16 len, char seq[10000]). */
+char *poa_to_consensus(const void *seqs, const int seq_count);
+
+/* ---- additive entry points (not in the reference) ---- */
+
+/* Correct `n_piles` seeds in one call so that thousands of alignments share each
+ * kernel launch.  Per-pile arguments are arrays of length n_piles whose elements have
+ * the meaning of the corresponding nextCorrect() argument; scalar options apply to all
+ * piles.  out[i] receives a malloc'd consensus_trimed (free with
+ * free_consensus_trimed).  host_threads <= 0 selects hardware concurrency.
+ * Returns 0. */
+int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, unsigned int **aln_end,
+                        const unsigned int *seq_count, const unsigned int *max_mem_len,
+                        const unsigned int *lqseq_max_length, unsigned int min_len_aln, unsigned int max_cov_aln,
+                        unsigned int min_cov, float min_error_corrected_ratio, unsigned int split, unsigned int fast,
+                        int read_type, int host_threads, consensus_trimed **out);
+
+/* Counters accumulated by this process's device runtime since the last reset. */
+typedef struct {
+    uint64_t tasks, wide_tasks, cells, d_steps, trace_bits, columns, pool_bases;
+    uint32_t max_band, forward_launches;
+    double forward_ms;
+} ndgpu_stats;
+void ndgpu_get_stats(ndgpu_stats *out);
+void ndgpu_reset_stats(void);
+/* Number of HIP devices visible (0 if none); does not create a context. */
+int ndgpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

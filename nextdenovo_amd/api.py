@@ -1,0 +1,124 @@
+"""ctypes binding of libndgpu_nextcorrect.so -- the host-side mirror of the reference's
+Python<->C boundary (lib/nextcorrect.py:19-24,56-90): same struct, same argument order,
+same return convention (len, identity, sequence)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+
+class ConsensusTrimed(C.Structure):
+    # lib/nextcorrect.py:19-24
+    _fields_ = [("len", C.c_uint), ("identity", C.c_float), ("seq", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("tasks", C.c_uint64), ("wide_tasks", C.c_uint64), ("cells", C.c_uint64), ("d_steps", C.c_uint64),
+                ("trace_bits", C.c_uint64), ("columns", C.c_uint64), ("pool_bases", C.c_uint64),
+                ("max_band", C.c_uint32), ("forward_launches", C.c_uint32), ("forward_ms", C.c_double)]
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load the native library.  Raises (never falls back to a CPU path) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError("libndgpu_nextcorrect.so is not built; run `python -m nextdenovo_amd.build`")
+        _build.build()
+    lib = C.CDLL(path)
+    lib.nextCorrect.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_uint, C.c_uint,
+                                C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int]
+    lib.nextCorrect.restype = C.POINTER(ConsensusTrimed)
+    lib.free_consensus_trimed.argtypes = [C.POINTER(ConsensusTrimed)]
+    lib.ndgpu_correct_batch.argtypes = [C.c_int, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint)),
+                                        C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.c_uint), C.POINTER(C.c_uint),
+                                        C.POINTER(C.c_uint), C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_uint,
+                                        C.c_uint, C.c_int, C.c_int, C.POINTER(C.POINTER(ConsensusTrimed))]
+    lib.ndgpu_correct_batch.restype = C.c_int
+    lib.ndgpu_get_stats.argtypes = [C.POINTER(Stats)]
+    lib.ndgpu_reset_stats.argtypes = []
+    lib.ndgpu_device_count.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def _take(lib, r):
+    ln = r.contents.len
+    ide = r.contents.identity
+    seq = C.string_at(r.contents.seq, ln) if ln > 4 else b""
+    lib.free_consensus_trimed(r)
+    return ln, ide, seq
+
+
+def correct(seqs, aln_start, aln_end, max_aln_length, min_len_aln=500, max_cov_aln=130, min_cov_base=4,
+            max_lq_length=10000, min_error_corrected_ratio=0.8, split=0, fast=0, read_type=1):
+    """Mirror of lib/nextcorrect.py:72-90 `correct()`; returns (len, identity, sequence bytes)."""
+    lib = load()
+    n = len(seqs)
+    c_seqs = (C.c_char_p * n)()
+    c_seqs[:] = seqs
+    st = (C.c_uint * n)(*aln_start)
+    en = (C.c_uint * n)(*aln_end)
+    r = lib.nextCorrect(c_seqs, st, en, n, max_aln_length, min_len_aln, max_cov_aln, min_cov_base, max_lq_length,
+                        min_error_corrected_ratio, split, fast, read_type)
+    return _take(lib, r)
+
+
+def correct_batch(piles, min_len_aln=500, max_cov_aln=130, min_cov_base=4, min_error_corrected_ratio=0.8, split=0,
+                  fast=0, read_type=1, host_threads=0):
+    """piles: list of (seqs, aln_start, aln_end, max_aln_length, max_lq_length).
+    Returns a list of (len, identity, sequence bytes) in pile order."""
+    lib = load()
+    n = len(piles)
+    if n == 0:
+        return []
+    keep = []
+    a_seqs = (C.POINTER(C.c_char_p) * n)()
+    a_st = (C.POINTER(C.c_uint) * n)()
+    a_en = (C.POINTER(C.c_uint) * n)()
+    cnt = (C.c_uint * n)()
+    mml = (C.c_uint * n)()
+    mlq = (C.c_uint * n)()
+    for i, (seqs, st, en, max_aln, max_lq) in enumerate(piles):
+        k = len(seqs)
+        cs = (C.c_char_p * k)()
+        cs[:] = seqs
+        s = (C.c_uint * k)(*st)
+        e = (C.c_uint * k)(*en)
+        keep.append((cs, s, e))
+        a_seqs[i] = C.cast(cs, C.POINTER(C.c_char_p))
+        a_st[i] = C.cast(s, C.POINTER(C.c_uint))
+        a_en[i] = C.cast(e, C.POINTER(C.c_uint))
+        cnt[i] = k
+        mml[i] = max_aln
+        mlq[i] = max_lq
+    out = (C.POINTER(ConsensusTrimed) * n)()
+    lib.ndgpu_correct_batch(n, a_seqs, a_st, a_en, cnt, mml, mlq, min_len_aln, max_cov_aln, min_cov_base,
+                            min_error_corrected_ratio, split, fast, read_type, host_threads, out)
+    return [_take(lib, out[i]) for i in range(n)]
+
+
+def stats() -> dict:
+    lib = load()
+    s = Stats()
+    lib.ndgpu_get_stats(C.byref(s))
+    return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+
+def reset_stats():
+    load().ndgpu_reset_stats()
+
+
+def device_count() -> int:
+    return int(load().ndgpu_device_count())

@@ -1,0 +1,242 @@
+// C ABI of the engine (include/ndgpu_nextcorrect.h).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ndgpu_nextcorrect.h"
+#include "nd_host.h"
+#include "nd_runtime.h"
+
+using namespace ndgpu;
+
+namespace {
+
+CorrectParams make_params(unsigned max_mem_len, unsigned min_len_aln, unsigned max_cov_aln, unsigned min_cov,
+                          unsigned lqseq_max_length, float ratio, unsigned split, unsigned fast, int read_type) {
+    CorrectParams p;
+    p.max_mem_len = max_mem_len;
+    p.min_len_aln = min_len_aln;
+    p.max_cov_aln = max_cov_aln;
+    p.min_cov = min_cov;
+    p.lqseq_max_length = lqseq_max_length;
+    p.min_error_corrected_ratio = ratio;
+    p.split = split;
+    p.fast = fast;
+    p.read_type = read_type;
+    return p;
+}
+
+template <typename F>
+void parallel_for(size_t n, int threads, F f) {
+    if (threads <= 1 || n <= 1) {
+        for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> pool;
+    const int nt = (int)std::min<size_t>((size_t)threads, n);
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&] {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+
+void run_single_alignment(char *q, int q_len, char *t, int t_len, alignment *a, int hq) {
+    AlnJob job;
+    job.q = q;
+    job.q_len = q_len;
+    job.t = t;
+    job.t_len = t_len;
+    job.hq = hq;
+    AlnJob *jp = &job;
+    DeviceAligner::instance().align_batch(&jp, 1);
+    if (job.status == ALN_NONE) return;  // reference leaves *align_rtn untouched (lib/align.c:440-560)
+    a->aln_t_e = a->aln_t_s + (unsigned)job.t_used - 1;
+    a->aln_t_len = (unsigned)job.t_used;
+    a->aln_q_len = (unsigned)job.q_used;
+    size_t n = job.ops.size();
+    int qi, ti;
+    if (job.status == ALN_GAP_ABORT) {
+        // reference: aln_len = 2 with the last two alignment columns (lib/align.c:542-556)
+        qi = job.q_used;
+        ti = job.t_used;
+        for (size_t c = n; c-- > 0;) {
+            if (job.ops[c] != OP_TONLY) qi--;
+            if (job.ops[c] != OP_QONLY) ti--;
+        }
+    } else {
+        qi = ti = 0;
+    }
+    for (size_t c = 0; c < n; c++) {
+        const uint8_t op = job.ops[c];
+        a->t_aln_str[c] = op == OP_QONLY ? '-' : t[ti++];
+        a->q_aln_str[c] = op == OP_TONLY ? '-' : q[qi++];
+    }
+    a->t_aln_str[n] = a->q_aln_str[n] = '\0';
+    a->aln_len = (unsigned)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+consensus_trimed *nextCorrect(char **seqs, unsigned int *aln_start, unsigned int *aln_end, unsigned int seq_count,
+                              unsigned int max_mem_len, unsigned int min_len_aln, unsigned int max_cov_aln,
+                              unsigned int min_cov, unsigned int lqseq_max_length, float min_error_corrected_ratio,
+                              unsigned int split, unsigned int fast, int read_type) {
+    PileEngine eng(seqs, aln_start, aln_end, seq_count,
+                   make_params(max_mem_len, min_len_aln, max_cov_aln, min_cov, lqseq_max_length,
+                               min_error_corrected_ratio, split, fast, read_type));
+    std::vector<AlnJob *> jobs;
+    while (!eng.done()) {
+        jobs.clear();
+        eng.collect_jobs(jobs);
+        DeviceAligner::instance().align_batch(jobs.data(), jobs.size());
+        eng.advance();
+    }
+    return (consensus_trimed *)eng.take_result();
+}
+
+void free_consensus_trimed(consensus_trimed *c) {
+    if (!c) return;
+    free(c->seq);
+    free(c);
+}
+
+int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, unsigned int **aln_end,
+                        const unsigned int *seq_count, const unsigned int *max_mem_len,
+                        const unsigned int *lqseq_max_length, unsigned int min_len_aln, unsigned int max_cov_aln,
+                        unsigned int min_cov, float min_error_corrected_ratio, unsigned int split, unsigned int fast,
+                        int read_type, int host_threads, consensus_trimed **out) {
+    if (n_piles <= 0) return 0;
+    if (host_threads <= 0) host_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    std::vector<PileEngine *> eng((size_t)n_piles, nullptr);
+    parallel_for((size_t)n_piles, host_threads, [&](size_t i) {
+        eng[i] = new PileEngine(seqs[i], aln_start[i], aln_end[i], seq_count[i],
+                                make_params(max_mem_len[i], min_len_aln, max_cov_aln, min_cov, lqseq_max_length[i],
+                                            min_error_corrected_ratio, split, fast, read_type));
+    });
+    std::vector<AlnJob *> jobs;
+    std::vector<size_t> live;
+    for (;;) {
+        jobs.clear();
+        live.clear();
+        for (size_t i = 0; i < (size_t)n_piles; i++)
+            if (!eng[i]->done()) {
+                live.push_back(i);
+                eng[i]->collect_jobs(jobs);
+            }
+        if (live.empty()) break;
+        DeviceAligner::instance().align_batch(jobs.data(), jobs.size());
+        parallel_for(live.size(), host_threads, [&](size_t k) { eng[live[k]]->advance(); });
+    }
+    for (size_t i = 0; i < (size_t)n_piles; i++) {
+        out[i] = (consensus_trimed *)eng[i]->take_result();
+        delete eng[i];
+    }
+    return 0;
+}
+
+void align(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *, uint8_t **) {
+    run_single_alignment(query_seq, q_len, target_seq, t_len, align_rtn, 0);
+}
+
+void align_hq(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *, uint8_t **) {
+    run_single_alignment(query_seq, q_len, target_seq, t_len, align_rtn, 1);
+}
+
+// The device owns the DP state; these exist so that code written against
+// lib/align.h links unchanged.  V gets the reference's size, D a 1-slot table.
+void malloc_vd(int **V, uint8_t ***D, uint64_t max_mem_d) {
+    *V = (int *)malloc((size_t)(max_mem_d ? max_mem_d : 1) * 2 * sizeof(int));
+    *D = (uint8_t **)calloc(1, sizeof(uint8_t *));
+}
+void clean_V(int *V, int max_mem_d) {
+    if (V && max_mem_d > 0) memset(V, 0, (size_t)max_mem_d * 2 * sizeof(int));
+}
+void destory_vd(int *V, uint8_t **D) {
+    free(V);
+    free(D);
+}
+
+void reverse_str(char *str, int len) {
+    for (int a = 0, b = len - 1; a < b; a++, b--) std::swap(str[a], str[b]);
+}
+
+void revcomp_bseq(char *str, int len) {
+    // complement table semantics of lib/align.c:3-20 for the IUPAC letters it maps
+    static const char *from = "ACGTUMRWSYKVHDBNacgtumrwsykvhdbn";
+    static const char *to = "TGCAAKYWSRMBDHVNtgcaakywsrmbdhvn";
+    static unsigned char lut[256];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 256; i++) lut[i] = (unsigned char)i;
+        for (int i = 0; from[i]; i++) lut[(unsigned char)from[i]] = (unsigned char)to[i];
+        init = true;
+    }
+    int a = 0, b = len - 1;
+    while (a < b) {
+        const unsigned char x = lut[(unsigned char)str[a]], y = lut[(unsigned char)str[b]];
+        str[a++] = (char)y;
+        str[b--] = (char)x;
+    }
+    if (a == b) str[a] = (char)lut[(unsigned char)str[a]];
+}
+
+void str_tolower(char *p) {
+    for (; *p; ++p) *p |= 0x20;
+}
+void str_toupper(char *p) {
+    for (; *p; ++p) *p &= (char)0xdf;
+}
+
+char *poa_to_consensus(const void *seqs, const int seq_count) {
+    // struct seq_ { uint16_t order, kscore, len; char seq[10000]; }  (lib/nextcorrect.h:63-68)
+    const size_t stride = 3 * sizeof(uint16_t) + 10000;
+    std::vector<std::string> in;
+    for (int i = 0; i < seq_count; i++) {
+        const unsigned char *rec = (const unsigned char *)seqs + (size_t)i * stride;
+        uint16_t len;
+        memcpy(&len, rec + 4, sizeof(len));
+        in.emplace_back((const char *)rec + 6, (size_t)len);
+    }
+    std::string r = poa_consensus(in);
+    char *out = (char *)malloc(r.size() + 1);
+    memcpy(out, r.c_str(), r.size() + 1);
+    return out;
+}
+
+void ndgpu_get_stats(ndgpu_stats *o) {
+    RuntimeStats s = DeviceAligner::instance().stats();
+    o->tasks = s.tasks;
+    o->wide_tasks = s.wide_tasks;
+    o->cells = s.cells;
+    o->d_steps = s.d_steps;
+    o->trace_bits = s.trace_bits;
+    o->columns = s.columns;
+    o->pool_bases = s.pool_bases;
+    o->max_band = s.max_band;
+    o->forward_launches = s.forward_launches;
+    o->forward_ms = s.forward_ms;
+}
+
+void ndgpu_reset_stats(void) { DeviceAligner::instance().reset_stats(); }
+
+int ndgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

@@ -510,6 +510,8 @@ class PileImpl {
             j.q_len = (int)seqs[i].size();
             j.t = seqs[0].c_str() + aln_start[i];
             j.t_len = (int)(aln_end[i] - aln_start[i] + 1);
+            j.t_owner = seqs[0].c_str();
+            j.t_owner_len = (int)seqs[0].size();
             j.hq = prm.read_type == 3;
         }
     }

@@ -29,6 +29,10 @@ struct AlnJob {
     const char *t = nullptr;
     int t_len = 0;
     int hq = 0;
+    // optional: `t` points into a larger buffer shared by many jobs (the seed); the
+    // runtime then packs/uploads that buffer once
+    const char *t_owner = nullptr;
+    int t_owner_len = 0;
     // results
     int status = ALN_NONE;
     int q_used = 0;            // aln_q_len

@@ -1,0 +1,47 @@
+// Device runtime interface (one instance per process, lazily created on the first
+// alignment so that a fork()ed worker pool -- lib/nextcorrect.py:232 -- initialises
+// HIP in the child, never in the parent).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "nd_host.h"
+
+namespace ndgpu {
+
+struct RuntimeStats {
+    uint64_t tasks = 0;            // alignments executed
+    uint64_t wide_tasks = 0;       // of which needed the HBM-ring kernel
+    uint64_t cells = 0;            // (d,k) cells evaluated
+    uint64_t d_steps = 0;          // edit steps executed
+    uint64_t trace_bits = 0;       // 1-bit move records of alignments that finished
+    uint64_t columns = 0;          // alignment columns produced
+    uint64_t pool_bases = 0;       // bases uploaded to the 2-bit pool
+    uint32_t max_band = 0;
+    uint32_t forward_launches = 0;
+    double forward_ms = 0;         // HIP-event time of the forward kernel launches
+};
+
+class DeviceAligner {
+  public:
+    static DeviceAligner &instance();
+    void align_batch(AlnJob **jobs, size_t n);
+    void *stream() const;
+    RuntimeStats stats() const;
+    void reset_stats();
+
+  private:
+    DeviceAligner();
+    ~DeviceAligner();
+    void run_chunk(AlnJob **jobs, size_t n);
+    void run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t> &ids);
+    struct State;
+    State *s_;
+};
+
+// AlignBatchFn-compatible entry
+void hip_align_backend(AlnJob **jobs, size_t n, void *ctx);
+
+}  // namespace ndgpu

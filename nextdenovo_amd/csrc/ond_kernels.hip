@@ -1,0 +1,288 @@
+// Hand-written CDNA4 (gfx950) kernels for the banded greedy O(ND) aligner that
+// NextDenovo's consensus is built on (reference: core() via align()/align_hq(),
+// lib/align.c:428-578).  Integer DP, no MFMA.
+//
+// K7  ond_forward   : one 64-lane wavefront per alignment.  Lane l of pass p owns
+//                     diagonal k = min_k + 2*(64p + l); all diagonals of one edit
+//                     step d are independent, so a step is: 2 LDS reads of the
+//                     furthest-reaching ring V[], a snake (XOR + ctz over 16-base
+//                     2-bit words fetched from the HBM-resident pool), 1 LDS write,
+//                     two wave ballots (move bits -> trace row, finish test), one
+//                     wave max (best anti-diagonal) and two ballots for the band
+//                     re-centring.  Traceback memory is 1 bit per evaluated cell
+//                     plus min_k per step, instead of the reference's one byte per
+//                     cell of an O(max_d^2) triangle.
+// K7w ond_forward<W>: same code with V[] in a global scratch ring and a wider
+//                     trace row, for the rare alignments whose live band exceeds
+//                     the 253-diagonal LDS fast path (exactness of the band-cap /
+//                     edit-budget failure semantics).
+// K8a ond_traceback : one lane per alignment walks d -> 0 reading the move bits,
+//                     re-deriving match runs with clz over 16-base words, and emits
+//                     2-bit column kinds back to front.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "nd_device.h"
+
+namespace ndgpu {
+
+namespace {
+
+__device__ __forceinline__ uint32_t fetch16(const uint32_t *__restrict__ pool, uint64_t off) {
+    const uint64_t w = off >> 4;
+    const uint32_t s = (uint32_t)(off & 15u) * 2u;
+    const uint64_t v = (uint64_t)pool[w] | ((uint64_t)pool[w + 1] << 32);
+    return (uint32_t)(v >> s);
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
+                                                          const uint32_t *__restrict__ pool,
+                                                          uint64_t *__restrict__ trace,
+                                                          int32_t *__restrict__ trace_mink,
+                                                          int32_t *__restrict__ vscratch,
+                                                          const int32_t *__restrict__ ids) {
+    __shared__ int32_t v_lds[WIDE ? 1 : kFastVSize];
+    const int tid = WIDE ? ids[blockIdx.x] : (int)blockIdx.x;
+    const AlnTask T = tasks[tid];
+    const int lane = (int)threadIdx.x;
+    int32_t *V = WIDE ? (vscratch + T.v_off) : v_lds;
+    const uint32_t vmask = WIDE ? T.v_mask : (uint32_t)(kFastVSize - 1);
+
+    for (uint32_t i = (uint32_t)lane; i <= vmask; i += 64) V[i] = 0;  // the reference memsets V per alignment
+    __syncthreads();
+
+    int min_k = 0, max_k = 0, best_m = -1;
+    int status = ST_NONE, fin_k = 0, fin_x = 0, fin_d = -1;
+    int d_steps = 0, max_band = 0;
+    long long cells = 0;
+    const int q_len = T.q_len, t_len = T.t_len;
+    const uint64_t q_off = T.q_off, t_off = T.t_off;
+    const uint64_t row0 = T.trace_off, mk0 = T.mink_off;
+    const uint32_t row_words = WIDE ? T.row_words : (uint32_t)kFastRowWords;
+
+    for (int d = 0; d < T.max_d && max_k - min_k <= T.band; d++) {
+        const int band = max_k - min_k;
+        if (!WIDE && band > kFastMaxBand) {
+            status = ST_NEED_WIDE;
+            break;
+        }
+        const int ncell = band >= 0 ? (band >> 1) + 1 : 0;
+        const int npass = (ncell + 63) >> 6;
+        d_steps++;
+        cells += ncell;
+        max_band = band > max_band ? band : max_band;
+        if (lane == 0) trace_mink[mk0 + d] = min_k;
+
+        int row_best = -1;
+        bool done = false;
+        for (int ps = 0; ps < npass; ps++) {
+            const int k = min_k + 2 * (ps * 64 + lane);
+            const bool act = k <= max_k;
+            int x = 0;
+            bool left = false;
+            if (act) {
+                const int vm = V[(uint32_t)(k - 1) & vmask];
+                const int vp = V[(uint32_t)(k + 1) & vmask];
+                // lib/align.c:443
+                const bool down = (k == min_k) || (k != max_k && vm < vp);
+                x = down ? vp : vm + 1;
+                left = !down;
+                int y = x - k;
+                // snake: 16 bases per XOR, first mismatch = ctz/2 (lib/align.c:452-455)
+                for (;;) {
+                    int rem = q_len - x;
+                    const int rt = t_len - y;
+                    rem = rt < rem ? rt : rem;
+                    if (rem <= 0) break;
+                    const uint32_t a = fetch16(pool, q_off + (uint64_t)(uint32_t)x);
+                    const uint32_t b = fetch16(pool, t_off + (uint64_t)(uint32_t)y);
+                    const uint32_t diff = a ^ b;
+                    int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
+                    m = m < rem ? m : rem;
+                    x += m;
+                    y += m;
+                    if (m < 16) break;
+                }
+            }
+            const unsigned long long lb = __ballot(act && left);
+            if (lane == 0) trace[row0 + (uint64_t)d * row_words + (uint32_t)ps] = lb;
+            const int y = x - k;
+            const unsigned long long fb = __ballot(act && x >= q_len && y >= t_len);
+            if (act) {
+                V[(uint32_t)k & vmask] = x;
+                const int m = x + y;
+                row_best = m > row_best ? m : row_best;
+            }
+            if (fb) {
+                // several diagonals may finish in one step: the smallest k wins (lib/align.c:467-470)
+                const int fl = __ffsll((long long)fb) - 1;
+                fin_k = min_k + 2 * (ps * 64 + fl);
+                fin_x = __shfl(x, fl, 64);
+                fin_d = d;
+                status = ST_FINISHED;
+                done = true;
+                break;
+            }
+        }
+        if (done) break;
+
+        const int rb = wave_max_i32(row_best);
+        best_m = rb > best_m ? rb : best_m;
+        __syncthreads();  // V[] of this step visible to every lane
+
+        // band re-centring (lib/align.c:473-489)
+        int new_min = max_k, new_max = min_k;
+        const int thr = best_m - 150;
+        for (int ps = 0; ps < npass; ps++) {
+            const int k = min_k + 2 * (ps * 64 + lane);
+            const bool q = k < max_k && (2 * V[(uint32_t)k & vmask] - k >= thr);
+            const unsigned long long qb = __ballot(q);
+            if (qb) {
+                new_min = min_k + 2 * (ps * 64 + (__ffsll((long long)qb) - 1));
+                break;
+            }
+        }
+        for (int ps = npass - 1; ps >= 0; ps--) {
+            const int k = min_k + 2 * (ps * 64 + lane);
+            const bool q = k <= max_k && k > min_k && (2 * V[(uint32_t)k & vmask] - k >= thr);
+            const unsigned long long qb = __ballot(q);
+            if (qb) {
+                new_max = min_k + 2 * (ps * 64 + (63 - __clzll((long long)qb)));
+                break;
+            }
+        }
+        max_k = new_max + 1;
+        min_k = new_min - 1;
+    }
+
+    if (lane == 0) {
+        AlnOut o;
+        o.status = status;
+        o.d_final = fin_d;
+        o.k_final = fin_k;
+        o.x_final = fin_x;
+        o.y_final = fin_x - fin_k;
+        o.n_cols = 0;
+        o.d_steps = d_steps;
+        o.max_band = max_band;
+        o.cells = cells;
+        outs[tid] = o;
+    }
+}
+
+__global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
+                                                            const uint32_t *__restrict__ pool,
+                                                            const uint64_t *__restrict__ trace,
+                                                            const int32_t *__restrict__ trace_mink,
+                                                            uint32_t *__restrict__ ops,
+                                                            const int32_t *__restrict__ ids, int n_tasks) {
+    const int slot = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (slot >= n_tasks) return;
+    const int gid = ids ? ids[slot] : slot;
+    if (outs[gid].status != ST_FINISHED) return;
+    const AlnTask T = tasks[gid];
+    int x = outs[gid].x_final - 1;  // 0-based last query base (lib/align.c:492)
+    int k = outs[gid].k_final;
+    int d = outs[gid].d_final;
+    int gap = 0;
+    uint32_t col = T.ops_cap;  // columns [col, ops_cap) are written
+    uint32_t acc = 0;
+    uint32_t *W = ops + T.ops_off;
+    bool aborted = false;
+
+    for (;;) {
+        // match run, back to front (lib/align.c:502-507), 16 bases per compare
+        for (;;) {
+            const int yy = x - k;
+            const int avail = (x < yy ? x : yy) + 1;
+            if (avail <= 0) break;
+            const int n = avail < 16 ? avail : 16;
+            const uint32_t a = fetch16(pool, T.q_off + (uint64_t)(uint32_t)(x - n + 1));
+            const uint32_t b = fetch16(pool, T.t_off + (uint64_t)(uint32_t)(yy - n + 1));
+            uint32_t diff = a ^ b;
+            if (n < 16) diff &= (1u << (2 * n)) - 1u;
+            const int m = diff ? n - 1 - ((31 - __builtin_clz(diff)) >> 1) : n;
+            if (m) {
+                int left_to_emit = m;  // match columns are code 0: only the cursor moves
+                while (left_to_emit > 0) {
+                    const uint32_t room = ((col - 1u) & 15u) + 1u;
+                    const uint32_t take = (uint32_t)left_to_emit < room ? (uint32_t)left_to_emit : room;
+                    col -= take;
+                    left_to_emit -= (int)take;
+                    if ((col & 15u) == 0) {
+                        W[col >> 4] = acc;
+                        acc = 0;
+                    }
+                }
+                x -= m;
+                gap = 0;
+            }
+            if (m < n) break;
+        }
+        if (x < 0 && x - k < 0) break;
+        bool left;
+        if (x < k) left = true;  // lib/align.c:512: forced query-consuming move
+        else if (x >= 0) {
+            const int idx = (k - trace_mink[T.mink_off + (uint64_t)(uint32_t)d]) >> 1;
+            left = (trace[T.trace_off + (uint64_t)(uint32_t)d * T.row_words + (uint32_t)(idx >> 6)] >> (idx & 63)) & 1ull;
+        } else left = false;
+        uint32_t code;
+        int nk, nx;
+        if (left) { nk = k - 1; nx = x - 1; code = 1u; if (x < 0) gap = 260; }
+        else { nk = k + 1; nx = x; code = 2u; if (x - k < 0) gap = 260; }
+        if (gap < 260) {
+            col--;
+            acc |= code << ((col & 15u) * 2u);
+            if ((col & 15u) == 0) {
+                W[col >> 4] = acc;
+                acc = 0;
+            }
+        }
+        if (gap++ > 250) {  // lib/align.c:542-545
+            aborted = true;
+            break;
+        }
+        d--;
+        k = nk;
+        x = nx;
+    }
+    if ((col & 15u) != 0) W[col >> 4] = acc;
+    outs[gid].n_cols = aborted ? 2 : (int32_t)(T.ops_cap - col);
+    outs[gid].status = aborted ? ST_GAP_ABORT : ST_ALIGNED;
+}
+
+}  // namespace
+
+void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, uint64_t *trace, int32_t *trace_mink,
+                        int n_tasks, void *stream) {
+    if (n_tasks <= 0) return;
+    hipLaunchKernelGGL(ond_forward_kernel<false>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs,
+                       pool, trace, trace_mink, (int32_t *)nullptr, (const int32_t *)nullptr);
+}
+
+void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, uint64_t *trace,
+                             int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream) {
+    if (n_ids <= 0) return;
+    hipLaunchKernelGGL(ond_forward_kernel<true>, dim3((unsigned)n_ids), dim3(64), 0, (hipStream_t)stream, tasks, outs,
+                       pool, trace, trace_mink, vscratch, task_ids);
+}
+
+void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint64_t *trace,
+                          const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream) {
+    if (n_tasks <= 0) return;
+    hipLaunchKernelGGL(ond_traceback_kernel, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       tasks, outs, pool, trace, trace_mink, ops, task_ids, n_tasks);
+}
+
+}  // namespace ndgpu
