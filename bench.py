@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- corrected bases / s of the MI355X read-correction hot path.
+
+One "step" = one full pass of the correction hot path (every seed pile of the
+workload: O(ND) alignments on the GPU -> consensus) over a synthetic read set that
+is already resident in HBM when the timed region starts.
+
+Workload (BASELINE.json configs[1]): synthetic
+E. coli-sized genome 4.6 Mb, 50x ONT-profile reads (lognormal, N50 ~ 20-25 kb,
+sub 3 % / ins 4 % / del 5 %), seed_cutoff 1k, piles derived analytically from the
+true read positions (nextdenovo_amd/synth.py).
+
+Launch contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
+started by torch.distributed.run with one rank per GPU.  Piles shard across ranks
+with no data-path collective (every rank corrects its own read set: weak scaling);
+RCCL is used only for the final corrected-base-count / max-time reduction.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-size", type=float, default=4.6e6)
+    ap.add_argument("--depth", type=float, default=50.0)
+    ap.add_argument("--profile", default="ont")
+    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+# ---- CPU baseline leg (the ONLY place bench.py touches oracle/) ---------------------------------
+_REF = None
+
+
+def _ref_worker(item):
+    """One fork()ed worker = one `nextcorrect.py -p` worker (lib/nextcorrect.py:183-199):
+    calls the compiled reference's nextCorrect() on one pile."""
+    global _REF
+    import ctypes as C
+    seqs, st, en, mal, mlq, rt = item
+    if _REF is None:
+        class CT(C.Structure):
+            _fields_ = [("len", C.c_uint), ("identity", C.c_float), ("seq", C.c_void_p)]
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "nextcorrect.so"))
+        lib.nextCorrect.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_uint,
+                                    C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_uint, C.c_uint,
+                                    C.c_int]
+        lib.nextCorrect.restype = C.POINTER(CT)
+        lib.free_consensus_trimed.argtypes = [C.POINTER(CT)]
+        _REF = lib
+    lib = _REF
+    n = len(seqs)
+    cs = (C.c_char_p * n)()
+    cs[:] = seqs
+    r = lib.nextCorrect(cs, (C.c_uint * n)(*st), (C.c_uint * n)(*en), n, mal, 500, 130, 4, mlq, 0.8, 0, 0, rt)
+    ln, ide = r.contents.len, r.contents.identity
+    lib.free_consensus_trimed(r)
+    return ln if (ln > 4 and ide >= 0.8) else 0
+
+
+def cpu_baseline(rs, piles, read_type, n_sample):
+    """Reference CPU path on a bounded sample of the same workload, all sample piles in
+    flight over a fork pool of `cores` workers (the reference's own parallelism model)."""
+    from multiprocessing import get_context
+    from nextdenovo_amd import synth
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "nextcorrect.so")
+    if not os.path.exists(ref_so):
+        return None
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    if n_sample <= 0:
+        n_sample = min(len(piles), 4 * cores)
+    step = max(1, len(piles) // n_sample)
+    sample = piles[::step][:n_sample]
+    items = []
+    for p in sample:
+        seqs, st, en, mal = synth.pile_sequences(rs, p)
+        items.append((seqs, st, en, mal, min(en[0] // 2, 10000), read_type))
+    ctx = get_context("fork")
+    with ctx.Pool(cores) as pool:
+        pool.map(_ref_worker, items[:cores])  # warm: dlopen + page in
+        t0 = time.perf_counter()
+        lens = pool.map(_ref_worker, items, chunksize=1)
+        dt = time.perf_counter() - t0
+    bases = int(sum(lens))
+    return {"value": bases / dt, "unit": "corrected bases/s", "cores": cores, "kind": "reference",
+            "sample": "%d of %d piles (every %d-th), %d corrected bases in %.2f s wall; compiled reference "
+                      "nextcorrect.so via fork pool" % (len(sample), len(piles), step, bases, dt),
+            "per_core": bases / dt / cores}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("NDGPU_DEVICE", str(local_rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    from nextdenovo_amd import api, synth
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    read_type = {"ont": 1, "clr": 2, "hifi": 3}[args.profile]
+    t_gen = time.perf_counter()
+    genome = synth.make_genome(int(args.genome_size), seed=42 + 1000 * rank)
+    rs = synth.simulate_reads(genome, args.depth, args.profile, seed=43 + 1000 * rank)
+    piles = synth.build_piles(rs, seed_cutoff=1000)
+    recs, pile_off = synth.flatten_piles(piles)
+    words, word_off, lens = synth.pack_db(rs)
+    t_gen = time.perf_counter() - t_gen
+
+    db = api.ReadDB(words, word_off, lens)  # reads resident in HBM from here on
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        res = db.correct_piles(recs, pile_off, read_type=read_type, host_threads=args.host_threads, lengths_only=True)
+        # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
+        return sum(ln for ln, ide in res if ln >= 500 and ln > 4 and ide >= 0.8)
+
+    for _ in range(args.warmup):
+        step()
+    api.reset_stats()
+    sync()
+    t0 = time.perf_counter()
+    bases = 0
+    for _ in range(args.steps):
+        bases += step()
+    sync()
+    dt = time.perf_counter() - t0
+    st = api.stats()
+
+    total_bases = bases
+    max_dt = dt
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        b = torch.tensor([bases], dtype=torch.int64, device="cuda")
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)  # the one collective of the path
+        max_dt = float(t.item())
+        total_bases = int(b.item())
+
+    if rank == 0:
+        # roofline of the dominant kernel (ond_forward): algorithmic bytes per launch =
+        # 2-bit operands read once + 1 trace bit per evaluated cell + 4 B min_k per edit step
+        launches = max(1, st["forward_launches"])
+        alg_bytes = (st["seq_bases"] / 4.0 + st["cells"] / 8.0 + 4.0 * st["d_steps"]) / launches
+        avg_ms = st["forward_ms"] / launches
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        peak = 8000.0
+        out = {
+            "metric": "corrected bases/sec",
+            "value": total_bases / max_dt,
+            "unit": "bases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": max_dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic E. coli-like %.1f Mb, %gx %s reads (lognormal mu 9.55 sigma 0.75), "
+                                   "seed_cutoff 1k, 1 read set per GPU" % (args.genome_size / 1e6, args.depth,
+                                                                          args.profile),
+                       "reads_per_gpu": len(rs), "read_bases_per_gpu": rs.total_bases(), "piles_per_gpu": len(piles),
+                       "overlaps_per_gpu": int(recs.shape[0]), "sharding": "piles, weak (one read set per rank)",
+                       "datagen_s": round(t_gen, 1)},
+            "roofline": {"bound": "hbm", "kernel": "ond_forward", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": int(launches),
+                         "cells_per_s": st["cells"] / (st["forward_ms"] * 1e-3) if st["forward_ms"] > 0 else 0.0},
+            "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "columns", "max_band")},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rs, piles, read_type, args.cpu_sample)
+        print(json.dumps(out))
+    db.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

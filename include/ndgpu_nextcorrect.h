@@ -86,9 +86,30 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
                         unsigned int min_cov, float min_error_corrected_ratio, unsigned int split, unsigned int fast,
                         int read_type, int host_threads, consensus_trimed **out);
 
+/* Resident read database: the additive replacement for ovlseq.so's init_ovls + getseq
+ * (reference lib/ovlseq.c:39-138, lib/nextcorrect.py:62-69,193).  `words` is the .2bit
+ * payload layout of lib/bseq.c:114-139 (16 bases per uint32, first base in the top two
+ * bits); read i starts at words[word_off[i]] and has len[i] bases.  The DB is uploaded to
+ * HBM once (forward + reverse complement) and stays there. */
+typedef struct ndgpu_db ndgpu_db;
+ndgpu_db *ndgpu_db_create(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off, const uint32_t *len);
+void ndgpu_db_destroy(ndgpu_db *db);
+
+/* Correct piles given as overlap records against a resident DB: the batched
+ * equivalent of lib/nextcorrect.py:183-199 (worker) + nextCorrect().  `recs` holds
+ * 8 uint32 per record in decode_ovl order (lib/ovl.c:189-200, lib/nextcorrect.py:106:
+ * seed, rev, t_s, t_e, query read, q_s, q_e, match; coordinates inclusive); pile i owns
+ * records [pile_off[i], pile_off[i+1]) and its first record is the seed self record.
+ * max_aln_length and the per-pile max_lq_length = min(seed_len/2, max_lq_length) are
+ * derived exactly as lib/nextcorrect.py:117,135-137,188 does.  Returns 0. */
+int ndgpu_correct_piles(ndgpu_db *db, int n_piles, const uint32_t *recs, const uint64_t *pile_off,
+                        unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
+                        unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
+                        unsigned int fast, int read_type, int host_threads, consensus_trimed **out);
+
 /* Counters accumulated by this process's device runtime since the last reset. */
 typedef struct {
-    uint64_t tasks, wide_tasks, cells, d_steps, trace_bits, columns, pool_bases;
+    uint64_t tasks, wide_tasks, cells, d_steps, trace_bits, columns, pool_bases, seq_bases;
     uint32_t max_band, forward_launches;
     double forward_ms;
 } ndgpu_stats;

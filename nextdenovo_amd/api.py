@@ -18,7 +18,7 @@ class ConsensusTrimed(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("tasks", C.c_uint64), ("wide_tasks", C.c_uint64), ("cells", C.c_uint64), ("d_steps", C.c_uint64),
-                ("trace_bits", C.c_uint64), ("columns", C.c_uint64), ("pool_bases", C.c_uint64),
+                ("trace_bits", C.c_uint64), ("columns", C.c_uint64), ("pool_bases", C.c_uint64), ("seq_bases", C.c_uint64),
                 ("max_band", C.c_uint32), ("forward_launches", C.c_uint32), ("forward_ms", C.c_double)]
 
 
@@ -46,6 +46,13 @@ def load(build_if_missing: bool = True):
                                         C.POINTER(C.c_uint), C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_uint,
                                         C.c_uint, C.c_int, C.c_int, C.POINTER(C.POINTER(ConsensusTrimed))]
     lib.ndgpu_correct_batch.restype = C.c_int
+    lib.ndgpu_db_create.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndgpu_db_create.restype = C.c_void_p
+    lib.ndgpu_db_destroy.argtypes = [C.c_void_p]
+    lib.ndgpu_correct_piles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
+                                        C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_int,
+                                        C.POINTER(C.POINTER(ConsensusTrimed))]
+    lib.ndgpu_correct_piles.restype = C.c_int
     lib.ndgpu_get_stats.argtypes = [C.POINTER(Stats)]
     lib.ndgpu_reset_stats.argtypes = []
     lib.ndgpu_device_count.restype = C.c_int
@@ -107,6 +114,45 @@ def correct_batch(piles, min_len_aln=500, max_cov_aln=130, min_cov_base=4, min_e
     lib.ndgpu_correct_batch(n, a_seqs, a_st, a_en, cnt, mml, mlq, min_len_aln, max_cov_aln, min_cov_base,
                             min_error_corrected_ratio, split, fast, read_type, host_threads, out)
     return [_take(lib, out[i]) for i in range(n)]
+
+
+class ReadDB:
+    """Device-resident 2-bit read database (additive replacement for ovlseq.so's
+    init_ovls/getseq, lib/nextcorrect.py:62-69).  words/word_off/lens as produced by
+    synth.pack_db() or read from a reference .2bit file."""
+
+    def __init__(self, words, word_off, lens):
+        import numpy as np
+        self._lib = load()
+        self._words = np.ascontiguousarray(words, dtype=np.uint32)
+        self._off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        self._len = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.n_reads = int(self._len.size)
+        self._h = self._lib.ndgpu_db_create(self.n_reads, self._words.ctypes.data, self._off.ctypes.data,
+                                            self._len.ctypes.data)
+
+    def close(self):
+        if self._h:
+            self._lib.ndgpu_db_destroy(self._h)
+            self._h = None
+
+    def correct_piles(self, recs, pile_off, min_len_aln=500, max_cov_aln=130, min_cov_base=4, max_lq_length=10000,
+                      min_error_corrected_ratio=0.8, split=0, fast=0, read_type=1, host_threads=0, lengths_only=False):
+        import numpy as np
+        recs = np.ascontiguousarray(recs, dtype=np.uint32)
+        pile_off = np.ascontiguousarray(pile_off, dtype=np.uint64)
+        n = int(pile_off.size) - 1
+        out = (C.POINTER(ConsensusTrimed) * n)()
+        self._lib.ndgpu_correct_piles(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
+                                      min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
+                                      host_threads, out)
+        if lengths_only:
+            res = []
+            for i in range(n):
+                res.append((out[i].contents.len, out[i].contents.identity))
+                self._lib.free_consensus_trimed(out[i])
+            return res
+        return [_take(self._lib, out[i]) for i in range(n)]
 
 
 def stats() -> dict:

@@ -148,6 +148,81 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
     return 0;
 }
 
+struct ndgpu_db {
+    ReadDb *db;
+};
+
+ndgpu_db *ndgpu_db_create(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off, const uint32_t *len) {
+    ndgpu_db *h = new ndgpu_db;
+    h->db = new ReadDb(n_reads, words, word_off, len);
+    DeviceAligner::instance().set_db(h->db->pool().data(), h->db->pool().size());
+    return h;
+}
+
+void ndgpu_db_destroy(ndgpu_db *h) {
+    if (!h) return;
+    delete h->db;
+    delete h;
+}
+
+int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const uint64_t *pile_off,
+                        unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
+                        unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
+                        unsigned int fast, int read_type, int host_threads, consensus_trimed **out) {
+    if (n_piles <= 0) return 0;
+    if (host_threads <= 0) host_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const ReadDb &db = *h->db;
+    size_t sub = 512;
+    if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
+    std::vector<AlnJob *> jobs;
+    std::vector<size_t> live;
+    for (size_t base = 0; base < (size_t)n_piles; base += sub) {
+        const size_t cnt = std::min(sub, (size_t)n_piles - base);
+        std::vector<PileEngine *> eng(cnt, nullptr);
+        parallel_for(cnt, host_threads, [&](size_t k) {
+            const uint64_t r0 = pile_off[base + k], r1 = pile_off[base + k + 1];
+            const size_t n = (size_t)(r1 - r0);
+            std::vector<std::string> strs(n);
+            std::vector<const char *> ptrs(n);
+            std::vector<unsigned> st(n), en(n);
+            std::vector<int64_t> dev(n);
+            unsigned max_aln = n ? recs[r0 * 8 + 3] + 1 : 0;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t *r = recs + (r0 + i) * 8;
+                strs[i] = db.window(r[4], r[5], r[6], (int)r[1]);
+                ptrs[i] = strs[i].c_str();
+                dev[i] = db.window_offset(r[4], r[5], r[6], (int)r[1]);
+                st[i] = r[2];
+                en[i] = r[3];
+                const unsigned v = r[3] - r[2] + r[6] - r[5] + 2;
+                if (v > max_aln && r[0] != r[4]) max_aln = v;
+            }
+            const unsigned lq = n ? std::min<unsigned>(en[0] / 2, max_lq_length) : max_lq_length;
+            eng[k] = new PileEngine(ptrs.data(), st.data(), en.data(), (unsigned)n,
+                                    make_params(max_aln, min_len_aln, max_cov_aln, min_cov, lq,
+                                                min_error_corrected_ratio, split, fast, read_type),
+                                    dev.data());
+        });
+        for (;;) {
+            jobs.clear();
+            live.clear();
+            for (size_t k = 0; k < cnt; k++)
+                if (!eng[k]->done()) {
+                    live.push_back(k);
+                    eng[k]->collect_jobs(jobs);
+                }
+            if (live.empty()) break;
+            DeviceAligner::instance().align_batch(jobs.data(), jobs.size());
+            parallel_for(live.size(), host_threads, [&](size_t k) { eng[live[k]]->advance(); });
+        }
+        for (size_t k = 0; k < cnt; k++) {
+            out[base + k] = (consensus_trimed *)eng[k]->take_result();
+            delete eng[k];
+        }
+    }
+    return 0;
+}
+
 void align(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *, uint8_t **) {
     run_single_alignment(query_seq, q_len, target_seq, t_len, align_rtn, 0);
 }
@@ -226,6 +301,7 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->trace_bits = s.trace_bits;
     o->columns = s.columns;
     o->pool_bases = s.pool_bases;
+    o->seq_bases = s.seq_bases;
     o->max_band = s.max_band;
     o->forward_launches = s.forward_launches;
     o->forward_ms = s.forward_ms;

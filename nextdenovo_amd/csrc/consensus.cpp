@@ -493,7 +493,8 @@ class PileImpl {
     struct LqSlot { int i, j, job; };  // (row, region) -> job index or -1 ('M' fill)
     std::vector<LqSlot> lq_slots;
 
-    PileImpl(const char *const *s, const unsigned *st, const unsigned *en, unsigned n, const CorrectParams &p)
+    PileImpl(const char *const *s, const unsigned *st, const unsigned *en, unsigned n, const CorrectParams &p,
+             const int64_t *dev_off)
         : prm(p) {
         lq_max_len = p.lqseq_max_length > 10000 ? 10000 : p.lqseq_max_length;  // DAG_MAX_LENGTH, nextcorrect.c:2231
         seqs.reserve(n);
@@ -512,6 +513,10 @@ class PileImpl {
             j.t_len = (int)(aln_end[i] - aln_start[i] + 1);
             j.t_owner = seqs[0].c_str();
             j.t_owner_len = (int)seqs[0].size();
+            if (dev_off && dev_off[0] >= 0 && dev_off[i] >= 0) {
+                j.q_dev = dev_off[i];
+                j.t_dev = dev_off[0] + aln_start[i];
+            }
             j.hq = prm.read_type == 3;
         }
     }
@@ -1106,8 +1111,8 @@ class PileImpl {
 };
 
 PileEngine::PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
-                       const CorrectParams &prm)
-    : impl_(new PileImpl(seqs, aln_start, aln_end, seq_count, prm)) {}
+                       const CorrectParams &prm, const int64_t *dev_off)
+    : impl_(new PileImpl(seqs, aln_start, aln_end, seq_count, prm, dev_off)) {}
 PileEngine::~PileEngine() { delete impl_; }
 bool PileEngine::done() const { return impl_->phase == PileImpl::DONE; }
 void PileEngine::collect_jobs(std::vector<AlnJob *> &out) { impl_->collect(out); }

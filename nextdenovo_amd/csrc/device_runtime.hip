@@ -113,7 +113,7 @@ struct DeviceAligner::State {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    DevBuf<uint32_t> d_pool, d_ops;
+    DevBuf<uint32_t> d_pool, d_ops, d_db;
     DevBuf<AlnTask> d_tasks;
     DevBuf<AlnOut> d_outs;
     DevBuf<uint64_t> d_trace;
@@ -154,6 +154,14 @@ DeviceAligner::~DeviceAligner() { delete s_; }
 DeviceAligner &DeviceAligner::instance() {
     static DeviceAligner *g = new DeviceAligner();  // intentionally leaked: no HIP calls at exit
     return *g;
+}
+
+void DeviceAligner::set_db(const uint32_t *pool_words, size_t n_words) {
+    std::lock_guard<std::mutex> lock(s_->mu);
+    HIP_CHECK(hipSetDevice(s_->device));
+    s_->d_db.reserve(n_words + 2);
+    HIP_CHECK(hipMemcpy(s_->d_db.p, pool_words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(s_->d_db.p + n_words, 0, 2 * sizeof(uint32_t)));
 }
 
 void *DeviceAligner::stream() const { return s_->stream; }
@@ -210,14 +218,21 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
         j.q_used = j.t_used = 0;
         t.q_len = j.q_len;
         t.t_len = j.t_len;
-        t.q_off = (uint64_t)pool.size() * 16;
-        if (!pack_append(pool, j.q, (size_t)j.q_len)) bad[i] = 1;
-        if (j.t_owner) {
+        S.stats.seq_bases += (uint64_t)j.q_len + (uint64_t)j.t_len;
+        if (j.q_dev >= 0) t.q_off = (uint64_t)j.q_dev | kOffDb;
+        else {
+            t.q_off = (uint64_t)pool.size() * 16;
+            if (!pack_append(pool, j.q, (size_t)j.q_len)) bad[i] = 1;
+            S.stats.pool_bases += (uint64_t)j.q_len;
+        }
+        if (j.t_dev >= 0) t.t_off = (uint64_t)j.t_dev | kOffDb;
+        else if (j.t_owner) {
             auto it = owners.find(j.t_owner);
             uint64_t base;
             if (it == owners.end()) {
                 base = (uint64_t)pool.size() * 16;
                 if (!pack_append(pool, j.t_owner, (size_t)j.t_owner_len)) bad[i] = 1;
+                S.stats.pool_bases += (uint64_t)j.t_owner_len;
                 owners.emplace(j.t_owner, bad[i] ? UINT64_MAX : base);
             } else base = it->second;
             if (base == UINT64_MAX) bad[i] = 1;
@@ -225,6 +240,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
         } else {
             t.t_off = (uint64_t)pool.size() * 16;
             if (!pack_append(pool, j.t, (size_t)j.t_len)) bad[i] = 1;
+            S.stats.pool_bases += (uint64_t)j.t_len;
         }
         int md, bd;
         limits_for(j.q_len + j.t_len, j.hq, &md, &bd);
@@ -239,7 +255,6 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
         trace_words += (uint64_t)md * kFastRowWords;
         mink_rows += (uint64_t)md;
         ops_words += (uint64_t)(t.ops_cap + 15) / 16 + 1;
-        S.stats.pool_bases += (uint64_t)j.q_len + (j.t_owner ? 0 : j.t_len);
     }
     pool.push_back(0);
     pool.push_back(0);  // fetch16 reads one word past the last base
@@ -257,9 +272,9 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     HIP_CHECK(hipMemcpyAsync(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipEventRecord(S.ev0, st));
-    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_trace.p, S.d_mink.p, (int)n, st);
+    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p, (int)n, st);
     HIP_CHECK(hipEventRecord(S.ev1, st));
-    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
+    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, n * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(S.h_ops.p, S.d_ops.p, ops_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -361,8 +376,8 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
                                      hipMemcpyHostToDevice, st));
         }
         HIP_CHECK(hipMemcpyAsync(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
-        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
+        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
+        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
         HIP_CHECK(hipStreamSynchronize(st));
         for (size_t i = 0; i < take; i++) {
             const int32_t id = ids[at + i];

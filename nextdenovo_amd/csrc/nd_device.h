@@ -46,17 +46,21 @@ struct AlnOut {
     int64_t cells;
 };
 
+constexpr uint64_t kOffDb = 1ull << 63;   // offset flag: sequence lives in the resident read DB
+constexpr uint64_t kOffMask = kOffDb - 1;
+
 constexpr int kFastVSize = 256;        // LDS ring of furthest-reaching x per diagonal
 constexpr int kFastRowWords = 2;       // 128 same-parity diagonals per row
 constexpr int kFastMaxBand = 253;      // band + 3 <= kFastVSize
 
 // launchers (ond_kernels.hip)
-void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, uint64_t *trace, int32_t *trace_mink,
-                        int n_tasks, void *stream);
-void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, uint64_t *trace,
-                             int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream);
+void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
+                        uint64_t *trace, int32_t *trace_mink, int n_tasks, void *stream);
+void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
+                             uint64_t *trace, int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream);
 // task_ids == nullptr: tasks [0, n); otherwise the listed tasks only
-void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint64_t *trace,
+void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
+                          const uint64_t *trace,
                           const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n, void *stream);
 
 }  // namespace ndgpu

@@ -33,6 +33,10 @@ struct AlnJob {
     // runtime then packs/uploads that buffer once
     const char *t_owner = nullptr;
     int t_owner_len = 0;
+    // optional: base offsets of q[0] / t[0] inside the device-resident read DB
+    // (ReadDb); when >= 0 nothing is packed or uploaded for that sequence
+    int64_t q_dev = -1;
+    int64_t t_dev = -1;
     // results
     int status = ALN_NONE;
     int q_used = 0;            // aln_q_len
@@ -65,8 +69,9 @@ class PileImpl;
 //     while (!done()) { collect_jobs(v); <run v on the device>; advance(); }
 class PileEngine {
   public:
+    // dev_off (optional, seq_count entries): ReadDb pool offset of seqs[i][0], or -1
     PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
-               const CorrectParams &prm);
+               const CorrectParams &prm, const int64_t *dev_off = nullptr);
     ~PileEngine();
     PileEngine(const PileEngine &) = delete;
     PileEngine &operator=(const PileEngine &) = delete;
@@ -81,5 +86,35 @@ class PileEngine {
 };
 
 ConsensusTrimed *make_error_seed(unsigned len);
+
+// Read database kept resident in HBM for the lifetime of a correction run: every
+// read forward AND reverse-complemented, 2 bit per base, LSB-first words (the device
+// packing of nd_device.h), so that any strand-corrected overlap substring
+// (reference: getseq/subbit_, lib/ovlseq.c:39-48, lib/bseq.c:241-255) is a plain
+// window of the pool -- no per-pile extraction or upload.
+class ReadDb {
+  public:
+    // `words`: reference .2bit payload layout (lib/bseq.c:114-139): 16 bases per
+    // uint32, first base in the two most significant bits; read i starts at
+    // words[word_off[i]] and has len[i] bases.
+    ReadDb(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off, const uint32_t *len);
+    uint32_t n_reads() const { return (uint32_t)len_.size(); }
+    uint32_t length(uint32_t r) const { return len_[r]; }
+    // pool offset (bases) of base `start` of the window [start, end] of read r, after
+    // optional reverse-complement of the window
+    int64_t window_offset(uint32_t r, uint32_t start, uint32_t end, int rev) const {
+        return rev ? (int64_t)(rc_off_[r] + (len_[r] - 1 - end)) : (int64_t)(fwd_off_[r] + start);
+    }
+    // ASCII copy of the same window (host side)
+    std::string window(uint32_t r, uint32_t start, uint32_t end, int rev) const;
+    const std::vector<uint32_t> &pool() const { return pool_; }
+    uint64_t total_bases() const { return total_; }
+
+  private:
+    std::vector<uint32_t> pool_;
+    std::vector<uint64_t> fwd_off_, rc_off_;
+    std::vector<uint32_t> len_;
+    uint64_t total_ = 0;
+};
 
 }  // namespace ndgpu

@@ -18,7 +18,8 @@ struct RuntimeStats {
     uint64_t d_steps = 0;          // edit steps executed
     uint64_t trace_bits = 0;       // 1-bit move records of alignments that finished
     uint64_t columns = 0;          // alignment columns produced
-    uint64_t pool_bases = 0;       // bases uploaded to the 2-bit pool
+    uint64_t pool_bases = 0;       // bases packed + uploaded per batch (0 for DB-resident sequences)
+    uint64_t seq_bases = 0;        // sum of q_len + t_len over all alignments (operand bases)
     uint32_t max_band = 0;
     uint32_t forward_launches = 0;
     double forward_ms = 0;         // HIP-event time of the forward kernel launches
@@ -28,6 +29,8 @@ class DeviceAligner {
   public:
     static DeviceAligner &instance();
     void align_batch(AlnJob **jobs, size_t n);
+    // upload (or replace) the resident read DB pool; AlnJob::q_dev/t_dev index into it
+    void set_db(const uint32_t *pool_words, size_t n_words);
     void *stream() const;
     RuntimeStats stats() const;
     void reset_stats();

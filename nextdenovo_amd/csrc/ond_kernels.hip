@@ -48,6 +48,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 template <bool WIDE>
 __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
                                                           const uint32_t *__restrict__ pool,
+                                                          const uint32_t *__restrict__ db_pool,
                                                           uint64_t *__restrict__ trace,
                                                           int32_t *__restrict__ trace_mink,
                                                           int32_t *__restrict__ vscratch,
@@ -67,7 +68,10 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
     int d_steps = 0, max_band = 0;
     long long cells = 0;
     const int q_len = T.q_len, t_len = T.t_len;
-    const uint64_t q_off = T.q_off, t_off = T.t_off;
+    // bit 63 of an offset selects the resident read DB instead of the per-batch pool
+    const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
+    const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
+    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
     const uint64_t row0 = T.trace_off, mk0 = T.mink_off;
     const uint32_t row_words = WIDE ? T.row_words : (uint32_t)kFastRowWords;
 
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
                     const int rt = t_len - y;
                     rem = rt < rem ? rt : rem;
                     if (rem <= 0) break;
-                    const uint32_t a = fetch16(pool, q_off + (uint64_t)(uint32_t)x);
-                    const uint32_t b = fetch16(pool, t_off + (uint64_t)(uint32_t)y);
+                    const uint32_t a = fetch16(qp, q_off + (uint64_t)(uint32_t)x);
+                    const uint32_t b = fetch16(tp, t_off + (uint64_t)(uint32_t)y);
                     const uint32_t diff = a ^ b;
                     int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
                     m = m < rem ? m : rem;
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
 
 __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
                                                             const uint32_t *__restrict__ pool,
+                                                            const uint32_t *__restrict__ db_pool,
                                                             const uint64_t *__restrict__ trace,
                                                             const int32_t *__restrict__ trace_mink,
                                                             uint32_t *__restrict__ ops,
@@ -192,6 +197,9 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     const int gid = ids ? ids[slot] : slot;
     if (outs[gid].status != ST_FINISHED) return;
     const AlnTask T = tasks[gid];
+    const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
+    const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
+    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
     int x = outs[gid].x_final - 1;  // 0-based last query base (lib/align.c:492)
     int k = outs[gid].k_final;
     int d = outs[gid].d_final;
@@ -208,8 +216,8 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
             const int avail = (x < yy ? x : yy) + 1;
             if (avail <= 0) break;
             const int n = avail < 16 ? avail : 16;
-            const uint32_t a = fetch16(pool, T.q_off + (uint64_t)(uint32_t)(x - n + 1));
-            const uint32_t b = fetch16(pool, T.t_off + (uint64_t)(uint32_t)(yy - n + 1));
+            const uint32_t a = fetch16(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
+            const uint32_t b = fetch16(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
             uint32_t diff = a ^ b;
             if (n < 16) diff &= (1u << (2 * n)) - 1u;
             const int m = diff ? n - 1 - ((31 - __builtin_clz(diff)) >> 1) : n;
@@ -264,25 +272,28 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
 
 }  // namespace
 
-void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, uint64_t *trace, int32_t *trace_mink,
+void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
+                        uint64_t *trace, int32_t *trace_mink,
                         int n_tasks, void *stream) {
     if (n_tasks <= 0) return;
     hipLaunchKernelGGL(ond_forward_kernel<false>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs,
-                       pool, trace, trace_mink, (int32_t *)nullptr, (const int32_t *)nullptr);
+                       pool, db_pool, trace, trace_mink, (int32_t *)nullptr, (const int32_t *)nullptr);
 }
 
-void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, uint64_t *trace,
+void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
+                             uint64_t *trace,
                              int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream) {
     if (n_ids <= 0) return;
     hipLaunchKernelGGL(ond_forward_kernel<true>, dim3((unsigned)n_ids), dim3(64), 0, (hipStream_t)stream, tasks, outs,
-                       pool, trace, trace_mink, vscratch, task_ids);
+                       pool, db_pool, trace, trace_mink, vscratch, task_ids);
 }
 
-void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint64_t *trace,
+void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
+                          const uint64_t *trace,
                           const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream) {
     if (n_tasks <= 0) return;
     hipLaunchKernelGGL(ond_traceback_kernel, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                       tasks, outs, pool, trace, trace_mink, ops, task_ids, n_tasks);
+                       tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
 }
 
 }  // namespace ndgpu

@@ -59,11 +59,11 @@ def _homopolymer_mask(seg: np.ndarray) -> np.ndarray:
     return rl[rid] >= 3
 
 
-def mutate(seg: np.ndarray, rng: np.random.Generator, profile: str):
+def mutate(seg: np.ndarray, rng: np.random.Generator, profile: str, first: int = 0):
     """Apply the error model to a genome segment (codes 0..3).
 
     Returns (read_codes, ckpt) where ckpt[j] is the read offset that
-    corresponds to genome offset j*CKPT of the segment (monotone).
+    corresponds to segment offset first + j*CKPT (monotone).
     """
     sub, ins, dele = PROFILES[profile]
     n = seg.size
@@ -87,7 +87,7 @@ def mutate(seg: np.ndarray, rng: np.random.Generator, profile: str):
         base[is_sub] = (base[is_sub] + rng.integers(1, 4, size=ns).astype(np.uint8)) & 3
     kept_idx = np.nonzero(keep)[0]
     out[off[kept_idx] + n_ins[kept_idx]] = base[kept_idx]
-    ckpt = off[::CKPT].astype(np.int64)
+    ckpt = off[first::CKPT].astype(np.int64)
     return out, ckpt
 
 
@@ -103,7 +103,8 @@ class ReadSet:
         self.gstart = []    # genome start of the covered segment
         self.gend = []      # genome end (exclusive)
         self.rev = []       # 1 if the read is the reverse complement of the genome
-        self.ckpt = []      # forward-strand genome->read checkpoints
+        self.ckpt = []      # forward-strand read offsets at absolute genome positions that are multiples of CKPT
+        self.gfirst = []    # first such genome position inside the read
 
     def __len__(self):
         return len(self.seqs)
@@ -124,7 +125,8 @@ def simulate_reads(genome: np.ndarray, depth: float, profile: str = "ont", seed:
         L = int(np.clip(rng.lognormal(mu, sigma), min_len, min(max_len, G)))
         s = int(rng.integers(0, G - L + 1))
         seg = genome[s:s + L]
-        codes, ck = mutate(seg, rng, profile)
+        gfirst = ((s + CKPT - 1) // CKPT) * CKPT
+        codes, ck = mutate(seg, rng, profile, gfirst - s)
         if codes.size < min_len:
             continue
         rev = int(rng.random() < 0.5)
@@ -133,30 +135,35 @@ def simulate_reads(genome: np.ndarray, depth: float, profile: str = "ont", seed:
         rs.gend.append(s + L)
         rs.rev.append(rev)
         rs.ckpt.append(ck)
+        rs.gfirst.append(gfirst)
         tot += codes.size
     return rs
 
 
-def _fwd_pos(rs: ReadSet, i: int, g: int) -> int:
-    """Offset in the forward-strand version of read i for genome position g
-    (snapped down to the checkpoint grid)."""
-    j = (g - rs.gstart[i]) // CKPT
-    ck = rs.ckpt[i]
-    j = min(max(j, 0), ck.size - 1)
-    return int(ck[j])
-
-
 def build_piles(rs: ReadSet, seed_cutoff: int = 1000, min_ovl: int = 500, max_cov_aln: int = 130,
-                min_len_aln: int = 500, min_cov_seed: int = 10, sort_depth: int = 40,
-                seed_ids=None):
-    """Return a list of piles.  pile = dict(seed=id, recs=np.ndarray[n,8] uint32)
-    recs[0] is the self record (ovl_sort.c:827-835).  Coordinates inclusive."""
+                min_len_aln: int = 500, min_cov_seed: int = 10, seed_ids=None):
+    """Return a list of piles.  pile = dict(seed=id, recs=np.ndarray[n,8] uint32);
+    recs[0] is the self record (util/ovl_sort.c:827-835).  Coordinates inclusive.
+    Vectorised over the candidate reads of each seed."""
     n = len(rs)
-    gs = np.asarray(rs.gstart)
-    ge = np.asarray(rs.gend)
+    gs = np.asarray(rs.gstart, dtype=np.int64)
+    ge = np.asarray(rs.gend, dtype=np.int64)
+    rv = np.asarray(rs.rev, dtype=np.int64)
+    lens = np.asarray([s.size for s in rs.seqs], dtype=np.int64)
+    ck_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([c.size for c in rs.ckpt], out=ck_off[1:])
+    ck_flat = np.concatenate(rs.ckpt) if n else np.zeros(0, dtype=np.int64)
+    ck_n = np.diff(ck_off)
     order = np.argsort(gs, kind="stable")
     gs_sorted = gs[order]
-    lens = np.asarray([s.size for s in rs.seqs])
+
+    gf = np.asarray(rs.gfirst, dtype=np.int64)
+
+    def fwd(ids, g):  # exact genome->read offsets at absolute CKPT-grid positions
+        j = (g - gf[ids]) // CKPT
+        j = np.minimum(np.maximum(j, 0), ck_n[ids] - 1)
+        return ck_flat[ck_off[ids] + j]
+
     piles = []
     ids = range(n) if seed_ids is None else seed_ids
     for si in ids:
@@ -164,60 +171,78 @@ def build_piles(rs: ReadSet, seed_cutoff: int = 1000, min_ovl: int = 500, max_co
         if L < seed_cutoff:
             continue
         a, b = int(gs[si]), int(ge[si])
-        # candidates: reads starting before b and ending after a
         hi = int(np.searchsorted(gs_sorted, b, side="left"))
         cand = order[:hi]
-        cand = cand[ge[cand] > a]
-        recs = []
-        for qi in cand:
-            qi = int(qi)
-            if qi == si:
-                continue
-            lo_g = max(a, int(gs[qi]))
-            hi_g = min(b, int(ge[qi]))
-            if hi_g - lo_g < min_ovl + 2 * CKPT:
-                continue
-            # snap to checkpoint grids of both reads: use genome positions that are
-            # multiples of CKPT relative to BOTH starts -> recompute per read
-            g0 = lo_g + CKPT
-            g1 = hi_g - CKPT
-            ts_f, te_f = _fwd_pos(rs, si, g0), _fwd_pos(rs, si, g1)
-            # genome positions actually used by the seed snap
-            g0s = rs.gstart[si] + ((g0 - rs.gstart[si]) // CKPT) * CKPT
-            g1s = rs.gstart[si] + ((g1 - rs.gstart[si]) // CKPT) * CKPT
-            qs_f, qe_f = _fwd_pos(rs, qi, g0s), _fwd_pos(rs, qi, g1s)
-            if te_f - ts_f < min_ovl or qe_f - qs_f < min_ovl:
-                continue
-            te_f -= 1
-            qe_f -= 1
-            # to seed-read orientation
-            if rs.rev[si]:
-                t_s, t_e = L - 1 - te_f, L - 1 - ts_f
-            else:
-                t_s, t_e = ts_f, te_f
-            Lq = int(lens[qi])
-            if rs.rev[qi]:
-                q_s, q_e = Lq - 1 - qe_f, Lq - 1 - qs_f
-            else:
-                q_s, q_e = qs_f, qe_f
-            rev = rs.rev[si] ^ rs.rev[qi]
-            match = int(0.45 * (t_e - t_s + 1))
-            recs.append((si, rev, t_s, t_e, qi, q_s, q_e, match))
-        if not recs:
+        cand = cand[(ge[cand] > a) & (cand != si)]
+        if cand.size == 0:
             continue
-        recs.sort(key=lambda r: (-r[7], r[3] - r[2]))
+        lo_g = np.maximum(a, gs[cand])
+        hi_g = np.minimum(b, ge[cand])
+        ok = hi_g - lo_g >= min_ovl + 2 * CKPT
+        cand, lo_g, hi_g = cand[ok], lo_g[ok], hi_g[ok]
+        if cand.size == 0:
+            continue
+        sid = np.full(cand.size, si, dtype=np.int64)
+        # overlap ends = the same absolute grid positions in both reads (like exact
+        # minimizer anchors), one grid step inside the true overlap
+        g0s = ((lo_g + CKPT - 1) // CKPT + 1) * CKPT
+        g1s = (hi_g // CKPT - 1) * CKPT
+        ts_f, te_f = fwd(sid, g0s), fwd(sid, g1s)
+        qs_f, qe_f = fwd(cand, g0s), fwd(cand, g1s)
+        ok = (te_f - ts_f >= min_ovl) & (qe_f - qs_f >= min_ovl)
+        cand, ts_f, te_f, qs_f, qe_f = cand[ok], ts_f[ok], te_f[ok] - 1, qs_f[ok], qe_f[ok] - 1
+        if cand.size == 0:
+            continue
+        if rs.rev[si]:
+            t_s, t_e = L - 1 - te_f, L - 1 - ts_f
+        else:
+            t_s, t_e = ts_f, te_f
+        Lq = lens[cand]
+        qr = rv[cand] == 1
+        q_s = np.where(qr, Lq - 1 - qe_f, qs_f)
+        q_e = np.where(qr, Lq - 1 - qs_f, qe_f)
+        rev = rv[cand] ^ int(rs.rev[si])
+        match = (0.45 * (t_e - t_s + 1)).astype(np.int64)
+        # util/ovl_sort.c:246-255: match desc, span asc
+        o = np.lexsort((t_e - t_s, -match))
+        recs = np.stack([np.full(cand.size, si), rev, t_s, t_e, cand, q_s, q_e, match], axis=1)[o]
         # lib/nextcorrect.py:124-126 admission
-        out = [(si, 0, 0, L - 1, si, 0, L - 1, 0)]
+        span = recs[:, 3] - recs[:, 2]
+        keep = np.zeros(recs.shape[0], dtype=bool)
         total = L
-        for r in recs:
-            if r[3] - r[2] < min_len_aln or total / L > max_cov_aln * 1.5:
+        lim = max_cov_aln * 1.5
+        for r in range(recs.shape[0]):
+            if span[r] < min_len_aln or total / L > lim:
                 continue
-            out.append(r)
-            total += r[3] - r[2] + 1
+            keep[r] = True
+            total += int(span[r]) + 1
         if total / L < min_cov_seed:
             continue
-        piles.append({"seed": si, "recs": np.asarray(out, dtype=np.uint32)})
+        out = np.concatenate([np.asarray([[si, 0, 0, L - 1, si, 0, L - 1, 0]], dtype=np.int64), recs[keep]])
+        piles.append({"seed": si, "recs": out.astype(np.uint32)})
     return piles
+
+
+def flatten_piles(piles):
+    """(recs[n,8] uint32 contiguous, pile_off[n_piles+1] uint64) for ndgpu_correct_piles."""
+    off = np.zeros(len(piles) + 1, dtype=np.uint64)
+    np.cumsum([p["recs"].shape[0] for p in piles], out=off[1:])
+    recs = np.ascontiguousarray(np.concatenate([p["recs"] for p in piles]).astype(np.uint32)) if piles else \
+        np.zeros((0, 8), dtype=np.uint32)
+    return recs, off
+
+
+def pack_db(rs: ReadSet):
+    """Reference .2bit payload for every read: (words uint32, word_off uint64, len uint32)."""
+    n = len(rs)
+    lens = np.asarray([s.size for s in rs.seqs], dtype=np.uint32)
+    nw = (lens.astype(np.int64) + 15) // 16
+    word_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(nw, out=word_off[1:])
+    words = np.zeros(int(word_off[-1]), dtype=np.uint32)
+    for i, s in enumerate(rs.seqs):
+        words[int(word_off[i]):int(word_off[i + 1])] = pack_2bit_msb(s)
+    return words, word_off[:-1].copy(), lens
 
 
 def pack_2bit_msb(codes: np.ndarray) -> np.ndarray:
