@@ -101,6 +101,16 @@ def cpu_baseline(rs, piles, read_type, n_sample):
             "per_core": bases / dt / cores}
 
 
+def reduce_over_ranks(dist, torch, bases: int, dt: float, device):
+    """The path's only collective: sum of corrected bases, max of wall
+    time.  RCCL over xGMI on the GPU box ("nccl" backend), gloo in the CPU tests."""
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    b = torch.tensor([bases], dtype=torch.int64, device=device)
+    dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    return int(b.item()), float(t.item())
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -156,12 +166,7 @@ def main():
     total_bases = bases
     max_dt = dt
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        b = torch.tensor([bases], dtype=torch.int64, device="cuda")
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)  # the one collective of the path
-        max_dt = float(t.item())
-        total_bases = int(b.item())
+        total_bases, max_dt = reduce_over_ranks(dist, torch, bases, dt, "cuda")
 
     if rank == 0:
         # roofline of the dominant kernel (ond_forward): algorithmic bytes per launch =

@@ -620,6 +620,10 @@ class PileImpl {
         msa.count_links(reads);
         const int factor = prm.read_type == 3 ? 4 : 3;
         Pos origin = msa.score_main(factor);
+        if (origin.t < 0) {  // no column carries a tag (reference: undefined behaviour)
+            finish_error(2);
+            return;
+        }
 
         if (prm.fast) {
             cns_fast(msa, origin);
@@ -1095,7 +1099,7 @@ class PileImpl {
 
     ConsensusTrimed *take() {
         if (error2 || result.len <= 4) {
-            ConsensusTrimed *c = make_error_seed(result.len < 2 ? result.len : result.len);
+            ConsensusTrimed *c = make_error_seed(result.len);
             c->identity = result.identity;
             if (!error2 && result.len == 4) memcpy(c->seq, result.seq.data(), std::min<size_t>(4, result.seq.size()));
             return c;
