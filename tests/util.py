@@ -21,8 +21,9 @@ class Aln(C.Structure):
                 ("t_aln_str", C.c_char_p)]
 
 
-class CT(C.Structure):
-    _fields_ = [("len", C.c_uint), ("identity", C.c_float), ("seq", C.c_void_p)]
+import sys
+sys.path.insert(0, os.path.dirname(HERE))
+from nextdenovo_amd.api import ConsensusTrimed as CT  # noqa: E402  (one ctypes type for every binding)
 
 
 def oracle_align(lib, q: bytes, t: bytes, hq=0):
