@@ -60,7 +60,10 @@ void run_single_alignment(char *q, int q_len, char *t, int t_len, alignment *a, 
     job.t_len = t_len;
     job.hq = hq;
     AlnJob *jp = &job;
-    DeviceAligner::instance().align_batch(&jp, 1);
+    {
+        HipBackend be;
+        be.run_align(&jp, 1);
+    }
     if (job.status == ALN_NONE) return;  // reference leaves *align_rtn untouched (lib/align.c:440-560)
     a->aln_t_e = a->aln_t_s + (unsigned)job.t_used - 1;
     a->aln_t_len = (unsigned)job.t_used;
@@ -98,13 +101,9 @@ consensus_trimed *nextCorrect(char **seqs, unsigned int *aln_start, unsigned int
     PileEngine eng(seqs, aln_start, aln_end, seq_count,
                    make_params(max_mem_len, min_len_aln, max_cov_aln, min_cov, lqseq_max_length,
                                min_error_corrected_ratio, split, fast, read_type));
-    std::vector<AlnJob *> jobs;
-    while (!eng.done()) {
-        jobs.clear();
-        eng.collect_jobs(jobs);
-        DeviceAligner::instance().align_batch(jobs.data(), jobs.size());
-        eng.advance();
-    }
+    PileEngine *ep = &eng;
+    HipBackend be;
+    run_engines(&ep, 1, be, 1);
     return (consensus_trimed *)eng.take_result();
 }
 
@@ -127,19 +126,9 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
                                 make_params(max_mem_len[i], min_len_aln, max_cov_aln, min_cov, lqseq_max_length[i],
                                             min_error_corrected_ratio, split, fast, read_type));
     });
-    std::vector<AlnJob *> jobs;
-    std::vector<size_t> live;
-    for (;;) {
-        jobs.clear();
-        live.clear();
-        for (size_t i = 0; i < (size_t)n_piles; i++)
-            if (!eng[i]->done()) {
-                live.push_back(i);
-                eng[i]->collect_jobs(jobs);
-            }
-        if (live.empty()) break;
-        DeviceAligner::instance().align_batch(jobs.data(), jobs.size());
-        parallel_for(live.size(), host_threads, [&](size_t k) { eng[live[k]]->advance(); });
+    {
+        HipBackend be;
+        run_engines(eng.data(), eng.size(), be, host_threads);
     }
     for (size_t i = 0; i < (size_t)n_piles; i++) {
         out[i] = (consensus_trimed *)eng[i]->take_result();
@@ -174,46 +163,32 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     const ReadDb &db = *h->db;
     size_t sub = 512;
     if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
-    std::vector<AlnJob *> jobs;
-    std::vector<size_t> live;
     for (size_t base = 0; base < (size_t)n_piles; base += sub) {
         const size_t cnt = std::min(sub, (size_t)n_piles - base);
         std::vector<PileEngine *> eng(cnt, nullptr);
         parallel_for(cnt, host_threads, [&](size_t k) {
             const uint64_t r0 = pile_off[base + k], r1 = pile_off[base + k + 1];
             const size_t n = (size_t)(r1 - r0);
-            std::vector<std::string> strs(n);
-            std::vector<const char *> ptrs(n);
-            std::vector<unsigned> st(n), en(n);
+            std::vector<unsigned> st(n), en(n), len(n);
             std::vector<int64_t> dev(n);
             unsigned max_aln = n ? recs[r0 * 8 + 3] + 1 : 0;
             for (size_t i = 0; i < n; i++) {
                 const uint32_t *r = recs + (r0 + i) * 8;
-                strs[i] = db.window(r[4], r[5], r[6], (int)r[1]);
-                ptrs[i] = strs[i].c_str();
                 dev[i] = db.window_offset(r[4], r[5], r[6], (int)r[1]);
+                len[i] = r[6] - r[5] + 1;
                 st[i] = r[2];
                 en[i] = r[3];
                 const unsigned v = r[3] - r[2] + r[6] - r[5] + 2;
                 if (v > max_aln && r[0] != r[4]) max_aln = v;
             }
             const unsigned lq = n ? std::min<unsigned>(en[0] / 2, max_lq_length) : max_lq_length;
-            eng[k] = new PileEngine(ptrs.data(), st.data(), en.data(), (unsigned)n,
+            eng[k] = new PileEngine(len.data(), dev.data(), st.data(), en.data(), (unsigned)n,
                                     make_params(max_aln, min_len_aln, max_cov_aln, min_cov, lq,
-                                                min_error_corrected_ratio, split, fast, read_type),
-                                    dev.data());
+                                                min_error_corrected_ratio, split, fast, read_type));
         });
-        for (;;) {
-            jobs.clear();
-            live.clear();
-            for (size_t k = 0; k < cnt; k++)
-                if (!eng[k]->done()) {
-                    live.push_back(k);
-                    eng[k]->collect_jobs(jobs);
-                }
-            if (live.empty()) break;
-            DeviceAligner::instance().align_batch(jobs.data(), jobs.size());
-            parallel_for(live.size(), host_threads, [&](size_t k) { eng[live[k]]->advance(); });
+        {
+            HipBackend be;
+            run_engines(eng.data(), cnt, be, host_threads);
         }
         for (size_t k = 0; k < cnt; k++) {
             out[base + k] = (consensus_trimed *)eng[k]->take_result();

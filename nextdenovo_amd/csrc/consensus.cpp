@@ -20,7 +20,9 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 namespace ndgpu {
 
@@ -154,58 +156,6 @@ struct Msa {
                 }
             }
         }
-    }
-
-    // lib/nextcorrect.c:2149-2202 (main MSA).  Returns the backtrack origin.
-    Pos score_main(int factor) {
-        int64_t global_best = -10;
-        Pos origin{-1, 0, 0};
-        const int ncols = (int)ncol();
-        for (int p = 0; p < ncols; p++) {
-            const int64_t penalty = (int64_t)factor * coverage[p];
-            for (unsigned d = 0; d < max_size[p]; d++) {
-                for (unsigned b = 0; b < 5; b++) {
-                    Cell &c = cell(p, d, b);
-                    c.best_score = -10;
-                    c.best_t = -1;
-                    int64_t via = INT64_MIN, via_pending = INT64_MIN;
-                    for (int32_t m = c.head; m != -1; m = links[m].next) {
-                        Link &lm = links[m];
-                        if (lm.pp_t == -1) {
-                            lm.score = 10 * (int64_t)lm.count - penalty;
-                        } else {
-                            const Cell &pc = cell(lm.pp_t, lm.pp_d, lm.pp_b);
-                            for (int32_t n = pc.head; n != -1; n = links[n].next) {
-                                const Link &ln = links[n];
-                                if (ln.pp_t != lm.ppp_t || ln.pp_d != lm.ppp_d || ln.pp_b != lm.ppp_b) continue;
-                                int64_t s = ln.score + 10 * (int64_t)lm.count - penalty;
-                                if (s > lm.score) {
-                                    lm.score = s;
-                                    via_pending = ln.score;
-                                }
-                                if (ln.score > via && (lm.pp_b == 4 || lm.pp_b == b)) {
-                                    via = ln.score;
-                                    c.best_score = lm.score;
-                                    c.best_t = lm.pp_t; c.best_d = lm.pp_d; c.best_b = lm.pp_b;
-                                    c.best_link = lm.count;
-                                }
-                            }
-                        }
-                        if (lm.score > c.best_score || (lm.score == c.best_score && lm.pp_b != 4)) {
-                            via = via_pending;
-                            c.best_score = lm.score;
-                            c.best_t = lm.pp_t; c.best_d = lm.pp_d; c.best_b = lm.pp_b;
-                            c.best_link = lm.count;
-                        }
-                    }
-                    if (c.best_score >= global_best - 3000) {
-                        origin = Pos{p, (uint16_t)d, (uint8_t)b};
-                        if (c.best_score > global_best) global_best = c.best_score;
-                    }
-                }
-            }
-        }
-        return origin;
     }
 
     // lib/nextcorrect.c:1263-1300 (second, low-quality-region MSA): 6 symbols,
@@ -472,14 +422,18 @@ void trim_terminal_ssr(Result &r) {
 
 class PileImpl {
   public:
-    enum Phase { MAIN, LQ_ROUND, DONE };
+    typedef PileEngine::Phase Phase;
 
     CorrectParams prm;
     unsigned lq_max_len;
-    std::vector<std::string> seqs;
-    std::vector<unsigned> aln_start, aln_end;
-    int seed_len;
-    Phase phase = MAIN;
+    std::vector<std::string> own_seqs;      // ASCII form only
+    std::vector<const char *> seq_ptr;
+    std::vector<unsigned> seq_len, aln_start, aln_end;
+    std::vector<int64_t> dev_off;
+    int seed_len = 0;
+    Phase phase = PileEngine::MAIN;
+    MainPile main;
+    ExtractPile extract;
     std::vector<AlnJob> jobs;
     Result result;
     bool error2 = false;
@@ -493,141 +447,79 @@ class PileImpl {
     struct LqSlot { int i, j, job; };  // (row, region) -> job index or -1 ('M' fill)
     std::vector<LqSlot> lq_slots;
 
-    PileImpl(const char *const *s, const unsigned *st, const unsigned *en, unsigned n, const CorrectParams &p,
-             const int64_t *dev_off)
+    PileImpl(const char *const *s, const unsigned *len, const int64_t *dev, const unsigned *st, const unsigned *en,
+             unsigned n, const CorrectParams &p)
         : prm(p) {
         lq_max_len = p.lqseq_max_length > 10000 ? 10000 : p.lqseq_max_length;  // DAG_MAX_LENGTH, nextcorrect.c:2231
-        seqs.reserve(n);
-        for (unsigned i = 0; i < n; i++) seqs.emplace_back(s[i]);
         aln_start.assign(st, st + n);
         aln_end.assign(en, en + n);
-        seed_len = n ? (int)en[0] + 1 : 0;
-        if (n == 0) { finish_error(2); return; }
-        // nextcorrect.c:2271-2293: every non-seed read is aligned to its seed window
-        jobs.resize(n > 0 ? n - 1 : 0);
-        for (unsigned i = 1; i < n; i++) {
-            AlnJob &j = jobs[i - 1];
-            j.q = seqs[i].c_str();
-            j.q_len = (int)seqs[i].size();
-            j.t = seqs[0].c_str() + aln_start[i];
-            j.t_len = (int)(aln_end[i] - aln_start[i] + 1);
-            j.t_owner = seqs[0].c_str();
-            j.t_owner_len = (int)seqs[0].size();
-            if (dev_off && dev_off[0] >= 0 && dev_off[i] >= 0) {
-                j.q_dev = dev_off[i];
-                j.t_dev = dev_off[0] + aln_start[i];
+        if (s) {
+            own_seqs.reserve(n);
+            for (unsigned i = 0; i < n; i++) own_seqs.emplace_back(s[i]);
+            for (unsigned i = 0; i < n; i++) {
+                seq_ptr.push_back(own_seqs[i].c_str());
+                seq_len.push_back((unsigned)own_seqs[i].size());
             }
-            j.hq = prm.read_type == 3;
+        } else {
+            seq_len.assign(len, len + n);
+            dev_off.assign(dev, dev + n);
         }
+        if (n == 0) { finish_error(2); return; }
+        seed_len = (int)en[0] + 1;
+        // the seed is its own alignment over [aln_start[0], aln_end[0]] (nextcorrect.c:2279-2282);
+        // lib/nextcorrect.py always passes 0 .. len-1
+        if (st[0] != 0 || seq_len[0] != (unsigned)seed_len) {
+            fprintf(stderr, "[ndgpu] seed record must span the whole seed (aln_start 0, aln_end len-1)\n");
+            finish_error(2);
+            return;
+        }
+        for (unsigned i = 1; i < n; i++)
+            if (en[i] < st[i] || en[i] >= (unsigned)seed_len) {
+                fprintf(stderr, "[ndgpu] overlap window outside the seed\n");
+                finish_error(2);
+                return;
+            }
+        main.n = n;
+        main.seqs = s ? seq_ptr.data() : nullptr;
+        main.seq_len = seq_len.data();
+        main.aln_start = aln_start.data();
+        main.aln_end = aln_end.data();
+        main.dev_off = s ? nullptr : dev_off.data();
+        main.min_len_aln = prm.min_len_aln;
+        main.max_cov_aln = prm.max_cov_aln;
+        main.factor = prm.read_type == 3 ? 4 : 3;  // nextcorrect.c:2147
+        main.hq = prm.read_type == 3;              // align_hq for HiFi, nextcorrect.c:2269
     }
 
     void finish_error(unsigned code) {
         result = Result();
         result.len = code;
         error2 = true;
-        phase = DONE;
+        phase = PileEngine::DONE;
     }
 
     void collect(std::vector<AlnJob *> &out) {
-        if (phase == DONE) return;
+        if (phase != PileEngine::LQ_ROUND) return;
         for (AlnJob &j : jobs) out.push_back(&j);
     }
 
     void advance() {
-        if (phase == MAIN) after_main();
-        else if (phase == LQ_ROUND) after_lq_round();
+        if (phase == PileEngine::MAIN) after_main();
+        else if (phase == PileEngine::EXTRACT) after_extract();
+        else if (phase == PileEngine::LQ_ROUND) after_lq_round();
     }
 
-    // -- main phase ----------------------------------------------------------------
-    std::vector<TagList> reads;  // accepted alignments in pile order
-
-    // get_align_shift(aln, 8) + get_align_tags on a column-kind stream
-    // (lib/nextcorrect.c:102-154, 1485-1536)
-    bool tags_from_ops(const AlnJob &job, unsigned t_s, unsigned t_e, Msa &msa, int &total_cov) {
-        if (job.status != ALN_OK) return false;
-        const std::vector<uint8_t> &ops = job.ops;
-        const int n = (int)ops.size();
-        int run = 0, i, tcols = 0;
-        for (i = 0; i < n; i++) {
-            run = ops[i] == OP_MATCH ? run + 1 : 0;
-            if (ops[i] != OP_QONLY) tcols++;
-            if (run == 8) break;
-        }
-        if (i >= n) return false;
-        const int shift = i - 7;
-        t_s += (unsigned)(tcols - 8);
-        run = 0;
-        int tc = 0;
-        for (i = n - 1; i >= 0; i--) {
-            run = ops[i] == OP_MATCH ? run + 1 : 0;
-            if (ops[i] != OP_QONLY) tc++;
-            if (run == 8) break;
-        }
-        t_e = t_e - (unsigned)tc + 8;
-        const int last = i + 7;
-        const unsigned aln_len = (unsigned)(last - shift + 1);
-        if (aln_len < prm.min_len_aln) return false;
-        total_cov += (int)(t_e - t_s + 1);
-
-        reads.emplace_back();
-        TagList &tl = reads.back();
-        tl.aln_t_s = t_s;
-        tl.tags.resize(aln_len);
-        // query offset of column `shift`
-        int qi = 0;
-        for (int c = 0; c < shift; c++) qi += ops[c] != OP_TONLY;
-        int32_t t = (int32_t)t_s - 1;
-        uint16_t delta = 0;
-        const char *q = job.q;
-        for (unsigned c = 0; c < aln_len; c++) {
-            const uint8_t op = ops[shift + c];
-            if (op != OP_QONLY) {
-                t++;
-                delta = 0;
-            }
-            Tag &g = tl.tags[c];
-            g.t_pos = t;
-            g.delta = delta++;
-            g.base = op == OP_TONLY ? 4 : base_code(q[qi++]);
-            if (g.delta == 0) msa.coverage[t]++;
-            if (g.delta >= msa.max_size[t]) msa.max_size[t] = g.delta + 1;
-        }
-        return true;
-    }
-
+    // -- main phase: the device returns the best_pp walk --------------------------------
     void after_main() {
-        Msa msa((size_t)seed_len);
-        int total_cov = 0;
-        const unsigned n = (unsigned)seqs.size();
-        for (unsigned i = 0; i < n && (unsigned)(total_cov / seed_len) <= prm.max_cov_aln; i++) {
-            if (i == 0) {
-                // the seed is its own alignment (nextcorrect.c:2279-2282)
-                const unsigned L = (unsigned)seqs[0].size();
-                if (L >= prm.min_len_aln) {
-                    total_cov += (int)(aln_end[0] - aln_start[0] + 1);
-                    reads.emplace_back();
-                    tags_from_strings(seqs[0], seqs[0], aln_start[0], reads.back(), msa);
-                }
-            } else {
-                tags_from_ops(jobs[i - 1], aln_start[i], aln_end[i], msa, total_cov);
-            }
-        }
-        jobs.clear();
-        jobs.shrink_to_fit();
-
-        // get_cns_from_align_tags (nextcorrect.c:2130-2217)
-        msa.allocate();
-        msa.count_links(reads);
-        const int factor = prm.read_type == 3 ? 4 : 3;
-        Pos origin = msa.score_main(factor);
-        if (origin.t < 0) {  // no column carries a tag (reference: undefined behaviour)
+        std::vector<PathStep> path;
+        path.swap(main.path);
+        if (path.empty()) {  // no column carries a tag (reference: undefined behaviour)
             finish_error(2);
             return;
         }
-
         if (prm.fast) {
-            cns_fast(msa, origin);
-            phase = DONE;
+            cns_fast(path);
+            phase = PileEngine::DONE;
             return;
         }
         if (prm.read_type == 3) {
@@ -635,31 +527,48 @@ class PileImpl {
             finish_error(2);
             return;
         }
-        if (!cns_from_best_score(msa, origin)) {
+        if (!cns_from_best_score(path)) {
             finish_error(2);
             return;
         }
-        // continue with the low-quality-region rounds
         lq_iter = 0;
         lq_max_dif_len = 0;
+        if (regions.empty()) {
+            lq_max_aln_length = 0;
+            start_lq_round();
+            return;
+        }
+        extract.slot = main.slot;
+        extract.regions.resize(regions.size());
+        for (size_t i = 0; i < regions.size(); i++) {
+            extract.regions[i].start = regions[i].start;
+            extract.regions[i].end = regions[i].end;
+            extract.regions[i].max_len = lq_max_len;
+        }
+        phase = PileEngine::EXTRACT;
+    }
+
+    void after_extract() {
+        lq_max_aln_length = lqseqs_from_candidates();
+        extract.regions.clear();
         start_lq_round();
     }
 
     // lib/nextcorrect.c:1717-1784
-    void cns_fast(Msa &msa, Pos cur) {
+    void cns_fast(const std::vector<PathStep> &path) {
         std::string out;
         LqReg lq[kLqRegMax];
         int lq_i = 0;
         const int min_cov = (int)prm.min_cov;
-        while (true) {
-            if (cur.b != 4) {
-                if ((int)msa.coverage[cur.t] > min_cov) {
-                    out.push_back((char)kIntToBase[cur.b]);
+        for (const PathStep &cur : path) {
+            if (cur.base != 4) {
+                if ((int)cur.cov > min_cov) {
+                    out.push_back((char)kIntToBase[cur.base]);
                     if (lq[lq_i].end >= lq[lq_i].start + 50 || !lq_i) {
                         if (++lq_i >= kLqRegMax) break;
                     } else lq[lq_i].end = 0;
                 } else {
-                    out.push_back((char)tolower(kIntToBase[cur.b]));
+                    out.push_back((char)tolower(kIntToBase[cur.base]));
                     if (!lq[lq_i].end) {
                         lq[lq_i].start = (unsigned)out.size() - 1;
                         lq[lq_i].lqlen = 0;
@@ -669,9 +578,6 @@ class PileImpl {
                     lq[lq_i].lqlen++;
                 }
             }
-            const Cell &c = msa.cell(cur.t, cur.d, cur.b);
-            cur = Pos{c.best_t, c.best_d, c.best_b};
-            if (cur.t == -1) break;
         }
         int i, lq_m = 0, hq_m = (int)lq[0].start, l = hq_m;
         unsigned lq_total_len = lq[0].lq_total_len - lq[0].lqlen;
@@ -690,120 +596,98 @@ class PileImpl {
         }
         result.len = (unsigned)(hq_m - lq_m);
         result.identity = 1 - (float)lq_total_len / result.len;
-        result.seq = out.substr((size_t)lq_m, result.len);
+        result.seq = (size_t)lq_m <= out.size() ? out.substr((size_t)lq_m, result.len) : std::string();
         std::reverse(result.seq.begin(), result.seq.end());
     }
 
     // lib/nextcorrect.c:1885-2006.  Returns false for the error_seed(2) outcome.
-    bool cns_from_best_score(Msa &msa, Pos cur) {
+    bool cns_from_best_score(const std::vector<PathStep> &path) {
         int p = 0, lable = 1;
         const int lq_min_length = 8;
         int qv = 0, pqv, hq = 0, lq = 0, lq_l = 0, lq_s = -1, lq_e = -1;
         int lqseq_total_length = 0;
         const int min_cov = (int)prm.min_cov;
         cns = CnsData();
-        cns.bases.reserve((size_t)seed_len + seed_len / 8 + 16);
+        cns.bases.reserve(path.size());
         regions.clear();
-        while (true) {
-            if (cur.b != 4) {
-                cns.bases.push_back(CnsBase{(unsigned)cur.t, 0});
-                const Cell &c = msa.cell(cur.t, cur.d, cur.b);
-                const int cov = msa.coverage[cur.t];
-                pqv = 100 * (int)c.best_link / cov;
-                if (pqv > 40) hq++;
-                else {
-                    hq = 0;
-                    lqseq_total_length++;
-                }
-                if (hq > lq_min_length / 2 && lq_e - lq_s < lq_min_length / 2) {
-                    qv = lq_l = lq = 0;
-                    lq_s = -1;
-                }
-                if ((qv + pqv) / (lq_l + 1) < 40) {
-                    if (lq_s == -1) lq_s = p;
-                    lq_e = p;
-                    lq = 1;
-                    lq_l++;
-                    qv += pqv;
-                } else if (lq && p - lq_e > 2 * lq_min_length && cns.bases[p].pos != cns.bases[p - 1].pos) {
-                    if (lq_e - lq_s + 1 > lq_min_length && (unsigned)(lq_e - lq_s + 1) < lq_max_len) {
-                        lq_e = p - lq_min_length - 1;
-                        lq_s = lq_s > lq_min_length ? lq_s - lq_min_length : 1;
-                        LqRegion r;
-                        r.end = cns.bases[lq_s].pos;
-                        r.start = cns.bases[lq_e].pos;
-                        if (!regions.empty() && r.end == regions.back().start) {
-                            while (r.end == regions.back().start && lq_s < p - 4) r.end = cns.bases[++lq_s].pos;
-                        }
-                        regions.push_back(std::move(r));
-                    }
-                    qv = lq_l = lq = 0;
-                    lq_s = -1;
-                } else if (lq && cns.bases[p].pos != cns.bases[p - 1].pos) {
-                    qv = lq_l = 0;
-                }
-                if (cov > min_cov && pqv > 20) {
-                    cns.bases[p].base = (char)kIntToBase[cur.b];
-                    lable = 0;
-                    cns.lstrip = 0;
-                } else {
-                    cns.bases[p].base = (char)tolower(kIntToBase[cur.b]);
-                    cns.uncorrected_len++;
-                    cns.lstrip++;
-                    if (lable) cns.rstrip++;
-                }
-                p++;
+        for (const PathStep &cur : path) {
+            if (cur.base == 4) continue;
+            cns.bases.push_back(CnsBase{(unsigned)cur.t_pos, 0});
+            const int cov = cur.cov;
+            pqv = 100 * (int)cur.link / cov;
+            if (pqv > 40) hq++;
+            else {
+                hq = 0;
+                lqseq_total_length++;
             }
-            const Cell &c = msa.cell(cur.t, cur.d, cur.b);
-            cur = Pos{c.best_t, c.best_d, c.best_b};
-            if (cur.t == -1) break;
+            if (hq > lq_min_length / 2 && lq_e - lq_s < lq_min_length / 2) {
+                qv = lq_l = lq = 0;
+                lq_s = -1;
+            }
+            if ((qv + pqv) / (lq_l + 1) < 40) {
+                if (lq_s == -1) lq_s = p;
+                lq_e = p;
+                lq = 1;
+                lq_l++;
+                qv += pqv;
+            } else if (lq && p - lq_e > 2 * lq_min_length && cns.bases[p].pos != cns.bases[p - 1].pos) {
+                if (lq_e - lq_s + 1 > lq_min_length && (unsigned)(lq_e - lq_s + 1) < lq_max_len) {
+                    lq_e = p - lq_min_length - 1;
+                    lq_s = lq_s > lq_min_length ? lq_s - lq_min_length : 1;
+                    LqRegion r;
+                    r.end = cns.bases[lq_s].pos;
+                    r.start = cns.bases[lq_e].pos;
+                    if (!regions.empty() && r.end == regions.back().start) {
+                        while (r.end == regions.back().start && lq_s < p - 4) r.end = cns.bases[++lq_s].pos;
+                    }
+                    regions.push_back(std::move(r));
+                }
+                qv = lq_l = lq = 0;
+                lq_s = -1;
+            } else if (lq && cns.bases[p].pos != cns.bases[p - 1].pos) {
+                qv = lq_l = 0;
+            }
+            if (cov > min_cov && pqv > 20) {
+                cns.bases[p].base = (char)kIntToBase[cur.base];
+                lable = 0;
+                cns.lstrip = 0;
+            } else {
+                cns.bases[p].base = (char)tolower(kIntToBase[cur.base]);
+                cns.uncorrected_len++;
+                cns.lstrip++;
+                if (lable) cns.rstrip++;
+            }
+            p++;
         }
         cns.len = (unsigned)p;
         const float lhs = (float)(cns.uncorrected_len - cns.lstrip - cns.rstrip);
         const float rhs = (float)(cns.len - cns.lstrip - cns.rstrip) * (1 - prm.min_error_corrected_ratio);
         if (!(cns.len > 2 && (double)lqseq_total_length < cns.len * 0.8 && lhs < rhs)) return false;
         std::reverse(cns.bases.begin(), cns.bases.end());
-        lq_max_aln_length = lqseqs_from_tags();
-        reads.clear();
-        reads.shrink_to_fit();
         return true;
     }
 
-    // lib/nextcorrect.c:356-510
-    int lqseqs_from_tags() {
+    // lib/nextcorrect.c:356-510 with the candidate strings (lines 373-404) already
+    // gathered by the backend
+    int lqseqs_from_candidates() {
         int max_aln_length = 0;
         std::vector<uint16_t> bins(kKmerBins);
-        for (LqRegion &lq : regions) {
-            int max_len_here = 0, large_seq = 0;
-            const int start = (int)lq.start, end = (int)lq.end;
+        for (size_t ri = 0; ri < regions.size(); ri++) {
+            LqRegion &lq = regions[ri];
+            RegionReq &rq = extract.regions[ri];
+            int max_len_here = 0;
+            const int large_seq = (int)rq.n_large;
             lq.len = 0;
             lq.seqs.clear();
             lq.has_seed = false;
-            for (const TagList &tl : reads) {
-                const std::vector<Tag> &tg = tl.tags;
-                if (!(tg.front().t_pos <= start && tg.back().t_pos >= end)) continue;
-                bool too_long = false;
-                std::string s;
-                for (size_t k = (size_t)(start - tg.front().t_pos); k < tg.size() && tg[k].t_pos <= end; k++) {
-                    if (tg[k].t_pos >= start && tg[k].base != 4) {
-                        s.push_back((char)kIntToBase[tg[k].base]);
-                        if (s.size() > lq_max_len - 1) {
-                            large_seq++;
-                            too_long = true;
-                            break;
-                        }
-                    }
-                }
-                if (!s.empty() && !too_long) {
-                    LqSeq q;
-                    q.len = (uint16_t)s.size();
-                    q.order = (uint16_t)lq.len;
-                    if ((int)s.size() > max_len_here) max_len_here = (int)s.size();
-                    q.seq = std::move(s);
-                    lq.seqs.push_back(std::move(q));
-                    lq.len++;
-                }
-                if (lq.len >= kLqCanMax) break;
+            for (std::string &s : rq.cands) {
+                LqSeq q;
+                q.len = (uint16_t)s.size();
+                q.order = (uint16_t)lq.len;
+                if ((int)s.size() > max_len_here) max_len_here = (int)s.size();
+                q.seq = std::move(s);
+                lq.seqs.push_back(std::move(q));
+                lq.len++;
             }
             if ((float)large_seq / (lq.len + large_seq) > 1.0 / 3 || lq.len <= 4 || (prm.split && lq.len < 10)) {
                 lq.len = 0;
@@ -917,7 +801,7 @@ class PileImpl {
                 lq_slots.push_back(slot);
             }
         }
-        phase = LQ_ROUND;
+        phase = PileEngine::LQ_ROUND;
         if (jobs.empty()) after_lq_round();  // nothing to align: still run the round
     }
 
@@ -1094,7 +978,7 @@ class PileImpl {
             result.identity = 1 - (float)lq[0].lq_total_len / result.len;
         }
         if (result.len > 1000 && result.identity > 0.8) trim_terminal_ssr(result);
-        phase = DONE;
+        phase = PileEngine::DONE;
     }
 
     ConsensusTrimed *take() {
@@ -1115,12 +999,67 @@ class PileImpl {
 };
 
 PileEngine::PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
-                       const CorrectParams &prm, const int64_t *dev_off)
-    : impl_(new PileImpl(seqs, aln_start, aln_end, seq_count, prm, dev_off)) {}
+                       const CorrectParams &prm)
+    : impl_(new PileImpl(seqs, nullptr, nullptr, aln_start, aln_end, seq_count, prm)) {}
+PileEngine::PileEngine(const unsigned *seq_len, const int64_t *dev_off, const unsigned *aln_start,
+                       const unsigned *aln_end, unsigned seq_count, const CorrectParams &prm)
+    : impl_(new PileImpl(nullptr, seq_len, dev_off, aln_start, aln_end, seq_count, prm)) {}
 PileEngine::~PileEngine() { delete impl_; }
-bool PileEngine::done() const { return impl_->phase == PileImpl::DONE; }
+PileEngine::Phase PileEngine::phase() const { return impl_->phase; }
+MainPile *PileEngine::main_request() { return &impl_->main; }
+ExtractPile *PileEngine::extract_request() { return &impl_->extract; }
 void PileEngine::collect_jobs(std::vector<AlnJob *> &out) { impl_->collect(out); }
 void PileEngine::advance() { impl_->advance(); }
 ConsensusTrimed *PileEngine::take_result() { return impl_->take(); }
+
+namespace {
+template <typename F>
+void parallel_for(size_t n, int threads, F f) {
+    if (threads <= 1 || n <= 1) {
+        for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> pool;
+    const int nt = (int)std::min<size_t>((size_t)threads, n);
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&] {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+}  // namespace
+
+void run_engines(PileEngine **eng, size_t n, Backend &be, int threads) {
+    std::vector<MainPile *> mains;
+    std::vector<ExtractPile *> extracts;
+    std::vector<AlnJob *> jobs;
+    std::vector<size_t> live;
+    for (;;) {
+        mains.clear();
+        extracts.clear();
+        jobs.clear();
+        live.clear();
+        for (size_t i = 0; i < n; i++) {
+            switch (eng[i]->phase()) {
+                case PileEngine::MAIN: mains.push_back(eng[i]->main_request()); break;
+                case PileEngine::EXTRACT: extracts.push_back(eng[i]->extract_request()); break;
+                case PileEngine::LQ_ROUND: eng[i]->collect_jobs(jobs); break;
+                default: continue;
+            }
+            live.push_back(i);
+        }
+        if (live.empty()) break;
+        if (!mains.empty()) be.run_main(mains.data(), mains.size());
+        if (!extracts.empty()) be.run_extract(extracts.data(), extracts.size());
+        if (!jobs.empty()) be.run_align(jobs.data(), jobs.size());
+        parallel_for(live.size(), threads, [&](size_t k) { eng[live[k]]->advance(); });
+    }
+    be.end_batch();
+}
 
 }  // namespace ndgpu

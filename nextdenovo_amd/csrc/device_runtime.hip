@@ -118,6 +118,21 @@ struct DeviceAligner::State {
     DevBuf<AlnOut> d_outs;
     DevBuf<uint64_t> d_trace;
     DevBuf<int32_t> d_mink, d_v, d_ids;
+    // main-phase state (alive from run_main to end_batch)
+    std::mutex batch_mu;
+    DevBuf<ReadDev> d_reads;
+    DevBuf<PileDev> d_piles;
+    DevBuf<uint32_t> d_read_pile, d_acc, d_tags, d_colidx, d_cov, d_inscnt, d_insmax, d_cellbase, d_entbase;
+    DevBuf<uint32_t> d_cell_start, d_cell_len, d_cell_bpp, d_cell_blink, d_ent_pp, d_ent_ppp, d_ent_cnt, d_err;
+    DevBuf<long long> d_ent_score;
+    DevBuf<PathItem> d_path;
+    DevBuf<ColBlock> d_blocks;
+    DevBuf<RegionDev> d_regions;
+    DevBuf<char> d_strpool;
+    DevBuf<unsigned long long> d_cursor;
+    std::vector<ReadDev> reads;
+    std::vector<PileDev> piles;
+    hipEvent_t evs[8] = {nullptr};
     PinBuf<uint32_t> h_ops;
     PinBuf<AlnOut> h_outs;
     std::vector<uint32_t> pool;
@@ -143,6 +158,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     HIP_CHECK(hipStreamCreateWithFlags(&s_->stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreate(&s_->ev0));
     HIP_CHECK(hipEventCreate(&s_->ev1));
+    for (auto &e : s_->evs) HIP_CHECK(hipEventCreate(&e));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)8 << 30))
         s_->trace_budget_bytes = free_b / 3;
@@ -338,7 +354,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
 
 void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t> &ids) {
     State &S = *s_;
-    (void)jobs;
+    const bool ops_to_host = jobs != nullptr;  // the device main phase keeps ops in HBM
     // process in groups bounded by the trace budget; wide rows are band-cap sized
     size_t at = 0;
     DevBuf<uint64_t> trace;
@@ -383,8 +399,9 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
             const int32_t id = ids[at + i];
             const AlnTask &t = S.tasks[id];
             HIP_CHECK(hipMemcpy(&S.h_outs.p[id], S.d_outs.p + id, sizeof(AlnOut), hipMemcpyDeviceToHost));
-            HIP_CHECK(hipMemcpy(S.h_ops.p + t.ops_off, S.d_ops.p + t.ops_off,
-                                ((uint64_t)(t.ops_cap + 15) / 16 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (ops_to_host)
+                HIP_CHECK(hipMemcpy(S.h_ops.p + t.ops_off, S.d_ops.p + t.ops_off,
+                                    ((uint64_t)(t.ops_cap + 15) / 16 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
         }
         S.stats.wide_tasks += take;
         at += take;
@@ -392,6 +409,336 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
     (void)n;
 }
 
-void hip_align_backend(AlnJob **jobs, size_t n, void *) { DeviceAligner::instance().align_batch(jobs, n); }
+void DeviceAligner::begin_batch() { s_->batch_mu.lock(); }
+void DeviceAligner::end_batch() { s_->batch_mu.unlock(); }
+
+// Main phase of a batch of piles, entirely on the device:
+//   K7 forward -> K8a traceback -> K8s shift scan -> accept -> K8b tags -> column scan
+//   -> [one host sync: exact cell / link totals] -> K9 link counting -> K10 scoring + walk.
+void DeviceAligner::run_main(MainPile **mp, size_t np) {
+    State &S = *s_;
+    std::lock_guard<std::mutex> lock(S.mu);
+    HIP_CHECK(hipSetDevice(S.device));
+    hipStream_t st = S.stream;
+    std::vector<uint32_t> &pool = S.pool;
+    std::vector<AlnTask> &tasks = S.tasks;
+    std::vector<ReadDev> &reads = S.reads;
+    std::vector<PileDev> &piles = S.piles;
+    pool.clear();
+    tasks.clear();
+    reads.clear();
+    piles.assign(np, PileDev());
+    std::vector<uint32_t> read_pile;
+    std::vector<uint8_t> bad_pile(np, 0);
+    uint64_t ops_words = 0, tag_slots = 0, colidx_slots = 0, col_slots = 0, acc_slots = 0;
+    for (size_t p = 0; p < np; p++) {
+        MainPile &M = *mp[p];
+        PileDev &P = piles[p];
+        M.path.clear();
+        M.slot = (int)p;
+        memset(&P, 0, sizeof(P));
+        P.seed_len = M.aln_end[0] + 1;
+        P.n_reads = M.n;
+        P.first_read = (uint32_t)reads.size();
+        P.min_len_aln = M.min_len_aln;
+        P.max_cov_aln = M.max_cov_aln;
+        P.factor = M.factor;
+        P.col_off = col_slots;
+        col_slots += (uint64_t)P.seed_len + 1;
+        P.acc_off = acc_slots;
+        acc_slots += M.n;
+        if (M.dev_off) P.seed_off = (uint64_t)M.dev_off[0] | kOffDb;
+        else {
+            P.seed_off = (uint64_t)pool.size() * 16;
+            if (!pack_append(pool, M.seqs[0], M.seq_len[0])) bad_pile[p] = 1;
+            S.stats.pool_bases += M.seq_len[0];
+        }
+        for (unsigned i = 0; i < M.n; i++) {
+            ReadDev R;
+            memset(&R, 0, sizeof(R));
+            R.aln_start = M.aln_start[i];
+            R.aln_end = M.aln_end[i];
+            uint64_t tag_cap, ci_cap;
+            if (i == 0) {
+                R.task = -1;
+                tag_cap = ci_cap = P.seed_len;
+            } else {
+                AlnTask t;
+                memset(&t, 0, sizeof(t));
+                t.q_len = (int32_t)M.seq_len[i];
+                t.t_len = (int32_t)(M.aln_end[i] - M.aln_start[i] + 1);
+                if (M.dev_off) t.q_off = (uint64_t)M.dev_off[i] | kOffDb;
+                else {
+                    t.q_off = (uint64_t)pool.size() * 16;
+                    if (!pack_append(pool, M.seqs[i], M.seq_len[i])) bad_pile[p] = 1;
+                    S.stats.pool_bases += M.seq_len[i];
+                }
+                t.t_off = P.seed_off + M.aln_start[i];
+                int md, bd;
+                limits_for(t.q_len + t.t_len, M.hq, &md, &bd);
+                t.max_d = md;
+                t.band = bd;
+                t.row_words = kFastRowWords;
+                t.ops_off = ops_words;
+                t.ops_cap = (uint32_t)(t.q_len + t.t_len);
+                ops_words += (uint64_t)(t.ops_cap + 15) / 16 + 1;
+                S.stats.seq_bases += (uint64_t)t.q_len + (uint64_t)t.t_len;
+                R.task = (int32_t)tasks.size();
+                tasks.push_back(t);
+                tag_cap = t.ops_cap;
+                ci_cap = (uint64_t)t.t_len;
+            }
+            R.tag_off = tag_slots;
+            tag_slots += tag_cap;
+            R.colidx_off = colidx_slots;
+            colidx_slots += ci_cap + 1;
+            reads.push_back(R);
+            read_pile.push_back((uint32_t)p);
+        }
+        if (bad_pile[p]) {  // bytes outside [ACGT]: nothing of this pile is aligned
+            fprintf(stderr, "[ndgpu] pile with bytes outside [ACGT]: reported as uncorrectable\n");
+            for (uint32_t r = P.first_read + 1; r < reads.size(); r++) tasks[reads[r].task].max_d = 0;
+            P.min_len_aln = 0xffffffffu;
+        }
+    }
+    pool.push_back(0);
+    pool.push_back(0);
+    const size_t nt = tasks.size(), nr = reads.size();
+
+    // forward/traceback chunks bounded by the trace budget
+    std::vector<size_t> chunk_end;
+    {
+        uint64_t tw = 0, mr = 0;
+        for (size_t i = 0; i < nt; i++) {
+            const uint64_t need = (uint64_t)tasks[i].max_d * (kFastRowWords * 8 + 4);
+            if (i && (tw * 8 + mr * 4 + need) > S.trace_budget_bytes) {
+                chunk_end.push_back(i);
+                tw = mr = 0;
+            }
+            tasks[i].trace_off = tw;
+            tasks[i].mink_off = mr;
+            tw += (uint64_t)tasks[i].max_d * kFastRowWords;
+            mr += (uint64_t)tasks[i].max_d;
+        }
+        chunk_end.push_back(nt);
+    }
+    uint64_t max_tw = 0, max_mr = 0;
+    {
+        size_t a = 0;
+        for (size_t b : chunk_end) {
+            if (b > a) {
+                const AlnTask &l = tasks[b - 1];
+                max_tw = std::max<uint64_t>(max_tw, l.trace_off + (uint64_t)l.max_d * kFastRowWords);
+                max_mr = std::max<uint64_t>(max_mr, l.mink_off + (uint64_t)l.max_d);
+            }
+            a = b;
+        }
+    }
+
+    S.d_pool.reserve(pool.size());
+    S.d_tasks.reserve(nt + 1);
+    S.d_outs.reserve(nt + 1);
+    S.h_outs.reserve(nt + 1);
+    S.d_trace.reserve(max_tw + 2);
+    S.d_mink.reserve(max_mr + 2);
+    S.d_ops.reserve(ops_words + 2);
+    S.d_reads.reserve(nr);
+    S.d_piles.reserve(np);
+    S.d_read_pile.reserve(nr);
+    S.d_acc.reserve(acc_slots + 1);
+    S.d_tags.reserve(tag_slots + 1);
+    S.d_colidx.reserve(colidx_slots + 1);
+    S.d_cov.reserve(col_slots + 1);
+    S.d_inscnt.reserve(col_slots + 1);
+    S.d_insmax.reserve(col_slots + 1);
+    S.d_cellbase.reserve(col_slots + 1);
+    S.d_entbase.reserve(col_slots + 1);
+    S.d_err.reserve(4);
+
+    HIP_CHECK(hipMemcpyAsync(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (nt) HIP_CHECK(hipMemcpyAsync(S.d_tasks.p, tasks.data(), nt * sizeof(AlnTask), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.d_reads.p, reads.data(), nr * sizeof(ReadDev), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.d_read_pile.p, read_pile.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(S.d_cov.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
+    HIP_CHECK(hipMemsetAsync(S.d_inscnt.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
+    HIP_CHECK(hipMemsetAsync(S.d_insmax.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
+    HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
+
+    {
+        size_t a = 0;
+        for (size_t b : chunk_end) {
+            if (b > a) {
+                HIP_CHECK(hipEventRecord(S.evs[0], st));
+                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p,
+                                   (int)(b - a), st);
+                HIP_CHECK(hipEventRecord(S.evs[1], st));
+                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p,
+                                     S.d_ops.p, nullptr, (int)(b - a), st);
+                HIP_CHECK(hipEventRecord(S.evs[2], st));
+                HIP_CHECK(hipEventSynchronize(S.evs[2]));
+                float ms = 0;
+                HIP_CHECK(hipEventElapsedTime(&ms, S.evs[0], S.evs[1]));
+                S.stats.forward_ms += ms;
+                S.stats.forward_launches++;
+                HIP_CHECK(hipEventElapsedTime(&ms, S.evs[1], S.evs[2]));
+                S.stats.traceback_ms += ms;
+            }
+            a = b;
+        }
+    }
+    if (nt) {
+        HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, nt * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<int32_t> wide;
+        for (size_t i = 0; i < nt; i++) {
+            const AlnOut &o = S.h_outs.p[i];
+            S.stats.cells += (uint64_t)o.cells;
+            S.stats.d_steps += (uint64_t)o.d_steps;
+            if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
+            if (o.status == ST_NEED_WIDE) wide.push_back((int32_t)i);
+        }
+        if (!wide.empty()) run_wide(nullptr, nt, wide);
+        S.stats.tasks += nt;
+    }
+
+    HIP_CHECK(hipEventRecord(S.evs[0], st));
+    launch_shift_scan(S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_reads.p, (int)nr, st);
+    launch_pile_accept(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_cov.p, (int)np, st);
+    launch_make_tags(S.d_piles.p, S.d_reads.p, S.d_tasks.p, S.d_ops.p, S.d_pool.p, S.d_db.p, S.d_read_pile.p,
+                     S.d_tags.p, S.d_colidx.p, S.d_inscnt.p, S.d_insmax.p, (int)nr, st);
+    launch_col_scan(S.d_piles.p, S.d_cov.p, S.d_inscnt.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, (int)np, st);
+    HIP_CHECK(hipEventRecord(S.evs[1], st));
+    HIP_CHECK(hipMemcpyAsync(piles.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+
+    uint64_t cells = 0, ents = 0, paths = 0;
+    std::vector<ColBlock> blocks;
+    for (size_t p = 0; p < np; p++) {
+        PileDev &P = piles[p];
+        P.cell_off = cells;
+        P.ent_off = ents;
+        P.path_off = paths;
+        cells += P.n_cells;
+        ents += P.n_tags;
+        paths += P.n_cells / 6 + 1;
+        for (uint32_t c = 0; c < P.seed_len; c += kColBlock) blocks.push_back(ColBlock{(uint32_t)p, c});
+        S.stats.tags += P.n_tags;
+        S.stats.cells_msa += P.n_cells;
+    }
+    S.stats.piles += np;
+    S.d_cell_start.reserve(cells + 1);
+    S.d_cell_len.reserve(cells + 1);
+    S.d_cell_bpp.reserve(cells + 1);
+    S.d_cell_blink.reserve(cells + 1);
+    S.d_ent_pp.reserve(ents + 1);
+    S.d_ent_ppp.reserve(ents + 1);
+    S.d_ent_cnt.reserve(ents + 1);
+    S.d_ent_score.reserve(ents + 1);
+    S.d_path.reserve(paths + 1);
+    S.d_blocks.reserve(blocks.size() + 1);
+    HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.d_blocks.p, blocks.data(), blocks.size() * sizeof(ColBlock), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(S.d_cell_bpp.p, 0, (cells + 1) * sizeof(uint32_t), st));
+    HIP_CHECK(hipEventRecord(S.evs[2], st));
+    launch_count_links(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_blocks.p, S.d_tags.p, S.d_colidx.p, S.d_insmax.p,
+                       S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
+                       S.d_ent_cnt.p, S.d_err.p, (int)blocks.size(), st);
+    HIP_CHECK(hipEventRecord(S.evs[3], st));
+    launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_cell_start.p, S.d_cell_len.p,
+                           S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
+                           S.d_cell_blink.p, S.d_path.p, (int)np, st);
+    HIP_CHECK(hipEventRecord(S.evs[4], st));
+    std::vector<PathItem> hpath(paths + 1);
+    uint32_t herr[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(piles.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(hpath.data(), S.d_path.p, paths * sizeof(PathItem), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(herr, S.d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    if (herr[0]) {
+        fprintf(stderr, "[ndgpu] FATAL: more than %d distinct links in one MSA cell (device capacity)\n", kLinkCap);
+        abort();
+    }
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[0], S.evs[1]));
+    S.stats.tags_ms += ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[2], S.evs[3]));
+    S.stats.links_ms += ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[3], S.evs[4]));
+    S.stats.score_ms += ms;
+    for (size_t p = 0; p < np; p++) {
+        const PileDev &P = piles[p];
+        MainPile &M = *mp[p];
+        M.n_aligned = P.n_acc;
+        if (bad_pile[p]) continue;
+        M.path.resize(P.path_len);
+        const PathItem *src = hpath.data() + P.path_off;
+        for (uint32_t k = 0; k < P.path_len; k++) {
+            PathStep &d = M.path[k];
+            d.t_pos = tag_tpos(src[k].tag);
+            d.delta = (uint16_t)tag_delta(src[k].tag);
+            d.base = (uint8_t)tag_base(src[k].tag);
+            d.link = src[k].link;
+            d.cov = src[k].cov;
+        }
+        S.stats.path_items += P.path_len;
+    }
+}
+
+void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
+    State &S = *s_;
+    std::lock_guard<std::mutex> lock(S.mu);
+    HIP_CHECK(hipSetDevice(S.device));
+    hipStream_t st = S.stream;
+    std::vector<RegionDev> regs;
+    for (size_t i = 0; i < n; i++)
+        for (RegionReq &r : ep[i]->regions) {
+            RegionDev g;
+            memset(&g, 0, sizeof(g));
+            g.pile = (uint32_t)ep[i]->slot;
+            g.start = r.start;
+            g.end = r.end;
+            g.max_len = r.max_len;
+            regs.push_back(g);
+        }
+    if (regs.empty()) return;
+    S.d_regions.reserve(regs.size());
+    S.d_cursor.reserve(2);
+    size_t cap = std::max<size_t>(S.d_strpool.cap, (size_t)64 << 20);
+    std::vector<char> hstr;
+    for (;;) {
+        S.d_strpool.reserve(cap);
+        cap = S.d_strpool.cap;
+        HIP_CHECK(hipMemcpyAsync(S.d_regions.p, regs.data(), regs.size() * sizeof(RegionDev), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync(S.d_cursor.p, 0, sizeof(unsigned long long), st));
+        HIP_CHECK(hipEventRecord(S.evs[5], st));
+        launch_extract(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_tags.p, S.d_colidx.p, S.d_regions.p, S.d_strpool.p,
+                       S.d_cursor.p, (unsigned long long)cap, (int)regs.size(), st);
+        HIP_CHECK(hipEventRecord(S.evs[6], st));
+        unsigned long long used = 0;
+        HIP_CHECK(hipMemcpyAsync(&used, S.d_cursor.p, sizeof(used), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, S.evs[5], S.evs[6]));
+        S.stats.extract_ms += ms;
+        if (used <= cap) {
+            hstr.resize((size_t)used + 1);
+            HIP_CHECK(hipMemcpyAsync(regs.data(), S.d_regions.p, regs.size() * sizeof(RegionDev), hipMemcpyDeviceToHost, st));
+            if (used) HIP_CHECK(hipMemcpyAsync(hstr.data(), S.d_strpool.p, (size_t)used, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            break;
+        }
+        cap = (size_t)used + ((size_t)16 << 20);  // pool too small: rerun with the exact size
+    }
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++)
+        for (RegionReq &r : ep[i]->regions) {
+            const RegionDev &g = regs[k++];
+            r.n_large = g.n_large;
+            r.cands.resize(g.n_ok);
+            for (uint32_t c = 0; c < g.n_ok; c++) r.cands[c].assign(hstr.data() + g.cand_off[c], g.cand_len[c]);
+        }
+}
 
 }  // namespace ndgpu

@@ -1,0 +1,605 @@
+// Main-phase consensus kernels for gfx950 (wave64): everything between the O(ND)
+// traceback and the O(L) low-quality-region logic runs on the device, so neither the
+// alignment columns nor the ~10^6 tags of a pile ever cross PCIe.
+//
+// K8s shift_scan     get_align_shift(aln, 8)           lib/nextcorrect.c:102-154
+//     pile_accept    min_len_aln + coverage cut         lib/nextcorrect.c:2271,2289-2292
+// K8b make_tags      get_align_tags                     lib/nextcorrect.c:1485-1536
+//     col_scan       per-column coverage / max_size / cell and link offsets
+//                    (allocate_msa_mem, lib/nextcorrect.c:175-198)
+// K9  count_links    update_msa                         lib/nextcorrect.c:212-250
+// K10 score_backtrack scoring DP + global pick + best_pp walk
+//                                                        lib/nextcorrect.c:2149-2202, 1907-1982
+// K11 extract        candidate strings of low-quality regions
+//                                                        lib/nextcorrect.c:373-404
+//
+// Bit-exactness notes: a (column, delta) slot holds at most one tag per read, so the
+// reference's first-seen order of (pp,ppp) links inside a cell is the order of the
+// reads that carry them; K9 keeps lanes in pile order and elects link leaders with
+// ctz(ballot), which reproduces that order.  K10 keeps the reference's sequential
+// tie-break state per cell (one lane per base symbol).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "nd_device.h"
+
+namespace ndgpu {
+
+namespace {
+
+__device__ __forceinline__ uint32_t op_at(const uint32_t *__restrict__ W, uint32_t col) {
+    return (W[col >> 4] >> ((col & 15u) * 2u)) & 3u;
+}
+__device__ __forceinline__ uint32_t code_at(const uint32_t *__restrict__ pool, uint64_t off) {
+    return (pool[off >> 4] >> ((uint32_t)(off & 15u) * 2u)) & 3u;
+}
+// read-DB code (A0 C1 G2 T3, lib/bseq.c:11-20) -> consensus code (A0 T1 G2 C3, lib/nextcorrect.c:52-62)
+__device__ __forceinline__ uint32_t cns_code(uint32_t c) { return (0x1230u >> (c * 4u)) & 7u; }
+
+__device__ __forceinline__ unsigned long long lanes_le(int lane) {  // bits 0..lane
+    return lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+}
+
+// ---- K8s -------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void shift_scan_kernel(const AlnTask *__restrict__ tasks,
+                                                         const AlnOut *__restrict__ outs,
+                                                         const uint32_t *__restrict__ ops, ReadDev *__restrict__ reads,
+                                                         int n_reads) {
+    const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (i >= n_reads) return;
+    ReadDev &R = reads[i];
+    R.aln_len = 0;
+    R.accepted = 0;
+    if (R.task < 0) return;  // the seed: handled by pile_accept
+    const AlnOut o = outs[R.task];
+    if (o.status != ST_ALIGNED) return;
+    const AlnTask T = tasks[R.task];
+    const uint32_t *W = ops + T.ops_off;
+    const uint32_t n = (uint32_t)o.n_cols, c0 = T.ops_cap - n;
+    int run = 0;
+    uint32_t tc = 0, qc = 0, j;
+    bool found = false;
+    for (j = 0; j < n; j++) {
+        const uint32_t op = op_at(W, c0 + j);
+        run = op == 0 ? run + 1 : 0;
+        tc += op != 1u;
+        qc += op != 2u;
+        if (run == 8) {
+            found = true;
+            break;
+        }
+    }
+    if (!found) return;
+    const uint32_t shift = j - 7;
+    run = 0;
+    uint32_t tb = 0;
+    int jj;
+    for (jj = (int)n - 1; jj >= 0; jj--) {
+        const uint32_t op = op_at(W, c0 + (uint32_t)jj);
+        run = op == 0 ? run + 1 : 0;
+        tb += op != 1u;
+        if (run == 8) break;
+    }
+    R.shift = c0 + shift;  // absolute column inside the task's ops region
+    R.aln_len = (uint32_t)(jj + 7) - shift + 1;
+    R.t_s = R.aln_start + tc - 8;
+    R.t_e = R.aln_end - tb + 8;
+    R.q_start = qc - 8;
+}
+
+__global__ __launch_bounds__(64) void pile_accept_kernel(PileDev *__restrict__ piles, ReadDev *__restrict__ reads,
+                                                          uint32_t *__restrict__ acc_list,
+                                                          uint32_t *__restrict__ cov_diff, int n_piles) {
+    const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (i >= n_piles) return;
+    PileDev &P = piles[i];
+    int total = 0;
+    uint32_t nacc = 0, ntags = 0;
+    const int L = (int)P.seed_len;
+    for (uint32_t r = 0; r < P.n_reads; r++) {
+        if ((uint32_t)(total / L) > P.max_cov_aln) break;  // lib/nextcorrect.c:2271
+        ReadDev &R = reads[P.first_read + r];
+        if (r == 0) {  // the seed aligned to itself (lib/nextcorrect.c:2279-2282)
+            R.shift = 0;
+            R.aln_len = P.seed_len;
+            R.t_s = R.aln_start;
+            R.t_e = R.aln_end;
+            R.q_start = 0;
+        }
+        if (R.aln_len >= P.min_len_aln) {
+            total += (int)(R.t_e - R.t_s + 1);
+            R.accepted = 1;
+            acc_list[P.acc_off + nacc++] = P.first_read + r;
+            ntags += R.aln_len;
+            // coverage as a difference array: every accepted read has exactly one delta-0 tag
+            // on each column of [t_s, t_e]
+            atomicAdd(&cov_diff[P.col_off + R.t_s], 1u);
+            atomicAdd(&cov_diff[P.col_off + R.t_e + 1], 0xffffffffu);
+        }
+    }
+    P.n_acc = nacc;
+    P.n_tags = ntags;
+}
+
+// ---- K8b -------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void make_tags_kernel(const PileDev *__restrict__ piles,
+                                                        const ReadDev *__restrict__ reads,
+                                                        const AlnTask *__restrict__ tasks,
+                                                        const uint32_t *__restrict__ ops,
+                                                        const uint32_t *__restrict__ pool,
+                                                        const uint32_t *__restrict__ db_pool,
+                                                        const uint32_t *__restrict__ read_pile,
+                                                        uint32_t *__restrict__ tags, uint32_t *__restrict__ colidx,
+                                                        uint32_t *__restrict__ ins_count,
+                                                        uint32_t *__restrict__ ins_max) {
+    const int r = (int)blockIdx.x;
+    const ReadDev R = reads[r];
+    if (!R.accepted) return;
+    const PileDev P = piles[read_pile[r]];
+    const int lane = (int)threadIdx.x;
+    uint32_t *tg = tags + R.tag_off;
+    uint32_t *ci = colidx + R.colidx_off;
+    if (R.task < 0) {
+        const uint32_t *sp = (P.seed_off >> 63) ? db_pool : pool;
+        const uint64_t so = P.seed_off & kOffMask;
+        for (uint32_t t = (uint32_t)lane; t < R.aln_len; t += 64) {
+            tg[t] = tag_pack((int32_t)(R.t_s + t), 0, cns_code(code_at(sp, so + t)));
+            ci[t] = t;
+        }
+        return;
+    }
+    const AlnTask T = tasks[R.task];
+    const uint32_t *W = ops + T.ops_off;
+    const uint32_t *qp = (T.q_off >> 63) ? db_pool : pool;
+    const uint64_t qo = T.q_off & kOffMask;
+    uint32_t *icnt = ins_count + P.col_off;
+    uint32_t *imax = ins_max + P.col_off;
+    int32_t carry_t = (int32_t)R.t_s - 1;
+    uint32_t carry_delta = 0, carry_q = R.q_start;
+    for (uint32_t c0 = 0; c0 < R.aln_len; c0 += 64) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        const bool valid = c < R.aln_len;
+        const uint32_t op = valid ? op_at(W, R.shift + c) : 0u;
+        const bool is_t = valid && op != 1u, is_q = valid && op != 2u;
+        const unsigned long long mt = __ballot(is_t), mq = __ballot(is_q);
+        const unsigned long long le = lanes_le(lane);
+        const int32_t t_pos = carry_t + (int32_t)__popcll(mt & le);
+        const unsigned long long mm = mt & le;
+        const uint32_t delta = mm ? (uint32_t)(lane - (63 - __clzll((long long)mm))) : carry_delta + (uint32_t)lane + 1u;
+        const uint32_t qidx = carry_q + (uint32_t)__popcll(mq & (le >> 1));
+        if (valid) {
+            const uint32_t base = is_q ? cns_code(code_at(qp, qo + qidx)) : 4u;
+            tg[c] = tag_pack(t_pos, delta, base);
+            if (delta == 0) ci[(uint32_t)t_pos - R.t_s] = c;
+            else {
+                atomicAdd(&icnt[t_pos], 1u);
+                atomicMax(&imax[t_pos], delta + 1u);
+            }
+        }
+        const uint32_t nv = R.aln_len - c0 < 64u ? R.aln_len - c0 : 64u;
+        carry_delta = (uint32_t)__shfl((int)delta, (int)nv - 1, 64);
+        carry_t += (int32_t)__popcll(mt);
+        carry_q += (uint32_t)__popcll(mq);
+    }
+}
+
+// ---- column scan: coverage, max_size, cell/link offsets ------------------------------
+__global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ piles, uint32_t *__restrict__ cov_diff,
+                                                       const uint32_t *__restrict__ ins_count,
+                                                       uint32_t *__restrict__ ins_max, uint32_t *__restrict__ cell_base,
+                                                       uint32_t *__restrict__ ent_base) {
+    PileDev &P = piles[blockIdx.x];
+    const int lane = (int)threadIdx.x;
+    const uint32_t L = P.seed_len;
+    uint32_t *cov = cov_diff + P.col_off;       // in: difference array, out: coverage
+    const uint32_t *icnt = ins_count + P.col_off;
+    uint32_t *ms = ins_max + P.col_off;         // in: max(delta+1) of insertion tags, out: max_size
+    uint32_t *cb = cell_base + P.col_off;
+    uint32_t *eb = ent_base + P.col_off;
+    uint32_t run_cov = 0, run_cells = 0, run_ents = 0;
+    for (uint32_t t0 = 0; t0 < L; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        const bool v = t < L;
+        uint32_t c = v ? cov[t] : 0u;
+        // inclusive wave prefix sums
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)c, o, 64);
+            if (lane >= o) c += u;
+        }
+        c += run_cov;
+        uint32_t m = 0, e = 0;
+        if (v) {
+            m = c ? (ms[t] > 1u ? ms[t] : 1u) : 0u;
+            e = c + icnt[t];
+        }
+        uint32_t pc = m * 6u, pe = e;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u1 = (uint32_t)__shfl_up((int)pc, o, 64);
+            const uint32_t u2 = (uint32_t)__shfl_up((int)pe, o, 64);
+            if (lane >= o) {
+                pc += u1;
+                pe += u2;
+            }
+        }
+        if (v) {
+            cov[t] = c;
+            ms[t] = m;
+            cb[t] = run_cells + pc - m * 6u;
+            eb[t] = run_ents + pe - e;
+        }
+        run_cov = (uint32_t)__shfl((int)c, 63, 64);
+        run_cells += (uint32_t)__shfl((int)pc, 63, 64);
+        run_ents += (uint32_t)__shfl((int)pe, 63, 64);
+    }
+    if (lane == 0) {
+        cb[L] = run_cells;
+        eb[L] = run_ents;
+        P.n_cells = run_cells;
+    }
+}
+
+// ---- K9 --------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restrict__ piles,
+                                                          const ReadDev *__restrict__ reads,
+                                                          const uint32_t *__restrict__ acc_list,
+                                                          const ColBlock *__restrict__ blocks,
+                                                          const uint32_t *__restrict__ tags,
+                                                          const uint32_t *__restrict__ colidx,
+                                                          const uint32_t *__restrict__ max_size,
+                                                          const uint32_t *__restrict__ cell_base,
+                                                          const uint32_t *__restrict__ ent_base,
+                                                          uint32_t *__restrict__ cell_start,
+                                                          uint32_t *__restrict__ cell_len, uint32_t *__restrict__ ent_pp,
+                                                          uint32_t *__restrict__ ent_ppp, uint32_t *__restrict__ ent_cnt,
+                                                          uint32_t *__restrict__ err) {
+    __shared__ uint32_t l_pp[6][kLinkCap], l_ppp[6][kLinkCap], l_cnt[6][kLinkCap];
+    __shared__ uint32_t l_n[8];
+    const ColBlock B = blocks[blockIdx.x];
+    const PileDev P = piles[B.pile];
+    const int lane = (int)threadIdx.x;
+    const uint32_t *ms = max_size + P.col_off;
+    const uint32_t *cb = cell_base + P.col_off;
+    const uint32_t *eb = ent_base + P.col_off;
+    const uint32_t *acc = acc_list + P.acc_off;
+    const uint32_t t_end = B.col0 + kColBlock < P.seed_len ? B.col0 + kColBlock : P.seed_len;
+
+    for (uint32_t t = B.col0; t < t_end; t++) {
+        const uint32_t width = ms[t];
+        uint64_t e = P.ent_off + eb[t];
+        for (uint32_t d = 0; d < width; d++) {
+            if (lane < 6) l_n[lane] = 0;
+            __syncthreads();
+            for (uint32_t r0 = 0; r0 < P.n_acc; r0 += 64) {
+                const uint32_t rank = r0 + (uint32_t)lane;
+                bool has = false;
+                uint32_t cur = 0, pp = kTagHead, ppp = kTagHead;
+                if (rank < P.n_acc) {
+                    const ReadDev *R = &reads[acc[rank]];
+                    const uint32_t ts = R->t_s, te = R->t_e;
+                    if (t >= ts && t <= te) {
+                        const uint32_t *ci = colidx + R->colidx_off;
+                        const uint32_t i0 = ci[t - ts];
+                        const uint32_t nx = t == te ? R->aln_len : ci[t + 1 - ts];
+                        const uint32_t i = i0 + d;
+                        if (i < nx) {
+                            const uint32_t *tg = tags + R->tag_off;
+                            has = true;
+                            cur = tg[i];
+                            if (i > 0) pp = tg[i - 1];
+                            if (i > 1) ppp = tg[i - 2];
+                        }
+                    }
+                }
+                const uint32_t b = cur & 7u;
+                for (uint32_t bb = 0; bb < 6; bb++) {
+                    const bool mine = has && b == bb;
+                    if (!__ballot(mine)) continue;
+                    uint32_t n0 = l_n[bb];
+                    int found = -1;
+                    if (mine) {
+                        for (uint32_t j = 0; j < n0; j++)
+                            if (l_pp[bb][j] == pp && l_ppp[bb][j] == ppp) {
+                                found = (int)j;
+                                break;
+                            }
+                        if (found >= 0) atomicAdd(&l_cnt[bb][found], 1u);
+                    }
+                    unsigned long long rem = __ballot(mine && found < 0);
+                    while (rem) {
+                        const int ld = __ffsll((long long)rem) - 1;  // earliest read that carries a new link
+                        const uint32_t kp = (uint32_t)__shfl((int)pp, ld, 64);
+                        const uint32_t kpp = (uint32_t)__shfl((int)ppp, ld, 64);
+                        const bool in_rem = (rem >> lane) & 1ull;
+                        const unsigned long long same = __ballot(in_rem && pp == kp && ppp == kpp);
+                        if (lane == ld) {
+                            if (n0 < (uint32_t)kLinkCap) {
+                                l_pp[bb][n0] = pp;
+                                l_ppp[bb][n0] = ppp;
+                                l_cnt[bb][n0] = (uint32_t)__popcll(same);
+                            } else {
+                                atomicExch(err, 1u);
+                            }
+                        }
+                        n0 = n0 < (uint32_t)kLinkCap ? n0 + 1 : n0;
+                        rem &= ~same;
+                    }
+                    __syncthreads();
+                    if (lane == 0) l_n[bb] = n0;
+                    __syncthreads();
+                }
+            }
+            // flush the six cells of (t, d), links contiguous per cell in first-seen order
+            const uint64_t cell0 = P.cell_off + cb[t] + (uint64_t)d * 6u;
+            for (uint32_t bb = 0; bb < 6; bb++) {
+                const uint32_t n = l_n[bb];
+                if (lane == 0) {
+                    cell_start[cell0 + bb] = (uint32_t)(e - P.ent_off);
+                    cell_len[cell0 + bb] = n;
+                }
+                for (uint32_t j = (uint32_t)lane; j < n; j += 64) {
+                    ent_pp[e + j] = l_pp[bb][j];
+                    ent_ppp[e + j] = l_ppp[bb][j];
+                    ent_cnt[e + j] = l_cnt[bb][j];
+                }
+                e += n;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- K10 -------------------------------------------------------------------------
+__device__ __forceinline__ long long ld_score(const long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_score(long long *p, long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ long long shfl_i64(long long v, int src) {
+    const int lo = __shfl((int)(v & 0xffffffffll), src, 64);
+    const int hi = __shfl((int)(v >> 32), src, 64);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+__global__ __launch_bounds__(64) void score_backtrack_kernel(
+    PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
+    const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ cell_start,
+    const uint32_t *__restrict__ cell_len, const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp,
+    const uint32_t *__restrict__ ent_cnt, long long *__restrict__ ent_score, uint32_t *__restrict__ cell_best_pp,
+    uint32_t *__restrict__ cell_best_link, PathItem *__restrict__ path) {
+    PileDev &P = piles[blockIdx.x];
+    const int lane = (int)threadIdx.x;
+    const uint32_t b = (uint32_t)lane;
+    const bool act = lane < 5;  // symbols A T G C - (lib/nextcorrect.c:2151)
+    const uint32_t L = P.seed_len;
+    const uint32_t *cov = coverage + P.col_off;
+    const uint32_t *ms = max_size + P.col_off;
+    const uint32_t *cb = cell_base + P.col_off;
+    const uint32_t *cs = cell_start + P.cell_off;
+    const uint32_t *cl = cell_len + P.cell_off;
+    const uint32_t *epp = ent_pp + P.ent_off;
+    const uint32_t *eppp = ent_ppp + P.ent_off;
+    const uint32_t *ecnt = ent_cnt + P.ent_off;
+    long long *esc = ent_score + P.ent_off;
+    uint32_t *bpp_out = cell_best_pp + P.cell_off;
+    uint32_t *blk_out = cell_best_link + P.cell_off;
+    const long long factor = P.factor;
+
+    long long gbest = -10;
+    int32_t o_t = -1;
+    uint32_t o_db = 0;
+    for (uint32_t p = 0; p < L; p++) {
+        const uint32_t width = ms[p];
+        const long long pen = factor * (long long)cov[p];
+        for (uint32_t d = 0; d < width; d++) {
+            long long best = -10;
+            uint32_t bpp = kTagHead, blink = 0;
+            if (act) {
+                const uint32_t cell = cb[p] + d * 6u + b;
+                const uint32_t st = cs[cell], n = cl[cell];
+                long long via = LLONG_MIN, via_next = LLONG_MIN;
+                for (uint32_t m = 0; m < n; m++) {
+                    const uint32_t mpp = epp[st + m], mppp = eppp[st + m];
+                    const long long gain = 10ll * (long long)ecnt[st + m] - pen;
+                    long long sc = 0;
+                    if (mpp == kTagHead) {
+                        sc = gain;
+                    } else {
+                        const uint32_t pc = cb[tag_tpos(mpp)] + tag_delta(mpp) * 6u + tag_base(mpp);
+                        const uint32_t ps = cs[pc], pn = cl[pc];
+                        const uint32_t pb = tag_base(mpp);
+                        for (uint32_t k = 0; k < pn; k++) {
+                            if (epp[ps + k] != mppp) continue;
+                            const long long ns = ld_score(&esc[ps + k]);
+                            const long long s = ns + gain;
+                            if (s > sc) {
+                                sc = s;
+                                via_next = ns;
+                            }
+                            if (ns > via && (pb == 4u || pb == b)) {
+                                via = ns;
+                                best = sc;
+                                bpp = mpp;
+                                blink = ecnt[st + m];
+                            }
+                        }
+                    }
+                    st_score(&esc[st + m], sc);
+                    if (sc > best || (sc == best && tag_base(mpp) != 4u)) {
+                        via = via_next;
+                        best = sc;
+                        bpp = mpp;
+                        blink = ecnt[st + m];
+                    }
+                }
+                bpp_out[cell] = bpp;
+                blk_out[cell] = blink;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // scores of this (p,d) are in L2 before any later read
+            // global pick in symbol order (lib/nextcorrect.c:2194-2199)
+            for (int bb = 0; bb < 5; bb++) {
+                const long long v = shfl_i64(best, bb);
+                if (v >= gbest - 3000) {
+                    o_t = (int32_t)p;
+                    o_db = (d << 3) | (uint32_t)bb;
+                    if (v > gbest) gbest = v;
+                }
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) {
+        P.origin_t = o_t;
+        P.origin_db = o_db;
+        uint32_t len = 0;
+        int32_t t = o_t;
+        uint32_t db = o_db;
+        PathItem *out = path + P.path_off;
+        const uint32_t cap = P.n_cells / 6u;
+        while (t >= 0 && len < cap) {
+            const uint32_t cell = cb[t] + (db >> 3) * 6u + (db & 7u);
+            PathItem it;
+            it.tag = tag_pack(t, db >> 3, db & 7u);
+            it.link = (uint16_t)__hip_atomic_load(&blk_out[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            it.cov = (uint16_t)cov[t];
+            out[len++] = it;
+            const uint32_t g = __hip_atomic_load(&bpp_out[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == kTagHead) break;
+            t = tag_tpos(g);
+            db = g & 0x7ffu;
+        }
+        P.path_len = len;
+    }
+}
+
+// ---- K11 -------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void extract_kernel(const PileDev *__restrict__ piles,
+                                                      const ReadDev *__restrict__ reads,
+                                                      const uint32_t *__restrict__ acc_list,
+                                                      const uint32_t *__restrict__ tags,
+                                                      const uint32_t *__restrict__ colidx, RegionDev *__restrict__ regions,
+                                                      char *__restrict__ strpool, unsigned long long *__restrict__ cursor,
+                                                      unsigned long long cap) {
+    RegionDev &G = regions[blockIdx.x];
+    const PileDev P = piles[G.pile];
+    const int lane = (int)threadIdx.x;
+    const uint32_t *acc = acc_list + P.acc_off;
+    const uint32_t start = G.start, end = G.end, max_len = G.max_len;
+    uint32_t ok_total = 0, large = 0;
+    for (uint32_t r0 = 0; r0 < P.n_acc && ok_total < 40u; r0 += 64) {
+        const uint32_t rank = r0 + (uint32_t)lane;
+        int status = 0;  // 1: candidate, 2: longer than max_len - 1
+        uint32_t len = 0, i0 = 0, i1 = 0;
+        const uint32_t *tg = nullptr;
+        if (rank < P.n_acc) {
+            const ReadDev *R = &reads[acc[rank]];
+            if (R->t_s <= start && R->t_e >= end) {  // lib/nextcorrect.c:377
+                const uint32_t *ci = colidx + R->colidx_off;
+                tg = tags + R->tag_off;
+                i0 = ci[start - R->t_s];
+                i1 = end == R->t_e ? R->aln_len : ci[end + 1 - R->t_s];
+                for (uint32_t i = i0; i < i1; i++)
+                    if ((tg[i] & 7u) != 4u) {
+                        if (++len > max_len - 1u) {
+                            status = 2;
+                            break;
+                        }
+                    }
+                if (status != 2 && len > 0) status = 1;
+            }
+        }
+        unsigned long long okm = __ballot(status == 1), lgm = __ballot(status == 2);
+        const uint32_t need = 40u - ok_total;  // stop right after the 40th candidate (lib/nextcorrect.c:402)
+        const uint32_t my_rank = (uint32_t)__popcll(okm & lanes_le(lane));
+        if ((uint32_t)__popcll(okm) >= need) {
+            const unsigned long long cutm = __ballot(status == 1 && my_rank == need);
+            const int cut = __ffsll((long long)cutm) - 1;
+            okm &= lanes_le(cut);
+            lgm &= lanes_le(cut);
+        }
+        if (status == 1 && ((okm >> lane) & 1ull)) {
+            const uint32_t slot = ok_total + my_rank - 1u;
+            const unsigned long long off = atomicAdd(cursor, (unsigned long long)len);
+            G.cand_off[slot] = (uint32_t)off;
+            G.cand_len[slot] = (uint16_t)len;
+            if (off + len <= cap) {
+                uint32_t k = 0;
+                for (uint32_t i = i0; i < i1; i++) {
+                    const uint32_t bs = tg[i] & 7u;
+                    if (bs != 4u) strpool[off + k++] = "ATGC-NM"[bs];
+                }
+            }
+        }
+        ok_total += (uint32_t)__popcll(okm);
+        large += (uint32_t)__popcll(lgm);
+    }
+    if (lane == 0) {
+        G.n_ok = ok_total;
+        G.n_large = large;
+    }
+}
+
+}  // namespace
+
+void launch_shift_scan(const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops, ReadDev *reads, int n_reads,
+                       void *stream) {
+    if (n_reads <= 0) return;
+    hipLaunchKernelGGL(shift_scan_kernel, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, tasks,
+                       outs, ops, reads, n_reads);
+}
+
+void launch_pile_accept(PileDev *piles, ReadDev *reads, uint32_t *acc_list, uint32_t *cov_diff, int n_piles,
+                        void *stream) {
+    if (n_piles <= 0) return;
+    hipLaunchKernelGGL(pile_accept_kernel, dim3((unsigned)((n_piles + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       piles, reads, acc_list, cov_diff, n_piles);
+}
+
+void launch_make_tags(const PileDev *piles, const ReadDev *reads, const AlnTask *tasks, const uint32_t *ops,
+                      const uint32_t *pool, const uint32_t *db_pool, const uint32_t *read_pile, uint32_t *tags,
+                      uint32_t *colidx, uint32_t *ins_count, uint32_t *ins_max, int n_reads, void *stream) {
+    if (n_reads <= 0) return;
+    hipLaunchKernelGGL(make_tags_kernel, dim3((unsigned)n_reads), dim3(64), 0, (hipStream_t)stream, piles, reads, tasks,
+                       ops, pool, db_pool, read_pile, tags, colidx, ins_count, ins_max);
+}
+
+void launch_col_scan(PileDev *piles, uint32_t *cov_diff, const uint32_t *ins_count, uint32_t *ins_max,
+                     uint32_t *cell_base, uint32_t *ent_base, int n_piles, void *stream) {
+    if (n_piles <= 0) return;
+    hipLaunchKernelGGL(col_scan_kernel, dim3((unsigned)n_piles), dim3(64), 0, (hipStream_t)stream, piles, cov_diff,
+                       ins_count, ins_max, cell_base, ent_base);
+}
+
+void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const ColBlock *blocks,
+                        const uint32_t *tags, const uint32_t *colidx, const uint32_t *max_size,
+                        const uint32_t *cell_base, const uint32_t *ent_base, uint32_t *cell_start, uint32_t *cell_len,
+                        uint32_t *ent_pp, uint32_t *ent_ppp, uint32_t *ent_cnt, uint32_t *err, int n_blocks,
+                        void *stream) {
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(count_links_kernel, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, piles, reads,
+                       acc_list, blocks, tags, colidx, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp,
+                       ent_ppp, ent_cnt, err);
+}
+
+void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,
+                            const uint32_t *cell_base, const uint32_t *cell_start, const uint32_t *cell_len,
+                            const uint32_t *ent_pp, const uint32_t *ent_ppp, const uint32_t *ent_cnt,
+                            long long *ent_score, uint32_t *cell_best_pp, uint32_t *cell_best_link, PathItem *path,
+                            int n_piles, void *stream) {
+    if (n_piles <= 0) return;
+    hipLaunchKernelGGL(score_backtrack_kernel, dim3((unsigned)n_piles), dim3(64), 0, (hipStream_t)stream, piles,
+                       coverage, max_size, cell_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, ent_score,
+                       cell_best_pp, cell_best_link, path);
+}
+
+void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,
+                    const uint32_t *colidx, RegionDev *regions, char *strpool, unsigned long long *strpool_cursor,
+                    unsigned long long strpool_cap, int n_regions, void *stream) {
+    if (n_regions <= 0) return;
+    hipLaunchKernelGGL(extract_kernel, dim3((unsigned)n_regions), dim3(64), 0, (hipStream_t)stream, piles, reads,
+                       acc_list, tags, colidx, regions, strpool, strpool_cursor, strpool_cap);
+}
+
+}  // namespace ndgpu

@@ -46,6 +46,108 @@ struct AlnOut {
     int64_t cells;
 };
 
+// ---- main-phase consensus on the device (msa_kernels.hip) ---------------------------------
+// Packed alignment tag (reference: align_tag, lib/nextcorrect.h:28-32): t_pos+1 in bits
+// [31:11] (so the head sentinel t_pos=-1,delta=0,base=0 packs to 0), delta in [10:3]
+// (an insertion run is at most 251 columns, lib/align.c:542), base code in [2:0]
+// (A0 T1 G2 C3 -4, lib/nextcorrect.c:52-62).
+constexpr uint32_t kTagHead = 0u;
+__host__ __device__ inline uint32_t tag_pack(int32_t t_pos, uint32_t delta, uint32_t base) {
+    return ((uint32_t)(t_pos + 1) << 11) | (delta << 3) | base;
+}
+__host__ __device__ inline int32_t tag_tpos(uint32_t g) { return (int32_t)(g >> 11) - 1; }
+__host__ __device__ inline uint32_t tag_delta(uint32_t g) { return (g >> 3) & 0xffu; }
+__host__ __device__ inline uint32_t tag_base(uint32_t g) { return g & 7u; }
+
+struct ReadDev {            // one per pile record (index 0 of a pile = the seed itself)
+    int32_t task;           // index into the AlnTask/AlnOut tables, -1 for the seed
+    uint32_t aln_start;     // inclusive seed window as handed to nextCorrect
+    uint32_t aln_end;
+    uint64_t tag_off;       // first tag slot of this read (uint32 units)
+    uint64_t colidx_off;    // first column-index slot (uint32 units), capacity = window length
+    // filled on the device
+    uint32_t shift;         // first kept alignment column (get_align_shift)
+    uint32_t aln_len;       // kept columns (0: dropped)
+    uint32_t t_s, t_e;      // seed coordinates after trimming
+    uint32_t q_start;       // query offset of column `shift`
+    uint32_t accepted;      // passed min_len_aln and the coverage cut
+    uint32_t pad_;
+};
+
+struct PileDev {
+    uint32_t seed_len;
+    uint32_t n_reads;       // records incl. the seed
+    uint32_t first_read;    // index of the seed's ReadDev
+    uint32_t min_len_aln;
+    uint32_t max_cov_aln;
+    int32_t factor;         // 3 (ont/clr) or 4 (hifi)   lib/nextcorrect.c:2147
+    uint64_t seed_off;      // pool offset of the seed (bit 63: resident DB)
+    uint64_t col_off;       // first slot of the per-column arrays (seed_len + 1 slots per pile)
+    uint64_t acc_off;       // first slot of the accepted-read list (n_reads slots)
+    // filled on the device
+    uint32_t n_acc;         // accepted reads (incl. seed)
+    uint32_t n_cells;       // 6 * sum(max_size)
+    uint32_t n_tags;        // sum of kept columns = upper bound of link entries
+    uint32_t path_len;
+    // filled by the host between the two halves of the phase
+    uint64_t cell_off;      // first cell of this pile
+    uint64_t ent_off;       // first link entry of this pile
+    uint64_t path_off;      // first path slot (capacity n_cells / 6)
+    int32_t origin_t;       // backtrack origin written by the scoring kernel
+    uint32_t origin_db;     // delta << 3 | base
+    uint32_t err;           // nonzero: device-side capacity error
+    uint32_t pad_;
+};
+
+struct PathItem {           // one visited cell of the best_pp walk (origin first)
+    uint32_t tag;           // packed (t_pos, delta, base)
+    uint16_t link;          // best_link_count of the cell
+    uint16_t cov;           // coverage of the column
+};
+
+struct ColBlock {           // work item of the link-counting kernel
+    uint32_t pile;
+    uint32_t col0;
+};
+
+struct RegionDev {          // low-quality region whose candidate strings are wanted
+    uint32_t pile;
+    uint32_t start, end;    // inclusive seed columns
+    uint32_t max_len;       // lqseq_max_length
+    // outputs
+    uint32_t n_ok;          // candidates written (<= 40)
+    uint32_t n_large;       // reads that exceeded max_len before the 40th candidate
+    uint32_t cand_off[40];  // byte offsets into the string pool
+    uint16_t cand_len[40];
+};
+
+constexpr int kColBlock = 32;          // columns per link-counting work item
+constexpr int kLinkCap = 192;          // distinct (pp,ppp) links per cell held in LDS
+
+void launch_shift_scan(const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops, ReadDev *reads, int n_reads,
+                       void *stream);
+void launch_pile_accept(PileDev *piles, ReadDev *reads, uint32_t *acc_list, uint32_t *cov_diff, int n_piles,
+                        void *stream);
+void launch_make_tags(const PileDev *piles, const ReadDev *reads, const AlnTask *tasks, const uint32_t *ops,
+                      const uint32_t *pool, const uint32_t *db_pool, const uint32_t *read_pile, uint32_t *tags,
+                      uint32_t *colidx, uint32_t *ins_count, uint32_t *ins_max, int n_reads, void *stream);
+// in: cov_diff (difference array), ins_max; out (in place): coverage, max_size; plus offsets
+void launch_col_scan(PileDev *piles, uint32_t *cov_diff, const uint32_t *ins_count, uint32_t *ins_max,
+                     uint32_t *cell_base, uint32_t *ent_base, int n_piles, void *stream);
+void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const ColBlock *blocks,
+                        const uint32_t *tags, const uint32_t *colidx, const uint32_t *max_size,
+                        const uint32_t *cell_base, const uint32_t *ent_base, uint32_t *cell_start, uint32_t *cell_len,
+                        uint32_t *ent_pp, uint32_t *ent_ppp, uint32_t *ent_cnt, uint32_t *err, int n_blocks,
+                        void *stream);
+void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,
+                            const uint32_t *cell_base, const uint32_t *cell_start, const uint32_t *cell_len,
+                            const uint32_t *ent_pp, const uint32_t *ent_ppp, const uint32_t *ent_cnt,
+                            long long *ent_score, uint32_t *cell_best_pp, uint32_t *cell_best_link, PathItem *path,
+                            int n_piles, void *stream);
+void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,
+                    const uint32_t *colidx, RegionDev *regions, char *strpool, unsigned long long *strpool_cursor,
+                    unsigned long long strpool_cap, int n_regions, void *stream);
+
 constexpr uint64_t kOffDb = 1ull << 63;   // offset flag: sequence lives in the resident read DB
 constexpr uint64_t kOffMask = kOffDb - 1;
 

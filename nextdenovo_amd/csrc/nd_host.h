@@ -44,9 +44,59 @@ struct AlnJob {
     std::vector<uint8_t> ops;  // forward column kinds (empty unless ALN_OK)
 };
 
-// Backend that executes a batch of alignments (the HIP runtime in the product;
-// tests may plug the CPU oracle to exercise the host logic without a GPU).
-typedef void (*AlignBatchFn)(AlnJob **jobs, size_t n, void *ctx);
+// One visited cell of the main MSA's best_pp walk, origin first (device: PathItem).
+struct PathStep {
+    int32_t t_pos;
+    uint16_t delta;
+    uint8_t base;   // A0 T1 G2 C3 -4 N5 (lib/nextcorrect.c:52-62)
+    uint16_t link;  // best_link_count of the cell
+    uint16_t cov;   // coverage of the column
+};
+
+// Main-phase request of one pile: align every read to its seed window, build the MSA
+// link graph, score it and walk best_pp (lib/nextcorrect.c:2271-2293, 2130-2202).
+// Executed entirely on the device by the HIP backend.
+struct MainPile {
+    // inputs
+    unsigned n = 0;                      // records, [0] = the seed
+    const char *const *seqs = nullptr;   // ASCII sequences, or nullptr when dev_off is used
+    const unsigned *seq_len = nullptr;
+    const unsigned *aln_start = nullptr;
+    const unsigned *aln_end = nullptr;
+    const int64_t *dev_off = nullptr;    // ReadDb pool offsets of seqs[i][0], or nullptr
+    unsigned min_len_aln = 500, max_cov_aln = 130;
+    int factor = 3;
+    int hq = 0;
+    // outputs
+    std::vector<PathStep> path;
+    unsigned n_aligned = 0;              // reads that entered the MSA (incl. the seed)
+    int slot = -1;                       // backend-private handle, valid until end_batch()
+};
+
+// Candidate strings of one low-quality region (lib/nextcorrect.c:373-404).
+struct RegionReq {
+    unsigned start = 0, end = 0;         // inclusive seed columns
+    unsigned max_len = 0;                // lqseq_max_length
+    std::vector<std::string> cands;      // <= 40, in pile order
+    unsigned n_large = 0;                // reads longer than max_len - 1 seen before the 40th candidate
+};
+
+struct ExtractPile {
+    int slot = -1;
+    std::vector<RegionReq> regions;
+};
+
+// Executes the device-side work of a batch of piles.  The product has exactly one
+// implementation (HipBackend, device_runtime.hip); tests plug the CPU oracle here to
+// exercise the host logic without a GPU.
+class Backend {
+  public:
+    virtual ~Backend() {}
+    virtual void run_main(MainPile **piles, size_t n) = 0;
+    virtual void run_extract(ExtractPile **piles, size_t n) = 0;
+    virtual void run_align(AlnJob **jobs, size_t n) = 0;
+    virtual void end_batch() = 0;  // releases whatever run_main kept for run_extract
+};
 
 struct CorrectParams {
     unsigned max_mem_len = 0;
@@ -64,26 +114,36 @@ std::string poa_consensus(const std::vector<std::string> &seqs);
 
 class PileImpl;
 
-// Per-seed consensus state machine.  Alignment work is exposed as batches of
-// AlnJob so that many piles can share one device launch:
-//     while (!done()) { collect_jobs(v); <run v on the device>; advance(); }
+// Per-seed consensus state machine.  Device work is exposed as requests so that many
+// piles share each launch:
+//     MAIN (MainPile) -> EXTRACT (ExtractPile) -> LQ round 1 (AlnJob) -> LQ round 2 -> DONE
 class PileEngine {
   public:
-    // dev_off (optional, seq_count entries): ReadDb pool offset of seqs[i][0], or -1
+    enum Phase { MAIN = 0, EXTRACT = 1, LQ_ROUND = 2, DONE = 3 };
+    // ASCII form (the nextCorrect ABI): seqs[i] NUL-terminated.
     PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
-               const CorrectParams &prm, const int64_t *dev_off = nullptr);
+               const CorrectParams &prm);
+    // Resident-DB form: only lengths and ReadDb pool offsets, no host copy of the reads.
+    PileEngine(const unsigned *seq_len, const int64_t *dev_off, const unsigned *aln_start, const unsigned *aln_end,
+               unsigned seq_count, const CorrectParams &prm);
     ~PileEngine();
     PileEngine(const PileEngine &) = delete;
     PileEngine &operator=(const PileEngine &) = delete;
 
-    bool done() const;
-    void collect_jobs(std::vector<AlnJob *> &out);
-    void advance();
+    Phase phase() const;
+    bool done() const { return phase() == DONE; }
+    MainPile *main_request();        // valid in MAIN
+    ExtractPile *extract_request();  // valid in EXTRACT
+    void collect_jobs(std::vector<AlnJob *> &out);  // LQ_ROUND
+    void advance();                  // consume the finished request(s), move on
     ConsensusTrimed *take_result();  // malloc'd, caller frees with free_consensus_trimed
 
   private:
     PileImpl *impl_;
 };
+
+// Drives a set of engines to completion over one backend (host phases on `threads`).
+void run_engines(PileEngine **eng, size_t n, Backend &be, int threads);
 
 ConsensusTrimed *make_error_seed(unsigned len);
 

@@ -23,12 +23,27 @@ struct RuntimeStats {
     uint32_t max_band = 0;
     uint32_t forward_launches = 0;
     double forward_ms = 0;         // HIP-event time of the forward kernel launches
+    double traceback_ms = 0;       // K8a
+    double tags_ms = 0;            // K8s + accept + K8b + column scan
+    double links_ms = 0;           // K9
+    double score_ms = 0;           // K10 (+ backtrack)
+    double extract_ms = 0;         // K11
+    uint64_t piles = 0;            // piles through the device main phase
+    uint64_t tags = 0;             // alignment tags generated on the device
+    uint64_t cells_msa = 0;        // MSA cells
+    uint64_t path_items = 0;
 };
 
 class DeviceAligner {
   public:
     static DeviceAligner &instance();
     void align_batch(AlnJob **jobs, size_t n);
+    // device main phase / candidate extraction of a batch of piles (see Backend in nd_host.h);
+    // begin_batch()/end_batch() bracket one batch and serialise batches of one process
+    void begin_batch();
+    void run_main(MainPile **piles, size_t n);
+    void run_extract(ExtractPile **piles, size_t n);
+    void end_batch();
     // upload (or replace) the resident read DB pool; AlnJob::q_dev/t_dev index into it
     void set_db(const uint32_t *pool_words, size_t n_words);
     void *stream() const;
@@ -44,7 +59,22 @@ class DeviceAligner {
     State *s_;
 };
 
-// AlignBatchFn-compatible entry
-void hip_align_backend(AlnJob **jobs, size_t n, void *ctx);
+// The product's only Backend: every request runs in HIP kernels on the device.
+class HipBackend : public Backend {
+  public:
+    HipBackend() { DeviceAligner::instance().begin_batch(); }
+    ~HipBackend() override { finish(); }
+    void run_main(MainPile **piles, size_t n) override { DeviceAligner::instance().run_main(piles, n); }
+    void run_extract(ExtractPile **piles, size_t n) override { DeviceAligner::instance().run_extract(piles, n); }
+    void run_align(AlnJob **jobs, size_t n) override { DeviceAligner::instance().align_batch(jobs, n); }
+    void end_batch() override { finish(); }
+
+  private:
+    void finish() {
+        if (open_) DeviceAligner::instance().end_batch();
+        open_ = false;
+    }
+    bool open_ = true;
+};
 
 }  // namespace ndgpu

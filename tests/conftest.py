@@ -43,7 +43,7 @@ def host_harness():
             os.path.join(csrc, "poa.cpp"), os.path.join(csrc, "readdb.cpp"), os.path.join(csrc, "nd_host.h"),
             os.path.join(ROOT, "oracle", "ond_oracle.c"), os.path.join(ROOT, "oracle", "msa_oracle.c")]
     if _stale(so, srcs):
-        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", so] + [s for s in srcs if not s.endswith(".h")]
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-o", so] + [s for s in srcs if not s.endswith(".h")]
         subprocess.run(cmd, check=True)
     return C.CDLL(so)
 

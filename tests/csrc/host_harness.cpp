@@ -1,8 +1,9 @@
 // tests/csrc/host_harness.cpp -- TEST-ONLY glue.
 // Runs the product's host-side consensus engine (nextdenovo_amd/csrc/consensus.cpp,
-// poa.cpp) with the CPU oracle (oracle/ond_oracle.c) plugged in as the alignment
-// backend, so that `pytest -m "not gpu"` can check the host logic against the
-// reference without a GPU.  The shipped library never links the oracle.
+// poa.cpp) over a CPU Backend built from the oracle (oracle/ond_oracle.c,
+// oracle/msa_oracle.c), so that `pytest -m "not gpu"` can check the host logic against
+// the reference without a GPU.  The shipped library never links the oracle; its only
+// Backend is HipBackend.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -12,21 +13,124 @@
 
 using namespace ndgpu;
 
-static void oracle_backend(AlnJob **jobs, size_t n, void *) {
-    for (size_t i = 0; i < n; i++) {
-        AlnJob &j = *jobs[i];
-        nd_oracle_aln r;
-        std::vector<uint8_t> ops((size_t)j.q_len + j.t_len + 1);
-        nd_oracle_align(j.q, j.q_len, j.t, j.t_len, j.hq, &r, nullptr, nullptr, ops.data());
-        j.status = r.status;
-        j.q_used = r.q_used;
-        j.t_used = r.t_used;
-        if (r.status == 1) {
-            ops.resize((size_t)r.aln_len);
-            j.ops.swap(ops);
-        } else j.ops.clear();
+namespace {
+
+uint8_t base_code(char c) {  // lib/nextcorrect.c:52-62
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'T': case 't': return 1;
+        case 'G': case 'g': return 2;
+        case 'C': case 'c': return 3;
+        case 'N': return 5;
+        case 'M': return 6;
+        default: return 4;
     }
 }
+
+class OracleBackend : public Backend {
+  public:
+    std::vector<std::vector<std::vector<nd_oracle_tag>>> kept;  // [slot][read] tags
+
+    void run_align(AlnJob **jobs, size_t n) override {
+        for (size_t i = 0; i < n; i++) {
+            AlnJob &j = *jobs[i];
+            nd_oracle_aln r;
+            std::vector<uint8_t> ops((size_t)j.q_len + j.t_len + 1);
+            nd_oracle_align(j.q, j.q_len, j.t, j.t_len, j.hq, &r, nullptr, nullptr, ops.data());
+            j.status = r.status;
+            j.q_used = r.q_used;
+            j.t_used = r.t_used;
+            if (r.status == 1) {
+                ops.resize((size_t)r.aln_len);
+                j.ops.swap(ops);
+            } else j.ops.clear();
+        }
+    }
+
+    void run_main(MainPile **piles, size_t n) override {
+        kept.clear();
+        kept.resize(n);
+        for (size_t p = 0; p < n; p++) {
+            MainPile &M = *piles[p];
+            M.slot = (int)p;
+            M.path.clear();
+            const int L = (int)M.aln_end[0] + 1;
+            std::vector<std::vector<nd_oracle_tag>> &reads = kept[p];
+            int total = 0;
+            for (unsigned i = 0; i < M.n && (unsigned)(total / L) <= M.max_cov_aln; i++) {
+                std::vector<nd_oracle_tag> tags;
+                if (i == 0) {
+                    if (M.seq_len[0] < M.min_len_aln) continue;
+                    total += (int)(M.aln_end[0] - M.aln_start[0] + 1);
+                    for (unsigned t = 0; t < M.seq_len[0]; t++)
+                        tags.push_back(nd_oracle_tag{(int32_t)(M.aln_start[0] + t), 0, base_code(M.seqs[0][t])});
+                } else {
+                    const char *q = M.seqs[i];
+                    const int ql = (int)M.seq_len[i];
+                    const char *t = M.seqs[0] + M.aln_start[i];
+                    const int tl = (int)(M.aln_end[i] - M.aln_start[i] + 1);
+                    nd_oracle_aln r;
+                    std::vector<uint8_t> ops((size_t)ql + tl + 1);
+                    nd_oracle_align(q, ql, t, tl, M.hq, &r, nullptr, nullptr, ops.data());
+                    if (r.status != 1) continue;
+                    unsigned ts = M.aln_start[i], te = M.aln_end[i];
+                    int shift = 0;
+                    const int len = nd_oracle_shift(ops.data(), r.aln_len, 8, &ts, &te, &shift);
+                    if ((unsigned)len < M.min_len_aln || len == 0) continue;
+                    total += (int)(te - ts + 1);
+                    int qi = 0;
+                    for (int c = 0; c < shift; c++) qi += ops[c] != 2;
+                    int32_t tp = (int32_t)ts - 1;
+                    uint16_t delta = 0;
+                    for (int c = 0; c < len; c++) {
+                        const uint8_t op = ops[shift + c];
+                        if (op != 1) { tp++; delta = 0; }
+                        tags.push_back(nd_oracle_tag{tp, delta++, op == 2 ? (uint8_t)4 : base_code(q[qi++])});
+                    }
+                }
+                reads.push_back(std::move(tags));
+            }
+            M.n_aligned = (unsigned)reads.size();
+            std::vector<const nd_oracle_tag *> ptr;
+            std::vector<uint32_t> len;
+            size_t cap = 16;
+            for (auto &r : reads) { ptr.push_back(r.data()); len.push_back((uint32_t)r.size()); cap += r.size(); }
+            std::vector<nd_oracle_path> path(cap);
+            const long np = reads.empty() ? 0 : nd_oracle_msa_path(ptr.data(), len.data(), (int)reads.size(), L, M.factor,
+                                                                   path.data(), (long)cap);
+            for (long k = 0; k < np; k++)
+                M.path.push_back(PathStep{path[k].t_pos, path[k].delta, path[k].base, path[k].link_count, path[k].coverage});
+        }
+    }
+
+    void run_extract(ExtractPile **piles, size_t n) override {
+        static const char kI2B[] = "ATGC-NM";
+        for (size_t p = 0; p < n; p++) {
+            const auto &reads = kept[piles[p]->slot];
+            for (RegionReq &rq : piles[p]->regions) {
+                rq.cands.clear();
+                rq.n_large = 0;
+                const int start = (int)rq.start, end = (int)rq.end;
+                for (const auto &tg : reads) {  // lib/nextcorrect.c:373-404
+                    if (!(tg.front().t_pos <= start && tg.back().t_pos >= end)) continue;
+                    std::string s;
+                    bool too_long = false;
+                    for (size_t k = (size_t)(start - tg.front().t_pos); k < tg.size() && tg[k].t_pos <= end; k++)
+                        if (tg[k].t_pos >= start && tg[k].base != 4) {
+                            s.push_back(kI2B[tg[k].base]);
+                            if (s.size() > rq.max_len - 1) { rq.n_large++; too_long = true; break; }
+                        }
+                    if (!s.empty() && !too_long) rq.cands.push_back(std::move(s));
+                    if (rq.cands.size() >= 40) break;
+                }
+            }
+        }
+    }
+
+    void end_batch() override { kept.clear(); }
+};
+
+}  // namespace
 
 extern "C" ConsensusTrimed *ndtest_correct(char **seqs, unsigned *aln_start, unsigned *aln_end, unsigned seq_count,
                                            unsigned max_mem_len, unsigned min_len_aln, unsigned max_cov_aln,
@@ -37,13 +141,9 @@ extern "C" ConsensusTrimed *ndtest_correct(char **seqs, unsigned *aln_start, uns
     p.lqseq_max_length = lqseq_max_length; p.min_error_corrected_ratio = ratio; p.split = split; p.fast = fast;
     p.read_type = read_type;
     PileEngine eng(seqs, aln_start, aln_end, seq_count, p);
-    std::vector<AlnJob *> jobs;
-    while (!eng.done()) {
-        jobs.clear();
-        eng.collect_jobs(jobs);
-        oracle_backend(jobs.data(), jobs.size(), nullptr);
-        eng.advance();
-    }
+    PileEngine *ep = &eng;
+    OracleBackend be;
+    run_engines(&ep, 1, be, 1);
     return eng.take_result();
 }
 
