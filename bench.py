@@ -199,7 +199,10 @@ def main():
                          "frac": achieved / peak, "traffic": None,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": int(launches),
                          "cells_per_s": st["cells"] / (st["forward_ms"] * 1e-3) if st["forward_ms"] > 0 else 0.0},
-            "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "columns", "max_band")},
+            "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "max_band", "piles", "tags",
+                                            "cells_msa", "path_items")},
+            "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
+                                                       "extract_ms")},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, piles, read_type, args.cpu_sample)

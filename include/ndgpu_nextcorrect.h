@@ -111,7 +111,9 @@ int ndgpu_correct_piles(ndgpu_db *db, int n_piles, const uint32_t *recs, const u
 typedef struct {
     uint64_t tasks, wide_tasks, cells, d_steps, trace_bits, columns, pool_bases, seq_bases;
     uint32_t max_band, forward_launches;
-    double forward_ms;
+    double forward_ms;      /* HIP-event time of K7 (O(ND) forward) launches */
+    double traceback_ms, tags_ms, links_ms, score_ms, extract_ms;
+    uint64_t piles, tags, cells_msa, path_items;
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

@@ -19,7 +19,10 @@ class ConsensusTrimed(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("tasks", C.c_uint64), ("wide_tasks", C.c_uint64), ("cells", C.c_uint64), ("d_steps", C.c_uint64),
                 ("trace_bits", C.c_uint64), ("columns", C.c_uint64), ("pool_bases", C.c_uint64), ("seq_bases", C.c_uint64),
-                ("max_band", C.c_uint32), ("forward_launches", C.c_uint32), ("forward_ms", C.c_double)]
+                ("max_band", C.c_uint32), ("forward_launches", C.c_uint32), ("forward_ms", C.c_double),
+                ("traceback_ms", C.c_double), ("tags_ms", C.c_double), ("links_ms", C.c_double),
+                ("score_ms", C.c_double), ("extract_ms", C.c_double), ("piles", C.c_uint64), ("tags", C.c_uint64),
+                ("cells_msa", C.c_uint64), ("path_items", C.c_uint64)]
 
 
 def lib_path() -> str:

@@ -163,38 +163,61 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     const ReadDb &db = *h->db;
     size_t sub = 512;
     if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
-    for (size_t base = 0; base < (size_t)n_piles; base += sub) {
-        const size_t cnt = std::min(sub, (size_t)n_piles - base);
-        std::vector<PileEngine *> eng(cnt, nullptr);
-        parallel_for(cnt, host_threads, [&](size_t k) {
-            const uint64_t r0 = pile_off[base + k], r1 = pile_off[base + k + 1];
-            const size_t n = (size_t)(r1 - r0);
-            std::vector<unsigned> st(n), en(n), len(n);
-            std::vector<int64_t> dev(n);
-            unsigned max_aln = n ? recs[r0 * 8 + 3] + 1 : 0;
-            for (size_t i = 0; i < n; i++) {
-                const uint32_t *r = recs + (r0 + i) * 8;
-                dev[i] = db.window_offset(r[4], r[5], r[6], (int)r[1]);
-                len[i] = r[6] - r[5] + 1;
-                st[i] = r[2];
-                en[i] = r[3];
-                const unsigned v = r[3] - r[2] + r[6] - r[5] + 2;
-                if (v > max_aln && r[0] != r[4]) max_aln = v;
+    // longest seeds first: the scoring DP is a sequential chain per seed, so similar lengths
+    // share a launch and the long chains start early
+    std::vector<uint32_t> order((size_t)n_piles);
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return recs[pile_off[a] * 8 + 3] > recs[pile_off[b] * 8 + 3];
+    });
+    int drivers = DeviceAligner::kMaxContexts;
+    if (const char *e = getenv("NDGPU_CONTEXTS")) drivers = std::max(1, std::min(atoi(e), (int)DeviceAligner::kMaxContexts));
+    const size_t n_sub = ((size_t)n_piles + sub - 1) / sub;
+    drivers = (int)std::min<size_t>((size_t)drivers, n_sub);
+    const int threads_each = std::max(1, host_threads / drivers);
+    std::atomic<size_t> next_sub(0);
+    auto drive = [&](int ctx) {
+        for (;;) {
+            const size_t sb = next_sub.fetch_add(1);
+            if (sb >= n_sub) break;
+            const size_t base = sb * sub;
+            const size_t cnt = std::min(sub, (size_t)n_piles - base);
+            std::vector<PileEngine *> eng(cnt, nullptr);
+            parallel_for(cnt, threads_each, [&](size_t k) {
+                const uint32_t pid = order[base + k];
+                const uint64_t r0 = pile_off[pid], r1 = pile_off[pid + 1];
+                const size_t n = (size_t)(r1 - r0);
+                std::vector<unsigned> st(n), en(n), len(n);
+                std::vector<int64_t> dev(n);
+                unsigned max_aln = n ? recs[r0 * 8 + 3] + 1 : 0;
+                for (size_t i = 0; i < n; i++) {
+                    const uint32_t *r = recs + (r0 + i) * 8;
+                    dev[i] = db.window_offset(r[4], r[5], r[6], (int)r[1]);
+                    len[i] = r[6] - r[5] + 1;
+                    st[i] = r[2];
+                    en[i] = r[3];
+                    const unsigned v = r[3] - r[2] + r[6] - r[5] + 2;
+                    if (v > max_aln && r[0] != r[4]) max_aln = v;
+                }
+                const unsigned lq = n ? std::min<unsigned>(en[0] / 2, max_lq_length) : max_lq_length;
+                eng[k] = new PileEngine(len.data(), dev.data(), st.data(), en.data(), (unsigned)n,
+                                        make_params(max_aln, min_len_aln, max_cov_aln, min_cov, lq,
+                                                    min_error_corrected_ratio, split, fast, read_type));
+            });
+            {
+                HipBackend be(ctx);
+                run_engines(eng.data(), cnt, be, threads_each);
             }
-            const unsigned lq = n ? std::min<unsigned>(en[0] / 2, max_lq_length) : max_lq_length;
-            eng[k] = new PileEngine(len.data(), dev.data(), st.data(), en.data(), (unsigned)n,
-                                    make_params(max_aln, min_len_aln, max_cov_aln, min_cov, lq,
-                                                min_error_corrected_ratio, split, fast, read_type));
-        });
-        {
-            HipBackend be;
-            run_engines(eng.data(), cnt, be, host_threads);
+            for (size_t k = 0; k < cnt; k++) {
+                out[order[base + k]] = (consensus_trimed *)eng[k]->take_result();
+                delete eng[k];
+            }
         }
-        for (size_t k = 0; k < cnt; k++) {
-            out[base + k] = (consensus_trimed *)eng[k]->take_result();
-            delete eng[k];
-        }
-    }
+    };
+    std::vector<std::thread> th;
+    for (int c = 1; c < drivers; c++) th.emplace_back(drive, c);
+    drive(0);
+    for (auto &t : th) t.join();
     return 0;
 }
 
@@ -268,7 +291,7 @@ char *poa_to_consensus(const void *seqs, const int seq_count) {
 }
 
 void ndgpu_get_stats(ndgpu_stats *o) {
-    RuntimeStats s = DeviceAligner::instance().stats();
+    RuntimeStats s = DeviceAligner::total_stats();
     o->tasks = s.tasks;
     o->wide_tasks = s.wide_tasks;
     o->cells = s.cells;
@@ -280,9 +303,18 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->max_band = s.max_band;
     o->forward_launches = s.forward_launches;
     o->forward_ms = s.forward_ms;
+    o->traceback_ms = s.traceback_ms;
+    o->tags_ms = s.tags_ms;
+    o->links_ms = s.links_ms;
+    o->score_ms = s.score_ms;
+    o->extract_ms = s.extract_ms;
+    o->piles = s.piles;
+    o->tags = s.tags;
+    o->cells_msa = s.cells_msa;
+    o->path_items = s.path_items;
 }
 
-void ndgpu_reset_stats(void) { DeviceAligner::instance().reset_stats(); }
+void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }
 
 int ndgpu_device_count(void) {
     int n = 0;

@@ -109,11 +109,16 @@ bool pack_append(std::vector<uint32_t> &pool, const char *s, size_t n) {
 
 }  // namespace
 
+// one resident read DB per process, shared by every context
+static uint32_t *g_db_pool = nullptr;
+static size_t g_db_cap = 0;
+static std::mutex g_db_mu;
+
 struct DeviceAligner::State {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    DevBuf<uint32_t> d_pool, d_ops, d_db;
+    DevBuf<uint32_t> d_pool, d_ops;
     DevBuf<AlnTask> d_tasks;
     DevBuf<AlnOut> d_outs;
     DevBuf<uint64_t> d_trace;
@@ -161,23 +166,55 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     for (auto &e : s_->evs) HIP_CHECK(hipEventCreate(&e));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)8 << 30))
-        s_->trace_budget_bytes = free_b / 3;
+        s_->trace_budget_bytes = free_b / (3 * kMaxContexts);
     else s_->trace_budget_bytes = (size_t)2 << 30;
 }
 
 DeviceAligner::~DeviceAligner() { delete s_; }
 
-DeviceAligner &DeviceAligner::instance() {
-    static DeviceAligner *g = new DeviceAligner();  // intentionally leaked: no HIP calls at exit
-    return *g;
+DeviceAligner &DeviceAligner::context(int i) {
+    // intentionally leaked: no HIP calls at exit.  Contexts own a stream + buffer set each, so
+    // batches driven from different host threads overlap on the device.
+    static DeviceAligner *g[kMaxContexts] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    i = i < 0 ? 0 : i % kMaxContexts;
+    if (!g[i]) g[i] = new DeviceAligner();
+    return *g[i];
+}
+
+DeviceAligner &DeviceAligner::instance() { return context(0); }
+
+RuntimeStats DeviceAligner::total_stats() {
+    RuntimeStats t;
+    for (int i = 0; i < kMaxContexts; i++) {
+        DeviceAligner &c = context(i);
+        const RuntimeStats &s = c.s_->stats;
+        t.tasks += s.tasks; t.wide_tasks += s.wide_tasks; t.cells += s.cells; t.d_steps += s.d_steps;
+        t.trace_bits += s.trace_bits; t.columns += s.columns; t.pool_bases += s.pool_bases; t.seq_bases += s.seq_bases;
+        t.max_band = s.max_band > t.max_band ? s.max_band : t.max_band;
+        t.forward_launches += s.forward_launches; t.forward_ms += s.forward_ms; t.traceback_ms += s.traceback_ms;
+        t.tags_ms += s.tags_ms; t.links_ms += s.links_ms; t.score_ms += s.score_ms; t.extract_ms += s.extract_ms;
+        t.piles += s.piles; t.tags += s.tags; t.cells_msa += s.cells_msa; t.path_items += s.path_items;
+    }
+    return t;
+}
+
+void DeviceAligner::reset_all_stats() {
+    for (int i = 0; i < kMaxContexts; i++) context(i).reset_stats();
 }
 
 void DeviceAligner::set_db(const uint32_t *pool_words, size_t n_words) {
     std::lock_guard<std::mutex> lock(s_->mu);
     HIP_CHECK(hipSetDevice(s_->device));
-    s_->d_db.reserve(n_words + 2);
-    HIP_CHECK(hipMemcpy(s_->d_db.p, pool_words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemset(s_->d_db.p + n_words, 0, 2 * sizeof(uint32_t)));
+    std::lock_guard<std::mutex> dbl(g_db_mu);
+    if (n_words + 2 > g_db_cap) {
+        if (g_db_pool) HIP_CHECK(hipFree(g_db_pool));
+        HIP_CHECK(hipMalloc((void **)&g_db_pool, (n_words + 2) * sizeof(uint32_t)));
+        g_db_cap = n_words + 2;
+    }
+    HIP_CHECK(hipMemcpy(g_db_pool, pool_words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(g_db_pool + n_words, 0, 2 * sizeof(uint32_t)));
 }
 
 void *DeviceAligner::stream() const { return s_->stream; }
@@ -288,9 +325,9 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     HIP_CHECK(hipMemcpyAsync(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipEventRecord(S.ev0, st));
-    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p, (int)n, st);
+    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p, (int)n, st);
     HIP_CHECK(hipEventRecord(S.ev1, st));
-    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
+    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, n * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(S.h_ops.p, S.d_ops.p, ops_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -392,8 +429,8 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
                                      hipMemcpyHostToDevice, st));
         }
         HIP_CHECK(hipMemcpyAsync(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
-        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.d_db.p, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
+        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
+        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
         HIP_CHECK(hipStreamSynchronize(st));
         for (size_t i = 0; i < take; i++) {
             const int32_t id = ids[at + i];
@@ -570,10 +607,10 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         for (size_t b : chunk_end) {
             if (b > a) {
                 HIP_CHECK(hipEventRecord(S.evs[0], st));
-                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p,
+                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p,
                                    (int)(b - a), st);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
-                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.d_db.p, S.d_trace.p, S.d_mink.p,
+                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p,
                                      S.d_ops.p, nullptr, (int)(b - a), st);
                 HIP_CHECK(hipEventRecord(S.evs[2], st));
                 HIP_CHECK(hipEventSynchronize(S.evs[2]));
@@ -605,7 +642,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     HIP_CHECK(hipEventRecord(S.evs[0], st));
     launch_shift_scan(S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_reads.p, (int)nr, st);
     launch_pile_accept(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_cov.p, (int)np, st);
-    launch_make_tags(S.d_piles.p, S.d_reads.p, S.d_tasks.p, S.d_ops.p, S.d_pool.p, S.d_db.p, S.d_read_pile.p,
+    launch_make_tags(S.d_piles.p, S.d_reads.p, S.d_tasks.p, S.d_ops.p, S.d_pool.p, g_db_pool, S.d_read_pile.p,
                      S.d_tags.p, S.d_colidx.p, S.d_inscnt.p, S.d_insmax.p, (int)nr, st);
     launch_col_scan(S.d_piles.p, S.d_cov.p, S.d_inscnt.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, (int)np, st);
     HIP_CHECK(hipEventRecord(S.evs[1], st));
@@ -645,7 +682,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                        S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
                        S.d_ent_cnt.p, S.d_err.p, (int)blocks.size(), st);
     HIP_CHECK(hipEventRecord(S.evs[3], st));
-    launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_cell_start.p, S.d_cell_len.p,
+    launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p,
                            S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
                            S.d_cell_blink.p, S.d_path.p, (int)np, st);
     HIP_CHECK(hipEventRecord(S.evs[4], st));

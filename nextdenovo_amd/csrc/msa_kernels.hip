@@ -362,13 +362,211 @@ __device__ __forceinline__ long long shfl_i64(long long v, int src) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-__global__ __launch_bounds__(64) void score_backtrack_kernel(
+// Fast path: one wave per pile, the link tables of the current and the previous
+// column staged in LDS (a link's pp tag always lies in column p or p-1), symbols
+// A T G C - on lanes 0..4, the reference's sequential tie-break state per cell.
+constexpr int kColCells = 384;  // max_size <= 64 per column
+constexpr int kColEnts = 1024;  // distinct links per column
+
+struct ColTab {
+    uint32_t cstart[kColCells];
+    uint32_t clen[kColCells];
+    uint32_t pp[kColEnts];
+    long long score[kColEnts];
+};
+
+__global__ __launch_bounds__(64) void score_fast_kernel(
+    PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
+    const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ ent_base,
+    const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_len,
+    const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp, const uint32_t *__restrict__ ent_cnt,
+    uint32_t *__restrict__ cell_best_pp, uint32_t *__restrict__ cell_best_link) {
+    __shared__ ColTab tab[2];
+    __shared__ uint32_t s_ppp[kColEnts], s_cnt[kColEnts];
+    __shared__ uint32_t s_bpp[kColCells], s_blink[kColCells];
+    PileDev &P = piles[blockIdx.x];
+    const int lane = (int)threadIdx.x;
+    const uint32_t b = (uint32_t)lane;
+    const bool act = lane < 5;
+    const uint32_t L = P.seed_len;
+    const uint32_t *cov = coverage + P.col_off;
+    const uint32_t *ms = max_size + P.col_off;
+    const uint32_t *cb = cell_base + P.col_off;
+    const uint32_t *eb = ent_base + P.col_off;
+    const uint32_t *cs = cell_start + P.cell_off;
+    const uint32_t *cl = cell_len + P.cell_off;
+    const uint32_t *epp = ent_pp + P.ent_off;
+    const uint32_t *eppp = ent_ppp + P.ent_off;
+    const uint32_t *ecnt = ent_cnt + P.ent_off;
+    uint32_t *bpp_out = cell_best_pp + P.cell_off;
+    uint32_t *blk_out = cell_best_link + P.cell_off;
+    const long long factor = P.factor;
+
+    long long gbest = -10;
+    int32_t o_t = -1;
+    uint32_t o_db = 0;
+
+    // Column metadata for 64 columns at a time (one coalesced load per array), and a
+    // register prefetch of the next column's tables: the first cell / first 4 links of
+    // every lane are in flight while the current column is scored out of LDS.
+    uint32_t m_width = 0, m_cell0 = 0, m_e0 = 0, m_ecap = 0, m_cov = 0;
+    uint32_t pf_cs = 0, pf_cl = 0, pf_pp[4] = {0, 0, 0, 0}, pf_ppp[4] = {0, 0, 0, 0}, pf_cnt[4] = {0, 0, 0, 0};
+    auto load_meta = [&](uint32_t p0) {
+        const uint32_t p = p0 + (uint32_t)lane;
+        if (p < L) {
+            m_width = ms[p];
+            m_cell0 = cb[p];
+            m_e0 = eb[p];
+            m_ecap = eb[p + 1] - m_e0;  // link capacity of the column (>= links actually present)
+            m_cov = cov[p];
+        } else m_width = m_cell0 = m_e0 = m_ecap = m_cov = 0;
+    };
+    auto prefetch = [&](uint32_t cell0, uint32_t ncell, uint32_t e0, uint32_t ecap) {
+        if ((uint32_t)lane < ncell) {
+            pf_cs = cs[cell0 + lane];
+            pf_cl = cl[cell0 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
+            if (e < ecap) {
+                pf_pp[j] = epp[e0 + e];
+                pf_ppp[j] = eppp[e0 + e];
+                pf_cnt[j] = ecnt[e0 + e];
+            }
+        }
+    };
+    load_meta(0);
+    {
+        const uint32_t w0 = (uint32_t)__shfl((int)m_width, 0, 64);
+        prefetch((uint32_t)__shfl((int)m_cell0, 0, 64), w0 * 6u, (uint32_t)__shfl((int)m_e0, 0, 64),
+                 (uint32_t)__shfl((int)m_ecap, 0, 64));
+    }
+    for (uint32_t p = 0; p < L; p++) {
+        const int ml = (int)(p & 63u);
+        const uint32_t width = (uint32_t)__shfl((int)m_width, ml, 64);
+        const uint32_t cell0 = (uint32_t)__shfl((int)m_cell0, ml, 64);
+        const uint32_t e0 = (uint32_t)__shfl((int)m_e0, ml, 64);
+        const uint32_t ecap = (uint32_t)__shfl((int)m_ecap, ml, 64);
+        const long long pen = factor * (long long)(uint32_t)__shfl((int)m_cov, ml, 64);
+        const uint32_t ncell = width * 6u;
+        if (ncell > (uint32_t)kColCells || ecap > (uint32_t)kColEnts) {
+            if (lane == 0) P.err = 2;  // rerun this pile in the HBM-resident kernel
+            return;
+        }
+        ColTab &cur = tab[p & 1u];
+        ColTab &prv = tab[(p & 1u) ^ 1u];
+        // 1. commit the prefetched tables of column p to LDS, fetch what did not fit
+        if ((uint32_t)lane < ncell) {
+            cur.cstart[lane] = pf_cs - e0;
+            cur.clen[lane] = pf_cl;
+        }
+        for (uint32_t c = (uint32_t)lane + 64u; c < ncell; c += 64) {
+            cur.cstart[c] = cs[cell0 + c] - e0;
+            cur.clen[c] = cl[cell0 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
+            if (e < ecap) {
+                cur.pp[e] = pf_pp[j];
+                s_ppp[e] = pf_ppp[j];
+                s_cnt[e] = pf_cnt[j];
+            }
+        }
+        for (uint32_t e = (uint32_t)lane + 256u; e < ecap; e += 64) {
+            cur.pp[e] = epp[e0 + e];
+            s_ppp[e] = eppp[e0 + e];
+            s_cnt[e] = ecnt[e0 + e];
+        }
+        // 2. start the loads of column p+1 (and of the next metadata block)
+        if (p + 1 < L) {
+            if (ml == 63) load_meta(p + 1);
+            const int nl = (int)((p + 1) & 63u);
+            const uint32_t nw = (uint32_t)__shfl((int)m_width, nl, 64);
+            prefetch((uint32_t)__shfl((int)m_cell0, nl, 64), nw * 6u, (uint32_t)__shfl((int)m_e0, nl, 64),
+                     (uint32_t)__shfl((int)m_ecap, nl, 64));
+        }
+        __syncthreads();
+        // 3. score column p out of LDS
+        for (uint32_t d = 0; d < width; d++) {
+            long long best = -10;
+            if (act) {
+                uint32_t bpp = kTagHead, blink = 0;
+                const uint32_t cell = d * 6u + b;
+                const uint32_t st = cur.cstart[cell], n = cur.clen[cell];
+                long long via = LLONG_MIN, via_next = LLONG_MIN;
+                for (uint32_t m = 0; m < n; m++) {
+                    const uint32_t mpp = cur.pp[st + m], mppp = s_ppp[st + m], cnt = s_cnt[st + m];
+                    const long long gain = 10ll * (long long)cnt - pen;
+                    long long sc = 0;
+                    if (mpp == kTagHead) {
+                        sc = gain;
+                    } else {
+                        const ColTab &T = (uint32_t)tag_tpos(mpp) == p ? cur : prv;
+                        const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
+                        const uint32_t ps = T.cstart[pc], pn = T.clen[pc];
+                        const uint32_t pb = tag_base(mpp);
+                        for (uint32_t k = 0; k < pn; k++) {
+                            if (T.pp[ps + k] != mppp) continue;
+                            const long long ns = T.score[ps + k];
+                            const long long s = ns + gain;
+                            if (s > sc) {
+                                sc = s;
+                                via_next = ns;
+                            }
+                            if (ns > via && (pb == 4u || pb == b)) {
+                                via = ns;
+                                best = sc;
+                                bpp = mpp;
+                                blink = cnt;
+                            }
+                        }
+                    }
+                    cur.score[st + m] = sc;
+                    if (sc > best || (sc == best && tag_base(mpp) != 4u)) {
+                        via = via_next;
+                        best = sc;
+                        bpp = mpp;
+                        blink = cnt;
+                    }
+                }
+                s_bpp[cell] = bpp;
+                s_blink[cell] = blink;
+            }
+            __syncthreads();  // scores of (p,d) visible before (p,d+1) reads them
+            for (int bb = 0; bb < 5; bb++) {  // lib/nextcorrect.c:2194-2199
+                const long long v = shfl_i64(best, bb);
+                if (v >= gbest - 3000) {
+                    o_t = (int32_t)p;
+                    o_db = (d << 3) | (uint32_t)bb;
+                    if (v > gbest) gbest = v;
+                }
+            }
+        }
+        for (uint32_t c = (uint32_t)lane; c < ncell; c += 64)
+            if (c % 6u < 5u) {
+                bpp_out[cell0 + c] = s_bpp[c];
+                blk_out[cell0 + c] = s_blink[c];
+            }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        P.origin_t = o_t;
+        P.origin_db = o_db;
+    }
+}
+
+// Slow path (rare): same DP with every table in HBM, for piles whose columns exceed the
+// LDS tables of the fast kernel.  Runs only on piles flagged err == 2.
+__global__ __launch_bounds__(64) void score_slow_kernel(
     PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
     const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ cell_start,
     const uint32_t *__restrict__ cell_len, const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp,
     const uint32_t *__restrict__ ent_cnt, long long *__restrict__ ent_score, uint32_t *__restrict__ cell_best_pp,
-    uint32_t *__restrict__ cell_best_link, PathItem *__restrict__ path) {
+    uint32_t *__restrict__ cell_best_link) {
     PileDev &P = piles[blockIdx.x];
+    if (P.err != 2) return;
     const int lane = (int)threadIdx.x;
     const uint32_t b = (uint32_t)lane;
     const bool act = lane < 5;  // symbols A T G C - (lib/nextcorrect.c:2151)
@@ -437,7 +635,6 @@ __global__ __launch_bounds__(64) void score_backtrack_kernel(
                 blk_out[cell] = blink;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // scores of this (p,d) are in L2 before any later read
-            // global pick in symbol order (lib/nextcorrect.c:2194-2199)
             for (int bb = 0; bb < 5; bb++) {
                 const long long v = shfl_i64(best, bb);
                 if (v >= gbest - 3000) {
@@ -448,30 +645,44 @@ __global__ __launch_bounds__(64) void score_backtrack_kernel(
             }
         }
     }
-    __threadfence();
-    __syncthreads();
     if (lane == 0) {
         P.origin_t = o_t;
         P.origin_db = o_db;
-        uint32_t len = 0;
-        int32_t t = o_t;
-        uint32_t db = o_db;
-        PathItem *out = path + P.path_off;
-        const uint32_t cap = P.n_cells / 6u;
-        while (t >= 0 && len < cap) {
-            const uint32_t cell = cb[t] + (db >> 3) * 6u + (db & 7u);
-            PathItem it;
-            it.tag = tag_pack(t, db >> 3, db & 7u);
-            it.link = (uint16_t)__hip_atomic_load(&blk_out[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            it.cov = (uint16_t)cov[t];
-            out[len++] = it;
-            const uint32_t g = __hip_atomic_load(&bpp_out[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g == kTagHead) break;
-            t = tag_tpos(g);
-            db = g & 0x7ffu;
-        }
-        P.path_len = len;
+        P.err = 0;
     }
+}
+
+// best_pp walk from the origin (lib/nextcorrect.c:1907-1982 visits exactly these cells)
+__global__ __launch_bounds__(64) void backtrack_kernel(PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage,
+                                                        const uint32_t *__restrict__ cell_base,
+                                                        const uint32_t *__restrict__ cell_best_pp,
+                                                        const uint32_t *__restrict__ cell_best_link,
+                                                        PathItem *__restrict__ path, int n_piles) {
+    const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (i >= n_piles) return;
+    PileDev &P = piles[i];
+    const uint32_t *cov = coverage + P.col_off;
+    const uint32_t *cb = cell_base + P.col_off;
+    const uint32_t *bpp = cell_best_pp + P.cell_off;
+    const uint32_t *blk = cell_best_link + P.cell_off;
+    PathItem *out = path + P.path_off;
+    const uint32_t cap = P.n_cells / 6u;
+    uint32_t len = 0;
+    int32_t t = P.origin_t;
+    uint32_t db = P.origin_db;
+    while (t >= 0 && len < cap) {
+        const uint32_t cell = cb[t] + (db >> 3) * 6u + (db & 7u);
+        PathItem it;
+        it.tag = tag_pack(t, db >> 3, db & 7u);
+        it.link = (uint16_t)blk[cell];
+        it.cov = (uint16_t)cov[t];
+        out[len++] = it;
+        const uint32_t g = bpp[cell];
+        if (g == kTagHead) break;
+        t = tag_tpos(g);
+        db = g & 0x7ffu;
+    }
+    P.path_len = len;
 }
 
 // ---- K11 -------------------------------------------------------------------------
@@ -584,14 +795,20 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
 }
 
 void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,
-                            const uint32_t *cell_base, const uint32_t *cell_start, const uint32_t *cell_len,
-                            const uint32_t *ent_pp, const uint32_t *ent_ppp, const uint32_t *ent_cnt,
-                            long long *ent_score, uint32_t *cell_best_pp, uint32_t *cell_best_link, PathItem *path,
-                            int n_piles, void *stream) {
+                            const uint32_t *cell_base, const uint32_t *ent_base, const uint32_t *cell_start,
+                            const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
+                            const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
+                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream) {
     if (n_piles <= 0) return;
-    hipLaunchKernelGGL(score_backtrack_kernel, dim3((unsigned)n_piles), dim3(64), 0, (hipStream_t)stream, piles,
-                       coverage, max_size, cell_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, ent_score,
-                       cell_best_pp, cell_best_link, path);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
+                       cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
+                       cell_best_link);
+    hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
+                       cell_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, ent_score, cell_best_pp,
+                       cell_best_link);
+    hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)((n_piles + 63) / 64)), dim3(64), 0, st, piles, coverage,
+                       cell_base, cell_best_pp, cell_best_link, path, n_piles);
 }
 
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,

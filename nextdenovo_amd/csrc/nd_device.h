@@ -140,10 +140,10 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
                         uint32_t *ent_pp, uint32_t *ent_ppp, uint32_t *ent_cnt, uint32_t *err, int n_blocks,
                         void *stream);
 void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,
-                            const uint32_t *cell_base, const uint32_t *cell_start, const uint32_t *cell_len,
-                            const uint32_t *ent_pp, const uint32_t *ent_ppp, const uint32_t *ent_cnt,
-                            long long *ent_score, uint32_t *cell_best_pp, uint32_t *cell_best_link, PathItem *path,
-                            int n_piles, void *stream);
+                            const uint32_t *cell_base, const uint32_t *ent_base, const uint32_t *cell_start,
+                            const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
+                            const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
+                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream);
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,
                     const uint32_t *colidx, RegionDev *regions, char *strpool, unsigned long long *strpool_cursor,
                     unsigned long long strpool_cap, int n_regions, void *stream);

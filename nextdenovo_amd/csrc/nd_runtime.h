@@ -36,7 +36,11 @@ struct RuntimeStats {
 
 class DeviceAligner {
   public:
-    static DeviceAligner &instance();
+    static constexpr int kMaxContexts = 4;
+    static DeviceAligner &instance();          // context 0
+    static DeviceAligner &context(int i);
+    static RuntimeStats total_stats();
+    static void reset_all_stats();
     void align_batch(AlnJob **jobs, size_t n);
     // device main phase / candidate extraction of a batch of piles (see Backend in nd_host.h);
     // begin_batch()/end_batch() bracket one batch and serialise batches of one process
@@ -62,18 +66,19 @@ class DeviceAligner {
 // The product's only Backend: every request runs in HIP kernels on the device.
 class HipBackend : public Backend {
   public:
-    HipBackend() { DeviceAligner::instance().begin_batch(); }
+    explicit HipBackend(int ctx = 0) : dev_(DeviceAligner::context(ctx)) { dev_.begin_batch(); }
     ~HipBackend() override { finish(); }
-    void run_main(MainPile **piles, size_t n) override { DeviceAligner::instance().run_main(piles, n); }
-    void run_extract(ExtractPile **piles, size_t n) override { DeviceAligner::instance().run_extract(piles, n); }
-    void run_align(AlnJob **jobs, size_t n) override { DeviceAligner::instance().align_batch(jobs, n); }
+    void run_main(MainPile **piles, size_t n) override { dev_.run_main(piles, n); }
+    void run_extract(ExtractPile **piles, size_t n) override { dev_.run_extract(piles, n); }
+    void run_align(AlnJob **jobs, size_t n) override { dev_.align_batch(jobs, n); }
     void end_batch() override { finish(); }
 
   private:
     void finish() {
-        if (open_) DeviceAligner::instance().end_batch();
+        if (open_) dev_.end_batch();
         open_ = false;
     }
+    DeviceAligner &dev_;
     bool open_ = true;
 };
 
