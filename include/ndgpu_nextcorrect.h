@@ -113,7 +113,8 @@ typedef struct {
     uint32_t max_band, forward_launches;
     double forward_ms;      /* HIP-event time of K7 (O(ND) forward) launches */
     double traceback_ms, tags_ms, links_ms, score_ms, extract_ms;
-    uint64_t piles, tags, cells_msa, path_items;
+    uint64_t piles, tags, cells_msa, path_items, links, score_launches;
+    double backtrack_ms;
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

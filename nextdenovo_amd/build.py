@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+           "-Wall", "-Wno-unused-function", "-o", LIB] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

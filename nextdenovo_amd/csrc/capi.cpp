@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -127,7 +128,7 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
                                             min_error_corrected_ratio, split, fast, read_type));
     });
     {
-        HipBackend be;
+        HipBackend be(0, host_threads);
         run_engines(eng.data(), eng.size(), be, host_threads);
     }
     for (size_t i = 0; i < (size_t)n_piles; i++) {
@@ -170,7 +171,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return recs[pile_off[a] * 8 + 3] > recs[pile_off[b] * 8 + 3];
     });
-    int drivers = DeviceAligner::kMaxContexts;
+    int drivers = 4;
     if (const char *e = getenv("NDGPU_CONTEXTS")) drivers = std::max(1, std::min(atoi(e), (int)DeviceAligner::kMaxContexts));
     const size_t n_sub = ((size_t)n_piles + sub - 1) / sub;
     drivers = (int)std::min<size_t>((size_t)drivers, n_sub);
@@ -205,7 +206,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                                                     min_error_corrected_ratio, split, fast, read_type));
             });
             {
-                HipBackend be(ctx);
+                HipBackend be(ctx, threads_each);
                 run_engines(eng.data(), cnt, be, threads_each);
             }
             for (size_t k = 0; k < cnt; k++) {
@@ -218,6 +219,17 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     for (int c = 1; c < drivers; c++) th.emplace_back(drive, c);
     drive(0);
     for (auto &t : th) t.join();
+    if (getenv("NDGPU_PROF")) {
+        fprintf(stderr, "[ndgpu prof] drivers %d x %d threads | main %.3f s  extract %.3f s  align %.3f s (%llu jobs)  "
+                        "advance %.3f s  (driver-thread wall sums)\n",
+                drivers, threads_each, g_prof.main_ns * 1e-9, g_prof.extract_ns * 1e-9, g_prof.align_ns * 1e-9,
+                (unsigned long long)g_prof.jobs.load(), g_prof.advance_ns * 1e-9);
+        fprintf(stderr, "[ndgpu prof] run_main: prep %.3f  align(K7+K8a) %.3f  tags %.3f  msa(K9+K10) %.3f  post %.3f s\n",
+                g_prof.m_prep * 1e-9, g_prof.m_aln * 1e-9, g_prof.m_tags * 1e-9, g_prof.m_msa * 1e-9,
+                g_prof.m_post * 1e-9);
+        g_prof.main_ns = g_prof.extract_ns = g_prof.align_ns = g_prof.advance_ns = g_prof.jobs = 0;
+        g_prof.m_prep = g_prof.m_aln = g_prof.m_tags = g_prof.m_msa = g_prof.m_post = 0;
+    }
     return 0;
 }
 
@@ -312,6 +324,9 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->tags = s.tags;
     o->cells_msa = s.cells_msa;
     o->path_items = s.path_items;
+    o->links = s.links;
+    o->score_launches = s.score_launches;
+    o->backtrack_ms = s.backtrack_ms;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

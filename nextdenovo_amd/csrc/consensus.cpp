@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <thread>
 
@@ -1034,6 +1035,14 @@ void parallel_for(size_t n, int threads, F f) {
 }
 }  // namespace
 
+HostProf g_prof;
+
+static inline uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
 void run_engines(PileEngine **eng, size_t n, Backend &be, int threads) {
     std::vector<MainPile *> mains;
     std::vector<ExtractPile *> extracts;
@@ -1054,10 +1063,20 @@ void run_engines(PileEngine **eng, size_t n, Backend &be, int threads) {
             live.push_back(i);
         }
         if (live.empty()) break;
+        uint64_t t0 = now_ns();
         if (!mains.empty()) be.run_main(mains.data(), mains.size());
+        uint64_t t1 = now_ns();
         if (!extracts.empty()) be.run_extract(extracts.data(), extracts.size());
+        uint64_t t2 = now_ns();
         if (!jobs.empty()) be.run_align(jobs.data(), jobs.size());
+        uint64_t t3 = now_ns();
         parallel_for(live.size(), threads, [&](size_t k) { eng[live[k]]->advance(); });
+        uint64_t t4 = now_ns();
+        g_prof.main_ns += t1 - t0;
+        g_prof.extract_ns += t2 - t1;
+        g_prof.align_ns += t3 - t2;
+        g_prof.advance_ns += t4 - t3;
+        g_prof.jobs += jobs.size();
     }
     be.end_batch();
 }

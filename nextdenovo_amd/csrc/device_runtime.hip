@@ -7,11 +7,13 @@
 // no host round trip between the forward sweep and the traceback.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -145,6 +147,7 @@ struct DeviceAligner::State {
     RuntimeStats stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t trace_budget_bytes = (size_t)48 << 30;
+    int host_threads = 1;
 };
 
 DeviceAligner::DeviceAligner() : s_(new State) {
@@ -166,21 +169,27 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     for (auto &e : s_->evs) HIP_CHECK(hipEventCreate(&e));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)8 << 30))
-        s_->trace_budget_bytes = free_b / (3 * kMaxContexts);
+        s_->trace_budget_bytes = free_b / 24;
     else s_->trace_budget_bytes = (size_t)2 << 30;
 }
 
 DeviceAligner::~DeviceAligner() { delete s_; }
 
+static DeviceAligner *g_ctx[DeviceAligner::kMaxContexts] = {nullptr};
+static std::mutex g_ctx_mu;
+
 DeviceAligner &DeviceAligner::context(int i) {
     // intentionally leaked: no HIP calls at exit.  Contexts own a stream + buffer set each, so
     // batches driven from different host threads overlap on the device.
-    static DeviceAligner *g[kMaxContexts] = {nullptr};
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
     i = i < 0 ? 0 : i % kMaxContexts;
-    if (!g[i]) g[i] = new DeviceAligner();
-    return *g[i];
+    if (!g_ctx[i]) g_ctx[i] = new DeviceAligner();
+    return *g_ctx[i];
+}
+
+DeviceAligner *DeviceAligner::peek(int i) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    return g_ctx[i];
 }
 
 DeviceAligner &DeviceAligner::instance() { return context(0); }
@@ -188,7 +197,9 @@ DeviceAligner &DeviceAligner::instance() { return context(0); }
 RuntimeStats DeviceAligner::total_stats() {
     RuntimeStats t;
     for (int i = 0; i < kMaxContexts; i++) {
-        DeviceAligner &c = context(i);
+        DeviceAligner *cp = peek(i);
+        if (!cp) continue;
+        DeviceAligner &c = *cp;
         const RuntimeStats &s = c.s_->stats;
         t.tasks += s.tasks; t.wide_tasks += s.wide_tasks; t.cells += s.cells; t.d_steps += s.d_steps;
         t.trace_bits += s.trace_bits; t.columns += s.columns; t.pool_bases += s.pool_bases; t.seq_bases += s.seq_bases;
@@ -196,12 +207,14 @@ RuntimeStats DeviceAligner::total_stats() {
         t.forward_launches += s.forward_launches; t.forward_ms += s.forward_ms; t.traceback_ms += s.traceback_ms;
         t.tags_ms += s.tags_ms; t.links_ms += s.links_ms; t.score_ms += s.score_ms; t.extract_ms += s.extract_ms;
         t.piles += s.piles; t.tags += s.tags; t.cells_msa += s.cells_msa; t.path_items += s.path_items;
+        t.links += s.links; t.score_launches += s.score_launches; t.backtrack_ms += s.backtrack_ms;
     }
     return t;
 }
 
 void DeviceAligner::reset_all_stats() {
-    for (int i = 0; i < kMaxContexts; i++) context(i).reset_stats();
+    for (int i = 0; i < kMaxContexts; i++)
+        if (DeviceAligner *c = peek(i)) c->reset_stats();
 }
 
 void DeviceAligner::set_db(const uint32_t *pool_words, size_t n_words) {
@@ -254,50 +267,70 @@ void DeviceAligner::align_batch(AlnJob **jobs, size_t n) {
     }
 }
 
+namespace {
+template <typename F>
+void par_ranges(size_t n, int threads, F f) {  // f(begin, end) over contiguous ranges
+    if (threads <= 1 || n < 4096) {
+        f((size_t)0, n);
+        return;
+    }
+    const size_t nt = std::min<size_t>((size_t)threads, (n + 2047) / 2048);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) {
+        const size_t a = n * t / nt, b = n * (t + 1) / nt;
+        th.emplace_back([=] { f(a, b); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// ASCII -> 2-bit into a preallocated word range (same coding as pack_append)
+bool pack_into(uint32_t *out, const char *s, size_t n) {
+    unsigned bad = 0;
+    size_t i = 0, w = 0;
+    for (; i + 16 <= n; w++, i += 16) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 16; b++) {
+            const uint8_t c = kCode.v[(unsigned char)s[i + b]];
+            bad |= c;
+            acc |= (uint32_t)(c & 3u) << (2 * b);
+        }
+        out[w] = acc;
+    }
+    if (i < n) {
+        uint32_t acc = 0;
+        for (int b = 0; i + b < n; b++) {
+            const uint8_t c = kCode.v[(unsigned char)s[i + b]];
+            bad |= c;
+            acc |= (uint32_t)(c & 3u) << (2 * b);
+        }
+        out[w] = acc;
+    }
+    return (bad & 0x80u) == 0;
+}
+}  // namespace
+
+void DeviceAligner::set_host_threads(int n) { s_->host_threads = n < 1 ? 1 : n; }
+
 void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     State &S = *s_;
     std::vector<uint32_t> &pool = S.pool;
     std::vector<AlnTask> &tasks = S.tasks;
-    pool.clear();
     tasks.assign(n, AlnTask());
-    std::unordered_map<const char *, uint64_t> owners;  // shared target buffers packed once
     std::vector<uint8_t> bad(n, 0);
-    uint64_t trace_words = 0, mink_rows = 0, ops_words = 0;
+    // pass 1 (serial, O(1) per job): offsets of every per-task region
+    std::vector<uint64_t> qw(n + 1), tw(n + 1);
+    uint64_t trace_words = 0, mink_rows = 0, ops_words = 0, pool_words = 0;
     for (size_t i = 0; i < n; i++) {
-        AlnJob &j = *jobs[i];
+        const AlnJob &j = *jobs[i];
         AlnTask &t = tasks[i];
-        j.status = ALN_NONE;
-        j.ops.clear();
-        j.q_used = j.t_used = 0;
         t.q_len = j.q_len;
         t.t_len = j.t_len;
-        S.stats.seq_bases += (uint64_t)j.q_len + (uint64_t)j.t_len;
-        if (j.q_dev >= 0) t.q_off = (uint64_t)j.q_dev | kOffDb;
-        else {
-            t.q_off = (uint64_t)pool.size() * 16;
-            if (!pack_append(pool, j.q, (size_t)j.q_len)) bad[i] = 1;
-            S.stats.pool_bases += (uint64_t)j.q_len;
-        }
-        if (j.t_dev >= 0) t.t_off = (uint64_t)j.t_dev | kOffDb;
-        else if (j.t_owner) {
-            auto it = owners.find(j.t_owner);
-            uint64_t base;
-            if (it == owners.end()) {
-                base = (uint64_t)pool.size() * 16;
-                if (!pack_append(pool, j.t_owner, (size_t)j.t_owner_len)) bad[i] = 1;
-                S.stats.pool_bases += (uint64_t)j.t_owner_len;
-                owners.emplace(j.t_owner, bad[i] ? UINT64_MAX : base);
-            } else base = it->second;
-            if (base == UINT64_MAX) bad[i] = 1;
-            t.t_off = base + (uint64_t)(j.t - j.t_owner);
-        } else {
-            t.t_off = (uint64_t)pool.size() * 16;
-            if (!pack_append(pool, j.t, (size_t)j.t_len)) bad[i] = 1;
-            S.stats.pool_bases += (uint64_t)j.t_len;
-        }
+        qw[i] = pool_words;
+        if (j.q_dev < 0) pool_words += ((uint64_t)j.q_len + 15) / 16;
+        tw[i] = pool_words;
+        if (j.t_dev < 0) pool_words += ((uint64_t)j.t_len + 15) / 16;
         int md, bd;
         limits_for(j.q_len + j.t_len, j.hq, &md, &bd);
-        if (bad[i]) md = 0;
         t.max_d = md;
         t.band = bd;
         t.row_words = kFastRowWords;
@@ -308,7 +341,31 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
         trace_words += (uint64_t)md * kFastRowWords;
         mink_rows += (uint64_t)md;
         ops_words += (uint64_t)(t.ops_cap + 15) / 16 + 1;
+        S.stats.seq_bases += (uint64_t)j.q_len + (uint64_t)j.t_len;
+        S.stats.pool_bases += (j.q_dev < 0 ? (uint64_t)j.q_len : 0) + (j.t_dev < 0 ? (uint64_t)j.t_len : 0);
     }
+    pool.assign(pool_words, 0);
+    // pass 2 (parallel): pack the sequences
+    par_ranges(n, S.host_threads, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            AlnJob &j = *jobs[i];
+            AlnTask &t = tasks[i];
+            j.status = ALN_NONE;
+            j.ops.clear();
+            j.q_used = j.t_used = 0;
+            if (j.q_dev >= 0) t.q_off = (uint64_t)j.q_dev | kOffDb;
+            else {
+                t.q_off = qw[i] * 16;
+                if (!pack_into(pool.data() + qw[i], j.q, (size_t)j.q_len)) bad[i] = 1;
+            }
+            if (j.t_dev >= 0) t.t_off = (uint64_t)j.t_dev | kOffDb;
+            else {
+                t.t_off = tw[i] * 16;
+                if (!pack_into(pool.data() + tw[i], j.t, (size_t)j.t_len)) bad[i] = 1;
+            }
+            if (bad[i]) t.max_d = 0;
+        }
+    });
     pool.push_back(0);
     pool.push_back(0);  // fetch16 reads one word past the last base
 
@@ -345,48 +402,55 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     if (!wide.empty()) run_wide(jobs, n, wide);
 
     for (size_t i = 0; i < n; i++) {
-        AlnJob &j = *jobs[i];
         const AlnOut &o = S.h_outs.p[i];
-        const AlnTask &t = tasks[i];
         S.stats.cells += (uint64_t)o.cells;
         S.stats.d_steps += (uint64_t)o.d_steps;
         if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
+        if (o.status == ST_ALIGNED) {
+            S.stats.trace_bits += (uint64_t)o.cells;
+            S.stats.columns += (uint64_t)o.n_cols;
+        }
         if (bad[i]) {
             static bool warned = false;
             if (!warned) {
                 fprintf(stderr, "[ndgpu] sequence with bytes outside [ACGT]: alignment skipped\n");
                 warned = true;
             }
-            continue;
-        }
-        if (o.status == ST_ALIGNED) {
-            j.status = ALN_OK;
-            j.q_used = o.x_final;
-            j.t_used = o.y_final;
-            const uint32_t nc = (uint32_t)o.n_cols, c0 = t.ops_cap - nc;
-            const uint32_t *W = S.h_ops.p + t.ops_off;
-            j.ops.resize(nc);
-            for (uint32_t c = 0; c < nc; c++) {
-                const uint32_t cc = c0 + c;
-                j.ops[c] = (uint8_t)((W[cc >> 4] >> ((cc & 15u) * 2u)) & 3u);
-            }
-            S.stats.trace_bits += (uint64_t)o.cells;
-            S.stats.columns += nc;
-        } else if (o.status == ST_GAP_ABORT) {
-            j.status = ALN_GAP_ABORT;
-            j.q_used = o.x_final;
-            j.t_used = o.y_final;
-            // the reference reports aln_len = 2: keep the last two alignment columns
-            const uint32_t *W = S.h_ops.p + t.ops_off;
-            j.ops.resize(2);
-            for (uint32_t c = 0; c < 2; c++) {
-                const uint32_t cc = t.ops_cap - 2 + c;
-                j.ops[c] = (uint8_t)((W[cc >> 4] >> ((cc & 15u) * 2u)) & 3u);
-            }
-        } else {
-            j.status = ALN_NONE;
         }
     }
+    par_ranges(n, S.host_threads, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            AlnJob &j = *jobs[i];
+            const AlnOut &o = S.h_outs.p[i];
+            const AlnTask &t = tasks[i];
+            if (bad[i]) continue;
+            if (o.status == ST_ALIGNED) {
+                j.status = ALN_OK;
+                j.q_used = o.x_final;
+                j.t_used = o.y_final;
+                const uint32_t nc = (uint32_t)o.n_cols, c0 = t.ops_cap - nc;
+                const uint32_t *W = S.h_ops.p + t.ops_off;
+                j.ops.resize(nc);
+                for (uint32_t c = 0; c < nc; c++) {
+                    const uint32_t cc = c0 + c;
+                    j.ops[c] = (uint8_t)((W[cc >> 4] >> ((cc & 15u) * 2u)) & 3u);
+                }
+            } else if (o.status == ST_GAP_ABORT) {
+                j.status = ALN_GAP_ABORT;
+                j.q_used = o.x_final;
+                j.t_used = o.y_final;
+                // the reference reports aln_len = 2: keep the last two alignment columns
+                const uint32_t *W = S.h_ops.p + t.ops_off;
+                j.ops.resize(2);
+                for (uint32_t c = 0; c < 2; c++) {
+                    const uint32_t cc = t.ops_cap - 2 + c;
+                    j.ops[c] = (uint8_t)((W[cc >> 4] >> ((cc & 15u) * 2u)) & 3u);
+                }
+            } else {
+                j.status = ALN_NONE;
+            }
+        }
+    });
 }
 
 void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t> &ids) {
@@ -452,8 +516,15 @@ void DeviceAligner::end_batch() { s_->batch_mu.unlock(); }
 // Main phase of a batch of piles, entirely on the device:
 //   K7 forward -> K8a traceback -> K8s shift scan -> accept -> K8b tags -> column scan
 //   -> [one host sync: exact cell / link totals] -> K9 link counting -> K10 scoring + walk.
+static inline uint64_t wall_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
 void DeviceAligner::run_main(MainPile **mp, size_t np) {
     State &S = *s_;
+    uint64_t tp0 = wall_ns();
     std::lock_guard<std::mutex> lock(S.mu);
     HIP_CHECK(hipSetDevice(S.device));
     hipStream_t st = S.stream;
@@ -592,6 +663,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_entbase.reserve(col_slots + 1);
     S.d_err.reserve(4);
 
+    uint64_t tp1 = wall_ns();
+    g_prof.m_prep += tp1 - tp0;
     HIP_CHECK(hipMemcpyAsync(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if (nt) HIP_CHECK(hipMemcpyAsync(S.d_tasks.p, tasks.data(), nt * sizeof(AlnTask), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.d_reads.p, reads.data(), nr * sizeof(ReadDev), hipMemcpyHostToDevice, st));
@@ -639,6 +712,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         S.stats.tasks += nt;
     }
 
+    uint64_t tp2 = wall_ns();
+    g_prof.m_aln += tp2 - tp1;
     HIP_CHECK(hipEventRecord(S.evs[0], st));
     launch_shift_scan(S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_reads.p, (int)nr, st);
     launch_pile_accept(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_cov.p, (int)np, st);
@@ -649,6 +724,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     HIP_CHECK(hipMemcpyAsync(piles.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
 
+    uint64_t tp3 = wall_ns();
+    g_prof.m_tags += tp3 - tp2;
     uint64_t cells = 0, ents = 0, paths = 0;
     std::vector<ColBlock> blocks;
     for (size_t p = 0; p < np; p++) {
@@ -676,7 +753,6 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_blocks.reserve(blocks.size() + 1);
     HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.d_blocks.p, blocks.data(), blocks.size() * sizeof(ColBlock), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemsetAsync(S.d_cell_bpp.p, 0, (cells + 1) * sizeof(uint32_t), st));
     HIP_CHECK(hipEventRecord(S.evs[2], st));
     launch_count_links(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_blocks.p, S.d_tags.p, S.d_colidx.p, S.d_insmax.p,
                        S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
@@ -684,7 +760,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     HIP_CHECK(hipEventRecord(S.evs[3], st));
     launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p,
                            S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
-                           S.d_cell_blink.p, S.d_path.p, (int)np, st);
+                           S.d_cell_blink.p, S.d_path.p, (int)np, st, S.evs[7]);
     HIP_CHECK(hipEventRecord(S.evs[4], st));
     std::vector<PathItem> hpath(paths + 1);
     uint32_t herr[4] = {0, 0, 0, 0};
@@ -693,6 +769,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     HIP_CHECK(hipMemcpyAsync(herr, S.d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
+    uint64_t tp4 = wall_ns();
+    g_prof.m_msa += tp4 - tp3;
     if (herr[0]) {
         fprintf(stderr, "[ndgpu] FATAL: more than %d distinct links in one MSA cell (device capacity)\n", kLinkCap);
         abort();
@@ -702,8 +780,11 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.stats.tags_ms += ms;
     HIP_CHECK(hipEventElapsedTime(&ms, S.evs[2], S.evs[3]));
     S.stats.links_ms += ms;
-    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[3], S.evs[4]));
+    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[3], S.evs[7]));
     S.stats.score_ms += ms;
+    S.stats.score_launches++;
+    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[7], S.evs[4]));
+    S.stats.backtrack_ms += ms;
     for (size_t p = 0; p < np; p++) {
         const PileDev &P = piles[p];
         MainPile &M = *mp[p];
@@ -720,7 +801,9 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             d.cov = src[k].cov;
         }
         S.stats.path_items += P.path_len;
+        S.stats.links += P.n_links;
     }
+    g_prof.m_post += wall_ns() - tp4;
 }
 
 void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {

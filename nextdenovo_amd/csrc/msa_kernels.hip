@@ -356,23 +356,40 @@ __device__ __forceinline__ long long ld_score(const long long *p) {
 __device__ __forceinline__ void st_score(long long *p, long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ long long readlane_i64(long long v, int src) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
 __device__ __forceinline__ long long shfl_i64(long long v, int src) {
     const int lo = __shfl((int)(v & 0xffffffffll), src, 64);
     const int hi = __shfl((int)(v >> 32), src, 64);
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// Fast path: one wave per pile, the link tables of the current and the previous
-// column staged in LDS (a link's pp tag always lies in column p or p-1), symbols
-// A T G C - on lanes 0..4, the reference's sequential tie-break state per cell.
-constexpr int kColCells = 384;  // max_size <= 64 per column
-constexpr int kColEnts = 1024;  // distinct links per column
+// Fast path: one wave per pile.  The scoring DP is a dependent chain over (column, delta)
+// steps, ~10^4-10^6 long, so the kernel is organised around the latency of one step:
+//   * the link tables of the current and the previous column live in LDS (a link's pp tag
+//     always lies in column p or p-1); the next column's tables are prefetched into
+//     registers while the current one is scored;
+//   * once per column every link is "resolved" lane-parallel (where its predecessor cell
+//     is, its gain 10*count - factor*coverage);
+//   * per step each link sits on its own lane and reduces its matching predecessor scores
+//     to four numbers; the reference's sequential tie-break state of the five symbol cells
+//     (lib/nextcorrect.c:2164-2192) is then advanced link by link with scalar lane reads;
+//   * scores are int32 here (a 10^6-column seed at depth 200 stays below 2^31); any pile
+//     that gets near the limit, or whose columns exceed the LDS tables, is redone by the
+//     int64 HBM-resident kernel below.
+constexpr int kColCells = 192;  // max_size <= 32 per column
+constexpr int kColEnts = 512;   // links per column
+constexpr int32_t kNoScore = INT32_MIN;
+constexpr int32_t kScoreGuard = 1 << 30;
 
 struct ColTab {
     uint32_t cstart[kColCells];
     uint32_t clen[kColCells];
     uint32_t pp[kColEnts];
-    long long score[kColEnts];
+    int32_t score[kColEnts];
 };
 
 __global__ __launch_bounds__(64) void score_fast_kernel(
@@ -382,12 +399,13 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
     const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp, const uint32_t *__restrict__ ent_cnt,
     uint32_t *__restrict__ cell_best_pp, uint32_t *__restrict__ cell_best_link) {
     __shared__ ColTab tab[2];
-    __shared__ uint32_t s_ppp[kColEnts], s_cnt[kColEnts];
+    __shared__ uint32_t s_ppp[kColEnts], s_cnt[kColEnts], s_res[kColEnts];
+    __shared__ int32_t s_gain[kColEnts];
     __shared__ uint32_t s_bpp[kColCells], s_blink[kColCells];
+    __builtin_amdgcn_s_setprio(3);  // latency-bound wave: issue priority over co-resident kernels
     PileDev &P = piles[blockIdx.x];
     const int lane = (int)threadIdx.x;
     const uint32_t b = (uint32_t)lane;
-    const bool act = lane < 5;
     const uint32_t L = P.seed_len;
     const uint32_t *cov = coverage + P.col_off;
     const uint32_t *ms = max_size + P.col_off;
@@ -400,18 +418,16 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
     const uint32_t *ecnt = ent_cnt + P.ent_off;
     uint32_t *bpp_out = cell_best_pp + P.cell_off;
     uint32_t *blk_out = cell_best_link + P.cell_off;
-    const long long factor = P.factor;
+    const int32_t factor = P.factor;
 
-    long long gbest = -10;
+    int32_t gbest = -10;
     int32_t o_t = -1;
-    uint32_t o_db = 0;
+    uint32_t o_db = 0, n_links = 0;
+    bool overflow = false;
 
-    // Column metadata for 64 columns at a time (one coalesced load per array), and a
-    // register prefetch of the next column's tables: the first cell / first 4 links of
-    // every lane are in flight while the current column is scored out of LDS.
     uint32_t m_width = 0, m_cell0 = 0, m_e0 = 0, m_ecap = 0, m_cov = 0;
     uint32_t pf_cs = 0, pf_cl = 0, pf_pp[4] = {0, 0, 0, 0}, pf_ppp[4] = {0, 0, 0, 0}, pf_cnt[4] = {0, 0, 0, 0};
-    auto load_meta = [&](uint32_t p0) {
+    auto load_meta = [&](uint32_t p0) {  // 64 columns of metadata, one coalesced load per array
         const uint32_t p = p0 + (uint32_t)lane;
         if (p < L) {
             m_width = ms[p];
@@ -436,26 +452,32 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
             }
         }
     };
+#ifdef ND_K10_PROF
+    long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+    unsigned long long n_steps = 0;
+#define TICK(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); long long tn_ = clock64(); tc[i] += tn_ - tprev; tprev = tn_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TICK(i)
+#endif
     load_meta(0);
-    {
-        const uint32_t w0 = (uint32_t)__shfl((int)m_width, 0, 64);
-        prefetch((uint32_t)__shfl((int)m_cell0, 0, 64), w0 * 6u, (uint32_t)__shfl((int)m_e0, 0, 64),
-                 (uint32_t)__shfl((int)m_ecap, 0, 64));
-    }
+    prefetch((uint32_t)__shfl((int)m_cell0, 0, 64), (uint32_t)__shfl((int)m_width, 0, 64) * 6u,
+             (uint32_t)__shfl((int)m_e0, 0, 64), (uint32_t)__shfl((int)m_ecap, 0, 64));
+
     for (uint32_t p = 0; p < L; p++) {
         const int ml = (int)(p & 63u);
-        const uint32_t width = (uint32_t)__shfl((int)m_width, ml, 64);
-        const uint32_t cell0 = (uint32_t)__shfl((int)m_cell0, ml, 64);
-        const uint32_t e0 = (uint32_t)__shfl((int)m_e0, ml, 64);
-        const uint32_t ecap = (uint32_t)__shfl((int)m_ecap, ml, 64);
-        const long long pen = factor * (long long)(uint32_t)__shfl((int)m_cov, ml, 64);
+        const uint32_t width = (uint32_t)__builtin_amdgcn_readlane((int)m_width, ml);
+        const uint32_t cell0 = (uint32_t)__builtin_amdgcn_readlane((int)m_cell0, ml);
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)m_e0, ml);
+        const uint32_t ecap = (uint32_t)__builtin_amdgcn_readlane((int)m_ecap, ml);
+        const int32_t pen = factor * (int32_t)__builtin_amdgcn_readlane((int)m_cov, ml);
         const uint32_t ncell = width * 6u;
         if (ncell > (uint32_t)kColCells || ecap > (uint32_t)kColEnts) {
-            if (lane == 0) P.err = 2;  // rerun this pile in the HBM-resident kernel
-            return;
+            overflow = true;
+            break;
         }
         ColTab &cur = tab[p & 1u];
         ColTab &prv = tab[(p & 1u) ^ 1u];
+        TICK(0)
         // 1. commit the prefetched tables of column p to LDS, fetch what did not fit
         if ((uint32_t)lane < ncell) {
             cur.cstart[lane] = pf_cs - e0;
@@ -479,64 +501,131 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
             s_ppp[e] = eppp[e0 + e];
             s_cnt[e] = ecnt[e0 + e];
         }
+        TICK(1)
         // 2. start the loads of column p+1 (and of the next metadata block)
         if (p + 1 < L) {
             if (ml == 63) load_meta(p + 1);
             const int nl = (int)((p + 1) & 63u);
-            const uint32_t nw = (uint32_t)__shfl((int)m_width, nl, 64);
-            prefetch((uint32_t)__shfl((int)m_cell0, nl, 64), nw * 6u, (uint32_t)__shfl((int)m_e0, nl, 64),
-                     (uint32_t)__shfl((int)m_ecap, nl, 64));
+            prefetch((uint32_t)__shfl((int)m_cell0, nl, 64), (uint32_t)__shfl((int)m_width, nl, 64) * 6u,
+                     (uint32_t)__shfl((int)m_e0, nl, 64), (uint32_t)__shfl((int)m_ecap, nl, 64));
+        }
+        if (ncell == 0) continue;
+        __syncthreads();
+        TICK(2)
+        // 2b. resolve every link of the column once; lane d keeps the link range of step d
+        {
+            const uint32_t nent = cur.cstart[ncell - 1u] + cur.clen[ncell - 1u];
+            n_links += nent;
+            for (uint32_t e = (uint32_t)lane; e < nent; e += 64) {
+                const uint32_t mpp = cur.pp[e];
+                uint32_t res = 0;
+                if (mpp != kTagHead) {
+                    const bool same = (uint32_t)tag_tpos(mpp) == p;
+                    const ColTab &T = same ? cur : prv;
+                    const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
+                    res = ((uint32_t)same << 31) | (T.cstart[pc] << 12) | T.clen[pc];
+                }
+                s_res[e] = res;
+                s_gain[e] = 10 * (int32_t)s_cnt[e] - pen;
+            }
+        }
+        uint32_t step_est = 0, step_n = 0;
+        if ((uint32_t)lane < width) {
+            step_est = cur.cstart[(uint32_t)lane * 6u];
+            step_n = cur.cstart[(uint32_t)lane * 6u + 4u] + cur.clen[(uint32_t)lane * 6u + 4u] - step_est;
         }
         __syncthreads();
-        // 3. score column p out of LDS
+        TICK(3)
+        // 3. score the steps of column p out of LDS
         for (uint32_t d = 0; d < width; d++) {
-            long long best = -10;
-            if (act) {
-                uint32_t bpp = kTagHead, blink = 0;
-                const uint32_t cell = d * 6u + b;
-                const uint32_t st = cur.cstart[cell], n = cur.clen[cell];
-                long long via = LLONG_MIN, via_next = LLONG_MIN;
-                for (uint32_t m = 0; m < n; m++) {
-                    const uint32_t mpp = cur.pp[st + m], mppp = s_ppp[st + m], cnt = s_cnt[st + m];
-                    const long long gain = 10ll * (long long)cnt - pen;
-                    long long sc = 0;
+            const uint32_t est = (uint32_t)__builtin_amdgcn_readlane((int)step_est, (int)d);
+            const uint32_t n_step = (uint32_t)__builtin_amdgcn_readlane((int)step_n, (int)d);
+            // 3a. one link per lane (64 at a time): final score + the three numbers the cell's
+            //     sequential state needs from it
+            int32_t best = -10, via = kNoScore, via_next = kNoScore;  // state of cell b in lane b
+            uint32_t bidx = 0xffffffffu;                              // link that holds best_pp
+            for (uint32_t g0 = 0; g0 < n_step; g0 += 64) {
+                const uint32_t g_n = n_step - g0 < 64u ? n_step - g0 : 64u;
+                int32_t r_sc = 0, r_impr = kNoScore, r_nsmax = kNoScore, r_scmax = 0;
+                uint32_t r_flags = 0;  // [2:0] owning cell, [3] predecessor symbol allows the via rule,
+                                       // [4] predecessor symbol is not a gap
+                if ((uint32_t)lane < g_n) {
+                    const uint32_t idx = est + g0 + (uint32_t)lane;
+                    const uint32_t mpp = cur.pp[idx], mppp = s_ppp[idx], res = s_res[idx];
+                    const int32_t gain = s_gain[idx];
+                    const uint32_t cell = (idx >= cur.cstart[d * 6u + 1u]) + (idx >= cur.cstart[d * 6u + 2u]) +
+                                          (idx >= cur.cstart[d * 6u + 3u]) + (idx >= cur.cstart[d * 6u + 4u]);
+                    const uint32_t pb = tag_base(mpp);
+                    r_flags = cell | ((pb == 4u || pb == cell) ? 8u : 0u) | (pb != 4u ? 16u : 0u);
                     if (mpp == kTagHead) {
-                        sc = gain;
+                        r_sc = gain;
                     } else {
-                        const ColTab &T = (uint32_t)tag_tpos(mpp) == p ? cur : prv;
-                        const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
-                        const uint32_t ps = T.cstart[pc], pn = T.clen[pc];
-                        const uint32_t pb = tag_base(mpp);
-                        for (uint32_t k = 0; k < pn; k++) {
-                            if (T.pp[ps + k] != mppp) continue;
-                            const long long ns = T.score[ps + k];
-                            const long long s = ns + gain;
-                            if (s > sc) {
-                                sc = s;
-                                via_next = ns;
+                        const ColTab &T = (res >> 31) ? cur : prv;
+                        const uint32_t ps = (res >> 12) & 0x7ffffu, pn = res & 0xfffu;
+                        for (uint32_t k0 = 0; k0 < pn; k0 += 4) {  // 4 predecessor links per LDS round trip
+                            uint32_t key[4];
+                            int32_t nsv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const uint32_t k = k0 + (uint32_t)u < pn ? k0 + (uint32_t)u : pn - 1u;
+                                key[u] = T.pp[ps + k];
+                                nsv[u] = T.score[ps + k];
                             }
-                            if (ns > via && (pb == 4u || pb == b)) {
-                                via = ns;
-                                best = sc;
-                                bpp = mpp;
-                                blink = cnt;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                if (k0 + (uint32_t)u < pn && key[u] == mppp) {
+                                    const int32_t ns = nsv[u];
+                                    if (ns + gain > r_sc) {
+                                        r_sc = ns + gain;
+                                        r_impr = ns;
+                                    }
+                                    if (ns > r_nsmax) {
+                                        r_nsmax = ns;
+                                        r_scmax = r_sc;
+                                    }
+                                }
                             }
                         }
                     }
-                    cur.score[st + m] = sc;
-                    if (sc > best || (sc == best && tag_base(mpp) != 4u)) {
-                        via = via_next;
-                        best = sc;
-                        bpp = mpp;
-                        blink = cnt;
+                    cur.score[idx] = r_sc;
+                    if (r_sc > kScoreGuard) overflow = true;
+                }
+                TICK(4)
+                // 3b. advance the cells' sequential state link by link (scalar lane reads)
+                for (uint32_t e = 0; e < g_n; e++) {
+                    const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)r_flags, (int)e);
+                    const int32_t sc = __builtin_amdgcn_readlane(r_sc, (int)e);
+                    const int32_t impr = __builtin_amdgcn_readlane(r_impr, (int)e);
+                    const int32_t nsmax = __builtin_amdgcn_readlane(r_nsmax, (int)e);
+                    const int32_t scmax = __builtin_amdgcn_readlane(r_scmax, (int)e);
+                    if (b == (fl & 7u)) {
+                        if (impr != kNoScore) via_next = impr;
+                        if (nsmax > via && (fl & 8u)) {
+                            via = nsmax;
+                            best = scmax;
+                            bidx = g0 + e;
+                        }
+                        if (sc > best || (sc == best && (fl & 16u))) {
+                            via = via_next;
+                            best = sc;
+                            bidx = g0 + e;
+                        }
                     }
                 }
-                s_bpp[cell] = bpp;
-                s_blink[cell] = blink;
+            }
+            TICK(5)
+            if (lane < 5) {
+                uint32_t bpp = kTagHead, blink = 0;
+                if (bidx != 0xffffffffu) {
+                    bpp = cur.pp[est + bidx];
+                    blink = s_cnt[est + bidx];
+                }
+                s_bpp[d * 6u + b] = bpp;
+                s_blink[d * 6u + b] = blink;
             }
             __syncthreads();  // scores of (p,d) visible before (p,d+1) reads them
-            for (int bb = 0; bb < 5; bb++) {  // lib/nextcorrect.c:2194-2199
-                const long long v = shfl_i64(best, bb);
+            for (int bb = 0; bb < 5; bb++) {  // global pick in symbol order (lib/nextcorrect.c:2194-2199)
+                const int32_t v = __builtin_amdgcn_readlane(best, bb);
                 if (v >= gbest - 3000) {
                     o_t = (int32_t)p;
                     o_db = (d << 3) | (uint32_t)bb;
@@ -544,16 +633,28 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
                 }
             }
         }
+        TICK(6)
         for (uint32_t c = (uint32_t)lane; c < ncell; c += 64)
             if (c % 6u < 5u) {
                 bpp_out[cell0 + c] = s_bpp[c];
                 blk_out[cell0 + c] = s_blink[c];
             }
         __syncthreads();
+        TICK(7)
+    }
+#ifdef ND_K10_PROF
+    if (lane == 0 && blockIdx.x == 0)
+        printf("[k10prof] L=%u | per col: meta %lld commit %lld prefetch+sync %lld resolve %lld links %lld fold %lld tail+pick %lld out %lld\n", L,
+               tc[0] / L, tc[1] / L, tc[2] / L, tc[3] / L, tc[4] / L, tc[5] / L, tc[6] / L, tc[7] / L);
+#endif
+    if (__ballot(overflow)) {
+        if (lane == 0) P.err = 2;  // redo this pile in the int64 / HBM-resident kernel
+        return;
     }
     if (lane == 0) {
         P.origin_t = o_t;
         P.origin_db = o_db;
+        P.n_links = n_links;
     }
 }
 
@@ -798,12 +899,14 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
                             const uint32_t *cell_base, const uint32_t *ent_base, const uint32_t *cell_start,
                             const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
                             const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
-                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream) {
+                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream,
+                            void *ev_after_fast) {
     if (n_piles <= 0) return;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
                        cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
                        cell_best_link);
+    if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
     hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
                        cell_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, ent_score, cell_best_pp,
                        cell_best_link);

@@ -96,7 +96,7 @@ struct PileDev {
     int32_t origin_t;       // backtrack origin written by the scoring kernel
     uint32_t origin_db;     // delta << 3 | base
     uint32_t err;           // nonzero: device-side capacity error
-    uint32_t pad_;
+    uint32_t n_links;       // distinct (pp,ppp) links of the pile (written by the scoring kernel)
 };
 
 struct PathItem {           // one visited cell of the best_pp walk (origin first)
@@ -143,7 +143,8 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
                             const uint32_t *cell_base, const uint32_t *ent_base, const uint32_t *cell_start,
                             const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
                             const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
-                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream);
+                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream,
+                            void *ev_after_fast);
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,
                     const uint32_t *colidx, RegionDev *regions, char *strpool, unsigned long long *strpool_cursor,
                     unsigned long long strpool_cap, int n_regions, void *stream);

@@ -2,6 +2,7 @@
 // public C ABI is include/ndgpu_nextcorrect.h).
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -141,6 +142,13 @@ class PileEngine {
   private:
     PileImpl *impl_;
 };
+
+// Wall-clock accounting of the host driver (summed over driver threads), NDGPU_PROF=1 prints it.
+struct HostProf {
+    std::atomic<uint64_t> main_ns{0}, extract_ns{0}, align_ns{0}, advance_ns{0}, build_ns{0}, jobs{0};
+    std::atomic<uint64_t> m_prep{0}, m_aln{0}, m_tags{0}, m_msa{0}, m_post{0};  // inside run_main
+};
+extern HostProf g_prof;
 
 // Drives a set of engines to completion over one backend (host phases on `threads`).
 void run_engines(PileEngine **eng, size_t n, Backend &be, int threads);

@@ -32,13 +32,17 @@ struct RuntimeStats {
     uint64_t tags = 0;             // alignment tags generated on the device
     uint64_t cells_msa = 0;        // MSA cells
     uint64_t path_items = 0;
+    uint64_t links = 0;            // distinct MSA links
+    uint64_t score_launches = 0;
+    double backtrack_ms = 0;
 };
 
 class DeviceAligner {
   public:
-    static constexpr int kMaxContexts = 4;
+    static constexpr int kMaxContexts = 16;
     static DeviceAligner &instance();          // context 0
     static DeviceAligner &context(int i);
+    static DeviceAligner *peek(int i);  // nullptr if context i was never used
     static RuntimeStats total_stats();
     static void reset_all_stats();
     void align_batch(AlnJob **jobs, size_t n);
@@ -50,6 +54,7 @@ class DeviceAligner {
     void end_batch();
     // upload (or replace) the resident read DB pool; AlnJob::q_dev/t_dev index into it
     void set_db(const uint32_t *pool_words, size_t n_words);
+    void set_host_threads(int n);   // threads used for packing / decoding inside a batch
     void *stream() const;
     RuntimeStats stats() const;
     void reset_stats();
@@ -66,7 +71,10 @@ class DeviceAligner {
 // The product's only Backend: every request runs in HIP kernels on the device.
 class HipBackend : public Backend {
   public:
-    explicit HipBackend(int ctx = 0) : dev_(DeviceAligner::context(ctx)) { dev_.begin_batch(); }
+    explicit HipBackend(int ctx = 0, int host_threads = 1) : dev_(DeviceAligner::context(ctx)) {
+        dev_.begin_batch();
+        dev_.set_host_threads(host_threads);
+    }
     ~HipBackend() override { finish(); }
     void run_main(MainPile **piles, size_t n) override { dev_.run_main(piles, n); }
     void run_extract(ExtractPile **piles, size_t n) override { dev_.run_extract(piles, n); }
