@@ -264,31 +264,81 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
     const uint32_t *acc = acc_list + P.acc_off;
     const uint32_t t_end = B.col0 + kColBlock < P.seed_len ? B.col0 + kColBlock : P.seed_len;
 
+    // Per-lane read descriptors of the first kRegChunks x 64 accepted reads stay in registers for
+    // the whole column block; deeper piles reload the rest from HBM.
+    constexpr int kRegChunks = 3;
+    uint32_t g_ts[kRegChunks], g_te[kRegChunks], g_len[kRegChunks];
+    const uint32_t *g_ci[kRegChunks];
+    const uint32_t *g_tg[kRegChunks];
+#pragma unroll
+    for (int ch = 0; ch < kRegChunks; ch++) {
+        const uint32_t rank = (uint32_t)ch * 64u + (uint32_t)lane;
+        g_ts[ch] = 1;
+        g_te[ch] = 0;  // empty interval: never covers a column
+        g_len[ch] = 0;
+        g_ci[ch] = nullptr;
+        g_tg[ch] = nullptr;
+        if (rank < P.n_acc) {
+            const ReadDev *R = &reads[acc[rank]];
+            g_ts[ch] = R->t_s;
+            g_te[ch] = R->t_e;
+            g_len[ch] = R->aln_len;
+            g_ci[ch] = colidx + R->colidx_off;
+            g_tg[ch] = tags + R->tag_off;
+        }
+    }
+    const uint32_t n_chunks = (P.n_acc + 63u) / 64u;
+
     for (uint32_t t = B.col0; t < t_end; t++) {
         const uint32_t width = ms[t];
         uint64_t e = P.ent_off + eb[t];
+        // tag index range of column t in every register-resident read
+        uint32_t c_i0[kRegChunks], c_nx[kRegChunks];
+#pragma unroll
+        for (int ch = 0; ch < kRegChunks; ch++) {
+            c_i0[ch] = 1;
+            c_nx[ch] = 0;
+            if (t >= g_ts[ch] && t <= g_te[ch]) {
+                c_i0[ch] = g_ci[ch][t - g_ts[ch]];
+                c_nx[ch] = t == g_te[ch] ? g_len[ch] : g_ci[ch][t + 1 - g_ts[ch]];
+            }
+        }
         for (uint32_t d = 0; d < width; d++) {
             if (lane < 6) l_n[lane] = 0;
             __syncthreads();
-            for (uint32_t r0 = 0; r0 < P.n_acc; r0 += 64) {
-                const uint32_t rank = r0 + (uint32_t)lane;
+            for (uint32_t chn = 0; chn < n_chunks; chn++) {
                 bool has = false;
                 uint32_t cur = 0, pp = kTagHead, ppp = kTagHead;
-                if (rank < P.n_acc) {
-                    const ReadDev *R = &reads[acc[rank]];
-                    const uint32_t ts = R->t_s, te = R->t_e;
-                    if (t >= ts && t <= te) {
-                        const uint32_t *ci = colidx + R->colidx_off;
-                        const uint32_t i0 = ci[t - ts];
-                        const uint32_t nx = t == te ? R->aln_len : ci[t + 1 - ts];
-                        const uint32_t i = i0 + d;
-                        if (i < nx) {
-                            const uint32_t *tg = tags + R->tag_off;
-                            has = true;
-                            cur = tg[i];
-                            if (i > 0) pp = tg[i - 1];
-                            if (i > 1) ppp = tg[i - 2];
+                uint32_t i0 = 1, nx = 0;
+                const uint32_t *tg = nullptr;
+                if (chn < (uint32_t)kRegChunks) {
+#pragma unroll
+                    for (int ch = 0; ch < kRegChunks; ch++)
+                        if ((uint32_t)ch == chn) {
+                            i0 = c_i0[ch];
+                            nx = c_nx[ch];
+                            tg = g_tg[ch];
                         }
+                } else {
+                    const uint32_t rank = chn * 64u + (uint32_t)lane;
+                    if (rank < P.n_acc) {
+                        const ReadDev *R = &reads[acc[rank]];
+                        const uint32_t ts = R->t_s, te = R->t_e;
+                        if (t >= ts && t <= te) {
+                            const uint32_t *ci = colidx + R->colidx_off;
+                            i0 = ci[t - ts];
+                            nx = t == te ? R->aln_len : ci[t + 1 - ts];
+                            tg = tags + R->tag_off;
+                        }
+                    }
+                }
+                {
+                    const uint32_t i = i0 + d;
+                    if (i < nx) {
+                        has = true;
+                        cur = tg[i];
+                        if (i > 0) pp = tg[i - 1];
+                        if (i > 1) ppp = tg[i - 2];
                     }
                 }
                 const uint32_t b = cur & 7u;
