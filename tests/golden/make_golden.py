@@ -15,6 +15,9 @@ Writes (all seeded, deterministic):
                                  nextCorrect() result for each (lib/nextcorrect.c:2219)
   tests/golden/poa.npz          inputs/outputs of the reference poa_to_consensus()
                                  (lib/dag.c:658-694)
+  tests/golden/stage/           a whole seed_cns stage: .2bit/.idx read DB, sorted.ovl(.bl) from the
+                                 reference chain and the cns.fasta(.idx) written by the reference's own
+                                 lib/nextcorrect.py -p 1 (default, -s, -b)
 The reference ships no golden vectors for this path; these files
 are what pins parity on machines where /root/reference does not exist.
 """
@@ -226,6 +229,42 @@ def make_poa(lib):
     return cases
 
 
+def make_stage(outdir):
+    """Inputs + expected output of the whole seed_cns stage: the reference's own
+    lib/nextcorrect.py (run from a temp copy next to oracle/_ref/*.so) at -p 1."""
+    import gzip
+    import shutil
+    import subprocess
+    g = synth.make_genome(24000, seed=31, n_repeats=0)
+    rs = synth.simulate_reads(g, 28, "ont", seed=32, mu=8.0, sigma=0.35, min_len=1000)
+    wd = tempfile.mkdtemp(prefix="ndstage")
+    fa = os.path.join(wd, "reads.fa")
+    refpipe.write_fasta(fa, [synth.codes_to_ascii(s) for s in rs.seqs])
+    idxs, so = refpipe.run_overlap_chain(wd, fa, seed_cutoff=2500)
+    lib = os.path.join(wd, "reflib")
+    os.makedirs(lib)
+    for f in ("nextcorrect.py", "kit.py"):
+        shutil.copy(os.path.join("/root/reference/lib", f), lib)
+    for f in ("nextcorrect.so", "ovlseq.so"):
+        os.symlink(os.path.join(refpipe.REFDIR, f), os.path.join(lib, f))
+    os.makedirs(outdir, exist_ok=True)
+    for variant, extra in (("default", []), ("split", ["-s"]), ("nobl", ["-b"])):
+        out = os.path.join(wd, "cns.%s.fasta" % variant)
+        subprocess.run([sys.executable, os.path.join(lib, "nextcorrect.py"), "-f", idxs, "-i", so, "-r", "ont", "-p", "1",
+                        "-min_len_seed", "1250", "-o", out] + extra, check=True, cwd=wd, capture_output=True)
+        for suffix in ("", ".idx"):
+            with open(out + suffix, "rb") as f, gzip.GzipFile(os.path.join(outdir, "cns.%s.fasta%s.gz" % (variant, suffix)),
+                                                               "wb", mtime=0) as gz:
+                gz.write(f.read())
+    db = os.path.join(wd, "db")
+    for f in sorted(os.listdir(db)):
+        shutil.copy(os.path.join(db, f), outdir)
+    shutil.copy(so, os.path.join(outdir, "input.seed.001.sorted.ovl"))
+    if os.path.exists(so + ".bl"):
+        shutil.copy(so + ".bl", os.path.join(outdir, "input.seed.001.sorted.ovl.bl"))
+    return sorted(os.listdir(outdir))
+
+
 def main():
     assert refpipe.have_ref("nextcorrect.so", "ovlseq.so", "minimap2-nd", "seq_dump", "ovl_sort"), \
         "build the reference first: make -C oracle ref"
@@ -275,6 +314,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "poa.npz"), seq=np.concatenate(flat), seq_off=np.asarray(off),
                         count=np.asarray(cnt), res=np.concatenate(res), res_off=np.asarray(reso))
     print("poa: %d cases" % len(cases))
+    print("stage:", make_stage(os.path.join(HERE, "stage")))
 
 
 if __name__ == "__main__":
