@@ -29,10 +29,11 @@ namespace ndgpu {
 
 namespace {
 
+typedef uint64_t __attribute__((aligned(4))) u64_a4;  // dwordx2 loads need 4-byte alignment only
+
 __device__ __forceinline__ uint32_t fetch16(const uint32_t *__restrict__ pool, uint64_t off) {
-    const uint64_t w = off >> 4;
     const uint32_t s = (uint32_t)(off & 15u) * 2u;
-    const uint64_t v = (uint64_t)pool[w] | ((uint64_t)pool[w + 1] << 32);
+    const uint64_t v = *(const u64_a4 *)(pool + (off >> 4));
     return (uint32_t)(v >> s);
 }
 
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
 
         int row_best = -1;
         bool done = false;
+        int x_keep = 0;
         for (int ps = 0; ps < npass; ps++) {
             const int k = min_k + 2 * (ps * 64 + lane);
             const bool act = k <= max_k;
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
                 const int m = x + y;
                 row_best = m > row_best ? m : row_best;
             }
+            x_keep = x;
             if (fb) {
                 // several diagonals may finish in one step: the smallest k wins (lib/align.c:467-470)
                 const int fl = __ffsll((long long)fb) - 1;
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         const int thr = best_m - 150;
         for (int ps = 0; ps < npass; ps++) {
             const int k = min_k + 2 * (ps * 64 + lane);
-            const bool q = k < max_k && (2 * V[(uint32_t)k & vmask] - k >= thr);
+            const int xv = npass == 1 ? x_keep : V[(uint32_t)k & vmask];  // single pass: x is still in a register
+            const bool q = k < max_k && (2 * xv - k >= thr);
             const unsigned long long qb = __ballot(q);
             if (qb) {
                 new_min = min_k + 2 * (ps * 64 + (__ffsll((long long)qb) - 1));
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         }
         for (int ps = npass - 1; ps >= 0; ps--) {
             const int k = min_k + 2 * (ps * 64 + lane);
-            const bool q = k <= max_k && k > min_k && (2 * V[(uint32_t)k & vmask] - k >= thr);
+            const int xv = npass == 1 ? x_keep : V[(uint32_t)k & vmask];
+            const bool q = k <= max_k && k > min_k && (2 * xv - k >= thr);
             const unsigned long long qb = __ballot(q);
             if (qb) {
                 new_max = min_k + 2 * (ps * 64 + (63 - __clzll((long long)qb)));
