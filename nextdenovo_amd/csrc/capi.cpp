@@ -201,9 +201,12 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                     if (v > max_aln && r[0] != r[4]) max_aln = v;
                 }
                 const unsigned lq = n ? std::min<unsigned>(en[0] / 2, max_lq_length) : max_lq_length;
+                std::string seed;  // only the HiFi consensus compares against the seed's own bases
+                if (read_type == 3 && n) seed = db.window(recs[r0 * 8 + 4], recs[r0 * 8 + 5], recs[r0 * 8 + 6], 0);
                 eng[k] = new PileEngine(len.data(), dev.data(), st.data(), en.data(), (unsigned)n,
                                         make_params(max_aln, min_len_aln, max_cov_aln, min_cov, lq,
-                                                    min_error_corrected_ratio, split, fast, read_type));
+                                                    min_error_corrected_ratio, split, fast, read_type),
+                                        read_type == 3 ? seed.c_str() : nullptr);
             });
             {
                 HipBackend be(ctx, threads_each);

@@ -438,6 +438,7 @@ class PileImpl {
     std::vector<AlnJob> jobs;
     Result result;
     bool error2 = false;
+    unsigned n_aligned = 0;
 
     // state carried through the low-quality-region rounds
     std::vector<LqRegion> regions;
@@ -448,9 +449,12 @@ class PileImpl {
     struct LqSlot { int i, j, job; };  // (row, region) -> job index or -1 ('M' fill)
     std::vector<LqSlot> lq_slots;
 
+    std::string seed_copy;  // DB form, HiFi only: the seed's own bases
+
     PileImpl(const char *const *s, const unsigned *len, const int64_t *dev, const unsigned *st, const unsigned *en,
-             unsigned n, const CorrectParams &p)
+             unsigned n, const CorrectParams &p, const char *seed_ascii)
         : prm(p) {
+        if (seed_ascii) seed_copy = seed_ascii;
         lq_max_len = p.lqseq_max_length > 10000 ? 10000 : p.lqseq_max_length;  // DAG_MAX_LENGTH, nextcorrect.c:2231
         aln_start.assign(st, st + n);
         aln_end.assign(en, en + n);
@@ -523,12 +527,9 @@ class PileImpl {
             phase = PileEngine::DONE;
             return;
         }
-        if (prm.read_type == 3) {
-            fprintf(stderr, "[ndgpu] read_type=hifi consensus is not implemented in this build\n");
-            finish_error(2);
-            return;
-        }
-        if (!cns_from_best_score(path)) {
+        n_aligned = main.n_aligned;
+        const bool ok = prm.read_type == 3 ? cns_kmer(path) : cns_from_best_score(path);
+        if (!ok) {
             finish_error(2);
             return;
         }
@@ -545,12 +546,13 @@ class PileImpl {
             extract.regions[i].start = regions[i].start;
             extract.regions[i].end = regions[i].end;
             extract.regions[i].max_len = lq_max_len;
+            extract.regions[i].max_len0 = prm.read_type == 3 ? 10000 : 0;  // DAG_MAX_LENGTH, nextcorrect.c:765
         }
         phase = PileEngine::EXTRACT;
     }
 
     void after_extract() {
-        lq_max_aln_length = lqseqs_from_candidates();
+        lq_max_aln_length = prm.read_type == 3 ? lqseqs_from_candidates_kmer() : lqseqs_from_candidates();
         extract.regions.clear();
         start_lq_round();
     }
@@ -666,6 +668,357 @@ class PileImpl {
         if (!(cns.len > 2 && (double)lqseq_total_length < cns.len * 0.8 && lhs < rhs)) return false;
         std::reverse(cns.bases.begin(), cns.bases.end());
         return true;
+    }
+
+    // HiFi backtrack + LQ windows: lib/nextcorrect.c:1786-1883
+    bool cns_kmer(const std::vector<PathStep> &path) {
+        const char *seed = !seq_ptr.empty() ? seq_ptr[0] : (seed_copy.empty() ? nullptr : seed_copy.c_str());
+        if (!seed) {
+            fprintf(stderr, "[ndgpu] HiFi consensus needs the seed sequence on the host\n");
+            return false;
+        }
+        const int lq_min_length = 2, dag_min_qv = 80;
+        int p = 0, qv, lq = 0, lq_s = -1, lq_e = -1, lqseq_total_length = 0;
+        const int min_cov = (int)prm.min_cov;
+        cns = CnsData();
+        cns.bases.reserve(path.size());
+        regions.clear();
+        for (const PathStep &cur : path) {
+            if (cur.base == 4) continue;
+            cns.bases.push_back(CnsBase{(unsigned)cur.t_pos, 0});
+            const int cov = cur.cov;
+            qv = 100 * (int)cur.link / cov;
+            if (cov < 4) {
+                lq = 0;
+                lq_s = -1;
+                lqseq_total_length++;
+            } else if (qv < dag_min_qv || cur.base != base_code(seed[cur.t_pos])) {
+                if (lq_s == -1) lq_s = p;
+                lq_e = p;
+                lq = 1;
+                lqseq_total_length++;
+            } else if (lq && p - lq_e > 2 * lq_min_length && cns.bases[p].pos != cns.bases[p - 1].pos) {
+                lq_e = p - lq_min_length - 1;
+                lq_s = lq_s > lq_min_length ? lq_s - lq_min_length : 1;
+                if (!regions.empty() && cns.bases[lq_s].pos >= regions.back().start) {
+                    regions.back().start = cns.bases[lq_e].pos;
+                } else {
+                    LqRegion r;
+                    r.end = cns.bases[lq_s].pos;
+                    r.start = cns.bases[lq_e].pos;
+                    regions.push_back(std::move(r));
+                }
+                lq = 0;
+                lq_s = -1;
+            }
+            cns.bases[p].base = cov > min_cov ? (char)kIntToBase[cur.base] : (char)tolower(kIntToBase[cur.base]);
+            p++;
+        }
+        cns.len = (unsigned)p;  // uncorrected_len, lstrip, rstrip stay 0 in this variant
+        const float rhs = (float)cns.len * (1 - prm.min_error_corrected_ratio);
+        if (!(cns.len > 2 && (double)lqseq_total_length < cns.len * 0.8 && 0.0f < rhs)) return false;
+        std::reverse(cns.bases.begin(), cns.bases.end());
+        return true;
+    }
+
+    // ---- helpers of the HiFi candidate phasing (lib/nextcorrect.c:512-737)
+    struct Phs { uint16_t d = 0, s = 0; int del = 0; };
+    static bool same_seq(const LqSeq &a, const LqSeq &b) { return a.len == b.len && a.seq == b.seq; }
+
+    static int remove_differ_len(LqRegion &lq) {  // :512-539
+        int s, j, k = (int)(lq.end - lq.start + 1);
+        const int offset = std::min(std::max(30, k / 10), k / 3);
+        int8_t dif[kLqCanMax] = {0};
+        for (j = s = 0; j < lq.len; j++) {
+            if (lq.seqs[j].len + offset >= k && lq.seqs[j].len <= k + offset) s++;
+            else dif[j] = 1;
+        }
+        if (s != lq.len && (s >= lq.len / 2 || (s >= lq.len / 3 && s >= 3))) {
+            k = lq.len;
+            for (j = 0; j < lq.len && j < k; j++)
+                if (dif[j])
+                    for (k--; k > j; k--)
+                        if (!dif[k]) {
+                            std::swap(lq.seqs[j], lq.seqs[k]);
+                            break;
+                        }
+            lq.len = k;
+        }
+        return s;
+    }
+
+    static void compact_flagged(LqRegion &lq, const int8_t *dif) {  // :599-609
+        int j, k;
+        for (k = lq.len, j = 0; j < lq.len && j < k; j++)
+            if (dif[j])
+                for (k--; k > j; k--)
+                    if (!dif[k]) {
+                        std::swap(lq.seqs[j], lq.seqs[k]);
+                        break;
+                    }
+        lq.len = k;
+    }
+
+    static void select_most2(LqRegion &lq, int len, int *m1, int *m2) {  // :632-653
+        int j, k;
+        int8_t used[kLqCanMax] = {0};
+        for (*m1 = *m2 = j = 0; j < std::min(lq.len, len); j++) {
+            lq.seqs[j].kscore = 1;
+            if (used[j]) continue;
+            for (k = j + 1; k < lq.len; k++)
+                if (same_seq(lq.seqs[j], lq.seqs[k])) {
+                    used[k] = 1;
+                    lq.seqs[j].kscore++;
+                }
+            if (lq.seqs[j].kscore > lq.seqs[*m1].kscore ||
+                (lq.seqs[j].kscore == lq.seqs[*m1].kscore && lq.seqs[j].order < lq.seqs[*m1].order)) {
+                *m2 = *m1;
+                *m1 = j;
+            } else if (*m2 == *m1 || lq.seqs[j].kscore > lq.seqs[*m2].kscore) {
+                *m2 = j;
+            }
+        }
+    }
+
+    static void select_most2_with_kscore(LqRegion &lq, int len, int *m1, int *m2) {  // :656-668
+        int j;
+        for (*m1 = *m2 = j = 0; j < std::min(lq.len, len); j++) {
+            if (lq.seqs[j].kscore > lq.seqs[*m1].kscore ||
+                (lq.seqs[j].kscore == lq.seqs[*m1].kscore && lq.seqs[j].order < lq.seqs[*m1].order)) {
+                *m2 = *m1;
+                *m1 = j;
+            } else if (*m2 == *m1 || lq.seqs[j].kscore > lq.seqs[*m2].kscore) {
+                *m2 = j;
+            }
+        }
+    }
+
+    static void run_ends(const std::string &q, int *s, int *e) {  // :678-683
+        const int n = (int)q.size();
+        *s = 0;
+        while (*s + 1 < n && q[*s] == q[*s + 1]) (*s)++;
+        *e = n - 1;
+        while (*e > 0 && q[*e - 1] == q[*e]) (*e)--;
+    }
+    static int homo_end_same(const std::string &a, const std::string &b) {  // :684-697
+        int as, ae, bs, be;
+        run_ends(a, &as, &ae);
+        run_ends(b, &bs, &be);
+        if (ae <= as && be <= bs) return 1;
+        if (ae - as != be - bs) return 0;
+        for (int i = 0; i <= ae - as; i++)
+            if (a[i + as] != b[i + bs]) return 0;
+        return 1;
+    }
+    static int prefixhomo_same(const std::string &a, const std::string &b) {  // :699-714
+        int i = 0, j = 0;
+        const int na = (int)a.size(), nb = (int)b.size();
+        while (i < na && j < nb) {
+            if (a[i] != b[j]) return 0;
+            while (i + 1 < na && a[i] == a[i + 1]) i++;
+            while (j + 1 < nb && b[j] == b[j + 1]) j++;
+            i++;
+            j++;
+        }
+        return 1;
+    }
+    static int trim_endssr_same(const std::string &x, const std::string &y) {  // :716-737
+        const std::string *a = &x, *b = &y;
+        if (a->size() < b->size()) std::swap(a, b);
+        const int na = (int)a->size(), nb = (int)b->size();
+        int i;
+        for (i = 0; i < nb; i++)
+            if ((*a)[i] != (*b)[i]) return 0;
+        for (int j = na - 1; j >= i; j--)
+            if ((*a)[j] != (*b)[nb - (na - j)]) return 0;
+        return 1;
+    }
+
+    // HiFi: generate_lqseqs_from_tags_kmer, lib/nextcorrect.c:740-1008, on the extracted candidates
+    int lqseqs_from_candidates_kmer() {
+        int max_aln_length = 0, max_aln_lqseq_len = 0;
+        int s = 0, k = 0, j, index;
+        for (size_t ri = 0; ri < regions.size(); ri++) {
+            LqRegion &lq = regions[ri];
+            RegionReq &rq = extract.regions[ri];
+            lq.len = 0;
+            lq.seqs.clear();
+            lq.has_seed = false;
+            for (size_t c = 0; c < rq.cands.size(); c++) {
+                LqSeq q;
+                q.len = (uint16_t)rq.cands[c].size();
+                q.order = rq.cand_rank[c];  // source read
+                q.kscore = 0;
+                if ((int)q.len > max_aln_lqseq_len) max_aln_lqseq_len = q.len;
+                q.seq = std::move(rq.cands[c]);
+                lq.seqs.push_back(std::move(q));
+                lq.len++;
+            }
+        }
+        std::vector<Phs> phase(n_aligned ? n_aligned : 1);
+        int has_heter = 0;
+        for (LqRegion &lq : regions) {  // heterozygous sites first (:789-810)
+            if (!lq.len) continue;
+            select_most2(lq, lq.len, &s, &k);
+            if (s != k && lq.seqs[k].kscore >= 3 && lq.seqs[s].len == lq.seqs[k].len) {
+                if (s == 0 || k == 0) {
+                    const int heter = s == 0 ? k : s;
+                    for (j = 0; j < lq.len; j++) {
+                        index = lq.seqs[j].order;
+                        if (same_seq(lq.seqs[0], lq.seqs[j])) phase[index].s++;
+                        else if (same_seq(lq.seqs[heter], lq.seqs[j])) phase[index].d++;
+                    }
+                }
+                lq.indexs = 1;
+            } else lq.indexs = 0;
+            if (!has_heter && (lq.indexs == 1 ||
+                               (s != k && lq.seqs[k].kscore >= 5 &&
+                                lq.seqs[s].kscore + lq.seqs[k].kscore >= lq.len * 0.8 &&
+                                !prefixhomo_same(lq.seqs[s].seq, lq.seqs[k].seq))))
+                has_heter = 1;
+        }
+        if (has_heter && !phase[0].s) {  // :812-854
+            for (LqRegion &lq : regions) {
+                if (!lq.len) continue;
+                select_most2_with_kscore(lq, lq.len, &s, &k);
+                if (s != k && lq.seqs[k].kscore >= 5 && (lq.seqs[s].kscore + lq.seqs[k].kscore) >= lq.len * 0.8 &&
+                    (lq.seqs[s].len >= lq.seqs[k].len + 5 || lq.seqs[k].len >= lq.seqs[s].len + 5 ||
+                     !prefixhomo_same(lq.seqs[s].seq, lq.seqs[k].seq))) {
+                    int s_, k_;
+                    if (s == 0) { s_ = 1; k_ = 0; }
+                    else if (k == 0) { s_ = 0; k_ = 1; }
+                    else {
+                        s_ = homo_end_same(lq.seqs[s].seq, lq.seqs[0].seq) || trim_endssr_same(lq.seqs[s].seq, lq.seqs[0].seq) ||
+                             prefixhomo_same(lq.seqs[s].seq, lq.seqs[0].seq);
+                        k_ = homo_end_same(lq.seqs[k].seq, lq.seqs[0].seq) || trim_endssr_same(lq.seqs[k].seq, lq.seqs[0].seq) ||
+                             prefixhomo_same(lq.seqs[k].seq, lq.seqs[0].seq);
+                    }
+                    int same, heter;
+                    if (s_ && !k_) { same = s; heter = k; }
+                    else if (k_ && !s_) { same = k; heter = s; }
+                    else continue;
+                    for (j = 0; j < lq.len; j++) {
+                        index = lq.seqs[j].order;
+                        if (same_seq(lq.seqs[same], lq.seqs[j])) phase[index].s++;
+                        else if (same_seq(lq.seqs[heter], lq.seqs[j])) phase[index].d++;
+                    }
+                    lq.indexs = 2;
+                } else lq.indexs = 0;
+            }
+        }
+        for (LqRegion &lq : regions) {  // mark_del_lqseq, :570-588
+            if (!lq.len) continue;
+            int kk = 0;
+            for (j = 1; j < lq.len; j++) {
+                const int i = lq.seqs[j].order;
+                if (phase[i].s >= 3 && !phase[i].d) kk++;
+            }
+            for (j = 0; j < lq.len; j++) {
+                const int i = lq.seqs[j].order;
+                if (kk >= 2) {
+                    if (phase[i].d) phase[i].del = 1;
+                } else if (phase[i].s < phase[i].d || phase[i].d >= 3) phase[i].del = 1;
+            }
+        }
+        for (LqRegion &lq : regions) {  // remove_differ_phase_lqseq, :590-610
+            if (!lq.len) continue;
+            int8_t dif[kLqCanMax] = {0};
+            for (j = 0; j < lq.len; j++)
+                if (phase[lq.seqs[j].order].del) dif[j] = 1;
+            compact_flagged(lq, dif);
+        }
+        std::vector<uint16_t> bins(kKmerBins);
+        for (LqRegion &lq : regions) {  // :874-984
+            if (!lq.len) continue;
+            select_most2(lq, lq.len, &s, &k);
+            index = lq.seqs[s].order;
+            if (lq.indexs && s != k && s != 0 && lq.seqs[k].kscore >= 3 && phase[index].s >= phase[index].d + 3) {
+                int sp = 0, kp = 0;
+                for (j = 1; j < lq.len; j++) {
+                    index = lq.seqs[j].order;
+                    if (phase[index].d >= 3) continue;
+                    if (same_seq(lq.seqs[s], lq.seqs[j])) sp += phase[index].s - phase[index].d;
+                    else if (same_seq(lq.seqs[k], lq.seqs[j])) kp += phase[index].s - phase[index].d;
+                }
+                if (sp < kp) s = k;
+            } else if (lq.seqs[0].len > 50 && lq.seqs[s].kscore < lq.len / 3 && lq.seqs[s].kscore < 3) {
+                const int sl = remove_differ_len(lq);
+                if (sl <= 3) {  // large length SD: keep the seed's own version
+                    s = 0;
+                    lq.seqs[s].kscore = 65534;
+                }
+            }
+            if (lq.seqs[s].kscore > 2 || lq.seqs[s].kscore >= lq.len / 2) {
+                lq.sudoseed = lq.seqs[s].seq;
+                lq.sudoseed_len = lq.seqs[s].len;
+                lq.has_seed = true;
+                if (lq.seqs[s].kscore < lq.len / 2)
+                    for (char &ch : lq.sudoseed) ch = (char)tolower(ch);
+                lq.len = -2;
+            } else {
+                remove_differ_len(lq);
+                if (lq.len > 4) {
+                    std::stable_sort(lq.seqs.begin(), lq.seqs.begin() + lq.len,
+                                     [](const LqSeq &a, const LqSeq &b) { return a.len < b.len; });  // compare_seq_by_len
+                    k = lq.len / 2;
+                    while (lq.len > k && (lq.seqs[lq.len - 1].len > 2 * lq.seqs[k].len ||
+                                          lq.seqs[lq.len - 1].len >= 1.4 * lq.seqs[lq.len - 2].len))
+                        lq.len--;
+                    if (k == lq.len) { lq.len = 0; continue; }
+                    j = 0;
+                    k = lq.len / 2;
+                    if (lq.seqs[j].len < lq.seqs[k].len / 2) {
+                        std::reverse(lq.seqs.begin(), lq.seqs.begin() + lq.len);
+                        while (lq.seqs[lq.len - 1].len < lq.seqs[k].len / 2) lq.len--;
+                        if (k == lq.len) { lq.len = 0; continue; }
+                    }
+                }
+                count_kmers(lq, bins.data(), kLqCanMax, 0);
+                count_kscore(lq, bins.data(), 0);
+                unsigned klastscore, kmaxscore;
+                unsigned kmaxlen = lq.seqs[0].len;
+                if (kmaxlen > 100) {
+                    uint16_t saved[65536 / 256];  // indexed by source-read rank (< aligned reads)
+                    std::vector<uint16_t> big;
+                    uint16_t *sv = saved;
+                    if (n_aligned > sizeof(saved) / sizeof(saved[0])) { big.resize(n_aligned); sv = big.data(); }
+                    for (j = 0; j < lq.len; j++) sv[lq.seqs[j].order] = lq.seqs[j].kscore;
+                    count_kmers(lq, bins.data(), kLqCanMax, 1);
+                    count_kscore(lq, bins.data(), 1);
+                    for (j = 0; j < lq.len; j++) lq.seqs[j].kscore = (uint16_t)(lq.seqs[j].kscore + sv[lq.seqs[j].order]);
+                }
+                sort_by_kscore_desc(lq);
+                kmaxlen = lq.seqs[0].len;
+                klastscore = kmaxscore = lq.seqs[0].kscore;
+                for (k = j = 0; j < lq.len; j++) {
+                    const unsigned ks = lq.seqs[j].kscore;
+                    if (ks * 10 < kmaxscore || j >= kLqSeqMax || ks * 2 < klastscore) break;
+                    klastscore = ks;
+                    if (j < kKmerMaxSeq && ks > kmaxscore * 0.8 && lq.seqs[j].len > kmaxlen) {
+                        kmaxlen = lq.seqs[j].len;
+                        k = j;
+                    }
+                }
+                lq.indexs = 0;
+                lq.indexe = (uint8_t)(kmaxlen > (unsigned)kLqRevLen && j > 6 ? 5 : j - 1);
+                if ((int)lq.indexe - (int)lq.indexs <= 1 || (lq.seqs[0].len > 20000 && lq.len < kLqCanMax / 3)) {
+                    lq.len = 0;
+                    continue;
+                }
+                j = lq.indexs;
+                if (lq.seqs[0].len < 3000) k = j + 6 < lq.indexe ? 6 : lq.indexe - j + 1;
+                else k = j + 2 < lq.indexe ? 2 : lq.indexe - j + 1;
+                if (lq.seqs[0].len < 20000) {
+                    std::vector<std::string> in;
+                    for (int x = 0; x < k; x++) in.push_back(lq.seqs[j + x].seq);
+                    lq.sudoseed = poa_consensus(in);
+                } else lq.sudoseed = lq.seqs[0].seq;
+                lq.has_seed = true;
+                lq.sudoseed_len = (unsigned)lq.sudoseed.size();
+            }
+            if (max_aln_lqseq_len + (int)lq.sudoseed_len > max_aln_length) max_aln_length = max_aln_lqseq_len + (int)lq.sudoseed_len;
+        }
+        return max_aln_length;
     }
 
     // lib/nextcorrect.c:356-510 with the candidate strings (lines 373-404) already
@@ -946,6 +1299,26 @@ class PileImpl {
         unsigned olen = (unsigned)out.size();
         if (lq_i < kLqRegMax + 1 && lq[lq_i].end == olen - 1) lq_i++;
 
+        if (prm.read_type == 3) {
+            unsigned a = 0, z = 0, lq_total_len = 0;
+            while (a < olen && out[a] >= 'a') a++;
+            while (z < olen && out[olen - 1 - z] >= 'a') z++;
+            if (a + z < olen) {
+                if (a > 0 || z > 0) out = out.substr(a, olen - a - z);
+                const int removed = (int)(a + z);
+                for (int q = 0; q < lq_i && q < kLqRegMax + 1; q++) lq_total_len += lq[q].lq_total_len;
+                result.len = (unsigned)out.size();
+                result.seq = out;
+                result.identity = 1 - (float)(lq_total_len - (unsigned)removed) / result.len;
+            } else {
+                result.len = 2;
+                result.identity = 0;
+                result.seq.clear();
+            }
+            if (result.len > 1000 && result.identity > 0.8) trim_terminal_ssr(result);
+            phase = PileEngine::DONE;
+            return;
+        }
         if (lq_i) {
             lq_m = 0;
             hq_m = lq[0].start;
@@ -1001,10 +1374,10 @@ class PileImpl {
 
 PileEngine::PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
                        const CorrectParams &prm)
-    : impl_(new PileImpl(seqs, nullptr, nullptr, aln_start, aln_end, seq_count, prm)) {}
+    : impl_(new PileImpl(seqs, nullptr, nullptr, aln_start, aln_end, seq_count, prm, nullptr)) {}
 PileEngine::PileEngine(const unsigned *seq_len, const int64_t *dev_off, const unsigned *aln_start,
-                       const unsigned *aln_end, unsigned seq_count, const CorrectParams &prm)
-    : impl_(new PileImpl(nullptr, seq_len, dev_off, aln_start, aln_end, seq_count, prm)) {}
+                       const unsigned *aln_end, unsigned seq_count, const CorrectParams &prm, const char *seed)
+    : impl_(new PileImpl(nullptr, seq_len, dev_off, aln_start, aln_end, seq_count, prm, seed)) {}
 PileEngine::~PileEngine() { delete impl_; }
 PileEngine::Phase PileEngine::phase() const { return impl_->phase; }
 MainPile *PileEngine::main_request() { return &impl_->main; }

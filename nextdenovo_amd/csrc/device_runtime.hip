@@ -820,6 +820,7 @@ void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
             g.start = r.start;
             g.end = r.end;
             g.max_len = r.max_len;
+            g.max_len0 = r.max_len0 ? r.max_len0 : r.max_len;
             regs.push_back(g);
         }
     if (regs.empty()) return;
@@ -857,7 +858,11 @@ void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
             const RegionDev &g = regs[k++];
             r.n_large = g.n_large;
             r.cands.resize(g.n_ok);
-            for (uint32_t c = 0; c < g.n_ok; c++) r.cands[c].assign(hstr.data() + g.cand_off[c], g.cand_len[c]);
+            r.cand_rank.resize(g.n_ok);
+            for (uint32_t c = 0; c < g.n_ok; c++) {
+                r.cands[c].assign(hstr.data() + g.cand_off[c], g.cand_len[c]);
+                r.cand_rank[c] = g.cand_rank[c];
+            }
         }
 }
 

@@ -848,12 +848,13 @@ __global__ __launch_bounds__(64) void extract_kernel(const PileDev *__restrict__
     const PileDev P = piles[G.pile];
     const int lane = (int)threadIdx.x;
     const uint32_t *acc = acc_list + P.acc_off;
-    const uint32_t start = G.start, end = G.end, max_len = G.max_len;
+    const uint32_t start = G.start, end = G.end;
     uint32_t ok_total = 0, large = 0;
     for (uint32_t r0 = 0; r0 < P.n_acc && ok_total < 40u; r0 += 64) {
         const uint32_t rank = r0 + (uint32_t)lane;
         int status = 0;  // 1: candidate, 2: longer than max_len - 1
         uint32_t len = 0, i0 = 0, i1 = 0;
+        const uint32_t max_len = rank == 0 ? G.max_len0 : G.max_len;
         const uint32_t *tg = nullptr;
         if (rank < P.n_acc) {
             const ReadDev *R = &reads[acc[rank]];
@@ -886,6 +887,7 @@ __global__ __launch_bounds__(64) void extract_kernel(const PileDev *__restrict__
             const unsigned long long off = atomicAdd(cursor, (unsigned long long)len);
             G.cand_off[slot] = (uint32_t)off;
             G.cand_len[slot] = (uint16_t)len;
+            G.cand_rank[slot] = (uint16_t)rank;
             if (off + len <= cap) {
                 uint32_t k = 0;
                 for (uint32_t i = i0; i < i1; i++) {

@@ -114,11 +114,13 @@ struct RegionDev {          // low-quality region whose candidate strings are wa
     uint32_t pile;
     uint32_t start, end;    // inclusive seed columns
     uint32_t max_len;       // lqseq_max_length
+    uint32_t max_len0;      // limit for the seed's own candidate (HiFi: DAG_MAX_LENGTH, else = max_len)
     // outputs
     uint32_t n_ok;          // candidates written (<= 40)
     uint32_t n_large;       // reads that exceeded max_len before the 40th candidate
     uint32_t cand_off[40];  // byte offsets into the string pool
     uint16_t cand_len[40];
+    uint16_t cand_rank[40]; // position of the source read among the pile's aligned reads
 };
 
 constexpr int kColBlock = 32;          // columns per link-counting work item

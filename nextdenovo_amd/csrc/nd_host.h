@@ -78,7 +78,9 @@ struct MainPile {
 struct RegionReq {
     unsigned start = 0, end = 0;         // inclusive seed columns
     unsigned max_len = 0;                // lqseq_max_length
+    unsigned max_len0 = 0;               // limit for the seed's own candidate (0: same as max_len)
     std::vector<std::string> cands;      // <= 40, in pile order
+    std::vector<uint16_t> cand_rank;     // source read of each candidate (index among aligned reads)
     unsigned n_large = 0;                // reads longer than max_len - 1 seen before the 40th candidate
 };
 
@@ -124,9 +126,10 @@ class PileEngine {
     // ASCII form (the nextCorrect ABI): seqs[i] NUL-terminated.
     PileEngine(const char *const *seqs, const unsigned *aln_start, const unsigned *aln_end, unsigned seq_count,
                const CorrectParams &prm);
-    // Resident-DB form: only lengths and ReadDb pool offsets, no host copy of the reads.
+    // Resident-DB form: only lengths and ReadDb pool offsets, no host copy of the reads
+    // (`seed` = ASCII copy of the seed itself, needed by the HiFi consensus only; may be null).
     PileEngine(const unsigned *seq_len, const int64_t *dev_off, const unsigned *aln_start, const unsigned *aln_end,
-               unsigned seq_count, const CorrectParams &prm);
+               unsigned seq_count, const CorrectParams &prm, const char *seed = nullptr);
     ~PileEngine();
     PileEngine(const PileEngine &) = delete;
     PileEngine &operator=(const PileEngine &) = delete;

@@ -109,18 +109,26 @@ class OracleBackend : public Backend {
             const auto &reads = kept[piles[p]->slot];
             for (RegionReq &rq : piles[p]->regions) {
                 rq.cands.clear();
+                rq.cand_rank.clear();
                 rq.n_large = 0;
+                const unsigned lim0 = rq.max_len0 ? rq.max_len0 : rq.max_len;
+                unsigned rank = 0;
                 const int start = (int)rq.start, end = (int)rq.end;
-                for (const auto &tg : reads) {  // lib/nextcorrect.c:373-404
+                for (const auto &tg : reads) {  // lib/nextcorrect.c:373-404 (and :757-784 for HiFi)
+                    const unsigned lim = rank == 0 ? lim0 : rq.max_len;
+                    const unsigned my_rank = rank++;
                     if (!(tg.front().t_pos <= start && tg.back().t_pos >= end)) continue;
                     std::string s;
                     bool too_long = false;
                     for (size_t k = (size_t)(start - tg.front().t_pos); k < tg.size() && tg[k].t_pos <= end; k++)
                         if (tg[k].t_pos >= start && tg[k].base != 4) {
                             s.push_back(kI2B[tg[k].base]);
-                            if (s.size() > rq.max_len - 1) { rq.n_large++; too_long = true; break; }
+                            if (s.size() > lim - 1) { rq.n_large++; too_long = true; break; }
                         }
-                    if (!s.empty() && !too_long) rq.cands.push_back(std::move(s));
+                    if (!s.empty() && !too_long) {
+                        rq.cands.push_back(std::move(s));
+                        rq.cand_rank.push_back((uint16_t)my_rank);
+                    }
                     if (rq.cands.size() >= 40) break;
                 }
             }

@@ -163,9 +163,28 @@ def make_piles(lib):
     code_of = np.full(256, 255, dtype=np.uint8)
     for i, ch in enumerate(b"ACGT"):
         code_of[ch] = i
-    for prof, preset, rt, gseed in (("ont", "ava-ont", 1, 11), ("clr", "ava-pb", 2, 12)):
+    for prof, preset, rt, gseed in (("ont", "ava-ont", 1, 11), ("clr", "ava-pb", 2, 12), ("hifi", "ava-hifi", 3, 13)):
         g = synth.make_genome(36000, seed=gseed, n_repeats=0)
-        rs = synth.simulate_reads(g, 32, prof, seed=gseed + 100, mu=8.0, sigma=0.35, min_len=1000)
+        if prof == "hifi":
+            # two haplotypes (SNPs + small indels + a homopolymer length difference every ~400 bp):
+            # exercises the phasing branches of generate_lqseqs_from_tags_kmer (nextcorrect.c:789-898)
+            rng = np.random.default_rng(gseed)
+            h2 = g.copy()
+            for pos in range(300, g.size - 300, 400):
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    h2[pos] = (h2[pos] + 1 + int(rng.integers(0, 3))) & 3
+                elif kind == 1:
+                    h2 = np.concatenate([h2[:pos], rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8), h2[pos:]])
+                else:
+                    h2[pos:pos + 6] = h2[pos]
+                    h2 = np.concatenate([h2[:pos], h2[pos:pos + 2], h2[pos:]])
+            r1 = synth.simulate_reads(g, 16, prof, seed=gseed + 100, mu=8.2, sigma=0.3, min_len=1000)
+            r2 = synth.simulate_reads(h2, 16, prof, seed=gseed + 200, mu=8.2, sigma=0.3, min_len=1000)
+            rs = synth.ReadSet()
+            rs.seqs = r1.seqs + r2.seqs
+        else:
+            rs = synth.simulate_reads(g, 32, prof, seed=gseed + 100, mu=8.0, sigma=0.35, min_len=1000)
         wd = tempfile.mkdtemp(prefix="ndgold")
         fa = os.path.join(wd, "reads.fa")
         refpipe.write_fasta(fa, [synth.codes_to_ascii(s) for s in rs.seqs])
@@ -178,6 +197,8 @@ def make_piles(lib):
                 variants += [(1, 0), (0, 1)]  # -fast and -s
             for fast, split in variants:
                 mlq = min(en[0] // 2, 10000 if prof == "ont" else 1000)
+                if prof == "hifi" and (fast or split):
+                    continue
                 ln, ide, seq = refpipe.call_nextcorrect(lib, seqs, st, en, mal, max_lq_length=mlq, split=split,
                                                         fast=fast, read_type=rt)
                 for s in seqs:

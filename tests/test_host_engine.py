@@ -22,7 +22,7 @@ def test_golden_piles(host_harness):
         if ln > 4:
             assert seq == p["exp_seq"], i
             assert np.float32(ide) == np.float32(p["exp_ide"]), i
-    assert {(1, 0, 0), (2, 0, 0), (1, 1, 0), (1, 0, 1)} <= seen
+    assert {(1, 0, 0), (2, 0, 0), (3, 0, 0), (1, 1, 0), (1, 0, 1)} <= seen
 
 
 def test_poa_golden(host_harness):
