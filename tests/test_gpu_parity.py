@@ -125,6 +125,28 @@ def test_db_path_equals_ascii_path_and_host_oracle(lib, host_harness):
         assert np.float32(a[1]) == np.float32(g[1]) == np.float32(c[1])
 
 
+def test_hifi_db_path_equals_ascii_path_and_host_oracle(lib, host_harness):
+    """read_type=3 (align_hq + k-mer phasing consensus) through the resident-DB entry."""
+    from nextdenovo_amd import api, synth
+    g = synth.make_genome(30000, seed=71, n_repeats=0)
+    rs = synth.simulate_reads(g, 30, "hifi", seed=72, mu=8.3, sigma=0.3)
+    piles = synth.build_piles(rs, seed_cutoff=1000)[:8]
+    words, off, lens = synth.pack_db(rs)
+    db = api.ReadDB(words, off, lens)
+    recs, poff = synth.flatten_piles(piles)
+    got = db.correct_piles(recs, poff, read_type=3, max_lq_length=1000, host_threads=4)
+    db.close()
+    fn, fr = util.bind_correct(host_harness, "ndtest_correct", "ndtest_free")
+    for p, g_ in zip(piles, got):
+        seqs, st, en, mal = synth.pile_sequences(rs, p)
+        mlq = min(en[0] // 2, 1000)
+        a = api.correct(seqs, st, en, mal, max_lq_length=mlq, read_type=3)
+        c = util.call_correct(fn, fr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal, max_lq=mlq, read_type=3,
+                                           fast=0, split=0))
+        assert a[0] == g_[0] == c[0] and a[0] > 1000
+        assert a[2] == g_[2] == c[2]
+
+
 def test_full_size_properties(lib, host_harness):
     """BASELINE config-2 sized reads (lognormal mu 9.55: 10-60 kb overlaps).  Size-independent
     properties: every alignment's two rows spell its inputs back (round trip), and a
