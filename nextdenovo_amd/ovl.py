@@ -83,3 +83,36 @@ def load_read_db(idx_fofn: str):
     rlen[ids] = np.concatenate(lens).astype(np.uint32)
     words = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint32)
     return words, word_off, rlen
+
+
+def read_2bit(path: str):
+    """One `.2bit` file -> (ids uint32[n], lens uint32[n], words uint32, word_off uint64[n]) in file
+    order (lib/bseq.c:257-299 kbit_read: u32 id, u32 len, ceil(len/16) words per read)."""
+    data = np.fromfile(path, dtype=np.uint8)
+    w = np.frombuffer(data[2:2 + ((data.size - 2) // 4) * 4].tobytes(), dtype=np.uint32)
+    ids, lens, offs = [], [], []
+    p = 0
+    while p + 2 <= w.size:
+        rid, ln = int(w[p]), int(w[p + 1])
+        ids.append(rid)
+        lens.append(ln)
+        offs.append(p + 2)
+        p += 2 + ((ln - 1) >> 4) + 1
+    return (np.asarray(ids, dtype=np.uint32), np.asarray(lens, dtype=np.uint32), w,
+            np.asarray(offs, dtype=np.uint64))
+
+
+def unpack_codes(words: np.ndarray, word_off: np.ndarray, lens: np.ndarray):
+    """2-bit words (16 bases per u32, first base in the top bits) -> (codes uint8, off uint64[n])."""
+    lens = np.asarray(lens, dtype=np.int64)
+    off = np.zeros(lens.size, dtype=np.uint64)
+    if lens.size:
+        off[1:] = np.cumsum(lens)[:-1]
+    out = np.empty(int(lens.sum()), dtype=np.uint8)
+    sh = (30 - 2 * np.arange(16)).astype(np.uint32)
+    for i in range(lens.size):
+        n = int(lens[i])
+        cnt = (n + 15) >> 4
+        ws = words[int(word_off[i]): int(word_off[i]) + cnt]
+        out[int(off[i]): int(off[i]) + n] = ((ws[:, None] >> sh[None, :]) & 3).astype(np.uint8).reshape(-1)[:n]
+    return out, off

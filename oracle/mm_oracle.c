@@ -1,0 +1,631 @@
+/* mm_oracle.c -- CPU restatement of the `minimap2-nd --step 1` overlap path (TEST INFRASTRUCTURE ONLY).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file; the
+ * product (nextdenovo_amd/) never does.
+ *
+ * Each function follows one routine of the reference tree (NextDenovo v2.5.2, minimap2 2.17 fork):
+ *   nd_mm_sketch      minimap2/sketch.c:75-143   (mm_sketch_shortkmer, k <= 28, ACGT-only input)
+ *   nd_mm_index_*     minimap2/index.c:81-98,170-191,197-250  (mm_idx_get / mm_idx_cal_max_occ / worker_post)
+ *   nd_mm_rs_sort128  minimap2/ksort.h:100-151   (KRADIX_SORT_INIT: in-place, UNSTABLE MSD radix sort;
+ *                     the order it leaves equal keys in is part of the result)
+ *   nd_mm_seeds       minimap2/map.c:91-127 (collect_matches), :129-152 (skip_seed), :214-246 (collect_seed_hits)
+ *   nd_mm_chain       minimap2/chain.c:22-162   (mm_chain_dp)
+ *   nd_mm_gen_regs    minimap2/hit.c:8-95        (mm_cal_fuzzy_len, mm_reg_set_coor, mm_gen_regs)
+ *   nd_mm_map_read    minimap2/map.c:506-576     (mm_map_frag, n_segs == 1, no CIGAR, mode != 3)
+ *   nd_mm_encode      lib/ovl.c:109-150          (encode_ovl) + minimap2/map.c:1296-1304 (step-1 filter)
+ *
+ * Pinned against the compiled reference binary oracle/_ref/minimap2-nd (tests/test_overlap_oracle.py:
+ * byte-identical .ovl on seeded read sets, ava-ont and ava-pb, with and without --dual=yes).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+typedef struct { uint64_t x, y; } nd_mm128;
+
+typedef struct {
+	int32_t k, w, hpc;
+	int32_t no_diag, no_dual;
+	int32_t min_cnt, min_sc, bw, max_gap, max_skip, max_iter;
+	int32_t minlen, seed;
+	int32_t dvt, maxhan1, maxhan2;
+} nd_mm_opt;
+
+typedef struct {
+	int32_t rev, rid, qs, qe, rs, re, mlen, blen, score, cnt, as;
+	uint32_t hash;
+} nd_mm_reg;
+
+#define NONE64 UINT64_MAX
+
+/* ---------------------------------------------------------------- hashes */
+
+static uint64_t mix64(uint64_t key, uint64_t mask) /* sketch.c:29-39 */
+{
+	key = (~key + (key << 21)) & mask;
+	key ^= key >> 24;
+	key = (key + (key << 3) + (key << 8)) & mask;
+	key ^= key >> 14;
+	key = (key + (key << 2) + (key << 4)) & mask;
+	key ^= key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+static uint32_t wang32(uint32_t key) /* khash.h:400-409 */
+{
+	key += ~(key << 15); key ^= key >> 10; key += key << 3;
+	key ^= key >> 6; key += ~(key << 11); key ^= key >> 16;
+	return key;
+}
+
+static uint32_t x31_str(const char *s) /* khash.h:383-388 */
+{
+	uint32_t h = (uint32_t)*s;
+	if (h) for (++s; *s; ++s) h = (h << 5) - h + (uint32_t)*s;
+	return h;
+}
+
+/* ---------------------------------------------------------------- sketch */
+
+/* codes[i] in 0..3 (reads come from .2bit files: no ambiguous bases).  out needs room for len+1 entries. */
+int64_t nd_mm_sketch(const uint8_t *codes, int len, int w, int k, uint32_t rid, int hpc, nd_mm128 *out)
+{
+	const uint64_t mask = (1ULL << 2 * k) - 1, top = 2ULL * (k - 1);
+	uint64_t fw = 0, rv = 0;
+	nd_mm128 ring[256], best = { NONE64, NONE64 };
+	int runq[32], rq_front = 0, rq_count = 0; /* last k homopolymer run lengths */
+	int i, j, good = 0, slot = 0, best_slot = 0, span = 0;
+	int64_t n = 0;
+	if (len <= 0 || w <= 0 || w >= 256 || k <= 0 || k > 28) return -1;
+	memset(ring, 0xff, sizeof(nd_mm128) * w);
+	for (i = 0; i < len; ++i) {
+		int c = codes[i], strand;
+		nd_mm128 cur = { NONE64, NONE64 };
+		if (hpc) {
+			int run = 1;
+			if (i + 1 < len && codes[i + 1] == c) {
+				for (run = 2; i + run < len; ++run)
+					if (codes[i + run] != c) break;
+				i += run - 1;
+			}
+			runq[(rq_count++ + rq_front) & 31] = run;
+			span += run;
+			if (rq_count > k) { span -= runq[rq_front]; rq_front = (rq_front + 1) & 31; --rq_count; }
+		} else span = good + 1 < k ? good + 1 : k;
+		fw = (fw << 2 | (uint64_t)c) & mask;
+		rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+		if (fw == rv) continue; /* palindromic k-mer: nothing is stored, the window does not advance */
+		strand = fw < rv ? 0 : 1;
+		++good;
+		if (good >= k && span < 256) {
+			cur.x = mix64(strand ? rv : fw, mask) << 8 | (uint64_t)span;
+			cur.y = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)strand;
+		}
+		ring[slot] = cur;
+		if (good == w + k - 1 && best.x != NONE64) { /* first full window: emit earlier copies of the minimum */
+			for (j = slot + 1; j < w; ++j) if (ring[j].x == best.x && ring[j].y != best.y) out[n++] = ring[j];
+			for (j = 0; j < slot; ++j) if (ring[j].x == best.x && ring[j].y != best.y) out[n++] = ring[j];
+		}
+		if (cur.x <= best.x) {
+			if (good >= w + k && best.x != NONE64) out[n++] = best;
+			best = cur, best_slot = slot;
+		} else if (slot == best_slot) { /* the minimum left the window: emit it and rescan */
+			if (good >= w + k - 1 && best.x != NONE64) out[n++] = best;
+			best.x = NONE64;
+			for (j = slot + 1; j < w; ++j) if (ring[j].x <= best.x) best = ring[j], best_slot = j;
+			for (j = 0; j <= slot; ++j) if (ring[j].x <= best.x) best = ring[j], best_slot = j;
+			if (good >= w + k - 1 && best.x != NONE64) {
+				for (j = slot + 1; j < w; ++j) if (ring[j].x == best.x && ring[j].y != best.y) out[n++] = ring[j];
+				for (j = 0; j <= slot; ++j) if (ring[j].x == best.x && ring[j].y != best.y) out[n++] = ring[j];
+			}
+		}
+		if (++slot == w) slot = 0;
+	}
+	if (best.x != NONE64) out[n++] = best;
+	return n;
+}
+
+/* ---------------------------------------------------------------- the reference's radix sort */
+
+#define LEAF 64 /* RS_MIN_SIZE */
+
+static void ins128(nd_mm128 *a, nd_mm128 *e)
+{
+	nd_mm128 *i, *j;
+	for (i = a + 1; i < e; ++i)
+		if (i->x < (i - 1)->x) {
+			nd_mm128 t = *i;
+			for (j = i; j > a && t.x < (j - 1)->x; --j) *j = *(j - 1);
+			*j = t;
+		}
+}
+
+static void flag128(nd_mm128 *beg, nd_mm128 *end, int shift)
+{
+	nd_mm128 *head[256], *tail[256], *p;
+	int d;
+	for (d = 0; d < 256; ++d) head[d] = tail[d] = beg;
+	for (p = beg; p != end; ++p) ++tail[p->x >> shift & 255];
+	for (d = 1; d < 256; ++d) tail[d] += tail[d - 1] - beg, head[d] = tail[d - 1];
+	for (d = 0; d < 256;) {
+		if (head[d] == tail[d]) { ++d; continue; }
+		int to = (int)(head[d]->x >> shift & 255);
+		if (to == d) { ++head[d]; continue; }
+		nd_mm128 hand = *head[d];
+		do { /* drop the element in hand at the front of its bucket, pick up what was there */
+			nd_mm128 put = hand;
+			hand = *head[to];
+			*head[to]++ = put;
+			to = (int)(hand.x >> shift & 255);
+		} while (to != d);
+		*head[d]++ = hand;
+	}
+	if (shift) {
+		nd_mm128 *lo = beg;
+		int next = shift > 8 ? shift - 8 : 0;
+		for (d = 0; d < 256; ++d) {
+			long sz = tail[d] - lo;
+			if (sz > LEAF) flag128(lo, tail[d], next);
+			else if (sz > 1) ins128(lo, tail[d]);
+			lo = tail[d];
+		}
+	}
+}
+
+void nd_mm_rs_sort128(nd_mm128 *a, int64_t n)
+{
+	if (n <= LEAF) ins128(a, a + n);
+	else flag128(a, a + n, 56);
+}
+
+static int cmp_u64(const void *a, const void *b)
+{
+	uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+	return x < y ? -1 : x > y;
+}
+
+/* ---------------------------------------------------------------- index */
+
+typedef struct {
+	int64_t n;        /* minimizers */
+	int64_t n_keys;
+	uint64_t *key;    /* distinct x>>8, ascending */
+	int64_t *start;   /* n_keys + 1 */
+	uint64_t *pos;    /* y values, ascending inside a key */
+	int32_t n_reads;
+	uint32_t *len;
+	char (*name)[12];
+} nd_mm_index;
+
+static int cmp_minier(const void *a, const void *b)
+{
+	const nd_mm128 *p = (const nd_mm128*)a, *q = (const nd_mm128*)b;
+	if (p->x >> 8 != q->x >> 8) return p->x >> 8 < q->x >> 8 ? -1 : 1;
+	return p->y < q->y ? -1 : p->y > q->y;
+}
+
+/* reads: 2-bit codes one per byte, concatenated; off[i] = start of read i; ids[i] = numeric read name */
+nd_mm_index *nd_mm_index_build(int32_t n_reads, const uint8_t *codes, const uint64_t *off, const uint32_t *len,
+                               const uint32_t *ids, int w, int k, int hpc)
+{
+	nd_mm_index *ix = (nd_mm_index*)calloc(1, sizeof(nd_mm_index));
+	int64_t cap = 0, n = 0, i, j;
+	nd_mm128 *all;
+	for (i = 0; i < n_reads; ++i) cap += (int64_t)len[i] + 1;
+	all = (nd_mm128*)malloc(sizeof(nd_mm128) * (cap > 0 ? cap : 1));
+	for (i = 0; i < n_reads; ++i)
+		if (len[i] > 0) n += nd_mm_sketch(codes + off[i], (int)len[i], w, k, (uint32_t)i, hpc, all + n);
+	qsort(all, n, sizeof(nd_mm128), cmp_minier);
+	ix->n = n;
+	ix->key = (uint64_t*)malloc(8 * (n > 0 ? n : 1));
+	ix->start = (int64_t*)malloc(8 * (n + 1));
+	ix->pos = (uint64_t*)malloc(8 * (n > 0 ? n : 1));
+	for (i = 0, j = 0; i < n; ++i) {
+		if (i == 0 || all[i].x >> 8 != all[i - 1].x >> 8) ix->key[j] = all[i].x >> 8, ix->start[j++] = i;
+		ix->pos[i] = all[i].y;
+	}
+	ix->n_keys = j;
+	ix->start[j] = n;
+	free(all);
+	ix->n_reads = n_reads;
+	ix->len = (uint32_t*)malloc(4 * (n_reads > 0 ? n_reads : 1));
+	ix->name = (char(*)[12])malloc(12 * (n_reads > 0 ? n_reads : 1));
+	for (i = 0; i < n_reads; ++i) ix->len[i] = len[i], sprintf(ix->name[i], "%u", ids[i]);
+	return ix;
+}
+
+void nd_mm_index_free(nd_mm_index *ix)
+{
+	if (!ix) return;
+	free(ix->key); free(ix->start); free(ix->pos); free(ix->len); free(ix->name); free(ix);
+}
+
+int64_t nd_mm_index_n(const nd_mm_index *ix) { return ix->n; }
+int64_t nd_mm_index_keys(const nd_mm_index *ix) { return ix->n_keys; }
+
+/* raw arrays for array-level parity tests of the device index */
+void nd_mm_index_dump(const nd_mm_index *ix, uint64_t *key, int64_t *start, uint64_t *pos)
+{
+	memcpy(key, ix->key, 8 * ix->n_keys);
+	memcpy(start, ix->start, 8 * (ix->n_keys + 1));
+	memcpy(pos, ix->pos, 8 * ix->n);
+}
+
+static const uint64_t *index_get(const nd_mm_index *ix, uint64_t minier, int *n)
+{
+	int64_t lo = 0, hi = ix->n_keys;
+	*n = 0;
+	while (lo < hi) {
+		int64_t mid = (lo + hi) >> 1;
+		if (ix->key[mid] < minier) lo = mid + 1; else hi = mid;
+	}
+	if (lo == ix->n_keys || ix->key[lo] != minier) return 0;
+	*n = (int)(ix->start[lo + 1] - ix->start[lo]);
+	return ix->pos + ix->start[lo];
+}
+
+/* occurrence threshold: (k-th smallest occurrence count) + 1, k = (uint32)((1 - f) * n_keys) */
+int32_t nd_mm_index_mid_occ(const nd_mm_index *ix, float f)
+{
+	int64_t n = ix->n_keys, i;
+	uint64_t *cnt;
+	uint32_t kth, thres;
+	if (f <= 0.) return INT32_MAX;
+	cnt = (uint64_t*)malloc(8 * (n > 0 ? n : 1));
+	for (i = 0; i < n; ++i) cnt[i] = (uint64_t)(ix->start[i + 1] - ix->start[i]);
+	qsort(cnt, n, 8, cmp_u64);
+	kth = (uint32_t)((1. - f) * n);
+	thres = (uint32_t)cnt[kth] + 1;
+	free(cnt);
+	return (int32_t)thres;
+}
+
+/* ---------------------------------------------------------------- seeds */
+
+#define SEED_TANDEM (1ULL << 42)
+#define SEED_SELF   (1ULL << 43)
+
+/* Anchors of one query read against the index, in the order the reference leaves them after its
+ * radix sort.  mv = query minimizers (rid field 0).  `a` needs room for the sum of occurrences. */
+int64_t nd_mm_seeds(const nd_mm_index *ix, const nd_mm_opt *opt, const char *qname, int qlen, int mid_occ,
+                    const nd_mm128 *mv, int64_t n_mv, nd_mm128 *a, int sorted)
+{
+	int64_t i, n_a = 0;
+	for (i = 0; i < n_mv; ++i) {
+		uint64_t minier = mv[i].x >> 8;
+		uint32_t q_pos = (uint32_t)mv[i].y, q_span = (uint32_t)(mv[i].x & 0xff);
+		int n_occ, tandem = 0, j;
+		const uint64_t *occ = index_get(ix, minier, &n_occ);
+		if (n_occ >= mid_occ) continue; /* repetitive minimizer */
+		if (i > 0 && minier == mv[i - 1].x >> 8) tandem = 1;
+		if (i < n_mv - 1 && minier == mv[i + 1].x >> 8) tandem = 1;
+		for (j = 0; j < n_occ; ++j) {
+			uint64_t r = occ[j];
+			uint32_t rid = (uint32_t)(r >> 32);
+			int32_t rpos = (int32_t)((uint32_t)r >> 1);
+			int is_self = 0;
+			nd_mm128 *p;
+			if (opt->no_diag || opt->no_dual) {
+				int cmp = strcmp(qname, ix->name[rid]);
+				if (opt->no_diag && cmp == 0 && (int)ix->len[rid] == qlen) {
+					if ((uint32_t)r >> 1 == q_pos >> 1) continue;
+					if ((r & 1) == (q_pos & 1)) is_self = 1;
+				}
+				if (opt->no_dual && cmp > 0) continue;
+			}
+			p = &a[n_a++];
+			if ((r & 1) == (q_pos & 1)) {
+				p->x = (r & 0xffffffff00000000ULL) | (uint64_t)(uint32_t)rpos;
+				p->y = (uint64_t)q_span << 32 | q_pos >> 1;
+			} else {
+				p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint64_t)(uint32_t)rpos;
+				p->y = (uint64_t)q_span << 32 | (uint32_t)(qlen - (int32_t)((q_pos >> 1) + 1 - q_span) - 1);
+			}
+			if (tandem) p->y |= SEED_TANDEM;
+			if (is_self) p->y |= SEED_SELF;
+		}
+	}
+	if (sorted) nd_mm_rs_sort128(a, n_a);
+	return n_a;
+}
+
+/* ---------------------------------------------------------------- chaining */
+
+static int ilog2(uint32_t v) /* floor(log2 v), v > 0 */
+{
+	int r = 0;
+	while (v >>= 1) ++r;
+	return r;
+}
+
+/* One read's chaining.  a[0..n) = sorted anchors (overwritten with the chained anchors, chains ordered by
+ * the target coordinate of their first anchor); u[] (room for n) = score<<32 | n_anchors per chain.
+ * f_out/p_out (optional, room for n) receive the DP score / predecessor arrays.  Returns the number of
+ * chains; *n_b = anchors kept. */
+int nd_mm_chain(const nd_mm_opt *opt, int64_t n, nd_mm128 *a, uint64_t *u, int64_t *n_b, int32_t *f_out, int32_t *p_out)
+{
+	const int max_dist = opt->max_gap, bw = opt->bw;
+	int32_t *f, *p, *t, *v, n_u, n_v, k;
+	int64_t i, j, st = 0;
+	uint64_t span_sum = 0;
+	float avg_span;
+	nd_mm128 *b, *w;
+	uint64_t *u2;
+	*n_b = 0;
+	if (n == 0) return 0;
+	f = (int32_t*)malloc(4 * n); p = (int32_t*)malloc(4 * n);
+	t = (int32_t*)calloc(n, 4); v = (int32_t*)malloc(4 * n);
+	for (i = 0; i < n; ++i) span_sum += a[i].y >> 32 & 0xff;
+	avg_span = (float)span_sum / n;
+	for (i = 0; i < n; ++i) {
+		const uint64_t ri = a[i].x;
+		const int32_t qi = (int32_t)a[i].y, span = (int32_t)(a[i].y >> 32 & 0xff);
+		int32_t best = span, skipped = 0;
+		int64_t best_j = -1;
+		while (st < i && ri > a[st].x + (uint64_t)max_dist) ++st;
+		if (i - st > opt->max_iter) st = i - opt->max_iter;
+		for (j = i - 1; j >= st; --j) {
+			int64_t dr = (int64_t)(ri - a[j].x);
+			int32_t dq = qi - (int32_t)a[j].y, dd, sc, gap_log;
+			if (dr == 0 || dq <= 0) continue;
+			if (dq > max_dist) continue;
+			dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
+			if (dd > bw) continue;
+			sc = (dq < dr ? dq : (int32_t)dr);
+			if (sc > span) sc = span;
+			gap_log = dd ? ilog2((uint32_t)dd) : 0;
+			sc -= (int)(dd * .01 * avg_span) + (gap_log >> 1);
+			sc += f[j];
+			if (sc > best) {
+				best = sc, best_j = j;
+				if (skipped > 0) --skipped;
+			} else if (t[j] == (int32_t)i) {
+				if (++skipped > opt->max_skip) break;
+			}
+			if (p[j] >= 0) t[p[j]] = (int32_t)i;
+		}
+		f[i] = best, p[i] = (int32_t)best_j;
+		v[i] = best_j >= 0 && v[best_j] > best ? v[best_j] : best;
+	}
+	if (f_out) memcpy(f_out, f, 4 * n);
+	if (p_out) memcpy(p_out, p, 4 * n);
+
+	/* chain ends: anchors nobody points to, with a peak score >= min_sc */
+	memset(t, 0, 4 * n);
+	for (i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
+	for (i = n_u = 0; i < n; ++i) {
+		if (t[i] == 0 && v[i] >= opt->min_sc) {
+			j = i;
+			while (j >= 0 && f[j] < v[j]) j = p[j];
+			if (j < 0) j = i;
+			u[n_u++] = (uint64_t)f[j] << 32 | (uint64_t)j;
+		}
+	}
+	if (n_u == 0) { free(f); free(p); free(t); free(v); return 0; }
+	qsort(u, n_u, 8, cmp_u64); /* keys are distinct (low word = anchor index) */
+	for (i = 0; i < n_u >> 1; ++i) { uint64_t s = u[i]; u[i] = u[n_u - 1 - i], u[n_u - 1 - i] = s; }
+
+	/* backtrack, best first; anchors already claimed stop a chain */
+	memset(t, 0, 4 * n);
+	for (i = n_v = k = 0; i < n_u; ++i) {
+		int32_t v0 = n_v, k0 = k;
+		j = (int32_t)u[i];
+		do { v[n_v++] = (int32_t)j; t[j] = 1; j = p[j]; } while (j >= 0 && t[j] == 0);
+		if (j < 0) {
+			if (n_v - v0 >= opt->min_cnt) u[k++] = u[i] >> 32 << 32 | (uint64_t)(n_v - v0);
+		} else if ((int32_t)(u[i] >> 32) - f[j] >= opt->min_sc) {
+			if (n_v - v0 >= opt->min_cnt) u[k++] = ((u[i] >> 32) - (uint64_t)f[j]) << 32 | (uint64_t)(n_v - v0);
+		}
+		if (k0 == k) n_v = v0;
+	}
+	n_u = k;
+	b = (nd_mm128*)malloc(sizeof(nd_mm128) * (n_v > 0 ? n_v : 1));
+	for (i = 0, k = 0; i < n_u; ++i) {
+		int32_t k0 = k, cnt = (int32_t)u[i];
+		for (j = 0; j < cnt; ++j) b[k++] = a[v[k0 + (cnt - 1 - j)]];
+	}
+	/* order chains by the x of their first anchor (the reference's own sort again) */
+	w = (nd_mm128*)malloc(sizeof(nd_mm128) * (n_u > 0 ? n_u : 1));
+	u2 = (uint64_t*)malloc(8 * (n_u > 0 ? n_u : 1));
+	for (i = k = 0; i < n_u; ++i) { w[i].x = b[k].x, w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)u[i]; }
+	nd_mm_rs_sort128(w, n_u);
+	for (i = k = 0; i < n_u; ++i) {
+		int32_t src = (int32_t)w[i].y, cnt = (int32_t)u[src];
+		u2[i] = u[src];
+		memcpy(&a[k], &b[w[i].y >> 32], sizeof(nd_mm128) * cnt);
+		k += cnt;
+	}
+	memcpy(u, u2, 8 * n_u);
+	*n_b = k;
+	free(f); free(p); free(t); free(v); free(b); free(w); free(u2);
+	return n_u;
+}
+
+/* ---------------------------------------------------------------- chains -> hits */
+
+static uint64_t mix64_full(uint64_t key) /* hit.c:41-51 */
+{
+	key = ~key + (key << 21);
+	key ^= key >> 24;
+	key = key + (key << 3) + (key << 8);
+	key ^= key >> 14;
+	key = key + (key << 2) + (key << 4);
+	key ^= key >> 28;
+	key = key + (key << 31);
+	return key;
+}
+
+uint32_t nd_mm_read_hash(const char *qname, int qlen, int seed) /* map.c:519-521 */
+{
+	uint32_t h = qname ? x31_str(qname) : 0;
+	h ^= wang32((uint32_t)qlen) + wang32((uint32_t)seed);
+	return wang32(h);
+}
+
+int nd_mm_gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const nd_mm128 *a, nd_mm_reg *r)
+{
+	nd_mm128 *z;
+	int i, k;
+	if (n_u == 0) return 0;
+	z = (nd_mm128*)malloc(sizeof(nd_mm128) * n_u);
+	for (i = k = 0; i < n_u; ++i) {
+		uint32_t h = (uint32_t)mix64_full((mix64_full(a[k].x) + mix64_full(a[k].y)) ^ hash);
+		z[i].x = u[i] ^ h;
+		z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];
+		k += (int32_t)u[i];
+	}
+	nd_mm_rs_sort128(z, n_u);
+	for (i = 0; i < n_u >> 1; ++i) { nd_mm128 s = z[i]; z[i] = z[n_u - 1 - i], z[n_u - 1 - i] = s; }
+	for (i = 0; i < n_u; ++i) {
+		nd_mm_reg *q = &r[i];
+		int32_t first, last, span0, m;
+		q->score = (int32_t)(z[i].x >> 32);
+		q->hash = (uint32_t)z[i].x;
+		q->cnt = (int32_t)z[i].y;
+		q->as = (int32_t)(z[i].y >> 32);
+		first = q->as, last = q->as + q->cnt - 1;
+		span0 = (int32_t)(a[first].y >> 32 & 0xff);
+		q->rev = (int32_t)(a[first].x >> 63);
+		q->rid = (int32_t)(a[first].x << 1 >> 33);
+		q->rs = (int32_t)a[first].x + 1 > span0 ? (int32_t)a[first].x + 1 - span0 : 0;
+		q->re = (int32_t)a[last].x + 1;
+		if (!q->rev) {
+			q->qs = (int32_t)a[first].y + 1 - span0;
+			q->qe = (int32_t)a[last].y + 1;
+		} else {
+			q->qs = qlen - ((int32_t)a[last].y + 1);
+			q->qe = qlen - ((int32_t)a[first].y + 1 - span0);
+		}
+		q->mlen = q->blen = span0;
+		for (m = first + 1; m <= last; ++m) {
+			int span = (int)(a[m].y >> 32 & 0xff);
+			int tl = (int32_t)a[m].x - (int32_t)a[m - 1].x;
+			int ql = (int32_t)a[m].y - (int32_t)a[m - 1].y;
+			q->blen += tl > ql ? tl : ql;
+			q->mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+		}
+	}
+	free(z);
+	return n_u;
+}
+
+/* ---------------------------------------------------------------- one read end to end */
+
+/* regs needs room for the chain count (<= number of anchors / min_cnt); returns the number of hits.
+ * work buffers are allocated inside. */
+int nd_mm_map_read(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
+                   nd_mm_reg *regs, int reg_cap)
+{
+	char qname[12];
+	nd_mm128 *mv, *a;
+	uint64_t *u;
+	int64_t n_mv, n_a = 0, i, n_b;
+	int n_u, n;
+	if (qlen <= 0) return 0;
+	sprintf(qname, "%u", qid);
+	mv = (nd_mm128*)malloc(sizeof(nd_mm128) * ((size_t)qlen + 1));
+	n_mv = nd_mm_sketch(qcodes, qlen, opt->w, opt->k, 0, opt->hpc, mv);
+	for (i = 0; i < n_mv; ++i) {
+		int n_occ;
+		index_get(ix, mv[i].x >> 8, &n_occ);
+		if (n_occ < mid_occ) n_a += n_occ;
+	}
+	a = (nd_mm128*)malloc(sizeof(nd_mm128) * (n_a > 0 ? n_a : 1));
+	n_a = nd_mm_seeds(ix, opt, qname, qlen, mid_occ, mv, n_mv, a, 1);
+	u = (uint64_t*)malloc(8 * (n_a > 0 ? n_a : 1));
+	n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
+	n = n_u <= reg_cap ? n_u : -n_u;
+	if (n > 0) nd_mm_gen_regs(nd_mm_read_hash(qname, qlen, opt->seed), qlen, n_u, u, a, regs);
+	free(mv); free(a); free(u);
+	return n;
+}
+
+/* ---------------------------------------------------------------- .ovl records */
+
+static int put_varint(uint8_t *out, uint32_t v) /* lib/ovl.c:10-29,129-145 */
+{
+	int sh, m = 0;
+	if (v <= 127) { out[0] = (uint8_t)v; return 1; }
+	for (sh = 28; sh >= 0; sh -= 7) {
+		uint32_t g = v >> sh & 127;
+		if (g > 0 || m > 0) out[m++] = (uint8_t)(g | 128);
+	}
+	out[m - 1] &= 127;
+	return m;
+}
+
+static int dovetail_class(int rev, uint32_t qs, uint32_t qe, uint32_t qlen, uint32_t ts, uint32_t te, uint32_t tlen,
+                          int32_t h1, int32_t h2) /* map.c:805-824; all comparisons are unsigned there (uint32 vs int32) */
+{
+	uint32_t a = (uint32_t)h1, b = (uint32_t)h2;
+	if (rev) {
+		if (qs <= a && ts <= a) return 1;
+		else if (qlen - qe <= a && tlen - te <= a) return 2;
+	} else {
+		if (qlen - qe <= a && ts <= a) return 4;
+		else if (qs <= a && tlen - te <= a) return 7;
+	}
+	if (h2 > 0) {
+		if (qs <= b && qe + b >= qlen) return 8;
+		if (ts <= b && te + b >= tlen) return 9;
+	}
+	return 0;
+}
+
+/* Appends the step-1 records of one query read; prev[2] = running (qname, tname) delta state.
+ * out needs 40 bytes per hit.  Returns bytes written. */
+int64_t nd_mm_encode(const nd_mm_index *ix, const nd_mm_opt *opt, uint32_t qid, int qlen, const uint32_t *tids,
+                     const nd_mm_reg *regs, int n_regs, uint32_t *prev, uint8_t *out)
+{
+	int64_t n = 0;
+	int i, f;
+	for (i = 0; i < n_regs; ++i) {
+		const nd_mm_reg *r = &regs[i];
+		uint32_t tid = tids[r->rid], fld[8], tspan;
+		uint32_t flags = (uint32_t)r->rev;
+		if (tid == qid) continue; /* names are the decimal ids: equal strings <=> equal ids */
+		if (r->qe - r->qs < opt->minlen) continue;
+		if (opt->dvt && !dovetail_class(r->rev, (uint32_t)r->qs, (uint32_t)r->qe, (uint32_t)qlen, (uint32_t)r->rs,
+		                                (uint32_t)r->re, ix->len[r->rid], opt->maxhan1, opt->maxhan2)) continue;
+		fld[3] = (uint32_t)(r->qe - r->qs), tspan = (uint32_t)(r->re - r->rs);
+		if (qid >= prev[0]) fld[0] = qid - prev[0]; else flags |= 2, fld[0] = prev[0] - qid;
+		prev[0] = qid;
+		if (tid >= prev[1]) fld[4] = tid - prev[1]; else flags |= 4, fld[4] = prev[1] - tid;
+		prev[1] = tid;
+		if (fld[3] >= tspan) fld[6] = fld[3] - tspan; else flags |= 8, fld[6] = tspan - fld[3];
+		fld[1] = flags & 0xff, fld[2] = (uint32_t)r->qs, fld[5] = (uint32_t)r->rs, fld[7] = (uint32_t)r->mlen;
+		for (f = 0; f < 8; ++f) n += put_varint(out + n, fld[f]);
+	}
+	return n;
+}
+
+/* Whole `minimap2-nd --step 1 target query` run for a single-part index (sum of target lengths below -I).
+ * Returns the number of .ovl bytes written (or -needed if out_cap is too small). */
+int64_t nd_mm_step1(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
+                    int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
+                    int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
+                    uint8_t *out, int64_t out_cap, int32_t *mid_occ_out)
+{
+	nd_mm_index *ix = nd_mm_index_build(n_t, tcodes, toff, tlen, tids, opt->w, opt->k, opt->hpc);
+	int mid_occ = mid_occ_fixed > 0 ? mid_occ_fixed : nd_mm_index_mid_occ(ix, mid_occ_frac);
+	uint32_t prev[2] = { 0, 0 };
+	int64_t n = 0;
+	int reg_cap = 1 << 16, i;
+	nd_mm_reg *regs = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * reg_cap);
+	if (mid_occ_out) *mid_occ_out = mid_occ;
+	for (i = 0; i < n_q; ++i) {
+		int n_regs = nd_mm_map_read(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)qlen[i], regs, reg_cap);
+		if (n_regs < 0) {
+			reg_cap = -n_regs + 1024;
+			regs = (nd_mm_reg*)realloc(regs, sizeof(nd_mm_reg) * reg_cap);
+			n_regs = nd_mm_map_read(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)qlen[i], regs, reg_cap);
+		}
+		if (n + 40LL * n_regs > out_cap) { n = -(n + 40LL * n_regs); break; }
+		n += nd_mm_encode(ix, opt, qids[i], (int)qlen[i], tids, regs, n_regs, prev, out + n);
+	}
+	free(regs);
+	nd_mm_index_free(ix);
+	return n;
+}

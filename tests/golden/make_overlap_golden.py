@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Golden vectors for the overlap path: a small seeded read set (with interspersed and tandem repeats, so
+that repetitive-minimizer filtering and equal-coordinate anchors occur) dumped by the reference seq_dump,
+and the `.ovl` files the compiled reference `minimap2-nd --step 1` (oracle/_ref/minimap2-nd) writes for it.
+Run in the build container (needs oracle/_ref):  python tests/golden/make_overlap_golden.py
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import mm_util as M  # noqa: E402
+from nextdenovo_amd import synth  # noqa: E402
+
+CASES = [  # (file tag, preset, target, query, dual, extra argv)
+    ("ont.sxp.dual", "ava-ont", "seed", "part", True, ()),
+    ("ont.sxs", "ava-ont", "seed", "seed", False, ()),
+    ("ont.sxp.f002", "ava-ont", "seed", "part", False, ("-f", "0.002")),
+    ("ont.sxs.f30", "ava-ont", "seed", "seed", False, ("-f", "30")),
+    ("pb.sxp.dual", "ava-pb", "seed", "part", True, ()),
+    ("pb.sxs", "ava-pb", "seed", "seed", False, ()),
+]
+
+
+def main():
+    out = os.path.join(HERE, "overlap")
+    os.makedirs(out, exist_ok=True)
+    rng = np.random.default_rng(3)
+    g = synth.make_genome(45000, seed=8, n_repeats=6, repeat_len=1800)
+    for pos, unit, copies in ((9000, 37, 50), (30000, 151, 14)):
+        blk = np.tile(rng.integers(0, 4, unit).astype(np.uint8), copies)
+        g[pos:pos + blk.size] = blk
+    rs = synth.simulate_reads(g, 22, "ont", seed=9, mu=8.6, sigma=0.5, min_len=800)
+    wd = tempfile.mkdtemp(prefix="ndovl")
+    seed, part = M.dump_reads(wd, [synth.codes_to_ascii(s) for s in rs.seqs], seed_cutoff=6000)
+    files = {"seed": seed, "part": part}
+    for k, p in files.items():
+        shutil.copy(p, os.path.join(out, k + ".2bit"))
+    for tag, preset, t, q, dual, extra in CASES:
+        b = M.ref_step1(files[t], files[q], os.path.join(out, tag + ".ovl"), preset, dual, extra)
+        print(tag, len(b), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""ctypes view of oracle/mm_oracle.c (the CPU restatement of `minimap2-nd --step 1`) + helpers that
+run the compiled reference binary.  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+class MMOpt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "no_diag", "no_dual", "min_cnt", "min_sc", "bw", "max_gap",
+                                         "max_skip", "max_iter", "minlen", "seed", "dvt", "maxhan1", "maxhan2")]
+
+
+class MMReg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("rev", "rid", "qs", "qe", "rs", "re", "mlen", "blen", "score", "cnt", "as_")] \
+        + [("hash", C.c_uint32)]
+
+
+MM128 = np.dtype([("x", np.uint64), ("y", np.uint64)])
+REG = np.dtype([(n, np.int32) for n in ("rev", "rid", "qs", "qe", "rs", "re", "mlen", "blen", "score", "cnt", "as_")]
+               + [("hash", np.uint32)])
+
+
+def preset(name: str, dual: bool = False, **kw) -> MMOpt:
+    """minimap2/options.c:12-62,84-97 (mm_mapopt_init + mm_set_opt) and main.c:190-193 (--step 1)."""
+    o = MMOpt(k=15, w=5, hpc=0, no_diag=1, no_dual=0 if dual else 1, min_cnt=3, min_sc=100, bw=500, max_gap=10000,
+              max_skip=25, max_iter=5000, minlen=500, seed=11, dvt=0, maxhan1=5000, maxhan2=500)
+    if name == "ava-ont":
+        o.bw = 2000
+    elif name == "ava-pb":
+        o.k, o.hpc = 19, 1
+    else:
+        raise ValueError(name)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def bind(lib):
+    P = C.c_void_p
+    lib.nd_mm_sketch.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, P]
+    lib.nd_mm_sketch.restype = C.c_int64
+    lib.nd_mm_rs_sort128.argtypes = [P, C.c_int64]
+    lib.nd_mm_index_build.argtypes = [C.c_int32, P, P, P, P, C.c_int, C.c_int, C.c_int]
+    lib.nd_mm_index_build.restype = P
+    lib.nd_mm_index_free.argtypes = [P]
+    lib.nd_mm_index_n.argtypes = [P]
+    lib.nd_mm_index_n.restype = C.c_int64
+    lib.nd_mm_index_keys.argtypes = [P]
+    lib.nd_mm_index_keys.restype = C.c_int64
+    lib.nd_mm_index_dump.argtypes = [P, P, P, P]
+    lib.nd_mm_index_mid_occ.argtypes = [P, C.c_float]
+    lib.nd_mm_index_mid_occ.restype = C.c_int32
+    lib.nd_mm_seeds.argtypes = [P, C.POINTER(MMOpt), C.c_char_p, C.c_int, C.c_int, P, C.c_int64, P, C.c_int]
+    lib.nd_mm_seeds.restype = C.c_int64
+    lib.nd_mm_chain.argtypes = [C.POINTER(MMOpt), C.c_int64, P, P, P, P, P]
+    lib.nd_mm_chain.restype = C.c_int
+    lib.nd_mm_read_hash.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    lib.nd_mm_read_hash.restype = C.c_uint32
+    lib.nd_mm_gen_regs.argtypes = [C.c_uint32, C.c_int, C.c_int, P, P, P]
+    lib.nd_mm_gen_regs.restype = C.c_int
+    lib.nd_mm_map_read.argtypes = [P, C.POINTER(MMOpt), C.c_int, C.c_uint32, P, C.c_int, P, C.c_int]
+    lib.nd_mm_map_read.restype = C.c_int
+    lib.nd_mm_step1.argtypes = [C.POINTER(MMOpt), C.c_float, C.c_int, C.c_int32, P, P, P, P, C.c_int32, P, P, P, P, P,
+                                C.c_int64, P]
+    lib.nd_mm_step1.restype = C.c_int64
+    return lib
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def sketch(lib, codes: np.ndarray, w, k, rid=0, hpc=0) -> np.ndarray:
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.zeros(codes.size + 1, dtype=MM128)
+    n = lib.nd_mm_sketch(ptr(codes), codes.size, w, k, rid, hpc, ptr(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0):
+    """tset/qset = (ids, lens, codes, off).  Returns (.ovl bytes, mid_occ)."""
+    tid, tl, tc, to = tset
+    qid, ql, qc, qo = qset
+    cap = 1 << 20
+    while True:
+        out = np.zeros(cap, dtype=np.uint8)
+        mo = C.c_int32(0)
+        n = lib.nd_mm_step1(C.byref(opt), np.float32(mid_occ_frac), mid_occ, tid.size, ptr(tc), ptr(to), ptr(tl), ptr(tid),
+                            qid.size, ptr(qc), ptr(qo), ptr(ql), ptr(qid), ptr(out), cap, C.byref(mo))
+        if n >= 0:
+            return out[:n].tobytes(), mo.value
+        cap = max(cap * 4, -n * 2)
+
+
+def load_set(path):
+    """One .2bit file -> (ids, lens, codes, off) as the oracle wants them."""
+    from nextdenovo_amd import ovl
+    ids, lens, words, woff = ovl.read_2bit(path)
+    codes, off = ovl.unpack_codes(words, woff, lens)
+    return (np.ascontiguousarray(ids), np.ascontiguousarray(lens), codes, off)
+
+
+def ref_step1(target_2bit, query_2bit, out_path, preset_name="ava-ont", dual=False, extra=(), threads=3):
+    cmd = [os.path.join(REFDIR, "minimap2-nd"), "--step", "1"]
+    if dual:
+        cmd.append("--dual=yes")
+    cmd += ["-t", str(threads), "-x", preset_name, *extra, target_2bit, query_2bit, "-o", out_path]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    with open(out_path, "rb") as f:
+        return f.read()
+
+
+def dump_reads(workdir, seqs_ascii, seed_cutoff, read_cutoff=500):
+    """seq_dump on a FASTA -> (seed.2bit, part.2bit or None)."""
+    from refpipe import run, write_fasta
+    os.makedirs(workdir, exist_ok=True)
+    fa = os.path.join(workdir, "reads.fa")
+    write_fasta(fa, seqs_ascii)
+    fofn = os.path.join(workdir, "input.fofn")
+    with open(fofn, "w") as f:
+        f.write(fa + "\n")
+    db = os.path.join(workdir, "db")
+    os.makedirs(db, exist_ok=True)
+    run([os.path.join(REFDIR, "seq_dump"), "-f", str(read_cutoff), "-s", str(seed_cutoff), "-b", "2g", "-n", "1", "-d", db,
+         fofn])
+    seed = os.path.join(db, "input.seed.001.2bit")
+    part = os.path.join(db, "input.part.001.2bit")
+    if not (os.path.exists(part) and os.path.getsize(part) > 2):
+        part = None
+    return seed, part

@@ -1,0 +1,81 @@
+"""The overlap oracle (oracle/mm_oracle.c) against (1) the committed golden `.ovl` files written by the compiled
+reference `minimap2-nd --step 1` and (2), when oracle/_ref is present, the reference binary run live on a fresh
+seeded read set.  Byte-for-byte."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import mm_util as M  # noqa: E402
+from make_overlap_golden import CASES  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "overlap")
+
+
+@pytest.fixture(scope="module")
+def lib(oracle_lib):
+    return M.bind(oracle_lib)
+
+
+@pytest.fixture(scope="module")
+def sets():
+    return {k: M.load_set(os.path.join(GOLD, k + ".2bit")) for k in ("seed", "part")}
+
+
+def case_kwargs(extra):
+    kw = {}
+    if "-f" in extra:
+        x = float(extra[extra.index("-f") + 1])
+        if x < 1.0:
+            kw["mid_occ_frac"] = x
+        else:
+            kw["mid_occ"] = int(x + .499)
+    return kw
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_oracle_matches_golden_ovl(lib, sets, case):
+    tag, preset, t, q, dual, extra = case
+    with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
+        want = f.read()
+    got, _ = M.step1(lib, M.preset(preset, dual), sets[t], sets[q], **case_kwargs(extra))
+    assert got == want
+
+
+def test_golden_set_has_equal_coordinate_anchors(lib, sets):
+    """The fixture must exercise the tie order of the reference's unstable radix sort."""
+    ids, lens, codes, off = sets["seed"]
+    opt = M.preset("ava-ont", False)
+    ix = lib.nd_mm_index_build(ids.size, M.ptr(codes), M.ptr(off), M.ptr(lens), M.ptr(ids), opt.w, opt.k, opt.hpc)
+    mid = lib.nd_mm_index_mid_occ(ix, np.float32(2e-4))
+    dup = 0
+    for i in range(ids.size):
+        mv = M.sketch(lib, codes[int(off[i]): int(off[i]) + int(lens[i])], opt.w, opt.k)
+        a = np.zeros(max(1, mv.size * mid), dtype=M.MM128)
+        n = lib.nd_mm_seeds(ix, C.byref(opt), str(int(ids[i])).encode(), int(lens[i]), mid, M.ptr(mv), mv.size, M.ptr(a), 1)
+        x = a["x"][:n]
+        assert (np.diff(x.astype(np.int64).view(np.uint64)) >= 0).all() if n > 1 else True
+        dup += int((x[1:] == x[:-1]).sum())
+    lib.nd_mm_index_free(ix)
+    assert dup > 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(M.REFDIR, "minimap2-nd")), reason="oracle/_ref not built")
+@pytest.mark.parametrize("profile,preset", [("ont", "ava-ont"), ("clr", "ava-pb")])
+def test_oracle_matches_live_reference(lib, profile, preset):
+    from nextdenovo_amd import synth
+    g = synth.make_genome(50000, seed=21, n_repeats=4, repeat_len=1200)
+    rs = synth.simulate_reads(g, 18, profile, seed=22)
+    wd = tempfile.mkdtemp(prefix="ndmm")
+    seed, part = M.dump_reads(wd, [synth.codes_to_ascii(s) for s in rs.seqs], seed_cutoff=8000)
+    S, P = M.load_set(seed), M.load_set(part)
+    for t, q, dual in ((seed, part, True), (seed, seed, False)):
+        want = M.ref_step1(t, q, os.path.join(wd, "o.ovl"), preset, dual)
+        got, _ = M.step1(lib, M.preset(preset, dual), S, S if q == seed else P)
+        assert len(want) > 1000 and got == want
