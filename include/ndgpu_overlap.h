@@ -1,0 +1,104 @@
+/* ndgpu_overlap.h -- C ABI of the MI355X overlap engine (libndgpu_overlap.so).
+ *
+ * Drop-in scope: the `minimap2-nd --step 1` path of NextDenovo v2.5.2 (all-vs-all raw-read overlap that feeds
+ * ovl_sort -> nextcorrect).  Citations are relative to the reference tree.
+ *
+ *   reference interface                                   this library
+ *   ----------------------------------------------------  -------------------------------------------
+ *   mm_set_opt()            minimap2/options.c:84-97       ndgpu_ovl_opt_preset()
+ *   main.c:190-193 (--step 1), :241,:328 (--dual), :337-343 (-f)   fields of ndgpu_ovl_opt
+ *   mm_idx_gen()            minimap2/index.c:351-370       ndgpu_ovl_index_create()   (K1 sketch + K2 sort/group, HBM resident)
+ *   mm_idx_cal_max_occ()    minimap2/index.c:170-191       ndgpu_ovl_index_mid_occ()
+ *   mm_idx_destroy()        minimap2/index.c:55-79         ndgpu_ovl_index_destroy()
+ *   mm_map_file() + the step-1 writer  minimap2/map.c:1376-1403, :1296-1304 + encode_ovl() lib/ovl.c:109-150
+ *                                                           ndgpu_ovl_map()  (K1, K3 seeds, sort, K4 chain DP, K5 hits; .ovl bytes)
+ *
+ * Reads are passed exactly as they are stored in NextDenovo's `.2bit` files (lib/bseq.c:114-139): 16 bases per
+ * uint32, first base in the two top bits, A=0 C=1 G=2 T=3; word_off[i] = index of read i's first word in `words`.
+ * ids[i] is the numeric read name (the reference prints it with "%u" and compares names as strings,
+ * map.c:136,1296; this library reproduces that ordering).
+ *
+ * All functions fail loudly (return NULL / negative and print to stderr) when no HIP device is usable; there
+ * is no CPU fallback.
+ */
+#ifndef NDGPU_OVERLAP_H
+#define NDGPU_OVERLAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ndgpu_ovl_opt {
+	int32_t k, w, hpc;                  /* mm_idxopt_t::k, ::w, ::flag & MM_I_HPC          (minimap.h) */
+	int32_t no_diag, no_dual;           /* MM_F_NO_DIAG, MM_F_NO_DUAL                      (minimap.h:8-9) */
+	int32_t min_cnt, min_chain_score;   /* mm_mapopt_t::min_cnt, ::min_chain_score */
+	int32_t bw, max_gap;                /* ::bw, ::max_gap */
+	int32_t max_chain_skip, max_chain_iter;
+	int32_t minlen;                     /* --minlen (500 for --step 1) */
+	int32_t seed;                       /* --seed (11) */
+	int32_t dvt, maxhan1, maxhan2;      /* --dvt, --maxhan1, --maxhan2 */
+	float   mid_occ_frac;               /* -f FLOAT (< 1) */
+	int32_t mid_occ;                    /* -f INT (>= 1); 0 = derive from mid_occ_frac */
+} ndgpu_ovl_opt;
+
+typedef struct ndgpu_ovl_index ndgpu_ovl_index;
+
+/* one step-1 overlap before varint coding: the fields of `overlap` (lib/ovl.h:20-25) */
+typedef struct ndgpu_ovl_rec {
+	uint32_t rev, qname, qs, qe, tname, ts, te, match;
+} ndgpu_ovl_rec;
+
+/* mm_mapopt_init + mm_idxopt_init + mm_set_opt(preset) + `--step 1`; preset = "ava-ont" | "ava-pb".
+ * Returns 0, or -1 for an unknown / unsupported preset (ava-hifi's k=51 sketch is not built yet). */
+int ndgpu_ovl_opt_preset(const char *preset, ndgpu_ovl_opt *opt);
+
+/* Sketch the target reads on the device and build the minimizer index in HBM. */
+ndgpu_ovl_index *ndgpu_ovl_index_create(const ndgpu_ovl_opt *opt, uint32_t n_reads, const uint32_t *words, uint64_t n_words,
+                                        const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids);
+void ndgpu_ovl_index_destroy(ndgpu_ovl_index *idx);
+/* occurrence threshold of the top `frac` repetitive minimizers (+1), as mm_idx_cal_max_occ */
+int32_t ndgpu_ovl_index_mid_occ(ndgpu_ovl_index *idx, float frac);
+/* n[0] = minimizers, n[1] = distinct minimizers, n[2] = target reads */
+void ndgpu_ovl_index_stat(const ndgpu_ovl_index *idx, uint64_t n[3]);
+
+/* Map the query reads against the index; returns the number of overlaps kept by the step-1 filter
+ * (self hits dropped, query span >= minlen, optional --dvt) in reference output order, or < 0 on error.
+ * *recs is malloc'd (release with ndgpu_ovl_free). */
+int64_t ndgpu_ovl_map(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                      uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids,
+                      ndgpu_ovl_rec **recs);
+
+/* encode_ovl(): append `n` records to a byte buffer as 8 big-endian base-128 varints each;
+ * prev[2] = running (qname, tname) state (`prev_t pid`, minimap2/main.c:29).  out needs 40 bytes per record.
+ * Returns bytes written. */
+int64_t ndgpu_ovl_encode(const ndgpu_ovl_rec *recs, int64_t n, uint32_t prev[2], uint8_t *out);
+
+void ndgpu_ovl_free(void *p);
+
+/* ---- array-level views used by the parity tests (same library, same kernels) ---- */
+
+/* K1 alone: minimizers of every read; rid_is_index != 0 puts the read index in the high word of y (index
+ * side), 0 leaves it 0 (query side, map.c:71).  off[n_reads+1], x/y malloc'd. */
+int64_t ndgpu_ovl_sketch(const ndgpu_ovl_opt *opt, uint32_t n_reads, const uint32_t *words, uint64_t n_words,
+                         const uint64_t *word_off, const uint32_t *lens, int rid_is_index, uint64_t **x, uint64_t **y,
+                         uint64_t *off);
+/* index arrays: key[n_keys] ascending, start[n_keys+1], pos[n_min] */
+void ndgpu_ovl_index_dump(const ndgpu_ovl_index *idx, uint64_t *key, uint64_t *start, uint64_t *pos);
+/* after ndgpu_ovl_map(..): the last batch's sorted anchors and chain-DP arrays of query `q` (index into that
+ * call's reads).  Returns the anchor count; arrays malloc'd. */
+int64_t ndgpu_ovl_debug_anchors(ndgpu_ovl_index *idx, uint32_t q, uint64_t **ax, uint64_t **ay, int32_t **f, int32_t **p);
+
+/* kernel timing of the calls so far on this index (ms, HIP events) and work counters */
+typedef struct ndgpu_ovl_stats {
+	double sketch_ms, index_sort_ms, seed_ms, sort_ms, exact_sort_ms, chain_ms, hits_ms;
+	uint64_t bases_sketched, minimizers, anchors, tie_reads, chain_cells, chains, overlaps, map_calls, batches;
+} ndgpu_ovl_stats;
+void ndgpu_ovl_get_stats(const ndgpu_ovl_index *idx, ndgpu_ovl_stats *st);
+void ndgpu_ovl_reset_stats(ndgpu_ovl_index *idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

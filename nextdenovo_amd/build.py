@@ -2,7 +2,8 @@
 
     python -m nextdenovo_amd.build
 
-produces nextdenovo_amd/libndgpu_nextcorrect.so (HIP kernels + host engine + C ABI).
+produces nextdenovo_amd/libndgpu_nextcorrect.so (correction stage: HIP kernels + host engine + C ABI)
+and nextdenovo_amd/libndgpu_overlap.so (overlap stage: `minimap2-nd --step 1` path).
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU
 box with the repo snapshot.
 """
@@ -17,26 +18,32 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libndgpu_nextcorrect.so")
 SOURCES = ["ond_kernels.hip", "msa_kernels.hip", "device_runtime.hip", "consensus.cpp", "poa.cpp", "readdb.cpp", "capi.cpp"]
 HEADERS = ["nd_device.h", "nd_host.h", "nd_runtime.h", os.path.join("..", "..", "include", "ndgpu_nextcorrect.h")]
+OVL_LIB = os.path.join(HERE, "libndgpu_overlap.so")
+OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip"]
+OVL_HEADERS = ["ovl_device.h", os.path.join("..", "..", "include", "ndgpu_overlap.h")]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib=None, deps=None) -> bool:
+    lib = lib or LIB
+    deps = deps or (SOURCES + HEADERS)
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    for lib, srcs, hdrs in ((LIB, SOURCES, HEADERS), (OVL_LIB, OVL_SOURCES, OVL_HEADERS)):
+        if not force and not _stale(lib, srcs + hdrs):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+               "-Wall", "-Wno-unused-function", "-o", lib] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in srcs]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return LIB
 
 

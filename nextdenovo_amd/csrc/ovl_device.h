@@ -1,0 +1,85 @@
+// ovl_device.h -- device-side types of the overlap engine and the launcher prototypes
+// (kernels: ovl_kernels.hip; host orchestration + C ABI: ovl_engine.hip).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace ndovl {
+
+constexpr uint64_t kSeedTandem = 1ULL << 42; // MM_SEED_TANDEM (minimap2/mmpriv.h:20)
+constexpr uint64_t kSeedSelf = 1ULL << 43;   // MM_SEED_SELF   (minimap2/mmpriv.h:21)
+
+struct OvlParams {
+	int32_t k, w, hpc;
+	int32_t no_diag, no_dual;
+	int32_t min_cnt, min_sc, bw, max_gap, max_skip, max_iter;
+	int32_t minlen, dvt, maxhan1, maxhan2;
+};
+
+// minimizer index of the target reads, resident in HBM
+struct IndexDev {
+	uint64_t n_keys;
+	const uint64_t *ukey;    // distinct minimizers (hash value), ascending
+	const uint64_t *ustart;  // n_keys + 1: first occurrence of each key in pos[]
+	const uint64_t *pos;     // read<<32 | last base<<1 | strand, ascending inside a key
+	const uint32_t *len;     // target read lengths
+	const uint32_t *id;      // numeric read names
+	const uint64_t *namekey; // order-preserving key of the decimal name string (strcmp order)
+};
+
+// query side (whole query set of one ndgpu_ovl_map call)
+struct QueryDev {
+	const uint32_t *len, *id, *hash;
+	const uint64_t *namekey;
+	const uint64_t *m_off;   // n_q + 1 offsets into the minimizer arrays
+};
+
+// sort key of an anchor: | read (batch local) | strand | target read | target position |
+struct KeyLayout {
+	uint32_t pos_bits;   // bits of the target position field
+	uint32_t rev_shift;  // = pos_bits + bits of the target read field
+	uint32_t read_shift; // = rev_shift + 1
+	uint32_t read_base;  // first query read of the batch
+	uint32_t total_bits;
+};
+
+struct OvlRec { uint32_t rev, qname, qs, qe, tname, ts, te, match; };
+
+size_t sketch_smem(int w);
+void launch_sketch(bool fill, const uint32_t *words, const uint64_t *woff, const uint32_t *len, const uint32_t *order,
+                   uint32_t n_reads, const OvlParams &P, int rid_is_index, const uint64_t *out_off, uint64_t *out_x,
+                   uint64_t *out_y, uint32_t *out_read, uint32_t *out_cnt, hipStream_t s);
+void launch_shift_keys(const uint64_t *x, uint64_t *key, uint64_t n, hipStream_t s);
+
+int sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout,
+                   size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s);
+int sort_keys_u32(void *tmp, size_t &tmp_bytes, const uint32_t *kin, uint32_t *kout, size_t n, hipStream_t s);
+int rle_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, size_t n, uint64_t *uniq, uint32_t *cnt, uint64_t *n_runs,
+            hipStream_t s);
+int exscan_u32_to_u64(void *tmp, size_t &tmp_bytes, const uint32_t *in, uint64_t *out, size_t n, hipStream_t s);
+
+void launch_seed_count(const uint64_t *mx, const uint64_t *my, const uint32_t *m_read, uint64_t n_m, const IndexDev &ix,
+                       const QueryDev &q, const OvlParams &P, int mid_occ, uint32_t *m_start, uint32_t *m_cnt, uint32_t *m_surv,
+                       hipStream_t s);
+void launch_seed_fill(const uint64_t *mx, const uint64_t *my, const uint32_t *m_read, uint64_t m0, uint64_t m1, const IndexDev &ix,
+                      const QueryDev &q, const OvlParams &P, const uint32_t *m_start, const uint32_t *m_cnt, const uint64_t *a_off,
+                      uint64_t a_base, const KeyLayout &L, uint64_t *ckey, uint64_t *ay, hipStream_t s);
+void launch_gather_read_off(const uint64_t *a_off, const uint64_t *m_off, uint32_t n_reads, uint64_t n_m, uint64_t total,
+                            uint64_t *r_aoff, hipStream_t s);
+void launch_local_off(const uint64_t *r_aoff_all, uint32_t r0, uint32_t n, uint64_t *r_aoff, hipStream_t s);
+void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, hipStream_t s);
+void launch_exact_sort(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
+                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *stacks, hipStream_t s);
+void launch_chain(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f,
+                  int32_t *p, int32_t *v, unsigned long long *cells, hipStream_t s);
+void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
+                 const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
+                 uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, OvlRec *recs, uint32_t *n_rec,
+                 uint32_t *n_chain, hipStream_t s);
+void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,
+                         const uint64_t *rec_off, OvlRec *dense, hipStream_t s);
+size_t sort_job_bytes();
+
+} // namespace ndovl

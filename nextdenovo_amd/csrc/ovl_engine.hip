@@ -1,0 +1,578 @@
+// ovl_engine.hip -- host orchestration + C ABI of the overlap engine (include/ndgpu_overlap.h).
+//
+// Data flow of one `minimap2-nd --step 1 target query` run (reference: minimap2/main.c:474-507):
+//   index_create : .2bit words -> HBM, K1 sketch (count, scan, fill), K2 two LSD sorts (position, then
+//                  minimizer) + run-length encode -> (ukey, ustart, pos) resident in HBM
+//   map          : K1 on the query set, K3a lookup/count over all query minimizers, then per batch of
+//                  query reads (bounded by an anchor budget): K3b fill, K3s sort (+ exact replay for reads
+//                  with equal keys), K4 chain DP, K5 hits, compaction, D2H of the overlap records
+//   encode       : serial delta + varint coding of the records on the host (lib/ovl.c:109-150)
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/ndgpu_overlap.h"
+#include "ovl_device.h"
+
+namespace ndovl {
+
+#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[ndgpu_overlap] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); throw std::runtime_error("hip"); } } while (0)
+
+template <class T> struct DevBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	DevBuf() = default;
+	explicit DevBuf(size_t count) { alloc(count); }
+	DevBuf(const DevBuf&) = delete;
+	DevBuf &operator=(const DevBuf&) = delete;
+	DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+	DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p, n = o.n; o.p = nullptr, o.n = 0; } return *this; }
+	~DevBuf() { release(); }
+	void alloc(size_t count) { release(); n = count; if (count) HIP_OK(hipMalloc((void**)&p, count * sizeof(T))); }
+	void release() { if (p) (void)hipFree(p); p = nullptr, n = 0; }
+	void upload(const T *src, size_t count, hipStream_t s) { if (count) HIP_OK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+	void download(T *dst, size_t count, hipStream_t s, size_t from = 0) const { if (count) HIP_OK(hipMemcpyAsync(dst, p + from, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
+	void zero(hipStream_t s) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+// strcmp() order of "%u" names as an integer key: digits left-aligned to 10 places, length as tie-break
+static uint64_t name_key(uint32_t id)
+{
+	static const uint64_t p10[11] = {1ULL, 10ULL, 100ULL, 1000ULL, 10000ULL, 100000ULL, 1000000ULL, 10000000ULL, 100000000ULL, 1000000000ULL,
+	                                 10000000000ULL};
+	int nd = 1;
+	while (nd < 10 && (uint64_t)id >= p10[nd]) ++nd;
+	return ((uint64_t)id * p10[10 - nd]) << 4 | (uint64_t)nd;
+}
+
+static uint32_t wang32(uint32_t key)
+{
+	key += ~(key << 15); key ^= key >> 10; key += key << 3;
+	key ^= key >> 6; key += ~(key << 11); key ^= key >> 16;
+	return key;
+}
+
+// per-read hash that orders a read's hits (minimap2/map.c:519-521): X31 over the decimal name
+static uint32_t read_hash(uint32_t id, uint32_t qlen, int seed)
+{
+	char name[16];
+	snprintf(name, sizeof(name), "%u", id);
+	uint32_t h = (uint32_t)name[0];
+	for (const char *s = name + 1; *s; ++s) h = (h << 5) - h + (uint32_t)*s;
+	h ^= wang32(qlen) + wang32((uint32_t)seed);
+	return wang32(h);
+}
+
+static unsigned bits_for(uint64_t max_value) // bits needed to hold values 0..max_value
+{
+	unsigned b = 1;
+	while (b < 64 && (max_value >> b)) ++b;
+	return b;
+}
+
+struct EvTimer {
+	hipEvent_t a, b;
+	hipStream_t s;
+	EvTimer(hipStream_t st) : s(st) { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
+	~EvTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+	void start() { HIP_OK(hipEventRecord(a, s)); }
+	double stop() { HIP_OK(hipEventRecord(b, s)); HIP_OK(hipEventSynchronize(b)); float ms = 0; HIP_OK(hipEventElapsedTime(&ms, a, b)); return ms; }
+};
+
+struct ReadSetDev {
+	uint32_t n = 0;
+	uint64_t bases = 0;
+	uint32_t max_len = 0;
+	DevBuf<uint32_t> words, len, id, order;
+	DevBuf<uint64_t> woff, namekey;
+	void upload(uint32_t n_reads, const uint32_t *w, uint64_t n_words, const uint64_t *off, const uint32_t *lens, const uint32_t *ids,
+	            hipStream_t s)
+	{
+		n = n_reads;
+		words.alloc(n_words + 1); words.upload(w, n_words, s);
+		woff.alloc(n); woff.upload(off, n, s);
+		len.alloc(n); len.upload(lens, n, s);
+		id.alloc(n); id.upload(ids, n, s);
+		std::vector<uint64_t> nk(n);
+		std::vector<uint32_t> ord(n);
+		bases = 0, max_len = 0;
+		for (uint32_t i = 0; i < n; ++i) { nk[i] = name_key(ids[i]); ord[i] = i; bases += lens[i]; max_len = std::max(max_len, lens[i]); }
+		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
+		namekey.alloc(n); namekey.upload(nk.data(), n, s);
+		order.alloc(n); order.upload(ord.data(), n, s);
+		HIP_OK(hipStreamSynchronize(s));
+	}
+};
+
+struct Sketch { // minimizers of a read set
+	uint64_t n = 0;
+	DevBuf<uint64_t> x, y, off; // off: n_reads + 1
+	DevBuf<uint32_t> read;
+};
+
+struct Engine {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	OvlParams P{};
+	ReadSetDev T;
+	uint64_t n_min = 0, n_keys = 0;
+	DevBuf<uint64_t> ukey, ustart, pos;
+	DevBuf<uint32_t> ucnt;
+	ndgpu_ovl_stats st{};
+	// debug view of the last map batch
+	std::vector<uint64_t> dbg_aoff;
+	DevBuf<uint64_t> dbg_ax, dbg_ay;
+	DevBuf<int32_t> dbg_f, dbg_p;
+	uint32_t dbg_r0 = 0, dbg_n = 0;
+
+	DevBuf<uint8_t> tmp;
+	void *temp(size_t bytes) { if (tmp.n < bytes) tmp.alloc(bytes + bytes / 4); return tmp.p; }
+
+	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p}; }
+
+	void sketch(const ReadSetDev &R, int rid_is_index, bool want_read, Sketch &out)
+	{
+		DevBuf<uint32_t> cnt(R.n + 1);
+		cnt.zero(stream);
+		EvTimer tm(stream);
+		tm.start();
+		launch_sketch(false, R.words.p, R.woff.p, R.len.p, R.order.p, R.n, P, rid_is_index, nullptr, nullptr, nullptr, nullptr, cnt.p, stream);
+		out.off.alloc(R.n + 1);
+		size_t tb = 0;
+		exscan_u32_to_u64(nullptr, tb, cnt.p, out.off.p, R.n + 1, stream);
+		exscan_u32_to_u64(temp(tb), tb, cnt.p, out.off.p, R.n + 1, stream);
+		uint64_t total = 0;
+		out.off.download(&total, 1, stream, R.n);
+		HIP_OK(hipStreamSynchronize(stream));
+		out.n = total;
+		out.x.alloc(total + 1); out.y.alloc(total + 1);
+		if (want_read) out.read.alloc(total + 1);
+		launch_sketch(true, R.words.p, R.woff.p, R.len.p, R.order.p, R.n, P, rid_is_index, out.off.p, out.x.p, out.y.p,
+		              want_read ? out.read.p : nullptr, nullptr, stream);
+		HIP_OK(hipGetLastError());
+		st.sketch_ms += tm.stop();
+		st.bases_sketched += 2 * R.bases; // count pass + fill pass
+		st.minimizers += total;
+	}
+
+	void build_index()
+	{
+		Sketch S;
+		sketch(T, 1, false, S);
+		n_min = S.n;
+		EvTimer tm(stream);
+		tm.start();
+		DevBuf<uint64_t> key(n_min + 1), key2(n_min + 1), y2(n_min + 1);
+		launch_shift_keys(S.x.p, key.p, n_min, stream);
+		// by position first (read<<32 | pos<<1 | strand), then stably by minimizer
+		const unsigned ybits = 32 + bits_for(T.n ? T.n - 1 : 0);
+		size_t tb = 0;
+		sort_pairs_u64(nullptr, tb, S.y.p, y2.p, key.p, key2.p, n_min, 0, ybits, stream);
+		if (n_min) sort_pairs_u64(temp(tb), tb, S.y.p, y2.p, key.p, key2.p, n_min, 0, ybits, stream);
+		pos.alloc(n_min + 1);
+		const unsigned kbits = 2u * (unsigned)P.k;
+		tb = 0;
+		sort_pairs_u64(nullptr, tb, key2.p, key.p, y2.p, pos.p, n_min, 0, kbits, stream);
+		if (n_min) sort_pairs_u64(temp(tb), tb, key2.p, key.p, y2.p, pos.p, n_min, 0, kbits, stream);
+		// distinct minimizers and their occurrence counts
+		DevBuf<uint64_t> uniq(n_min + 1), n_runs(1);
+		ucnt.alloc(n_min + 2);
+		ucnt.zero(stream);
+		n_keys = 0;
+		if (n_min) {
+			tb = 0;
+			rle_u64(nullptr, tb, key.p, n_min, uniq.p, ucnt.p, n_runs.p, stream);
+			rle_u64(temp(tb), tb, key.p, n_min, uniq.p, ucnt.p, n_runs.p, stream);
+			n_runs.download(&n_keys, 1, stream);
+			HIP_OK(hipStreamSynchronize(stream));
+		}
+		ukey.alloc(n_keys + 1);
+		if (n_keys) HIP_OK(hipMemcpyAsync(ukey.p, uniq.p, n_keys * 8, hipMemcpyDeviceToDevice, stream));
+		ustart.alloc(n_keys + 2);
+		tb = 0;
+		exscan_u32_to_u64(nullptr, tb, ucnt.p, ustart.p, n_keys + 1, stream);
+		exscan_u32_to_u64(temp(tb), tb, ucnt.p, ustart.p, n_keys + 1, stream);
+		HIP_OK(hipGetLastError());
+		st.index_sort_ms += tm.stop();
+	}
+
+	int32_t mid_occ(float f)
+	{
+		if (f <= 0.) return INT32_MAX;
+		if (!n_keys) return 1;
+		DevBuf<uint32_t> sorted(n_keys);
+		size_t tb = 0;
+		sort_keys_u32(nullptr, tb, ucnt.p, sorted.p, n_keys, stream);
+		sort_keys_u32(temp(tb), tb, ucnt.p, sorted.p, n_keys, stream);
+		const uint32_t kth = (uint32_t)((1. - f) * n_keys);
+		uint32_t v = 0;
+		sorted.download(&v, 1, stream, kth);
+		HIP_OK(hipStreamSynchronize(stream));
+		return (int32_t)(v + 1);
+	}
+
+	int64_t map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
+	            const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out);
+};
+
+static OvlParams to_params(const ndgpu_ovl_opt &o)
+{
+	OvlParams P{};
+	P.k = o.k, P.w = o.w, P.hpc = o.hpc, P.no_diag = o.no_diag, P.no_dual = o.no_dual, P.min_cnt = o.min_cnt, P.min_sc = o.min_chain_score;
+	P.bw = o.bw, P.max_gap = o.max_gap, P.max_skip = o.max_chain_skip, P.max_iter = o.max_chain_iter, P.minlen = o.minlen, P.dvt = o.dvt;
+	P.maxhan1 = o.maxhan1, P.maxhan2 = o.maxhan2;
+	return P;
+}
+
+static const char *check_opt(const ndgpu_ovl_opt &o)
+{
+	if (o.k < 1 || o.k > 28) return "k must be in 1..28 (the k > 28 sketch of ava-hifi is not built)";
+	if (o.w < 1 || o.w > 64) return "w must be in 1..64";
+	if (o.min_cnt < 2) return "min_cnt must be >= 2";
+	if (o.max_chain_iter < 1 || o.max_chain_iter >= 8192) return "max_chain_iter must be in 1..8191";
+	if (o.max_gap < 0 || o.bw < 0) return "negative max_gap / bw";
+	return nullptr;
+}
+
+int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
+                    const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out)
+{
+	OvlParams Pm = to_params(o);
+	Pm.k = P.k, Pm.w = P.w, Pm.hpc = P.hpc; // the sketch parameters belong to the index
+	const OvlParams Pi = P;
+	P = Pm;
+	struct Restore { Engine *e; OvlParams p; ~Restore() { e->P = p; } } restore{this, Pi};
+	++st.map_calls;
+	out.clear();
+	if (!n_q) return 0;
+
+	ReadSetDev Q;
+	Q.upload(n_q, words, n_words, woff, lens, ids, stream);
+	std::vector<uint32_t> qh(n_q);
+	for (uint32_t i = 0; i < n_q; ++i) qh[i] = read_hash(ids[i], lens[i], o.seed);
+	DevBuf<uint32_t> qhash(n_q);
+	qhash.upload(qh.data(), n_q, stream);
+
+	Sketch S;
+	sketch(Q, 0, true, S);
+	const uint64_t n_m = S.n;
+	const IndexDev ix = index_dev();
+	const QueryDev qd{Q.len.p, Q.id.p, qhash.p, Q.namekey.p, S.off.p};
+
+	// K3a over every query minimizer
+	EvTimer tm(stream);
+	tm.start();
+	DevBuf<uint32_t> m_start(n_m + 1), m_cnt(n_m + 1), m_surv(n_m + 2);
+	m_surv.zero(stream);
+	launch_seed_count(S.x.p, S.y.p, S.read.p, n_m, ix, qd, P, mid, m_start.p, m_cnt.p, m_surv.p, stream);
+	DevBuf<uint64_t> a_off(n_m + 2);
+	size_t tb = 0;
+	exscan_u32_to_u64(nullptr, tb, m_surv.p, a_off.p, n_m + 1, stream);
+	exscan_u32_to_u64(temp(tb), tb, m_surv.p, a_off.p, n_m + 1, stream);
+	uint64_t total_a = 0;
+	a_off.download(&total_a, 1, stream, n_m);
+	HIP_OK(hipStreamSynchronize(stream));
+	DevBuf<uint64_t> r_aoff_all(n_q + 1);
+	launch_gather_read_off(a_off.p, S.off.p, n_q, n_m, total_a, r_aoff_all.p, stream);
+	std::vector<uint64_t> h_raoff(n_q + 1), h_moff(n_q + 1);
+	r_aoff_all.download(h_raoff.data(), n_q + 1, stream);
+	S.off.download(h_moff.data(), n_q + 1, stream);
+	HIP_OK(hipGetLastError());
+	st.seed_ms += tm.stop();
+	st.anchors += total_a;
+
+	// batches of query reads bounded by an anchor budget and by the sort-key width
+	const unsigned pos_bits = bits_for(T.max_len ? T.max_len - 1 : 0);
+	const unsigned rid_bits = bits_for(T.n ? T.n - 1 : 0);
+	if (pos_bits + rid_bits + 1 >= 63) { fprintf(stderr, "[ndgpu_overlap] target set too large for the anchor sort key\n"); return -1; }
+	const unsigned read_bits_max = 64 - (pos_bits + rid_bits + 1);
+	const uint64_t max_batch_reads = read_bits_max >= 32 ? 0xffffffffULL : (1ULL << read_bits_max);
+	uint64_t budget = 192ULL << 20; // anchors per batch (~100 B of HBM each)
+	if (const char *e = getenv("NDGPU_OVL_BATCH_ANCHORS")) budget = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
+
+	uint32_t r0 = 0;
+	while (r0 < n_q) {
+		uint32_t r1 = r0;
+		while (r1 < n_q && (r1 - r0) < max_batch_reads && (r1 == r0 || h_raoff[r1 + 1] - h_raoff[r0] <= budget)) ++r1;
+		const uint32_t nb = r1 - r0;
+		const uint64_t a_base = h_raoff[r0], na = h_raoff[r1] - a_base;
+		++st.batches;
+		if (na == 0) { r0 = r1; continue; }
+		KeyLayout L;
+		L.pos_bits = pos_bits, L.rev_shift = pos_bits + rid_bits, L.read_shift = L.rev_shift + 1, L.read_base = r0;
+		L.total_bits = L.read_shift + bits_for(nb - 1);
+
+		DevBuf<uint64_t> r_aoff(nb + 1);
+		launch_local_off(r_aoff_all.p, r0, nb, r_aoff.p, stream);
+		DevBuf<uint64_t> ckey(na), uy(na), skey(na), ay(na);
+		tm.start();
+		launch_seed_fill(S.x.p, S.y.p, S.read.p, h_moff[r0], h_moff[r1], ix, qd, P, m_start.p, m_cnt.p, a_off.p, a_base, L, ckey.p, uy.p,
+		                 stream);
+		HIP_OK(hipGetLastError());
+		st.seed_ms += tm.stop();
+
+		tm.start();
+		tb = 0;
+		sort_pairs_u64(nullptr, tb, ckey.p, skey.p, uy.p, ay.p, na, 0, L.total_bits, stream);
+		sort_pairs_u64(temp(tb), tb, ckey.p, skey.p, uy.p, ay.p, na, 0, L.total_bits, stream);
+		DevBuf<uint64_t> ax(na);
+		DevBuf<uint32_t> tie(nb);
+		tie.zero(stream);
+		launch_anchor_decode(skey.p, na, L, ax.p, tie.p, stream);
+		std::vector<uint32_t> h_tie(nb);
+		tie.download(h_tie.data(), nb, stream);
+		HIP_OK(hipGetLastError());
+		st.sort_ms += tm.stop();
+		std::vector<uint32_t> tie_reads;
+		for (uint32_t i = 0; i < nb; ++i) if (h_tie[i]) tie_reads.push_back(i);
+		st.tie_reads += tie_reads.size();
+		DevBuf<uint8_t> stacks((na / 64 + 2 * (size_t)nb + 4) * sort_job_bytes());
+		if (!tie_reads.empty()) {
+			tm.start();
+			DevBuf<uint32_t> d_tie(tie_reads.size());
+			d_tie.upload(tie_reads.data(), tie_reads.size(), stream);
+			launch_exact_sort(d_tie.p, (uint32_t)tie_reads.size(), r_aoff.p, ckey.p, uy.p, L, ax.p, ay.p, stacks.p, stream);
+			HIP_OK(hipGetLastError());
+			st.exact_sort_ms += tm.stop();
+		}
+		ckey.release(); uy.release(); skey.release();
+
+		// K4
+		DevBuf<int32_t> f(na), p(na), v(na), t(na);
+		DevBuf<unsigned long long> cells(1);
+		cells.zero(stream);
+		tm.start();
+		launch_chain(r_aoff.p, nb, ax.p, ay.p, P, f.p, p.p, v.p, cells.p, stream);
+		HIP_OK(hipGetLastError());
+		st.chain_ms += tm.stop();
+		unsigned long long h_cells = 0;
+		cells.download(&h_cells, 1, stream);
+
+		// K5 (keeps copies of f/p for the debug view first: K5 reuses v and t only)
+		const uint64_t rec_cap = na / (uint64_t)std::max(1, P.min_cnt) + nb + 1;
+		DevBuf<uint64_t> u(na), bx(na), by(na), wx(na), wy(na);
+		DevBuf<uint32_t> tables((size_t)nb * 512), n_rec(nb + 1), n_chain(nb);
+		DevBuf<OvlRec> recs(rec_cap);
+		n_rec.zero(stream);
+		tm.start();
+		launch_hits(r_aoff.p, nb, r0, ax.p, ay.p, ix, qd, P, f.p, p.p, v.p, t.p, u.p, bx.p, by.p, wx.p, wy.p, tables.p, stacks.p, recs.p,
+		            n_rec.p, n_chain.p, stream);
+		DevBuf<uint64_t> rec_off(nb + 1);
+		tb = 0;
+		exscan_u32_to_u64(nullptr, tb, n_rec.p, rec_off.p, nb + 1, stream);
+		exscan_u32_to_u64(temp(tb), tb, n_rec.p, rec_off.p, nb + 1, stream);
+		uint64_t n_out = 0;
+		rec_off.download(&n_out, 1, stream, nb);
+		std::vector<uint32_t> h_chain(nb);
+		n_chain.download(h_chain.data(), nb, stream);
+		HIP_OK(hipStreamSynchronize(stream));
+		DevBuf<OvlRec> dense(n_out + 1);
+		launch_compact_recs(r_aoff.p, nb, P.min_cnt, recs.p, n_rec.p, rec_off.p, dense.p, stream);
+		HIP_OK(hipGetLastError());
+		st.hits_ms += tm.stop();
+		const size_t old = out.size();
+		out.resize(old + n_out);
+		if (n_out) HIP_OK(hipMemcpyAsync(out.data() + old, dense.p, n_out * sizeof(OvlRec), hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipStreamSynchronize(stream));
+		st.chain_cells += h_cells;
+		for (uint32_t c : h_chain) st.chains += c;
+		st.overlaps += n_out;
+
+		// debug view (last batch)
+		dbg_r0 = r0, dbg_n = nb;
+		dbg_aoff.assign(h_raoff.begin() + r0, h_raoff.begin() + r1 + 1);
+		for (auto &x : dbg_aoff) x -= a_base;
+		dbg_ax = std::move(ax); dbg_ay = std::move(ay); dbg_f = std::move(f); dbg_p = std::move(p);
+		r0 = r1;
+	}
+	return (int64_t)out.size();
+}
+
+} // namespace ndovl
+
+using namespace ndovl;
+
+struct ndgpu_ovl_index { Engine e; };
+
+extern "C" {
+
+int ndgpu_ovl_opt_preset(const char *preset, ndgpu_ovl_opt *o)
+{
+	memset(o, 0, sizeof(*o));
+	// mm_idxopt_init / mm_mapopt_init (minimap2/options.c:4-62) + --step 1 (main.c:192-193)
+	o->k = 15, o->w = 10, o->hpc = 0;
+	o->seed = 11, o->mid_occ_frac = 2e-4f, o->min_cnt = 3, o->min_chain_score = 40, o->bw = 500, o->max_gap = 5000;
+	o->max_chain_skip = 25, o->max_chain_iter = 5000, o->minlen = 500, o->maxhan1 = 5000, o->maxhan2 = 500, o->dvt = 0;
+	if (!preset) return 0;
+	if (strcmp(preset, "ava-ont") == 0) { // options.c:84-88
+		o->k = 15, o->w = 5, o->hpc = 0, o->no_diag = 1, o->no_dual = 1;
+		o->min_chain_score = 100, o->max_gap = 10000, o->max_chain_skip = 25, o->bw = 2000;
+	} else if (strcmp(preset, "ava-pb") == 0) { // options.c:89-92
+		o->k = 19, o->w = 5, o->hpc = 1, o->no_diag = 1, o->no_dual = 1;
+		o->min_chain_score = 100, o->max_gap = 10000, o->max_chain_skip = 25;
+	} else {
+		fprintf(stderr, "[ndgpu_overlap] preset '%s' is not supported (ava-ont, ava-pb)\n", preset);
+		return -1;
+	}
+	return 0;
+}
+
+ndgpu_ovl_index *ndgpu_ovl_index_create(const ndgpu_ovl_opt *opt, uint32_t n_reads, const uint32_t *words, uint64_t n_words,
+                                        const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids)
+{
+	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return nullptr; }
+	ndgpu_ovl_index *h = nullptr;
+	try {
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+			fprintf(stderr, "[ndgpu_overlap] no HIP device: the overlap engine has no CPU path\n");
+			return nullptr;
+		}
+		int dev = 0;
+		if (const char *e = getenv("NDGPU_DEVICE")) dev = atoi(e);
+		HIP_OK(hipSetDevice(dev));
+		h = new ndgpu_ovl_index();
+		h->e.device = dev;
+		HIP_OK(hipStreamCreate(&h->e.stream));
+		h->e.P = to_params(*opt);
+		h->e.T.upload(n_reads, words, n_words, word_off, lens, ids, h->e.stream);
+		h->e.build_index();
+		return h;
+	} catch (...) {
+		delete h;
+		return nullptr;
+	}
+}
+
+void ndgpu_ovl_index_destroy(ndgpu_ovl_index *h)
+{
+	if (!h) return;
+	hipStream_t s = h->e.stream;
+	if (s) (void)hipStreamSynchronize(s);
+	delete h;
+	if (s) (void)hipStreamDestroy(s);
+}
+
+int32_t ndgpu_ovl_index_mid_occ(ndgpu_ovl_index *h, float frac)
+{
+	try { return h->e.mid_occ(frac); } catch (...) { return -1; }
+}
+
+void ndgpu_ovl_index_stat(const ndgpu_ovl_index *h, uint64_t n[3]) { n[0] = h->e.n_min, n[1] = h->e.n_keys, n[2] = h->e.T.n; }
+
+int64_t ndgpu_ovl_map(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                      uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, ndgpu_ovl_rec **recs)
+{
+	*recs = nullptr;
+	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return -1; }
+	try {
+		HIP_OK(hipSetDevice(h->e.device));
+		std::vector<OvlRec> out;
+		int64_t n = h->e.map(*opt, mid_occ, n_reads, words, n_words, word_off, lens, ids, out);
+		if (n < 0) return n;
+		static_assert(sizeof(OvlRec) == sizeof(ndgpu_ovl_rec), "record layout");
+		*recs = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec) * (size_t)(n ? n : 1));
+		if (n) memcpy(*recs, out.data(), sizeof(ndgpu_ovl_rec) * (size_t)n);
+		return n;
+	} catch (...) {
+		return -2;
+	}
+}
+
+static int put_varint(uint8_t *out, uint32_t v)
+{
+	if (v <= 127) { out[0] = (uint8_t)v; return 1; }
+	int m = 0;
+	for (int sh = 28; sh >= 0; sh -= 7) {
+		const uint32_t g = v >> sh & 127;
+		if (g > 0 || m > 0) out[m++] = (uint8_t)(g | 128);
+	}
+	out[m - 1] &= 127;
+	return m;
+}
+
+int64_t ndgpu_ovl_encode(const ndgpu_ovl_rec *recs, int64_t n, uint32_t prev[2], uint8_t *out)
+{
+	int64_t nb = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		const ndgpu_ovl_rec &r = recs[i];
+		uint32_t fld[8], flags = r.rev;
+		const uint32_t qspan = r.qe - r.qs, tspan = r.te - r.ts;
+		fld[3] = qspan;
+		if (r.qname >= prev[0]) fld[0] = r.qname - prev[0]; else flags |= 2, fld[0] = prev[0] - r.qname;
+		prev[0] = r.qname;
+		if (r.tname >= prev[1]) fld[4] = r.tname - prev[1]; else flags |= 4, fld[4] = prev[1] - r.tname;
+		prev[1] = r.tname;
+		if (qspan >= tspan) fld[6] = qspan - tspan; else flags |= 8, fld[6] = tspan - qspan;
+		fld[1] = flags & 0xff, fld[2] = r.qs, fld[5] = r.ts, fld[7] = r.match;
+		for (int k = 0; k < 8; ++k) nb += put_varint(out + nb, fld[k]);
+	}
+	return nb;
+}
+
+void ndgpu_ovl_free(void *p) { free(p); }
+
+int64_t ndgpu_ovl_sketch(const ndgpu_ovl_opt *opt, uint32_t n_reads, const uint32_t *words, uint64_t n_words, const uint64_t *word_off,
+                         const uint32_t *lens, int rid_is_index, uint64_t **x, uint64_t **y, uint64_t *off)
+{
+	*x = *y = nullptr;
+	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return -1; }
+	try {
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { fprintf(stderr, "[ndgpu_overlap] no HIP device\n"); return -1; }
+		Engine e;
+		if (const char *d = getenv("NDGPU_DEVICE")) e.device = atoi(d);
+		HIP_OK(hipSetDevice(e.device));
+		HIP_OK(hipStreamCreate(&e.stream));
+		e.P = to_params(*opt);
+		std::vector<uint32_t> ids(n_reads, 0);
+		ReadSetDev R;
+		R.upload(n_reads, words, n_words, word_off, lens, ids.data(), e.stream);
+		Sketch S;
+		e.sketch(R, rid_is_index, false, S);
+		*x = (uint64_t*)malloc(8 * (S.n + 1)), *y = (uint64_t*)malloc(8 * (S.n + 1));
+		S.x.download(*x, S.n, e.stream); S.y.download(*y, S.n, e.stream); S.off.download(off, n_reads + 1, e.stream);
+		HIP_OK(hipStreamSynchronize(e.stream));
+		const int64_t n = (int64_t)S.n;
+		S = Sketch(); R = ReadSetDev(); e.tmp.release();
+		(void)hipStreamDestroy(e.stream);
+		return n;
+	} catch (...) {
+		return -2;
+	}
+}
+
+void ndgpu_ovl_index_dump(const ndgpu_ovl_index *h, uint64_t *key, uint64_t *start, uint64_t *pos)
+{
+	const Engine &e = h->e;
+	e.ukey.download(key, e.n_keys, e.stream);
+	e.ustart.download(start, e.n_keys + 1, e.stream);
+	e.pos.download(pos, e.n_min, e.stream);
+	(void)hipStreamSynchronize(e.stream);
+}
+
+int64_t ndgpu_ovl_debug_anchors(ndgpu_ovl_index *h, uint32_t q, uint64_t **ax, uint64_t **ay, int32_t **f, int32_t **p)
+{
+	Engine &e = h->e;
+	*ax = *ay = nullptr, *f = *p = nullptr;
+	if (q < e.dbg_r0 || q >= e.dbg_r0 + e.dbg_n) return -1;
+	const uint64_t a0 = e.dbg_aoff[q - e.dbg_r0], n = e.dbg_aoff[q - e.dbg_r0 + 1] - a0;
+	*ax = (uint64_t*)malloc(8 * (n + 1)), *ay = (uint64_t*)malloc(8 * (n + 1));
+	*f = (int32_t*)malloc(4 * (n + 1)), *p = (int32_t*)malloc(4 * (n + 1));
+	e.dbg_ax.download(*ax, n, e.stream, a0); e.dbg_ay.download(*ay, n, e.stream, a0);
+	e.dbg_f.download(*f, n, e.stream, a0); e.dbg_p.download(*p, n, e.stream, a0);
+	(void)hipStreamSynchronize(e.stream);
+	return (int64_t)n;
+}
+
+void ndgpu_ovl_get_stats(const ndgpu_ovl_index *h, ndgpu_ovl_stats *st) { *st = h->e.st; }
+void ndgpu_ovl_reset_stats(ndgpu_ovl_index *h) { h->e.st = ndgpu_ovl_stats{}; }
+
+} // extern "C"

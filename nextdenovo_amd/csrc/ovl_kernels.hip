@@ -1,0 +1,796 @@
+// ovl_kernels.hip -- gfx950 kernels of the overlap engine (`minimap2-nd --step 1` path).
+//
+//   K1  sketch_kernel        (w,k)-minimizers of every read            (minimap2/sketch.c:75-143)
+//   K2  rocPRIM radix sort + run-length encode -> index arrays          (minimap2/index.c:197-250)
+//   K3a seed_count_kernel    index lookup + surviving-hit count         (minimap2/map.c:91-152)
+//   K3b seed_fill_kernel     anchors in generation order + sort key     (minimap2/map.c:214-246)
+//   K3s rocPRIM radix sort of (read | strand | target | position) keys; anchor_decode_kernel flags
+//       reads that hold equal keys; exact_sort_kernel replays the reference's unstable in-place
+//       radix sort (minimap2/ksort.h:100-151) for exactly those reads
+//   K4  chain_kernel         chaining DP, one wavefront per query read  (minimap2/chain.c:44-85)
+//   K5  hits_kernel          chain ends, backtrack, ordering, hit coordinates, step-1 filter
+//                            (minimap2/chain.c:87-162, hit.c:8-95, map.c:1296-1304)
+//
+// Integer / byte work, HBM- and latency-bound: nothing here is shaped like a GEMM.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "ovl_device.h"
+
+namespace ndovl {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+
+__device__ __forceinline__ uint64_t hash_masked(uint64_t key, uint64_t mask)
+{
+	key = (~key + (key << 21)) & mask;
+	key ^= key >> 24;
+	key = (key + (key << 3) + (key << 8)) & mask;
+	key ^= key >> 14;
+	key = (key + (key << 2) + (key << 4)) & mask;
+	key ^= key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+__device__ __forceinline__ uint64_t hash_full(uint64_t key)
+{
+	key = ~key + (key << 21);
+	key ^= key >> 24;
+	key = key + (key << 3) + (key << 8);
+	key ^= key >> 14;
+	key = key + (key << 2) + (key << 4);
+	key ^= key >> 28;
+	key = key + (key << 31);
+	return key;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: minimizer sketch.  One lane walks one read (the window automaton is sequential); reads are
+// handed out longest-first so that the lanes of a wavefront finish together.  The w-slot ring lives
+// in LDS, transposed so that lane l touches bank (l mod 32) only.
+
+struct BaseReader {
+	const uint32_t *w;
+	uint32_t cur;
+	int cur_idx;
+	__device__ BaseReader(const uint32_t *p) : w(p), cur(0), cur_idx(-1) {}
+	__device__ __forceinline__ int at(int i)
+	{
+		int wi = i >> 4;
+		if (wi != cur_idx) cur = w[wi], cur_idx = wi;
+		return (int)(cur >> (30 - 2 * (i & 15)) & 3u);
+	}
+};
+
+template <bool FILL>
+__global__ void __launch_bounds__(64) sketch_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ woff,
+                                                     const uint32_t *__restrict__ len, const uint32_t *__restrict__ order,
+                                                     uint32_t n_reads, int w, int k, int hpc, int rid_is_index,
+                                                     const uint64_t *__restrict__ out_off, uint64_t *__restrict__ out_x,
+                                                     uint64_t *__restrict__ out_y, uint32_t *__restrict__ out_read,
+                                                     uint32_t *__restrict__ out_cnt)
+{
+	extern __shared__ uint8_t smem[];
+	uint64_t *ring_x = reinterpret_cast<uint64_t*>(smem);                      // [w][64]
+	uint32_t *ring_y = reinterpret_cast<uint32_t*>(smem + (size_t)w * 64 * 8); // [w][64]
+	uint16_t *runq = reinterpret_cast<uint16_t*>(smem + (size_t)w * 64 * 12);  // [32][64]
+	const int lane = threadIdx.x;
+	const uint32_t slot_r = blockIdx.x * 64u + lane;
+	if (slot_r >= n_reads) return;
+	const uint32_t r = order[slot_r];
+	const int n = (int)len[r];
+	const uint64_t rid_hi = rid_is_index ? (uint64_t)r << 32 : 0;
+	uint64_t o = FILL ? out_off[r] : 0;
+	uint32_t cnt = 0;
+	if (n > 0) {
+		BaseReader rd(words + woff[r]);
+		const uint64_t mask = (1ULL << 2 * k) - 1, top = 2ULL * (k - 1);
+		uint64_t fw = 0, rv = 0, best_x = ~0ULL;
+		uint32_t best_y = ~0u;
+		int good = 0, slot = 0, best_slot = 0, span = 0, rq_front = 0, rq_count = 0;
+		for (int j = 0; j < w; ++j) ring_x[j * 64 + lane] = ~0ULL, ring_y[j * 64 + lane] = ~0u;
+#define EMIT(X, Y) do { if (FILL) { out_x[o + cnt] = (X); out_y[o + cnt] = rid_hi | (uint64_t)(Y); if (out_read) out_read[o + cnt] = r; } ++cnt; } while (0)
+		for (int i = 0; i < n; ++i) {
+			const int c = rd.at(i);
+			uint64_t cur_x = ~0ULL;
+			uint32_t cur_y = ~0u;
+			if (hpc) {
+				int run = 1;
+				if (i + 1 < n && rd.at(i + 1) == c) {
+					for (run = 2; i + run < n; ++run)
+						if (rd.at(i + run) != c) break;
+					i += run - 1;
+				}
+				const int rc = run > 256 ? 256 : run; // only "span < 256" and spans below it are observable
+				runq[((rq_count++ + rq_front) & 31) * 64 + lane] = (uint16_t)rc;
+				span += rc;
+				if (rq_count > k) { span -= runq[rq_front * 64 + lane]; rq_front = (rq_front + 1) & 31; --rq_count; }
+			} else span = good + 1 < k ? good + 1 : k;
+			fw = (fw << 2 | (uint64_t)c) & mask;
+			rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+			if (fw == rv) continue;
+			const int strand = fw < rv ? 0 : 1;
+			++good;
+			if (good >= k && span < 256) {
+				cur_x = hash_masked(strand ? rv : fw, mask) << 8 | (uint64_t)span;
+				cur_y = (uint32_t)i << 1 | (uint32_t)strand;
+			}
+			ring_x[slot * 64 + lane] = cur_x, ring_y[slot * 64 + lane] = cur_y;
+			if (good == w + k - 1 && best_x != ~0ULL) {
+				for (int j = slot + 1; j < w; ++j)
+					if (ring_x[j * 64 + lane] == best_x && ring_y[j * 64 + lane] != best_y) EMIT(best_x, ring_y[j * 64 + lane]);
+				for (int j = 0; j < slot; ++j)
+					if (ring_x[j * 64 + lane] == best_x && ring_y[j * 64 + lane] != best_y) EMIT(best_x, ring_y[j * 64 + lane]);
+			}
+			if (cur_x <= best_x) {
+				if (good >= w + k && best_x != ~0ULL) EMIT(best_x, best_y);
+				best_x = cur_x, best_y = cur_y, best_slot = slot;
+			} else if (slot == best_slot) {
+				if (good >= w + k - 1 && best_x != ~0ULL) EMIT(best_x, best_y);
+				best_x = ~0ULL;
+				for (int j = slot + 1; j < w; ++j)
+					if (ring_x[j * 64 + lane] <= best_x) best_x = ring_x[j * 64 + lane], best_y = ring_y[j * 64 + lane], best_slot = j;
+				for (int j = 0; j <= slot; ++j)
+					if (ring_x[j * 64 + lane] <= best_x) best_x = ring_x[j * 64 + lane], best_y = ring_y[j * 64 + lane], best_slot = j;
+				if (good >= w + k - 1 && best_x != ~0ULL) {
+					for (int j = slot + 1; j < w; ++j)
+						if (ring_x[j * 64 + lane] == best_x && ring_y[j * 64 + lane] != best_y) EMIT(best_x, ring_y[j * 64 + lane]);
+					for (int j = 0; j <= slot; ++j)
+						if (ring_x[j * 64 + lane] == best_x && ring_y[j * 64 + lane] != best_y) EMIT(best_x, ring_y[j * 64 + lane]);
+				}
+			}
+			if (++slot == w) slot = 0;
+		}
+		if (best_x != ~0ULL) EMIT(best_x, best_y);
+#undef EMIT
+	}
+	if (!FILL) out_cnt[r] = cnt;
+}
+
+size_t sketch_smem(int w) { return (size_t)w * 64 * 12 + 32 * 64 * 2; }
+
+void launch_sketch(bool fill, const uint32_t *words, const uint64_t *woff, const uint32_t *len, const uint32_t *order,
+                   uint32_t n_reads, const OvlParams &P, int rid_is_index, const uint64_t *out_off, uint64_t *out_x,
+                   uint64_t *out_y, uint32_t *out_read, uint32_t *out_cnt, hipStream_t s)
+{
+	if (!n_reads) return;
+	dim3 grid((n_reads + 63) / 64), block(64);
+	size_t sm = sketch_smem(P.w);
+	if (fill)
+		hipLaunchKernelGGL(sketch_kernel<true>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
+		                   out_off, out_x, out_y, out_read, out_cnt);
+	else
+		hipLaunchKernelGGL(sketch_kernel<false>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
+		                   out_off, out_x, out_y, out_read, out_cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels
+
+__global__ void shift_keys_kernel(const uint64_t *__restrict__ x, uint64_t *__restrict__ key, uint64_t n)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) key[i] = x[i] >> 8;
+}
+
+void launch_shift_keys(const uint64_t *x, uint64_t *key, uint64_t n, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(shift_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, key, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rocPRIM wrappers (plain library primitives: LSD radix sort, run-length encode, scans)
+
+#define RP_CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) return (int)_e; } while (0)
+
+int sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout,
+                   size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s)
+{
+	RP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s));
+	return 0;
+}
+
+int sort_keys_u32(void *tmp, size_t &tmp_bytes, const uint32_t *kin, uint32_t *kout, size_t n, hipStream_t s)
+{
+	RP_CHECK(rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, 0, 32, s));
+	return 0;
+}
+
+int rle_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, size_t n, uint64_t *uniq, uint32_t *cnt, uint64_t *n_runs,
+            hipStream_t s)
+{
+	RP_CHECK(rocprim::run_length_encode(tmp, tmp_bytes, kin, (unsigned int)n, uniq, cnt, n_runs, s));
+	return 0;
+}
+
+int exscan_u32_to_u64(void *tmp, size_t &tmp_bytes, const uint32_t *in, uint64_t *out, size_t n, hipStream_t s)
+{
+	auto it = rocprim::make_transform_iterator(in, [] __device__(uint32_t v) { return (uint64_t)v; });
+	RP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: seeds
+
+__device__ __forceinline__ bool index_lookup(const IndexDev &ix, uint64_t minier, uint32_t &start, uint32_t &cnt)
+{
+	uint64_t lo = 0, hi = ix.n_keys;
+	while (lo < hi) {
+		uint64_t mid = (lo + hi) >> 1;
+		if (ix.ukey[mid] < minier) lo = mid + 1; else hi = mid;
+	}
+	if (lo == ix.n_keys || ix.ukey[lo] != minier) { start = 0, cnt = 0; return false; }
+	start = (uint32_t)ix.ustart[lo];
+	cnt = (uint32_t)(ix.ustart[lo + 1] - ix.ustart[lo]);
+	return true;
+}
+
+// skip_seed(): 0 = keep, 1 = drop; *self as the reference's is_self
+__device__ __forceinline__ int seed_skipped(const OvlParams &P, const IndexDev &ix, uint64_t r, uint32_t q_pos, uint64_t q_namekey,
+                                            uint32_t q_len, int *self)
+{
+	*self = 0;
+	if (P.no_diag || P.no_dual) {
+		const uint32_t rid = (uint32_t)(r >> 32);
+		const uint64_t tk = ix.namekey[rid];
+		if (P.no_diag && q_namekey == tk && ix.len[rid] == q_len) {
+			if ((uint32_t)r >> 1 == q_pos >> 1) return 1;
+			if ((r & 1) == (q_pos & 1)) *self = 1;
+		}
+		if (P.no_dual && q_namekey > tk) return 1;
+	}
+	return 0;
+}
+
+__global__ void seed_count_kernel(const uint64_t *__restrict__ mx, const uint64_t *__restrict__ my, const uint32_t *__restrict__ m_read,
+                                  uint64_t n_m, IndexDev ix, QueryDev q, OvlParams P, int mid_occ, uint32_t *__restrict__ m_start,
+                                  uint32_t *__restrict__ m_cnt, uint32_t *__restrict__ m_surv)
+{
+	uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= n_m) return;
+	uint32_t start, cnt, surv = 0;
+	index_lookup(ix, mx[m] >> 8, start, cnt);
+	if ((int64_t)cnt >= (int64_t)mid_occ) cnt = 0; // repetitive minimizer: contributes nothing
+	if (cnt) {
+		const uint32_t rd = m_read[m], q_pos = (uint32_t)my[m];
+		const uint64_t qk = q.namekey[rd];
+		const uint32_t ql = q.len[rd];
+		if (P.no_diag || P.no_dual) {
+			for (uint32_t j = 0; j < cnt; ++j) {
+				int self;
+				surv += !seed_skipped(P, ix, ix.pos[start + j], q_pos, qk, ql, &self);
+			}
+		} else surv = cnt;
+	}
+	m_start[m] = start, m_cnt[m] = cnt, m_surv[m] = surv;
+}
+
+__global__ void seed_fill_kernel(const uint64_t *__restrict__ mx, const uint64_t *__restrict__ my, const uint32_t *__restrict__ m_read,
+                                 uint64_t m0, uint64_t m1, IndexDev ix, QueryDev q, OvlParams P, const uint32_t *__restrict__ m_start,
+                                 const uint32_t *__restrict__ m_cnt, const uint64_t *__restrict__ a_off, uint64_t a_base, KeyLayout L,
+                                 uint64_t *__restrict__ ckey, uint64_t *__restrict__ ay)
+{
+	uint64_t m = m0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= m1) return;
+	const uint32_t cnt = m_cnt[m];
+	if (!cnt) return;
+	const uint32_t start = m_start[m], rd = m_read[m];
+	const uint64_t minier = mx[m] >> 8;
+	const uint32_t q_pos = (uint32_t)my[m], q_span = (uint32_t)(mx[m] & 0xff);
+	const uint64_t qk = q.namekey[rd];
+	const uint32_t ql = q.len[rd];
+	// neighbours inside the same read carrying the same minimizer -> MM_SEED_TANDEM
+	bool tandem = false;
+	if (m > q.m_off[rd] && mx[m - 1] >> 8 == minier) tandem = true;
+	if (m + 1 < q.m_off[rd + 1] && mx[m + 1] >> 8 == minier) tandem = true;
+	uint64_t o = a_off[m] - a_base;
+	const uint64_t rd_bits = (uint64_t)(rd - L.read_base) << L.read_shift;
+	for (uint32_t j = 0; j < cnt; ++j) {
+		const uint64_t r = ix.pos[start + j];
+		int self;
+		if (seed_skipped(P, ix, r, q_pos, qk, ql, &self)) continue;
+		const uint64_t rid = r >> 32, rpos = (uint32_t)r >> 1;
+		uint64_t y, rev;
+		if ((r & 1) == (q_pos & 1)) {
+			rev = 0;
+			y = (uint64_t)q_span << 32 | (uint64_t)(q_pos >> 1);
+		} else {
+			rev = 1;
+			y = (uint64_t)q_span << 32 | (uint64_t)(uint32_t)((int32_t)ql - (int32_t)((q_pos >> 1) + 1 - q_span) - 1);
+		}
+		if (tandem) y |= kSeedTandem;
+		if (self) y |= kSeedSelf;
+		ckey[o] = rd_bits | rev << L.rev_shift | rid << L.pos_bits | rpos;
+		ay[o] = y;
+		++o;
+	}
+}
+
+void launch_seed_count(const uint64_t *mx, const uint64_t *my, const uint32_t *m_read, uint64_t n_m, const IndexDev &ix,
+                       const QueryDev &q, const OvlParams &P, int mid_occ, uint32_t *m_start, uint32_t *m_cnt, uint32_t *m_surv,
+                       hipStream_t s)
+{
+	if (n_m) hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((n_m + 255) / 256)), dim3(256), 0, s, mx, my, m_read, n_m, ix, q, P,
+	                            mid_occ, m_start, m_cnt, m_surv);
+}
+
+void launch_seed_fill(const uint64_t *mx, const uint64_t *my, const uint32_t *m_read, uint64_t m0, uint64_t m1, const IndexDev &ix,
+                      const QueryDev &q, const OvlParams &P, const uint32_t *m_start, const uint32_t *m_cnt, const uint64_t *a_off,
+                      uint64_t a_base, const KeyLayout &L, uint64_t *ckey, uint64_t *ay, hipStream_t s)
+{
+	if (m1 > m0) hipLaunchKernelGGL(seed_fill_kernel, dim3((unsigned)((m1 - m0 + 255) / 256)), dim3(256), 0, s, mx, my, m_read, m0, m1, ix, q,
+	                                P, m_start, m_cnt, a_off, a_base, L, ckey, ay);
+}
+
+// anchor offset of every read (= a_off at the read's first minimizer), n_reads + 1 entries
+__global__ void gather_read_off_kernel(const uint64_t *__restrict__ a_off, const uint64_t *__restrict__ m_off, uint32_t n_reads, uint64_t n_m,
+                                       uint64_t total, uint64_t *__restrict__ r_aoff)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_reads) return;
+	const uint64_t m = m_off[r];
+	r_aoff[r] = m < n_m ? a_off[m] : total;
+}
+
+void launch_gather_read_off(const uint64_t *a_off, const uint64_t *m_off, uint32_t n_reads, uint64_t n_m, uint64_t total,
+                            uint64_t *r_aoff, hipStream_t s)
+{
+	hipLaunchKernelGGL(gather_read_off_kernel, dim3((n_reads + 256) / 256), dim3(256), 0, s, a_off, m_off, n_reads, n_m, total, r_aoff);
+}
+
+__global__ void local_off_kernel(const uint64_t *__restrict__ all, uint32_t r0, uint32_t n, uint64_t *__restrict__ out)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i <= n) out[i] = all[r0 + i] - all[r0];
+}
+
+void launch_local_off(const uint64_t *r_aoff_all, uint32_t r0, uint32_t n, uint64_t *r_aoff, hipStream_t s)
+{
+	hipLaunchKernelGGL(local_off_kernel, dim3((n + 256) / 256), dim3(256), 0, s, r_aoff_all, r0, n, r_aoff);
+}
+
+// sorted keys -> anchor x; a read is flagged when two neighbouring anchors of it carry the same key
+__device__ __forceinline__ uint64_t key_to_x(uint64_t key, const KeyLayout &L)
+{
+	const uint64_t rpos = key & ((1ULL << L.pos_bits) - 1);
+	const uint64_t rid = key >> L.pos_bits & ((1ULL << (L.rev_shift - L.pos_bits)) - 1);
+	const uint64_t rev = key >> L.rev_shift & 1;
+	return rev << 63 | rid << 32 | rpos;
+}
+
+__global__ void anchor_decode_kernel(const uint64_t *__restrict__ skey, uint64_t n, KeyLayout L, uint64_t *__restrict__ ax,
+                                     uint32_t *__restrict__ tie_flag)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t key = skey[i];
+	ax[i] = key_to_x(key, L);
+	if (i > 0 && skey[i - 1] == key) tie_flag[(uint32_t)(key >> L.read_shift)] = 1; // benign race: all writers store 1
+}
+
+void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(anchor_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, n, L, ax, tie_flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's radix_sort_128x, replayed step by step (ksort.h:100-151): in-place MSD "American
+// flag" passes of 8 bits starting at bit 56, buckets of <= 64 elements finished by insertion sort.
+// It is not stable, and the order it leaves equal keys in reaches the chaining DP, so reads that own
+// equal keys are sorted by this code instead of the LSD sort.  Sequential by nature (each step
+// depends on the element just displaced): one lane runs it, tables in LDS or scratch.
+
+struct SortJob { uint32_t beg, end; int32_t shift; };
+
+__device__ void insertion_sort_xy(uint64_t *x, uint64_t *y, uint32_t beg, uint32_t end)
+{
+	for (uint32_t i = beg + 1; i < end; ++i) {
+		if (x[i] < x[i - 1]) {
+			const uint64_t tx = x[i], ty = y[i];
+			uint32_t j = i;
+			for (; j > beg && tx < x[j - 1]; --j) x[j] = x[j - 1], y[j] = y[j - 1];
+			x[j] = tx, y[j] = ty;
+		}
+	}
+}
+
+// head/tail: 256 entries each; stack: room for n/64 + 2 jobs
+__device__ void reference_sort_xy(uint64_t *x, uint64_t *y, uint32_t n, uint32_t *head, uint32_t *tail, SortJob *stack)
+{
+	if (n <= 64) { insertion_sort_xy(x, y, 0, n); return; }
+	int sp = 0;
+	stack[sp++] = SortJob{0, n, 56};
+	while (sp) {
+		const SortJob job = stack[--sp];
+		const int sh = job.shift;
+		for (int d = 0; d < 256; ++d) tail[d] = 0;
+		for (uint32_t i = job.beg; i < job.end; ++i) ++tail[x[i] >> sh & 255];
+		uint32_t run = job.beg;
+		for (int d = 0; d < 256; ++d) { head[d] = run; run += tail[d]; tail[d] = run; }
+		for (int d = 0; d < 256;) {
+			if (head[d] == tail[d]) { ++d; continue; }
+			int to = (int)(x[head[d]] >> sh & 255);
+			if (to == d) { ++head[d]; continue; }
+			uint64_t hx = x[head[d]], hy = y[head[d]];
+			do {
+				const uint32_t at = head[to]++;
+				const uint64_t px = hx, py = hy;
+				hx = x[at], hy = y[at];
+				x[at] = px, y[at] = py;
+				to = (int)(hx >> sh & 255);
+			} while (to != d);
+			const uint32_t at = head[d]++;
+			x[at] = hx, y[at] = hy;
+		}
+		if (sh) {
+			const int next = sh > 8 ? sh - 8 : 0;
+			uint32_t lo = job.beg;
+			for (int d = 0; d < 256; ++d) {
+				const uint32_t hi = tail[d], sz = hi - lo;
+				if (sz > 64) stack[sp++] = SortJob{lo, hi, next};
+				else if (sz > 1) insertion_sort_xy(x, y, lo, hi);
+				lo = hi;
+			}
+		}
+	}
+}
+
+// One wavefront per flagged read: rebuild the read's anchors in generation order from the unsorted
+// key/value arrays, then lane 0 replays the reference sort on them.
+__global__ void __launch_bounds__(64) exact_sort_kernel(const uint32_t *__restrict__ tie_reads, uint32_t n_tie,
+                                                         const uint64_t *__restrict__ r_aoff,
+                                                         const uint64_t *__restrict__ ukey, const uint64_t *__restrict__ uy, KeyLayout L,
+                                                         uint64_t *__restrict__ ax, uint64_t *__restrict__ ay,
+                                                         SortJob *__restrict__ stacks)
+{
+	__shared__ uint32_t head[256], tail[256];
+	if (blockIdx.x >= n_tie) return;
+	const uint32_t rl = tie_reads[blockIdx.x]; // batch-local read index
+	const uint64_t a0 = r_aoff[rl], a1 = r_aoff[rl + 1];
+	const uint32_t n = (uint32_t)(a1 - a0);
+	for (uint32_t i = threadIdx.x; i < n; i += 64) {
+		ax[a0 + i] = key_to_x(ukey[a0 + i], L);
+		ay[a0 + i] = uy[a0 + i];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) reference_sort_xy(ax + a0, ay + a0, n, head, tail, stacks + a0 / 64 + 2 * (size_t)rl);
+}
+
+void launch_exact_sort(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
+                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *stacks, hipStream_t s)
+{
+	if (n_tie) hipLaunchKernelGGL(exact_sort_kernel, dim3(n_tie), dim3(64), 0, s, tie_reads, n_tie, r_aoff, ukey, uy, L, ax, ay,
+	                              (SortJob*)stacks);
+}
+
+size_t sort_job_bytes() { return sizeof(SortJob); }
+
+// ------------------------------------------------------------------------------------------------
+// K4: chaining DP.  One wavefront per query read walks its anchors in order (f[i] depends on every
+// earlier f[j]); the predecessor window of anchor i is scored 64 candidates at a time, newest first,
+// and the reference's sequential inner loop -- running maximum, skip counter with its early exit,
+// "already on a better path" marks -- is reproduced with wavefront prefix operations:
+//   running max        exclusive prefix max over lanes
+//   skip counter       prefix composition of x -> max(x + a, b) maps (+1 / -1 floored at 0)
+//   exit               first lane whose counter exceeds max_skip
+// Marks (t[] in the reference) live in an LDS ring indexed by anchor number; scores/predecessors in HBM.
+
+constexpr int kRing = 8192; // > max_chain_iter (5000)
+
+__device__ __forceinline__ int wave_excl_max(int v, int lane)
+{
+	// inclusive max-scan, then shift by one lane
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		int o = __shfl_up(v, d, 64);
+		if (lane >= d) v = v > o ? v : o;
+	}
+	int e = __shfl_up(v, 1, 64);
+	return lane == 0 ? INT32_MIN : e;
+}
+
+__global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, const uint64_t *__restrict__ ax,
+                                                    const uint64_t *__restrict__ ay, OvlParams P, int32_t *__restrict__ f,
+                                                    int32_t *__restrict__ p, int32_t *__restrict__ v, unsigned long long *__restrict__ cells)
+{
+	__shared__ int32_t ring[kRing];
+	const uint32_t rd = blockIdx.x;
+	if (rd >= n_reads) return;
+	const int lane = threadIdx.x;
+	const uint64_t a0 = r_aoff[rd];
+	const int64_t n = (int64_t)(r_aoff[rd + 1] - a0);
+	if (n == 0) return;
+	const uint64_t *X = ax + a0, *Y = ay + a0;
+	int32_t *F = f + a0, *Pp = p + a0, *V = v + a0;
+
+	// average seed span of the read, as a float quotient
+	unsigned long long sum = 0;
+	for (int64_t i = lane; i < n; i += 64) sum += Y[i] >> 32 & 0xff;
+	for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
+	const float avg_span = (float)((double)(float)sum / (double)(float)n);
+	const double lin = .01;
+
+	for (int i = lane; i < kRing; i += 64) ring[i] = -1;
+	__syncthreads();
+
+	const uint64_t max_dist = (uint64_t)P.max_gap;
+	int64_t st = 0;
+	unsigned long long my_cells = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		const uint64_t ri = X[i];
+		const uint64_t yi = Y[i];
+		const int32_t qi = (int32_t)yi, span = (int32_t)(yi >> 32 & 0xff);
+		while (st < i && ri > X[st] + max_dist) ++st;
+		if (i - st > P.max_iter) st = i - P.max_iter;
+		int32_t best = span, skipped = 0;
+		int64_t best_j = -1;
+		bool stop = false;
+		for (int64_t base = i - 1; base >= st && !stop; base -= 64) {
+			const int64_t j = base - lane;
+			const bool in_win = j >= st;
+			bool act = false;
+			int32_t sc = INT32_MIN, pj = -1;
+			if (in_win) {
+				const uint64_t xj = X[j];
+				const int64_t dr = (int64_t)(ri - xj);
+				const int32_t dq = qi - (int32_t)Y[j];
+				if (!(dr == 0 || dq <= 0 || dq > P.max_gap)) {
+					const int32_t dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
+					if (dd <= P.bw) {
+						int32_t s0 = dq < dr ? dq : (int32_t)dr;
+						if (s0 > span) s0 = span;
+						const int32_t lg = dd ? 31 - __clz(dd) : 0;
+						s0 -= (int)(dd * lin * avg_span) + (lg >> 1);
+						sc = s0 + F[j];
+						pj = Pp[j];
+						act = true;
+					}
+				}
+			}
+			my_cells += in_win;
+			// marks made by this chunk must be visible to its own later lanes: write all, then read
+			if (act && pj >= st) ring[pj & (kRing - 1)] = (int32_t)i; // marks below the window are never read
+			__builtin_amdgcn_wave_barrier();
+			const bool marked = act && ring[(int32_t)j & (kRing - 1)] == (int32_t)i;
+			// running maximum before this lane
+			int run = wave_excl_max(act ? sc : INT32_MIN, lane);
+			if (run < best) run = best;
+			const bool newmax = act && sc > run;
+			// skip counter: compose x -> max(x + a, b)
+			int a = 0, b = INT32_MIN / 2;
+			if (newmax) a = -1, b = 0;
+			else if (marked) a = 1;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const int oa = __shfl_up(a, d, 64), ob = __shfl_up(b, d, 64);
+				if (lane >= d) { // (a,b) after (oa,ob)
+					const int nb = ob + a > b ? ob + a : b;
+					a = oa + a, b = nb;
+				}
+			}
+			const int after = skipped + a > b ? skipped + a : b;
+			const bool exits = marked && !newmax && after > P.max_skip;
+			const unsigned long long exit_mask = __ballot(exits);
+			unsigned long long live = ~0ULL;
+			if (exit_mask) {
+				const int el = __ffsll((long long)exit_mask) - 1;
+				live = el ? (~0ULL >> (64 - el)) : 0ULL; // lanes strictly before the exit lane
+				stop = true;
+			}
+			const unsigned long long nm = __ballot(newmax) & live;
+			if (nm) {
+				const int last = 63 - __clzll((long long)nm);
+				best = __shfl(sc, last, 64);
+				best_j = base - last;
+			}
+			if (!stop) skipped = __shfl(after, 63, 64);
+		}
+		if (lane == 0) {
+			F[i] = best, Pp[i] = (int32_t)best_j;
+			int32_t peak = best;
+			if (best_j >= 0) { const int32_t vb = V[best_j]; if (vb > best) peak = vb; }
+			V[i] = peak;
+		}
+		__threadfence_block();
+		__builtin_amdgcn_wave_barrier();
+	}
+	for (int d = 32; d; d >>= 1) my_cells += __shfl_xor(my_cells, d, 64);
+	if (lane == 0 && cells) atomicAdd(cells, my_cells);
+}
+
+void launch_chain(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f,
+                  int32_t *p, int32_t *v, unsigned long long *cells, hipStream_t s)
+{
+	if (n_reads) hipLaunchKernelGGL(chain_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, ax, ay, P, f, p, v, cells);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: chains -> hits.  Per read the work is a few hundred pointer-chasing steps (peak search,
+// backtrack) and two tiny sorts: one lane per read, 64 reads per wavefront, all reads in flight.
+
+__device__ void heap_sort_desc(uint64_t *a, int32_t n)
+{
+	// min-heap based in-place sort -> descending order
+	for (int32_t start = n / 2 - 1; start >= 0; --start) {
+		int32_t root = start;
+		for (;;) {
+			int32_t c = 2 * root + 1;
+			if (c >= n) break;
+			if (c + 1 < n && a[c + 1] < a[c]) ++c;
+			if (a[root] <= a[c]) break;
+			uint64_t t = a[root]; a[root] = a[c], a[c] = t;
+			root = c;
+		}
+	}
+	for (int32_t end = n - 1; end > 0; --end) {
+		uint64_t t = a[0]; a[0] = a[end], a[end] = t;
+		int32_t root = 0;
+		for (;;) {
+			int32_t c = 2 * root + 1;
+			if (c >= end) break;
+			if (c + 1 < end && a[c + 1] < a[c]) ++c;
+			if (a[root] <= a[c]) break;
+			uint64_t t2 = a[root]; a[root] = a[c], a[c] = t2;
+			root = c;
+		}
+	}
+}
+
+__device__ __forceinline__ int dovetail_class(int rev, uint32_t qs, uint32_t qe, uint32_t qlen, uint32_t ts, uint32_t te, uint32_t tlen,
+                                              int32_t h1, int32_t h2)
+{
+	const uint32_t a = (uint32_t)h1, b = (uint32_t)h2;
+	if (rev) {
+		if (qs <= a && ts <= a) return 1;
+		else if (qlen - qe <= a && tlen - te <= a) return 2;
+	} else {
+		if (qlen - qe <= a && ts <= a) return 4;
+		else if (qs <= a && tlen - te <= a) return 7;
+	}
+	if (h2 > 0) {
+		if (qs <= b && qe + b >= qlen) return 8;
+		if (ts <= b && te + b >= tlen) return 9;
+	}
+	return 0;
+}
+
+__global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *__restrict__ ax,
+                            const uint64_t *__restrict__ ay, IndexDev ix, QueryDev q, OvlParams P, const int32_t *__restrict__ f,
+                            const int32_t *__restrict__ p, int32_t *__restrict__ v, int32_t *__restrict__ t, uint64_t *__restrict__ u,
+                            uint64_t *__restrict__ bx, uint64_t *__restrict__ by, uint64_t *__restrict__ wx, uint64_t *__restrict__ wy,
+                            uint32_t *__restrict__ tables, SortJob *__restrict__ stacks, OvlRec *__restrict__ recs,
+                            uint32_t *__restrict__ n_rec, uint32_t *__restrict__ n_chain)
+{
+	const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rl >= n_reads) return;
+	const uint32_t rd = read_base + rl;
+	const uint64_t a0 = r_aoff[rl];
+	const int32_t n = (int32_t)(r_aoff[rl + 1] - a0);
+	n_rec[rl] = 0, n_chain[rl] = 0;
+	if (n == 0) return;
+	const uint64_t *X = ax + a0, *Y = ay + a0;
+	const int32_t *F = f + a0, *Pp = p + a0;
+	int32_t *V = v + a0, *T = t + a0;
+	uint64_t *U = u + a0, *BX = bx + a0, *BY = by + a0, *WX = wx + a0, *WY = wy + a0;
+	uint32_t *head = tables + (size_t)rl * 512, *tail = head + 256;
+	SortJob *stack = stacks + a0 / 64 + 2 * (size_t)rl;
+
+	// chain ends
+	for (int32_t i = 0; i < n; ++i) T[i] = 0;
+	for (int32_t i = 0; i < n; ++i) if (Pp[i] >= 0) T[Pp[i]] = 1;
+	int32_t n_u = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		if (T[i] == 0 && V[i] >= P.min_sc) {
+			int32_t j = i;
+			while (j >= 0 && F[j] < V[j]) j = Pp[j];
+			if (j < 0) j = i;
+			U[n_u++] = (uint64_t)(uint32_t)F[j] << 32 | (uint32_t)j;
+		}
+	}
+	if (n_u == 0) return;
+	heap_sort_desc(U, n_u); // distinct keys
+
+	// backtrack, best chain first
+	for (int32_t i = 0; i < n; ++i) T[i] = 0;
+	int32_t n_v = 0, k = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const int32_t v0 = n_v, k0 = k;
+		int32_t j = (int32_t)U[i];
+		do { V[n_v++] = j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0);
+		if (j < 0) {
+			if (n_v - v0 >= P.min_cnt) U[k++] = U[i] >> 32 << 32 | (uint64_t)(uint32_t)(n_v - v0);
+		} else if ((int32_t)(U[i] >> 32) - F[j] >= P.min_sc) {
+			if (n_v - v0 >= P.min_cnt) U[k++] = ((U[i] >> 32) - (uint64_t)F[j]) << 32 | (uint64_t)(uint32_t)(n_v - v0);
+		}
+		if (k0 == k) n_v = v0;
+	}
+	n_u = k;
+	if (n_u == 0) return;
+	// chained anchors, each chain in increasing order
+	k = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const int32_t k0 = k, cnt = (int32_t)U[i];
+		for (int32_t j = 0; j < cnt; ++j) { const int32_t src = V[k0 + (cnt - 1 - j)]; BX[k] = X[src], BY[k] = Y[src]; ++k; }
+	}
+	// order chains by the x of their first anchor (the reference sort, ties included)
+	k = 0;
+	for (int32_t i = 0; i < n_u; ++i) { WX[i] = BX[k], WY[i] = (uint64_t)(uint32_t)k << 32 | (uint32_t)i; k += (int32_t)U[i]; }
+	reference_sort_xy(WX, WY, (uint32_t)n_u, head, tail, stack);
+	// hash-ordered hits: z.x = score<<32 | (cnt ^ h), z.y = first<<32 | cnt, over the re-ordered chains
+	const uint32_t qhash = q.hash[rd];
+	// (the host rejects min_cnt < 2, so n_u <= n / 2 and the upper halves of WX/WY are free)
+	uint64_t *ZX = WX + n_u, *ZY = WY + n_u;
+	// The reference now copies the chains back in this order; the anchors are the same, so they are addressed
+	// in place through `first` (their offset in B).
+	for (int32_t i = 0; i < n_u; ++i) {
+		const int32_t src = (int32_t)WY[i];
+		const int32_t first = (int32_t)(WY[i] >> 32), cnt = (int32_t)U[src];
+		const uint32_t h = (uint32_t)hash_full((hash_full(BX[first]) + hash_full(BY[first])) ^ (uint64_t)qhash);
+		ZX[i] = U[src] ^ (uint64_t)h;
+		ZY[i] = (uint64_t)(uint32_t)first << 32 | (uint32_t)cnt;
+	}
+	reference_sort_xy(ZX, ZY, (uint32_t)n_u, head, tail, stack);
+	// reversed: larger first
+	const uint32_t qid = q.id[rd], qlen = q.len[rd];
+	OvlRec *out = recs + a0 / (uint64_t)(P.min_cnt > 1 ? P.min_cnt : 1) + rl;
+	uint32_t n_out = 0;
+	for (int32_t i = n_u - 1; i >= 0; --i) {
+		const int32_t first = (int32_t)(ZY[i] >> 32), cnt = (int32_t)ZY[i], last = first + cnt - 1;
+		const int32_t span0 = (int32_t)(BY[first] >> 32 & 0xff);
+		const uint32_t rev = (uint32_t)(BX[first] >> 63), rid = (uint32_t)(BX[first] << 1 >> 33);
+		const int32_t rs = (int32_t)BX[first] + 1 > span0 ? (int32_t)BX[first] + 1 - span0 : 0;
+		const int32_t re = (int32_t)BX[last] + 1;
+		int32_t qs, qe;
+		if (!rev) qs = (int32_t)BY[first] + 1 - span0, qe = (int32_t)BY[last] + 1;
+		else qs = (int32_t)qlen - ((int32_t)BY[last] + 1), qe = (int32_t)qlen - ((int32_t)BY[first] + 1 - span0);
+		const uint32_t tid = ix.id[rid];
+		if (tid == qid) continue;
+		if (qe - qs < P.minlen) continue;
+		if (P.dvt && !dovetail_class((int)rev, (uint32_t)qs, (uint32_t)qe, qlen, (uint32_t)rs, (uint32_t)re, ix.len[rid], P.maxhan1,
+		                             P.maxhan2)) continue;
+		int32_t mlen = span0;
+		for (int32_t m = first + 1; m <= last; ++m) {
+			const int sp = (int)(BY[m] >> 32 & 0xff);
+			const int tl = (int32_t)BX[m] - (int32_t)BX[m - 1];
+			const int ql = (int32_t)BY[m] - (int32_t)BY[m - 1];
+			mlen += tl > sp && ql > sp ? sp : tl < ql ? tl : ql;
+		}
+		OvlRec r;
+		r.rev = rev, r.qname = qid, r.qs = (uint32_t)qs, r.qe = (uint32_t)qe, r.tname = tid, r.ts = (uint32_t)rs, r.te = (uint32_t)re,
+		r.match = (uint32_t)mlen;
+		out[n_out++] = r;
+	}
+	n_rec[rl] = n_out, n_chain[rl] = (uint32_t)n_u;
+}
+
+void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
+                 const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
+                 uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, OvlRec *recs, uint32_t *n_rec,
+                 uint32_t *n_chain, hipStream_t s)
+{
+	if (n_reads) hipLaunchKernelGGL(hits_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
+	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, recs, n_rec, n_chain);
+}
+
+// gather per-read record runs into one dense array
+__global__ void compact_recs_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *__restrict__ recs,
+                                    const uint32_t *__restrict__ n_rec, const uint64_t *__restrict__ rec_off, OvlRec *__restrict__ dense)
+{
+	const uint32_t rl = blockIdx.x;
+	if (rl >= n_reads) return;
+	const OvlRec *src = recs + r_aoff[rl] / (uint64_t)(min_cnt > 1 ? min_cnt : 1) + rl;
+	OvlRec *dst = dense + rec_off[rl];
+	for (uint32_t i = threadIdx.x; i < n_rec[rl]; i += blockDim.x) dst[i] = src[i];
+}
+
+void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,
+                         const uint64_t *rec_off, OvlRec *dense, hipStream_t s)
+{
+	if (n_reads) hipLaunchKernelGGL(compact_recs_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, min_cnt, recs, n_rec, rec_off, dense);
+}
+
+} // namespace ndovl

@@ -1,0 +1,190 @@
+"""ctypes binding of the MI355X overlap engine (include/ndgpu_overlap.h, libndgpu_overlap.so).
+
+The host-side mirror of what `minimap2-nd --step 1` does around its C core: build the index of the
+target reads, map the query reads, encode the overlaps (see nextdenovo_amd/minimap2_nd.py for the CLI).
+There is no CPU path: every call needs a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libndgpu_overlap.so")
+
+
+class Opt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "no_diag", "no_dual", "min_cnt", "min_chain_score", "bw", "max_gap",
+                                         "max_chain_skip", "max_chain_iter", "minlen", "seed", "dvt", "maxhan1", "maxhan2")] \
+        + [("mid_occ_frac", C.c_float), ("mid_occ", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("sketch_ms", "index_sort_ms", "seed_ms", "sort_ms", "exact_sort_ms", "chain_ms",
+                                          "hits_ms")] \
+        + [(n, C.c_uint64) for n in ("bases_sketched", "minimizers", "anchors", "tie_reads", "chain_cells", "chains",
+                                     "overlaps", "map_calls", "batches")]
+
+
+REC = np.dtype([(n, np.uint32) for n in ("rev", "qname", "qs", "qe", "tname", "ts", "te", "match")])
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build
+        build.build()
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.ndgpu_ovl_opt_preset.argtypes = [C.c_char_p, C.POINTER(Opt)]
+    lib.ndgpu_ovl_index_create.argtypes = [C.POINTER(Opt), C.c_uint32, P, C.c_uint64, P, P, P]
+    lib.ndgpu_ovl_index_create.restype = P
+    lib.ndgpu_ovl_index_destroy.argtypes = [P]
+    lib.ndgpu_ovl_index_mid_occ.argtypes = [P, C.c_float]
+    lib.ndgpu_ovl_index_mid_occ.restype = C.c_int32
+    lib.ndgpu_ovl_index_stat.argtypes = [P, P]
+    lib.ndgpu_ovl_map.argtypes = [P, C.POINTER(Opt), C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, C.POINTER(P)]
+    lib.ndgpu_ovl_map.restype = C.c_int64
+    lib.ndgpu_ovl_encode.argtypes = [P, C.c_int64, P, P]
+    lib.ndgpu_ovl_encode.restype = C.c_int64
+    lib.ndgpu_ovl_free.argtypes = [P]
+    lib.ndgpu_ovl_sketch.argtypes = [C.POINTER(Opt), C.c_uint32, P, C.c_uint64, P, P, C.c_int, C.POINTER(P), C.POINTER(P), P]
+    lib.ndgpu_ovl_sketch.restype = C.c_int64
+    lib.ndgpu_ovl_index_dump.argtypes = [P, P, P, P]
+    lib.ndgpu_ovl_debug_anchors.argtypes = [P, C.c_uint32, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
+    lib.ndgpu_ovl_debug_anchors.restype = C.c_int64
+    lib.ndgpu_ovl_get_stats.argtypes = [P, C.POINTER(Stats)]
+    lib.ndgpu_ovl_reset_stats.argtypes = [P]
+    _lib = lib
+    return lib
+
+
+def preset(name: str, **kw) -> Opt:
+    o = Opt()
+    if load().ndgpu_ovl_opt_preset(name.encode() if name else None, C.byref(o)) != 0:
+        raise ValueError("unsupported preset %r" % name)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _take(lib, p, n, dtype):
+    a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(n) * np.dtype(dtype).itemsize,)).copy() if n else \
+        np.zeros(0, dtype=np.uint8)
+    lib.ndgpu_ovl_free(p)
+    return a.view(dtype)
+
+
+class ReadSet:
+    """Reads as stored in a .2bit file (see ovl.read_2bit)."""
+
+    def __init__(self, ids, lens, words, word_off):
+        self.ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.words = np.ascontiguousarray(words, dtype=np.uint32)
+        self.word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+
+    @classmethod
+    def from_2bit(cls, path):
+        from . import ovl
+        return cls(*ovl.read_2bit(path))
+
+    def __len__(self):
+        return int(self.ids.size)
+
+    def subset(self, lo, hi):
+        return ReadSet(self.ids[lo:hi], self.lens[lo:hi], self.words, self.word_off[lo:hi])
+
+
+def sketch(opt: Opt, rs: ReadSet, rid_is_index=False):
+    """K1 only -> (x, y, off)."""
+    lib = load()
+    x, y = C.c_void_p(), C.c_void_p()
+    off = np.zeros(len(rs) + 1, dtype=np.uint64)
+    n = lib.ndgpu_ovl_sketch(C.byref(opt), len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off), _ptr(rs.lens),
+                             1 if rid_is_index else 0, C.byref(x), C.byref(y), _ptr(off))
+    if n < 0:
+        raise RuntimeError("ndgpu_ovl_sketch failed (%d): no usable HIP device?" % n)
+    return _take(lib, x, n, np.uint64), _take(lib, y, n, np.uint64), off
+
+
+class Index:
+    def __init__(self, opt: Opt, rs: ReadSet):
+        self.lib = load()
+        self.opt = opt
+        self.h = self.lib.ndgpu_ovl_index_create(C.byref(opt), len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off),
+                                                 _ptr(rs.lens), _ptr(rs.ids))
+        if not self.h:
+            raise RuntimeError("ndgpu_ovl_index_create failed: the overlap engine needs a HIP device (no CPU path)")
+
+    def close(self):
+        if self.h:
+            self.lib.ndgpu_ovl_index_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def stat(self):
+        n = np.zeros(3, dtype=np.uint64)
+        self.lib.ndgpu_ovl_index_stat(self.h, _ptr(n))
+        return dict(minimizers=int(n[0]), keys=int(n[1]), reads=int(n[2]))
+
+    def mid_occ(self, frac=None) -> int:
+        f = self.opt.mid_occ_frac if frac is None else frac
+        return int(self.lib.ndgpu_ovl_index_mid_occ(self.h, np.float32(f)))
+
+    def dump(self):
+        s = self.stat()
+        key = np.zeros(s["keys"], dtype=np.uint64)
+        start = np.zeros(s["keys"] + 1, dtype=np.uint64)
+        pos = np.zeros(s["minimizers"], dtype=np.uint64)
+        self.lib.ndgpu_ovl_index_dump(self.h, _ptr(key), _ptr(start), _ptr(pos))
+        return key, start, pos
+
+    def map(self, rs: ReadSet, mid_occ: int, opt: Opt | None = None) -> np.ndarray:
+        opt = opt or self.opt
+        recs = C.c_void_p()
+        n = self.lib.ndgpu_ovl_map(self.h, C.byref(opt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off),
+                                   _ptr(rs.lens), _ptr(rs.ids), C.byref(recs))
+        if n < 0:
+            raise RuntimeError("ndgpu_ovl_map failed (%d)" % n)
+        return _take(self.lib, recs, n, REC)
+
+    def debug_anchors(self, q: int):
+        ax, ay, f, p = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = self.lib.ndgpu_ovl_debug_anchors(self.h, q, C.byref(ax), C.byref(ay), C.byref(f), C.byref(p))
+        if n < 0:
+            raise IndexError(q)
+        return (_take(self.lib, ax, n, np.uint64), _take(self.lib, ay, n, np.uint64), _take(self.lib, f, n, np.int32),
+                _take(self.lib, p, n, np.int32))
+
+    def stats(self) -> dict:
+        st = Stats()
+        self.lib.ndgpu_ovl_get_stats(self.h, C.byref(st))
+        return {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def reset_stats(self):
+        self.lib.ndgpu_ovl_reset_stats(self.h)
+
+
+def encode(recs: np.ndarray, prev: np.ndarray) -> bytes:
+    """encode_ovl over a record array; prev = uint32[2] running state, updated in place."""
+    lib = load()
+    recs = np.ascontiguousarray(recs)
+    out = np.zeros(40 * max(1, recs.size), dtype=np.uint8)
+    n = lib.ndgpu_ovl_encode(_ptr(recs), recs.size, _ptr(prev), _ptr(out))
+    return out[:n].tobytes()

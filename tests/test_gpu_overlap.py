@@ -1,0 +1,170 @@
+"""MI355X overlap engine (libndgpu_overlap.so, through its C ABI) against the overlap oracle and the golden
+`.ovl` files of the compiled reference.  Bit-exact at every stage: minimizers, index arrays, occurrence
+threshold, sorted anchors (including the reference sort's order of equal keys), chain-DP arrays, records, bytes."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import mm_util as M  # noqa: E402
+from make_overlap_golden import CASES  # noqa: E402
+from test_overlap_oracle import case_kwargs  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(HERE, "golden", "overlap")
+
+
+@pytest.fixture(scope="module")
+def olib(oracle_lib):
+    return M.bind(oracle_lib)
+
+
+@pytest.fixture(scope="module")
+def sets():
+    from nextdenovo_amd import overlap
+    out = {}
+    for k in ("seed", "part"):
+        p = os.path.join(GOLD, k + ".2bit")
+        out[k] = (overlap.ReadSet.from_2bit(p), M.load_set(p))
+    return out
+
+
+def dev_opt(preset, dual, extra=()):
+    from nextdenovo_amd import overlap
+    o = overlap.preset(preset)
+    if dual:
+        o.no_dual = 0
+    kw = case_kwargs(extra)
+    if "mid_occ_frac" in kw:
+        o.mid_occ_frac = kw["mid_occ_frac"]
+    if "mid_occ" in kw:
+        o.mid_occ = kw["mid_occ"]
+    return o
+
+
+def oracle_sketch_all(olib, oset, w, k, hpc, rid_is_index):
+    ids, lens, codes, off = oset
+    xs, ys, offs = [], [], [0]
+    for i in range(ids.size):
+        mv = M.sketch(olib, codes[int(off[i]): int(off[i]) + int(lens[i])], w, k, i if rid_is_index else 0, hpc)
+        xs.append(mv["x"])
+        ys.append(mv["y"])
+        offs.append(offs[-1] + mv.size)
+    return np.concatenate(xs), np.concatenate(ys), np.asarray(offs, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("preset", ["ava-ont", "ava-pb"])
+@pytest.mark.parametrize("rid_is_index", [False, True])
+def test_sketch_matches_oracle(olib, sets, preset, rid_is_index):
+    from nextdenovo_amd import overlap
+    o = overlap.preset(preset)
+    for k in ("seed", "part"):
+        rs, oset = sets[k]
+        x, y, off = overlap.sketch(o, rs, rid_is_index)
+        ex, ey, eoff = oracle_sketch_all(olib, oset, o.w, o.k, o.hpc, rid_is_index)
+        assert np.array_equal(off, eoff)
+        assert np.array_equal(x, ex) and np.array_equal(y, ey)
+
+
+@pytest.mark.parametrize("preset", ["ava-ont", "ava-pb"])
+def test_index_matches_oracle(olib, sets, preset):
+    from nextdenovo_amd import overlap
+    o = overlap.preset(preset)
+    rs, (ids, lens, codes, off) = sets["seed"]
+    ix = olib.nd_mm_index_build(ids.size, M.ptr(codes), M.ptr(off), M.ptr(lens), M.ptr(ids), o.w, o.k, o.hpc)
+    nk, nm = olib.nd_mm_index_keys(ix), olib.nd_mm_index_n(ix)
+    ekey, estart, epos = np.zeros(nk, np.uint64), np.zeros(nk + 1, np.int64), np.zeros(nm, np.uint64)
+    olib.nd_mm_index_dump(ix, M.ptr(ekey), M.ptr(estart), M.ptr(epos))
+    with overlap.Index(o, rs) as dix:
+        key, start, pos = dix.dump()
+        assert np.array_equal(key, ekey) and np.array_equal(start.astype(np.int64), estart) and np.array_equal(pos, epos)
+        for f in (2e-4, 2e-3, 0.05):
+            assert dix.mid_occ(f) == olib.nd_mm_index_mid_occ(ix, np.float32(f))
+    olib.nd_mm_index_free(ix)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_ovl_bytes_match_reference_golden(sets, case):
+    from nextdenovo_amd import overlap
+    tag, preset, t, q, dual, extra = case
+    with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
+        want = f.read()
+    o = dev_opt(preset, dual, extra)
+    with overlap.Index(o, sets[t][0]) as ix:
+        mid = o.mid_occ if o.mid_occ > 0 else ix.mid_occ()
+        recs = ix.map(sets[q][0], mid)
+        got = overlap.encode(recs, np.zeros(2, dtype=np.uint32))
+        st = ix.stats()
+    assert got == want
+    assert st["anchors"] > 0 and st["chains"] > 0
+
+
+@pytest.mark.parametrize("preset,dual,tq", [("ava-ont", True, ("seed", "part")), ("ava-ont", False, ("seed", "seed")),
+                                            ("ava-pb", False, ("seed", "seed"))])
+def test_anchors_and_chain_arrays_match_oracle(olib, sets, preset, dual, tq, monkeypatch):
+    """Sorted anchors (tie order of the reference sort included) and the DP's f[] / p[] per query read."""
+    from nextdenovo_amd import overlap
+    monkeypatch.setenv("NDGPU_OVL_BATCH_ANCHORS", "100000000")
+    o = dev_opt(preset, dual)
+    oo = M.preset(preset, dual)
+    trs, (tid, tl, tc, to) = sets[tq[0]]
+    qrs, (qid, ql, qc, qo) = sets[tq[1]]
+    ix = olib.nd_mm_index_build(tid.size, M.ptr(tc), M.ptr(to), M.ptr(tl), M.ptr(tid), oo.w, oo.k, oo.hpc)
+    mid = olib.nd_mm_index_mid_occ(ix, np.float32(2e-4))
+    n_tie = 0
+    with overlap.Index(o, trs) as dix:
+        assert dix.mid_occ() == mid
+        dix.map(qrs, mid)
+        for i in range(qid.size):
+            ax, ay, f, p = dix.debug_anchors(i)
+            mv = M.sketch(olib, qc[int(qo[i]): int(qo[i]) + int(ql[i])], oo.w, oo.k, 0, oo.hpc)
+            a = np.zeros(max(1, mv.size * mid), dtype=M.MM128)
+            n = olib.nd_mm_seeds(ix, C.byref(oo), str(int(qid[i])).encode(), int(ql[i]), mid, M.ptr(mv), mv.size, M.ptr(a), 1)
+            a = a[:n].copy()
+            assert ax.size == n
+            assert np.array_equal(ax, a["x"]) and np.array_equal(ay, a["y"]), "anchors of query %d" % i
+            n_tie += int((a["x"][1:] == a["x"][:-1]).sum()) if n > 1 else 0
+            if n:
+                ef, ep = np.zeros(n, np.int32), np.zeros(n, np.int32)
+                u = np.zeros(n, np.uint64)
+                nb = C.c_int64(0)
+                olib.nd_mm_chain(C.byref(oo), n, M.ptr(a), M.ptr(u), C.byref(nb), M.ptr(ef), M.ptr(ep))
+                assert np.array_equal(f, ef) and np.array_equal(p, ep), "chain DP of query %d" % i
+        st = dix.stats()
+    olib.nd_mm_index_free(ix)
+    if preset == "ava-ont":
+        assert n_tie > 0 and st["tie_reads"] > 0  # the exact-replay path really ran
+
+
+@pytest.mark.parametrize("profile,preset", [("ont", "ava-ont"), ("clr", "ava-pb")])
+def test_live_set_many_batches(olib, profile, preset, monkeypatch, tmp_path):
+    """A fresh seeded read set, mapped in several small batches, against the oracle's whole-run bytes."""
+    from nextdenovo_amd import overlap, synth
+    monkeypatch.setenv("NDGPU_OVL_BATCH_ANCHORS", "20000")
+    g = synth.make_genome(120000, seed=77, n_repeats=5, repeat_len=2000)
+    rs = synth.simulate_reads(g, 20, profile, seed=78)
+    n = len(rs.seqs)
+    ids = np.arange(n, dtype=np.uint32)
+    lens = np.asarray([s.size for s in rs.seqs], dtype=np.uint32)
+    words = [synth.pack_2bit_msb(s) for s in rs.seqs]
+    woff = np.zeros(n, dtype=np.uint64)
+    woff[1:] = np.cumsum([w.size for w in words])[:-1]
+    dset = overlap.ReadSet(ids, lens, np.concatenate(words), woff)
+    codes = np.concatenate(rs.seqs).astype(np.uint8)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+    oset = (ids, lens, codes, off)
+    for dual in (False, True):
+        want, mid = M.step1(olib, M.preset(preset, dual), oset, oset)
+        o = dev_opt(preset, dual)
+        with overlap.Index(o, dset) as ix:
+            assert ix.mid_occ() == mid
+            recs = ix.map(dset, mid)
+            assert ix.stats()["batches"] >= 3
+        got = overlap.encode(recs, np.zeros(2, dtype=np.uint32))
+        assert len(want) > 5000 and got == want
