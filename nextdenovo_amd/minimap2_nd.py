@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""`minimap2-nd --step 1` on the MI355X: all-vs-all raw-read overlap, `.ovl` out.
+
+Takes the command line nextDenovo writes for the raw-align subtasks (reference nextDenovo:436-466):
+
+    python -m nextdenovo_amd.minimap2_nd --step 1 [--dual=yes] -t 8 -x ava-ont [-f N] [-I 4G] target.2bit query.2bit -o out.ovl
+
+and writes the byte-identical overlap file.  Mirrors minimap2/main.c for the options of this path (preset
+first, then the remaining options in order: main.c:140-366); the index is split into parts exactly as
+mm_idx_gen does with -I (index.c:284-287,351-360), the occurrence threshold comes from the first part
+(options.c:70-71), every query file is mapped against every part in turn (main.c:474-507).
+
+Options of other paths (-a, -c, --step 2/3, ava-hifi, FASTA input) are rejected, not approximated.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from . import overlap
+
+IDX_MINI_BATCH = 50000000      # mm_idxopt_init (options.c:9)
+IDX_BATCH = 4000000000         # options.c:10
+
+
+def parse_num(s: str) -> int:
+    """mm_parse_num (minimap2/misc / main.c): float with optional K/M/G suffix."""
+    mult = 1.0
+    if s and s[-1] in "gG":
+        mult, s = 1e9, s[:-1]
+    elif s and s[-1] in "mM":
+        mult, s = 1e6, s[:-1]
+    elif s and s[-1] in "kK":
+        mult, s = 1e3, s[:-1]
+    return int(float(s) * mult + .499)
+
+
+def yes_no(v: str) -> bool:
+    return v.lower() in ("yes", "y")
+
+
+class Args:
+    def __init__(self):
+        self.preset = None
+        self.step = 0
+        self.out = None
+        self.batch_size = IDX_BATCH
+        self.files = []
+        self.ops = []  # (name, value) in command-line order, applied after the preset
+
+
+LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode"}
+SHORT_WITH_ARG = set("xtfIKkwornmgsNpM")
+
+
+def parse_argv(argv) -> Args:
+    a = Args()
+    i = 0
+    while i < len(argv):
+        tok = argv[i]
+        if tok.startswith("--"):
+            name, _, val = tok.partition("=")
+            if name in LONG_WITH_ARG and not _:
+                i += 1
+                val = argv[i]
+            a.ops.append((name, val))
+        elif tok.startswith("-") and len(tok) > 1:
+            c = tok[1]
+            if c in SHORT_WITH_ARG:
+                val = tok[2:]
+                if not val:
+                    i += 1
+                    val = argv[i]
+                a.ops.append(("-" + c, val))
+            else:
+                for ch in tok[1:]:
+                    a.ops.append(("-" + ch, None))
+        else:
+            a.files.append(tok)
+        i += 1
+    return a
+
+
+def build_opt(a: Args) -> overlap.Opt:
+    for name, val in a.ops:
+        if name == "-x":
+            a.preset = val
+    opt = overlap.preset(a.preset)  # raises for unsupported presets
+    for name, val in a.ops:
+        if name == "-x" or name == "-t":
+            continue
+        elif name == "--step":
+            a.step = int(val)
+            if a.step != 1:
+                raise SystemExit("[ERROR] only --step 1 is built in this engine")
+            opt.minlen = 500
+        elif name == "--dual":
+            opt.no_dual = 0 if yes_no(val) else 1
+        elif name == "-X":
+            opt.no_diag, opt.no_dual = 1, 1
+        elif name == "-f":
+            head, _, tail = val.partition(",")
+            x = float(head)
+            if x < 1.0:
+                opt.mid_occ_frac, opt.mid_occ = x, 0
+            else:
+                opt.mid_occ = int(x + .499)
+            if tail:
+                raise SystemExit("[ERROR] -f FLOAT,INT (max_occ re-chaining) is not supported")
+        elif name == "-I":
+            a.batch_size = parse_num(val)
+        elif name == "-K":
+            pass  # query mini-batch size: affects only when the reference flushes its buffer
+        elif name == "-k":
+            opt.k = int(val)
+        elif name == "-w":
+            opt.w = int(val)
+        elif name == "-H":
+            opt.hpc = 1
+        elif name == "-r":
+            opt.bw = parse_num(val)
+        elif name == "-n":
+            opt.min_cnt = int(val)
+        elif name == "-m":
+            opt.min_chain_score = int(val)
+        elif name == "-g":
+            opt.max_gap = parse_num(val)
+        elif name == "--minlen":
+            opt.minlen = parse_num(val)
+        elif name == "--maxhan1":
+            opt.maxhan1 = parse_num(val)
+        elif name == "--maxhan2":
+            opt.maxhan2 = parse_num(val)
+        elif name == "--dvt":
+            opt.dvt = 1
+        elif name == "--seed":
+            opt.seed = int(val)
+        elif name == "-o":
+            a.out = val
+        else:
+            raise SystemExit("[ERROR] option %s is outside the --step 1 overlap path of this engine" % name)
+    if a.step != 1:
+        raise SystemExit("[ERROR] --step 1 is required")
+    return opt
+
+
+def index_parts(lens: np.ndarray, batch_size: int, mini_batch=IDX_MINI_BATCH):
+    """Read ranges of the index parts, as mm_idx_gen forms them: mini-batches of >= min(mini_batch, batch_size)
+    bases are appended while the running total is still <= batch_size."""
+    mbs = min(mini_batch, batch_size)
+    n, i, parts = int(lens.size), 0, []
+    while i < n:
+        start, total = i, 0
+        while i < n and total <= batch_size:
+            size = 0
+            while i < n:
+                size += int(lens[i])
+                i += 1
+                if size >= mbs:
+                    break
+            total += size
+        parts.append((start, i))
+    return parts
+
+
+def run(argv) -> int:
+    a = parse_argv(argv)
+    opt = build_opt(a)
+    if len(a.files) < 2:
+        raise SystemExit("[ERROR] missing input: target.2bit query.2bit")
+    target = overlap.ReadSet.from_2bit(a.files[0])
+    queries = [overlap.ReadSet.from_2bit(f) if f != a.files[0] else target for f in a.files[1:]]
+    prev = np.zeros(2, dtype=np.uint32)  # `prev_t pid` lives for the whole run (main.c:29)
+    mid_occ = opt.mid_occ
+    out = open(a.out, "wb") if a.out else sys.stdout.buffer
+    try:
+        for lo, hi in index_parts(target.lens, a.batch_size):
+            with overlap.Index(opt, target.subset(lo, hi)) as ix:
+                if mid_occ <= 0:
+                    mid_occ = ix.mid_occ()
+                for q in queries:
+                    recs = ix.map(q, mid_occ)
+                    out.write(overlap.encode(recs, prev))
+    finally:
+        if a.out:
+            out.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(run(sys.argv[1:]))

@@ -116,3 +116,14 @@ def unpack_codes(words: np.ndarray, word_off: np.ndarray, lens: np.ndarray):
         ws = words[int(word_off[i]): int(word_off[i]) + cnt]
         out[int(off[i]): int(off[i]) + n] = ((ws[:, None] >> sh[None, :]) & 3).astype(np.uint8).reshape(-1)[:n]
     return out, off
+
+
+def write_2bit(path: str, ids, lens, words, word_off):
+    """Writer of the `.2bit` container (lib/bseq.c:93-139): magic {0,254}, then u32 id, u32 len, words per read."""
+    with open(path, "wb") as f:
+        f.write(bytes([0, 254]))
+        for i in range(len(ids)):
+            n = int(lens[i])
+            cnt = (n + 15) >> 4
+            f.write(np.asarray([ids[i], n], dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(words[int(word_off[i]): int(word_off[i]) + cnt], dtype=np.uint32).tobytes())

@@ -601,16 +601,17 @@ int64_t nd_mm_encode(const nd_mm_index *ix, const nd_mm_opt *opt, uint32_t qid, 
 	return n;
 }
 
-/* Whole `minimap2-nd --step 1 target query` run for a single-part index (sum of target lengths below -I).
+/* Whole `minimap2-nd --step 1 target query` run for ONE index part (prev_io carries the delta state of
+ * encode_ovl from part to part; the caller fixes mid_occ after the first part, options.c:70-71).
  * Returns the number of .ovl bytes written (or -needed if out_cap is too small). */
 int64_t nd_mm_step1(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
                     int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
                     int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
-                    uint8_t *out, int64_t out_cap, int32_t *mid_occ_out)
+                    uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io)
 {
 	nd_mm_index *ix = nd_mm_index_build(n_t, tcodes, toff, tlen, tids, opt->w, opt->k, opt->hpc);
 	int mid_occ = mid_occ_fixed > 0 ? mid_occ_fixed : nd_mm_index_mid_occ(ix, mid_occ_frac);
-	uint32_t prev[2] = { 0, 0 };
+	uint32_t prev[2] = { prev_io ? prev_io[0] : 0, prev_io ? prev_io[1] : 0 };
 	int64_t n = 0;
 	int reg_cap = 1 << 16, i;
 	nd_mm_reg *regs = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * reg_cap);
@@ -627,5 +628,6 @@ int64_t nd_mm_step1(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
 	}
 	free(regs);
 	nd_mm_index_free(ix);
+	if (prev_io && n >= 0) prev_io[0] = prev[0], prev_io[1] = prev[1];
 	return n;
 }

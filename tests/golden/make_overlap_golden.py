@@ -24,6 +24,8 @@ CASES = [  # (file tag, preset, target, query, dual, extra argv)
     ("ont.sxs.f30", "ava-ont", "seed", "seed", False, ("-f", "30")),
     ("pb.sxp.dual", "ava-pb", "seed", "part", True, ()),
     ("pb.sxs", "ava-pb", "seed", "seed", False, ()),
+    ("ont.sxs.I200k", "ava-ont", "seed", "seed", False, ("-I", "200k")),
+    ("ont.sxp.dual.I150k", "ava-ont", "seed", "part", True, ("-I", "150k")),
 ]
 
 

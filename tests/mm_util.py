@@ -69,7 +69,7 @@ def bind(lib):
     lib.nd_mm_map_read.argtypes = [P, C.POINTER(MMOpt), C.c_int, C.c_uint32, P, C.c_int, P, C.c_int]
     lib.nd_mm_map_read.restype = C.c_int
     lib.nd_mm_step1.argtypes = [C.POINTER(MMOpt), C.c_float, C.c_int, C.c_int32, P, P, P, P, C.c_int32, P, P, P, P, P,
-                                C.c_int64, P]
+                                C.c_int64, P, P]
     lib.nd_mm_step1.restype = C.c_int64
     return lib
 
@@ -86,19 +86,32 @@ def sketch(lib, codes: np.ndarray, w, k, rid=0, hpc=0) -> np.ndarray:
     return out[:n].copy()
 
 
-def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0):
-    """tset/qset = (ids, lens, codes, off).  Returns (.ovl bytes, mid_occ)."""
+def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0, batch_size=None):
+    """tset/qset = (ids, lens, codes, off).  Returns (.ovl bytes, mid_occ).  batch_size = the -I value: the
+    target set is indexed in parts (nextdenovo_amd.minimap2_nd.index_parts restates mm_idx_gen's rule)."""
     tid, tl, tc, to = tset
     qid, ql, qc, qo = qset
-    cap = 1 << 20
-    while True:
-        out = np.zeros(cap, dtype=np.uint8)
-        mo = C.c_int32(0)
-        n = lib.nd_mm_step1(C.byref(opt), np.float32(mid_occ_frac), mid_occ, tid.size, ptr(tc), ptr(to), ptr(tl), ptr(tid),
-                            qid.size, ptr(qc), ptr(qo), ptr(ql), ptr(qid), ptr(out), cap, C.byref(mo))
-        if n >= 0:
-            return out[:n].tobytes(), mo.value
-        cap = max(cap * 4, -n * 2)
+    parts = [(0, tid.size)]
+    if batch_size is not None:
+        from nextdenovo_amd.minimap2_nd import index_parts
+        parts = index_parts(tl, batch_size)
+    prev = np.zeros(2, dtype=np.uint32)
+    blob = b""
+    for lo, hi in parts:
+        cap = 1 << 20
+        while True:
+            out = np.zeros(cap, dtype=np.uint8)
+            mo = C.c_int32(0)
+            pv = prev.copy()
+            n = lib.nd_mm_step1(C.byref(opt), np.float32(mid_occ_frac), mid_occ, hi - lo, ptr(tc), ptr(to[lo:hi]), ptr(tl[lo:hi]),
+                                ptr(tid[lo:hi]), qid.size, ptr(qc), ptr(qo), ptr(ql), ptr(qid), ptr(out), cap, C.byref(mo), ptr(pv))
+            if n >= 0:
+                break
+            cap = max(cap * 4, -n * 2)
+        prev = pv
+        mid_occ = mo.value  # the threshold of the first part is kept (options.c:70-71)
+        blob += out[:n].tobytes()
+    return blob, mid_occ
 
 
 def load_set(path):

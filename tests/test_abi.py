@@ -40,3 +40,68 @@ def test_host_helpers(native_lib):
 
 def test_device_count_does_not_need_gpu(native_lib):
     assert native_lib.ndgpu_device_count() >= 0
+
+
+def test_overlap_exports_and_host_side():
+    """libndgpu_overlap.so: every symbol of include/ndgpu_overlap.h is exported; the host-only entry points
+    (preset table, .ovl encoder) work without a GPU, the device entry points refuse loudly."""
+    import ctypes as C
+    import numpy as np
+    from nextdenovo_amd import overlap
+    lib = overlap.load()
+    header = os.path.join(os.path.dirname(util.HERE), "include", "ndgpu_overlap.h")
+    names = _declared_functions(header)
+    assert {"ndgpu_ovl_opt_preset", "ndgpu_ovl_index_create", "ndgpu_ovl_map", "ndgpu_ovl_encode", "ndgpu_ovl_sketch"} <= names
+    for n in sorted(names):
+        assert hasattr(lib, n), "missing export: " + n
+    o = overlap.preset("ava-ont")
+    assert (o.k, o.w, o.hpc, o.bw, o.max_gap, o.min_chain_score, o.minlen, o.no_diag, o.no_dual) == (15, 5, 0, 2000, 10000, 100, 500, 1, 1)
+    o = overlap.preset("ava-pb")
+    assert (o.k, o.w, o.hpc, o.bw) == (19, 5, 1, 500)
+    # encoder: two records, delta / flag coding as lib/ovl.c:109-150
+    recs = np.zeros(2, dtype=overlap.REC)
+    recs[0] = (1, 300, 10, 2000, 5, 0, 1900, 777)
+    recs[1] = (0, 200, 128, 700, 90, 16384, 17000, 3)
+    prev = np.zeros(2, dtype=np.uint32)
+    b = overlap.encode(recs, prev)
+    from nextdenovo_amd import ovl
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".ovl") as f:
+        f.write(b)
+        f.flush()
+        back = ovl.decode_ovl(f.name)
+    assert back.tolist() == [[300, 1, 10, 2000, 5, 0, 1900, 777], [200, 0, 128, 700, 90, 16384, 17000, 3]]
+    assert prev.tolist() == [200, 90]
+    if lib.ndgpu_ovl_index_create and not _has_gpu():
+        import pytest
+        rs = overlap.ReadSet(np.zeros(1, np.uint32), np.asarray([40], np.uint32), np.zeros(3, np.uint32), np.zeros(1, np.uint64))
+        with pytest.raises(RuntimeError):
+            overlap.Index(o, rs)
+
+
+def _has_gpu():
+    from nextdenovo_amd import api
+    try:
+        return api.device_count() > 0
+    except Exception:
+        return False
+
+
+def test_minimap2_nd_cli_host_logic():
+    from nextdenovo_amd import minimap2_nd as m
+    import numpy as np
+    a = m.parse_argv("--step 1 --dual=yes -t 8 -x ava-ont -f 1000 -I 6G s.2bit p.2bit -o x.ovl".split())
+    o = m.build_opt(a)
+    assert (a.files, a.out, a.batch_size) == (["s.2bit", "p.2bit"], "x.ovl", 6000000000)
+    assert (o.no_dual, o.mid_occ, o.minlen, o.k, o.w) == (0, 1000, 500, 15, 5)
+    a = m.parse_argv("-x ava-pb --step 1 -f 0.0005 --minlen 1k a b".split())
+    o = m.build_opt(a)
+    assert (o.no_dual, o.mid_occ, o.minlen, o.hpc) == (1, 0, 1000, 1) and abs(o.mid_occ_frac - 0.0005) < 1e-9
+    assert m.parse_num("4G") == 4000000000 and m.parse_num("150k") == 150000 and m.parse_num("2.5m") == 2500000
+    lens = np.asarray([60, 60, 60, 60, 60, 10], dtype=np.uint32)
+    assert m.index_parts(lens, 100, mini_batch=50) == [(0, 2), (2, 4), (4, 6)]   # a part closes once its total exceeds -I
+    assert m.index_parts(lens, 10**9) == [(0, 6)]
+    import pytest
+    for bad in ("--step 2 -x ava-ont a b", "--step 1 -x ava-hifi a b", "--step 1 -x ava-ont -c a b"):
+        with pytest.raises((SystemExit, ValueError)):
+            m.build_opt(m.parse_argv(bad.split()))

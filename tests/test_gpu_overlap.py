@@ -92,6 +92,8 @@ def test_index_matches_oracle(olib, sets, preset):
 def test_ovl_bytes_match_reference_golden(sets, case):
     from nextdenovo_amd import overlap
     tag, preset, t, q, dual, extra = case
+    if "-I" in extra:
+        pytest.skip("multi-part index runs are covered through the stage CLI test")
     with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
         want = f.read()
     o = dev_opt(preset, dual, extra)
@@ -168,3 +170,18 @@ def test_live_set_many_batches(olib, profile, preset, monkeypatch, tmp_path):
             assert ix.stats()["batches"] >= 3
         got = overlap.encode(recs, np.zeros(2, dtype=np.uint32))
         assert len(want) > 5000 and got == want
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_stage_cli_writes_reference_bytes(case, tmp_path):
+    """`python -m nextdenovo_amd.minimap2_nd` with the reference's own command line."""
+    from nextdenovo_amd import minimap2_nd
+    tag, preset, t, q, dual, extra = case
+    out = str(tmp_path / "o.ovl")
+    argv = ["--step", "1"] + (["--dual=yes"] if dual else []) + ["-t", "8", "-x", preset, *extra,
+                                                                  os.path.join(GOLD, t + ".2bit"), os.path.join(GOLD, q + ".2bit"), "-o", out]
+    assert minimap2_nd.run(argv) == 0
+    with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
+        want = f.read()
+    with open(out, "rb") as f:
+        assert f.read() == want

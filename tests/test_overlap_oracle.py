@@ -36,6 +36,9 @@ def case_kwargs(extra):
             kw["mid_occ_frac"] = x
         else:
             kw["mid_occ"] = int(x + .499)
+    if "-I" in extra:
+        from nextdenovo_amd.minimap2_nd import parse_num
+        kw["batch_size"] = parse_num(extra[extra.index("-I") + 1])
     return kw
 
 
