@@ -46,11 +46,21 @@ struct KeyLayout {
 };
 
 struct OvlRec { uint32_t rev, qname, qs, qe, tname, ts, te, match; };
+struct SketchTile { uint32_t read, start; }; // one block of K1: symbols [start, start + tile) of a read
 
 size_t sketch_smem(int w);
 void launch_sketch(bool fill, const uint32_t *words, const uint64_t *woff, const uint32_t *len, const uint32_t *order,
                    uint32_t n_reads, const OvlParams &P, int rid_is_index, const uint64_t *out_off, uint64_t *out_x,
                    uint64_t *out_y, uint32_t *out_read, uint32_t *out_cnt, hipStream_t s);
+void launch_run_compact(bool fill, const uint32_t *words, const uint64_t *woff, const uint32_t *len, const SketchTile *tiles,
+                        uint32_t n_tiles, const uint64_t *tile_prefix, const uint32_t *first_tile, const uint64_t *roff, uint32_t *tile_cnt,
+                        uint8_t *sym, uint32_t *rstart, uint32_t *n_sym, hipStream_t s);
+void launch_sketch_tiles(bool fill, bool hpc, const uint32_t *words, const uint64_t *woff, const uint32_t *len, const uint8_t *sym,
+                         const uint32_t *rstart, const uint64_t *roff, const uint32_t *n_sym, const SketchTile *tiles, uint32_t n_tiles,
+                         const OvlParams &P, int rid_is_index, const uint64_t *tile_off, uint32_t *tile_cnt, uint64_t *out_x, uint64_t *out_y,
+                         uint32_t *out_read, hipStream_t s);
+int sketch_tile_symbols();
+void launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint32_t n, uint64_t *dst, hipStream_t s);
 void launch_shift_keys(const uint64_t *x, uint64_t *key, uint64_t n, hipStream_t s);
 
 int sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout,

@@ -92,11 +92,13 @@ struct ReadSetDev {
 	uint32_t max_len = 0;
 	DevBuf<uint32_t> words, len, id, order;
 	DevBuf<uint64_t> woff, namekey;
+	std::vector<uint32_t> h_len;
 	void upload(uint32_t n_reads, const uint32_t *w, uint64_t n_words, const uint64_t *off, const uint32_t *lens, const uint32_t *ids,
 	            hipStream_t s)
 	{
 		n = n_reads;
-		words.alloc(n_words + 1); words.upload(w, n_words, s);
+		h_len.assign(lens, lens + n_reads);
+		words.alloc(n_words + 4); words.upload(w, n_words, s);
 		woff.alloc(n); woff.upload(off, n, s);
 		len.alloc(n); len.upload(lens, n, s);
 		id.alloc(n); id.upload(ids, n, s);
@@ -137,8 +139,94 @@ struct Engine {
 
 	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p}; }
 
+	// tiles of `tile` symbols over reads whose symbol counts are n_sym[]; first[r] = first tile of read r
+	// (of the next non-empty read for an empty one), first[n] = number of tiles
+	static void make_tiles(const uint32_t *n_sym, uint32_t n, uint32_t tile, std::vector<SketchTile> &tiles, std::vector<uint32_t> &first)
+	{
+		tiles.clear();
+		first.assign((size_t)n + 1, 0);
+		for (uint32_t r = 0; r < n; ++r) {
+			first[r] = (uint32_t)tiles.size();
+			for (uint32_t s = 0; s < n_sym[r]; s += tile) tiles.push_back(SketchTile{r, s});
+		}
+		first[n] = (uint32_t)tiles.size();
+	}
+
+	void exscan(const uint32_t *in, uint64_t *out, size_t n)
+	{
+		size_t tb = 0;
+		exscan_u32_to_u64(nullptr, tb, in, out, n, stream);
+		exscan_u32_to_u64(temp(tb), tb, in, out, n, stream);
+	}
+
+	// K1, position-parallel form (odd k)
+	void sketch_tiled(const ReadSetDev &R, int rid_is_index, bool want_read, Sketch &out)
+	{
+		const uint32_t TS = (uint32_t)sketch_tile_symbols();
+		EvTimer tm(stream);
+		tm.start();
+		std::vector<SketchTile> tiles;
+		std::vector<uint32_t> first;
+		DevBuf<uint8_t> sym;
+		DevBuf<uint32_t> rstart, n_sym_d;
+		DevBuf<uint64_t> roff;
+		std::vector<uint32_t> h_nsym;
+		if (P.hpc) {
+			make_tiles(R.h_len.data(), R.n, TS, tiles, first);
+			const uint32_t nt = (uint32_t)tiles.size();
+			DevBuf<SketchTile> d_tiles(nt + 1);
+			d_tiles.upload(tiles.data(), nt, stream);
+			DevBuf<uint32_t> d_first(R.n + 1), cnt(nt + 1);
+			d_first.upload(first.data(), R.n + 1, stream);
+			cnt.zero(stream);
+			std::vector<uint64_t> h_roff(R.n + 1);
+			uint64_t acc = 0;
+			for (uint32_t r = 0; r < R.n; ++r) { h_roff[r] = acc + r; acc += R.h_len[r]; }
+			h_roff[R.n] = acc + R.n;
+			roff.alloc(R.n + 1); roff.upload(h_roff.data(), R.n + 1, stream);
+			sym.alloc(acc + R.n + 1); rstart.alloc(acc + R.n + 1); n_sym_d.alloc(R.n + 1);
+			n_sym_d.zero(stream);
+			launch_run_compact(false, R.words.p, R.woff.p, R.len.p, d_tiles.p, nt, nullptr, d_first.p, roff.p, cnt.p, sym.p, rstart.p,
+			                   n_sym_d.p, stream);
+			DevBuf<uint64_t> prefix(nt + 1);
+			exscan(cnt.p, prefix.p, nt + 1);
+			launch_run_compact(true, R.words.p, R.woff.p, R.len.p, d_tiles.p, nt, prefix.p, d_first.p, roff.p, cnt.p, sym.p, rstart.p,
+			                   n_sym_d.p, stream);
+			h_nsym.resize(R.n);
+			n_sym_d.download(h_nsym.data(), R.n, stream);
+			HIP_OK(hipStreamSynchronize(stream));
+			HIP_OK(hipGetLastError());
+			make_tiles(h_nsym.data(), R.n, TS, tiles, first);
+		} else make_tiles(R.h_len.data(), R.n, TS, tiles, first);
+		const uint32_t nt = (uint32_t)tiles.size();
+		DevBuf<SketchTile> d_tiles(nt + 1);
+		d_tiles.upload(tiles.data(), nt, stream);
+		DevBuf<uint32_t> d_first(R.n + 1), cnt(nt + 1);
+		d_first.upload(first.data(), R.n + 1, stream);
+		cnt.zero(stream);
+		launch_sketch_tiles(false, P.hpc != 0, R.words.p, R.woff.p, R.len.p, sym.p, rstart.p, roff.p, n_sym_d.p, d_tiles.p, nt, P, rid_is_index,
+		                    nullptr, cnt.p, nullptr, nullptr, nullptr, stream);
+		DevBuf<uint64_t> tile_off(nt + 1);
+		exscan(cnt.p, tile_off.p, nt + 1);
+		uint64_t total = 0;
+		tile_off.download(&total, 1, stream, nt);
+		HIP_OK(hipStreamSynchronize(stream));
+		out.n = total;
+		out.x.alloc(total + 1); out.y.alloc(total + 1);
+		if (want_read) out.read.alloc(total + 1);
+		launch_sketch_tiles(true, P.hpc != 0, R.words.p, R.woff.p, R.len.p, sym.p, rstart.p, roff.p, n_sym_d.p, d_tiles.p, nt, P, rid_is_index,
+		                    tile_off.p, cnt.p, out.x.p, out.y.p, want_read ? out.read.p : nullptr, stream);
+		out.off.alloc(R.n + 1);
+		launch_gather_u64(tile_off.p, d_first.p, R.n + 1, out.off.p, stream);
+		HIP_OK(hipGetLastError());
+		st.sketch_ms += tm.stop();
+		st.bases_sketched += 2 * R.bases;
+		st.minimizers += total;
+	}
+
 	void sketch(const ReadSetDev &R, int rid_is_index, bool want_read, Sketch &out)
 	{
+		if ((P.k & 1) && !getenv("NDGPU_OVL_SEQ_SKETCH")) { sketch_tiled(R, rid_is_index, want_read, out); return; }
 		DevBuf<uint32_t> cnt(R.n + 1);
 		cnt.zero(stream);
 		EvTimer tm(stream);

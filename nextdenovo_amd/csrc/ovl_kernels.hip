@@ -168,6 +168,261 @@ void launch_sketch(bool fill, const uint32_t *words, const uint64_t *woff, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1, position-parallel form (odd k: no k-mer equals its reverse complement, so every symbol advances
+// the window).  What the window automaton of sketch.c emits is, in closed form:
+//   * symbol s is emitted iff its value x_s is a minimum (ties included) of at least one full window of
+//     w consecutive k-mers containing it, i.e. iff a + b >= w - 1 where a / b count the neighbours to
+//     the left / right (at most w-1, inside the read) whose value is >= x_s;
+//   * output order = position order;
+//   * the first window is special (sketch.c:122-127 runs before the w-th k-mer is compared and the
+//     replaced minimum is not written while l < w+k): with R' = rightmost minimum of the first w-1
+//     k-mers and D' its equal-valued copies, D' is emitted too when x[w-1] < x[R'], and R' is NOT
+//     emitted when x[w-1] == x[R'];
+//   * a read with fewer than w k-mers emits only the rightmost minimum of all its k-mers.
+// (tests/test_gpu_overlap.py checks this against the sequential restatement on every read, and
+// tools/ + the oracle tests fuzz the rule on low-complexity reads.)
+// With HPC the symbols are homopolymer runs: a first pass compacts each read into (run base, run start).
+
+constexpr int kTS = 1024;          // symbols per tile
+constexpr int kSkThreads = 256;
+constexpr int kCH = kTS / kSkThreads;
+constexpr int kHalo = 63;          // w - 1 <= 63
+constexpr int kExt = kTS + 2 * kHalo;
+constexpr int kECH = (kExt + kSkThreads - 1) / kSkThreads;
+
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_tot /*LDS[4]*/, uint32_t &total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+	if (lane == 63) wave_tot[wv] = inc;
+	__syncthreads();
+	uint32_t base = 0;
+	total = 0;
+	for (int i = 0; i < kSkThreads / 64; ++i) { if (i < wv) base += wave_tot[i]; total += wave_tot[i]; }
+	__syncthreads();
+	return base + inc - v;
+}
+
+// HPC pre-pass over base tiles: run starts -> (run base, run start position) per read
+template <bool FILL>
+__global__ void __launch_bounds__(kSkThreads) run_compact_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ woff,
+                                                                 const uint32_t *__restrict__ len, const SketchTile *__restrict__ tiles,
+                                                                 uint32_t n_tiles, const uint64_t *__restrict__ tile_prefix,
+                                                                 const uint32_t *__restrict__ first_tile, const uint64_t *__restrict__ roff,
+                                                                 uint32_t *__restrict__ tile_cnt, uint8_t *__restrict__ sym,
+                                                                 uint32_t *__restrict__ rstart, uint32_t *__restrict__ n_sym)
+{
+	__shared__ uint32_t wave_tot[kSkThreads / 64];
+	const uint32_t tile = blockIdx.x;
+	if (tile >= n_tiles) return;
+	const uint32_t r = tiles[tile].read, t0 = tiles[tile].start, n = len[r];
+	const uint32_t *w = words + woff[r];
+	const uint32_t s0 = t0 + threadIdx.x * kCH;
+	uint32_t flags = 0, cnt = 0;
+	int codes[kCH];
+	int prev = s0 > 0 && s0 - 1 < n ? (int)(w[(s0 - 1) >> 4] >> (30 - 2 * ((s0 - 1) & 15)) & 3u) : -1;
+#pragma unroll
+	for (int c = 0; c < kCH; ++c) {
+		const uint32_t i = s0 + c;
+		codes[c] = -1;
+		if (i < n) {
+			const int b = (int)(w[i >> 4] >> (30 - 2 * (i & 15)) & 3u);
+			codes[c] = b;
+			if (b != prev) flags |= 1u << c, ++cnt;
+			prev = b;
+		}
+	}
+	uint32_t total;
+	const uint32_t excl = block_excl_scan(cnt, wave_tot, total);
+	if (!FILL) {
+		if (threadIdx.x == 0) tile_cnt[tile] = total;
+		return;
+	}
+	const uint64_t base = roff[r] + (tile_prefix[tile] - tile_prefix[first_tile[r]]) + excl;
+	uint32_t k = 0;
+#pragma unroll
+	for (int c = 0; c < kCH; ++c)
+		if (flags >> c & 1) { sym[base + k] = (uint8_t)codes[c]; rstart[base + k] = s0 + c; ++k; }
+	if (threadIdx.x == 0 && t0 + kTS >= n) { // last tile of the read: sentinel + run count
+		const uint32_t ns = (uint32_t)(tile_prefix[tile + 1] - tile_prefix[first_tile[r]]);
+		rstart[roff[r] + ns] = n;
+		n_sym[r] = ns;
+	}
+}
+
+void launch_run_compact(bool fill, const uint32_t *words, const uint64_t *woff, const uint32_t *len, const SketchTile *tiles,
+                        uint32_t n_tiles, const uint64_t *tile_prefix, const uint32_t *first_tile, const uint64_t *roff, uint32_t *tile_cnt,
+                        uint8_t *sym, uint32_t *rstart, uint32_t *n_sym, hipStream_t s)
+{
+	if (!n_tiles) return;
+	if (fill) hipLaunchKernelGGL(run_compact_kernel<true>, dim3(n_tiles), dim3(kSkThreads), 0, s, words, woff, len, tiles, n_tiles, tile_prefix,
+	                             first_tile, roff, tile_cnt, sym, rstart, n_sym);
+	else hipLaunchKernelGGL(run_compact_kernel<false>, dim3(n_tiles), dim3(kSkThreads), 0, s, words, woff, len, tiles, n_tiles, tile_prefix,
+	                        first_tile, roff, tile_cnt, sym, rstart, n_sym);
+}
+
+template <bool FILL, bool HPC>
+__global__ void __launch_bounds__(kSkThreads) sketch_tile_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ woff,
+                                                                 const uint32_t *__restrict__ len, const uint8_t *__restrict__ sym,
+                                                                 const uint32_t *__restrict__ rstart, const uint64_t *__restrict__ roff,
+                                                                 const uint32_t *__restrict__ n_sym, const SketchTile *__restrict__ tiles,
+                                                                 uint32_t n_tiles, int w, int k, int rid_is_index,
+                                                                 const uint64_t *__restrict__ tile_off, uint32_t *__restrict__ tile_cnt,
+                                                                 uint64_t *__restrict__ out_x, uint64_t *__restrict__ out_y,
+                                                                 uint32_t *__restrict__ out_read)
+{
+	__shared__ uint64_t xs[kExt];
+	__shared__ uint32_t ys[kExt];
+	__shared__ uint32_t wave_tot[kSkThreads / 64];
+	__shared__ unsigned long long force_mask;
+	__shared__ int clear_m, short_emit; // short_emit: -2 = normal read, -1 = short read without output, >= 0 symbol to emit
+	const uint32_t tile = blockIdx.x;
+	if (tile >= n_tiles) return;
+	const uint32_t r = tiles[tile].read;
+	const int t0 = (int)tiles[tile].start;
+	const int N = HPC ? (int)n_sym[r] : (int)len[r];
+	const int hw = w - 1, lo = k - 1;
+	const int e0 = t0 - hw > 0 ? t0 - hw : 0;
+	const int e1 = t0 + kTS + hw < N ? t0 + kTS + hw : N;
+	const uint64_t mask = (1ULL << 2 * k) - 1, top = 2ULL * (k - 1);
+	const uint32_t *wp = words + woff[r];
+	const uint64_t ro = HPC ? roff[r] : 0;
+
+	// values of the extended range, a contiguous chunk per thread with a rolling k-mer
+	{
+		const int first = e0 + (int)threadIdx.x * kECH;
+		int last = first + kECH; // exclusive
+		if (last > e1) last = e1;
+		if (first < last) {
+			int j = first - (k - 1);
+			if (j < 0) j = 0;
+			uint64_t fw = 0, rv = 0;
+			for (; j < last; ++j) {
+				int c;
+				if (HPC) c = (int)sym[ro + j];
+				else c = (int)(wp[j >> 4] >> (30 - 2 * (j & 15)) & 3u);
+				fw = (fw << 2 | (uint64_t)c) & mask;
+				rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+				if (j >= first) {
+					uint64_t x = ~0ULL;
+					uint32_t y = ~0u;
+					if (j >= lo) {
+						uint32_t pos = (uint32_t)j, span = (uint32_t)k;
+						if (HPC) {
+							const uint32_t nxt = rstart[ro + j + 1];
+							pos = nxt - 1;
+							span = nxt - rstart[ro + j + 1 - k];
+						}
+						if (span < 256) {
+							const int strand = fw < rv ? 0 : 1;
+							x = hash_masked(strand ? rv : fw, mask) << 8 | (uint64_t)span;
+							y = pos << 1 | (uint32_t)strand;
+						}
+					}
+					xs[j - e0] = x, ys[j - e0] = y;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		force_mask = 0, clear_m = -1, short_emit = -2;
+		if (t0 == 0) {
+			const int nk = N - lo;
+			if (nk < w) { // fewer k-mers than one window: only the final minimum is written (sketch.c:141-142)
+				short_emit = -1;
+				uint64_t best = ~0ULL;
+				for (int s = lo; s < N; ++s) if (xs[s - e0] <= best && xs[s - e0] != ~0ULL) best = xs[s - e0], short_emit = s;
+			} else if (w >= 2) {
+				uint64_t best = ~0ULL;
+				int rp = -1;
+				for (int m = 0; m < w - 1; ++m) if (xs[lo + m - e0] <= best) best = xs[lo + m - e0], rp = m;
+				if (best != ~0ULL) {
+					const uint64_t xw = xs[lo + w - 1 - e0];
+					if (xw < best) {
+						for (int m = 0; m < w - 1; ++m) if (m != rp && xs[lo + m - e0] == best) force_mask |= 1ULL << m;
+					} else if (xw == best) clear_m = rp;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	uint32_t flags = 0, cnt = 0;
+	const int s0 = t0 + (int)threadIdx.x * kCH;
+#pragma unroll
+	for (int c = 0; c < kCH; ++c) {
+		const int s = s0 + c;
+		if (s >= N || s < lo) continue;
+		bool emit;
+		if (short_emit != -2) emit = s == short_emit;
+		else {
+			const uint64_t x = xs[s - e0];
+			emit = false;
+			if (x != ~0ULL) {
+				int a = 0, b = 0;
+				for (int t = s - 1; t >= lo && a < hw && xs[t - e0] >= x; --t) ++a;
+				for (int t = s + 1; t < N && b < hw && xs[t - e0] >= x; ++t) ++b;
+				emit = a + b >= hw;
+			}
+			const int m = s - lo;
+			if (t0 == 0 && m < hw) {
+				if (force_mask >> m & 1) emit = true;
+				if (m == clear_m) emit = false;
+			}
+		}
+		if (emit) flags |= 1u << c, ++cnt;
+	}
+	uint32_t total;
+	const uint32_t excl = block_excl_scan(cnt, wave_tot, total);
+	if (!FILL) {
+		if (threadIdx.x == 0) tile_cnt[tile] = total;
+		return;
+	}
+	uint64_t o = tile_off[tile] + excl;
+	const uint64_t rid_hi = rid_is_index ? (uint64_t)r << 32 : 0;
+#pragma unroll
+	for (int c = 0; c < kCH; ++c)
+		if (flags >> c & 1) {
+			const int s = s0 + c;
+			out_x[o] = xs[s - e0];
+			out_y[o] = rid_hi | (uint64_t)ys[s - e0];
+			if (out_read) out_read[o] = r;
+			++o;
+		}
+}
+
+void launch_sketch_tiles(bool fill, bool hpc, const uint32_t *words, const uint64_t *woff, const uint32_t *len, const uint8_t *sym,
+                         const uint32_t *rstart, const uint64_t *roff, const uint32_t *n_sym, const SketchTile *tiles, uint32_t n_tiles,
+                         const OvlParams &P, int rid_is_index, const uint64_t *tile_off, uint32_t *tile_cnt, uint64_t *out_x, uint64_t *out_y,
+                         uint32_t *out_read, hipStream_t s)
+{
+	if (!n_tiles) return;
+	dim3 g(n_tiles), b(kSkThreads);
+#define SK_ARGS words, woff, len, sym, rstart, roff, n_sym, tiles, n_tiles, P.w, P.k, rid_is_index, tile_off, tile_cnt, out_x, out_y, out_read
+	if (fill && hpc) hipLaunchKernelGGL((sketch_tile_kernel<true, true>), g, b, 0, s, SK_ARGS);
+	else if (fill) hipLaunchKernelGGL((sketch_tile_kernel<true, false>), g, b, 0, s, SK_ARGS);
+	else if (hpc) hipLaunchKernelGGL((sketch_tile_kernel<false, true>), g, b, 0, s, SK_ARGS);
+	else hipLaunchKernelGGL((sketch_tile_kernel<false, false>), g, b, 0, s, SK_ARGS);
+#undef SK_ARGS
+}
+
+int sketch_tile_symbols() { return kTS; }
+
+// off[r] = tile_off[first_tile[r]] for r in 0..n_reads
+__global__ void gather_u64_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint64_t *__restrict__ dst)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = src[idx[i]];
+}
+
+void launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint32_t n, uint64_t *dst, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(gather_u64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, n, dst);
+}
+
+// ------------------------------------------------------------------------------------------------
 // small utility kernels
 
 __global__ void shift_keys_kernel(const uint64_t *__restrict__ x, uint64_t *__restrict__ key, uint64_t n)

@@ -185,3 +185,46 @@ def test_stage_cli_writes_reference_bytes(case, tmp_path):
         want = f.read()
     with open(out, "rb") as f:
         assert f.read() == want
+
+
+def _adversarial_reads(seed=11):
+    rng = np.random.default_rng(seed)
+    reads = []
+    for t in range(260):
+        mode = t % 5
+        n = int(rng.integers(1, 150)) if t % 3 else int(rng.integers(900, 2600))   # around and across the 1024-symbol tile
+        if mode == 0:
+            c = rng.integers(0, 4, n)
+        elif mode == 1:
+            c = rng.integers(0, 2, n)
+        elif mode == 2:
+            u = rng.integers(0, 4, int(rng.integers(1, 7)))
+            c = np.tile(u, n // u.size + 1)[:n]
+        elif mode == 3:
+            c = rng.integers(0, 4, n)
+            c[rng.integers(0, n, n // 3)] = 0
+        else:
+            parts = [np.full(int(rng.choice([1, 1, 2, 3, 40, 130, 260, 300])), int(rng.integers(0, 4))) for _ in range(int(rng.integers(3, 40)))]
+            c = np.concatenate(parts)
+        reads.append(c.astype(np.uint8))
+    return reads
+
+
+@pytest.mark.parametrize("k,w,hpc", [(15, 5, 0), (19, 5, 1), (5, 1, 0), (7, 8, 1), (11, 17, 0), (3, 2, 1), (27, 64, 0), (14, 5, 0), (6, 3, 1)])
+def test_sketch_adversarial_reads(olib, k, w, hpc):
+    """Low-complexity / tandem / homopolymer-heavy / very short reads: the position-parallel K1 (odd k) and the
+    sequential K1 (even k) both reproduce the window automaton, first-window quirks included."""
+    from nextdenovo_amd import overlap, synth
+    reads = _adversarial_reads()
+    lens = np.asarray([r.size for r in reads], dtype=np.uint32)
+    words = [synth.pack_2bit_msb(r) for r in reads]
+    woff = np.zeros(len(reads), dtype=np.uint64)
+    woff[1:] = np.cumsum([x.size for x in words])[:-1]
+    rs = overlap.ReadSet(np.arange(len(reads), dtype=np.uint32), lens, np.concatenate(words), woff)
+    o = overlap.preset("ava-ont", k=k, w=w, hpc=hpc)
+    x, y, off = overlap.sketch(o, rs, True)
+    for i, r in enumerate(reads):
+        mv = M.sketch(olib, r, w, k, i, hpc)
+        lo, hi = int(off[i]), int(off[i + 1])
+        assert hi - lo == mv.size and np.array_equal(x[lo:hi], mv["x"]) and np.array_equal(y[lo:hi], mv["y"]), \
+            "read %d (len %d)" % (i, r.size)

@@ -57,8 +57,8 @@ def main():
             t3 = time.time()
             st = ix.stats()
             info = ix.stat()
-        res = dict(index_s=t1 - t0, map_s=t2 - t1, encode_s=t3 - t2, total_s=t3 - t0, mid_occ=mid, overlaps=int(recs.size),
-                   ovl_bytes=len(blob), index=info, **st)
+        res = dict(index_s=t1 - t0, map_s=t2 - t1, encode_s=t3 - t2, total_s=t3 - t0, mid_occ=mid, n_recs=int(recs.size),
+                   ovl_bytes=len(blob), index=info, stats=st)
         print(json.dumps(res), flush=True)
     if a.ref_threads:
         wd = tempfile.mkdtemp(prefix="ovlscale")
