@@ -1,9 +1,15 @@
 #!/usr/bin/env python
 """bench.py -- corrected bases / s of the MI355X read-correction hot path.
 
-One "step" = one full pass of the correction hot path (every seed pile of the
-workload: O(ND) alignments on the GPU -> consensus) over a synthetic read set that
-is already resident in HBM when the timed region starts.
+One "step" = one full pass of the correction hot path over a synthetic read set:
+  (1) overlap stage (`minimap2-nd --step 1` path): minimizer sketch, index, seeds, anchor sort, chain DP,
+      hits, .ovl encoding of the all-vs-all job (leave out with --no-overlap);
+  (2) consensus stage (`nextcorrect` path): every seed pile of the workload -- O(ND) alignments on the
+      GPU -> MSA -> scoring DP -> consensus -- with the reads already resident in HBM.
+`value` = corrected bases / wall time of (1) + (2).  The two stages are joined in the reference by
+ovl_sort (not part of the hot path): the piles of (2) are derived analytically from
+the true read positions (same admission rules), the overlaps of (1) are checked byte-for-byte against the
+reference in tests/.
 
 Workload (BASELINE.json configs[1]): synthetic
 E. coli-sized genome 4.6 Mb, 50x ONT-profile reads (lognormal, N50 ~ 20-25 kb,
@@ -38,6 +44,7 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-overlap", action="store_true", help="leave the overlap stage (minimap2-nd --step 1 path) out of the step")
     return ap.parse_args()
 
 
@@ -101,6 +108,33 @@ def cpu_baseline(rs, piles, read_type, n_sample):
             "per_core": bases / dt / cores}
 
 
+def cpu_baseline_overlap(rs_dev, preset):
+    """Reference overlapper (oracle/_ref/minimap2-nd --step 1 -t cores) on the same read set: the whole
+    all-vs-all job (it finishes in seconds on the host cores), wall time including its index build."""
+    import subprocess
+    import tempfile
+    from nextdenovo_amd import ovl
+    exe = os.path.join(ROOT, "oracle", "_ref", "minimap2-nd")
+    if not os.path.exists(exe):
+        return None
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    wd = tempfile.mkdtemp(prefix="ndbench")
+    p = os.path.join(wd, "reads.2bit")
+    ovl.write_2bit(p, rs_dev.ids, rs_dev.lens, rs_dev.words, rs_dev.word_off)
+    out = os.path.join(wd, "ref.ovl")
+    t0 = time.perf_counter()
+    subprocess.run([exe, "--step", "1", "-t", str(cores), "-x", preset, p, p, "-o", out], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dt = time.perf_counter() - t0
+    nbytes = os.path.getsize(out)
+    bases = int(rs_dev.lens.sum())
+    for f in (p, out):
+        os.remove(f)
+    return {"value": bases / dt, "unit": "query bases/s", "cores": cores, "kind": "reference", "wall_s": dt, "ovl_bytes": nbytes,
+            "sample": "whole read set (%d reads, %d bases) all-vs-all, compiled reference minimap2-nd --step 1 -t %d -x %s"
+                      % (len(rs_dev), bases, cores, preset)}
+
+
 def reduce_over_ranks(dist, torch, bases: int, dt: float, device):
     """The path's only collective: sum of corrected bases, max of wall
     time.  RCCL over xGMI on the GPU box ("nccl" backend), gloo in the CPU tests."""
@@ -141,12 +175,44 @@ def main():
 
     db = api.ReadDB(words, word_off, lens)  # reads resident in HBM from here on
 
+    # overlap stage (minimap2-nd --step 1 path): the same reads as a .2bit-layout set, all-vs-all
+    ovl_state = None
+    if not args.no_overlap:
+        from nextdenovo_amd import overlap
+        preset = "ava-ont" if args.profile == "ont" else "ava-pb"
+        n_r = len(rs)
+        r_lens = np.asarray([s.size for s in rs.seqs], dtype=np.uint32)
+        r_words = [synth.pack_2bit_msb(s) for s in rs.seqs]
+        r_woff = np.zeros(n_r, dtype=np.uint64)
+        r_woff[1:] = np.cumsum([w.size for w in r_words])[:-1]
+        rs_dev = overlap.ReadSet(np.arange(1, n_r + 1, dtype=np.uint32), r_lens, np.concatenate(r_words), r_woff)
+        ovl_state = {"opt": overlap.preset(preset), "set": rs_dev, "preset": preset, "stats": None, "bytes": 0, "recs": 0,
+                     "wall": 0.0}
+
+    def overlap_step():
+        """index the read set, map it against itself, encode the records: one `minimap2-nd --step 1 seed seed` job"""
+        from nextdenovo_amd import overlap
+        t0 = time.perf_counter()
+        with overlap.Index(ovl_state["opt"], ovl_state["set"]) as ix:
+            recs = ix.map(ovl_state["set"], ix.mid_occ())
+            blob = overlap.encode(recs, np.zeros(2, dtype=np.uint32))
+            st = ix.stats()
+        ovl_state["wall"] += time.perf_counter() - t0
+        ovl_state["bytes"], ovl_state["recs"] = len(blob), int(recs.size)
+        if ovl_state["stats"] is None:
+            ovl_state["stats"] = st
+        else:
+            for k, v in st.items():
+                ovl_state["stats"][k] += v
+
     def sync():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
     def step():
+        if ovl_state is not None:
+            overlap_step()
         res = db.correct_piles(recs, pile_off, read_type=read_type, host_threads=args.host_threads, lengths_only=True)
         # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
         return sum(ln for ln, ide in res if ln >= 500 and ln > 4 and ide >= 0.8)
@@ -154,6 +220,8 @@ def main():
     for _ in range(args.warmup):
         step()
     api.reset_stats()
+    if ovl_state is not None:
+        ovl_state["stats"], ovl_state["wall"] = None, 0.0
     sync()
     t0 = time.perf_counter()
     bases = 0
@@ -216,8 +284,32 @@ def main():
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms")},
         }
+        if ovl_state is not None:
+            ost = ovl_state["stats"]
+            q_bases = int(ovl_state["set"].lens.sum())
+            o_ms = ovl_state["wall"] / args.steps * 1e3
+            # dominant overlap kernels by time; algorithmic bytes of the anchor pipeline:
+            # 16 B per anchor written by K3, sorted (LSD passes of 8 bits: 2 x 16 B per pass), read once by K4
+            passes = 6
+            a_bytes = ost["anchors"] / args.steps * (16.0 + passes * 32.0 + 16.0)
+            gpu_ms = sum(ost[k] for k in ("sketch_ms", "index_sort_ms", "seed_ms", "sort_ms", "exact_sort_ms", "chain_ms", "hits_ms")) / args.steps
+            out["overlap"] = {
+                "included_in_value": True,
+                "value": q_bases * world / (o_ms * 1e-3), "unit": "query bases/s (all-vs-all, index build included)",
+                "ms_per_step": o_ms, "gpu_kernel_ms_per_step": gpu_ms,
+                "kernel_ms": {k: round(ost[k] / args.steps, 3) for k in ("sketch_ms", "index_sort_ms", "seed_ms", "sort_ms", "exact_sort_ms",
+                                                                        "chain_ms", "hits_ms")},
+                "counters": {k: int(ost[k] // args.steps) for k in ("bases_sketched", "minimizers", "anchors", "tie_reads", "chain_cells",
+                                                                    "chains", "overlaps")},
+                "ovl_bytes": ovl_state["bytes"], "records": ovl_state["recs"],
+                "sketch_gsymbols_per_s": ost["bases_sketched"] / (ost["sketch_ms"] * 1e-3) / 1e9 if ost["sketch_ms"] > 0 else 0.0,
+                "anchor_pipeline_alg_GBps": a_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0,
+                "chain_gcells_per_s": ost["chain_cells"] / (ost["chain_ms"] * 1e-3) / 1e9 if ost["chain_ms"] > 0 else 0.0,
+            }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, piles, read_type, args.cpu_sample)
+            if ovl_state is not None:
+                out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(ovl_state["set"], ovl_state["preset"])
         print(json.dumps(out))
     db.close()
     if dist is not None:

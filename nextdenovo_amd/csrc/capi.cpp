@@ -173,7 +173,28 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     });
     int drivers = 4;
     if (const char *e = getenv("NDGPU_CONTEXTS")) drivers = std::max(1, std::min(atoi(e), (int)DeviceAligner::kMaxContexts));
-    const size_t n_sub = ((size_t)n_piles + sub - 1) / sub;
+    // sub-batches: at most `sub` piles and at most `tag_budget` estimated alignment columns each, so that the
+    // device buffers of a context (sized by the largest sub-batch it has seen) stay bounded whatever the seed lengths
+    uint64_t tag_budget = 1300000000ull;
+    if (const char *e = getenv("NDGPU_SUBBATCH_TAGS")) tag_budget = std::max<uint64_t>(1000000ull, strtoull(e, nullptr, 10));
+    std::vector<size_t> sub_start{0};
+    {
+        uint64_t acc = 0;
+        size_t cnt = 0;
+        for (size_t k = 0; k < (size_t)n_piles; k++) {
+            const uint32_t pid = order[k];
+            uint64_t est = 0;
+            for (uint64_t r = pile_off[pid]; r < pile_off[pid + 1]; r++) est += (uint64_t)(recs[r * 8 + 3] - recs[r * 8 + 2] + 1);
+            est += est / 6;
+            if (cnt && (cnt >= sub || acc + est > tag_budget)) {
+                sub_start.push_back(k);
+                acc = 0, cnt = 0;
+            }
+            acc += est, cnt++;
+        }
+        sub_start.push_back((size_t)n_piles);
+    }
+    const size_t n_sub = sub_start.size() - 1;
     drivers = (int)std::min<size_t>((size_t)drivers, n_sub);
     const int threads_each = std::max(1, host_threads / drivers);
     std::atomic<size_t> next_sub(0);
@@ -181,8 +202,8 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
         for (;;) {
             const size_t sb = next_sub.fetch_add(1);
             if (sb >= n_sub) break;
-            const size_t base = sb * sub;
-            const size_t cnt = std::min(sub, (size_t)n_piles - base);
+            const size_t base = sub_start[sb];
+            const size_t cnt = sub_start[sb + 1] - base;
             std::vector<PileEngine *> eng(cnt, nullptr);
             parallel_for(cnt, threads_each, [&](size_t k) {
                 const uint32_t pid = order[base + k];

@@ -169,7 +169,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     for (auto &e : s_->evs) HIP_CHECK(hipEventCreate(&e));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)8 << 30))
-        s_->trace_budget_bytes = free_b / 24;
+        s_->trace_budget_bytes = std::min<size_t>(free_b / 24, (size_t)8 << 30);
     else s_->trace_budget_bytes = (size_t)2 << 30;
 }
 
