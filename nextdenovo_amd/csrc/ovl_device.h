@@ -80,14 +80,16 @@ void launch_gather_read_off(const uint64_t *a_off, const uint64_t *m_off, uint32
                             uint64_t *r_aoff, hipStream_t s);
 void launch_local_off(const uint64_t *r_aoff_all, uint32_t r0, uint32_t n, uint64_t *r_aoff, hipStream_t s);
 void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, hipStream_t s);
-void launch_exact_sort(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
-                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *stacks, hipStream_t s);
+void launch_sort_init(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
+                      const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *jobs, uint32_t *n_jobs, hipStream_t s);
+void launch_sort_pass(const void *jobs, uint32_t n_jobs, uint64_t *x, uint64_t *y, uint64_t *tx, uint64_t *ty, uint32_t *gs, void *next,
+                      uint32_t *n_next, hipStream_t s);
 void launch_chain(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f,
-                  int32_t *p, int32_t *v, unsigned long long *cells, hipStream_t s);
+                  int32_t *p, int32_t *v, int32_t *t, uint64_t *u, uint32_t *n_end, unsigned long long *cells, hipStream_t s);
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
                  const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
-                 uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, OvlRec *recs, uint32_t *n_rec,
-                 uint32_t *n_chain, hipStream_t s);
+                 uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
+                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, hipStream_t s);
 void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,
                          const uint64_t *rec_off, OvlRec *dense, hipStream_t s);
 size_t sort_job_bytes();

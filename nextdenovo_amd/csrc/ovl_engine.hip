@@ -422,22 +422,44 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		for (uint32_t i = 0; i < nb; ++i) if (h_tie[i]) tie_reads.push_back(i);
 		st.tie_reads += tie_reads.size();
 		DevBuf<uint8_t> stacks((na / 64 + 2 * (size_t)nb + 4) * sort_job_bytes());
+		DevBuf<uint64_t> bx(na), by(na);   // K5 chain buffers; scratch of the replay passes before that
+		DevBuf<int32_t> t(na);             // K4/K5 marks; scratch of the replay passes before that
 		if (!tie_reads.empty()) {
 			tm.start();
 			DevBuf<uint32_t> d_tie(tie_reads.size());
 			d_tie.upload(tie_reads.data(), tie_reads.size(), stream);
-			launch_exact_sort(d_tie.p, (uint32_t)tie_reads.size(), r_aoff.p, ckey.p, uy.p, L, ax.p, ay.p, stacks.p, stream);
+			const size_t job_cap = na / 64 + tie_reads.size() + 4;
+			DevBuf<uint8_t> jobs_a(job_cap * sort_job_bytes()), jobs_b(job_cap * sort_job_bytes());
+			DevBuf<uint32_t> n_jobs(2);
+			n_jobs.zero(stream);
+			launch_sort_init(d_tie.p, (uint32_t)tie_reads.size(), r_aoff.p, ckey.p, uy.p, L, ax.p, ay.p, jobs_a.p, n_jobs.p, stream);
+			uint32_t cur = 0;
+			n_jobs.download(&cur, 1, stream);
+			HIP_OK(hipStreamSynchronize(stream));
+			DevBuf<uint8_t> *ja = &jobs_a, *jb = &jobs_b;
+			int which = 0;
+			while (cur) { // at most 8 rounds (digit positions 56, 48, ..., 0)
+				HIP_OK(hipMemsetAsync(n_jobs.p + (1 - which), 0, 4, stream));
+				launch_sort_pass(ja->p, cur, ax.p, ay.p, bx.p, by.p, (uint32_t*)t.p, jb->p, n_jobs.p + (1 - which), stream);
+				n_jobs.download(&cur, 1, stream, 1 - which);
+				HIP_OK(hipStreamSynchronize(stream));
+				std::swap(ja, jb);
+				which = 1 - which;
+			}
 			HIP_OK(hipGetLastError());
 			st.exact_sort_ms += tm.stop();
 		}
 		ckey.release(); uy.release(); skey.release();
 
 		// K4
-		DevBuf<int32_t> f(na), p(na), v(na), t(na);
+		DevBuf<int32_t> f(na), p(na), v(na);
+		DevBuf<uint64_t> u(na);
+		DevBuf<uint32_t> n_end(nb + 1);
 		DevBuf<unsigned long long> cells(1);
 		cells.zero(stream);
+		t.zero(stream);
 		tm.start();
-		launch_chain(r_aoff.p, nb, ax.p, ay.p, P, f.p, p.p, v.p, cells.p, stream);
+		launch_chain(r_aoff.p, nb, ax.p, ay.p, P, f.p, p.p, v.p, t.p, u.p, n_end.p, cells.p, stream);
 		HIP_OK(hipGetLastError());
 		st.chain_ms += tm.stop();
 		unsigned long long h_cells = 0;
@@ -445,13 +467,13 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 
 		// K5 (keeps copies of f/p for the debug view first: K5 reuses v and t only)
 		const uint64_t rec_cap = na / (uint64_t)std::max(1, P.min_cnt) + nb + 1;
-		DevBuf<uint64_t> u(na), bx(na), by(na), wx(na), wy(na);
+		DevBuf<uint64_t> wx(na), wy(na);
 		DevBuf<uint32_t> tables((size_t)nb * 512), n_rec(nb + 1), n_chain(nb);
 		DevBuf<OvlRec> recs(rec_cap);
 		n_rec.zero(stream);
 		tm.start();
-		launch_hits(r_aoff.p, nb, r0, ax.p, ay.p, ix, qd, P, f.p, p.p, v.p, t.p, u.p, bx.p, by.p, wx.p, wy.p, tables.p, stacks.p, recs.p,
-		            n_rec.p, n_chain.p, stream);
+		launch_hits(r_aoff.p, nb, r0, ax.p, ay.p, ix, qd, P, f.p, p.p, v.p, t.p, u.p, bx.p, by.p, wx.p, wy.p, tables.p, stacks.p, n_end.p,
+		            recs.p, n_rec.p, n_chain.p, stream);
 		DevBuf<uint64_t> rec_off(nb + 1);
 		tb = 0;
 		exscan_u32_to_u64(nullptr, tb, n_rec.p, rec_off.p, nb + 1, stream);

@@ -694,15 +694,23 @@ __device__ void reference_sort_xy(uint64_t *x, uint64_t *y, uint32_t n, uint32_t
 	}
 }
 
-// One wavefront per flagged read: rebuild the read's anchors in generation order from the unsorted
-// key/value arrays, then lane 0 replays the reference sort on them.
-__global__ void __launch_bounds__(64) exact_sort_kernel(const uint32_t *__restrict__ tie_reads, uint32_t n_tie,
-                                                         const uint64_t *__restrict__ r_aoff,
-                                                         const uint64_t *__restrict__ ukey, const uint64_t *__restrict__ uy, KeyLayout L,
-                                                         uint64_t *__restrict__ ax, uint64_t *__restrict__ ay,
-                                                         SortJob *__restrict__ stacks)
+// Replay driver.  The recursion of the reference sort is unrolled into rounds: a round handles every open
+// bucket ("job": range + digit position) with one wavefront each and appends the sub-buckets that still
+// hold more than 64 elements to the next round's list.  Inside a job:
+//   histogram                      all lanes (LDS atomics)
+//   one non-empty digit            nothing moves
+//   two non-empty digits (A < B)   closed form of the cycle-leader pass, all lanes:  bucket A keeps its
+//                                  elements in place and the j-th misplaced slot receives the j-th A-element
+//                                  found in bucket B's region; bucket B becomes  e_1, natives before f_1,
+//                                  e_2, natives between f_1 and f_2, ...  (e_j = j-th B-element found in A's
+//                                  region, f_j = slot of the j-th A-element in B's region)
+//   otherwise                      the pass itself, lane 0 (each step depends on the element just displaced)
+//   buckets of <= 64 elements      insertion sort, one lane per bucket
+__global__ void __launch_bounds__(64) sort_init_kernel(const uint32_t *__restrict__ tie_reads, uint32_t n_tie,
+                                                        const uint64_t *__restrict__ r_aoff, const uint64_t *__restrict__ ukey,
+                                                        const uint64_t *__restrict__ uy, KeyLayout L, uint64_t *__restrict__ ax,
+                                                        uint64_t *__restrict__ ay, SortJob *__restrict__ jobs, uint32_t *__restrict__ n_jobs)
 {
-	__shared__ uint32_t head[256], tail[256];
 	if (blockIdx.x >= n_tie) return;
 	const uint32_t rl = tie_reads[blockIdx.x]; // batch-local read index
 	const uint64_t a0 = r_aoff[rl], a1 = r_aoff[rl + 1];
@@ -712,14 +720,128 @@ __global__ void __launch_bounds__(64) exact_sort_kernel(const uint32_t *__restri
 		ay[a0 + i] = uy[a0 + i];
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) reference_sort_xy(ax + a0, ay + a0, n, head, tail, stacks + a0 / 64 + 2 * (size_t)rl);
+	if (threadIdx.x == 0) {
+		if (n <= 64) insertion_sort_xy(ax + a0, ay + a0, 0, n);
+		else jobs[atomicAdd(n_jobs, 1u)] = SortJob{(uint32_t)a0, (uint32_t)a1, 56};
+	}
 }
 
-void launch_exact_sort(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
-                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *stacks, hipStream_t s)
+__global__ void __launch_bounds__(64) sort_pass_kernel(const SortJob *__restrict__ jobs, uint32_t n_jobs, uint64_t *__restrict__ x,
+                                                        uint64_t *__restrict__ y, uint64_t *__restrict__ tx, uint64_t *__restrict__ ty,
+                                                        uint32_t *__restrict__ gs, SortJob *__restrict__ next, uint32_t *__restrict__ n_next)
 {
-	if (n_tie) hipLaunchKernelGGL(exact_sort_kernel, dim3(n_tie), dim3(64), 0, s, tie_reads, n_tie, r_aoff, ukey, uy, L, ax, ay,
-	                              (SortJob*)stacks);
+	__shared__ uint32_t cnt[256], head[256], tail[256];
+	__shared__ int nz, dA, dB;
+	if (blockIdx.x >= n_jobs) return;
+	const SortJob job = jobs[blockIdx.x];
+	const int lane = threadIdx.x, sh = job.shift;
+	const uint32_t beg = job.beg, end = job.end;
+	for (int d = lane; d < 256; d += 64) cnt[d] = 0;
+	__syncthreads();
+	for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&cnt[x[i] >> sh & 255], 1u);
+	__syncthreads();
+	if (lane == 0) {
+		uint32_t run = beg;
+		int k = 0, a = -1, b = -1;
+		for (int d = 0; d < 256; ++d) {
+			if (cnt[d]) { if (k == 0) a = d; else if (k == 1) b = d; ++k; }
+			head[d] = run; run += cnt[d]; tail[d] = run;
+		}
+		nz = k, dA = a, dB = b;
+	}
+	__syncthreads();
+	if (nz == 2) {
+		const uint32_t mid = tail[dA], nB = end - mid, nA = mid - beg;
+		// slots of the A-elements inside B's region, in order
+		uint32_t m = 0;
+		for (uint32_t base = 0; base < nB; base += 64) {
+			const uint32_t pos = base + lane;
+			const bool g = pos < nB && (int)(x[mid + pos] >> sh & 255) == dA;
+			const unsigned long long bm = __ballot(g);
+			if (g) gs[beg + m + __popcll(bm & ((1ULL << lane) - 1))] = pos;
+			m += (uint32_t)__popcll(bm);
+		}
+		__threadfence_block();
+		__builtin_amdgcn_wave_barrier();
+		// A's region: natives stay; the j-th misplaced element e_j moves behind f_(j-1), its slot takes g_j
+		uint32_t j = 0;
+		for (uint32_t base = 0; base < nA; base += 64) {
+			const uint32_t pos = base + lane;
+			const bool in = pos < nA;
+			const uint64_t vx = in ? x[beg + pos] : 0, vy = in ? y[beg + pos] : 0;
+			const bool e = in && (int)(vx >> sh & 255) == dB;
+			const unsigned long long bm = __ballot(e);
+			if (e) {
+				const uint32_t jj = j + (uint32_t)__popcll(bm & ((1ULL << lane) - 1)); // 0-based rank
+				const uint32_t tgt = jj == 0 ? 0 : gs[beg + jj - 1] + 1;
+				tx[mid + tgt] = vx, ty[mid + tgt] = vy;
+				const uint32_t src = mid + gs[beg + jj];
+				tx[beg + pos] = x[src], ty[beg + pos] = y[src];
+			} else if (in) tx[beg + pos] = vx, ty[beg + pos] = vy;
+			j += (uint32_t)__popcll(bm);
+		}
+		// B's region: natives in front of a remaining A-slot shift right by one
+		uint32_t fcnt = 0;
+		for (uint32_t base = 0; base < nB; base += 64) {
+			const uint32_t pos = base + lane;
+			const bool in = pos < nB;
+			const uint64_t vx = in ? x[mid + pos] : 0, vy = in ? y[mid + pos] : 0;
+			const bool g = in && (int)(vx >> sh & 255) == dA;
+			const unsigned long long bm = __ballot(g);
+			if (in && !g) {
+				const uint32_t before = fcnt + (uint32_t)__popcll(bm & ((1ULL << lane) - 1));
+				const uint32_t np = before < m ? pos + 1 : pos;
+				tx[mid + np] = vx, ty[mid + np] = vy;
+			}
+			fcnt += (uint32_t)__popcll(bm);
+		}
+		__threadfence_block();
+		__builtin_amdgcn_wave_barrier();
+		for (uint32_t i = beg + lane; i < end; i += 64) x[i] = tx[i], y[i] = ty[i];
+		__threadfence_block();
+	} else if (nz > 2) {
+		if (lane == 0) {
+			for (int d = 0; d < 256;) {
+				if (head[d] == tail[d]) { ++d; continue; }
+				int to = (int)(x[head[d]] >> sh & 255);
+				if (to == d) { ++head[d]; continue; }
+				uint64_t hx = x[head[d]], hy = y[head[d]];
+				do {
+					const uint32_t at = head[to]++;
+					const uint64_t px = hx, py = hy;
+					hx = x[at], hy = y[at];
+					x[at] = px, y[at] = py;
+					to = (int)(hx >> sh & 255);
+				} while (to != d);
+				const uint32_t at = head[d]++;
+				x[at] = hx, y[at] = hy;
+			}
+		}
+		__threadfence_block();
+	}
+	__syncthreads();
+	if (sh) {
+		const int nsh = sh > 8 ? sh - 8 : 0;
+		for (int d = lane; d < 256; d += 64) {
+			const uint32_t hi = tail[d], lo = hi - cnt[d], sz = cnt[d];
+			if (sz > 64) next[atomicAdd(n_next, 1u)] = SortJob{lo, hi, nsh};
+			else if (sz > 1) insertion_sort_xy(x, y, lo, hi);
+		}
+	}
+}
+
+void launch_sort_init(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
+                      const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *jobs, uint32_t *n_jobs, hipStream_t s)
+{
+	if (n_tie) hipLaunchKernelGGL(sort_init_kernel, dim3(n_tie), dim3(64), 0, s, tie_reads, n_tie, r_aoff, ukey, uy, L, ax, ay, (SortJob*)jobs,
+	                              n_jobs);
+}
+
+void launch_sort_pass(const void *jobs, uint32_t n_jobs, uint64_t *x, uint64_t *y, uint64_t *tx, uint64_t *ty, uint32_t *gs, void *next,
+                      uint32_t *n_next, hipStream_t s)
+{
+	if (n_jobs) hipLaunchKernelGGL(sort_pass_kernel, dim3(n_jobs), dim3(64), 0, s, (const SortJob*)jobs, n_jobs, x, y, tx, ty, gs,
+	                               (SortJob*)next, n_next);
 }
 
 size_t sort_job_bytes() { return sizeof(SortJob); }
@@ -748,51 +870,67 @@ __device__ __forceinline__ int wave_excl_max(int v, int lane)
 	return lane == 0 ? INT32_MIN : e;
 }
 
+// The 64 most recent anchors (x, query position, f, p, v) ride in registers, lane l = anchor i-1-l, and are
+// shifted by one lane per iteration: the usual predecessor window never touches memory.  Older chunks of
+// a long window come from HBM (F/P/V are written there by lane 0 every iteration).
 __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, const uint64_t *__restrict__ ax,
                                                     const uint64_t *__restrict__ ay, OvlParams P, int32_t *__restrict__ f,
-                                                    int32_t *__restrict__ p, int32_t *__restrict__ v, unsigned long long *__restrict__ cells)
+                                                    int32_t *__restrict__ p, int32_t *__restrict__ v, int32_t *__restrict__ t,
+                                                    uint64_t *__restrict__ u, uint32_t *__restrict__ n_end,
+                                                    unsigned long long *__restrict__ cells)
 {
-	__shared__ int32_t ring[kRing];
+	__shared__ uint16_t ring[kRing];
 	const uint32_t rd = blockIdx.x;
 	if (rd >= n_reads) return;
 	const int lane = threadIdx.x;
 	const uint64_t a0 = r_aoff[rd];
-	const int64_t n = (int64_t)(r_aoff[rd + 1] - a0);
-	if (n == 0) return;
+	const int32_t n = (int32_t)(r_aoff[rd + 1] - a0);
+	if (n == 0) { if (lane == 0) n_end[rd] = 0; return; }
 	const uint64_t *X = ax + a0, *Y = ay + a0;
-	int32_t *F = f + a0, *Pp = p + a0, *V = v + a0;
+	int32_t *F = f + a0, *Pp = p + a0, *V = v + a0, *T = t + a0;
+	uint64_t *U = u + a0;
 
 	// average seed span of the read, as a float quotient
 	unsigned long long sum = 0;
-	for (int64_t i = lane; i < n; i += 64) sum += Y[i] >> 32 & 0xff;
+	for (int32_t i = lane; i < n; i += 64) sum += Y[i] >> 32 & 0xff;
 	for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
 	const float avg_span = (float)((double)(float)sum / (double)(float)n);
 	const double lin = .01;
-
-	for (int i = lane; i < kRing; i += 64) ring[i] = -1;
-	__syncthreads();
-
 	const uint64_t max_dist = (uint64_t)P.max_gap;
-	int64_t st = 0;
+
+	uint64_t wx = 0;                       // register window
+	int32_t wq = 0, wf = 0, wp = -1, wv = 0;
+	uint64_t cx = lane < n ? X[lane] : 0, cy = lane < n ? Y[lane] : 0;             // anchors of the current block of 64
+	uint64_t nx = 64 + lane < n ? X[64 + lane] : 0, ny = 64 + lane < n ? Y[64 + lane] : 0; // next block, prefetched
 	unsigned long long my_cells = 0;
-	for (int64_t i = 0; i < n; ++i) {
-		const uint64_t ri = X[i];
-		const uint64_t yi = Y[i];
+
+	for (int32_t i = 0; i < n; ++i) {
+		const int bl = i & 63;
+		if (bl == 0 && i) {
+			cx = nx, cy = ny;
+			const int32_t q = i + 64 + lane;
+			nx = q < n ? X[q] : 0, ny = q < n ? Y[q] : 0;
+		}
+		const uint64_t ri = __shfl(cx, bl, 64), yi = __shfl(cy, bl, 64);
 		const int32_t qi = (int32_t)yi, span = (int32_t)(yi >> 32 & 0xff);
-		while (st < i && ri > X[st] + max_dist) ++st;
-		if (i - st > P.max_iter) st = i - P.max_iter;
-		int32_t best = span, skipped = 0;
-		int64_t best_j = -1;
-		bool stop = false;
-		for (int64_t base = i - 1; base >= st && !stop; base -= 64) {
-			const int64_t j = base - lane;
-			const bool in_win = j >= st;
+		int32_t best = span, skipped = 0, best_j = -1;
+		bool stop = false, fenced = false;
+		for (int32_t base = i - 1; base >= 0 && !stop; base -= 64) {
+			const int32_t j = base - lane;
+			uint64_t xj;
+			int32_t qj, fj, pj;
+			if (base == i - 1) xj = wx, qj = wq, fj = wf, pj = wp;
+			else {
+				if (!fenced) { __threadfence_block(); fenced = true; }
+				xj = 0, qj = 0, fj = 0, pj = -1;
+				if (j >= 0) xj = X[j], qj = (int32_t)Y[j], fj = F[j], pj = Pp[j];
+			}
+			const bool in_win = j >= 0 && i - j <= P.max_iter && ri <= xj + max_dist;
 			bool act = false;
-			int32_t sc = INT32_MIN, pj = -1;
+			int32_t sc = INT32_MIN;
 			if (in_win) {
-				const uint64_t xj = X[j];
 				const int64_t dr = (int64_t)(ri - xj);
-				const int32_t dq = qi - (int32_t)Y[j];
+				const int32_t dq = qi - qj;
 				if (!(dr == 0 || dq <= 0 || dq > P.max_gap)) {
 					const int32_t dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
 					if (dd <= P.bw) {
@@ -800,18 +938,19 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 						if (s0 > span) s0 = span;
 						const int32_t lg = dd ? 31 - __clz(dd) : 0;
 						s0 -= (int)(dd * lin * avg_span) + (lg >> 1);
-						sc = s0 + F[j];
-						pj = Pp[j];
+						sc = s0 + fj;
 						act = true;
 					}
 				}
 			}
 			my_cells += in_win;
-			// marks made by this chunk must be visible to its own later lanes: write all, then read
-			if (act && pj >= st) ring[pj & (kRing - 1)] = (int32_t)i; // marks below the window are never read
+			const unsigned long long win_mask = __ballot(in_win);
+			if (win_mask == 0) break;
+			// marks made by this chunk must be visible to its own later lanes: write all, then read.  A slot is
+			// shared by anchors kRing apart, so marks for anchors more than kRing behind i are dropped (never read).
+			if (act && pj >= 0 && pj > i - kRing) ring[pj & (kRing - 1)] = (uint16_t)i;
 			__builtin_amdgcn_wave_barrier();
-			const bool marked = act && ring[(int32_t)j & (kRing - 1)] == (int32_t)i;
-			// running maximum before this lane
+			const bool marked = act && ring[j & (kRing - 1)] == (uint16_t)i;
 			int run = wave_excl_max(act ? sc : INT32_MIN, lane);
 			if (run < best) run = best;
 			const bool newmax = act && sc > run;
@@ -842,25 +981,59 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 				best = __shfl(sc, last, 64);
 				best_j = base - last;
 			}
+			if (win_mask != ~0ULL) break; // the window ended inside this chunk
 			if (!stop) skipped = __shfl(after, 63, 64);
 		}
-		if (lane == 0) {
-			F[i] = best, Pp[i] = (int32_t)best_j;
-			int32_t peak = best;
-			if (best_j >= 0) { const int32_t vb = V[best_j]; if (vb > best) peak = vb; }
-			V[i] = peak;
+		// peak score on the path ending here
+		int32_t peak = best;
+		if (best_j >= 0) {
+			int32_t vb;
+			const int back = i - 1 - best_j;
+			if (back < 64) vb = __shfl(wv, back, 64);
+			else { if (!fenced) { __threadfence_block(); fenced = true; } vb = V[best_j]; }
+			if (vb > best) peak = vb;
 		}
-		__threadfence_block();
+		if (lane == 0) F[i] = best, Pp[i] = best_j, V[i] = peak, ring[i & (kRing - 1)] = (uint16_t)i;
+		// shift the register window by one anchor
+		wx = __shfl_up(wx, 1, 64), wq = __shfl_up(wq, 1, 64), wf = __shfl_up(wf, 1, 64), wp = __shfl_up(wp, 1, 64);
+		wv = __shfl_up(wv, 1, 64);
+		if (lane == 0) wx = ri, wq = qi, wf = best, wp = best_j, wv = peak;
 		__builtin_amdgcn_wave_barrier();
 	}
 	for (int d = 32; d; d >>= 1) my_cells += __shfl_xor(my_cells, d, 64);
 	if (lane == 0 && cells) atomicAdd(cells, my_cells);
+
+	// chain ends (chain.c:87-104): anchors nobody points to whose peak reaches min_sc; t[] arrives zeroed
+	__threadfence_block();
+	__builtin_amdgcn_wave_barrier();
+	for (int32_t i = lane; i < n; i += 64) { const int32_t pi = Pp[i]; if (pi >= 0) T[pi] = 1; }
+	__threadfence_block();
+	__builtin_amdgcn_wave_barrier();
+	uint32_t n_u = 0;
+	for (int32_t base = 0; base < n; base += 64) {
+		const int32_t i = base + lane;
+		bool e = false;
+		uint64_t uv = 0;
+		if (i < n && T[i] == 0 && V[i] >= P.min_sc) {
+			int32_t j = i;
+			while (j >= 0 && F[j] < V[j]) j = Pp[j];
+			if (j < 0) j = i;
+			uv = (uint64_t)(uint32_t)F[j] << 32 | (uint32_t)j;
+			e = true;
+		}
+		const unsigned long long m = __ballot(e);
+		if (e) U[n_u + __popcll(m & ((1ULL << lane) - 1))] = uv;
+		n_u += (uint32_t)__popcll(m);
+	}
+	__builtin_amdgcn_wave_barrier();
+	for (int32_t i = lane; i < n; i += 64) T[i] = 0; // the backtrack of K5 starts from a clean t[]
+	if (lane == 0) n_end[rd] = n_u;
 }
 
 void launch_chain(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f,
-                  int32_t *p, int32_t *v, unsigned long long *cells, hipStream_t s)
+                  int32_t *p, int32_t *v, int32_t *t, uint64_t *u, uint32_t *n_end, unsigned long long *cells, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(chain_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, ax, ay, P, f, p, v, cells);
+	if (n_reads) hipLaunchKernelGGL(chain_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, ax, ay, P, f, p, v, t, u, n_end, cells);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -917,8 +1090,8 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
                             const uint64_t *__restrict__ ay, IndexDev ix, QueryDev q, OvlParams P, const int32_t *__restrict__ f,
                             const int32_t *__restrict__ p, int32_t *__restrict__ v, int32_t *__restrict__ t, uint64_t *__restrict__ u,
                             uint64_t *__restrict__ bx, uint64_t *__restrict__ by, uint64_t *__restrict__ wx, uint64_t *__restrict__ wy,
-                            uint32_t *__restrict__ tables, SortJob *__restrict__ stacks, OvlRec *__restrict__ recs,
-                            uint32_t *__restrict__ n_rec, uint32_t *__restrict__ n_chain)
+                            uint32_t *__restrict__ tables, SortJob *__restrict__ stacks, const uint32_t *__restrict__ n_end,
+                            OvlRec *__restrict__ recs, uint32_t *__restrict__ n_rec, uint32_t *__restrict__ n_chain)
 {
 	const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rl >= n_reads) return;
@@ -934,23 +1107,12 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 	uint32_t *head = tables + (size_t)rl * 512, *tail = head + 256;
 	SortJob *stack = stacks + a0 / 64 + 2 * (size_t)rl;
 
-	// chain ends
-	for (int32_t i = 0; i < n; ++i) T[i] = 0;
-	for (int32_t i = 0; i < n; ++i) if (Pp[i] >= 0) T[Pp[i]] = 1;
-	int32_t n_u = 0;
-	for (int32_t i = 0; i < n; ++i) {
-		if (T[i] == 0 && V[i] >= P.min_sc) {
-			int32_t j = i;
-			while (j >= 0 && F[j] < V[j]) j = Pp[j];
-			if (j < 0) j = i;
-			U[n_u++] = (uint64_t)(uint32_t)F[j] << 32 | (uint32_t)j;
-		}
-	}
+	// chain ends were collected by K4 (u[], n_end[]); t[] is zero
+	int32_t n_u = (int32_t)n_end[rl];
 	if (n_u == 0) return;
 	heap_sort_desc(U, n_u); // distinct keys
 
 	// backtrack, best chain first
-	for (int32_t i = 0; i < n; ++i) T[i] = 0;
 	int32_t n_v = 0, k = 0;
 	for (int32_t i = 0; i < n_u; ++i) {
 		const int32_t v0 = n_v, k0 = k;
@@ -1024,11 +1186,11 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
                  const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
-                 uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, OvlRec *recs, uint32_t *n_rec,
-                 uint32_t *n_chain, hipStream_t s)
+                 uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
+                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, hipStream_t s)
 {
 	if (n_reads) hipLaunchKernelGGL(hits_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
-	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, recs, n_rec, n_chain);
+	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain);
 }
 
 // gather per-read record runs into one dense array
