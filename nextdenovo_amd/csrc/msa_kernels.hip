@@ -590,23 +590,17 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
         for (uint32_t d = 0; d < width; d++) {
             const uint32_t est = (uint32_t)__builtin_amdgcn_readlane((int)step_est, (int)d);
             const uint32_t n_step = (uint32_t)__builtin_amdgcn_readlane((int)step_n, (int)d);
-            // 3a. one link per lane (64 at a time): final score + the three numbers the cell's
-            //     sequential state needs from it
-            int32_t best = -10, via = kNoScore, via_next = kNoScore;  // state of cell b in lane b
-            uint32_t bidx = 0xffffffffu;                              // link that holds best_pp
+            // 3a. one link per lane (64 at a time): final score + the three numbers the cell's sequential
+            //     state needs from it, parked in the LDS slots this link no longer needs (resolve word, gain, ppp)
+            int32_t best = -10;              // state of cell b, lanes 0..4
+            uint32_t bidx = 0xffffffffu;     // link that holds best_pp
             for (uint32_t g0 = 0; g0 < n_step; g0 += 64) {
                 const uint32_t g_n = n_step - g0 < 64u ? n_step - g0 : 64u;
-                int32_t r_sc = 0, r_impr = kNoScore, r_nsmax = kNoScore, r_scmax = 0;
-                uint32_t r_flags = 0;  // [2:0] owning cell, [3] predecessor symbol allows the via rule,
-                                       // [4] predecessor symbol is not a gap
                 if ((uint32_t)lane < g_n) {
+                    int32_t r_sc = 0, r_impr = kNoScore, r_nsmax = kNoScore, r_scmax = 0;
                     const uint32_t idx = est + g0 + (uint32_t)lane;
                     const uint32_t mpp = cur.pp[idx], mppp = s_ppp[idx], res = s_res[idx];
                     const int32_t gain = s_gain[idx];
-                    const uint32_t cell = (idx >= cur.cstart[d * 6u + 1u]) + (idx >= cur.cstart[d * 6u + 2u]) +
-                                          (idx >= cur.cstart[d * 6u + 3u]) + (idx >= cur.cstart[d * 6u + 4u]);
-                    const uint32_t pb = tag_base(mpp);
-                    r_flags = cell | ((pb == 4u || pb == cell) ? 8u : 0u) | (pb != 4u ? 16u : 0u);
                     if (mpp == kTagHead) {
                         r_sc = gain;
                     } else {
@@ -638,27 +632,46 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
                         }
                     }
                     cur.score[idx] = r_sc;
+                    s_res[idx] = (uint32_t)r_impr;
+                    s_gain[idx] = r_nsmax;
+                    s_ppp[idx] = (uint32_t)r_scmax;
                     if (r_sc > kScoreGuard) overflow = true;
                 }
-                TICK(4)
-                // 3b. advance the cells' sequential state link by link (scalar lane reads)
-                for (uint32_t e = 0; e < g_n; e++) {
-                    const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)r_flags, (int)e);
-                    const int32_t sc = __builtin_amdgcn_readlane(r_sc, (int)e);
-                    const int32_t impr = __builtin_amdgcn_readlane(r_impr, (int)e);
-                    const int32_t nsmax = __builtin_amdgcn_readlane(r_nsmax, (int)e);
-                    const int32_t scmax = __builtin_amdgcn_readlane(r_scmax, (int)e);
-                    if (b == (fl & 7u)) {
-                        if (impr != kNoScore) via_next = impr;
-                        if (nsmax > via && (fl & 8u)) {
-                            via = nsmax;
-                            best = scmax;
-                            bidx = g0 + e;
-                        }
-                        if (sc > best || (sc == best && (fl & 16u))) {
-                            via = via_next;
-                            best = sc;
-                            bidx = g0 + e;
+            }
+            __syncthreads();
+            TICK(4)
+            // 3b. the five symbol cells advance their sequential state in parallel, one lane per cell, each over
+            //     its own links in first-seen order (lib/nextcorrect.c:2164-2192)
+            if (lane < 5) {
+                const uint32_t cst = cur.cstart[d * 6u + b], cn = cur.clen[d * 6u + b];
+                int32_t via = kNoScore, via_next = kNoScore;
+                for (uint32_t m0 = 0; m0 < cn; m0 += 4) {  // 4 links per LDS round trip
+                    int32_t a_sc[4], a_impr[4], a_ns[4], a_scm[4];
+                    uint32_t a_pb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t idx = cst + (m0 + (uint32_t)u < cn ? m0 + (uint32_t)u : cn - 1u);
+                        a_sc[u] = cur.score[idx];
+                        a_impr[u] = (int32_t)s_res[idx];
+                        a_ns[u] = s_gain[idx];
+                        a_scm[u] = (int32_t)s_ppp[idx];
+                        a_pb[u] = tag_base(cur.pp[idx]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (m0 + (uint32_t)u < cn) {
+                            const uint32_t rel = cst + m0 + (uint32_t)u - est;
+                            if (a_impr[u] != kNoScore) via_next = a_impr[u];
+                            if (a_ns[u] > via && (a_pb[u] == 4u || a_pb[u] == b)) {
+                                via = a_ns[u];
+                                best = a_scm[u];
+                                bidx = rel;
+                            }
+                            if (a_sc[u] > best || (a_sc[u] == best && a_pb[u] != 4u)) {
+                                via = via_next;
+                                best = a_sc[u];
+                                bidx = rel;
+                            }
                         }
                     }
                 }
