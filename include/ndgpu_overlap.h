@@ -10,6 +10,7 @@
  *   mm_idx_gen()            minimap2/index.c:351-370       ndgpu_ovl_index_create()   (K1 sketch + K2 sort/group, HBM resident)
  *   mm_idx_cal_max_occ()    minimap2/index.c:170-191       ndgpu_ovl_index_mid_occ()
  *   mm_idx_destroy()        minimap2/index.c:55-79         ndgpu_ovl_index_destroy()
+ *   util/ovl_sort.c (whole program, raw reads)               ndgpu_ovl_sort()  (S1 expand, S2 sort, S3 per-seed filter)
  *   mm_map_file() + the step-1 writer  minimap2/map.c:1376-1403, :1296-1304 + encode_ovl() lib/ovl.c:109-150
  *                                                           ndgpu_ovl_map()  (K1, K3 seeds, sort, K4 chain DP, K5 hits; .ovl bytes)
  *
@@ -76,6 +77,22 @@ int64_t ndgpu_ovl_map(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mi
 int64_t ndgpu_ovl_encode(const ndgpu_ovl_rec *recs, int64_t n, uint32_t prev[2], uint8_t *out);
 
 void ndgpu_ovl_free(void *p);
+
+/* ---- overlap sort / filter: the `ovl_sort` program between the two stages (util/ovl_sort.c, raw reads, no -H) ----
+ *
+ *   files[f][0..n_per_file[f])  step-1 records of input file f in file order (what ndgpu_ovl_map returned, or a decoded .ovl:
+ *                               half-open ends), files in input.fofn order
+ *   seed_len[id]                length of read `id` if it is a seed of this seed file (its .idx, util/ovl_sort.c:106-131), else 0
+ *   min_seed_len                shortest seed of the .idx;  max_bin_cov = -k (40);  max_flank_len = -l (300)
+ *
+ * Returns the records of `sorted.ovl` in file order (per seed: the self record, then the admitted overlaps, inclusive
+ * ends; util/ovl_sort.c:675-741, 433-571, 876-925) and the `.bl` verdicts ('c' contained, 'k' chimeric) in seed order.
+ * Covers the in-memory case of the reference (no temporary files); equal (seed, match, span) keys keep input order.
+ * All three outputs are malloc'd (ndgpu_ovl_free). */
+typedef struct ndgpu_ovl_sort_stats { double gpu_ms; uint64_t raw_records, candidates, seeds, kept; } ndgpu_ovl_sort_stats;
+int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
+                       uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
+                       uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats);
 
 /* ---- array-level views used by the parity tests (same library, same kernels) ---- */
 

@@ -1,0 +1,201 @@
+// ovlsort_engine.hip -- host orchestration + C ABI of the overlap sort / filter stage (util/ovl_sort.c path).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/ndgpu_overlap.h"
+#include "ovl_device.h"
+
+namespace ndovl {
+
+#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[ndgpu_overlap] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); throw std::runtime_error("hip"); } } while (0)
+
+namespace {
+template <class T> struct Buf {
+	T *p = nullptr;
+	size_t n = 0;
+	Buf() = default;
+	explicit Buf(size_t c) { n = c; if (c) HIP_OK(hipMalloc((void**)&p, c * sizeof(T))); }
+	Buf(const Buf&) = delete;
+	Buf &operator=(const Buf&) = delete;
+	~Buf() { if (p) (void)hipFree(p); }
+};
+}
+
+void launch_expand_flags(const OvlRec *raw, uint64_t n, const uint32_t *seed_len, uint32_t n_ids, uint32_t *hq, uint32_t *ht, uint32_t *mq,
+                         uint32_t *mt, hipStream_t s);
+void launch_expand_count(uint64_t n, const uint32_t *file_of, const uint64_t *file_start, const uint32_t *hq, const uint32_t *ht,
+                         const uint64_t *mqs, const uint64_t *mts, uint32_t *sel, hipStream_t s);
+void launch_sel_count(const uint32_t *sel, uint64_t n, uint32_t *cnt, hipStream_t s);
+void launch_expand_write(const OvlRec *raw, uint64_t n, const uint32_t *sel, const uint64_t *pos, OvlRec *cand, uint32_t *k_span,
+                         uint32_t *k_match, uint32_t *k_seed, hipStream_t s);
+void launch_iota(uint32_t *a, uint64_t n, hipStream_t s);
+void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst, hipStream_t s);
+void launch_seed_flag(const OvlRec *cand, const uint32_t *perm, uint64_t n, uint32_t *flag, hipStream_t s);
+void launch_seed_start(const uint32_t *flag, const uint64_t *rank, uint64_t n, uint64_t *start, hipStream_t s);
+int sort_pairs_u32(void *tmp, size_t &tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                   hipStream_t s);
+void launch_seed_filter(const OvlRec *cand, const uint32_t *perm, const uint64_t *seed_start, uint32_t n_seeds, uint64_t n_cand,
+                        const uint32_t *seed_len, int max_bin_cov, int flank, int min_seed_len, uint32_t max_bins, uint32_t *kept, OvlRec *out,
+                        uint32_t *n_out, uint32_t *bl_id, uint8_t *bl_kind, hipStream_t s);
+void launch_compact_seed_recs(const uint64_t *seed_start, uint32_t n_seeds, const OvlRec *out, const uint32_t *n_out, const uint64_t *off,
+                              OvlRec *dense, hipStream_t s);
+
+struct SortRun {
+	hipStream_t st = nullptr;
+	Buf<uint8_t> *tmp = nullptr;
+	size_t tmp_bytes = 0;
+	~SortRun() { delete tmp; }
+	void *temp(size_t b)
+	{
+		if (!tmp || tmp->n < b) { delete tmp; tmp = new Buf<uint8_t>(b + b / 4 + 256); }
+		return tmp->p;
+	}
+	void exscan(const uint32_t *in, uint64_t *out, size_t n)
+	{
+		size_t tb = 0;
+		exscan_u32_to_u64(nullptr, tb, in, out, n, st);
+		exscan_u32_to_u64(temp(tb), tb, in, out, n, st);
+	}
+	// stable LSD pass: reorder perm by key[perm]
+	void pass(const uint32_t *key, uint32_t *perm, uint32_t *perm2, uint32_t *k1, uint32_t *k2, size_t n)
+	{
+		launch_gather_u32(key, perm, n, k1, st);
+		size_t tb = 0;
+		sort_pairs_u32(nullptr, tb, k1, k2, perm, perm2, n, st);
+		sort_pairs_u32(temp(tb), tb, k1, k2, perm, perm2, n, st);
+		HIP_OK(hipMemcpyAsync(perm, perm2, n * 4, hipMemcpyDeviceToDevice, st));
+	}
+};
+
+} // namespace ndovl
+
+using namespace ndovl;
+
+extern "C" int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
+                                  uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
+                                  uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats)
+{
+	*out = nullptr, *bl_id = nullptr, *bl_kind = nullptr, *n_bl = 0;
+	if (stats) memset(stats, 0, sizeof(*stats));
+	try {
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+			fprintf(stderr, "[ndgpu_overlap] no HIP device: the overlap sort has no CPU path\n");
+			return -1;
+		}
+		int dev = 0;
+		if (const char *e = getenv("NDGPU_DEVICE")) dev = atoi(e);
+		HIP_OK(hipSetDevice(dev % n_dev));
+		SortRun R;
+		HIP_OK(hipStreamCreate(&R.st));
+		struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } guard{R.st};
+		hipEvent_t ev0, ev1;
+		HIP_OK(hipEventCreate(&ev0)); HIP_OK(hipEventCreate(&ev1));
+		HIP_OK(hipEventRecord(ev0, R.st));
+
+		uint64_t n = 0;
+		std::vector<uint64_t> h_fstart((size_t)n_files + 1);
+		for (int f = 0; f < n_files; ++f) { h_fstart[f] = n; n += (uint64_t)n_per_file[f]; }
+		h_fstart[n_files] = n;
+		if (n == 0) { *out = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec)); *bl_id = (uint32_t*)malloc(4); *bl_kind = (uint8_t*)malloc(1); return 0; }
+		std::vector<uint32_t> h_file_of(n);
+		Buf<OvlRec> raw(n);
+		for (int f = 0; f < n_files; ++f) {
+			std::fill(h_file_of.begin() + h_fstart[f], h_file_of.begin() + h_fstart[f + 1], (uint32_t)f);
+			if (n_per_file[f]) HIP_OK(hipMemcpyAsync(raw.p + h_fstart[f], files[f], (size_t)n_per_file[f] * sizeof(OvlRec), hipMemcpyHostToDevice, R.st));
+		}
+		Buf<uint32_t> file_of(n), d_seed(n_ids + 1);
+		Buf<uint64_t> fstart((size_t)n_files + 1);
+		HIP_OK(hipMemcpyAsync(file_of.p, h_file_of.data(), n * 4, hipMemcpyHostToDevice, R.st));
+		HIP_OK(hipMemcpyAsync(fstart.p, h_fstart.data(), ((size_t)n_files + 1) * 8, hipMemcpyHostToDevice, R.st));
+		HIP_OK(hipMemcpyAsync(d_seed.p, seed_len, (size_t)n_ids * 4, hipMemcpyHostToDevice, R.st));
+
+		// S1: candidates
+		Buf<uint32_t> hq(n + 1), ht(n + 1), mq(n + 1), mt(n + 1), sel(n + 1), cnt(n + 1);
+		Buf<uint64_t> mqs(n + 1), mts(n + 1), pos(n + 1);
+		HIP_OK(hipMemsetAsync(mq.p, 0, (n + 1) * 4, R.st));
+		HIP_OK(hipMemsetAsync(mt.p, 0, (n + 1) * 4, R.st));
+		HIP_OK(hipMemsetAsync(cnt.p, 0, (n + 1) * 4, R.st));
+		launch_expand_flags(raw.p, n, d_seed.p, n_ids, hq.p, ht.p, mq.p, mt.p, R.st);
+		R.exscan(mq.p, mqs.p, n + 1);
+		R.exscan(mt.p, mts.p, n + 1);
+		launch_expand_count(n, file_of.p, fstart.p, hq.p, ht.p, mqs.p, mts.p, sel.p, R.st);
+		launch_sel_count(sel.p, n, cnt.p, R.st);
+		R.exscan(cnt.p, pos.p, n + 1);
+		uint64_t nc = 0;
+		HIP_OK(hipMemcpyAsync(&nc, pos.p + n, 8, hipMemcpyDeviceToHost, R.st));
+		HIP_OK(hipStreamSynchronize(R.st));
+		if (nc == 0) { *out = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec)); *bl_id = (uint32_t*)malloc(4); *bl_kind = (uint8_t*)malloc(1); return 0; }
+		if (nc >= 0x7fffffffull) { fprintf(stderr, "[ndgpu_overlap] too many candidates for one sort call\n"); return -3; }
+		Buf<OvlRec> cand(nc);
+		Buf<uint32_t> k_span(nc), k_match(nc), k_seed(nc), perm(nc), perm2(nc), k1(nc), k2(nc);
+		launch_expand_write(raw.p, n, sel.p, pos.p, cand.p, k_span.p, k_match.p, k_seed.p, R.st);
+
+		// S2: (seed asc, match desc, span asc), stable
+		launch_iota(perm.p, nc, R.st);
+		R.pass(k_span.p, perm.p, perm2.p, k1.p, k2.p, nc);
+		R.pass(k_match.p, perm.p, perm2.p, k1.p, k2.p, nc);
+		R.pass(k_seed.p, perm.p, perm2.p, k1.p, k2.p, nc);
+
+		// seeds
+		Buf<uint32_t> flag(nc + 1);
+		Buf<uint64_t> rank(nc + 1);
+		HIP_OK(hipMemsetAsync(flag.p, 0, (nc + 1) * 4, R.st));
+		launch_seed_flag(cand.p, perm.p, nc, flag.p, R.st);
+		R.exscan(flag.p, rank.p, nc + 1);
+		uint64_t n_seeds = 0;
+		HIP_OK(hipMemcpyAsync(&n_seeds, rank.p + nc, 8, hipMemcpyDeviceToHost, R.st));
+		HIP_OK(hipStreamSynchronize(R.st));
+		Buf<uint64_t> sstart(n_seeds + 1);
+		launch_seed_start(flag.p, rank.p, nc, sstart.p, R.st);
+
+		// S3
+		uint32_t max_len = 0;
+		for (uint32_t i = 0; i < n_ids; ++i) max_len = std::max(max_len, seed_len[i]);
+		const uint32_t max_bins = (max_len >> 6) + 2;
+		Buf<uint32_t> kept(nc + n_seeds + 1), n_out(n_seeds + 1), d_bl_id(n_seeds + 1);
+		Buf<uint8_t> d_bl_kind(n_seeds + 1);
+		Buf<OvlRec> outrec(nc + n_seeds + 1);
+		HIP_OK(hipMemsetAsync(n_out.p, 0, (n_seeds + 1) * 4, R.st));
+		launch_seed_filter(cand.p, perm.p, sstart.p, (uint32_t)n_seeds, nc, d_seed.p, max_bin_cov, max_flank_len, min_seed_len, max_bins, kept.p,
+		                   outrec.p, n_out.p, d_bl_id.p, d_bl_kind.p, R.st);
+		Buf<uint64_t> off(n_seeds + 1);
+		R.exscan(n_out.p, off.p, n_seeds + 1);
+		uint64_t total = 0;
+		HIP_OK(hipMemcpyAsync(&total, off.p + n_seeds, 8, hipMemcpyDeviceToHost, R.st));
+		HIP_OK(hipStreamSynchronize(R.st));
+		HIP_OK(hipGetLastError());
+		Buf<OvlRec> dense(total + 1);
+		launch_compact_seed_recs(sstart.p, (uint32_t)n_seeds, outrec.p, n_out.p, off.p, dense.p, R.st);
+		*out = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec) * (total + 1));
+		std::vector<uint32_t> h_id(n_seeds);
+		std::vector<uint8_t> h_kind(n_seeds);
+		HIP_OK(hipMemcpyAsync(*out, dense.p, total * sizeof(OvlRec), hipMemcpyDeviceToHost, R.st));
+		HIP_OK(hipMemcpyAsync(h_id.data(), d_bl_id.p, n_seeds * 4, hipMemcpyDeviceToHost, R.st));
+		HIP_OK(hipMemcpyAsync(h_kind.data(), d_bl_kind.p, n_seeds, hipMemcpyDeviceToHost, R.st));
+		HIP_OK(hipEventRecord(ev1, R.st));
+		HIP_OK(hipStreamSynchronize(R.st));
+		HIP_OK(hipGetLastError());
+		*bl_id = (uint32_t*)malloc(4 * (n_seeds + 1));
+		*bl_kind = (uint8_t*)malloc(n_seeds + 1);
+		int64_t nb = 0;
+		for (uint64_t i = 0; i < n_seeds; ++i)
+			if (h_kind[i]) (*bl_id)[nb] = h_id[i], (*bl_kind)[nb++] = h_kind[i];
+		*n_bl = nb;
+		if (stats) {
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, ev0, ev1);
+			stats->gpu_ms = ms, stats->raw_records = n, stats->candidates = nc, stats->seeds = n_seeds, stats->kept = total;
+		}
+		(void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+		return (int64_t)total;
+	} catch (...) {
+		return -2;
+	}
+}

@@ -188,3 +188,44 @@ def encode(recs: np.ndarray, prev: np.ndarray) -> bytes:
     out = np.zeros(40 * max(1, recs.size), dtype=np.uint8)
     n = lib.ndgpu_ovl_encode(_ptr(recs), recs.size, _ptr(prev), _ptr(out))
     return out[:n].tobytes()
+
+
+class SortStats(C.Structure):
+    _fields_ = [("gpu_ms", C.c_double)] + [(n, C.c_uint64) for n in ("raw_records", "candidates", "seeds", "kept")]
+
+
+def from_decoded(a: np.ndarray) -> np.ndarray:
+    """[n,8] array in decode_ovl order (qname, rev, qs, qe, tname, ts, te, match) -> record array."""
+    r = np.zeros(a.shape[0], dtype=REC)
+    for i, n in enumerate(("qname", "rev", "qs", "qe", "tname", "ts", "te", "match")):
+        r[n] = a[:, i]
+    return r
+
+
+def sort_overlaps(files, seed_len: np.ndarray, min_seed_len: int, max_bin_cov: int = 40, max_flank_len: int = 300):
+    """The `ovl_sort` step on the device (ndgpu_ovl_sort).  files = list of record arrays (step-1 overlaps, one per
+    input file, fofn order).  Returns (sorted records, [(seed id, 'c'|'k'), ...], stats dict)."""
+    lib = load()
+    if not hasattr(lib.ndgpu_ovl_sort, "_bound"):
+        lib.ndgpu_ovl_sort.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_uint32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_int64), C.POINTER(SortStats)]
+        lib.ndgpu_ovl_sort.restype = C.c_int64
+        lib.ndgpu_ovl_sort._bound = True
+    files = [np.ascontiguousarray(f, dtype=REC) for f in files]
+    nf = len(files)
+    ptrs = (C.c_void_p * max(1, nf))(*[f.ctypes.data for f in files])
+    cnts = (C.c_int64 * max(1, nf))(*[f.size for f in files])
+    seed_len = np.ascontiguousarray(seed_len, dtype=np.uint32)
+    out, bid, bkind = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nbl = C.c_int64(0)
+    st = SortStats()
+    n = lib.ndgpu_ovl_sort(ptrs, cnts, nf, _ptr(seed_len), seed_len.size, int(min_seed_len), int(max_bin_cov), int(max_flank_len),
+                           C.byref(out), C.byref(bid), C.byref(bkind), C.byref(nbl), C.byref(st))
+    if n < 0:
+        raise RuntimeError("ndgpu_ovl_sort failed (%d): no usable HIP device?" % n)
+    recs = _take(lib, out, n, REC)
+    ids = _take(lib, bid, nbl.value, np.uint32)
+    kinds = _take(lib, bkind, nbl.value, np.uint8)
+    bl = [(int(i), chr(int(k))) for i, k in zip(ids, kinds)]
+    return recs, bl, {n_: getattr(st, n_) for n_, _ in SortStats._fields_}

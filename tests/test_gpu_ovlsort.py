@@ -1,0 +1,121 @@
+"""MI355X overlap sort / filter (ndgpu_ovl_sort, the `ovl_sort` step) and the whole correction stage chained on the
+device: .2bit reads -> overlap -> sort -> consensus, against the reference chain's committed outputs."""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import mm_util as M  # noqa: E402
+import os_util as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+STAGE = os.path.join(HERE, "golden", "stage")
+
+
+def _golden(name, gz=False):
+    p = os.path.join(STAGE, name + (".gz" if gz else ""))
+    with (gzip.open(p, "rb") if gz else open(p, "rb")) as f:
+        return f.read()
+
+
+def _device_raw(dual_pairs):
+    """GPU overlap runs of the stage fixture: [(target, query, dual)] -> list of record arrays."""
+    from nextdenovo_amd import overlap
+    sets = {k: overlap.ReadSet.from_2bit(os.path.join(STAGE, "input.%s.001.2bit" % k)) for k in ("seed", "part")}
+    out = []
+    for t, q, dual in dual_pairs:
+        o = overlap.preset("ava-ont")
+        if dual:
+            o.no_dual = 0
+        with overlap.Index(o, sets[t]) as ix:
+            out.append(ix.map(sets[q], ix.mid_occ()))
+    return out
+
+
+def test_device_overlap_then_sort_matches_reference_sorted_ovl():
+    from nextdenovo_amd import overlap, ovl_sort
+    files = _device_raw([("seed", "part", True), ("seed", "seed", False)])
+    sl, mn = ovl_sort.read_idx(os.path.join(STAGE, ".input.seed.001.idx"))
+    recs, bl, st = overlap.sort_overlaps(files, sl, mn, 40, 300)
+    assert overlap.encode(recs, np.zeros(2, dtype=np.uint32)) == _golden("input.seed.001.sorted.ovl")
+    assert "".join("%d %s\n" % x for x in bl).encode() == _golden("input.seed.001.sorted.ovl.bl")
+    assert st["seeds"] > 10 and st["kept"] == recs.size
+
+
+@pytest.mark.parametrize("k", [40, 18])
+def test_sort_matches_oracle_on_chimeric_set(oracle_lib, k):
+    """Deeper set with glued (chimeric) reads: every admission / trimming branch, against the sort oracle."""
+    from nextdenovo_amd import overlap, synth
+    olib = O.bind(oracle_lib)
+    rng = np.random.default_rng(4)
+    g = synth.make_genome(120000, seed=45, n_repeats=5, repeat_len=2500)
+    rs = synth.simulate_reads(g, 55, "ont", seed=46)
+    seqs = list(rs.seqs)
+    for t in range(30):
+        a, b = rng.integers(0, len(seqs), 2)
+        y = synth.revcomp_codes(seqs[b]) if t % 2 else seqs[b]
+        seqs.append(np.concatenate([seqs[a][: max(1500, seqs[a].size // 2)], y[: max(1500, y.size // 2)]]))
+    n = len(seqs)
+    ids = np.arange(n, dtype=np.uint32)
+    lens = np.asarray([s.size for s in seqs], dtype=np.uint32)
+    words = [synth.pack_2bit_msb(s) for s in seqs]
+    woff = np.zeros(n, dtype=np.uint64)
+    woff[1:] = np.cumsum([w.size for w in words])[:-1]
+    allr = overlap.ReadSet(ids, lens, np.concatenate(words), woff)
+    is_seed = lens >= 7000
+    order = np.concatenate([np.flatnonzero(is_seed), np.flatnonzero(~is_seed)])
+    seeds = overlap.ReadSet(ids[is_seed], lens[is_seed], allr.words, woff[is_seed])
+    parts = overlap.ReadSet(ids[~is_seed], lens[~is_seed], allr.words, woff[~is_seed])
+    files = []
+    for q, dual in ((parts, True), (seeds, False)):
+        o = overlap.preset("ava-ont")
+        o.no_dual = 0 if dual else 1
+        with overlap.Index(o, seeds) as ix:
+            files.append(ix.map(q, ix.mid_occ()))
+    seed_len = np.where(is_seed, lens, 0).astype(np.uint32)
+    mn = int(lens[is_seed].min())
+    recs, bl, st = overlap.sort_overlaps(files, seed_len, mn, k, 300)
+    raws = [np.stack([f[c] for c in ("qname", "rev", "qs", "qe", "tname", "ts", "te", "match")], axis=1) for f in files]
+    want, want_bl, _ = O.oracle_sort(olib, raws, seed_len, mn, max_bin_cov=k)
+    assert len(want) > 50000
+    assert overlap.encode(recs, np.zeros(2, dtype=np.uint32)) == want
+    assert "".join("%d %s\n" % x for x in bl) == want_bl
+    assert any(kind == "c" for _, kind in bl)
+
+
+def test_whole_stage_on_device_from_2bit_to_cns_fasta(tmp_path):
+    """The three stage command lines chained (raw_align x2 -> sort_align -> seed_cns), all on the MI355X engines:
+    `cns.fasta` / `.idx` equal what the reference chain wrote."""
+    from nextdenovo_amd import minimap2_nd, ovl_sort
+    d = str(tmp_path / "w")
+    shutil.copytree(STAGE, d)
+    seed, part = os.path.join(d, "input.seed.001.2bit"), os.path.join(d, "input.part.001.2bit")
+    o0, o1 = os.path.join(d, "raw0.ovl"), os.path.join(d, "raw1.ovl")
+    assert minimap2_nd.run(["--step", "1", "--dual=yes", "-t", "8", "-x", "ava-ont", seed, part, "-o", o0]) == 0
+    assert minimap2_nd.run(["--step", "1", "-I", "3G", "-t", "8", "-x", "ava-ont", seed, seed, "-o", o1]) == 0
+    fofn = os.path.join(d, "ovl.fofn")
+    with open(fofn, "w") as f:
+        f.write(o0 + "\n" + o1 + "\n")
+    so = os.path.join(d, "mine.sorted.ovl")
+    assert ovl_sort.run(["-m", "2g", "-t", "4", "-k", "40", "-i", os.path.join(d, ".input.seed.001.idx"), "-o", so, fofn]) == 0
+    assert open(so, "rb").read() == _golden("input.seed.001.sorted.ovl")
+    assert open(so + ".bl", "rb").read() == _golden("input.seed.001.sorted.ovl.bl")
+    idxs = os.path.join(d, "idxs.fofn")
+    with open(idxs, "w") as f:
+        for n in sorted(os.listdir(d)):
+            if n.startswith(".input.") and n.endswith(".idx"):
+                f.write(os.path.join(d, n) + "\n")
+    out = os.path.join(d, "cns.fasta")
+    cmd = [sys.executable, "-m", "nextdenovo_amd.nextcorrect", "-f", idxs, "-i", so, "-r", "ont", "-p", "4", "-min_len_seed", "1250",
+           "-o", out]
+    r = subprocess.run(cmd, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out, "rb").read() == _golden("cns.default.fasta", gz=True)
+    assert open(out + ".idx", "rb").read() == _golden("cns.default.fasta.idx", gz=True)
