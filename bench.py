@@ -1,20 +1,21 @@
 #!/usr/bin/env python
 """bench.py -- corrected bases / s of the MI355X read-correction hot path.
 
-One "step" = one full pass of the correction hot path over a synthetic read set:
-  (1) overlap stage (`minimap2-nd --step 1` path): minimizer sketch, index, seeds, anchor sort, chain DP,
-      hits, .ovl encoding of the all-vs-all job (leave out with --no-overlap);
-  (2) consensus stage (`nextcorrect` path): every seed pile of the workload -- O(ND) alignments on the
-      GPU -> MSA -> scoring DP -> consensus -- with the reads already resident in HBM.
-`value` = corrected bases / wall time of (1) + (2).  The two stages are joined in the reference by
-ovl_sort (not part of the hot path): the piles of (2) are derived analytically from
-the true read positions (same admission rules), the overlaps of (1) are checked byte-for-byte against the
-reference in tests/.
+One "step" = one full pass of the correction hot path over a synthetic read set that is resident in HBM:
+  (1) overlap stage (`minimap2-nd --step 1` path): minimizer sketch, index, seeds, anchor sort, chain DP, hits of
+      the all-vs-all job;
+  (2) sort stage (`ovl_sort` path): both directions of every overlap, (seed, match, span) order, coverage-bin
+      admission and chimera trimming per seed, `.bl` verdicts -- then the pile admission rules of
+      lib/nextcorrect.py:92-143 on the host (vectorised);
+  (3) consensus stage (`nextcorrect` path): every pile that came out of (2) -- O(ND) alignments -> MSA -> scoring DP
+      -> consensus.
+`value` = corrected bases / wall time of (1) + (2) + (3): the whole raw_align -> sort_align -> seed_cns chain of the
+reference, with no file in between.  Each stage is checked byte-for-byte against the reference in tests/
+(`--no-overlap` / `--analytic-piles` run stage (3) on piles derived from the true read positions instead).
 
-Workload (BASELINE.json configs[1]): synthetic
-E. coli-sized genome 4.6 Mb, 50x ONT-profile reads (lognormal, N50 ~ 20-25 kb,
-sub 3 % / ins 4 % / del 5 %), seed_cutoff 1k, piles derived analytically from the
-true read positions (nextdenovo_amd/synth.py).
+Workload (BASELINE.json configs[1]): synthetic E. coli-sized genome 4.6 Mb, 50x
+ONT-profile reads (lognormal, N50 ~ 20-25 kb, sub 3 % / ins 4 % / del 5 %), seed_cutoff 1k (every read is a seed),
+`-x ava-ont`, `ovl_sort -k 40` (nextdenovo_amd/synth.py generates the reads).
 
 Launch contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
 started by torch.distributed.run with one rank per GPU.  Piles shard across ranks
@@ -44,7 +45,9 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--no-overlap", action="store_true", help="leave the overlap stage (minimap2-nd --step 1 path) out of the step")
+    ap.add_argument("--no-overlap", action="store_true", help="consensus stage only, on analytically derived piles")
+    ap.add_argument("--analytic-piles", action="store_true",
+                    help="run the overlap stage but feed the consensus stage with piles derived from the true read positions")
     return ap.parse_args()
 
 
@@ -165,45 +168,63 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     read_type = {"ont": 1, "clr": 2, "hifi": 3}[args.profile]
+    analytic = args.analytic_piles or args.no_overlap
     t_gen = time.perf_counter()
     genome = synth.make_genome(int(args.genome_size), seed=42 + 1000 * rank)
     rs = synth.simulate_reads(genome, args.depth, args.profile, seed=43 + 1000 * rank)
-    piles = synth.build_piles(rs, seed_cutoff=1000)
-    recs, pile_off = synth.flatten_piles(piles)
+    piles = synth.build_piles(rs, seed_cutoff=1000) if analytic else []
+    recs, pile_off = synth.flatten_piles(piles) if analytic else (None, None)
     words, word_off, lens = synth.pack_db(rs)
     t_gen = time.perf_counter() - t_gen
 
     db = api.ReadDB(words, word_off, lens)  # reads resident in HBM from here on
 
-    # overlap stage (minimap2-nd --step 1 path): the same reads as a .2bit-layout set, all-vs-all
+    # overlap + sort stages: the same reads as a .2bit-layout set (read id = index in the DB), all-vs-all; every read is
+    # a seed (seed_cutoff 1k <= shortest read), so the run is the single `seed x seed` job of nextDenovo:456-464
     ovl_state = None
     if not args.no_overlap:
         from nextdenovo_amd import overlap
         preset = "ava-ont" if args.profile == "ont" else "ava-pb"
         n_r = len(rs)
-        r_lens = np.asarray([s.size for s in rs.seqs], dtype=np.uint32)
-        r_words = [synth.pack_2bit_msb(s) for s in rs.seqs]
-        r_woff = np.zeros(n_r, dtype=np.uint64)
-        r_woff[1:] = np.cumsum([w.size for w in r_words])[:-1]
-        rs_dev = overlap.ReadSet(np.arange(1, n_r + 1, dtype=np.uint32), r_lens, np.concatenate(r_words), r_woff)
+        rs_dev = overlap.ReadSet(np.arange(n_r, dtype=np.uint32), lens, words, word_off)
+        depth = int(round(args.depth))
         ovl_state = {"opt": overlap.preset(preset), "set": rs_dev, "preset": preset, "stats": None, "bytes": 0, "recs": 0,
-                     "wall": 0.0}
+                     "wall": 0.0, "sort_wall": 0.0, "asm_wall": 0.0, "sort_stats": None,
+                     "k": (depth - 2) if depth <= 30 else min(depth - 5, 40),  # lib/config_parser.py:44
+                     "seed_len": lens.astype(np.uint32), "min_seed": int(lens.min()), "last": None}
 
     def overlap_step():
-        """index the read set, map it against itself, encode the records: one `minimap2-nd --step 1 seed seed` job"""
-        from nextdenovo_amd import overlap
+        """one `minimap2-nd --step 1 seed seed` job (index, map) and, in pipeline mode, `ovl_sort` + the pile assembly
+        of lib/nextcorrect.py:92-143 on its records"""
+        from nextdenovo_amd import nextcorrect as nc, overlap
         t0 = time.perf_counter()
         with overlap.Index(ovl_state["opt"], ovl_state["set"]) as ix:
-            recs = ix.map(ovl_state["set"], ix.mid_occ())
-            blob = overlap.encode(recs, np.zeros(2, dtype=np.uint32))
+            raw = ix.map(ovl_state["set"], ix.mid_occ())
             st = ix.stats()
-        ovl_state["wall"] += time.perf_counter() - t0
-        ovl_state["bytes"], ovl_state["recs"] = len(blob), int(recs.size)
+        ovl_state["recs"] = int(raw.size)
+        if analytic:  # stand-alone overlap job: the records are encoded as the .ovl file would be
+            ovl_state["bytes"] = len(overlap.encode(raw, np.zeros(2, dtype=np.uint32)))
+        t1 = time.perf_counter()
+        ovl_state["wall"] += t1 - t0
         if ovl_state["stats"] is None:
             ovl_state["stats"] = st
         else:
             for k, v in st.items():
                 ovl_state["stats"][k] += v
+        if analytic:
+            return None
+        srt, bl, sst = overlap.sort_overlaps([raw], ovl_state["seed_len"], ovl_state["min_seed"], ovl_state["k"], 300)
+        t2 = time.perf_counter()
+        dec = np.stack([srt[c] for c in ("qname", "rev", "qs", "qe", "tname", "ts", "te", "match")], axis=1)
+        skip = [i for i, kind in bl]  # the .bl blacklist is honoured as lib/nextcorrect.py does by default
+        rows, off, seeds = nc.assemble_piles_fast(dec, 500, 500, 130, 10, skip)
+        sub = np.ascontiguousarray(dec[rows])
+        t3 = time.perf_counter()
+        ovl_state["sort_wall"] += t2 - t1
+        ovl_state["asm_wall"] += t3 - t2
+        ovl_state["sort_stats"] = sst
+        ovl_state["last"] = (sub, off, seeds, len(bl))
+        return sub, off
 
     def sync():
         if dist is not None:
@@ -211,9 +232,12 @@ def main():
             torch.cuda.synchronize()
 
     def step():
+        r_, o_ = recs, pile_off
         if ovl_state is not None:
-            overlap_step()
-        res = db.correct_piles(recs, pile_off, read_type=read_type, host_threads=args.host_threads, lengths_only=True)
+            got = overlap_step()
+            if got is not None:
+                r_, o_ = got
+        res = db.correct_piles(r_, o_, read_type=read_type, host_threads=args.host_threads, lengths_only=True)
         # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
         return sum(ln for ln, ide in res if ln >= 500 and ln > 4 and ide >= 0.8)
 
@@ -221,7 +245,7 @@ def main():
         step()
     api.reset_stats()
     if ovl_state is not None:
-        ovl_state["stats"], ovl_state["wall"] = None, 0.0
+        ovl_state["stats"], ovl_state["wall"], ovl_state["sort_wall"], ovl_state["asm_wall"] = None, 0.0, 0.0, 0.0
     sync()
     t0 = time.perf_counter()
     bases = 0
@@ -237,6 +261,10 @@ def main():
         total_bases, max_dt = reduce_over_ranks(dist, torch, bases, dt, "cuda")
 
     if rank == 0:
+        if not analytic:  # the piles the last step really corrected (for the config line and the CPU sample)
+            sub, off, seeds, n_bl = ovl_state["last"]
+            piles = [{"seed": int(seeds[i]), "recs": sub[int(off[i]):int(off[i + 1])]} for i in range(seeds.size)]
+            recs = sub
         # Roofline of the dominant kernel by GPU time: K10 score_fast (scoring DP).  Algorithmic
         # bytes per launch = every MSA cell table entry read once (start,len: 8 B) and its best_pp /
         # best_link written once (8 B) + every link read once (pp, ppp, count: 12 B) + the per-column
@@ -269,6 +297,8 @@ def main():
                                                                           args.profile),
                        "reads_per_gpu": len(rs), "read_bases_per_gpu": rs.total_bases(), "piles_per_gpu": len(piles),
                        "overlaps_per_gpu": int(recs.shape[0]), "sharding": "piles, weak (one read set per rank)",
+                       "piles_from": "analytic (true read positions)" if analytic else
+                       "the step's own overlap -> ovl_sort -> pile assembly chain on the device",
                        "datagen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": "score_fast_kernel (K10 scoring DP)", "achieved": achieved,
                          "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": None,
@@ -306,6 +336,13 @@ def main():
                 "anchor_pipeline_alg_GBps": a_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0,
                 "chain_gcells_per_s": ost["chain_cells"] / (ost["chain_ms"] * 1e-3) / 1e9 if ost["chain_ms"] > 0 else 0.0,
             }
+            if not analytic:
+                out["overlap"]["sort"] = {"ms_per_step": ovl_state["sort_wall"] / args.steps * 1e3,
+                                          "gpu_ms": ovl_state["sort_stats"]["gpu_ms"],
+                                          "candidates": int(ovl_state["sort_stats"]["candidates"]),
+                                          "kept": int(ovl_state["sort_stats"]["kept"]), "blacklisted": int(ovl_state["last"][3]),
+                                          "k": ovl_state["k"]}
+                out["overlap"]["pile_assembly_ms_per_step"] = ovl_state["asm_wall"] / args.steps * 1e3
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, piles, read_type, args.cpu_sample)
             if ovl_state is not None:

@@ -186,7 +186,10 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
             uint64_t est = 0;
             for (uint64_t r = pile_off[pid]; r < pile_off[pid + 1]; r++) est += (uint64_t)(recs[r * 8 + 3] - recs[r * 8 + 2] + 1);
             est += est / 6;
-            if (cnt && (cnt >= sub || acc + est > tag_budget)) {
+            // the first sub-batches are small (16, 32, 64, ... piles): they hold the longest seeds, whose scoring
+            // chains bound the whole call, so their alignment / MSA phases must not wait for hundreds of other piles
+            const size_t ramp = std::min<size_t>(sub, (size_t)16 << std::min<size_t>(sub_start.size() - 1, 16));
+            if (cnt && (cnt >= ramp || acc + est > tag_budget)) {
                 sub_start.push_back(k);
                 acc = 0, cnt = 0;
             }

@@ -816,14 +816,19 @@ __global__ __launch_bounds__(64) void score_slow_kernel(
     }
 }
 
-// best_pp walk from the origin (lib/nextcorrect.c:1907-1982 visits exactly these cells)
+// best_pp walk from the origin (lib/nextcorrect.c:1907-1982 visits exactly these cells).  One wavefront per
+// pile: the walk is a pointer chase (each step needs the cell the previous one named), so the 64 columns below
+// the current one are staged in LDS with coalesced loads -- cell base, coverage and the (best_pp, best_link) of
+// the six delta-0 cells -- and the chase runs out of LDS; only insertion cells (delta > 0) go to HBM.
 __global__ __launch_bounds__(64) void backtrack_kernel(PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage,
                                                         const uint32_t *__restrict__ cell_base,
                                                         const uint32_t *__restrict__ cell_best_pp,
                                                         const uint32_t *__restrict__ cell_best_link,
                                                         PathItem *__restrict__ path, int n_piles) {
-    const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+    __shared__ uint32_t s_cb[64], s_cov[64], s_bpp[64 * 6], s_blk[64 * 6];
+    const int i = (int)blockIdx.x;
     if (i >= n_piles) return;
+    const int lane = (int)threadIdx.x;
     PileDev &P = piles[i];
     const uint32_t *cov = coverage + P.col_off;
     const uint32_t *cb = cell_base + P.col_off;
@@ -835,18 +840,51 @@ __global__ __launch_bounds__(64) void backtrack_kernel(PileDev *__restrict__ pil
     int32_t t = P.origin_t;
     uint32_t db = P.origin_db;
     while (t >= 0 && len < cap) {
-        const uint32_t cell = cb[t] + (db >> 3) * 6u + (db & 7u);
-        PathItem it;
-        it.tag = tag_pack(t, db >> 3, db & 7u);
-        it.link = (uint16_t)blk[cell];
-        it.cov = (uint16_t)cov[t];
-        out[len++] = it;
-        const uint32_t g = bpp[cell];
-        if (g == kTagHead) break;
-        t = tag_tpos(g);
-        db = g & 0x7ffu;
+        const int32_t hi = t, lo = t > 63 ? t - 63 : 0;
+        {
+            const int32_t c = hi - lane;
+            if (c >= lo) {
+                const uint32_t base = cb[c];
+                s_cb[lane] = base;
+                s_cov[lane] = cov[c];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    s_bpp[lane * 6 + k] = bpp[base + k];
+                    s_blk[lane * 6 + k] = blk[base + k];
+                }
+            }
+        }
+        __syncthreads();
+        while (t >= lo && len < cap) {
+            const int rel = hi - t;
+            const uint32_t dl = db >> 3, bs = db & 7u;
+            uint32_t g, lk;
+            if (dl == 0) {
+                g = s_bpp[rel * 6 + (int)bs];
+                lk = s_blk[rel * 6 + (int)bs];
+            } else {
+                const uint32_t cell = s_cb[rel] + dl * 6u + bs;
+                g = bpp[cell];
+                lk = blk[cell];
+            }
+            if (lane == 0) {
+                PathItem it;
+                it.tag = tag_pack(t, dl, bs);
+                it.link = (uint16_t)lk;
+                it.cov = (uint16_t)s_cov[rel];
+                out[len] = it;
+            }
+            len++;
+            if (g == kTagHead) {
+                t = -1;
+                break;
+            }
+            t = tag_tpos(g);
+            db = g & 0x7ffu;
+        }
+        __syncthreads();
     }
-    P.path_len = len;
+    if (lane == 0) P.path_len = len;
 }
 
 // ---- K11 -------------------------------------------------------------------------
@@ -975,7 +1013,7 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
     hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
                        cell_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, ent_score, cell_best_pp,
                        cell_best_link);
-    hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)((n_piles + 63) / 64)), dim3(64), 0, st, piles, coverage,
+    hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage,
                        cell_base, cell_best_pp, cell_best_link, path, n_piles);
 }
 

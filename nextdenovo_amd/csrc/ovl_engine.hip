@@ -20,8 +20,77 @@
 
 #include "../../include/ndgpu_overlap.h"
 #include "ovl_device.h"
+#include "ovl_pool.h"
+
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 namespace ndovl {
+
+// ---- caching allocator (ovl_pool.h) ----
+namespace {
+std::mutex g_pool_mu;
+std::multimap<size_t, void*> g_pool_free;        // size class -> block
+std::unordered_map<void*, size_t> g_pool_size;   // live + cached blocks -> size class
+size_t g_pool_cached = 0;
+size_t size_class(size_t b)
+{
+	if (b < 4096) return 4096;
+	size_t p = 4096;
+	while (p * 2 <= b) p *= 2;              // p <= b < 2p
+	const size_t step = p / 8;
+	return p + (b - p + step - 1) / step * step;
+}
+}
+
+void *pool_alloc(size_t bytes)
+{
+	const size_t c = size_class(bytes);
+	{
+		std::lock_guard<std::mutex> g(g_pool_mu);
+		auto it = g_pool_free.find(c);
+		if (it != g_pool_free.end()) {
+			void *p = it->second;
+			g_pool_free.erase(it);
+			g_pool_cached -= c;
+			return p;
+		}
+	}
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, c);
+	if (e != hipSuccess) { // give the cache back and retry once
+		pool_trim();
+		e = hipMalloc(&p, c);
+	}
+	if (e != hipSuccess) {
+		fprintf(stderr, "[ndgpu_overlap] hipMalloc of %zu bytes failed: %s\n", c, hipGetErrorString(e));
+		throw std::runtime_error("hipMalloc");
+	}
+	std::lock_guard<std::mutex> g(g_pool_mu);
+	g_pool_size[p] = c;
+	return p;
+}
+
+void pool_free(void *p)
+{
+	if (!p) return;
+	std::lock_guard<std::mutex> g(g_pool_mu);
+	auto it = g_pool_size.find(p);
+	if (it == g_pool_size.end()) { (void)hipFree(p); return; }
+	g_pool_free.emplace(it->second, p);
+	g_pool_cached += it->second;
+}
+
+void pool_trim()
+{
+	std::lock_guard<std::mutex> g(g_pool_mu);
+	for (auto &kv : g_pool_free) { (void)hipFree(kv.second); g_pool_size.erase(kv.second); }
+	g_pool_free.clear();
+	g_pool_cached = 0;
+}
+
+size_t pool_cached_bytes() { std::lock_guard<std::mutex> g(g_pool_mu); return g_pool_cached; }
 
 #define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[ndgpu_overlap] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); throw std::runtime_error("hip"); } } while (0)
 
@@ -35,8 +104,8 @@ template <class T> struct DevBuf {
 	DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
 	DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p, n = o.n; o.p = nullptr, o.n = 0; } return *this; }
 	~DevBuf() { release(); }
-	void alloc(size_t count) { release(); n = count; if (count) HIP_OK(hipMalloc((void**)&p, count * sizeof(T))); }
-	void release() { if (p) (void)hipFree(p); p = nullptr, n = 0; }
+	void alloc(size_t count) { release(); n = count; if (count) p = (T*)pool_alloc(count * sizeof(T)); }
+	void release() { if (p) pool_free(p); p = nullptr, n = 0; }
 	void upload(const T *src, size_t count, hipStream_t s) { if (count) HIP_OK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s)); }
 	void download(T *dst, size_t count, hipStream_t s, size_t from = 0) const { if (count) HIP_OK(hipMemcpyAsync(dst, p + from, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
 	void zero(hipStream_t s) { if (n) HIP_OK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }

@@ -10,6 +10,7 @@
 
 #include "../../include/ndgpu_overlap.h"
 #include "ovl_device.h"
+#include "ovl_pool.h"
 
 namespace ndovl {
 
@@ -20,10 +21,10 @@ template <class T> struct Buf {
 	T *p = nullptr;
 	size_t n = 0;
 	Buf() = default;
-	explicit Buf(size_t c) { n = c; if (c) HIP_OK(hipMalloc((void**)&p, c * sizeof(T))); }
+	explicit Buf(size_t c) { n = c; if (c) p = (T*)pool_alloc(c * sizeof(T)); }
 	Buf(const Buf&) = delete;
 	Buf &operator=(const Buf&) = delete;
-	~Buf() { if (p) (void)hipFree(p); }
+	~Buf() { if (p) pool_free(p); }
 };
 }
 

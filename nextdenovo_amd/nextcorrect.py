@@ -90,6 +90,44 @@ def assemble_piles(recs: np.ndarray, args, skip):
         yield seed_name, rows
 
 
+def assemble_piles_fast(recs: np.ndarray, min_len_seed: int, min_len_aln: int, max_cov_aln: int, min_cov_seed: int, skip=()):
+    """Vectorised form of assemble_piles (same admission rules, lib/nextcorrect.py:92-143) for large record arrays.
+    Returns (rows, pile_off, seeds): rows = indices into recs of the admitted records of every valid pile, in order."""
+    n = recs.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint32)
+    t = recs[:, 0].astype(np.int64)
+    q = recs[:, 4].astype(np.int64)
+    span = recs[:, 3].astype(np.int64) - recs[:, 2].astype(np.int64)
+    first = np.flatnonzero(np.r_[True, t[1:] != t[:-1]])          # first record of every seed group
+    gid = np.cumsum(np.r_[True, t[1:] != t[:-1]]) - 1
+    seed_len = recs[first, 3].astype(np.int64) + 1                 # the group's first record is the self record
+    seed_ok = seed_len >= min_len_seed
+    if len(skip):
+        seed_ok &= ~np.isin(t[first], np.fromiter(skip, dtype=np.int64, count=len(skip)))
+    ok = (span >= min_len_aln) & seed_ok[gid]
+    # one overlap per query read: first occurrence among the length-admitted records of the group
+    idx = np.flatnonzero(ok)
+    order = np.lexsort((idx, q[idx], gid[idx]))
+    so = idx[order]
+    dup = np.r_[False, (gid[so][1:] == gid[so][:-1]) & (q[so][1:] == q[so][:-1])]
+    ok[so[dup]] = False
+    # cumulative depth limit: total_length before the record over seed length must not exceed 1.5 x max_cov_aln
+    add = np.where(ok, span + 1, 0)
+    cum = np.cumsum(add) - add
+    cum -= cum[first][gid]
+    ok &= cum / seed_len[gid] <= max_cov_aln * 1.5
+    add = np.where(ok, span + 1, 0)
+    total = np.add.reduceat(add, first)
+    valid = seed_ok & (total / seed_len >= min_cov_seed)
+    ok &= valid[gid]
+    rows = np.flatnonzero(ok)
+    counts = np.add.reduceat(ok.astype(np.int64), first)[valid]
+    pile_off = np.zeros(counts.size + 1, dtype=np.uint64)
+    np.cumsum(counts, out=pile_off[1:])
+    return rows, pile_off, t[first][valid].astype(np.uint32)
+
+
 def main(args):
     corrected_region = re.compile(r"[ACGT]+")
     OUT, IDX = sys.stdout, None
