@@ -162,7 +162,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     if (n_piles <= 0) return 0;
     if (host_threads <= 0) host_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const ReadDb &db = *h->db;
-    size_t sub = 512;
+    size_t sub = 384;
     if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
     // longest seeds first: the scoring DP is a sequential chain per seed, so similar lengths
     // share a launch and the long chains start early
@@ -171,11 +171,11 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return recs[pile_off[a] * 8 + 3] > recs[pile_off[b] * 8 + 3];
     });
-    int drivers = 4;
+    int drivers = 6;
     if (const char *e = getenv("NDGPU_CONTEXTS")) drivers = std::max(1, std::min(atoi(e), (int)DeviceAligner::kMaxContexts));
     // sub-batches: at most `sub` piles and at most `tag_budget` estimated alignment columns each, so that the
     // device buffers of a context (sized by the largest sub-batch it has seen) stay bounded whatever the seed lengths
-    uint64_t tag_budget = 1300000000ull;
+    uint64_t tag_budget = 900000000ull;
     if (const char *e = getenv("NDGPU_SUBBATCH_TAGS")) tag_budget = std::max<uint64_t>(1000000ull, strtoull(e, nullptr, 10));
     std::vector<size_t> sub_start{0};
     {
@@ -200,11 +200,10 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     const size_t n_sub = sub_start.size() - 1;
     drivers = (int)std::min<size_t>((size_t)drivers, n_sub);
     const int threads_each = std::max(1, host_threads / drivers);
-    std::atomic<size_t> next_sub(0);
+    // sub-batch j always goes to context j mod drivers: a context then sees the same sub-batch sizes call after call
+    // and its grow-only device buffers stop being re-allocated (a hipFree / hipMalloc stalls every context)
     auto drive = [&](int ctx) {
-        for (;;) {
-            const size_t sb = next_sub.fetch_add(1);
-            if (sb >= n_sub) break;
+        for (size_t sb = (size_t)ctx; sb < n_sub; sb += (size_t)drivers) {
             const size_t base = sub_start[sb];
             const size_t cnt = sub_start[sb + 1] - base;
             std::vector<PileEngine *> eng(cnt, nullptr);
