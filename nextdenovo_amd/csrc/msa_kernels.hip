@@ -442,19 +442,28 @@ struct ColTab {
     int32_t score[kColEnts];
 };
 
-__global__ __launch_bounds__(64) void score_fast_kernel(
+// Two wavefronts per pile.  The scoring chain itself -- links read their predecessors' scores, the five symbol
+// cells fold their links, the global pick -- is wave 0 ("scorer").  Everything that does not depend on scores
+// runs one column ahead on wave 1 ("loader"): fetch the column's cell / link tables from HBM (register prefetch
+// of the column after), commit them to LDS, resolve every link (where its predecessor cell is, its gain), and
+// store the finished results of the column before.  One barrier per column joins the two.
+__global__ __launch_bounds__(128) void score_fast_kernel(
     PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
     const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ ent_base,
     const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_len,
     const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp, const uint32_t *__restrict__ ent_cnt,
     uint32_t *__restrict__ cell_best_pp, uint32_t *__restrict__ cell_best_link) {
-    __shared__ ColTab tab[2];
-    __shared__ uint32_t s_ppp[kColEnts], s_cnt[kColEnts], s_res[kColEnts];
-    __shared__ int32_t s_gain[kColEnts];
-    __shared__ uint32_t s_bpp[kColCells], s_blink[kColCells];
-    __builtin_amdgcn_s_setprio(3);  // latency-bound wave: issue priority over co-resident kernels
+    __shared__ ColTab tab[3];                                   // columns p-1, p, p+1 (slot = column mod 3)
+    __shared__ uint32_t s_ppp[2][kColEnts], s_cnt[2][kColEnts], s_res[2][kColEnts];
+    __shared__ int32_t s_gain[2][kColEnts];
+    __shared__ uint32_t s_bpp[2][kColCells], s_blink[2][kColCells];
+    __shared__ uint32_t s_meta[2][5][64];                       // width, cell0, e0, ecap, coverage of 2 x 64 columns
+    __shared__ uint32_t s_colw[2], s_colc0[2], s_stop[2];       // per prepared column: width, first cell, "does not fit"
+    __shared__ uint32_t s_links, s_sc_ovf;
+    __builtin_amdgcn_s_setprio(3);  // latency-bound waves: issue priority over co-resident kernels
     PileDev &P = piles[blockIdx.x];
-    const int lane = (int)threadIdx.x;
+    const int wave = (int)(threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u);
     const uint32_t b = (uint32_t)lane;
     const uint32_t L = P.seed_len;
     const uint32_t *cov = coverage + P.col_off;
@@ -470,22 +479,22 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
     uint32_t *blk_out = cell_best_link + P.cell_off;
     const int32_t factor = P.factor;
 
-    int32_t gbest = -10;
-    int32_t o_t = -1;
-    uint32_t o_db = 0, n_links = 0;
-    bool overflow = false;
-
-    uint32_t m_width = 0, m_cell0 = 0, m_e0 = 0, m_ecap = 0, m_cov = 0;
+    // ---- loader state
     uint32_t pf_cs = 0, pf_cl = 0, pf_pp[4] = {0, 0, 0, 0}, pf_ppp[4] = {0, 0, 0, 0}, pf_cnt[4] = {0, 0, 0, 0};
+    uint32_t n_links = 0;
     auto load_meta = [&](uint32_t p0) {  // 64 columns of metadata, one coalesced load per array
         const uint32_t p = p0 + (uint32_t)lane;
+        uint32_t w_ = 0, c_ = 0, e_ = 0, k_ = 0, v_ = 0;
         if (p < L) {
-            m_width = ms[p];
-            m_cell0 = cb[p];
-            m_e0 = eb[p];
-            m_ecap = eb[p + 1] - m_e0;  // link capacity of the column (>= links actually present)
-            m_cov = cov[p];
-        } else m_width = m_cell0 = m_e0 = m_ecap = m_cov = 0;
+            w_ = ms[p];
+            c_ = cb[p];
+            e_ = eb[p];
+            k_ = eb[p + 1] - e_;  // link capacity of the column (>= links actually present)
+            v_ = cov[p];
+        }
+        const uint32_t par = (p0 >> 6) & 1u;
+        s_meta[par][0][lane] = w_, s_meta[par][1][lane] = c_, s_meta[par][2][lane] = e_, s_meta[par][3][lane] = k_;
+        s_meta[par][4][lane] = v_;
     };
     auto prefetch = [&](uint32_t cell0, uint32_t ncell, uint32_t e0, uint32_t ecap) {
         if ((uint32_t)lane < ncell) {
@@ -502,222 +511,239 @@ __global__ __launch_bounds__(64) void score_fast_kernel(
             }
         }
     };
-#ifdef ND_K10_PROF
-    long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
-    unsigned long long n_steps = 0;
-#define TICK(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); long long tn_ = clock64(); tc[i] += tn_ - tprev; tprev = tn_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define TICK(i)
-#endif
-    load_meta(0);
-    prefetch((uint32_t)__shfl((int)m_cell0, 0, 64), (uint32_t)__shfl((int)m_width, 0, 64) * 6u,
-             (uint32_t)__shfl((int)m_e0, 0, 64), (uint32_t)__shfl((int)m_ecap, 0, 64));
-
-    for (uint32_t p = 0; p < L; p++) {
-        const int ml = (int)(p & 63u);
-        const uint32_t width = (uint32_t)__builtin_amdgcn_readlane((int)m_width, ml);
-        const uint32_t cell0 = (uint32_t)__builtin_amdgcn_readlane((int)m_cell0, ml);
-        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)m_e0, ml);
-        const uint32_t ecap = (uint32_t)__builtin_amdgcn_readlane((int)m_ecap, ml);
-        const int32_t pen = factor * (int32_t)__builtin_amdgcn_readlane((int)m_cov, ml);
+    // prepare column q: tables -> LDS, links resolved.  Runs on the loader wave only.
+    auto prepare = [&](uint32_t q) {
+        const int ml = (int)(q & 63u);
+        const uint32_t mp = (q >> 6) & 1u, slot = q & 1u;
+        const uint32_t width = s_meta[mp][0][ml], cell0 = s_meta[mp][1][ml], e0 = s_meta[mp][2][ml], ecap = s_meta[mp][3][ml];
+        const int32_t pen = factor * (int32_t)s_meta[mp][4][ml];
         const uint32_t ncell = width * 6u;
-        if (ncell > (uint32_t)kColCells || ecap > (uint32_t)kColEnts) {
-            overflow = true;
+        const bool fits = ncell <= (uint32_t)kColCells && ecap <= (uint32_t)kColEnts;
+        if (lane == 0) s_colw[slot] = width, s_colc0[slot] = cell0, s_stop[slot] = fits ? 0u : 1u;
+        ColTab &cur = tab[q % 3u];
+        const ColTab &prv = tab[(q + 2u) % 3u];
+        if (fits) {
+            if ((uint32_t)lane < ncell) {
+                cur.cstart[lane] = pf_cs - e0;
+                cur.clen[lane] = pf_cl;
+            }
+            for (uint32_t c = (uint32_t)lane + 64u; c < ncell; c += 64) {
+                cur.cstart[c] = cs[cell0 + c] - e0;
+                cur.clen[c] = cl[cell0 + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
+                if (e < ecap) {
+                    cur.pp[e] = pf_pp[j];
+                    s_ppp[slot][e] = pf_ppp[j];
+                    s_cnt[slot][e] = pf_cnt[j];
+                }
+            }
+            for (uint32_t e = (uint32_t)lane + 256u; e < ecap; e += 64) {
+                cur.pp[e] = epp[e0 + e];
+                s_ppp[slot][e] = eppp[e0 + e];
+                s_cnt[slot][e] = ecnt[e0 + e];
+            }
+        }
+        // the loads of column q+1 start now (and the next metadata block when q closes one)
+        if (q + 1 < L) {
+            if (ml == 63) load_meta(q + 1);
+            __builtin_amdgcn_wave_barrier();
+            const int nl = (int)((q + 1) & 63u);
+            const uint32_t np_ = ((q + 1) >> 6) & 1u;
+            prefetch(s_meta[np_][1][nl], s_meta[np_][0][nl] * 6u, s_meta[np_][2][nl], s_meta[np_][3][nl]);
+        }
+        if (!fits || ncell == 0) return;
+        __builtin_amdgcn_wave_barrier();
+        // resolve every link of the column once
+        const uint32_t nent = cur.cstart[ncell - 1u] + cur.clen[ncell - 1u];
+        n_links += nent;
+        for (uint32_t e = (uint32_t)lane; e < nent; e += 64) {
+            const uint32_t mpp = cur.pp[e];
+            uint32_t res = 0;
+            if (mpp != kTagHead) {
+                const bool same = (uint32_t)tag_tpos(mpp) == q;
+                const ColTab &T = same ? cur : prv;
+                const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
+                res = ((uint32_t)same << 31) | (T.cstart[pc] << 12) | T.clen[pc];
+            }
+            s_res[slot][e] = res;
+            s_gain[slot][e] = 10 * (int32_t)s_cnt[slot][e] - pen;
+        }
+    };
+
+    // ---- scorer state
+    int32_t gbest = -10;
+    int32_t o_t = -1;
+    uint32_t o_db = 0;
+    bool sc_overflow = false;
+
+    if (threadIdx.x == 0) s_links = 0, s_sc_ovf = 0;
+    if (wave == 1) {
+        load_meta(0);
+        __builtin_amdgcn_wave_barrier();
+        prefetch(s_meta[0][1][0], s_meta[0][0][0] * 6u, s_meta[0][2][0], s_meta[0][3][0]);
+        prepare(0);
+    }
+    __syncthreads();
+
+    bool stopped = false;
+    for (uint32_t p = 0; p < L; p++) {
+        const uint32_t slot = p & 1u;
+        if (s_stop[slot]) {  // column p does not fit the LDS tables: the pile goes to the HBM-resident kernel
+            stopped = true;
             break;
         }
-        ColTab &cur = tab[p & 1u];
-        ColTab &prv = tab[(p & 1u) ^ 1u];
-        TICK(0)
-        // 1. commit the prefetched tables of column p to LDS, fetch what did not fit
-        if ((uint32_t)lane < ncell) {
-            cur.cstart[lane] = pf_cs - e0;
-            cur.clen[lane] = pf_cl;
-        }
-        for (uint32_t c = (uint32_t)lane + 64u; c < ncell; c += 64) {
-            cur.cstart[c] = cs[cell0 + c] - e0;
-            cur.clen[c] = cl[cell0 + c];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
-            if (e < ecap) {
-                cur.pp[e] = pf_pp[j];
-                s_ppp[e] = pf_ppp[j];
-                s_cnt[e] = pf_cnt[j];
-            }
-        }
-        for (uint32_t e = (uint32_t)lane + 256u; e < ecap; e += 64) {
-            cur.pp[e] = epp[e0 + e];
-            s_ppp[e] = eppp[e0 + e];
-            s_cnt[e] = ecnt[e0 + e];
-        }
-        TICK(1)
-        // 2. start the loads of column p+1 (and of the next metadata block)
-        if (p + 1 < L) {
-            if (ml == 63) load_meta(p + 1);
-            const int nl = (int)((p + 1) & 63u);
-            prefetch((uint32_t)__shfl((int)m_cell0, nl, 64), (uint32_t)__shfl((int)m_width, nl, 64) * 6u,
-                     (uint32_t)__shfl((int)m_e0, nl, 64), (uint32_t)__shfl((int)m_ecap, nl, 64));
-        }
-        if (ncell == 0) continue;
-        __syncthreads();
-        TICK(2)
-        // 2b. resolve every link of the column once; lane d keeps the link range of step d
-        {
-            const uint32_t nent = cur.cstart[ncell - 1u] + cur.clen[ncell - 1u];
-            n_links += nent;
-            for (uint32_t e = (uint32_t)lane; e < nent; e += 64) {
-                const uint32_t mpp = cur.pp[e];
-                uint32_t res = 0;
-                if (mpp != kTagHead) {
-                    const bool same = (uint32_t)tag_tpos(mpp) == p;
-                    const ColTab &T = same ? cur : prv;
-                    const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
-                    res = ((uint32_t)same << 31) | (T.cstart[pc] << 12) | T.clen[pc];
+        if (wave == 1) {
+            // column p+1 first (its commit drains the memory counter: nothing younger than the prefetched loads may
+            // be in flight), then the results of column p-1, which the scorer finished before the barrier
+            const uint32_t ps_ = slot ^ 1u, pw = p > 0 ? s_colw[ps_] * 6u : 0u, pc0 = s_colc0[ps_];
+            if (p + 1 < L) prepare(p + 1);
+            for (uint32_t c = (uint32_t)lane; c < pw; c += 64)
+                if (c % 6u < 5u) {
+                    bpp_out[pc0 + c] = s_bpp[ps_][c];
+                    blk_out[pc0 + c] = s_blink[ps_][c];
                 }
-                s_res[e] = res;
-                s_gain[e] = 10 * (int32_t)s_cnt[e] - pen;
-            }
-        }
-        uint32_t step_est = 0, step_n = 0;
-        if ((uint32_t)lane < width) {
-            step_est = cur.cstart[(uint32_t)lane * 6u];
-            step_n = cur.cstart[(uint32_t)lane * 6u + 4u] + cur.clen[(uint32_t)lane * 6u + 4u] - step_est;
-        }
-        __syncthreads();
-        TICK(3)
-        // 3. score the steps of column p out of LDS
-        for (uint32_t d = 0; d < width; d++) {
-            const uint32_t est = (uint32_t)__builtin_amdgcn_readlane((int)step_est, (int)d);
-            const uint32_t n_step = (uint32_t)__builtin_amdgcn_readlane((int)step_n, (int)d);
-            // 3a. one link per lane (64 at a time): final score + the three numbers the cell's sequential
-            //     state needs from it, parked in the LDS slots this link no longer needs (resolve word, gain, ppp)
-            int32_t best = -10;              // state of cell b, lanes 0..4
-            uint32_t bidx = 0xffffffffu;     // link that holds best_pp
-            for (uint32_t g0 = 0; g0 < n_step; g0 += 64) {
-                const uint32_t g_n = n_step - g0 < 64u ? n_step - g0 : 64u;
-                if ((uint32_t)lane < g_n) {
-                    int32_t r_sc = 0, r_impr = kNoScore, r_nsmax = kNoScore, r_scmax = 0;
-                    const uint32_t idx = est + g0 + (uint32_t)lane;
-                    const uint32_t mpp = cur.pp[idx], mppp = s_ppp[idx], res = s_res[idx];
-                    const int32_t gain = s_gain[idx];
-                    if (mpp == kTagHead) {
-                        r_sc = gain;
-                    } else {
-                        const ColTab &T = (res >> 31) ? cur : prv;
-                        const uint32_t ps = (res >> 12) & 0x7ffffu, pn = res & 0xfffu;
-                        for (uint32_t k0 = 0; k0 < pn; k0 += 4) {  // 4 predecessor links per LDS round trip
-                            uint32_t key[4];
-                            int32_t nsv[4];
+        } else {
+            const uint32_t width = s_colw[slot];
+            if (width) {
+                ColTab &cur = tab[p % 3u];
+                const ColTab &prv = tab[(p + 2u) % 3u];
+                uint32_t step_est = 0, step_n = 0;
+                if ((uint32_t)lane < width) {
+                    step_est = cur.cstart[(uint32_t)lane * 6u];
+                    step_n = cur.cstart[(uint32_t)lane * 6u + 4u] + cur.clen[(uint32_t)lane * 6u + 4u] - step_est;
+                }
+                for (uint32_t d = 0; d < width; d++) {
+                    const uint32_t est = (uint32_t)__builtin_amdgcn_readlane((int)step_est, (int)d);
+                    const uint32_t n_step = (uint32_t)__builtin_amdgcn_readlane((int)step_n, (int)d);
+                    // one link per lane (64 at a time): final score + the three numbers the cell's sequential state
+                    // needs from it, parked in the LDS slots this link no longer needs (resolve word, gain, ppp)
+                    int32_t best = -10;           // state of cell b, lanes 0..4
+                    uint32_t bidx = 0xffffffffu;  // link that holds best_pp
+                    for (uint32_t g0 = 0; g0 < n_step; g0 += 64) {
+                        const uint32_t g_n = n_step - g0 < 64u ? n_step - g0 : 64u;
+                        if ((uint32_t)lane < g_n) {
+                            int32_t r_sc = 0, r_impr = kNoScore, r_nsmax = kNoScore, r_scmax = 0;
+                            const uint32_t idx = est + g0 + (uint32_t)lane;
+                            const uint32_t mpp = cur.pp[idx], mppp = s_ppp[slot][idx], res = s_res[slot][idx];
+                            const int32_t gain = s_gain[slot][idx];
+                            if (mpp == kTagHead) {
+                                r_sc = gain;
+                            } else {
+                                const ColTab &T = (res >> 31) ? cur : prv;
+                                const uint32_t ps = (res >> 12) & 0x7ffffu, pn = res & 0xfffu;
+                                for (uint32_t k0 = 0; k0 < pn; k0 += 4) {  // 4 predecessor links per LDS round trip
+                                    uint32_t key[4];
+                                    int32_t nsv[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; u++) {
+                                        const uint32_t k = k0 + (uint32_t)u < pn ? k0 + (uint32_t)u : pn - 1u;
+                                        key[u] = T.pp[ps + k];
+                                        nsv[u] = T.score[ps + k];
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 4; u++) {
+                                        if (k0 + (uint32_t)u < pn && key[u] == mppp) {
+                                            const int32_t ns = nsv[u];
+                                            if (ns + gain > r_sc) {
+                                                r_sc = ns + gain;
+                                                r_impr = ns;
+                                            }
+                                            if (ns > r_nsmax) {
+                                                r_nsmax = ns;
+                                                r_scmax = r_sc;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            cur.score[idx] = r_sc;
+                            s_res[slot][idx] = (uint32_t)r_impr;
+                            s_gain[slot][idx] = r_nsmax;
+                            s_ppp[slot][idx] = (uint32_t)r_scmax;
+                            if (r_sc > kScoreGuard) sc_overflow = true;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // the five symbol cells advance their sequential state in parallel, one lane per cell, each over
+                    // its own links in first-seen order (lib/nextcorrect.c:2164-2192)
+                    if (lane < 5) {
+                        const uint32_t cst = cur.cstart[d * 6u + b], cn = cur.clen[d * 6u + b];
+                        int32_t via = kNoScore, via_next = kNoScore;
+                        for (uint32_t m0 = 0; m0 < cn; m0 += 4) {  // 4 links per LDS round trip
+                            int32_t a_sc[4], a_impr[4], a_ns[4], a_scm[4];
+                            uint32_t a_pb[4];
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
-                                const uint32_t k = k0 + (uint32_t)u < pn ? k0 + (uint32_t)u : pn - 1u;
-                                key[u] = T.pp[ps + k];
-                                nsv[u] = T.score[ps + k];
+                                const uint32_t idx = cst + (m0 + (uint32_t)u < cn ? m0 + (uint32_t)u : cn - 1u);
+                                a_sc[u] = cur.score[idx];
+                                a_impr[u] = (int32_t)s_res[slot][idx];
+                                a_ns[u] = s_gain[slot][idx];
+                                a_scm[u] = (int32_t)s_ppp[slot][idx];
+                                a_pb[u] = tag_base(cur.pp[idx]);
                             }
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
-                                if (k0 + (uint32_t)u < pn && key[u] == mppp) {
-                                    const int32_t ns = nsv[u];
-                                    if (ns + gain > r_sc) {
-                                        r_sc = ns + gain;
-                                        r_impr = ns;
+                                if (m0 + (uint32_t)u < cn) {
+                                    const uint32_t rel = cst + m0 + (uint32_t)u - est;
+                                    if (a_impr[u] != kNoScore) via_next = a_impr[u];
+                                    if (a_ns[u] > via && (a_pb[u] == 4u || a_pb[u] == b)) {
+                                        via = a_ns[u];
+                                        best = a_scm[u];
+                                        bidx = rel;
                                     }
-                                    if (ns > r_nsmax) {
-                                        r_nsmax = ns;
-                                        r_scmax = r_sc;
+                                    if (a_sc[u] > best || (a_sc[u] == best && a_pb[u] != 4u)) {
+                                        via = via_next;
+                                        best = a_sc[u];
+                                        bidx = rel;
                                     }
                                 }
                             }
                         }
+                        uint32_t bpp = kTagHead, blink = 0;
+                        if (bidx != 0xffffffffu) {
+                            bpp = cur.pp[est + bidx];
+                            blink = s_cnt[slot][est + bidx];
+                        }
+                        s_bpp[slot][d * 6u + b] = bpp;
+                        s_blink[slot][d * 6u + b] = blink;
                     }
-                    cur.score[idx] = r_sc;
-                    s_res[idx] = (uint32_t)r_impr;
-                    s_gain[idx] = r_nsmax;
-                    s_ppp[idx] = (uint32_t)r_scmax;
-                    if (r_sc > kScoreGuard) overflow = true;
-                }
-            }
-            __syncthreads();
-            TICK(4)
-            // 3b. the five symbol cells advance their sequential state in parallel, one lane per cell, each over
-            //     its own links in first-seen order (lib/nextcorrect.c:2164-2192)
-            if (lane < 5) {
-                const uint32_t cst = cur.cstart[d * 6u + b], cn = cur.clen[d * 6u + b];
-                int32_t via = kNoScore, via_next = kNoScore;
-                for (uint32_t m0 = 0; m0 < cn; m0 += 4) {  // 4 links per LDS round trip
-                    int32_t a_sc[4], a_impr[4], a_ns[4], a_scm[4];
-                    uint32_t a_pb[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t idx = cst + (m0 + (uint32_t)u < cn ? m0 + (uint32_t)u : cn - 1u);
-                        a_sc[u] = cur.score[idx];
-                        a_impr[u] = (int32_t)s_res[idx];
-                        a_ns[u] = s_gain[idx];
-                        a_scm[u] = (int32_t)s_ppp[idx];
-                        a_pb[u] = tag_base(cur.pp[idx]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (m0 + (uint32_t)u < cn) {
-                            const uint32_t rel = cst + m0 + (uint32_t)u - est;
-                            if (a_impr[u] != kNoScore) via_next = a_impr[u];
-                            if (a_ns[u] > via && (a_pb[u] == 4u || a_pb[u] == b)) {
-                                via = a_ns[u];
-                                best = a_scm[u];
-                                bidx = rel;
-                            }
-                            if (a_sc[u] > best || (a_sc[u] == best && a_pb[u] != 4u)) {
-                                via = via_next;
-                                best = a_sc[u];
-                                bidx = rel;
-                            }
+                    __builtin_amdgcn_wave_barrier();  // scores of (p,d) visible before (p,d+1) reads them (one wave, LDS in order)
+                    for (int bb = 0; bb < 5; bb++) {  // global pick in symbol order (lib/nextcorrect.c:2194-2199)
+                        const int32_t v = __builtin_amdgcn_readlane(best, bb);
+                        if (v >= gbest - 3000) {
+                            o_t = (int32_t)p;
+                            o_db = (d << 3) | (uint32_t)bb;
+                            if (v > gbest) gbest = v;
                         }
                     }
                 }
             }
-            TICK(5)
-            if (lane < 5) {
-                uint32_t bpp = kTagHead, blink = 0;
-                if (bidx != 0xffffffffu) {
-                    bpp = cur.pp[est + bidx];
-                    blink = s_cnt[est + bidx];
-                }
-                s_bpp[d * 6u + b] = bpp;
-                s_blink[d * 6u + b] = blink;
-            }
-            __syncthreads();  // scores of (p,d) visible before (p,d+1) reads them
-            for (int bb = 0; bb < 5; bb++) {  // global pick in symbol order (lib/nextcorrect.c:2194-2199)
-                const int32_t v = __builtin_amdgcn_readlane(best, bb);
-                if (v >= gbest - 3000) {
-                    o_t = (int32_t)p;
-                    o_db = (d << 3) | (uint32_t)bb;
-                    if (v > gbest) gbest = v;
-                }
-            }
         }
-        TICK(6)
-        for (uint32_t c = (uint32_t)lane; c < ncell; c += 64)
-            if (c % 6u < 5u) {
-                bpp_out[cell0 + c] = s_bpp[c];
-                blk_out[cell0 + c] = s_blink[c];
-            }
-        __syncthreads();
-        TICK(7)
+        __syncthreads();  // the loader prepared column p+1 while the scorer worked on p; both meet here
     }
-#ifdef ND_K10_PROF
-    if (lane == 0 && blockIdx.x == 0)
-        printf("[k10prof] L=%u | per col: meta %lld commit %lld prefetch+sync %lld resolve %lld links %lld fold %lld tail+pick %lld out %lld\n", L,
-               tc[0] / L, tc[1] / L, tc[2] / L, tc[3] / L, tc[4] / L, tc[5] / L, tc[6] / L, tc[7] / L);
-#endif
-    if (__ballot(overflow)) {
-        if (lane == 0) P.err = 2;  // redo this pile in the int64 / HBM-resident kernel
-        return;
-    }
-    if (lane == 0) {
-        P.origin_t = o_t;
-        P.origin_db = o_db;
-        P.n_links = n_links;
+    if (wave == 1) {
+        if (!stopped && L > 0) {  // results of the last column
+            const uint32_t ps_ = (L - 1u) & 1u, pw = s_colw[ps_] * 6u, pc0 = s_colc0[ps_];
+            for (uint32_t c = (uint32_t)lane; c < pw; c += 64)
+                if (c % 6u < 5u) {
+                    bpp_out[pc0 + c] = s_bpp[ps_][c];
+                    blk_out[pc0 + c] = s_blink[ps_][c];
+                }
+        }
+        if (lane == 0) s_links = n_links;
+    } else if (__ballot(sc_overflow) && lane == 0) s_sc_ovf = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (stopped || s_sc_ovf) {
+            P.err = 2;  // redo this pile in the int64 / HBM-resident kernel
+        } else {
+            P.origin_t = o_t;
+            P.origin_db = o_db;
+            P.n_links = s_links;
+        }
     }
 }
 
@@ -1006,7 +1032,7 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
                             void *ev_after_fast) {
     if (n_piles <= 0) return;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
+    hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)n_piles), dim3(128), 0, st, piles, coverage, max_size,
                        cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
                        cell_best_link);
     if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
