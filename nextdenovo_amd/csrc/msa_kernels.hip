@@ -438,8 +438,16 @@ constexpr int32_t kScoreGuard = 1 << 30;
 struct ColTab {
     uint32_t cstart[kColCells];
     uint32_t clen[kColCells];
-    uint32_t pp[kColEnts];
-    int32_t score[kColEnts];
+    uint2 ps[kColEnts];  // per link: x = pp tag, y = score (int32 bits) -- one 8-byte LDS access for both
+};
+
+// per-link operands of the column being scored, one 16-byte LDS access: before a link is scored
+// {ppp, resolve word, gain, count}; after it {score at the best predecessor (scmax), improving predecessor
+// score (impr), best predecessor score (nsmax), count}
+struct LinkAux {
+    uint32_t a, b_;
+    int32_t c;
+    uint32_t cnt;
 };
 
 // Two wavefronts per pile.  The scoring chain itself -- links read their predecessors' scores, the five symbol
@@ -454,8 +462,7 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
     const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp, const uint32_t *__restrict__ ent_cnt,
     uint32_t *__restrict__ cell_best_pp, uint32_t *__restrict__ cell_best_link) {
     __shared__ ColTab tab[3];                                   // columns p-1, p, p+1 (slot = column mod 3)
-    __shared__ uint32_t s_ppp[2][kColEnts], s_cnt[2][kColEnts], s_res[2][kColEnts];
-    __shared__ int32_t s_gain[2][kColEnts];
+    __shared__ __attribute__((aligned(16))) LinkAux s_aux[2][kColEnts];
     __shared__ uint32_t s_bpp[2][kColCells], s_blink[2][kColCells];
     __shared__ uint32_t s_meta[2][5][64];                       // width, cell0, e0, ecap, coverage of 2 x 64 columns
     __shared__ uint32_t s_colw[2], s_colc0[2], s_stop[2];       // per prepared column: width, first cell, "does not fit"
@@ -535,15 +542,15 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
             for (int j = 0; j < 4; j++) {
                 const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
                 if (e < ecap) {
-                    cur.pp[e] = pf_pp[j];
-                    s_ppp[slot][e] = pf_ppp[j];
-                    s_cnt[slot][e] = pf_cnt[j];
+                    cur.ps[e].x = pf_pp[j];
+                    s_aux[slot][e].a = pf_ppp[j];
+                    s_aux[slot][e].cnt = pf_cnt[j];
                 }
             }
             for (uint32_t e = (uint32_t)lane + 256u; e < ecap; e += 64) {
-                cur.pp[e] = epp[e0 + e];
-                s_ppp[slot][e] = eppp[e0 + e];
-                s_cnt[slot][e] = ecnt[e0 + e];
+                cur.ps[e].x = epp[e0 + e];
+                s_aux[slot][e].a = eppp[e0 + e];
+                s_aux[slot][e].cnt = ecnt[e0 + e];
             }
         }
         // the loads of column q+1 start now (and the next metadata block when q closes one)
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
         const uint32_t nent = cur.cstart[ncell - 1u] + cur.clen[ncell - 1u];
         n_links += nent;
         for (uint32_t e = (uint32_t)lane; e < nent; e += 64) {
-            const uint32_t mpp = cur.pp[e];
+            const uint32_t mpp = cur.ps[e].x;
             uint32_t res = 0;
             if (mpp != kTagHead) {
                 const bool same = (uint32_t)tag_tpos(mpp) == q;
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                 const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
                 res = ((uint32_t)same << 31) | (T.cstart[pc] << 12) | T.clen[pc];
             }
-            s_res[slot][e] = res;
-            s_gain[slot][e] = 10 * (int32_t)s_cnt[slot][e] - pen;
+            s_aux[slot][e].b_ = res;
+            s_aux[slot][e].c = 10 * (int32_t)s_aux[slot][e].cnt - pen;
         }
     };
 
@@ -620,15 +627,16 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                     const uint32_t n_step = (uint32_t)__builtin_amdgcn_readlane((int)step_n, (int)d);
                     // one link per lane (64 at a time): final score + the three numbers the cell's sequential state
                     // needs from it, parked in the LDS slots this link no longer needs (resolve word, gain, ppp)
-                    int32_t best = -10;           // state of cell b, lanes 0..4
-                    uint32_t bidx = 0xffffffffu;  // link that holds best_pp
+                    int32_t best = -10;                  // state of cell b, lanes 0..4
+                    uint32_t bpp = kTagHead, blink = 0;  // best_pp / best_link of cell b
                     for (uint32_t g0 = 0; g0 < n_step; g0 += 64) {
                         const uint32_t g_n = n_step - g0 < 64u ? n_step - g0 : 64u;
                         if ((uint32_t)lane < g_n) {
                             int32_t r_sc = 0, r_impr = kNoScore, r_nsmax = kNoScore, r_scmax = 0;
                             const uint32_t idx = est + g0 + (uint32_t)lane;
-                            const uint32_t mpp = cur.pp[idx], mppp = s_ppp[slot][idx], res = s_res[slot][idx];
-                            const int32_t gain = s_gain[slot][idx];
+                            const LinkAux ax = s_aux[slot][idx];
+                            const uint32_t mpp = cur.ps[idx].x, mppp = ax.a, res = ax.b_;
+                            const int32_t gain = ax.c;
                             if (mpp == kTagHead) {
                                 r_sc = gain;
                             } else {
@@ -640,8 +648,9 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
 #pragma unroll
                                     for (int u = 0; u < 4; u++) {
                                         const uint32_t k = k0 + (uint32_t)u < pn ? k0 + (uint32_t)u : pn - 1u;
-                                        key[u] = T.pp[ps + k];
-                                        nsv[u] = T.score[ps + k];
+                                        const uint2 t2 = T.ps[ps + k];
+                                        key[u] = t2.x;
+                                        nsv[u] = (int32_t)t2.y;
                                     }
 #pragma unroll
                                     for (int u = 0; u < 4; u++) {
@@ -659,10 +668,10 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                                     }
                                 }
                             }
-                            cur.score[idx] = r_sc;
-                            s_res[slot][idx] = (uint32_t)r_impr;
-                            s_gain[slot][idx] = r_nsmax;
-                            s_ppp[slot][idx] = (uint32_t)r_scmax;
+                            cur.ps[idx].y = (uint32_t)r_sc;
+                            LinkAux wr;
+                            wr.a = (uint32_t)r_scmax, wr.b_ = (uint32_t)r_impr, wr.c = r_nsmax, wr.cnt = ax.cnt;
+                            s_aux[slot][idx] = wr;
                             if (r_sc > kScoreGuard) sc_overflow = true;
                         }
                     }
@@ -674,38 +683,32 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                         int32_t via = kNoScore, via_next = kNoScore;
                         for (uint32_t m0 = 0; m0 < cn; m0 += 4) {  // 4 links per LDS round trip
                             int32_t a_sc[4], a_impr[4], a_ns[4], a_scm[4];
-                            uint32_t a_pb[4];
+                            uint32_t a_pp[4], a_cnt[4];
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
                                 const uint32_t idx = cst + (m0 + (uint32_t)u < cn ? m0 + (uint32_t)u : cn - 1u);
-                                a_sc[u] = cur.score[idx];
-                                a_impr[u] = (int32_t)s_res[slot][idx];
-                                a_ns[u] = s_gain[slot][idx];
-                                a_scm[u] = (int32_t)s_ppp[slot][idx];
-                                a_pb[u] = tag_base(cur.pp[idx]);
+                                const uint2 t2 = cur.ps[idx];
+                                const LinkAux ax = s_aux[slot][idx];
+                                a_pp[u] = t2.x, a_sc[u] = (int32_t)t2.y;
+                                a_scm[u] = (int32_t)ax.a, a_impr[u] = (int32_t)ax.b_, a_ns[u] = ax.c, a_cnt[u] = ax.cnt;
                             }
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
                                 if (m0 + (uint32_t)u < cn) {
-                                    const uint32_t rel = cst + m0 + (uint32_t)u - est;
+                                    const uint32_t pb = tag_base(a_pp[u]);
                                     if (a_impr[u] != kNoScore) via_next = a_impr[u];
-                                    if (a_ns[u] > via && (a_pb[u] == 4u || a_pb[u] == b)) {
+                                    if (a_ns[u] > via && (pb == 4u || pb == b)) {
                                         via = a_ns[u];
                                         best = a_scm[u];
-                                        bidx = rel;
+                                        bpp = a_pp[u], blink = a_cnt[u];
                                     }
-                                    if (a_sc[u] > best || (a_sc[u] == best && a_pb[u] != 4u)) {
+                                    if (a_sc[u] > best || (a_sc[u] == best && pb != 4u)) {
                                         via = via_next;
                                         best = a_sc[u];
-                                        bidx = rel;
+                                        bpp = a_pp[u], blink = a_cnt[u];
                                     }
                                 }
                             }
-                        }
-                        uint32_t bpp = kTagHead, blink = 0;
-                        if (bidx != 0xffffffffu) {
-                            bpp = cur.pp[est + bidx];
-                            blink = s_cnt[slot][est + bidx];
                         }
                         s_bpp[slot][d * 6u + b] = bpp;
                         s_blink[slot][d * 6u + b] = blink;
