@@ -202,8 +202,12 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     const int threads_each = std::max(1, host_threads / drivers);
     // sub-batch j always goes to context j mod drivers: a context then sees the same sub-batch sizes call after call
     // and its grow-only device buffers stop being re-allocated (a hipFree / hipMalloc stalls every context)
+    // (dealt in snake order -- 0..D-1, D-1..0, ... -- so that the context that got the longest chains of a round
+    // gets the lightest sub-batch of the next)
     auto drive = [&](int ctx) {
-        for (size_t sb = (size_t)ctx; sb < n_sub; sb += (size_t)drivers) {
+        for (size_t round = 0; round * (size_t)drivers < n_sub; round++) {
+            const size_t sb = round * (size_t)drivers + (size_t)((round & 1) ? drivers - 1 - ctx : ctx);
+            if (sb >= n_sub) continue;
             const size_t base = sub_start[sb];
             const size_t cnt = sub_start[sb + 1] - base;
             std::vector<PileEngine *> eng(cnt, nullptr);
