@@ -6,6 +6,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per device context (read when HIP initialises)
+
 from . import build as _build
 
 _LIB = None

@@ -171,7 +171,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return recs[pile_off[a] * 8 + 3] > recs[pile_off[b] * 8 + 3];
     });
-    int drivers = 6;
+    int drivers = 8;
     if (const char *e = getenv("NDGPU_CONTEXTS")) drivers = std::max(1, std::min(atoi(e), (int)DeviceAligner::kMaxContexts));
     // sub-batches: at most `sub` piles and at most `tag_budget` estimated alignment columns each, so that the
     // device buffers of a context (sized by the largest sub-batch it has seen) stay bounded whatever the seed lengths

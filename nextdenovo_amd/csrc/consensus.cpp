@@ -1450,6 +1450,10 @@ void run_engines(PileEngine **eng, size_t n, Backend &be, int threads) {
         g_prof.align_ns += t3 - t2;
         g_prof.advance_ns += t4 - t3;
         g_prof.jobs += jobs.size();
+        static const bool trace = getenv("NDGPU_TRACE") != nullptr;
+        if (trace)  // one line per round of a sub-batch: which phases ran, on how many piles / jobs, and when (ms)
+            fprintf(stderr, "[ndgpu trace] be %p piles %zu | main %zu [%.1f %.1f] extract %zu [%.1f] align %zu [%.1f] advance [%.1f]\n",
+                    (void *)&be, n, mains.size(), t0 * 1e-6, t1 * 1e-6, extracts.size(), t2 * 1e-6, jobs.size(), t3 * 1e-6, t4 * 1e-6);
     }
     be.end_batch();
 }

@@ -118,7 +118,9 @@ static std::mutex g_db_mu;
 
 struct DeviceAligner::State {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, lat_stream = nullptr;  // lat_stream: reserved compute units (see the constructor)
+    hipEvent_t ev_lat0 = nullptr, ev_lat1 = nullptr;
+    int reserved_cus = 0;
     std::mutex mu;
     DevBuf<uint32_t> d_pool, d_ops;
     DevBuf<AlnTask> d_tasks;
@@ -151,6 +153,9 @@ struct DeviceAligner::State {
 };
 
 DeviceAligner::DeviceAligner() : s_(new State) {
+    // every context drives its own stream; with the runtime's default of 4 hardware queues streams share a queue and
+    // a 0.5 s scoring launch of one context stalls the small kernels of another (must be set before HIP initialises)
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -163,7 +168,28 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     s_->device = env ? atoi(env) : 0;
     if (s_->device >= n) s_->device = s_->device % n;
     HIP_CHECK(hipSetDevice(s_->device));
-    HIP_CHECK(hipStreamCreateWithFlags(&s_->stream, hipStreamNonBlocking));
+    // Optional CU partition (NDGPU_RESERVED_CUS=n, default off): the first n compute units are kept for the scoring
+    // launches of the small sub-batches that hold the longest seeds (lat_stream), every other kernel of every context
+    // runs on the rest.  Measured on config 2: the long chains gain nothing (their 3.5 us per column is the chain
+    // itself, not interference: 691 ms alone vs 821 ms with 8 contexts resident), so it stays off.
+    {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, s_->device));
+        const int n_cu = prop.multiProcessorCount;
+        int reserve = 0;
+        if (const char *e = getenv("NDGPU_RESERVED_CUS")) reserve = atoi(e);
+        if (reserve < 0 || reserve * 2 > n_cu) reserve = 0;
+        s_->reserved_cus = reserve;
+        if (reserve) {
+            const uint32_t words = (uint32_t)((n_cu + 31) / 32);
+            std::vector<uint32_t> rest(words, 0), res(words, 0);
+            for (int c = 0; c < n_cu; c++) (c < reserve ? res : rest)[c >> 5] |= 1u << (c & 31);
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&s_->stream, words, rest.data()));
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&s_->lat_stream, words, res.data()));
+            HIP_CHECK(hipEventCreateWithFlags(&s_->ev_lat0, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&s_->ev_lat1, hipEventDisableTiming));
+        } else HIP_CHECK(hipStreamCreateWithFlags(&s_->stream, hipStreamNonBlocking));
+    }
     HIP_CHECK(hipEventCreate(&s_->ev0));
     HIP_CHECK(hipEventCreate(&s_->ev1));
     for (auto &e : s_->evs) HIP_CHECK(hipEventCreate(&e));
@@ -758,10 +784,22 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                        S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
                        S.d_ent_cnt.p, S.d_err.p, (int)blocks.size(), st);
     HIP_CHECK(hipEventRecord(S.evs[3], st));
+    // a sub-batch small enough for the reserved compute units (4 two-wave blocks each) scores there
+    const bool on_reserved = S.lat_stream && np <= (size_t)S.reserved_cus * 2;
+    hipStream_t sst = on_reserved ? S.lat_stream : st;
+    if (on_reserved) {
+        HIP_CHECK(hipEventRecord(S.ev_lat0, st));
+        HIP_CHECK(hipStreamWaitEvent(sst, S.ev_lat0, 0));
+        HIP_CHECK(hipEventRecord(S.evs[3], sst));
+    }
     launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p,
                            S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
-                           S.d_cell_blink.p, S.d_path.p, (int)np, st, S.evs[7]);
-    HIP_CHECK(hipEventRecord(S.evs[4], st));
+                           S.d_cell_blink.p, S.d_path.p, (int)np, sst, S.evs[7]);
+    HIP_CHECK(hipEventRecord(S.evs[4], sst));
+    if (on_reserved) {
+        HIP_CHECK(hipEventRecord(S.ev_lat1, sst));
+        HIP_CHECK(hipStreamWaitEvent(st, S.ev_lat1, 0));
+    }
     std::vector<PathItem> hpath(paths + 1);
     uint32_t herr[4] = {0, 0, 0, 0};
     HIP_CHECK(hipMemcpyAsync(piles.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
@@ -785,6 +823,19 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.stats.score_launches++;
     HIP_CHECK(hipEventElapsedTime(&ms, S.evs[7], S.evs[4]));
     S.stats.backtrack_ms += ms;
+    {
+        static const bool trace = getenv("NDGPU_TRACE") != nullptr;
+        if (trace) {
+            float t_links = 0, t_score = 0, t_back = 0;
+            (void)hipEventElapsedTime(&t_links, S.evs[2], S.evs[3]);
+            (void)hipEventElapsedTime(&t_score, S.evs[3], S.evs[7]);
+            (void)hipEventElapsedTime(&t_back, S.evs[7], S.evs[4]);
+            uint32_t longest = 0;
+            for (size_t p = 0; p < np; p++) longest = std::max(longest, piles[p].seed_len);
+            fprintf(stderr, "[ndgpu trace] run_main %zu piles longest %u | host prep %.1f align %.1f tags %.1f msa %.1f ms | K9 %.1f K10 %.1f backtrack %.1f ms\n",
+                    np, longest, (tp1 - tp0) * 1e-6, (tp2 - tp1) * 1e-6, (tp3 - tp2) * 1e-6, (tp4 - tp3) * 1e-6, t_links, t_score, t_back);
+        }
+    }
     for (size_t p = 0; p < np; p++) {
         const PileDev &P = piles[p];
         MainPile &M = *mp[p];

@@ -467,8 +467,12 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
     __shared__ uint32_t s_meta[2][5][64];                       // width, cell0, e0, ecap, coverage of 2 x 64 columns
     __shared__ uint32_t s_colw[2], s_colc0[2], s_stop[2];       // per prepared column: width, first cell, "does not fit"
     __shared__ uint32_t s_links, s_sc_ovf;
-    __builtin_amdgcn_s_setprio(3);  // latency-bound waves: issue priority over co-resident kernels
     PileDev &P = piles[blockIdx.x];
+    // latency-bound waves: issue priority over co-resident kernels, and the longest chains (they bound the whole
+    // call) over the shorter ones that share their SIMDs
+    if (P.seed_len >= 90000u) __builtin_amdgcn_s_setprio(3);
+    else if (P.seed_len >= 45000u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
     const int wave = (int)(threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t b = (uint32_t)lane;

@@ -609,6 +609,7 @@ ndgpu_ovl_index *ndgpu_ovl_index_create(const ndgpu_ovl_opt *opt, uint32_t n_rea
 	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return nullptr; }
 	ndgpu_ovl_index *h = nullptr;
 	try {
+		setenv("GPU_MAX_HW_QUEUES", "16", 0); // see csrc/device_runtime.hip: the process may go on to drive 8 consensus streams
 		int n_dev = 0;
 		if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
 			fprintf(stderr, "[ndgpu_overlap] no HIP device: the overlap engine has no CPU path\n");

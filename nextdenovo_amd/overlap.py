@@ -11,6 +11,8 @@ import os
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per device context (read when HIP initialises)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libndgpu_overlap.so")
 
