@@ -579,6 +579,18 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                 const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
                 res = ((uint32_t)same << 31) | (T.cstart[pc] << 12) | T.clen[pc];
             }
+            // which links of the predecessor cell continue this link (their pp equals this link's ppp): tags only, no
+            // scores, so the loader can do it; the scorer then touches matching predecessors only.  Cells with more
+            // than 32 links keep ppp and are scanned by the scorer.
+            const uint32_t pn = res & 0xfffu;
+            if (mpp != kTagHead && pn <= 32u) {
+                const ColTab &T = (res >> 31) ? cur : prv;
+                const uint32_t ps = (res >> 12) & 0x7ffffu, mppp = s_aux[slot][e].a;
+                uint32_t match = 0;
+                for (uint32_t k = 0; k < pn; k++)
+                    if (T.ps[ps + k].x == mppp) match |= 1u << k;
+                s_aux[slot][e].a = match;
+            }
             s_aux[slot][e].b_ = res;
             s_aux[slot][e].c = 10 * (int32_t)s_aux[slot][e].cnt - pen;
         }
@@ -646,6 +658,25 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                             } else {
                                 const ColTab &T = (res >> 31) ? cur : prv;
                                 const uint32_t ps = (res >> 12) & 0x7ffffu, pn = res & 0xfffu;
+                                if (pn <= 32u) {
+                                    // mppp holds the loader's match mask: visit the matching predecessors in order,
+                                    // two scores per LDS round trip
+                                    uint32_t m = mppp;
+                                    while (m) {
+                                        const uint32_t k1 = (uint32_t)__builtin_ctz(m);
+                                        m &= m - 1u;
+                                        const uint32_t k2 = m ? (uint32_t)__builtin_ctz(m) : k1;
+                                        const bool two = m != 0u;
+                                        m &= m - 1u;
+                                        const int32_t ns1 = (int32_t)T.ps[ps + k1].y, ns2 = (int32_t)T.ps[ps + k2].y;
+                                        if (ns1 + gain > r_sc) r_sc = ns1 + gain, r_impr = ns1;
+                                        if (ns1 > r_nsmax) r_nsmax = ns1, r_scmax = r_sc;
+                                        if (two) {
+                                            if (ns2 + gain > r_sc) r_sc = ns2 + gain, r_impr = ns2;
+                                            if (ns2 > r_nsmax) r_nsmax = ns2, r_scmax = r_sc;
+                                        }
+                                    }
+                                } else
                                 for (uint32_t k0 = 0; k0 < pn; k0 += 4) {  // 4 predecessor links per LDS round trip
                                     uint32_t key[4];
                                     int32_t nsv[4];
