@@ -288,6 +288,16 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
         }
     }
     const uint32_t n_chunks = (P.n_acc + 63u) / 64u;
+    // A register-resident read is scanned strictly in tag order (column by column, delta by delta), so its
+    // stream is read once, 16 bytes at a time, and the two previous tags of every tag are simply carried along.
+    uint4 w_tag[kRegChunks];
+    uint32_t w_i[kRegChunks], w_p1[kRegChunks], w_p2[kRegChunks];
+#pragma unroll
+    for (int ch = 0; ch < kRegChunks; ch++) {
+        w_tag[ch] = make_uint4(0, 0, 0, 0);
+        w_i[ch] = 0xffffffffu;  // no window yet
+        w_p1[ch] = w_p2[ch] = kTagHead;
+    }
 
     for (uint32_t t = B.col0; t < t_end; t++) {
         const uint32_t width = ms[t];
@@ -315,9 +325,25 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
 #pragma unroll
                     for (int ch = 0; ch < kRegChunks; ch++)
                         if ((uint32_t)ch == chn) {
-                            i0 = c_i0[ch];
-                            nx = c_nx[ch];
-                            tg = g_tg[ch];
+                            const uint32_t i = c_i0[ch] + d;
+                            if (i < c_nx[ch]) {
+                                const uint32_t *tp = g_tg[ch];
+                                if (w_i[ch] == 0xffffffffu) {  // first tag of this read inside the column block
+                                    if (i > 0) w_p1[ch] = tp[i - 1];
+                                    if (i > 1) w_p2[ch] = tp[i - 2];
+                                }
+                                if (w_i[ch] == 0xffffffffu || i - w_i[ch] >= 4u) {
+                                    w_tag[ch] = *reinterpret_cast<const uint4 *>(tp + i);
+                                    w_i[ch] = i;
+                                }
+                                const uint32_t k = i - w_i[ch];
+                                cur = k == 0 ? w_tag[ch].x : k == 1 ? w_tag[ch].y : k == 2 ? w_tag[ch].z : w_tag[ch].w;
+                                pp = w_p1[ch];
+                                ppp = w_p2[ch];
+                                w_p2[ch] = w_p1[ch];
+                                w_p1[ch] = cur;
+                                has = true;
+                            }
                         }
                 } else {
                     const uint32_t rank = chn * 64u + (uint32_t)lane;
@@ -332,7 +358,7 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                         }
                     }
                 }
-                {
+                if (chn >= (uint32_t)kRegChunks) {
                     const uint32_t i = i0 + d;
                     if (i < nx) {
                         has = true;
