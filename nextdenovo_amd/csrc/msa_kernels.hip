@@ -476,29 +476,29 @@ struct LinkAux {
     uint32_t cnt;
 };
 
-// Two wavefronts per pile.  The scoring chain itself -- links read their predecessors' scores, the five symbol
-// cells fold their links, the global pick -- is wave 0 ("scorer").  Everything that does not depend on scores
-// runs one column ahead on wave 1 ("loader"): fetch the column's cell / link tables from HBM (register prefetch
-// of the column after), commit them to LDS, resolve every link (where its predecessor cell is, its gain), and
-// store the finished results of the column before.  One barrier per column joins the two.
-__global__ __launch_bounds__(128) void score_fast_kernel(
+// Three wavefronts per pile, one barrier per column:
+//   loader (wave 1), one column ahead: the column's cell / link tables HBM -> registers (prefetch) -> LDS, every link
+//     resolved (predecessor cell range, gain, mask of the predecessor links it continues), finished results stored;
+//   scorer (wave 0), the dependent chain: one link per lane takes the best of its matching predecessors' scores;
+//   folder (wave 2), one column behind: the five symbol cells of every step fold their links with the reference's
+//     sequential tie-break rules (lib/nextcorrect.c:2164-2192) and the global pick (:2194-2199) is updated -- nothing a
+//     later score depends on, so it is off the chain.
+__global__ __launch_bounds__(192) void score_fast_kernel(
     PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
     const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ ent_base,
     const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_len,
     const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp, const uint32_t *__restrict__ ent_cnt,
     uint32_t *__restrict__ cell_best_pp, uint32_t *__restrict__ cell_best_link) {
-    __shared__ ColTab tab[3];                                   // columns p-1, p, p+1 (slot = column mod 3)
-    __shared__ __attribute__((aligned(16))) LinkAux s_aux[2][kColEnts];
-    __shared__ uint32_t s_bpp[2][kColCells], s_blink[2][kColCells];
+    __shared__ ColTab tab[3];                                          // columns p-1, p, p+1 (slot = column mod 3)
+    __shared__ __attribute__((aligned(16))) LinkAux s_aux[3][kColEnts];  // same slots
+    __shared__ uint32_t s_bpp[2][kColCells], s_blink[2][kColCells];      // slot = column & 1
     __shared__ uint32_t s_meta[2][5][64];                       // width, cell0, e0, ecap, coverage of 2 x 64 columns
-    __shared__ uint32_t s_colw[2], s_colc0[2], s_stop[2];       // per prepared column: width, first cell, "does not fit"
+    __shared__ uint32_t s_colw[3], s_colc0[3], s_stop[3];       // per prepared column: width, first cell, "does not fit"
     __shared__ uint32_t s_links, s_sc_ovf;
+    __shared__ int32_t s_ot;
+    __shared__ uint32_t s_odb;
     PileDev &P = piles[blockIdx.x];
-    // latency-bound waves: issue priority over co-resident kernels, and the longest chains (they bound the whole
-    // call) over the shorter ones that share their SIMDs
-    if (P.seed_len >= 90000u) __builtin_amdgcn_s_setprio(3);
-    else if (P.seed_len >= 45000u) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(3);  // latency-bound waves: issue priority over co-resident kernels
     const int wave = (int)(threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t b = (uint32_t)lane;
@@ -551,14 +551,15 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
     // prepare column q: tables -> LDS, links resolved.  Runs on the loader wave only.
     auto prepare = [&](uint32_t q) {
         const int ml = (int)(q & 63u);
-        const uint32_t mp = (q >> 6) & 1u, slot = q & 1u;
+        const uint32_t mp = (q >> 6) & 1u, slot = q % 3u;
         const uint32_t width = s_meta[mp][0][ml], cell0 = s_meta[mp][1][ml], e0 = s_meta[mp][2][ml], ecap = s_meta[mp][3][ml];
         const int32_t pen = factor * (int32_t)s_meta[mp][4][ml];
         const uint32_t ncell = width * 6u;
         const bool fits = ncell <= (uint32_t)kColCells && ecap <= (uint32_t)kColEnts;
         if (lane == 0) s_colw[slot] = width, s_colc0[slot] = cell0, s_stop[slot] = fits ? 0u : 1u;
-        ColTab &cur = tab[q % 3u];
+        ColTab &cur = tab[slot];
         const ColTab &prv = tab[(q + 2u) % 3u];
+        LinkAux *aux = s_aux[slot];
         if (fits) {
             if ((uint32_t)lane < ncell) {
                 cur.cstart[lane] = pf_cs - e0;
@@ -573,14 +574,14 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                 const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
                 if (e < ecap) {
                     cur.ps[e].x = pf_pp[j];
-                    s_aux[slot][e].a = pf_ppp[j];
-                    s_aux[slot][e].cnt = pf_cnt[j];
+                    aux[e].a = pf_ppp[j];
+                    aux[e].cnt = pf_cnt[j];
                 }
             }
             for (uint32_t e = (uint32_t)lane + 256u; e < ecap; e += 64) {
                 cur.ps[e].x = epp[e0 + e];
-                s_aux[slot][e].a = eppp[e0 + e];
-                s_aux[slot][e].cnt = ecnt[e0 + e];
+                aux[e].a = eppp[e0 + e];
+                aux[e].cnt = ecnt[e0 + e];
             }
         }
         // the loads of column q+1 start now (and the next metadata block when q closes one)
@@ -611,24 +612,33 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
             const uint32_t pn = res & 0xfffu;
             if (mpp != kTagHead && pn <= 32u) {
                 const ColTab &T = (res >> 31) ? cur : prv;
-                const uint32_t ps = (res >> 12) & 0x7ffffu, mppp = s_aux[slot][e].a;
+                const uint32_t ps = (res >> 12) & 0x7ffffu, mppp = aux[e].a;
                 uint32_t match = 0;
                 for (uint32_t k = 0; k < pn; k++)
                     if (T.ps[ps + k].x == mppp) match |= 1u << k;
-                s_aux[slot][e].a = match;
+                aux[e].a = match;
             }
-            s_aux[slot][e].b_ = res;
-            s_aux[slot][e].c = 10 * (int32_t)s_aux[slot][e].cnt - pen;
+            aux[e].b_ = res;
+            aux[e].c = 10 * (int32_t)aux[e].cnt - pen;
         }
     };
+    auto store_results = [&](uint32_t q) {  // best_pp / best_link of column q (folded one iteration ago)
+        const uint32_t pw = s_colw[q % 3u] * 6u, pc0 = s_colc0[q % 3u], sl = q & 1u;
+        for (uint32_t c = (uint32_t)lane; c < pw; c += 64)
+            if (c % 6u < 5u) {
+                bpp_out[pc0 + c] = s_bpp[sl][c];
+                blk_out[pc0 + c] = s_blink[sl][c];
+            }
+    };
 
-    // ---- scorer state
+    // ---- folder state
     int32_t gbest = -10;
     int32_t o_t = -1;
     uint32_t o_db = 0;
+    // ---- scorer state
     bool sc_overflow = false;
 
-    if (threadIdx.x == 0) s_links = 0, s_sc_ovf = 0;
+    if (threadIdx.x == 0) s_links = 0, s_sc_ovf = 0, s_ot = -1, s_odb = 0;
     if (wave == 1) {
         load_meta(0);
         __builtin_amdgcn_wave_barrier();
@@ -638,27 +648,34 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
     __syncthreads();
 
     bool stopped = false;
-    for (uint32_t p = 0; p < L; p++) {
-        const uint32_t slot = p & 1u;
-        if (s_stop[slot]) {  // column p does not fit the LDS tables: the pile goes to the HBM-resident kernel
+    // iteration p: loader prepares column p+1 and stores column p-2, scorer scores column p, folder folds column p-1
+    for (uint32_t p = 0; p <= L; p++) {
+        if (p < L && s_stop[p % 3u]) {  // column p does not fit the LDS tables: the pile goes to the HBM-resident kernel
             stopped = true;
             break;
         }
         if (wave == 1) {
-            // column p+1 first (its commit drains the memory counter: nothing younger than the prefetched loads may
-            // be in flight), then the results of column p-1, which the scorer finished before the barrier
-            const uint32_t ps_ = slot ^ 1u, pw = p > 0 ? s_colw[ps_] * 6u : 0u, pc0 = s_colc0[ps_];
+            // (column p+1 first: its commit drains the memory counter, nothing younger than the prefetched loads may be
+            // in flight; the stores come after)
+            const bool st_ok = p >= 2;
+            uint32_t sw = 0, sc0 = 0;
+            if (st_ok) sw = s_colw[(p - 2u) % 3u] * 6u, sc0 = s_colc0[(p - 2u) % 3u];  // slot p+1 = slot p-2: read before prepare
             if (p + 1 < L) prepare(p + 1);
-            for (uint32_t c = (uint32_t)lane; c < pw; c += 64)
-                if (c % 6u < 5u) {
-                    bpp_out[pc0 + c] = s_bpp[ps_][c];
-                    blk_out[pc0 + c] = s_blink[ps_][c];
-                }
-        } else {
-            const uint32_t width = s_colw[slot];
+            if (st_ok) {
+                const uint32_t sl = (p - 2u) & 1u;
+                for (uint32_t c = (uint32_t)lane; c < sw; c += 64)
+                    if (c % 6u < 5u) {
+                        bpp_out[sc0 + c] = s_bpp[sl][c];
+                        blk_out[sc0 + c] = s_blink[sl][c];
+                    }
+            }
+        } else if (wave == 0) {
+            const uint32_t slot = p % 3u;
+            const uint32_t width = p < L ? s_colw[slot] : 0u;
             if (width) {
-                ColTab &cur = tab[p % 3u];
+                ColTab &cur = tab[slot];
                 const ColTab &prv = tab[(p + 2u) % 3u];
+                LinkAux *aux = s_aux[slot];
                 uint32_t step_est = 0, step_n = 0;
                 if ((uint32_t)lane < width) {
                     step_est = cur.cstart[(uint32_t)lane * 6u];
@@ -668,15 +685,13 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                     const uint32_t est = (uint32_t)__builtin_amdgcn_readlane((int)step_est, (int)d);
                     const uint32_t n_step = (uint32_t)__builtin_amdgcn_readlane((int)step_n, (int)d);
                     // one link per lane (64 at a time): final score + the three numbers the cell's sequential state
-                    // needs from it, parked in the LDS slots this link no longer needs (resolve word, gain, ppp)
-                    int32_t best = -10;                  // state of cell b, lanes 0..4
-                    uint32_t bpp = kTagHead, blink = 0;  // best_pp / best_link of cell b
+                    // needs from it, left in the link's operand record for the folder
                     for (uint32_t g0 = 0; g0 < n_step; g0 += 64) {
                         const uint32_t g_n = n_step - g0 < 64u ? n_step - g0 : 64u;
                         if ((uint32_t)lane < g_n) {
                             int32_t r_sc = 0, r_impr = kNoScore, r_nsmax = kNoScore, r_scmax = 0;
                             const uint32_t idx = est + g0 + (uint32_t)lane;
-                            const LinkAux ax = s_aux[slot][idx];
+                            const LinkAux ax = aux[idx];
                             const uint32_t mpp = cur.ps[idx].x, mppp = ax.a, res = ax.b_;
                             const int32_t gain = ax.c;
                             if (mpp == kTagHead) {
@@ -732,13 +747,22 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                             cur.ps[idx].y = (uint32_t)r_sc;
                             LinkAux wr;
                             wr.a = (uint32_t)r_scmax, wr.b_ = (uint32_t)r_impr, wr.c = r_nsmax, wr.cnt = ax.cnt;
-                            s_aux[slot][idx] = wr;
+                            aux[idx] = wr;
                             if (r_sc > kScoreGuard) sc_overflow = true;
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    // the five symbol cells advance their sequential state in parallel, one lane per cell, each over
-                    // its own links in first-seen order (lib/nextcorrect.c:2164-2192)
+                    __builtin_amdgcn_wave_barrier();  // scores of (p,d) in LDS before (p,d+1) reads them (one wave, in order)
+                }
+            }
+        } else if (p > 0) {
+            const uint32_t q = p - 1u, slot = q % 3u, sl = q & 1u;
+            const uint32_t width = s_colw[slot];
+            if (width) {
+                const ColTab &cur = tab[slot];
+                const LinkAux *aux = s_aux[slot];
+                for (uint32_t d = 0; d < width; d++) {
+                    int32_t best = -10;                  // state of cell b, lanes 0..4
+                    uint32_t bpp = kTagHead, blink = 0;  // best_pp / best_link of cell b
                     if (lane < 5) {
                         const uint32_t cst = cur.cstart[d * 6u + b], cn = cur.clen[d * 6u + b];
                         int32_t via = kNoScore, via_next = kNoScore;
@@ -749,7 +773,7 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                             for (int u = 0; u < 4; u++) {
                                 const uint32_t idx = cst + (m0 + (uint32_t)u < cn ? m0 + (uint32_t)u : cn - 1u);
                                 const uint2 t2 = cur.ps[idx];
-                                const LinkAux ax = s_aux[slot][idx];
+                                const LinkAux ax = aux[idx];
                                 a_pp[u] = t2.x, a_sc[u] = (int32_t)t2.y;
                                 a_scm[u] = (int32_t)ax.a, a_impr[u] = (int32_t)ax.b_, a_ns[u] = ax.c, a_cnt[u] = ax.cnt;
                             }
@@ -771,14 +795,13 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                                 }
                             }
                         }
-                        s_bpp[slot][d * 6u + b] = bpp;
-                        s_blink[slot][d * 6u + b] = blink;
+                        s_bpp[sl][d * 6u + b] = bpp;
+                        s_blink[sl][d * 6u + b] = blink;
                     }
-                    __builtin_amdgcn_wave_barrier();  // scores of (p,d) visible before (p,d+1) reads them (one wave, LDS in order)
                     for (int bb = 0; bb < 5; bb++) {  // global pick in symbol order (lib/nextcorrect.c:2194-2199)
                         const int32_t v = __builtin_amdgcn_readlane(best, bb);
                         if (v >= gbest - 3000) {
-                            o_t = (int32_t)p;
+                            o_t = (int32_t)q;
                             o_db = (d << 3) | (uint32_t)bb;
                             if (v > gbest) gbest = v;
                         }
@@ -786,26 +809,23 @@ __global__ __launch_bounds__(128) void score_fast_kernel(
                 }
             }
         }
-        __syncthreads();  // the loader prepared column p+1 while the scorer worked on p; both meet here
+        __syncthreads();
     }
     if (wave == 1) {
-        if (!stopped && L > 0) {  // results of the last column
-            const uint32_t ps_ = (L - 1u) & 1u, pw = s_colw[ps_] * 6u, pc0 = s_colc0[ps_];
-            for (uint32_t c = (uint32_t)lane; c < pw; c += 64)
-                if (c % 6u < 5u) {
-                    bpp_out[pc0 + c] = s_bpp[ps_][c];
-                    blk_out[pc0 + c] = s_blink[ps_][c];
-                }
+        if (!stopped) {  // columns L-2 was stored in the last iteration (p = L); L-1 is left
+            if (L >= 1) store_results(L - 1u);
         }
         if (lane == 0) s_links = n_links;
-    } else if (__ballot(sc_overflow) && lane == 0) s_sc_ovf = 1;
+    } else if (wave == 0) {
+        if (__ballot(sc_overflow) && lane == 0) s_sc_ovf = 1;
+    } else if (lane == 0) s_ot = o_t, s_odb = o_db;
     __syncthreads();
     if (threadIdx.x == 0) {
         if (stopped || s_sc_ovf) {
             P.err = 2;  // redo this pile in the int64 / HBM-resident kernel
         } else {
-            P.origin_t = o_t;
-            P.origin_db = o_db;
+            P.origin_t = s_ot;
+            P.origin_db = s_odb;
             P.n_links = s_links;
         }
     }
@@ -1096,7 +1116,7 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
                             void *ev_after_fast) {
     if (n_piles <= 0) return;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)n_piles), dim3(128), 0, st, piles, coverage, max_size,
+    hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)n_piles), dim3(192), 0, st, piles, coverage, max_size,
                        cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
                        cell_best_link);
     if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
