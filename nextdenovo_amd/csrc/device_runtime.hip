@@ -152,6 +152,8 @@ struct DeviceAligner::State {
     int host_threads = 1;
 };
 
+static int g_ctx_creating = -1;  // index of the context under construction (guarded by g_ctx_mu)
+
 DeviceAligner::DeviceAligner() : s_(new State) {
     // every context drives its own stream; with the runtime's default of 4 hardware queues streams share a queue and
     // a 0.5 s scoring launch of one context stalls the small kernels of another (must be set before HIP initialises)
@@ -188,7 +190,14 @@ DeviceAligner::DeviceAligner() : s_(new State) {
             HIP_CHECK(hipExtStreamCreateWithCUMask(&s_->lat_stream, words, res.data()));
             HIP_CHECK(hipEventCreateWithFlags(&s_->ev_lat0, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&s_->ev_lat1, hipEventDisableTiming));
-        } else HIP_CHECK(hipStreamCreateWithFlags(&s_->stream, hipStreamNonBlocking));
+        } else {
+            // contexts 0..2 receive the sub-batches with the longest seeds (capi.cpp deals sub-batch j to context j
+            // in the first round): their kernels go first when the device is oversubscribed
+            int least = 0, greatest = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int prio = (g_ctx_creating >= 0 && g_ctx_creating < 3 && !getenv("NDGPU_NO_STREAM_PRIO")) ? greatest : least;
+            HIP_CHECK(hipStreamCreateWithPriority(&s_->stream, hipStreamNonBlocking, prio));
+        }
     }
     HIP_CHECK(hipEventCreate(&s_->ev0));
     HIP_CHECK(hipEventCreate(&s_->ev1));
@@ -209,7 +218,11 @@ DeviceAligner &DeviceAligner::context(int i) {
     // batches driven from different host threads overlap on the device.
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     i = i < 0 ? 0 : i % kMaxContexts;
-    if (!g_ctx[i]) g_ctx[i] = new DeviceAligner();
+    if (!g_ctx[i]) {
+        g_ctx_creating = i;
+        g_ctx[i] = new DeviceAligner();
+        g_ctx_creating = -1;
+    }
     return *g_ctx[i];
 }
 
