@@ -169,6 +169,8 @@ def main():
 
     read_type = {"ont": 1, "clr": 2, "hifi": 3}[args.profile]
     analytic = args.analytic_piles or args.no_overlap
+    if args.host_threads <= 0:  # the ranks of one node share its cores
+        args.host_threads = max(8, (os.cpu_count() or 8) // max(1, world))
     t_gen = time.perf_counter()
     genome = synth.make_genome(int(args.genome_size), seed=42 + 1000 * rank)
     rs = synth.simulate_reads(genome, args.depth, args.profile, seed=43 + 1000 * rank)
@@ -343,7 +345,7 @@ def main():
                                           "kept": int(ovl_state["sort_stats"]["kept"]), "blacklisted": int(ovl_state["last"][3]),
                                           "k": ovl_state["k"]}
                 out["overlap"]["pile_assembly_ms_per_step"] = ovl_state["asm_wall"] / args.steps * 1e3
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(rs, piles, read_type, args.cpu_sample)
             if ovl_state is not None:
                 out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(ovl_state["set"], ovl_state["preset"])
