@@ -199,7 +199,8 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     }
     const size_t n_sub = sub_start.size() - 1;
     drivers = (int)std::min<size_t>((size_t)drivers, n_sub);
-    const int threads_each = std::max(1, host_threads / drivers);
+    int threads_each = std::max(1, host_threads / drivers);  // (measured: more threads per context is slower)
+    if (const char *e = getenv("NDGPU_THREADS_PER_CONTEXT")) threads_each = std::max(1, atoi(e));
     // sub-batch j always goes to context j mod drivers: a context then sees the same sub-batch sizes call after call
     // and its grow-only device buffers stop being re-allocated (a hipFree / hipMalloc stalls every context)
     // (dealt in snake order -- 0..D-1, D-1..0, ... -- so that the context that got the longest chains of a round
