@@ -254,7 +254,6 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                                                           uint32_t *__restrict__ ent_ppp, uint32_t *__restrict__ ent_cnt,
                                                           uint32_t *__restrict__ err) {
     __shared__ uint32_t l_pp[6][kLinkCap], l_ppp[6][kLinkCap], l_cnt[6][kLinkCap];
-    __shared__ uint32_t l_n[8];
     const ColBlock B = blocks[blockIdx.x];
     const PileDev P = piles[B.pile];
     const int lane = (int)threadIdx.x;
@@ -314,8 +313,7 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
             }
         }
         for (uint32_t d = 0; d < width; d++) {
-            if (lane < 6) l_n[lane] = 0;
-            __syncthreads();
+            uint32_t n_cell[6] = {0, 0, 0, 0, 0, 0};  // links collected so far in the six cells of (t, d): the same in every lane
             for (uint32_t chn = 0; chn < n_chunks; chn++) {
                 bool has = false;
                 uint32_t cur = 0, pp = kTagHead, ppp = kTagHead;
@@ -368,10 +366,11 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                     }
                 }
                 const uint32_t b = cur & 7u;
+#pragma unroll
                 for (uint32_t bb = 0; bb < 6; bb++) {
                     const bool mine = has && b == bb;
                     if (!__ballot(mine)) continue;
-                    uint32_t n0 = l_n[bb];
+                    uint32_t n0 = n_cell[bb];
                     int found = -1;
                     if (mine) {
                         for (uint32_t j = 0; j < n0; j++)
@@ -400,15 +399,15 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                         n0 = n0 < (uint32_t)kLinkCap ? n0 + 1 : n0;
                         rem &= ~same;
                     }
-                    __syncthreads();
-                    if (lane == 0) l_n[bb] = n0;
-                    __syncthreads();
+                    n_cell[bb] = n0;
+                    __builtin_amdgcn_wave_barrier();  // one wavefront: LDS operations complete in program order
                 }
             }
             // flush the six cells of (t, d), links contiguous per cell in first-seen order
             const uint64_t cell0 = P.cell_off + cb[t] + (uint64_t)d * 6u;
+#pragma unroll
             for (uint32_t bb = 0; bb < 6; bb++) {
-                const uint32_t n = l_n[bb];
+                const uint32_t n = n_cell[bb];
                 if (lane == 0) {
                     cell_start[cell0 + bb] = (uint32_t)(e - P.ent_off);
                     cell_len[cell0 + bb] = n;
@@ -420,7 +419,7 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                 }
                 e += n;
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
