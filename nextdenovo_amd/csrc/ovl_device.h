@@ -79,13 +79,23 @@ void launch_seed_fill(const uint64_t *mx, const uint64_t *my, const uint32_t *m_
 void launch_gather_read_off(const uint64_t *a_off, const uint64_t *m_off, uint32_t n_reads, uint64_t n_m, uint64_t total,
                             uint64_t *r_aoff, hipStream_t s);
 void launch_local_off(const uint64_t *r_aoff_all, uint32_t r0, uint32_t n, uint64_t *r_aoff, hipStream_t s);
-void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, hipStream_t s);
+void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, uint64_t *segval,
+                          hipStream_t s);
+int incl_max_scan_u64(void *tmp, size_t &tmp_bytes, const uint64_t *in, uint64_t *out, size_t n, hipStream_t s);
+void launch_slab_flag(const uint64_t *skey, const uint64_t *segstart1, uint64_t n, const KeyLayout &L, const uint64_t *r_aoff,
+                      uint32_t *flag, hipStream_t s);
+void launch_slab_write(const uint64_t *skey, const uint32_t *flag, const uint64_t *rank, uint64_t n, const KeyLayout &L,
+                       uint64_t *slab_i0, uint32_t *slab_read, hipStream_t s);
+void launch_read_span(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ay, float *avg_span, hipStream_t s);
 void launch_sort_init(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *jobs, uint32_t *n_jobs, hipStream_t s);
 void launch_sort_pass(const void *jobs, uint32_t n_jobs, uint64_t *x, uint64_t *y, uint64_t *tx, uint64_t *ty, uint32_t *gs, void *next,
                       uint32_t *n_next, hipStream_t s);
-void launch_chain(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f,
-                  int32_t *p, int32_t *v, int32_t *t, uint64_t *u, uint32_t *n_end, unsigned long long *cells, hipStream_t s);
+void launch_chain(const uint64_t *slab_i0, const uint32_t *slab_read, uint32_t n_slabs, uint64_t n_anchors, const uint64_t *r_aoff,
+                  const float *read_avg_span, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f, int32_t *p, int32_t *v,
+                  unsigned long long *cells, hipStream_t s);
+void launch_chain_ends(const uint64_t *r_aoff, uint32_t n_reads, const OvlParams &P, const int32_t *f, const int32_t *p, const int32_t *v,
+                       int32_t *t, uint64_t *u, uint32_t *n_end, hipStream_t s);
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
                  const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
                  uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,

@@ -482,7 +482,19 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		DevBuf<uint64_t> ax(na);
 		DevBuf<uint32_t> tie(nb);
 		tie.zero(stream);
-		launch_anchor_decode(skey.p, na, L, ax.p, tie.p, stream);
+		DevBuf<uint64_t> segval(na), segstart1(na);
+		launch_anchor_decode(skey.p, na, L, ax.p, tie.p, segval.p, stream);
+		// K4 work units: runs of whole (strand, target) segments of a read, ~1024 anchors each
+		tb = 0;
+		incl_max_scan_u64(nullptr, tb, segval.p, segstart1.p, na, stream);
+		incl_max_scan_u64(temp(tb), tb, segval.p, segstart1.p, na, stream);
+		DevBuf<uint32_t> slab_flag(na + 1);
+		slab_flag.zero(stream);
+		launch_slab_flag(skey.p, segstart1.p, na, L, r_aoff.p, slab_flag.p, stream);
+		DevBuf<uint64_t> slab_rank(na + 1);
+		exscan(slab_flag.p, slab_rank.p, na + 1);
+		uint64_t n_slabs = 0;
+		slab_rank.download(&n_slabs, 1, stream, na);
 		std::vector<uint32_t> h_tie(nb);
 		tie.download(h_tie.data(), nb, stream);
 		HIP_OK(hipGetLastError());
@@ -518,7 +530,13 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 			HIP_OK(hipGetLastError());
 			st.exact_sort_ms += tm.stop();
 		}
-		ckey.release(); uy.release(); skey.release();
+		DevBuf<uint64_t> slab_i0(n_slabs + 1);
+		DevBuf<uint32_t> slab_read(n_slabs + 1);
+		launch_slab_write(skey.p, slab_flag.p, slab_rank.p, na, L, slab_i0.p, slab_read.p, stream);
+		DevBuf<float> avg_span(nb + 1);
+		launch_read_span(r_aoff.p, nb, ay.p, avg_span.p, stream);
+		HIP_OK(hipStreamSynchronize(stream));
+		ckey.release(); uy.release(); skey.release(); segval.release(); segstart1.release(); slab_flag.release(); slab_rank.release();
 
 		// K4
 		DevBuf<int32_t> f(na), p(na), v(na);
@@ -528,7 +546,8 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		cells.zero(stream);
 		t.zero(stream);
 		tm.start();
-		launch_chain(r_aoff.p, nb, ax.p, ay.p, P, f.p, p.p, v.p, t.p, u.p, n_end.p, cells.p, stream);
+		launch_chain(slab_i0.p, slab_read.p, (uint32_t)n_slabs, na, r_aoff.p, avg_span.p, ax.p, ay.p, P, f.p, p.p, v.p, cells.p, stream);
+		launch_chain_ends(r_aoff.p, nb, P, f.p, p.p, v.p, t.p, u.p, n_end.p, stream);
 		HIP_OK(hipGetLastError());
 		st.chain_ms += tm.stop();
 		unsigned long long h_cells = 0;

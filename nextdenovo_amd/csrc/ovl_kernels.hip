@@ -617,19 +617,91 @@ __device__ __forceinline__ uint64_t key_to_x(uint64_t key, const KeyLayout &L)
 	return rev << 63 | rid << 32 | rpos;
 }
 
+// segval[i] = i + 1 where a (query read, strand, target read) segment starts, else 0: an inclusive max-scan of it
+// gives every anchor the start of its segment.  Chains never leave a segment (chain.c:51: ri > a[st].x + max_dist).
 __global__ void anchor_decode_kernel(const uint64_t *__restrict__ skey, uint64_t n, KeyLayout L, uint64_t *__restrict__ ax,
-                                     uint32_t *__restrict__ tie_flag)
+                                     uint32_t *__restrict__ tie_flag, uint64_t *__restrict__ segval)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint64_t key = skey[i];
 	ax[i] = key_to_x(key, L);
-	if (i > 0 && skey[i - 1] == key) tie_flag[(uint32_t)(key >> L.read_shift)] = 1; // benign race: all writers store 1
+	const uint64_t prev = i > 0 ? skey[i - 1] : ~key;
+	if (i > 0 && prev == key) tie_flag[(uint32_t)(key >> L.read_shift)] = 1; // benign race: all writers store 1
+	segval[i] = (i == 0 || prev >> L.pos_bits != key >> L.pos_bits) ? i + 1 : 0;
 }
 
-void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, hipStream_t s)
+void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, uint64_t *segval,
+                          hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(anchor_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, n, L, ax, tie_flag);
+	if (n) hipLaunchKernelGGL(anchor_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, n, L, ax, tie_flag, segval);
+}
+
+int incl_max_scan_u64(void *tmp, size_t &tmp_bytes, const uint64_t *in, uint64_t *out, size_t n, hipStream_t s)
+{
+	RP_CHECK(rocprim::inclusive_scan(tmp, tmp_bytes, in, out, n, rocprim::maximum<uint64_t>(), s));
+	return 0;
+}
+
+// K4 work units ("slabs"): runs of whole segments of one read, cut where the running anchor count since the read's
+// start passes a multiple of kSlab.  flag[i] = 1 on the first anchor of a slab.
+constexpr uint32_t kSlabShift = 10;
+
+__global__ void slab_flag_kernel(const uint64_t *__restrict__ skey, const uint64_t *__restrict__ segstart1, uint64_t n, KeyLayout L,
+                                 const uint64_t *__restrict__ r_aoff, uint32_t *__restrict__ flag)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t rl = (uint32_t)(skey[i] >> L.read_shift);
+	const uint64_t a0 = r_aoff[rl];
+	uint32_t f = 0;
+	if (i == a0) f = 1;
+	else {
+		const uint64_t sid = (segstart1[i] - 1 - a0) >> kSlabShift, pid = (segstart1[i - 1] - 1 - a0) >> kSlabShift;
+		f = sid != pid;
+	}
+	flag[i] = f;
+}
+
+__global__ void slab_write_kernel(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ flag, const uint64_t *__restrict__ rank,
+                                  uint64_t n, KeyLayout L, uint64_t *__restrict__ slab_i0, uint32_t *__restrict__ slab_read)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || !flag[i]) return;
+	slab_i0[rank[i]] = i;
+	slab_read[rank[i]] = (uint32_t)(skey[i] >> L.read_shift);
+}
+
+void launch_slab_flag(const uint64_t *skey, const uint64_t *segstart1, uint64_t n, const KeyLayout &L, const uint64_t *r_aoff,
+                      uint32_t *flag, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(slab_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, segstart1, n, L, r_aoff, flag);
+}
+
+void launch_slab_write(const uint64_t *skey, const uint32_t *flag, const uint64_t *rank, uint64_t n, const KeyLayout &L,
+                       uint64_t *slab_i0, uint32_t *slab_read, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(slab_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, flag, rank, n, L, slab_i0,
+	                          slab_read);
+}
+
+// average seed span of every read, as the reference's float quotient (chain.c:41-42)
+__global__ void __launch_bounds__(64) read_span_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, const uint64_t *__restrict__ ay,
+                                                        float *__restrict__ avg_span)
+{
+	const uint32_t rd = blockIdx.x;
+	if (rd >= n_reads) return;
+	const uint64_t a0 = r_aoff[rd];
+	const int64_t n = (int64_t)(r_aoff[rd + 1] - a0);
+	unsigned long long sum = 0;
+	for (int64_t i = threadIdx.x; i < n; i += 64) sum += ay[a0 + i] >> 32 & 0xff;
+	for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
+	if (threadIdx.x == 0) avg_span[rd] = n ? (float)((double)(float)sum / (double)(float)n) : 0.f;
+}
+
+void launch_read_span(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ay, float *avg_span, hipStream_t s)
+{
+	if (n_reads) hipLaunchKernelGGL(read_span_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, ay, avg_span);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -873,40 +945,38 @@ __device__ __forceinline__ int wave_excl_max(int v, int lane)
 // The 64 most recent anchors (x, query position, f, p, v) ride in registers, lane l = anchor i-1-l, and are
 // shifted by one lane per iteration: the usual predecessor window never touches memory.  Older chunks of
 // a long window come from HBM (F/P/V are written there by lane 0 every iteration).
-__global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, const uint64_t *__restrict__ ax,
+__global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ slab_i0, const uint32_t *__restrict__ slab_read,
+                                                    uint32_t n_slabs, uint64_t n_anchors, const uint64_t *__restrict__ r_aoff,
+                                                    const float *__restrict__ read_avg_span, const uint64_t *__restrict__ ax,
                                                     const uint64_t *__restrict__ ay, OvlParams P, int32_t *__restrict__ f,
-                                                    int32_t *__restrict__ p, int32_t *__restrict__ v, int32_t *__restrict__ t,
-                                                    uint64_t *__restrict__ u, uint32_t *__restrict__ n_end,
+                                                    int32_t *__restrict__ p, int32_t *__restrict__ v,
                                                     unsigned long long *__restrict__ cells)
 {
 	__shared__ uint16_t ring[kRing];
-	const uint32_t rd = blockIdx.x;
-	if (rd >= n_reads) return;
+	const uint32_t sb = blockIdx.x;
+	if (sb >= n_slabs) return;
 	const int lane = threadIdx.x;
+	// one slab = whole segments [i0, n) of one read (indices relative to the read: p[] holds read-relative indices)
+	const uint32_t rd = slab_read[sb];
 	const uint64_t a0 = r_aoff[rd];
-	const int32_t n = (int32_t)(r_aoff[rd + 1] - a0);
-	if (n == 0) { if (lane == 0) n_end[rd] = 0; return; }
+	const int32_t i0 = (int32_t)(slab_i0[sb] - a0);
+	const int32_t n = (int32_t)((sb + 1 < n_slabs && slab_read[sb + 1] == rd ? slab_i0[sb + 1] : r_aoff[rd + 1]) - a0);
+	(void)n_anchors;
 	const uint64_t *X = ax + a0, *Y = ay + a0;
-	int32_t *F = f + a0, *Pp = p + a0, *V = v + a0, *T = t + a0;
-	uint64_t *U = u + a0;
-
-	// average seed span of the read, as a float quotient
-	unsigned long long sum = 0;
-	for (int32_t i = lane; i < n; i += 64) sum += Y[i] >> 32 & 0xff;
-	for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
-	const float avg_span = (float)((double)(float)sum / (double)(float)n);
+	int32_t *F = f + a0, *Pp = p + a0, *V = v + a0;
+	const float avg_span = read_avg_span[rd];
 	const double lin = .01;
 	const uint64_t max_dist = (uint64_t)P.max_gap;
 
 	uint64_t wx = 0;                       // register window
 	int32_t wq = 0, wf = 0, wp = -1, wv = 0;
-	uint64_t cx = lane < n ? X[lane] : 0, cy = lane < n ? Y[lane] : 0;             // anchors of the current block of 64
-	uint64_t nx = 64 + lane < n ? X[64 + lane] : 0, ny = 64 + lane < n ? Y[64 + lane] : 0; // next block, prefetched
+	uint64_t cx = i0 + lane < n ? X[i0 + lane] : 0, cy = i0 + lane < n ? Y[i0 + lane] : 0;  // anchors of the current block of 64
+	uint64_t nx = i0 + 64 + lane < n ? X[i0 + 64 + lane] : 0, ny = i0 + 64 + lane < n ? Y[i0 + 64 + lane] : 0; // next block
 	unsigned long long my_cells = 0;
 
-	for (int32_t i = 0; i < n; ++i) {
-		const int bl = i & 63;
-		if (bl == 0 && i) {
+	for (int32_t i = i0; i < n; ++i) {
+		const int bl = (i - i0) & 63;
+		if (bl == 0 && i != i0) {
 			cx = nx, cy = ny;
 			const int32_t q = i + 64 + lane;
 			nx = q < n ? X[q] : 0, ny = q < n ? Y[q] : 0;
@@ -915,7 +985,7 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 		const int32_t qi = (int32_t)yi, span = (int32_t)(yi >> 32 & 0xff);
 		int32_t best = span, skipped = 0, best_j = -1;
 		bool stop = false, fenced = false;
-		for (int32_t base = i - 1; base >= 0 && !stop; base -= 64) {
+		for (int32_t base = i - 1; base >= i0 && !stop; base -= 64) {
 			const int32_t j = base - lane;
 			uint64_t xj;
 			int32_t qj, fj, pj;
@@ -923,9 +993,9 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 			else {
 				if (!fenced) { __threadfence_block(); fenced = true; }
 				xj = 0, qj = 0, fj = 0, pj = -1;
-				if (j >= 0) xj = X[j], qj = (int32_t)Y[j], fj = F[j], pj = Pp[j];
+				if (j >= i0) xj = X[j], qj = (int32_t)Y[j], fj = F[j], pj = Pp[j];
 			}
-			const bool in_win = j >= 0 && i - j <= P.max_iter && ri <= xj + max_dist;
+			const bool in_win = j >= i0 && i - j <= P.max_iter && ri <= xj + max_dist;
 			bool act = false;
 			int32_t sc = INT32_MIN;
 			if (in_win) {
@@ -1003,9 +1073,24 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 	for (int d = 32; d; d >>= 1) my_cells += __shfl_xor(my_cells, d, 64);
 	if (lane == 0 && cells) atomicAdd(cells, my_cells);
 
-	// chain ends (chain.c:87-104): anchors nobody points to whose peak reaches min_sc; t[] arrives zeroed
-	__threadfence_block();
-	__builtin_amdgcn_wave_barrier();
+}
+
+// chain ends (chain.c:87-104), one wavefront per read after all its slabs: anchors nobody points to whose peak
+// reaches min_sc, with the peak walk; t[] arrives zeroed and leaves zeroed for the backtrack of K5
+__global__ void __launch_bounds__(64) chain_ends_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, OvlParams P,
+                                                         const int32_t *__restrict__ f, const int32_t *__restrict__ p,
+                                                         const int32_t *__restrict__ v, int32_t *__restrict__ t, uint64_t *__restrict__ u,
+                                                         uint32_t *__restrict__ n_end)
+{
+	const uint32_t rd = blockIdx.x;
+	if (rd >= n_reads) return;
+	const int lane = threadIdx.x;
+	const uint64_t a0 = r_aoff[rd];
+	const int32_t n = (int32_t)(r_aoff[rd + 1] - a0);
+	if (n == 0) { if (lane == 0) n_end[rd] = 0; return; }
+	const int32_t *F = f + a0, *Pp = p + a0, *V = v + a0;
+	int32_t *T = t + a0;
+	uint64_t *U = u + a0;
 	for (int32_t i = lane; i < n; i += 64) { const int32_t pi = Pp[i]; if (pi >= 0) T[pi] = 1; }
 	__threadfence_block();
 	__builtin_amdgcn_wave_barrier();
@@ -1026,14 +1111,22 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 		n_u += (uint32_t)__popcll(m);
 	}
 	__builtin_amdgcn_wave_barrier();
-	for (int32_t i = lane; i < n; i += 64) T[i] = 0; // the backtrack of K5 starts from a clean t[]
+	for (int32_t i = lane; i < n; i += 64) T[i] = 0;
 	if (lane == 0) n_end[rd] = n_u;
 }
 
-void launch_chain(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f,
-                  int32_t *p, int32_t *v, int32_t *t, uint64_t *u, uint32_t *n_end, unsigned long long *cells, hipStream_t s)
+void launch_chain(const uint64_t *slab_i0, const uint32_t *slab_read, uint32_t n_slabs, uint64_t n_anchors, const uint64_t *r_aoff,
+                  const float *read_avg_span, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f, int32_t *p, int32_t *v,
+                  unsigned long long *cells, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(chain_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, ax, ay, P, f, p, v, t, u, n_end, cells);
+	if (n_slabs) hipLaunchKernelGGL(chain_kernel, dim3(n_slabs), dim3(64), 0, s, slab_i0, slab_read, n_slabs, n_anchors, r_aoff, read_avg_span,
+	                                ax, ay, P, f, p, v, cells);
+}
+
+void launch_chain_ends(const uint64_t *r_aoff, uint32_t n_reads, const OvlParams &P, const int32_t *f, const int32_t *p, const int32_t *v,
+                       int32_t *t, uint64_t *u, uint32_t *n_end, hipStream_t s)
+{
+	if (n_reads) hipLaunchKernelGGL(chain_ends_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, P, f, p, v, t, u, n_end);
 }
 
 // ------------------------------------------------------------------------------------------------
