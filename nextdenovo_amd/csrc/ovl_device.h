@@ -27,7 +27,11 @@ struct IndexDev {
 	const uint32_t *len;     // target read lengths
 	const uint32_t *id;      // numeric read names
 	const uint64_t *namekey; // order-preserving key of the decimal name string (strcmp order)
+	const uint32_t *bucket;  // 2^kBucketBits + 1 entries: first key index of every top-bits bucket (narrows the binary search)
+	uint32_t bucket_shift;   // key >> bucket_shift = bucket
 };
+
+constexpr int kBucketBits = 22;
 
 // query side (whole query set of one ndgpu_ovl_map call)
 struct QueryDev {
@@ -62,6 +66,7 @@ void launch_sketch_tiles(bool fill, bool hpc, const uint32_t *words, const uint6
 int sketch_tile_symbols();
 void launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint32_t n, uint64_t *dst, hipStream_t s);
 void launch_shift_keys(const uint64_t *x, uint64_t *key, uint64_t n, hipStream_t s);
+void launch_build_buckets(const uint64_t *ukey, uint64_t n_keys, uint32_t shift, uint32_t *bucket, hipStream_t s);
 
 int sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout,
                    size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s);

@@ -195,7 +195,8 @@ struct Engine {
 	ReadSetDev T;
 	uint64_t n_min = 0, n_keys = 0;
 	DevBuf<uint64_t> ukey, ustart, pos;
-	DevBuf<uint32_t> ucnt;
+	DevBuf<uint32_t> ucnt, bucket;
+	uint32_t bucket_shift = 0;
 	ndgpu_ovl_stats st{};
 	// debug view of the last map batch
 	std::vector<uint64_t> dbg_aoff;
@@ -206,7 +207,7 @@ struct Engine {
 	DevBuf<uint8_t> tmp;
 	void *temp(size_t bytes) { if (tmp.n < bytes) tmp.alloc(bytes + bytes / 4); return tmp.p; }
 
-	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p}; }
+	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p, bucket.p, bucket_shift}; }
 
 	// tiles of `tile` symbols over reads whose symbol counts are n_sym[]; first[r] = first tile of read r
 	// (of the next non-empty read for an empty one), first[n] = number of tiles
@@ -356,6 +357,11 @@ struct Engine {
 		tb = 0;
 		exscan_u32_to_u64(nullptr, tb, ucnt.p, ustart.p, n_keys + 1, stream);
 		exscan_u32_to_u64(temp(tb), tb, ucnt.p, ustart.p, n_keys + 1, stream);
+		// top-bits table over the distinct keys (hash values have 2k bits)
+		const unsigned key_bits = 2u * (unsigned)P.k;
+		bucket_shift = key_bits > (unsigned)kBucketBits ? key_bits - (unsigned)kBucketBits : 0;
+		bucket.alloc(((size_t)1 << kBucketBits) + 2);
+		launch_build_buckets(ukey.p, n_keys, bucket_shift, bucket.p, stream);
 		HIP_OK(hipGetLastError());
 		st.index_sort_ms += tm.stop();
 	}

@@ -471,9 +471,29 @@ int exscan_u32_to_u64(void *tmp, size_t &tmp_bytes, const uint32_t *in, uint64_t
 // ------------------------------------------------------------------------------------------------
 // K3: seeds
 
+// bucket[h] = number of keys below h << shift (one binary search per table entry, at index build)
+__global__ void build_buckets_kernel(const uint64_t *__restrict__ ukey, uint64_t n_keys, uint32_t shift, uint32_t *__restrict__ bucket)
+{
+	const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+	if (h > (1u << kBucketBits)) return;
+	const uint64_t want = (uint64_t)h << shift;
+	uint64_t lo = 0, hi = n_keys;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (ukey[mid] < want) lo = mid + 1; else hi = mid;
+	}
+	bucket[h] = (uint32_t)lo;
+}
+
+void launch_build_buckets(const uint64_t *ukey, uint64_t n_keys, uint32_t shift, uint32_t *bucket, hipStream_t s)
+{
+	hipLaunchKernelGGL(build_buckets_kernel, dim3(((1u << kBucketBits) + 256) / 256), dim3(256), 0, s, ukey, n_keys, shift, bucket);
+}
+
 __device__ __forceinline__ bool index_lookup(const IndexDev &ix, uint64_t minier, uint32_t &start, uint32_t &cnt)
 {
-	uint64_t lo = 0, hi = ix.n_keys;
+	const uint32_t h = (uint32_t)(minier >> ix.bucket_shift);
+	uint64_t lo = ix.bucket[h], hi = ix.bucket[h + 1];
 	while (lo < hi) {
 		uint64_t mid = (lo + hi) >> 1;
 		if (ix.ukey[mid] < minier) lo = mid + 1; else hi = mid;
