@@ -119,3 +119,35 @@ def test_whole_stage_on_device_from_2bit_to_cns_fasta(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(out, "rb").read() == _golden("cns.default.fasta", gz=True)
     assert open(out + ".idx", "rb").read() == _golden("cns.default.fasta.idx", gz=True)
+
+
+@pytest.mark.skipif(not all(os.path.exists(os.path.join(O.REFDIR, n)) for n in ("minimap2-nd", "ovl_sort", "seq_dump")),
+                    reason="oracle/_ref not built")
+def test_workload_scale_chain_matches_reference_binaries(tmp_path):
+    """A 0.8 Mb / 45x ONT set (2.7k reads, 36 Mb: the read-length mix of config 2): the compiled reference's
+    minimap2-nd --step 1 and ovl_sort (many threads) against the device's, file for file."""
+    from nextdenovo_amd import minimap2_nd, ovl_sort, synth
+    g = synth.make_genome(800000, seed=91)
+    rs = synth.simulate_reads(g, 45, "ont", seed=92)
+    wd = str(tmp_path)
+    seed, part = M.dump_reads(wd, [synth.codes_to_ascii(s) for s in rs.seqs], seed_cutoff=12000)
+    idx = os.path.join(wd, "db", ".input.seed.001.idx")
+    jobs = [(seed, part, True, "0"), (seed, seed, False, "1")]
+    ref_files, my_files = [], []
+    for t, q, dual, tag in jobs:
+        r = os.path.join(wd, "ref.%s.ovl" % tag)
+        M.ref_step1(t, q, r, "ava-ont", dual, threads=32)
+        m = os.path.join(wd, "mine.%s.ovl" % tag)
+        argv = ["--step", "1"] + (["--dual=yes"] if dual else []) + ["-t", "8", "-x", "ava-ont", t, q, "-o", m]
+        assert minimap2_nd.run(argv) == 0
+        assert os.path.getsize(r) > 100000 and open(m, "rb").read() == open(r, "rb").read()
+        ref_files.append(r)
+        my_files.append(m)
+    want, want_bl = O.ref_sort(wd, idx, ref_files, k=40, threads=8)
+    fofn = os.path.join(wd, "mine.fofn")
+    with open(fofn, "w") as f:
+        f.write("\n".join(my_files) + "\n")
+    so = os.path.join(wd, "mine.sorted.ovl")
+    assert ovl_sort.run(["-m", "2g", "-t", "8", "-k", "40", "-i", idx, "-o", so, fofn]) == 0
+    assert len(want) > 500000 and open(so, "rb").read() == want
+    assert open(so + ".bl").read() == want_bl
