@@ -51,8 +51,9 @@ typedef struct ndgpu_ovl_rec {
 	uint32_t rev, qname, qs, qe, tname, ts, te, match;
 } ndgpu_ovl_rec;
 
-/* mm_mapopt_init + mm_idxopt_init + mm_set_opt(preset) + `--step 1`; preset = "ava-ont" | "ava-pb".
- * Returns 0, or -1 for an unknown / unsupported preset (ava-hifi's k=51 sketch is not built yet). */
+/* mm_mapopt_init + mm_idxopt_init + mm_set_opt(preset) + `--step 1`; preset = "ava-ont" | "ava-pb" | "ava-hifi"
+ * (options.c:84-111; ava-hifi = k 51, w 51, HPC: the two-word k-mer sketch mm_sketch_nextdenovo_longkmer, sketch.c:283-356).
+ * Returns 0, or -1 for an unknown preset.  k may be 1..28, or odd in 33..63. */
 int ndgpu_ovl_opt_preset(const char *preset, ndgpu_ovl_opt *opt);
 
 /* Sketch the target reads on the device and build the minimizer index in HBM. */

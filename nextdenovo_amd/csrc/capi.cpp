@@ -201,6 +201,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     drivers = (int)std::min<size_t>((size_t)drivers, n_sub);
     int threads_each = std::max(1, host_threads / drivers);  // (measured: more threads per context is slower)
     if (const char *e = getenv("NDGPU_THREADS_PER_CONTEXT")) threads_each = std::max(1, atoi(e));
+    CoreGovernor::set_total(getenv("NDGPU_NO_BORROW") ? 0 : host_threads);
     // sub-batch j always goes to context j mod drivers: a context then sees the same sub-batch sizes call after call
     // and its grow-only device buffers stop being re-allocated (a hipFree / hipMalloc stalls every context)
     // (dealt in snake order -- 0..D-1, D-1..0, ... -- so that the context that got the longest chains of a round
@@ -212,7 +213,8 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
             const size_t base = sub_start[sb];
             const size_t cnt = sub_start[sb + 1] - base;
             std::vector<PileEngine *> eng(cnt, nullptr);
-            parallel_for(cnt, threads_each, [&](size_t k) {
+            CoreLease *build_lease = new CoreLease(threads_each);
+            parallel_for(cnt, build_lease->n, [&](size_t k) {
                 const uint32_t pid = order[base + k];
                 const uint64_t r0 = pile_off[pid], r1 = pile_off[pid + 1];
                 const size_t n = (size_t)(r1 - r0);
@@ -236,6 +238,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                                                     min_error_corrected_ratio, split, fast, read_type),
                                         read_type == 3 ? seed.c_str() : nullptr);
             });
+            delete build_lease;
             {
                 HipBackend be(ctx, threads_each);
                 run_engines(eng.data(), cnt, be, threads_each);

@@ -1410,6 +1410,21 @@ void parallel_for(size_t n, int threads, F f) {
 
 HostProf g_prof;
 
+static std::atomic<int> g_cores_total(0), g_cores_used(0);
+void CoreGovernor::set_total(int total) { g_cores_total.store(total < 0 ? 0 : total); }
+int CoreGovernor::acquire(int base) {
+    if (base < 1) base = 1;
+    const int total = g_cores_total.load();
+    int used = g_cores_used.load();
+    for (;;) {
+        int grant = total - used;
+        if (grant < base) grant = base;
+        if (grant > 4 * base) grant = 4 * base;  // thread start-up and allocator contention eat the gain beyond this
+        if (g_cores_used.compare_exchange_weak(used, used + grant)) return grant;
+    }
+}
+void CoreGovernor::release(int granted) { g_cores_used.fetch_sub(granted); }
+
 static inline uint64_t now_ns() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
                std::chrono::steady_clock::now().time_since_epoch())
@@ -1443,7 +1458,10 @@ void run_engines(PileEngine **eng, size_t n, Backend &be, int threads) {
         uint64_t t2 = now_ns();
         if (!jobs.empty()) be.run_align(jobs.data(), jobs.size());
         uint64_t t3 = now_ns();
-        parallel_for(live.size(), threads, [&](size_t k) { eng[live[k]]->advance(); });
+        {
+            CoreLease lease(threads);
+            parallel_for(live.size(), lease.n, [&](size_t k) { eng[live[k]]->advance(); });
+        }
         uint64_t t4 = now_ns();
         g_prof.main_ns += t1 - t0;
         g_prof.extract_ns += t2 - t1;

@@ -308,11 +308,13 @@ void DeviceAligner::align_batch(AlnJob **jobs, size_t n) {
 
 namespace {
 template <typename F>
-void par_ranges(size_t n, int threads, F f) {  // f(begin, end) over contiguous ranges
-    if (threads <= 1 || n < 4096) {
+void par_ranges(size_t n, int base_threads, F f) {  // f(begin, end) over contiguous ranges
+    if (base_threads <= 1 || n < 4096) {
         f((size_t)0, n);
         return;
     }
+    CoreLease lease(base_threads);
+    const int threads = lease.n;
     const size_t nt = std::min<size_t>((size_t)threads, (n + 2047) / 2048);
     std::vector<std::thread> th;
     for (size_t t = 0; t < nt; t++) {
@@ -916,18 +918,32 @@ void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
         }
         cap = (size_t)used + ((size_t)16 << 20);  // pool too small: rerun with the exact size
     }
-    size_t k = 0;
-    for (size_t i = 0; i < n; i++)
-        for (RegionReq &r : ep[i]->regions) {
-            const RegionDev &g = regs[k++];
-            r.n_large = g.n_large;
-            r.cands.resize(g.n_ok);
-            r.cand_rank.resize(g.n_ok);
-            for (uint32_t c = 0; c < g.n_ok; c++) {
-                r.cands[c].assign(hstr.data() + g.cand_off[c], g.cand_len[c]);
-                r.cand_rank[c] = g.cand_rank[c];
+    std::vector<size_t> first(n + 1, 0);
+    for (size_t i = 0; i < n; i++) first[i + 1] = first[i] + ep[i]->regions.size();
+    auto fill = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            size_t k = first[i];
+            for (RegionReq &r : ep[i]->regions) {
+                const RegionDev &g = regs[k++];
+                r.n_large = g.n_large;
+                r.cands.resize(g.n_ok);
+                r.cand_rank.resize(g.n_ok);
+                for (uint32_t c = 0; c < g.n_ok; c++) {
+                    r.cands[c].assign(hstr.data() + g.cand_off[c], g.cand_len[c]);
+                    r.cand_rank[c] = g.cand_rank[c];
+                }
             }
         }
+    };
+    if (n < 32 || S.host_threads <= 1) {
+        fill(0, n);
+    } else {
+        CoreLease lease(S.host_threads);
+        const size_t nt = std::min<size_t>((size_t)lease.n, n / 8);
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++) th.emplace_back(fill, n * t / nt, n * (t + 1) / nt);
+        for (auto &x : th) x.join();
+    }
 }
 
 }  // namespace ndgpu

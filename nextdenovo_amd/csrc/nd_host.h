@@ -153,6 +153,22 @@ struct HostProf {
 };
 extern HostProf g_prof;
 
+// Host cores are shared by the driver threads of all device contexts: each host section is guaranteed its base share and
+// borrows the cores that no other section is using at that moment (the tail of a call, when few contexts are still
+// busy, would otherwise run on an eighth of the machine).  total = 0 switches borrowing off.
+struct CoreGovernor {
+    static void set_total(int total);
+    static int acquire(int base);    // threads granted (>= base)
+    static void release(int granted);
+};
+struct CoreLease {
+    int n;
+    explicit CoreLease(int base) : n(CoreGovernor::acquire(base)) {}
+    ~CoreLease() { CoreGovernor::release(n); }
+    CoreLease(const CoreLease &) = delete;
+    CoreLease &operator=(const CoreLease &) = delete;
+};
+
 // Drives a set of engines to completion over one backend (host phases on `threads`).
 void run_engines(PileEngine **eng, size_t n, Backend &be, int threads);
 

@@ -335,7 +335,7 @@ struct Engine {
 		sort_pairs_u64(nullptr, tb, S.y.p, y2.p, key.p, key2.p, n_min, 0, ybits, stream);
 		if (n_min) sort_pairs_u64(temp(tb), tb, S.y.p, y2.p, key.p, key2.p, n_min, 0, ybits, stream);
 		pos.alloc(n_min + 1);
-		const unsigned kbits = 2u * (unsigned)P.k;
+		const unsigned kbits = std::min(56u, 2u * (unsigned)P.k); // x >> 8: the long k-mer hash of ava-hifi fills all 56 bits
 		tb = 0;
 		sort_pairs_u64(nullptr, tb, key2.p, key.p, y2.p, pos.p, n_min, 0, kbits, stream);
 		if (n_min) sort_pairs_u64(temp(tb), tb, key2.p, key.p, y2.p, pos.p, n_min, 0, kbits, stream);
@@ -358,7 +358,7 @@ struct Engine {
 		exscan_u32_to_u64(nullptr, tb, ucnt.p, ustart.p, n_keys + 1, stream);
 		exscan_u32_to_u64(temp(tb), tb, ucnt.p, ustart.p, n_keys + 1, stream);
 		// top-bits table over the distinct keys (hash values have 2k bits)
-		const unsigned key_bits = 2u * (unsigned)P.k;
+		const unsigned key_bits = std::min(56u, 2u * (unsigned)P.k);
 		bucket_shift = key_bits > (unsigned)kBucketBits ? key_bits - (unsigned)kBucketBits : 0;
 		bucket.alloc(((size_t)1 << kBucketBits) + 2);
 		launch_build_buckets(ukey.p, n_keys, bucket_shift, bucket.p, stream);
@@ -396,7 +396,8 @@ static OvlParams to_params(const ndgpu_ovl_opt &o)
 
 static const char *check_opt(const ndgpu_ovl_opt &o)
 {
-	if (o.k < 1 || o.k > 28) return "k must be in 1..28 (the k > 28 sketch of ava-hifi is not built)";
+	if (o.k < 1 || (o.k > 28 && (o.k < 33 || o.k > 63 || !(o.k & 1))))
+		return "k must be in 1..28, or odd in 33..63 (the two-word k-mer sketch of ava-hifi)";
 	if (o.w < 1 || o.w > 64) return "w must be in 1..64";
 	if (o.min_cnt < 2) return "min_cnt must be >= 2";
 	if (o.max_chain_iter < 1 || o.max_chain_iter >= 8192) return "max_chain_iter must be in 1..8191";
@@ -621,8 +622,11 @@ int ndgpu_ovl_opt_preset(const char *preset, ndgpu_ovl_opt *o)
 	} else if (strcmp(preset, "ava-pb") == 0) { // options.c:89-92
 		o->k = 19, o->w = 5, o->hpc = 1, o->no_diag = 1, o->no_dual = 1;
 		o->min_chain_score = 100, o->max_gap = 10000, o->max_chain_skip = 25;
+	} else if (strcmp(preset, "ava-hifi") == 0) { // options.c:99-111 (the alignment scores it also sets are not used by --step 1)
+		o->k = 51, o->w = 51, o->hpc = 1, o->no_diag = 1, o->no_dual = 1, o->mid_occ_frac = 1e-4f;
+		o->min_chain_score = 100, o->max_gap = 10000, o->max_chain_skip = 25;
 	} else {
-		fprintf(stderr, "[ndgpu_overlap] preset '%s' is not supported (ava-ont, ava-pb)\n", preset);
+		fprintf(stderr, "[ndgpu_overlap] preset '%s' is not supported (ava-ont, ava-pb, ava-hifi)\n", preset);
 		return -1;
 	}
 	return 0;

@@ -263,7 +263,11 @@ void launch_run_compact(bool fill, const uint32_t *words, const uint64_t *woff, 
 	                        first_tile, roff, tile_cnt, sym, rstart, n_sym);
 }
 
-template <bool FILL, bool HPC>
+// LONGK: 33 <= k <= 63 (the ava-hifi preset's k = 51, sketch.c:283-356): the k-mer takes two words and its value is
+// hash64(top word) + hash64_no_mask(low word) (hash256to64, sketch.c:274-281); with HPC the span is what the reference's
+// 32-slot run-length ring (sketch.c:40-58) leaves once more than 32 runs are queued: the first 32 runs of the read plus
+// the last k mod 32.
+template <bool FILL, bool HPC, bool LONGK>
 __global__ void __launch_bounds__(kSkThreads) sketch_tile_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ woff,
                                                                  const uint32_t *__restrict__ len, const uint8_t *__restrict__ sym,
                                                                  const uint32_t *__restrict__ rstart, const uint64_t *__restrict__ roff,
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(kSkThreads) sketch_tile_kernel(const uint32_t 
 	const int hw = w - 1, lo = k - 1;
 	const int e0 = t0 - hw > 0 ? t0 - hw : 0;
 	const int e1 = t0 + kTS + hw < N ? t0 + kTS + hw : N;
-	const uint64_t mask = (1ULL << 2 * k) - 1, top = 2ULL * (k - 1);
+	const uint64_t mask = (1ULL << (LONGK ? 2 * (k - 32) : 2 * k)) - 1, top = LONGK ? 2ULL * (k - 1) - 64 : 2ULL * (k - 1);
 	const uint32_t *wp = words + woff[r];
 	const uint64_t ro = HPC ? roff[r] : 0;
 
@@ -298,13 +302,20 @@ __global__ void __launch_bounds__(kSkThreads) sketch_tile_kernel(const uint32_t 
 		if (first < last) {
 			int j = first - (k - 1);
 			if (j < 0) j = 0;
-			uint64_t fw = 0, rv = 0;
+			uint64_t fw = 0, rv = 0, fw_lo = 0, rv_lo = 0;
 			for (; j < last; ++j) {
 				int c;
 				if (HPC) c = (int)sym[ro + j];
 				else c = (int)(wp[j >> 4] >> (30 - 2 * (j & 15)) & 3u);
-				fw = (fw << 2 | (uint64_t)c) & mask;
-				rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+				if (LONGK) {
+					fw = (fw << 2 | fw_lo >> 62) & mask;
+					fw_lo = fw_lo << 2 | (uint64_t)c;
+					rv_lo = rv_lo >> 2 | rv << 62;
+					rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+				} else {
+					fw = (fw << 2 | (uint64_t)c) & mask;
+					rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+				}
 				if (j >= first) {
 					uint64_t x = ~0ULL;
 					uint32_t y = ~0u;
@@ -313,11 +324,22 @@ __global__ void __launch_bounds__(kSkThreads) sketch_tile_kernel(const uint32_t 
 						if (HPC) {
 							const uint32_t nxt = rstart[ro + j + 1];
 							pos = nxt - 1;
-							span = nxt - rstart[ro + j + 1 - k];
+							if (LONGK && j >= k) span = rstart[ro + 32] - rstart[ro] + nxt - rstart[ro + j + 1 - (k & 31)];
+							else span = nxt - rstart[ro + j + 1 - k];
 						}
 						if (span < 256) {
-							const int strand = fw < rv ? 0 : 1;
-							x = hash_masked(strand ? rv : fw, mask) << 8 | (uint64_t)span;
+							int strand;
+							uint64_t h;
+							if (LONGK) {
+								strand = (fw < rv || (fw == rv && fw_lo < rv_lo)) ? 0 : 1;
+								const uint64_t l_ = strand ? rv_lo : fw_lo;
+								h = hash_masked(strand ? rv : fw, mask);
+								if (l_) h += hash_full(l_);
+							} else {
+								strand = fw < rv ? 0 : 1;
+								h = hash_masked(strand ? rv : fw, mask);
+							}
+							x = h << 8 | (uint64_t)span;
 							y = pos << 1 | (uint32_t)strand;
 						}
 					}
@@ -401,10 +423,15 @@ void launch_sketch_tiles(bool fill, bool hpc, const uint32_t *words, const uint6
 	if (!n_tiles) return;
 	dim3 g(n_tiles), b(kSkThreads);
 #define SK_ARGS words, woff, len, sym, rstart, roff, n_sym, tiles, n_tiles, P.w, P.k, rid_is_index, tile_off, tile_cnt, out_x, out_y, out_read
-	if (fill && hpc) hipLaunchKernelGGL((sketch_tile_kernel<true, true>), g, b, 0, s, SK_ARGS);
-	else if (fill) hipLaunchKernelGGL((sketch_tile_kernel<true, false>), g, b, 0, s, SK_ARGS);
-	else if (hpc) hipLaunchKernelGGL((sketch_tile_kernel<false, true>), g, b, 0, s, SK_ARGS);
-	else hipLaunchKernelGGL((sketch_tile_kernel<false, false>), g, b, 0, s, SK_ARGS);
+	if (P.k > 32) {
+		if (fill && hpc) hipLaunchKernelGGL((sketch_tile_kernel<true, true, true>), g, b, 0, s, SK_ARGS);
+		else if (fill) hipLaunchKernelGGL((sketch_tile_kernel<true, false, true>), g, b, 0, s, SK_ARGS);
+		else if (hpc) hipLaunchKernelGGL((sketch_tile_kernel<false, true, true>), g, b, 0, s, SK_ARGS);
+		else hipLaunchKernelGGL((sketch_tile_kernel<false, false, true>), g, b, 0, s, SK_ARGS);
+	} else if (fill && hpc) hipLaunchKernelGGL((sketch_tile_kernel<true, true, false>), g, b, 0, s, SK_ARGS);
+	else if (fill) hipLaunchKernelGGL((sketch_tile_kernel<true, false, false>), g, b, 0, s, SK_ARGS);
+	else if (hpc) hipLaunchKernelGGL((sketch_tile_kernel<false, true, false>), g, b, 0, s, SK_ARGS);
+	else hipLaunchKernelGGL((sketch_tile_kernel<false, false, false>), g, b, 0, s, SK_ARGS);
 #undef SK_ARGS
 }
 

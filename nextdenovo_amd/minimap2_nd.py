@@ -3,14 +3,14 @@
 
 Takes the command line nextDenovo writes for the raw-align subtasks (reference nextDenovo:436-466):
 
-    python -m nextdenovo_amd.minimap2_nd --step 1 [--dual=yes] -t 8 -x ava-ont [-f N] [-I 4G] target.2bit query.2bit -o out.ovl
+    python -m nextdenovo_amd.minimap2_nd --step 1 [--dual=yes] -t 8 -x ava-ont|ava-pb|ava-hifi [-f N] [-I 4G] target.2bit query.2bit -o out.ovl
 
 and writes the byte-identical overlap file.  Mirrors minimap2/main.c for the options of this path (preset
 first, then the remaining options in order: main.c:140-366); the index is split into parts exactly as
 mm_idx_gen does with -I (index.c:284-287,351-360), the occurrence threshold comes from the first part
 (options.c:70-71), every query file is mapped against every part in turn (main.c:474-507).
 
-Options of other paths (-a, -c, --step 2/3, ava-hifi, FASTA input) are rejected, not approximated.
+Options of other paths (-a, -c, --step 2/3, --mode 3, FASTA input) are rejected, not approximated.
 """
 from __future__ import annotations
 

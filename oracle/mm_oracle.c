@@ -4,7 +4,7 @@
  * product (nextdenovo_amd/) never does.
  *
  * Each function follows one routine of the reference tree (NextDenovo v2.5.2, minimap2 2.17 fork):
- *   nd_mm_sketch      minimap2/sketch.c:75-143   (mm_sketch_shortkmer, k <= 28, ACGT-only input)
+ *   nd_mm_sketch      minimap2/sketch.c:75-143   (mm_sketch_shortkmer, k <= 28) and :283-356 (the long k-mer sketch of ava-hifi); ACGT-only input
  *   nd_mm_index_*     minimap2/index.c:81-98,170-191,197-250  (mm_idx_get / mm_idx_cal_max_occ / worker_post)
  *   nd_mm_rs_sort128  minimap2/ksort.h:100-151   (KRADIX_SORT_INIT: in-place, UNSTABLE MSD radix sort;
  *                     the order it leaves equal keys in is part of the result)
@@ -69,16 +69,36 @@ static uint32_t x31_str(const char *s) /* khash.h:383-388 */
 
 /* ---------------------------------------------------------------- sketch */
 
-/* codes[i] in 0..3 (reads come from .2bit files: no ambiguous bases).  out needs room for len+1 entries. */
+static uint64_t mix64_full(uint64_t key) /* hash64_no_mask, sketch.c:262-272; the same function is hit.c:41-51 */
+{
+	key = ~key + (key << 21);
+	key ^= key >> 24;
+	key = key + (key << 3) + (key << 8);
+	key ^= key >> 14;
+	key = key + (key << 2) + (key << 4);
+	key ^= key >> 28;
+	key = key + (key << 31);
+	return key;
+}
+
+/* codes[i] in 0..3 (reads come from .2bit files: no ambiguous bases).  out needs room for len+1 entries.
+ * k <= 28: mm_sketch_shortkmer (sketch.c:77-143); 33 <= k <= 63: mm_sketch_nextdenovo_longkmer (sketch.c:283-356, the
+ * ava-hifi preset's k = 51) with the k-mer in two words (u[1] = the top 2(k-32) bits, u[0] = the low 64) -- the same window
+ * automaton, another k-mer value: hash64(u[1], mask) + (u[0] ? hash64_no_mask(u[0]) : 0)  (hash256to64, sketch.c:274-281).
+ * The run-length queue keeps the reference's 32 slots (sketch.c:40-58): with k > 31 it wraps, and the span the reference
+ * reports for a homopolymer-compressed long k-mer is what this ring leaves. */
 int64_t nd_mm_sketch(const uint8_t *codes, int len, int w, int k, uint32_t rid, int hpc, nd_mm128 *out)
 {
-	const uint64_t mask = (1ULL << 2 * k) - 1, top = 2ULL * (k - 1);
-	uint64_t fw = 0, rv = 0;
+	const int longk = k > 28;
+	const int kbits = longk ? 2 * (k - 32) : 2 * k;              /* bits of the top word */
+	const uint64_t mask = (1ULL << kbits) - 1;
+	const int top = longk ? 2 * (k - 1) - 64 : 2 * (k - 1);      /* where a new base enters the reverse strand's top word */
+	uint64_t fw = 0, rv = 0, fw_lo = 0, rv_lo = 0;
 	nd_mm128 ring[256], best = { NONE64, NONE64 };
-	int runq[32], rq_front = 0, rq_count = 0; /* last k homopolymer run lengths */
+	int runq[32], rq_front = 0, rq_count = 0; /* last k homopolymer run lengths (32 slots, as tiny_queue_t) */
 	int i, j, good = 0, slot = 0, best_slot = 0, span = 0;
 	int64_t n = 0;
-	if (len <= 0 || w <= 0 || w >= 256 || k <= 0 || k > 28) return -1;
+	if (len <= 0 || w <= 0 || w >= 256 || k <= 0 || (k > 28 && k < 33) || k > 63) return -1;
 	memset(ring, 0xff, sizeof(nd_mm128) * w);
 	for (i = 0; i < len; ++i) {
 		int c = codes[i], strand;
@@ -94,13 +114,27 @@ int64_t nd_mm_sketch(const uint8_t *codes, int len, int w, int k, uint32_t rid, 
 			span += run;
 			if (rq_count > k) { span -= runq[rq_front]; rq_front = (rq_front + 1) & 31; --rq_count; }
 		} else span = good + 1 < k ? good + 1 : k;
-		fw = (fw << 2 | (uint64_t)c) & mask;
-		rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
-		if (fw == rv) continue; /* palindromic k-mer: nothing is stored, the window does not advance */
-		strand = fw < rv ? 0 : 1;
+		if (longk) {
+			fw = (fw << 2 | fw_lo >> 62) & mask;
+			fw_lo = fw_lo << 2 | (uint64_t)c;
+			rv_lo = rv_lo >> 2 | rv << 62;
+			rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+			if (fw == rv && fw_lo == rv_lo) continue;
+			strand = (fw < rv || (fw == rv && fw_lo < rv_lo)) ? 0 : 1;
+		} else {
+			fw = (fw << 2 | (uint64_t)c) & mask;
+			rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+			if (fw == rv) continue; /* palindromic k-mer: nothing is stored, the window does not advance */
+			strand = fw < rv ? 0 : 1;
+		}
 		++good;
 		if (good >= k && span < 256) {
-			cur.x = mix64(strand ? rv : fw, mask) << 8 | (uint64_t)span;
+			uint64_t h = mix64(strand ? rv : fw, mask);
+			if (longk) {
+				const uint64_t lo = strand ? rv_lo : fw_lo;
+				if (lo) h += mix64_full(lo);
+			}
+			cur.x = h << 8 | (uint64_t)span;
 			cur.y = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)strand;
 		}
 		ring[slot] = cur;
@@ -444,18 +478,6 @@ int nd_mm_chain(const nd_mm_opt *opt, int64_t n, nd_mm128 *a, uint64_t *u, int64
 }
 
 /* ---------------------------------------------------------------- chains -> hits */
-
-static uint64_t mix64_full(uint64_t key) /* hit.c:41-51 */
-{
-	key = ~key + (key << 21);
-	key ^= key >> 24;
-	key = key + (key << 3) + (key << 8);
-	key ^= key >> 14;
-	key = key + (key << 2) + (key << 4);
-	key ^= key >> 28;
-	key = key + (key << 31);
-	return key;
-}
 
 uint32_t nd_mm_read_hash(const char *qname, int qlen, int seed) /* map.c:519-521 */
 {

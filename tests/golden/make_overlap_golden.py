@@ -26,7 +26,12 @@ CASES = [  # (file tag, preset, target, query, dual, extra argv)
     ("pb.sxs", "ava-pb", "seed", "seed", False, ()),
     ("ont.sxs.I200k", "ava-ont", "seed", "seed", False, ("-I", "200k")),
     ("ont.sxp.dual.I150k", "ava-ont", "seed", "part", True, ("-I", "150k")),
+    # HiFi reads (hseed / hpart): k = 51, w = 51, homopolymer-compressed -- the two-word k-mer sketch (sketch.c:283-356)
+    ("hifi.sxs", "ava-hifi", "hseed", "hseed", False, ()),
+    ("hifi.sxp.dual", "ava-hifi", "hseed", "hpart", True, ()),
+    ("hifi.sxs.f40", "ava-hifi", "hseed", "hseed", False, ("-f", "40")),   # nextDenovo passes -f seed_depth*20 (config_parser.py:46-47)
 ]
+SETS = ("seed", "part", "hseed", "hpart")
 
 
 def main():
@@ -43,6 +48,15 @@ def main():
     files = {"seed": seed, "part": part}
     for k, p in files.items():
         shutil.copy(p, os.path.join(out, k + ".2bit"))
+    gh = synth.make_genome(60000, seed=18, n_repeats=5, repeat_len=2500)
+    for pos, unit, copies in ((12000, 61, 40),):
+        blk = np.tile(rng.integers(0, 4, unit).astype(np.uint8), copies)
+        gh[pos:pos + blk.size] = blk
+    rh = synth.simulate_reads(gh, 24, "hifi", seed=19, mu=8.9, sigma=0.3, min_len=3000)
+    hs, hp = M.dump_reads(os.path.join(wd, "hifi"), [synth.codes_to_ascii(s) for s in rh.seqs], seed_cutoff=8000)
+    files["hseed"], files["hpart"] = hs, hp
+    for k in ("hseed", "hpart"):
+        shutil.copy(files[k], os.path.join(out, k + ".2bit"))
     for tag, preset, t, q, dual, extra in CASES:
         b = M.ref_step1(files[t], files[q], os.path.join(out, tag + ".ovl"), preset, dual, extra)
         print(tag, len(b), "bytes")

@@ -36,6 +36,8 @@ def preset(name: str, dual: bool = False, **kw) -> MMOpt:
         o.bw = 2000
     elif name == "ava-pb":
         o.k, o.hpc = 19, 1
+    elif name == "ava-hifi":  # options.c:99-111 (mid_occ_frac 1e-4 is the caller's to pass)
+        o.k, o.w, o.hpc = 51, 51, 1
     else:
         raise ValueError(name)
     for k, v in kw.items():

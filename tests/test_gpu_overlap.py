@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import mm_util as M  # noqa: E402
-from make_overlap_golden import CASES  # noqa: E402
+from make_overlap_golden import CASES, SETS  # noqa: E402
 from test_overlap_oracle import case_kwargs  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +28,7 @@ def olib(oracle_lib):
 def sets():
     from nextdenovo_amd import overlap
     out = {}
-    for k in ("seed", "part"):
+    for k in SETS:
         p = os.path.join(GOLD, k + ".2bit")
         out[k] = (overlap.ReadSet.from_2bit(p), M.load_set(p))
     return out
@@ -58,12 +58,12 @@ def oracle_sketch_all(olib, oset, w, k, hpc, rid_is_index):
     return np.concatenate(xs), np.concatenate(ys), np.asarray(offs, dtype=np.uint64)
 
 
-@pytest.mark.parametrize("preset", ["ava-ont", "ava-pb"])
+@pytest.mark.parametrize("preset", ["ava-ont", "ava-pb", "ava-hifi"])
 @pytest.mark.parametrize("rid_is_index", [False, True])
 def test_sketch_matches_oracle(olib, sets, preset, rid_is_index):
     from nextdenovo_amd import overlap
     o = overlap.preset(preset)
-    for k in ("seed", "part"):
+    for k in (("hseed", "hpart", "seed") if preset == "ava-hifi" else ("seed", "part")):
         rs, oset = sets[k]
         x, y, off = overlap.sketch(o, rs, rid_is_index)
         ex, ey, eoff = oracle_sketch_all(olib, oset, o.w, o.k, o.hpc, rid_is_index)
@@ -71,11 +71,11 @@ def test_sketch_matches_oracle(olib, sets, preset, rid_is_index):
         assert np.array_equal(x, ex) and np.array_equal(y, ey)
 
 
-@pytest.mark.parametrize("preset", ["ava-ont", "ava-pb"])
+@pytest.mark.parametrize("preset", ["ava-ont", "ava-pb", "ava-hifi"])
 def test_index_matches_oracle(olib, sets, preset):
     from nextdenovo_amd import overlap
     o = overlap.preset(preset)
-    rs, (ids, lens, codes, off) = sets["seed"]
+    rs, (ids, lens, codes, off) = sets["hseed" if preset == "ava-hifi" else "seed"]
     ix = olib.nd_mm_index_build(ids.size, M.ptr(codes), M.ptr(off), M.ptr(lens), M.ptr(ids), o.w, o.k, o.hpc)
     nk, nm = olib.nd_mm_index_keys(ix), olib.nd_mm_index_n(ix)
     ekey, estart, epos = np.zeros(nk, np.uint64), np.zeros(nk + 1, np.int64), np.zeros(nm, np.uint64)
@@ -83,7 +83,7 @@ def test_index_matches_oracle(olib, sets, preset):
     with overlap.Index(o, rs) as dix:
         key, start, pos = dix.dump()
         assert np.array_equal(key, ekey) and np.array_equal(start.astype(np.int64), estart) and np.array_equal(pos, epos)
-        for f in (2e-4, 2e-3, 0.05):
+        for f in (1e-4, 2e-4, 2e-3, 0.05):
             assert dix.mid_occ(f) == olib.nd_mm_index_mid_occ(ix, np.float32(f))
     olib.nd_mm_index_free(ix)
 
@@ -107,7 +107,7 @@ def test_ovl_bytes_match_reference_golden(sets, case):
 
 
 @pytest.mark.parametrize("preset,dual,tq", [("ava-ont", True, ("seed", "part")), ("ava-ont", False, ("seed", "seed")),
-                                            ("ava-pb", False, ("seed", "seed"))])
+                                            ("ava-pb", False, ("seed", "seed")), ("ava-hifi", True, ("hseed", "hpart"))])
 def test_anchors_and_chain_arrays_match_oracle(olib, sets, preset, dual, tq, monkeypatch):
     """Sorted anchors (tie order of the reference sort included) and the DP's f[] / p[] per query read."""
     from nextdenovo_amd import overlap
@@ -117,7 +117,7 @@ def test_anchors_and_chain_arrays_match_oracle(olib, sets, preset, dual, tq, mon
     trs, (tid, tl, tc, to) = sets[tq[0]]
     qrs, (qid, ql, qc, qo) = sets[tq[1]]
     ix = olib.nd_mm_index_build(tid.size, M.ptr(tc), M.ptr(to), M.ptr(tl), M.ptr(tid), oo.w, oo.k, oo.hpc)
-    mid = olib.nd_mm_index_mid_occ(ix, np.float32(2e-4))
+    mid = olib.nd_mm_index_mid_occ(ix, np.float32(1e-4 if preset == "ava-hifi" else 2e-4))
     n_tie = 0
     with overlap.Index(o, trs) as dix:
         assert dix.mid_occ() == mid
@@ -143,7 +143,7 @@ def test_anchors_and_chain_arrays_match_oracle(olib, sets, preset, dual, tq, mon
         assert n_tie > 0 and st["tie_reads"] > 0  # the exact-replay path really ran
 
 
-@pytest.mark.parametrize("profile,preset", [("ont", "ava-ont"), ("clr", "ava-pb")])
+@pytest.mark.parametrize("profile,preset", [("ont", "ava-ont"), ("clr", "ava-pb"), ("hifi", "ava-hifi")])
 def test_live_set_many_batches(olib, profile, preset, monkeypatch, tmp_path):
     """A fresh seeded read set, mapped in several small batches, against the oracle's whole-run bytes."""
     from nextdenovo_amd import overlap, synth
@@ -162,7 +162,7 @@ def test_live_set_many_batches(olib, profile, preset, monkeypatch, tmp_path):
     off[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
     oset = (ids, lens, codes, off)
     for dual in (False, True):
-        want, mid = M.step1(olib, M.preset(preset, dual), oset, oset)
+        want, mid = M.step1(olib, M.preset(preset, dual), oset, oset, **case_kwargs((), preset))
         o = dev_opt(preset, dual)
         with overlap.Index(o, dset) as ix:
             assert ix.mid_occ() == mid
@@ -210,10 +210,12 @@ def _adversarial_reads(seed=11):
     return reads
 
 
-@pytest.mark.parametrize("k,w,hpc", [(15, 5, 0), (19, 5, 1), (5, 1, 0), (7, 8, 1), (11, 17, 0), (3, 2, 1), (27, 64, 0), (14, 5, 0), (6, 3, 1)])
+@pytest.mark.parametrize("k,w,hpc", [(15, 5, 0), (19, 5, 1), (5, 1, 0), (7, 8, 1), (11, 17, 0), (3, 2, 1), (27, 64, 0), (14, 5, 0), (6, 3, 1),
+                                     (51, 51, 1), (51, 51, 0), (33, 4, 1), (63, 7, 1), (35, 64, 0), (47, 1, 1)])
 def test_sketch_adversarial_reads(olib, k, w, hpc):
     """Low-complexity / tandem / homopolymer-heavy / very short reads: the position-parallel K1 (odd k) and the
-    sequential K1 (even k) both reproduce the window automaton, first-window quirks included."""
+    sequential K1 (even k) both reproduce the window automaton, first-window quirks included; k > 32 is the two-word k-mer
+    of ava-hifi, whose homopolymer-compressed span comes out of the reference's wrapped 32-slot run queue."""
     from nextdenovo_amd import overlap, synth
     reads = _adversarial_reads()
     lens = np.asarray([r.size for r in reads], dtype=np.uint32)

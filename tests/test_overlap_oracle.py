@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import mm_util as M  # noqa: E402
-from make_overlap_golden import CASES  # noqa: E402
+from make_overlap_golden import CASES, SETS  # noqa: E402
 
 GOLD = os.path.join(HERE, "golden", "overlap")
 
@@ -25,11 +25,13 @@ def lib(oracle_lib):
 
 @pytest.fixture(scope="module")
 def sets():
-    return {k: M.load_set(os.path.join(GOLD, k + ".2bit")) for k in ("seed", "part")}
+    return {k: M.load_set(os.path.join(GOLD, k + ".2bit")) for k in SETS}
 
 
-def case_kwargs(extra):
+def case_kwargs(extra, preset=None):
     kw = {}
+    if preset == "ava-hifi":
+        kw["mid_occ_frac"] = 1e-4  # options.c:108
     if "-f" in extra:
         x = float(extra[extra.index("-f") + 1])
         if x < 1.0:
@@ -47,7 +49,7 @@ def test_oracle_matches_golden_ovl(lib, sets, case):
     tag, preset, t, q, dual, extra = case
     with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
         want = f.read()
-    got, _ = M.step1(lib, M.preset(preset, dual), sets[t], sets[q], **case_kwargs(extra))
+    got, _ = M.step1(lib, M.preset(preset, dual), sets[t], sets[q], **case_kwargs(extra, preset))
     assert got == want
 
 
@@ -70,7 +72,7 @@ def test_golden_set_has_equal_coordinate_anchors(lib, sets):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(M.REFDIR, "minimap2-nd")), reason="oracle/_ref not built")
-@pytest.mark.parametrize("profile,preset", [("ont", "ava-ont"), ("clr", "ava-pb")])
+@pytest.mark.parametrize("profile,preset", [("ont", "ava-ont"), ("clr", "ava-pb"), ("hifi", "ava-hifi")])
 def test_oracle_matches_live_reference(lib, profile, preset):
     from nextdenovo_amd import synth
     g = synth.make_genome(50000, seed=21, n_repeats=4, repeat_len=1200)
@@ -80,5 +82,5 @@ def test_oracle_matches_live_reference(lib, profile, preset):
     S, P = M.load_set(seed), M.load_set(part)
     for t, q, dual in ((seed, part, True), (seed, seed, False)):
         want = M.ref_step1(t, q, os.path.join(wd, "o.ovl"), preset, dual)
-        got, _ = M.step1(lib, M.preset(preset, dual), S, S if q == seed else P)
+        got, _ = M.step1(lib, M.preset(preset, dual), S, S if q == seed else P, **case_kwargs((), preset))
         assert len(want) > 1000 and got == want
