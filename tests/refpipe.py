@@ -76,7 +76,7 @@ def run(cmd, cwd=None):
 
 
 def run_overlap_chain(workdir, fasta, seed_cutoff, read_cutoff=500, preset="ava-ont", threads=4,
-                      sort_depth=40):
+                      sort_depth=40, extra=()):
     """Returns (idxs_fofn, sorted_ovl)."""
     db = os.path.join(workdir, "db")
     ra = os.path.join(workdir, "ra")
@@ -92,10 +92,10 @@ def run_overlap_chain(workdir, fasta, seed_cutoff, read_cutoff=500, preset="ava-
     ovls = []
     if os.path.exists(part2) and os.path.getsize(part2) > 2:
         o = os.path.join(ra, "input.seed.001.2bit.0.ovl")
-        run([R("minimap2-nd"), "--step", "1", "--dual=yes", "-t", str(threads), "-x", preset, seed2, part2, "-o", o])
+        run([R("minimap2-nd"), "--step", "1", "--dual=yes", "-t", str(threads), "-x", preset, *extra, seed2, part2, "-o", o])
         ovls.append(o)
     o = os.path.join(ra, "input.seed.001.2bit.1.ovl")
-    run([R("minimap2-nd"), "--step", "1", "-I", "3G", "-t", str(threads), "-x", preset, seed2, seed2, "-o", o])
+    run([R("minimap2-nd"), "--step", "1", "-I", "3G", "-t", str(threads), "-x", preset, *extra, seed2, seed2, "-o", o])
     ovls.append(o)
     with open(os.path.join(ra, "input.fofn"), "w") as f:
         f.write("\n".join(ovls) + "\n")

@@ -151,3 +151,63 @@ def test_workload_scale_chain_matches_reference_binaries(tmp_path):
     assert ovl_sort.run(["-m", "2g", "-t", "8", "-k", "40", "-i", idx, "-o", so, fofn]) == 0
     assert len(want) > 500000 and open(so, "rb").read() == want
     assert open(so + ".bl").read() == want_bl
+
+
+@pytest.mark.skipif(not all(os.path.exists(os.path.join(O.REFDIR, n)) for n in ("minimap2-nd", "ovl_sort", "seq_dump", "nextcorrect.so",
+                                                                                "ovlseq.so")), reason="oracle/_ref not built")
+def test_hifi_stage_chain_matches_reference(tmp_path):
+    """HiFi reads through the whole correction stage as nextDenovo runs it for `read_type = hifi` (raw_align with
+    `-x ava-hifi -f seed_depth*20`, lib/config_parser.py:46-47,212; sort_align; seed_cns with `-r hifi -max_lq_length 1000`):
+    the compiled reference programs against the three device command lines -- raw .ovl files, sorted.ovl, .bl and every
+    corrected record."""
+    import refpipe
+    import util
+    from nextdenovo_amd import minimap2_nd, ovl_sort, synth
+    g = synth.make_genome(90000, seed=31, n_repeats=3, repeat_len=3000)
+    rs = synth.simulate_reads(g, 30, "hifi", seed=32, mu=9.0, sigma=0.25, min_len=4000)
+    wd = str(tmp_path)
+    fa = os.path.join(wd, "reads.fa")
+    refpipe.write_fasta(fa, [synth.codes_to_ascii(s) for s in rs.seqs])
+    idxs, so_ref = refpipe.run_overlap_chain(wd, fa, seed_cutoff=8500, preset="ava-hifi", extra=("-f", "800"), sort_depth=28)
+    db, ra = os.path.join(wd, "db"), os.path.join(wd, "ra")
+    seed, part = os.path.join(db, "input.seed.001.2bit"), os.path.join(db, "input.part.001.2bit")
+    mine = []
+    for t, q, dual, tag in ((seed, part, True, "0"), (seed, seed, False, "1")):
+        ref_file = os.path.join(ra, "input.seed.001.2bit.%s.ovl" % tag)
+        if not os.path.exists(ref_file):
+            continue
+        m = os.path.join(wd, "mine.%s.ovl" % tag)
+        argv = ["--step", "1"] + (["--dual=yes"] if dual else ["-I", "3G"]) + ["-t", "8", "-x", "ava-hifi", "-f", "800", t, q, "-o", m]
+        assert minimap2_nd.run(argv) == 0
+        assert os.path.getsize(ref_file) > 20000 and open(m, "rb").read() == open(ref_file, "rb").read()
+        mine.append(m)
+    assert len(mine) == 2
+    fofn = os.path.join(wd, "mine.fofn")
+    with open(fofn, "w") as f:
+        f.write("\n".join(mine) + "\n")
+    so = os.path.join(wd, "mine.sorted.ovl")
+    assert ovl_sort.run(["-m", "2g", "-t", "4", "-k", "28", "-i", os.path.join(db, ".input.seed.001.idx"), "-o", so, fofn]) == 0
+    assert open(so, "rb").read() == open(so_ref, "rb").read()
+    assert open(so + ".bl").read() == open(so_ref + ".bl").read()
+    bl = {int(line.split()[0]) for line in open(so_ref + ".bl") if line.strip()}
+    # reference consensus of every pile nextcorrect.py would form (lib/nextcorrect.py:92-143,183-199,236)
+    rfn, rfr = util.bind_correct(refpipe.ref_cns())
+    want = {}
+    for seed_name, seqs, st, en, mal, _ in refpipe.read_piles(idxs, so_ref, min_len_seed=4250, blacklist=bl):
+        a = util.call_correct(rfn, rfr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal, max_lq=min(en[0] // 2, 1000),
+                                             read_type=3, fast=0, split=0))
+        if a[0] >= 4250 and a[1] >= 0.8:
+            want[int(seed_name)] = (a[0], "%f" % a[1], a[2])
+    assert len(want) > 30
+    out = os.path.join(wd, "cns.fasta")
+    cmd = [sys.executable, "-m", "nextdenovo_amd.nextcorrect", "-f", idxs, "-i", so, "-r", "hifi", "-p", "4", "-max_lq_length", "1000",
+           "-min_len_seed", "4250", "-o", out]
+    r = subprocess.run(cmd, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = {}
+    with open(out, "rb") as f:
+        lines = f.read().split(b"\n")
+    for h, s_ in zip(lines[0::2], lines[1::2]):
+        name, ln, ide = h[1:].split()
+        got[int(name)] = (int(ln), ide.decode(), s_)
+    assert got == want
