@@ -276,6 +276,19 @@ def main():
         k10_bytes = (16.0 * st["cells_msa"] + 12.0 * st["links"] + 20.0 * st["path_items"]) / k10_launches
         k10_ms = st["score_ms"] / k10_launches
         achieved = k10_bytes / (k10_ms * 1e-3) / 1e9 if k10_ms > 0 else 0.0
+        # HBM bytes per K10 launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself):
+        # used only when this run is the workload those passes profiled (seeded data: the launches are the same ones)
+        traffic, traffic_note = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_k10_traffic.json")) as f:
+                pm = json.load(f)
+            w_ = pm["workload"]
+            if (not analytic and ovl_state is not None and int(args.genome_size) == w_["genome_size"] and int(args.depth) == w_["depth"]
+                    and args.profile == w_["profile"] and abs(k10_launches / args.steps - pm["launches_per_step"]) < 0.5):
+                traffic = (pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024.0
+                traffic_note = pm["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         launches = max(1, st["forward_launches"])
         alg_bytes = (st["seq_bases"] / 4.0 + st["cells"] / 8.0 + 4.0 * st["d_steps"]) / launches
         avg_ms = st["forward_ms"] / launches
@@ -303,7 +316,9 @@ def main():
                        "the step's own overlap -> ovl_sort -> pile assembly chain on the device",
                        "datagen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": "score_fast_kernel (K10 scoring DP)", "achieved": achieved,
-                         "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": None,
+                         "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_note,
+                         "traffic_over_algorithmic": (traffic / k10_bytes) if traffic and k10_bytes else None,
                          "alg_bytes_per_launch": k10_bytes, "avg_launch_ms": k10_ms, "launches": int(k10_launches),
                          "note": "latency-bound dependent chain (one wave per seed), not bandwidth-bound",
                          "k7_ond_forward": {"achieved": k7_achieved, "frac": k7_achieved / peak,
