@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""The whole correction stage of NextDenovo on the MI355X with nothing on disk in between.
+
+nextDenovo runs three kinds of subtasks over the `seq_dump` output directory and exchanges files between them
+(reference nextDenovo:426-467 raw_align, :344-354 sort_align, :77-84 seed_cns):
+
+    minimap2-nd --step 1 ... input.seed.NNN.2bit input.part.MMM.2bit -o input.seed.NNN.2bit.K.ovl      (one per file pair)
+    ovl_sort ... -i .input.seed.NNN.idx -o input.seed.NNN.sorted.ovl input.fofn                        (one per seed file)
+    nextcorrect.py -f idxs -i input.seed.NNN.sorted.ovl -r ont ... -o cns.fasta                        (one per seed file)
+
+This command does the same jobs in the same order on the device and hands the records from one step to the next in
+memory: the step-1 overlaps never get varint-coded, sorted.ovl is never written or re-read, each seed file's minimizer
+index is built once for all of its jobs, and the reads are uploaded once.
+
+    python -m nextdenovo_amd.correct_stage -d 01.raw_align -x ava-ont -k 40 -r ont -min_len_seed 5000 -o cns
+
+writes `cns.NNN.fasta` (+ `.idx`) per seed file, byte-identical to what the three reference programs produce when the
+sort's input list names the `.ovl` files in job order (the reference lists them in directory order, which only matters
+for overlaps with equal (seed, match, span) keys).  `--keep DIR` also writes the `.ovl`, `sorted.ovl` and `.bl` files
+with the reference's names, for resuming or debugging with the file-based commands.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import sys
+
+import numpy as np
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nextdenovo_amd import api, minimap2_nd, nextcorrect, overlap  # noqa: E402
+
+
+def job_matrix(n_seed: int, n_part: int):
+    """raw_align's job list (nextDenovo:426-467): (k, seed file i, other kind, other index, dual)."""
+    jobs, k = [], 0
+    for i in range(n_seed):
+        for j in range(n_part):
+            jobs.append((k, i, "part", j, True))
+            k += 1
+        for t in range(i, n_seed):
+            jobs.append((k, i, "seed", t, t != i))
+            k += 1
+    return jobs
+
+
+class _IndexCache:
+    """The index parts of one target file, built on first use and shared by every job that maps against it."""
+
+    def __init__(self, opt, target):
+        self.opt, self.target, self.parts, self.mid_occ = opt, target, {}, opt.mid_occ
+
+    def map(self, query, batch_size, dual):
+        o = overlap.Opt.from_buffer_copy(self.opt)
+        o.no_dual = 0 if dual else 1
+        out = []
+        for lo, hi in minimap2_nd.index_parts(self.target.lens, batch_size):
+            ix = self.parts.get((lo, hi))
+            if ix is None:
+                ix = self.parts[(lo, hi)] = overlap.Index(self.opt, self.target.subset(lo, hi))
+            if self.mid_occ <= 0:
+                self.mid_occ = ix.mid_occ()  # the first part's threshold is kept (options.c:70-71)
+            out.append(ix.map(query, self.mid_occ, opt=o))
+        return np.concatenate(out) if len(out) > 1 else out[0]
+
+    def close(self):
+        for ix in self.parts.values():
+            ix.close()
+        self.parts = {}
+
+
+def read_db_from_sets(sets):
+    """All reads of the run, indexed by read id (ids are dense over seed and part files, util/seq_dump.c:83-84)."""
+    n = max(int(s.ids.max()) + 1 if len(s) else 0 for s in sets)
+    word_off = np.zeros(n, dtype=np.uint64)
+    lens = np.zeros(n, dtype=np.uint32)
+    chunks, base = [], 0
+    for s in sets:
+        word_off[s.ids] = s.word_off + np.uint64(base)
+        lens[s.ids] = s.lens
+        chunks.append(s.words)
+        base += s.words.size
+    return np.concatenate(chunks), word_off, lens
+
+
+def run(argv) -> int:
+    ap = argparse.ArgumentParser(prog="correct_stage", description=__doc__.split("\n")[0])
+    ap.add_argument("-d", dest="dir", required=True, help="seq_dump output directory (input.seed.*.2bit, input.part.*.2bit)")
+    ap.add_argument("-x", dest="preset", required=True, choices=["ava-ont", "ava-pb", "ava-hifi"])
+    ap.add_argument("-f", dest="occ", default=None, help="minimap2-nd -f (FLOAT < 1 or INT)")
+    ap.add_argument("-k", dest="sort_k", type=int, default=40, help="ovl_sort -k")
+    ap.add_argument("-l", dest="flank", type=int, default=300, help="ovl_sort -l")
+    ap.add_argument("-r", dest="read_type", required=True, type=str.lower, choices=["clr", "hifi", "ont"])
+    ap.add_argument("--seed-files", default=None, help="comma separated seed file numbers to correct (default: all)")
+    ap.add_argument("--keep", default=None, metavar="DIR", help="also write .ovl / sorted.ovl / .bl files there")
+    ap.add_argument("-o", dest="out", required=True, help="output prefix: PREFIX.NNN.fasta (+ .idx)")
+    for name, typ, dflt in (("-max_cov_aln", int, 130), ("-max_lq_length", str, None), ("-min_cov_seed", int, 10),
+                            ("-min_len_seed", str, 10000), ("-min_len_aln", str, 500), ("-min_cov_base", int, 4),
+                            ("-min_error_corrected_ratio", float, 0.8), ("-p", int, 0)):
+        ap.add_argument(name, dest=name.lstrip("-") if name != "-p" else "process", type=typ, default=dflt)
+    ap.add_argument("-s", dest="split", action="store_true")
+    ap.add_argument("-fast", action="store_true")
+    ap.add_argument("-b", dest="blacklist", action="store_false", default=True)
+    ap.add_argument("--batch", type=int, default=4096)
+    a = ap.parse_args(argv)
+    if a.max_lq_length is None:
+        a.max_lq_length = 10000 if a.preset == "ava-ont" else 1000  # lib/config_parser.py:217-221
+    a.max_lq_length = nextcorrect.parse_num_unit(a.max_lq_length)
+    a.min_len_seed = nextcorrect.parse_num_unit(a.min_len_seed)
+    a.min_len_aln = nextcorrect.parse_num_unit(a.min_len_aln)
+    a.read_type = {"ont": 1, "clr": 2, "hifi": 3}[a.read_type]
+
+    seed_paths = sorted(glob.glob(os.path.join(a.dir, "input.seed.*.2bit")))
+    part_paths = [p for p in sorted(glob.glob(os.path.join(a.dir, "input.part.*.2bit"))) if os.path.getsize(p) > 2]
+    if not seed_paths:
+        raise SystemExit("[ERROR] no input.seed.*.2bit in %s" % a.dir)
+    seeds = [overlap.ReadSet.from_2bit(p) for p in seed_paths]
+    parts = [overlap.ReadSet.from_2bit(p) for p in part_paths]
+    want = set(range(len(seeds))) if a.seed_files is None else {int(x) - 1 for x in a.seed_files.split(",")}
+
+    argv_mm = ["--step", "1", "-x", a.preset] + (["-f", a.occ] if a.occ else []) + ["a", "b"]
+    opt = minimap2_nd.build_opt(minimap2_nd.parse_argv(argv_mm))
+    seed_batch = 6000000000 if a.preset == "ava-hifi" else 3000000000  # -I 6G / 3G of the seed x seed jobs (nextDenovo:430,456)
+
+    # --- raw_align: every job once, records kept in host memory
+    per_seed_files = {i: [] for i in range(len(seeds))}   # seed file -> [(k, records)] of the jobs that involve it
+    caches = {}
+    for k, i, kind, j, dual in job_matrix(len(seeds), len(parts)):
+        if i not in want and not (kind == "seed" and j in want):
+            continue
+        if i not in caches:
+            caches[i] = _IndexCache(opt, seeds[i])
+        query = parts[j] if kind == "part" else seeds[j]
+        recs = caches[i].map(query, minimap2_nd.IDX_BATCH if kind == "part" else seed_batch, dual)
+        per_seed_files[i].append((k, recs))
+        if kind == "seed" and j != i:
+            per_seed_files[j].append((k, recs))          # the `ln -sf` mirror of a seed x seed job (nextDenovo:459)
+        if a.keep:
+            os.makedirs(a.keep, exist_ok=True)
+            name = "%s.%d.ovl" % (os.path.basename(seed_paths[i]), k)
+            with open(os.path.join(a.keep, name), "wb") as f:
+                f.write(overlap.encode(recs, np.zeros(2, dtype=np.uint32)))
+        if kind == "seed" and j == len(seeds) - 1:
+            caches.pop(i).close()                         # seed file i is not a target again
+    for c in caches.values():
+        c.close()
+
+    # --- sort_align + seed_cns per seed file
+    words, word_off, lens = read_db_from_sets(seeds + parts)
+    db = api.ReadDB(words, word_off, lens)
+    fail = 0
+    try:
+        for i in sorted(want):
+            s = seeds[i]
+            seed_len = np.zeros(int(lens.size), dtype=np.uint32)
+            seed_len[s.ids] = s.lens
+            files = [r for _, r in sorted(per_seed_files[i], key=lambda kr: kr[0])]
+            srt, bl, _ = overlap.sort_overlaps(files, seed_len, int(s.lens.min()) if len(s) else 0, a.sort_k, a.flank)
+            tag = os.path.basename(seed_paths[i])[len("input.seed."):-len(".2bit")]
+            if a.keep:
+                so = os.path.join(a.keep, "input.seed.%s.sorted.ovl" % tag)
+                with open(so, "wb") as f:
+                    f.write(overlap.encode(srt, np.zeros(2, dtype=np.uint32)))
+                with open(so + ".bl", "w") as f:
+                    for rid, kind in bl:
+                        f.write("%d %s\n" % (rid, kind))
+            dec = np.stack([srt[c] for c in ("qname", "rev", "qs", "qe", "tname", "ts", "te", "match")], axis=1)
+            skip = [rid for rid, _ in bl] if a.blacklist else []
+            rows, off, names = nextcorrect.assemble_piles_fast(dec, a.min_len_seed, a.min_len_aln, a.max_cov_aln, a.min_cov_seed, skip)
+            piles = [(int(names[p]), rows[int(off[p]):int(off[p + 1])]) for p in range(names.size)]
+            out = "%s.%s.fasta" % (a.out, tag)
+            with open(out, "w") as OUT, open(out + ".idx", "w") as IDX:
+                fail += nextcorrect.correct_and_write(db, dec, piles, a, OUT, IDX)
+    finally:
+        db.close()
+    return 1 if fail > 5 else 0
+
+
+if __name__ == "__main__":
+    sys.exit(run(sys.argv[1:]))

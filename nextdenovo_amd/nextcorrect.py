@@ -128,27 +128,10 @@ def assemble_piles_fast(recs: np.ndarray, min_len_seed: int, min_len_aln: int, m
     return rows, pile_off, t[first][valid].astype(np.uint32)
 
 
-def main(args):
+def correct_and_write(db, recs, piles, args, OUT, IDX):
+    """Correct `piles` = [(seed, row indices into recs)] in device batches and write the records as
+    lib/nextcorrect.py:233-260 does.  Returns the number of seeds that failed with len == 3."""
     corrected_region = re.compile(r"[ACGT]+")
-    OUT, IDX = sys.stdout, None
-    skip = set()
-    read_blacklist(args.blacklist, skip)
-    if args.out != "stdout":
-        if os.path.exists(args.out):
-            IDX = open(args.out + ".idx", "r+")
-            pos = read_corrected_seeds(IDX, skip)
-            OUT = open(args.out, "r+")
-            OUT.seek(pos, 0)
-            OUT.truncate()
-        else:
-            OUT = open(args.out, "w")
-            IDX = open(args.out + ".idx", "w")
-
-    words, word_off, lens = ovl.load_read_db(args.idxs)
-    db = api.ReadDB(words, word_off, lens)
-    recs = ovl.decode_ovl(args.ovl)
-    piles = list(assemble_piles(recs, args, skip))
-
     fail_seed = 0
     batch = max(1, args.batch)
     for b0 in range(0, len(piles), batch):
@@ -179,6 +162,30 @@ def main(args):
                     fail_seed += 1
                 elif IDX:
                     print("%d\t%d\t%d" % (seed_name, 0, 0), file=IDX)
+    return fail_seed
+
+
+def main(args):
+    OUT, IDX = sys.stdout, None
+    skip = set()
+    read_blacklist(args.blacklist, skip)
+    if args.out != "stdout":
+        if os.path.exists(args.out):
+            IDX = open(args.out + ".idx", "r+")
+            pos = read_corrected_seeds(IDX, skip)
+            OUT = open(args.out, "r+")
+            OUT.seek(pos, 0)
+            OUT.truncate()
+        else:
+            OUT = open(args.out, "w")
+            IDX = open(args.out + ".idx", "w")
+
+    words, word_off, lens = ovl.load_read_db(args.idxs)
+    db = api.ReadDB(words, word_off, lens)
+    recs = ovl.decode_ovl(args.ovl)
+    piles = list(assemble_piles(recs, args, skip))
+
+    fail_seed = correct_and_write(db, recs, piles, args, OUT, IDX)
     db.close()
     if args.out != "stdout":
         OUT.close()

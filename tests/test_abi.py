@@ -109,3 +109,12 @@ def test_minimap2_nd_cli_host_logic():
     for bad in ("--step 2 -x ava-ont a b", "--step 1 -x ava-hifi --mode 3 a b", "--step 1 -x map-ont a b", "--step 1 -x ava-ont -c a b"):
         with pytest.raises((SystemExit, ValueError)):
             m.build_opt(m.parse_argv(bad.split()))
+
+
+def test_correct_stage_job_matrix():
+    """raw_align's job list (reference nextDenovo:426-467): per seed file its part jobs, then the seed x seed jobs t >= i."""
+    from nextdenovo_amd.correct_stage import job_matrix
+    assert job_matrix(1, 1) == [(0, 0, "part", 0, True), (1, 0, "seed", 0, False)]
+    assert job_matrix(2, 1) == [(0, 0, "part", 0, True), (1, 0, "seed", 0, False), (2, 0, "seed", 1, True),
+                                (3, 1, "part", 0, True), (4, 1, "seed", 1, False)]
+    assert [j[0] for j in job_matrix(3, 2)] == list(range(3 * 2 + 6))

@@ -211,3 +211,81 @@ def test_hifi_stage_chain_matches_reference(tmp_path):
         name, ln, ide = h[1:].split()
         got[int(name)] = (int(ln), ide.decode(), s_)
     assert got == want
+
+
+def test_fused_stage_equals_file_chain_golden(tmp_path):
+    """`correct_stage` (overlap -> sort -> consensus with nothing on disk in between) on the stage fixture: the same
+    cns.fasta / .idx the reference chain wrote through its files; --keep reproduces the intermediate files too."""
+    from nextdenovo_amd import correct_stage
+    keep = str(tmp_path / "keep")
+    out = str(tmp_path / "cns")
+    assert correct_stage.run(["-d", STAGE, "-x", "ava-ont", "-k", "40", "-r", "ont", "-min_len_seed", "1250", "-p", "4",
+                              "--keep", keep, "-o", out]) == 0
+    assert open(out + ".001.fasta", "rb").read() == _golden("cns.default.fasta", gz=True)
+    assert open(out + ".001.fasta.idx", "rb").read() == _golden("cns.default.fasta.idx", gz=True)
+    assert open(os.path.join(keep, "input.seed.001.sorted.ovl"), "rb").read() == _golden("input.seed.001.sorted.ovl")
+    assert open(os.path.join(keep, "input.seed.001.sorted.ovl.bl"), "rb").read() == _golden("input.seed.001.sorted.ovl.bl")
+
+
+@pytest.mark.skipif(not all(os.path.exists(os.path.join(O.REFDIR, n)) for n in ("minimap2-nd", "ovl_sort", "seq_dump")),
+                    reason="oracle/_ref not built")
+def test_fused_stage_two_seed_files_matches_reference_programs(tmp_path):
+    """Two seed files + a part file: the five raw_align jobs of nextDenovo:426-467 (the seed1 x seed2 job serves both
+    sorts through its symlink), one sort and one consensus run per seed file.  The fused command's --keep files against
+    the compiled reference programs run job by job, its cns files against the file-based device command on the
+    reference's sorted.ovl."""
+    import refpipe
+    from nextdenovo_amd import correct_stage, synth
+    g = synth.make_genome(70000, seed=41, n_repeats=3, repeat_len=1500)
+    rs = synth.simulate_reads(g, 32, "ont", seed=42, mu=8.7, sigma=0.45, min_len=900)
+    wd = str(tmp_path)
+    fa = os.path.join(wd, "reads.fa")
+    refpipe.write_fasta(fa, [synth.codes_to_ascii(s) for s in rs.seqs])
+    fofn = os.path.join(wd, "input.fofn")
+    with open(fofn, "w") as f:
+        f.write(fa + "\n")
+    db = os.path.join(wd, "db")
+    os.makedirs(db)
+    R = lambda n: os.path.join(O.REFDIR, n)  # noqa: E731
+    refpipe.run([R("seq_dump"), "-f", "500", "-s", "5000", "-b", "2g", "-n", "2", "-d", db, fofn])
+    s1, s2, p1 = (os.path.join(db, n) for n in ("input.seed.001.2bit", "input.seed.002.2bit", "input.part.001.2bit"))
+    assert os.path.getsize(s2) > 1000 and os.path.getsize(p1) > 1000
+    ra = os.path.join(wd, "ra")
+    os.makedirs(ra)
+    jobs = [(0, s1, p1, True, None), (1, s1, s1, False, "3G"), (2, s1, s2, True, "3G"), (3, s2, p1, True, None), (4, s2, s2, False, "3G")]
+    ref_ovl = {}
+    for k, t, q, dual, batch in jobs:
+        o = os.path.join(ra, "%s.%d.ovl" % (os.path.basename(t), k))
+        cmd = [R("minimap2-nd"), "--step", "1"] + (["-I", batch] if batch else []) + (["--dual=yes"] if dual else []) + \
+            ["-t", "8", "-x", "ava-ont", t, q, "-o", o]
+        refpipe.run(cmd)
+        ref_ovl[k] = o
+    keep = os.path.join(wd, "keep")
+    out = os.path.join(wd, "cns")
+    assert correct_stage.run(["-d", db, "-x", "ava-ont", "-k", "30", "-r", "ont", "-min_len_seed", "2500", "-p", "4", "--keep", keep,
+                              "-o", out]) == 0
+    for k, t, q, dual, batch in jobs:
+        mine = os.path.join(keep, os.path.basename(ref_ovl[k]))
+        assert os.path.getsize(ref_ovl[k]) > 5000 and open(mine, "rb").read() == open(ref_ovl[k], "rb").read(), "job %d" % k
+    idxs = os.path.join(wd, "idxs.fofn")
+    with open(idxs, "w") as f:
+        for n in sorted(os.listdir(db)):
+            if n.startswith(".input.") and n.endswith(".idx"):
+                f.write(os.path.join(db, n) + "\n")
+    for tag, ks in (("001", (0, 1, 2)), ("002", (2, 3, 4))):
+        with open(os.path.join(ra, "in%s.fofn" % tag), "w") as f:
+            f.write("\n".join(ref_ovl[k] for k in ks) + "\n")
+        refpipe.run([R("ovl_sort"), "-m", "2g", "-t", "4", "-k", "30", "-i", os.path.join(db, ".input.seed.%s.idx" % tag),
+                     "-o", "ref.%s.sorted.ovl" % tag, "in%s.fofn" % tag], cwd=ra)
+        so_ref = os.path.join(ra, "ref.%s.sorted.ovl" % tag)
+        so = os.path.join(keep, "input.seed.%s.sorted.ovl" % tag)
+        assert os.path.getsize(so_ref) > 10000 and open(so, "rb").read() == open(so_ref, "rb").read()
+        assert open(so + ".bl").read() == open(so_ref + ".bl").read()
+        file_out = os.path.join(wd, "file.%s.fasta" % tag)
+        cmd = [sys.executable, "-m", "nextdenovo_amd.nextcorrect", "-f", idxs, "-i", so_ref, "-r", "ont", "-p", "4", "-min_len_seed", "2500",
+               "-o", file_out]
+        r = subprocess.run(cmd, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert os.path.getsize(file_out) > 50000
+        assert open(out + ".%s.fasta" % tag, "rb").read() == open(file_out, "rb").read()
+        assert open(out + ".%s.fasta.idx" % tag, "rb").read() == open(file_out + ".idx", "rb").read()
