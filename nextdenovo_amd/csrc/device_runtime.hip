@@ -847,6 +847,18 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             (void)hipEventElapsedTime(&t_back, S.evs[7], S.evs[4]);
             uint32_t longest = 0;
             for (size_t p = 0; p < np; p++) longest = std::max(longest, piles[p].seed_len);
+#ifdef NDGPU_K10_PROF
+            {
+                unsigned long long b[4] = {0, 0, 0, 0}, cols = 0;
+                for (size_t p = 0; p < np; p++) {
+                    for (int k = 0; k < 4; k++) b[k] += piles[p].prof[k];
+                    cols += piles[p].seed_len;
+                }
+                if (cols)
+                    fprintf(stderr, "[ndgpu k10prof] %zu piles %llu positions | cycles per position: loader %.0f scorer %.0f folder %.0f total %.0f\n",
+                            np, cols, (double)b[0] / cols, (double)b[1] / cols, (double)b[2] / cols, (double)b[3] / cols);
+            }
+#endif
             fprintf(stderr, "[ndgpu trace] run_main %zu piles longest %u | host prep %.1f align %.1f tags %.1f msa %.1f ms | K9 %.1f K10 %.1f backtrack %.1f ms\n",
                     np, longest, (tp1 - tp0) * 1e-6, (tp2 - tp1) * 1e-6, (tp3 - tp2) * 1e-6, (tp4 - tp3) * 1e-6, t_links, t_score, t_back);
         }

@@ -647,12 +647,19 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
     __syncthreads();
 
     bool stopped = false;
+#ifdef NDGPU_K10_PROF
+    unsigned long long prof_busy = 0;
+    const unsigned long long prof_start = clock64();
+#endif
     // iteration p: loader prepares column p+1 and stores column p-2, scorer scores column p, folder folds column p-1
     for (uint32_t p = 0; p <= L; p++) {
         if (p < L && s_stop[p % 3u]) {  // column p does not fit the LDS tables: the pile goes to the HBM-resident kernel
             stopped = true;
             break;
         }
+#ifdef NDGPU_K10_PROF
+        const unsigned long long prof_t0 = clock64();
+#endif
         if (wave == 1) {
             // (column p+1 first: its commit drains the memory counter, nothing younger than the prefetched loads may be
             // in flight; the stores come after)
@@ -759,11 +766,15 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             if (width) {
                 const ColTab &cur = tab[slot];
                 const LinkAux *aux = s_aux[slot];
-                for (uint32_t d = 0; d < width; d++) {
-                    int32_t best = -10;                  // state of cell b, lanes 0..4
-                    uint32_t bpp = kTagHead, blink = 0;  // best_pp / best_link of cell b
-                    if (lane < 5) {
-                        const uint32_t cst = cur.cstart[d * 6u + b], cn = cur.clen[d * 6u + b];
+                // every (delta, symbol) cell of the column folds its links on its own lane (12 deltas x 5 symbols per pass):
+                // the cells are independent, only the global pick below walks them in order
+                for (uint32_t d0 = 0; d0 < width; d0 += 12u) {
+                    const uint32_t dl = (uint32_t)lane / 5u, d = d0 + dl, cb_ = (uint32_t)lane - dl * 5u;
+                    const uint32_t n_d = width - d0 < 12u ? width - d0 : 12u;
+                    int32_t best = -10;                  // state of cell (d, cb_)
+                    uint32_t bpp = kTagHead, blink = 0;  // best_pp / best_link of the cell
+                    if (dl < n_d) {
+                        const uint32_t cst = cur.cstart[d * 6u + cb_], cn = cur.clen[d * 6u + cb_];
                         int32_t via = kNoScore, via_next = kNoScore;
                         for (uint32_t m0 = 0; m0 < cn; m0 += 4) {  // 4 links per LDS round trip
                             int32_t a_sc[4], a_impr[4], a_ns[4], a_scm[4];
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
                                 if (m0 + (uint32_t)u < cn) {
                                     const uint32_t pb = tag_base(a_pp[u]);
                                     if (a_impr[u] != kNoScore) via_next = a_impr[u];
-                                    if (a_ns[u] > via && (pb == 4u || pb == b)) {
+                                    if (a_ns[u] > via && (pb == 4u || pb == cb_)) {
                                         via = a_ns[u];
                                         best = a_scm[u];
                                         bpp = a_pp[u], blink = a_cnt[u];
@@ -794,22 +805,32 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
                                 }
                             }
                         }
-                        s_bpp[sl][d * 6u + b] = bpp;
-                        s_blink[sl][d * 6u + b] = blink;
+                        s_bpp[sl][d * 6u + cb_] = bpp;
+                        s_blink[sl][d * 6u + cb_] = blink;
                     }
-                    for (int bb = 0; bb < 5; bb++) {  // global pick in symbol order (lib/nextcorrect.c:2194-2199)
-                        const int32_t v = __builtin_amdgcn_readlane(best, bb);
+                    const int n_act = (int)(n_d * 5u);
+                    for (int l = 0; l < n_act; l++) {  // global pick in (delta, symbol) order (lib/nextcorrect.c:2194-2199)
+                        const int32_t v = __builtin_amdgcn_readlane(best, l);
                         if (v >= gbest - 3000) {
                             o_t = (int32_t)q;
-                            o_db = (d << 3) | (uint32_t)bb;
+                            o_db = ((d0 + (uint32_t)l / 5u) << 3) | ((uint32_t)l % 5u);
                             if (v > gbest) gbest = v;
                         }
                     }
                 }
             }
         }
+#ifdef NDGPU_K10_PROF
+        prof_busy += clock64() - prof_t0;
+#endif
         __syncthreads();
     }
+#ifdef NDGPU_K10_PROF
+    if (lane == 0) {
+        P.prof[wave == 1 ? 0 : wave == 0 ? 1 : 2] = prof_busy;
+        if (wave == 0) P.prof[3] = clock64() - prof_start;
+    }
+#endif
     if (wave == 1) {
         if (!stopped) {  // columns L-2 was stored in the last iteration (p = L); L-1 is left
             if (L >= 1) store_results(L - 1u);

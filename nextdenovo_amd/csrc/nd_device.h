@@ -97,6 +97,9 @@ struct PileDev {
     uint32_t origin_db;     // delta << 3 | base
     uint32_t err;           // nonzero: device-side capacity error
     uint32_t n_links;       // distinct (pp,ppp) links of the pile (written by the scoring kernel)
+#ifdef NDGPU_K10_PROF
+    unsigned long long prof[4];  // busy cycles of the loader / scorer / folder wave and the kernel's total (NDGPU_TRACE prints them)
+#endif
 };
 
 struct PathItem {           // one visited cell of the best_pp walk (origin first)
