@@ -150,6 +150,8 @@ struct DeviceAligner::State {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t trace_budget_bytes = (size_t)48 << 30;
     int host_threads = 1;
+    bool k9_full_capacity = getenv("NDGPU_K9_FULL") != nullptr;  // skip the small-capacity first attempt of K9
+    uint64_t k9_retries = 0;
 };
 
 static int g_ctx_creating = -1;  // index of the context under construction (guarded by g_ctx_mu)
@@ -792,36 +794,47 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_ent_score.reserve(ents + 1);
     S.d_path.reserve(paths + 1);
     S.d_blocks.reserve(blocks.size() + 1);
-    HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(S.d_blocks.p, blocks.data(), blocks.size() * sizeof(ColBlock), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipEventRecord(S.evs[2], st));
-    launch_count_links(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_blocks.p, S.d_tags.p, S.d_colidx.p, S.d_insmax.p,
-                       S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
-                       S.d_ent_cnt.p, S.d_err.p, (int)blocks.size(), st);
-    HIP_CHECK(hipEventRecord(S.evs[3], st));
-    // a sub-batch small enough for the reserved compute units (4 two-wave blocks each) scores there
-    const bool on_reserved = S.lat_stream && np <= (size_t)S.reserved_cus * 2;
-    hipStream_t sst = on_reserved ? S.lat_stream : st;
-    if (on_reserved) {
-        HIP_CHECK(hipEventRecord(S.ev_lat0, st));
-        HIP_CHECK(hipStreamWaitEvent(sst, S.ev_lat0, 0));
-        HIP_CHECK(hipEventRecord(S.evs[3], sst));
-    }
-    launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p,
-                           S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
-                           S.d_cell_blink.p, S.d_path.p, (int)np, sst, S.evs[7]);
-    HIP_CHECK(hipEventRecord(S.evs[4], sst));
-    if (on_reserved) {
-        HIP_CHECK(hipEventRecord(S.ev_lat1, sst));
-        HIP_CHECK(hipStreamWaitEvent(st, S.ev_lat1, 0));
-    }
     std::vector<PathItem> hpath(paths + 1);
+    std::vector<PileDev> piles_out(np);
     uint32_t herr[4] = {0, 0, 0, 0};
-    HIP_CHECK(hipMemcpyAsync(piles.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(hpath.data(), S.d_path.p, paths * sizeof(PathItem), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(herr, S.d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    HIP_CHECK(hipGetLastError());
+    // attempt 0 counts links with the small LDS lists; a cell with more distinct links than they hold raises err[0] and the
+    // sub-batch is counted and scored again with the full capacity (everything the kernels write is rewritten)
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
+        if (attempt) HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
+        HIP_CHECK(hipEventRecord(S.evs[2], st));
+        launch_count_links(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_blocks.p, S.d_tags.p, S.d_colidx.p, S.d_insmax.p,
+                           S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
+                           S.d_ent_cnt.p, S.d_err.p, (int)blocks.size(), attempt != 0 || S.k9_full_capacity, st);
+        HIP_CHECK(hipEventRecord(S.evs[3], st));
+        // a sub-batch small enough for the reserved compute units (4 two-wave blocks each) scores there
+        const bool on_reserved = S.lat_stream && np <= (size_t)S.reserved_cus * 2;
+        hipStream_t sst = on_reserved ? S.lat_stream : st;
+        if (on_reserved) {
+            HIP_CHECK(hipEventRecord(S.ev_lat0, st));
+            HIP_CHECK(hipStreamWaitEvent(sst, S.ev_lat0, 0));
+            HIP_CHECK(hipEventRecord(S.evs[3], sst));
+        }
+        launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p,
+                               S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
+                               S.d_cell_blink.p, S.d_path.p, (int)np, sst, S.evs[7]);
+        HIP_CHECK(hipEventRecord(S.evs[4], sst));
+        if (on_reserved) {
+            HIP_CHECK(hipEventRecord(S.ev_lat1, sst));
+            HIP_CHECK(hipStreamWaitEvent(st, S.ev_lat1, 0));
+        }
+        HIP_CHECK(hipMemcpyAsync(piles_out.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(hpath.data(), S.d_path.p, paths * sizeof(PathItem), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(herr, S.d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipGetLastError());
+        static const bool force_retry = getenv("NDGPU_K9_FORCE_RETRY") != nullptr;  // test hook: take the overflow path
+        if ((!herr[0] && !force_retry) || attempt || S.k9_full_capacity) break;
+        S.k9_retries++;
+        if (getenv("NDGPU_TRACE")) fprintf(stderr, "[ndgpu trace] K9: a cell holds more than %d distinct links, sub-batch repeated with %d\n", kLinkCapSmall, kLinkCap);
+    }
+    piles.swap(piles_out);
     uint64_t tp4 = wall_ns();
     g_prof.m_msa += tp4 - tp3;
     if (herr[0]) {

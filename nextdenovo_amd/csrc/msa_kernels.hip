@@ -240,6 +240,10 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
 }
 
 // ---- K9 --------------------------------------------------------------------------
+// CAP = links per cell the LDS lists hold.  The launch tries the small capacity first (4.6 KB of LDS per wavefront instead
+// of 13.8 KB: the kernel is latency-bound and lives on resident wavefronts); a cell that overflows raises err[0] and the
+// host repeats the sub-batch with kLinkCap.
+template <int CAP>
 __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restrict__ piles,
                                                           const ReadDev *__restrict__ reads,
                                                           const uint32_t *__restrict__ acc_list,
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                                                           uint32_t *__restrict__ cell_len, uint32_t *__restrict__ ent_pp,
                                                           uint32_t *__restrict__ ent_ppp, uint32_t *__restrict__ ent_cnt,
                                                           uint32_t *__restrict__ err) {
-    __shared__ uint32_t l_pp[6][kLinkCap], l_ppp[6][kLinkCap], l_cnt[6][kLinkCap];
+    __shared__ uint32_t l_pp[6][CAP], l_ppp[6][CAP], l_cnt[6][CAP];
     const ColBlock B = blocks[blockIdx.x];
     const PileDev P = piles[B.pile];
     const int lane = (int)threadIdx.x;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
 
     // Per-lane read descriptors of the first kRegChunks x 64 accepted reads stay in registers for
     // the whole column block; deeper piles reload the rest from HBM.
-    constexpr int kRegChunks = 3;
+    constexpr int kRegChunks = 2;
     uint32_t g_ts[kRegChunks], g_te[kRegChunks], g_len[kRegChunks];
     const uint32_t *g_ci[kRegChunks];
     const uint32_t *g_tg[kRegChunks];
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                         const bool in_rem = (rem >> lane) & 1ull;
                         const unsigned long long same = __ballot(in_rem && pp == kp && ppp == kpp);
                         if (lane == ld) {
-                            if (n0 < (uint32_t)kLinkCap) {
+                            if (n0 < (uint32_t)CAP) {
                                 l_pp[bb][n0] = pp;
                                 l_ppp[bb][n0] = ppp;
                                 l_cnt[bb][n0] = (uint32_t)__popcll(same);
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                                 atomicExch(err, 1u);
                             }
                         }
-                        n0 = n0 < (uint32_t)kLinkCap ? n0 + 1 : n0;
+                        n0 = n0 < (uint32_t)CAP ? n0 + 1 : n0;
                         rem &= ~same;
                     }
                     n_cell[bb] = n0;
@@ -500,7 +504,6 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
     __builtin_amdgcn_s_setprio(3);  // latency-bound waves: issue priority over co-resident kernels
     const int wave = (int)(threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
-    const uint32_t b = (uint32_t)lane;
     const uint32_t L = P.seed_len;
     const uint32_t *cov = coverage + P.col_off;
     const uint32_t *ms = max_size + P.col_off;
@@ -1121,11 +1124,16 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
                         const uint32_t *tags, const uint32_t *colidx, const uint32_t *max_size,
                         const uint32_t *cell_base, const uint32_t *ent_base, uint32_t *cell_start, uint32_t *cell_len,
                         uint32_t *ent_pp, uint32_t *ent_ppp, uint32_t *ent_cnt, uint32_t *err, int n_blocks,
-                        void *stream) {
+                        bool full_capacity, void *stream) {
     if (n_blocks <= 0) return;
-    hipLaunchKernelGGL(count_links_kernel, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, piles, reads,
-                       acc_list, blocks, tags, colidx, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp,
-                       ent_ppp, ent_cnt, err);
+    if (full_capacity)
+        hipLaunchKernelGGL(count_links_kernel<kLinkCap>, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, piles, reads,
+                           acc_list, blocks, tags, colidx, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp,
+                           ent_ppp, ent_cnt, err);
+    else
+        hipLaunchKernelGGL(count_links_kernel<kLinkCapSmall>, dim3((unsigned)n_blocks), dim3(64), 0, (hipStream_t)stream, piles,
+                           reads, acc_list, blocks, tags, colidx, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp,
+                           ent_ppp, ent_cnt, err);
 }
 
 void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,

@@ -127,7 +127,8 @@ struct RegionDev {          // low-quality region whose candidate strings are wa
 };
 
 constexpr int kColBlock = 32;          // columns per link-counting work item
-constexpr int kLinkCap = 192;          // distinct (pp,ppp) links per cell held in LDS
+constexpr int kLinkCap = 192;          // distinct (pp,ppp) links per cell held in LDS (<= 1.5 x max_cov_aln reads reach a cell)
+constexpr int kLinkCapSmall = 64;      // capacity of the first attempt of the link-counting kernel
 
 void launch_shift_scan(const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops, ReadDev *reads, int n_reads,
                        void *stream);
@@ -142,7 +143,7 @@ void launch_col_scan(PileDev *piles, uint32_t *cov_diff, const uint32_t *ins_cou
 void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const ColBlock *blocks,
                         const uint32_t *tags, const uint32_t *colidx, const uint32_t *max_size,
                         const uint32_t *cell_base, const uint32_t *ent_base, uint32_t *cell_start, uint32_t *cell_len,
-                        uint32_t *ent_pp, uint32_t *ent_ppp, uint32_t *ent_cnt, uint32_t *err, int n_blocks,
+                        uint32_t *ent_pp, uint32_t *ent_ppp, uint32_t *ent_cnt, uint32_t *err, int n_blocks, bool full_capacity,
                         void *stream);
 void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,
                             const uint32_t *cell_base, const uint32_t *ent_base, const uint32_t *cell_start,

@@ -10,6 +10,7 @@ import refpipe
 import util
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.fixture(scope="module")
@@ -145,6 +146,40 @@ def test_hifi_db_path_equals_ascii_path_and_host_oracle(lib, host_harness):
                                            fast=0, split=0))
         assert a[0] == g_[0] == c[0] and a[0] > 1000
         assert a[2] == g_[2] == c[2]
+
+
+def test_deep_piles_and_link_capacity_retry(lib, host_harness):
+    """Depth-170 piles (more reads than K9 keeps register-resident, up to the 1.5 x max_cov_aln admission limit) against
+    the host engine + oracle, and the same piles through K9's overflow path (small LDS link lists -> full capacity)."""
+    import subprocess
+    import sys
+    from nextdenovo_amd import api, synth
+    rs, piles = _synth_set(12000, 8.0, 0.3, 81, depth=170)
+    piles = sorted(piles, key=lambda p: -len(p["recs"]))[:3]
+    assert len(piles[0]["recs"]) > 140
+    fn, fr = util.bind_correct(host_harness, "ndtest_correct", "ndtest_free")
+    want = []
+    for p in piles:
+        seqs, st, en, mal = synth.pile_sequences(rs, p)
+        mlq = min(en[0] // 2, 10000)
+        a = api.correct(seqs, st, en, mal, max_lq_length=mlq)
+        c = util.call_correct(fn, fr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal, max_lq=mlq, read_type=1,
+                                           fast=0, split=0))
+        assert a[0] == c[0] and a[2] == c[2] and a[0] > 1000
+        want.append((a[0], a[2]))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_gpu_parity import _synth_set\nfrom nextdenovo_amd import api, synth\n"
+            "rs, piles = _synth_set(12000, 8.0, 0.3, 81, depth=170)\n"
+            "piles = sorted(piles, key=lambda p: -len(p['recs']))[:3]\n"
+            "for p in piles:\n"
+            "    seqs, st, en, mal = synth.pile_sequences(rs, p)\n"
+            "    a = api.correct(seqs, st, en, mal, max_lq_length=min(en[0] // 2, 10000))\n"
+            "    print(a[0], a[2].decode())\n") % (HERE, os.path.dirname(HERE))
+    env = dict(os.environ, NDGPU_K9_FORCE_RETRY="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [ln.split() for ln in r.stdout.strip().splitlines()]
+    assert [(int(a), b.encode()) for a, b in got] == want
 
 
 def test_full_size_properties(lib, host_harness):
