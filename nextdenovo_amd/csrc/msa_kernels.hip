@@ -459,15 +459,19 @@ __device__ __forceinline__ long long shfl_i64(long long v, int src) {
 //   * scores are int32 here (a 10^6-column seed at depth 200 stays below 2^31); any pile
 //     that gets near the limit, or whose columns exceed the LDS tables, is redone by the
 //     int64 HBM-resident kernel below.
-constexpr int kColCells = 192;  // max_size <= 32 per column
-constexpr int kColEnts = 512;   // links per column
+// LDS table capacities of the fast kernel, two tiers: every pile first runs with the small tables (25 KB per pile: 6 piles
+// resident per compute unit instead of 3); a pile with a column that does not fit them is redone with the large ones, and
+// one that does not fit those either (or whose int32 scores get near the limit) by the HBM-resident kernel.
+constexpr int kColCellsSmall = 96, kColEntsSmall = 256;   // max_size <= 16, <= 256 link slots per column
+constexpr int kColCells = 192, kColEnts = 512;            // max_size <= 32, <= 512 link slots per column
 constexpr int32_t kNoScore = INT32_MIN;
 constexpr int32_t kScoreGuard = 1 << 30;
 
+template <int CELLS, int ENTS>
 struct ColTab {
-    uint32_t cstart[kColCells];
-    uint32_t clen[kColCells];
-    uint2 ps[kColEnts];  // per link: x = pp tag, y = score (int32 bits) -- one 8-byte LDS access for both
+    uint32_t cstart[CELLS];
+    uint32_t clen[CELLS];
+    uint2 ps[ENTS];  // per link: x = pp tag, y = score (int32 bits) -- one 8-byte LDS access for both
 };
 
 // per-link operands of the column being scored, one 16-byte LDS access: before a link is scored
@@ -486,21 +490,24 @@ struct LinkAux {
 //   folder (wave 2), one column behind: the five symbol cells of every step fold their links with the reference's
 //     sequential tie-break rules (lib/nextcorrect.c:2164-2192) and the global pick (:2194-2199) is updated -- nothing a
 //     later score depends on, so it is off the chain.
+template <int CELLS, int ENTS, bool REDO>
 __global__ __launch_bounds__(192) void score_fast_kernel(
     PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
     const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ ent_base,
     const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_len,
     const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp, const uint32_t *__restrict__ ent_cnt,
     uint32_t *__restrict__ cell_best_pp, uint32_t *__restrict__ cell_best_link) {
-    __shared__ ColTab tab[3];                                          // columns p-1, p, p+1 (slot = column mod 3)
-    __shared__ __attribute__((aligned(16))) LinkAux s_aux[3][kColEnts];  // same slots
-    __shared__ uint32_t s_bpp[2][kColCells], s_blink[2][kColCells];      // slot = column & 1
+    using Tab = ColTab<CELLS, ENTS>;
+    __shared__ Tab tab[3];                                          // columns p-1, p, p+1 (slot = column mod 3)
+    __shared__ __attribute__((aligned(16))) LinkAux s_aux[3][ENTS];  // same slots
+    __shared__ uint32_t s_bpp[2][CELLS], s_blink[2][CELLS];      // slot = column & 1
     __shared__ uint32_t s_meta[2][5][64];                       // width, cell0, e0, ecap, coverage of 2 x 64 columns
     __shared__ uint32_t s_colw[3], s_colc0[3], s_stop[3];       // per prepared column: width, first cell, "does not fit"
     __shared__ uint32_t s_links, s_sc_ovf;
     __shared__ int32_t s_ot;
     __shared__ uint32_t s_odb;
     PileDev &P = piles[blockIdx.x];
+    if (REDO && P.err != 3) return;  // second tier: only the piles the small tables could not hold
     __builtin_amdgcn_s_setprio(3);  // latency-bound waves: issue priority over co-resident kernels
     const int wave = (int)(threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
@@ -557,10 +564,10 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
         const uint32_t width = s_meta[mp][0][ml], cell0 = s_meta[mp][1][ml], e0 = s_meta[mp][2][ml], ecap = s_meta[mp][3][ml];
         const int32_t pen = factor * (int32_t)s_meta[mp][4][ml];
         const uint32_t ncell = width * 6u;
-        const bool fits = ncell <= (uint32_t)kColCells && ecap <= (uint32_t)kColEnts;
+        const bool fits = ncell <= (uint32_t)CELLS && ecap <= (uint32_t)ENTS;
         if (lane == 0) s_colw[slot] = width, s_colc0[slot] = cell0, s_stop[slot] = fits ? 0u : 1u;
-        ColTab &cur = tab[slot];
-        const ColTab &prv = tab[(q + 2u) % 3u];
+        Tab &cur = tab[slot];
+        const Tab &prv = tab[(q + 2u) % 3u];
         LinkAux *aux = s_aux[slot];
         if (fits) {
             if ((uint32_t)lane < ncell) {
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             uint32_t res = 0;
             if (mpp != kTagHead) {
                 const bool same = (uint32_t)tag_tpos(mpp) == q;
-                const ColTab &T = same ? cur : prv;
+                const Tab &T = same ? cur : prv;
                 const uint32_t pc = tag_delta(mpp) * 6u + tag_base(mpp);
                 res = ((uint32_t)same << 31) | (T.cstart[pc] << 12) | T.clen[pc];
             }
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             // than 32 links keep ppp and are scanned by the scorer.
             const uint32_t pn = res & 0xfffu;
             if (mpp != kTagHead && pn <= 32u) {
-                const ColTab &T = (res >> 31) ? cur : prv;
+                const Tab &T = (res >> 31) ? cur : prv;
                 const uint32_t ps = (res >> 12) & 0x7ffffu, mppp = aux[e].a;
                 uint32_t match = 0;
                 for (uint32_t k = 0; k < pn; k++)
@@ -682,8 +689,8 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             const uint32_t slot = p % 3u;
             const uint32_t width = p < L ? s_colw[slot] : 0u;
             if (width) {
-                ColTab &cur = tab[slot];
-                const ColTab &prv = tab[(p + 2u) % 3u];
+                Tab &cur = tab[slot];
+                const Tab &prv = tab[(p + 2u) % 3u];
                 LinkAux *aux = s_aux[slot];
                 uint32_t step_est = 0, step_n = 0;
                 if ((uint32_t)lane < width) {
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
                             if (mpp == kTagHead) {
                                 r_sc = gain;
                             } else {
-                                const ColTab &T = (res >> 31) ? cur : prv;
+                                const Tab &T = (res >> 31) ? cur : prv;
                                 const uint32_t ps = (res >> 12) & 0x7ffffu, pn = res & 0xfffu;
                                 if (pn <= 32u) {
                                     // mppp holds the loader's match mask: visit the matching predecessors in order,
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             const uint32_t q = p - 1u, slot = q % 3u, sl = q & 1u;
             const uint32_t width = s_colw[slot];
             if (width) {
-                const ColTab &cur = tab[slot];
+                const Tab &cur = tab[slot];
                 const LinkAux *aux = s_aux[slot];
                 // every (delta, symbol) cell of the column folds its links on its own lane (12 deltas x 5 symbols per pass):
                 // the cells are independent, only the global pick below walks them in order
@@ -844,9 +851,12 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
     } else if (lane == 0) s_ot = o_t, s_odb = o_db;
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (stopped || s_sc_ovf) {
+        if (stopped && !REDO) {
+            P.err = 3;  // redo this pile with the large tables
+        } else if (stopped || s_sc_ovf) {
             P.err = 2;  // redo this pile in the int64 / HBM-resident kernel
         } else {
+            if (REDO) P.err = 0;
             P.origin_t = s_ot;
             P.origin_db = s_odb;
             P.n_links = s_links;
@@ -1144,8 +1154,11 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
                             void *ev_after_fast) {
     if (n_piles <= 0) return;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)n_piles), dim3(192), 0, st, piles, coverage, max_size,
-                       cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
+    hipLaunchKernelGGL((score_fast_kernel<kColCellsSmall, kColEntsSmall, false>), dim3((unsigned)n_piles), dim3(192), 0, st, piles,
+                       coverage, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
+                       cell_best_link);
+    hipLaunchKernelGGL((score_fast_kernel<kColCells, kColEnts, true>), dim3((unsigned)n_piles), dim3(192), 0, st, piles,
+                       coverage, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
                        cell_best_link);
     if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
     hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
