@@ -95,6 +95,13 @@ int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_f
                        uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
                        uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats);
 
+/* ---- read ingestion: the 2-bit packing of `seq_dump` (seq2bit, lib/bseq.c:114-139; called from util/seq_dump.c:36-41) ----
+ * Read i is the lens[i] ASCII bytes at ascii + ascii_off[i]; its ceil(lens[i]/16) words go to words + word_off[i] (word_off ascending,
+ * reads back to back).  Bytes other than ACGTU (either case) are coded 4 and OR-ed in as the reference does, so they disturb the low
+ * bit of the preceding base.  Returns the number of words written, < 0 on error. */
+int64_t ndgpu_pack_2bit(uint32_t n_reads, const uint8_t *ascii, uint64_t n_bytes, const uint64_t *ascii_off, const uint32_t *lens,
+                        const uint64_t *word_off, uint32_t *words);
+
 /* ---- array-level views used by the parity tests (same library, same kernels) ---- */
 
 /* K1 alone: minimizers of every read; rid_is_index != 0 puts the read index in the high word of y (index

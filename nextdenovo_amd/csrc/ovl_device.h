@@ -64,6 +64,8 @@ void launch_sketch_tiles(bool fill, bool hpc, const uint32_t *words, const uint6
                          const OvlParams &P, int rid_is_index, const uint64_t *tile_off, uint32_t *tile_cnt, uint64_t *out_x, uint64_t *out_y,
                          uint32_t *out_read, hipStream_t s);
 int sketch_tile_symbols();
+void launch_pack_2bit(const uint8_t *ascii, const uint64_t *a_off, const uint32_t *len, const uint64_t *w_off, uint32_t n_reads, uint64_t n_words,
+                      uint32_t *words, hipStream_t s);
 void launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint32_t n, uint64_t *dst, hipStream_t s);
 void launch_shift_keys(const uint64_t *x, uint64_t *key, uint64_t n, hipStream_t s);
 void launch_build_buckets(const uint64_t *ukey, uint64_t n_keys, uint32_t shift, uint32_t *bucket, hipStream_t s);

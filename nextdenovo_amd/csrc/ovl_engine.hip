@@ -728,6 +728,36 @@ int64_t ndgpu_ovl_encode(const ndgpu_ovl_rec *recs, int64_t n, uint32_t prev[2],
 
 void ndgpu_ovl_free(void *p) { free(p); }
 
+int64_t ndgpu_pack_2bit(uint32_t n_reads, const uint8_t *ascii, uint64_t n_bytes, const uint64_t *ascii_off, const uint32_t *lens,
+                        const uint64_t *word_off, uint32_t *words)
+{
+	if (!n_reads) return 0;
+	try {
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { fprintf(stderr, "[ndgpu_overlap] no HIP device\n"); return -1; }
+		int device = 0;
+		if (const char *d = getenv("NDGPU_DEVICE")) device = atoi(d);
+		HIP_OK(hipSetDevice(device));
+		hipStream_t st;
+		HIP_OK(hipStreamCreate(&st));
+		const uint64_t n_words = word_off[n_reads - 1] + ((uint64_t)lens[n_reads - 1] + 15) / 16;
+		{
+			DevBuf<uint8_t> d_a(n_bytes + 16);
+			DevBuf<uint64_t> d_ao(n_reads), d_wo(n_reads);
+			DevBuf<uint32_t> d_len(n_reads), d_w(n_words + 1);
+			d_a.upload(ascii, n_bytes, st); d_ao.upload(ascii_off, n_reads, st); d_wo.upload(word_off, n_reads, st); d_len.upload(lens, n_reads, st);
+			launch_pack_2bit(d_a.p, d_ao.p, d_len.p, d_wo.p, n_reads, n_words, d_w.p, st);
+			HIP_OK(hipGetLastError());
+			d_w.download(words, n_words, st);
+			HIP_OK(hipStreamSynchronize(st));
+		}
+		(void)hipStreamDestroy(st);
+		return (int64_t)n_words;
+	} catch (...) {
+		return -2;
+	}
+}
+
 int64_t ndgpu_ovl_sketch(const ndgpu_ovl_opt *opt, uint32_t n_reads, const uint32_t *words, uint64_t n_words, const uint64_t *word_off,
                          const uint32_t *lens, int rid_is_index, uint64_t **x, uint64_t **y, uint64_t *off)
 {

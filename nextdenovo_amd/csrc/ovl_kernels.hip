@@ -444,6 +444,45 @@ __global__ void gather_u64_kernel(const uint64_t *__restrict__ src, const uint32
 	if (i < n) dst[i] = src[idx[i]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// seq_dump's 2-bit packing (seq2bit, lib/bseq.c:114-139) for a batch of reads: one thread per output word, 16 input
+// bytes each.  A byte that is not ACGTU (either case) has code 4 and is OR-ed in like the others, so its bit 2 lands on
+// the low bit of the base before it (and is lost at the start of a word), exactly as `buffer << 2 | nt_table[c]` does.
+__global__ void pack_2bit_kernel(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ len,
+                                 const uint64_t *__restrict__ w_off, uint32_t n_reads, uint64_t n_words, uint32_t *__restrict__ words)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_words) return;
+	uint32_t lo = 0, hi = n_reads; // last read whose first word is <= w
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (w_off[mid] <= w) lo = mid; else hi = mid; }
+	const uint32_t r = lo, n = len[r];
+	const uint32_t b0 = (uint32_t)(w - w_off[r]) * 16u;
+	const uint8_t *s = ascii + a_off[r] + b0;
+	const uint32_t cnt = n - b0 < 16u ? n - b0 : 16u;
+	uint64_t acc = 0;
+	for (uint32_t j = 0; j < cnt; ++j) {
+		const uint8_t c = s[j];
+		uint32_t code = 4;
+		switch (c) {
+		case 'A': case 'a': code = 0; break;
+		case 'C': case 'c': code = 1; break;
+		case 'G': case 'g': code = 2; break;
+		case 'T': case 't': case 'U': case 'u': code = 3; break;
+		default: break;
+		}
+		acc |= (uint64_t)code << (30 - 2 * (int)j);
+	}
+	words[w] = (uint32_t)acc;
+}
+
+void launch_pack_2bit(const uint8_t *ascii, const uint64_t *a_off, const uint32_t *len, const uint64_t *w_off, uint32_t n_reads, uint64_t n_words,
+                      uint32_t *words, hipStream_t s)
+{
+	if (!n_words) return;
+	hipLaunchKernelGGL(pack_2bit_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, ascii, a_off, len, w_off, n_reads, n_words,
+	                   words);
+}
+
 void launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint32_t n, uint64_t *dst, hipStream_t s)
 {
 	if (n) hipLaunchKernelGGL(gather_u64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, n, dst);

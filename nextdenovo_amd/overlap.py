@@ -61,6 +61,8 @@ def load():
     lib.ndgpu_ovl_index_dump.argtypes = [P, P, P, P]
     lib.ndgpu_ovl_debug_anchors.argtypes = [P, C.c_uint32, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
     lib.ndgpu_ovl_debug_anchors.restype = C.c_int64
+    lib.ndgpu_pack_2bit.argtypes = [C.c_uint32, P, C.c_uint64, P, P, P, P]
+    lib.ndgpu_pack_2bit.restype = C.c_int64
     lib.ndgpu_ovl_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.ndgpu_ovl_reset_stats.argtypes = [P]
     _lib = lib
@@ -181,6 +183,23 @@ class Index:
 
     def reset_stats(self):
         self.lib.ndgpu_ovl_reset_stats(self.h)
+
+
+def pack_2bit(ascii_buf: np.ndarray, ascii_off: np.ndarray, lens: np.ndarray):
+    """seq2bit (lib/bseq.c:114-139) of a batch of reads on the device -> (words uint32, word_off uint64[n])."""
+    lib = load()
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    ascii_off = np.ascontiguousarray(ascii_off, dtype=np.uint64)
+    ascii_buf = np.ascontiguousarray(ascii_buf, dtype=np.uint8)
+    nw = (lens.astype(np.uint64) + np.uint64(15)) // np.uint64(16)
+    word_off = np.zeros(lens.size, dtype=np.uint64)
+    if lens.size:
+        word_off[1:] = np.cumsum(nw)[:-1]
+    words = np.zeros(int(nw.sum()) + 1, dtype=np.uint32)
+    n = lib.ndgpu_pack_2bit(lens.size, _ptr(ascii_buf), ascii_buf.size, _ptr(ascii_off), _ptr(lens), _ptr(word_off), _ptr(words))
+    if n < 0:
+        raise RuntimeError("ndgpu_pack_2bit failed (%d): no usable HIP device?" % n)
+    return words[:n], word_off
 
 
 def encode(recs: np.ndarray, prev: np.ndarray) -> bytes:

@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""`seq_dump` with the 2-bit packing on the MI355X: FASTA/FASTQ[.gz] reads -> `input.{seed,part}.NNN.2bit` + hidden `.idx`.
+
+Takes the command line nextDenovo writes for the db_split task (reference nextDenovo:536-551, util/seq_dump.c:168-252):
+
+    python -m nextdenovo_amd.seq_dump -f 1k -s 10k -b 2g -n 2 -d 01.raw_align input.fofn
+
+and writes byte-identical files: reads shorter than -f are dropped, reads in [-f, -s) go to part files (a new file
+whenever the running length exceeds -b), reads of at least -s (and shorter than 1,000,000) are dealt round-robin to the
+-n seed files, ids are assigned in input order over both kinds (util/seq_dump.c:74-114); every read is stored as
+`u32 id, u32 len, ceil(len/16) u32` with 16 bases per word, first base in the top bits (lib/bseq.c:114-139), and indexed
+as `id \\t offset + 8 \\t len` (util/seq_dump.c:36-41).  Parsing follows kseq.h (multi-line FASTA / FASTQ, `\\r\\n`,
+a FASTQ record whose quality length differs from its sequence length ends the file).  The packing of each input file's
+reads is one device launch (`ndgpu_pack_2bit`); there is no CPU packing path.
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import sys
+
+import numpy as np
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nextdenovo_amd import overlap  # noqa: E402
+
+LEN_LIMIT = 1000000  # util/seq_dump.c:13
+
+
+def parse_num(s: str) -> int:
+    """mm_parse_num of util/seq_dump.c:150-159 (strtod + K/M/G suffix)."""
+    import re
+    m = re.match(r"\s*([-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?))", s)
+    x = float(m.group(1)) if m else 0.0
+    rest = s[m.end():] if m else s
+    if rest[:1] in ("G", "g"):
+        x *= 1e9
+    elif rest[:1] in ("M", "m"):
+        x *= 1e6
+    elif rest[:1] in ("K", "k"):
+        x *= 1e3
+    return int(x + .499)
+
+
+def read_records(path: str):
+    """kseq_read over one file (lib/kseq.h:180-222): returns (buffer uint8, [(offset, length)]) -- the sequences are
+    copied back to back into the buffer, line breaks removed."""
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    opener = gzip.open if magic == b"\x1f\x8b" else open
+    with opener(path, "rb") as f:
+        data = f.read()
+    out = bytearray()
+    recs = []
+    n = len(data)
+    pos = 0
+
+    def line_end(p):
+        e = data.find(b"\n", p)
+        return n if e < 0 else e
+
+    # find the first header
+    while pos < n and data[pos] not in (0x3e, 0x40):  # '>' '@'
+        pos += 1
+    while pos < n:
+        e = line_end(pos)            # header line (name / comment are not used by seq_dump)
+        pos = min(e + 1, n)
+        start = len(out)
+        c = -1
+        while pos < n:               # sequence lines until a line that starts with '>', '+' or '@'
+            c = data[pos]
+            if c in (0x3e, 0x2b, 0x40):
+                break
+            if c == 0x0a:
+                pos += 1
+                c = -1
+                continue
+            e = line_end(pos)
+            line = data[pos:e]
+            if line.endswith(b"\r"):
+                line = line[:-1]
+            out += line
+            pos = min(e + 1, n)
+            c = -1
+        seq_len = len(out) - start
+        if c != 0x2b:                # FASTA record (or end of file)
+            recs.append((start, seq_len))
+            if c == -1:
+                break
+            continue                 # pos sits on the next header
+        # FASTQ: skip the '+' line, read quality lines until they cover the sequence
+        e = line_end(pos)
+        pos = min(e + 1, n)
+        qual_len = 0
+        got_line = False
+        while pos < n or not got_line:
+            if pos >= n:
+                break
+            e = line_end(pos)
+            line = data[pos:e]
+            if line.endswith(b"\r"):
+                line = line[:-1]
+            qual_len += len(line)
+            pos = min(e + 1, n)
+            got_line = True
+            if qual_len >= seq_len:
+                break
+        if qual_len != seq_len:      # kseq_read returns -2: the caller's loop stops, the record is not used
+            del out[start:]
+            break
+        recs.append((start, seq_len))
+        while pos < n and data[pos] not in (0x3e, 0x40):   # next header (last_char == 0: scan for it)
+            pos += 1
+    return np.frombuffer(bytes(out), dtype=np.uint8), recs
+
+
+class _Out:
+    def __init__(self, prefix2, prefix_idx, cnt):
+        self.f2 = open("%s%03d.2bit" % (prefix2, cnt), "wb")
+        self.fi = open("%s%03d.idx" % (prefix_idx, cnt), "w")
+        self.f2.write(bytes([0, 254]))   # init_seq_mode (lib/bseq.c:93-97)
+        self.offset = 2
+        self.length = 0
+
+    def put(self, rid, n, words):
+        self.fi.write("%u\t%u\t%u\n" % (rid, self.offset + 8, n))
+        self.f2.write(np.asarray([rid, n], dtype=np.uint32).tobytes())
+        self.f2.write(words.tobytes())
+        self.offset += 8 + 4 * words.size
+
+    def close(self):
+        self.f2.close()
+        self.fi.close()
+
+
+def run(argv) -> int:
+    import getopt
+    opts, args = getopt.getopt(argv, "f:s:b:n:d:")
+    o = dict(opts)
+    if len(args) < 1 or "-d" not in o or "-n" not in o or "-s" not in o or "-f" not in o:
+        sys.stderr.write("Usage: seq_dump -f min_read_len -s min_seed_len -b block_size -n seed_files -d outdir input.fofn\n")
+        return 1
+    flt, seed_flt = parse_num(o["-f"]), parse_num(o["-s"])
+    if seed_flt <= flt:
+        sys.stderr.write("Error! Seed filter length should be larger than filter length!\n")
+        return 1
+    block = parse_num(o.get("-b", "0")) or (1 << 64) - 1
+    seed_n = int(o["-n"])
+    d = o["-d"]
+    os.makedirs(d, exist_ok=True)
+    part_pre, part_idx = os.path.join(d, "input.part."), os.path.join(d, ".input.part.")
+    seed_pre, seed_idx = os.path.join(d, "input.seed."), os.path.join(d, ".input.seed.")
+    seeds = [_Out(seed_pre, seed_idx, i + 1) for i in range(seed_n)]
+    part_cnt = 1
+    part = _Out(part_pre, part_idx, part_cnt)
+    next_id, seed_cnt = 0, 1
+    fofn = args[0]
+    base = os.path.dirname(fofn) or "."
+    with open(fofn) as f:
+        lines = f.read().split("\n")
+    for line in lines:
+        if len(line) == 0 or line.startswith("#"):
+            continue
+        path = line if line.startswith("/") else os.path.join(base, line)
+        buf, recs = read_records(path)
+        keep = [(s, l) for s, l in recs if (flt <= l < seed_flt) or (seed_flt <= l < LEN_LIMIT)]
+        if not keep:
+            continue
+        a_off = np.asarray([s for s, _ in keep], dtype=np.uint64)
+        lens = np.asarray([min(l, LEN_LIMIT) for _, l in keep], dtype=np.uint32)   # convert_2bit truncates (seq_dump.c:38)
+        words, w_off = overlap.pack_2bit(buf, a_off, lens)                         # one device launch per input file
+        for k, (_, l) in enumerate(keep):
+            n = int(lens[k])
+            w = words[int(w_off[k]): int(w_off[k]) + (n + 15) // 16]
+            if l < seed_flt:
+                part.length += l
+                if part.length > block:
+                    part.close()
+                    part_cnt += 1
+                    part = _Out(part_pre, part_idx, part_cnt)
+                    part.length = l
+                part.put(next_id, n, w)
+            else:
+                if seed_cnt > seed_n:
+                    seed_cnt = 1
+                seeds[seed_cnt - 1].put(next_id, n, w)
+                seeds[seed_cnt - 1].length += l
+                seed_cnt += 1
+            next_id += 1
+    for s in seeds:
+        s.close()
+    part.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(run(sys.argv[1:]))

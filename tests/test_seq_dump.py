@@ -1,0 +1,113 @@
+"""`seq_dump` drop-in (nextdenovo_amd/seq_dump.py): the kseq-faithful parser on the CPU, the whole command (2-bit packing on the
+device through `ndgpu_pack_2bit`) against the compiled reference `seq_dump` on the GPU box."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
+
+
+def _make_inputs(d):
+    """Three input files that exercise the parser: multi-line FASTA with lower case / N / CRLF / empty lines, FASTQ whose
+    quality lines start with '@' and '+', a gzip'd FASTA; lengths on both sides of the two cut-offs."""
+    rng = np.random.default_rng(5)
+
+    def seq(n, alphabet="ACGT"):
+        return "".join(rng.choice(list(alphabet), n))
+
+    recs1 = [seq(n) for n in (50, 700, 1200, 1203, 5000, 4999, 2333, 16, 17, 9000, 640, 15999)]
+    recs1[3] = recs1[3][:400] + "NNNN" + recs1[3][404:600].lower() + "RYK" + recs1[3][603:]
+    recs1[5] = "N" + recs1[5][1:-1] + "N"
+    p1 = os.path.join(d, "a.fa")
+    with open(p1, "w", newline="") as f:
+        f.write("junk before the first header\n")
+        for i, s in enumerate(recs1):
+            f.write(">r%d some comment\n" % i)
+            w = (60, 80, 10 ** 6)[i % 3]
+            for k in range(0, len(s), w):
+                f.write(s[k:k + w] + ("\r\n" if i % 4 == 1 else "\n"))
+            if i % 5 == 0:
+                f.write("\n")
+    recs2 = [seq(n) for n in (800, 3100, 450, 7000, 2999, 3000)]
+    p2 = os.path.join(d, "b.fq")
+    with open(p2, "w") as f:
+        for i, s in enumerate(recs2):
+            q = "".join(rng.choice(list("@+>IJK#5"), len(s)))
+            q = ("@" if i % 2 == 0 else "+") + q[1:]
+            f.write("@q%d\n%s\n+q%d\n" % (i, s, i))
+            if i == 3:   # quality over two lines
+                f.write(q[:100] + "\n" + q[100:] + "\n")
+            else:
+                f.write(q + "\n")
+    recs3 = [seq(n, "ACGTacgtN") for n in (2500, 999, 1000, 60000)]
+    p3 = os.path.join(d, "c.fa.gz")
+    with gzip.open(p3, "wt") as f:
+        for i, s in enumerate(recs3):
+            f.write(">g%d\n%s\n" % (i, s))
+    fofn = os.path.join(d, "input.fofn")
+    with open(fofn, "w") as f:
+        f.write("# comment line\n%s\nb.fq\n\nc.fa.gz\n" % p1)   # absolute and fofn-relative paths
+    return fofn, [recs1, recs2, recs3]
+
+
+def test_parser_follows_kseq(tmp_path):
+    from nextdenovo_amd import seq_dump
+    fofn, recs = _make_inputs(str(tmp_path))
+    for name, want in zip(("a.fa", "b.fq", "c.fa.gz"), recs):
+        buf, got = seq_dump.read_records(str(tmp_path / name))
+        assert [l for _, l in got] == [len(s) for s in want]
+        for (s0, l), s in zip(got, want):
+            assert buf[s0:s0 + l].tobytes().decode() == s
+    # quality lines are read until they cover the sequence, whatever they start with; a record whose quality stays short
+    # ends the file (kseq_read returns -2)
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@a\nACGT\n+\nIIII\n@b\nACGTACGT\n+\nIII\n@c\nAC\n+\nII\n")
+    _, got = seq_dump.read_records(str(bad))
+    assert [l for _, l in got] == [4, 8]          # "III" + "@c" + "AC" + "+" = 8 quality characters
+    bad.write_text("@a\nACGT\n+\nIIII\n@b\nACGTACGT\n+\nIII\n")
+    _, got = seq_dump.read_records(str(bad))
+    assert [l for _, l in got] == [4]
+    assert seq_dump.parse_num("1k") == 1000 and seq_dump.parse_num("2.5g") == 2500000000 and seq_dump.parse_num("750") == 750
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "seq_dump")), reason="oracle/_ref not built")
+def test_parser_lengths_match_reference_idx(tmp_path):
+    """The compiled reference seq_dump on the same files: ids, offsets and lengths of its .idx files (no device needed)."""
+    from nextdenovo_amd import seq_dump
+    fofn, _ = _make_inputs(str(tmp_path))
+    ref = tmp_path / "ref"
+    subprocess.run([os.path.join(REFDIR, "seq_dump"), "-f", "1k", "-s", "3k", "-b", "6k", "-n", "2", "-d", str(ref), fofn], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lens = {}
+    for n in os.listdir(ref):
+        if n.endswith(".idx"):
+            for line in open(ref / n):
+                i, _, ln = line.split("\t")
+                lens[int(i)] = int(ln)
+    mine = []
+    for name in ("a.fa", "b.fq", "c.fa.gz"):
+        _, got = seq_dump.read_records(str(tmp_path / name))
+        mine += [l for _, l in got if 1000 <= l < 1000000]
+    assert [lens[i] for i in sorted(lens)] == mine and len(mine) >= 12
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "seq_dump")), reason="oracle/_ref not built")
+@pytest.mark.parametrize("argv", [("-f", "1k", "-s", "3k", "-b", "6k", "-n", "2"), ("-f", "500", "-s", "1001", "-b", "0", "-n", "3"),
+                                  ("-f", "16", "-s", "2.5k", "-b", "1g", "-n", "1")])
+def test_seq_dump_files_equal_reference(tmp_path, argv):
+    from nextdenovo_amd import seq_dump
+    fofn, _ = _make_inputs(str(tmp_path))
+    ref, mine = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([os.path.join(REFDIR, "seq_dump"), *argv, "-d", ref, fofn], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    assert seq_dump.run([*argv, "-d", mine, fofn]) == 0
+    names = sorted(os.listdir(ref))
+    assert names == sorted(os.listdir(mine)) and len(names) >= 4
+    for n in names:
+        assert open(os.path.join(ref, n), "rb").read() == open(os.path.join(mine, n), "rb").read(), n
