@@ -119,7 +119,8 @@ static std::mutex g_db_mu;
 struct DeviceAligner::State {
     int device = 0;
     hipStream_t stream = nullptr, lat_stream = nullptr;  // lat_stream: reserved compute units (see the constructor)
-    hipEvent_t ev_lat0 = nullptr, ev_lat1 = nullptr;
+    hipStream_t stream2 = nullptr;                        // scoring launch of the piles that need the large LDS tables
+    hipEvent_t ev_lat0 = nullptr, ev_lat1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     int reserved_cus = 0;
     std::mutex mu;
     DevBuf<uint32_t> d_pool, d_ops;
@@ -199,6 +200,9 @@ DeviceAligner::DeviceAligner() : s_(new State) {
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
             const int prio = (g_ctx_creating >= 0 && g_ctx_creating < 3 && !getenv("NDGPU_NO_STREAM_PRIO")) ? greatest : least;
             HIP_CHECK(hipStreamCreateWithPriority(&s_->stream, hipStreamNonBlocking, prio));
+            HIP_CHECK(hipStreamCreateWithPriority(&s_->stream2, hipStreamNonBlocking, prio));
+            HIP_CHECK(hipEventCreateWithFlags(&s_->ev_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&s_->ev_join, hipEventDisableTiming));
         }
     }
     HIP_CHECK(hipEventCreate(&s_->ev0));
@@ -800,6 +804,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     uint32_t herr[4] = {0, 0, 0, 0};
     // attempt 0 counts links with the small LDS lists; a cell with more distinct links than they hold raises err[0] and the
     // sub-batch is counted and scored again with the full capacity (everything the kernels write is rewritten)
+    bool any_large = false;  // the column scan flagged piles (err = 3) whose columns need the large scoring tables
+    for (size_t p = 0; p < np; p++) any_large = any_large || piles[p].err == 3;
     for (int attempt = 0; attempt < 2; attempt++) {
         HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
         if (attempt) HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
@@ -818,7 +824,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         }
         launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p,
                                S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
-                               S.d_cell_blink.p, S.d_path.p, (int)np, sst, S.evs[7]);
+                               S.d_cell_blink.p, S.d_path.p, (int)np, sst, S.evs[7], any_large, on_reserved ? nullptr : S.stream2,
+                               S.ev_fork, S.ev_join);
         HIP_CHECK(hipEventRecord(S.evs[4], sst));
         if (on_reserved) {
             HIP_CHECK(hipEventRecord(S.ev_lat1, sst));

@@ -184,6 +184,8 @@ __global__ __launch_bounds__(64) void make_tags_kernel(const PileDev *__restrict
     }
 }
 
+constexpr int kColCellsSmall = 96, kColEntsSmall = 256;   // small scoring tables (K10): max_size <= 16, <= 256 link slots per column
+
 // ---- column scan: coverage, max_size, cell/link offsets ------------------------------
 __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ piles, uint32_t *__restrict__ cov_diff,
                                                        const uint32_t *__restrict__ ins_count,
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
     uint32_t *cb = cell_base + P.col_off;
     uint32_t *eb = ent_base + P.col_off;
     uint32_t run_cov = 0, run_cells = 0, run_ents = 0;
+    uint32_t big = 0;  // a column of this lane needs the large scoring tables
     for (uint32_t t0 = 0; t0 < L; t0 += 64) {
         const uint32_t t = t0 + (uint32_t)lane;
         const bool v = t < L;
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
             m = c ? (ms[t] > 1u ? ms[t] : 1u) : 0u;
             e = c + icnt[t];
         }
+        if (m * 6u > (uint32_t)kColCellsSmall || e > (uint32_t)kColEntsSmall) big = 1;
         uint32_t pc = m * 6u, pe = e;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t u1 = (uint32_t)__shfl_up((int)pc, o, 64);
@@ -232,10 +236,12 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
         run_cells += (uint32_t)__shfl((int)pc, 63, 64);
         run_ents += (uint32_t)__shfl((int)pe, 63, 64);
     }
+    const bool any_big = __ballot(big != 0) != 0ull;
     if (lane == 0) {
         cb[L] = run_cells;
         eb[L] = run_ents;
         P.n_cells = run_cells;
+        P.err = any_big ? 3u : 0u;  // 3: scored with the large LDS tables (score_fast_kernel tiers)
     }
 }
 
@@ -459,10 +465,10 @@ __device__ __forceinline__ long long shfl_i64(long long v, int src) {
 //   * scores are int32 here (a 10^6-column seed at depth 200 stays below 2^31); any pile
 //     that gets near the limit, or whose columns exceed the LDS tables, is redone by the
 //     int64 HBM-resident kernel below.
-// LDS table capacities of the fast kernel, two tiers: every pile first runs with the small tables (25 KB per pile: 6 piles
-// resident per compute unit instead of 3); a pile with a column that does not fit them is redone with the large ones, and
-// one that does not fit those either (or whose int32 scores get near the limit) by the HBM-resident kernel.
-constexpr int kColCellsSmall = 96, kColEntsSmall = 256;   // max_size <= 16, <= 256 link slots per column
+// LDS table capacities of the fast kernel, two tiers: a pile whose columns all fit the small tables (25 KB per pile: 6 piles
+// resident per compute unit instead of 3) is scored with them, the others (flagged err = 3 by the column scan) with the
+// large ones by a second launch that runs at the same time on another stream; a pile that does not fit those either (or
+// whose int32 scores get near the limit) goes to the HBM-resident kernel.
 constexpr int kColCells = 192, kColEnts = 512;            // max_size <= 32, <= 512 link slots per column
 constexpr int32_t kNoScore = INT32_MIN;
 constexpr int32_t kScoreGuard = 1 << 30;
@@ -490,7 +496,7 @@ struct LinkAux {
 //   folder (wave 2), one column behind: the five symbol cells of every step fold their links with the reference's
 //     sequential tie-break rules (lib/nextcorrect.c:2164-2192) and the global pick (:2194-2199) is updated -- nothing a
 //     later score depends on, so it is off the chain.
-template <int CELLS, int ENTS, bool REDO>
+template <int CELLS, int ENTS, bool REDO /* launch with the large tables */>
 __global__ __launch_bounds__(192) void score_fast_kernel(
     PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
     const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ ent_base,
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
     __shared__ int32_t s_ot;
     __shared__ uint32_t s_odb;
     PileDev &P = piles[blockIdx.x];
-    if (REDO && P.err != 3) return;  // second tier: only the piles the small tables could not hold
+    if (REDO != (P.err == 3)) return;  // REDO: the launch with the large tables; the column scan chose the tier of every pile
     __builtin_amdgcn_s_setprio(3);  // latency-bound waves: issue priority over co-resident kernels
     const int wave = (int)(threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
@@ -851,9 +857,7 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
     } else if (lane == 0) s_ot = o_t, s_odb = o_db;
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (stopped && !REDO) {
-            P.err = 3;  // redo this pile with the large tables
-        } else if (stopped || s_sc_ovf) {
+        if (stopped || s_sc_ovf) {
             P.err = 2;  // redo this pile in the int64 / HBM-resident kernel
         } else {
             if (REDO) P.err = 0;
@@ -1151,15 +1155,25 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
                             const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
                             const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
                             uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream,
-                            void *ev_after_fast) {
+                            void *ev_after_fast, bool any_large, void *stream_large, void *ev_fork, void *ev_join) {
     if (n_piles <= 0) return;
     hipStream_t st = (hipStream_t)stream;
+    const bool forked = any_large && stream_large && stream_large != stream;
+    if (any_large) {  // the piles that need the large tables are scored at the same time on a second stream
+        hipStream_t s2 = forked ? (hipStream_t)stream_large : st;
+        if (forked) {
+            (void)hipEventRecord((hipEvent_t)ev_fork, st);
+            (void)hipStreamWaitEvent(s2, (hipEvent_t)ev_fork, 0);
+        }
+        hipLaunchKernelGGL((score_fast_kernel<kColCells, kColEnts, true>), dim3((unsigned)n_piles), dim3(192), 0, s2, piles,
+                           coverage, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
+                           cell_best_link);
+        if (forked) (void)hipEventRecord((hipEvent_t)ev_join, s2);
+    }
     hipLaunchKernelGGL((score_fast_kernel<kColCellsSmall, kColEntsSmall, false>), dim3((unsigned)n_piles), dim3(192), 0, st, piles,
                        coverage, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
                        cell_best_link);
-    hipLaunchKernelGGL((score_fast_kernel<kColCells, kColEnts, true>), dim3((unsigned)n_piles), dim3(192), 0, st, piles,
-                       coverage, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
-                       cell_best_link);
+    if (forked) (void)hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0);
     if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
     hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
                        cell_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, ent_score, cell_best_pp,

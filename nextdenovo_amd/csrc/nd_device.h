@@ -150,7 +150,7 @@ void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint
                             const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
                             const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
                             uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream,
-                            void *ev_after_fast);
+                            void *ev_after_fast, bool any_large, void *stream_large, void *ev_fork, void *ev_join);
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,
                     const uint32_t *colidx, RegionDev *regions, char *strpool, unsigned long long *strpool_cursor,
                     unsigned long long strpool_cap, int n_regions, void *stream);
