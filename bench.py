@@ -233,18 +233,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    cns_wall = [0.0]
+
     def step():
         r_, o_ = recs, pile_off
         if ovl_state is not None:
             got = overlap_step()
             if got is not None:
                 r_, o_ = got
+        t_c = time.perf_counter()
         res = db.correct_piles(r_, o_, read_type=read_type, host_threads=args.host_threads, lengths_only=True)
+        cns_wall[0] += time.perf_counter() - t_c
         # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
         return sum(ln for ln, ide in res if ln >= 500 and ln > 4 and ide >= 0.8)
 
     for _ in range(args.warmup):
         step()
+    cns_wall[0] = 0.0
     api.reset_stats()
     if ovl_state is not None:
         ovl_state["stats"], ovl_state["wall"], ovl_state["sort_wall"], ovl_state["asm_wall"] = None, 0.0, 0.0, 0.0
@@ -330,6 +335,7 @@ def main():
                                             "cells_msa", "links", "path_items")},
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms")},
+            "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
         }
         if ovl_state is not None:
             ost = ovl_state["stats"]

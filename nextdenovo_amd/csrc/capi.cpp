@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -155,12 +157,31 @@ void ndgpu_db_destroy(ndgpu_db *h) {
     delete h;
 }
 
+namespace {
+std::mutex g_reap_mu;
+std::vector<std::thread> g_reapers;
+void join_reapers() {
+    std::vector<std::thread> v;
+    {
+        std::lock_guard<std::mutex> lock(g_reap_mu);
+        v.swap(g_reapers);
+    }
+    for (auto &t : v) t.join();
+}
+struct ReaperAtExit {
+    ~ReaperAtExit() { join_reapers(); }
+} g_reaper_at_exit;
+}  // namespace
+
 int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const uint64_t *pile_off,
                         unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
                         unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
                         unsigned int fast, int read_type, int host_threads, consensus_trimed **out) {
     if (n_piles <= 0) return 0;
     if (host_threads <= 0) host_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    join_reapers();  // the previous call's teardown
+    const auto t_call0 = std::chrono::steady_clock::now();
+    std::atomic<uint64_t> build_ns{0}, take_ns{0};
     const ReadDb &db = *h->db;
     size_t sub = 384;
     if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
@@ -213,6 +234,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
             const size_t base = sub_start[sb];
             const size_t cnt = sub_start[sb + 1] - base;
             std::vector<PileEngine *> eng(cnt, nullptr);
+            const auto t_b0 = std::chrono::steady_clock::now();
             CoreLease *build_lease = new CoreLease(threads_each);
             parallel_for(cnt, build_lease->n, [&](size_t k) {
                 const uint32_t pid = order[base + k];
@@ -239,20 +261,33 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                                         read_type == 3 ? seed.c_str() : nullptr);
             });
             delete build_lease;
+            build_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_b0).count();
             {
                 HipBackend be(ctx, threads_each);
                 run_engines(eng.data(), cnt, be, threads_each);
             }
-            for (size_t k = 0; k < cnt; k++) {
-                out[order[base + k]] = (consensus_trimed *)eng[k]->take_result();
-                delete eng[k];
+            const auto t_t0 = std::chrono::steady_clock::now();
+            for (size_t k = 0; k < cnt; k++) out[order[base + k]] = (consensus_trimed *)eng[k]->take_result();
+            // tearing down the per-pile host state (thousands of small vectors per pile, ~0.3 ms each; parallel frees
+            // only fight over the allocator) is not on anybody's critical path: a reaper thread does it while the caller
+            // goes on, and the next call (or the library's unload) waits for it
+            {
+                std::lock_guard<std::mutex> lock(g_reap_mu);
+                g_reapers.emplace_back([v = std::move(eng)] {
+                    for (PileEngine *e : v) delete e;
+                });
             }
+            take_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_t0).count();
         }
     };
     std::vector<std::thread> th;
     for (int c = 1; c < drivers; c++) th.emplace_back(drive, c);
     drive(0);
     for (auto &t : th) t.join();
+    if (getenv("NDGPU_TRACE"))
+        fprintf(stderr, "[ndgpu trace] correct_piles %d piles in %zu sub-batches: %.1f ms wall | engine build %.1f ms, result take %.1f ms (summed over contexts)\n",
+                n_piles, n_sub, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_call0).count() * 1e-3,
+                build_ns.load() * 1e-6, take_ns.load() * 1e-6);
     if (getenv("NDGPU_PROF")) {
         fprintf(stderr, "[ndgpu prof] drivers %d x %d threads | main %.3f s  extract %.3f s  align %.3f s (%llu jobs)  "
                         "advance %.3f s  (driver-thread wall sums)\n",
