@@ -217,10 +217,8 @@ def main():
             return None
         srt, bl, sst = overlap.sort_overlaps([raw], ovl_state["seed_len"], ovl_state["min_seed"], ovl_state["k"], 300)
         t2 = time.perf_counter()
-        dec = np.stack([srt[c] for c in ("qname", "rev", "qs", "qe", "tname", "ts", "te", "match")], axis=1)
         skip = [i for i, kind in bl]  # the .bl blacklist is honoured as lib/nextcorrect.py does by default
-        rows, off, seeds = nc.assemble_piles_fast(dec, 500, 500, 130, 10, skip)
-        sub = np.ascontiguousarray(dec[rows])
+        sub, off, seeds = overlap.assemble_piles(srt, ovl_state["seed_len"].size, 500, 500, 130, 10, skip)
         t3 = time.perf_counter()
         ovl_state["sort_wall"] += t2 - t1
         ovl_state["asm_wall"] += t3 - t2

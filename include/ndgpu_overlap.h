@@ -95,6 +95,17 @@ int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_f
                        uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
                        uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats);
 
+/* ---- pile admission between the sort and the consensus: read_seq_data of lib/nextcorrect.py:92-143 on the records of a sorted.ovl
+ * (what ndgpu_ovl_sort returned).  One pile per seed whose length is >= min_len_seed and that is not in skip_ids (the `.bl` list /
+ * seeds already corrected): overlaps shorter than min_len_aln, repeated query reads and overlaps beyond 1.5 x max_cov_aln of
+ * cumulative depth are dropped, piles below min_cov_seed of depth are dropped.  recs8[i] = the admitted record i in the field order
+ * nextCorrect's callers use (seed, rev, seed start, seed end (inclusive), read, read start, read end, match); pile p =
+ * recs8[pile_off[p] .. pile_off[p+1]); seeds[p] = its seed id.  Host logic (no device work); outputs malloc'd (ndgpu_ovl_free).
+ * Returns the number of admitted records. */
+int64_t ndgpu_assemble_piles(const ndgpu_ovl_rec *sorted, int64_t n, uint32_t n_ids, uint32_t min_len_seed, uint32_t min_len_aln,
+                             uint32_t max_cov_aln, uint32_t min_cov_seed, const uint32_t *skip_ids, int64_t n_skip, uint32_t **recs8,
+                             uint64_t **pile_off, uint32_t **seeds, int64_t *n_piles);
+
 /* ---- read ingestion: the 2-bit packing of `seq_dump` (seq2bit, lib/bseq.c:114-139; called from util/seq_dump.c:36-41) ----
  * Read i is the lens[i] ASCII bytes at ascii + ascii_off[i]; its ceil(lens[i]/16) words go to words + word_off[i] (word_off ascending,
  * reads back to back).  Bytes other than ACGTU (either case) are coded 4 and OR-ed in as the reference does, so they disturb the low

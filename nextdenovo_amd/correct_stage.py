@@ -166,10 +166,9 @@ def run(argv) -> int:
                 with open(so + ".bl", "w") as f:
                     for rid, kind in bl:
                         f.write("%d %s\n" % (rid, kind))
-            dec = np.stack([srt[c] for c in ("qname", "rev", "qs", "qe", "tname", "ts", "te", "match")], axis=1)
             skip = [rid for rid, _ in bl] if a.blacklist else []
-            rows, off, names = nextcorrect.assemble_piles_fast(dec, a.min_len_seed, a.min_len_aln, a.max_cov_aln, a.min_cov_seed, skip)
-            piles = [(int(names[p]), rows[int(off[p]):int(off[p + 1])]) for p in range(names.size)]
+            dec, off, names = overlap.assemble_piles(srt, int(lens.size), a.min_len_seed, a.min_len_aln, a.max_cov_aln, a.min_cov_seed, skip)
+            piles = [(int(names[p]), np.arange(int(off[p]), int(off[p + 1]))) for p in range(names.size)]
             out = "%s.%s.fasta" % (a.out, tag)
             with open(out, "w") as OUT, open(out + ".idx", "w") as IDX:
                 fail += nextcorrect.correct_and_write(db, dec, piles, a, OUT, IDX)

@@ -200,3 +200,65 @@ extern "C" int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64
 		return -2;
 	}
 }
+
+
+// Pile admission of lib/nextcorrect.py:92-143 (read_seq_data) over the records of a sorted.ovl, in file order -- host
+// logic, one pass, no device work: what the stage CLI and the fused stage feed to ndgpu_correct_piles.
+extern "C" int64_t ndgpu_assemble_piles(const ndgpu_ovl_rec *sorted, int64_t n, uint32_t n_ids, uint32_t min_len_seed, uint32_t min_len_aln,
+                                        uint32_t max_cov_aln, uint32_t min_cov_seed, const uint32_t *skip_ids, int64_t n_skip, uint32_t **recs8,
+                                        uint64_t **pile_off, uint32_t **seeds, int64_t *n_piles)
+{
+	*recs8 = nullptr, *pile_off = nullptr, *seeds = nullptr, *n_piles = 0;
+	std::vector<uint8_t> skip(n_ids ? n_ids : 1, 0);
+	for (int64_t i = 0; i < n_skip; ++i) if (skip_ids[i] < n_ids) skip[skip_ids[i]] = 1;
+	std::vector<uint32_t> used(n_ids ? n_ids : 1, 0); // stamp = group counter of the last pile that admitted the read
+	std::vector<uint32_t> out;
+	std::vector<uint64_t> off{0};
+	std::vector<uint32_t> names;
+	out.reserve((size_t)n * 8);
+	const double lim = (double)max_cov_aln * 1.5;
+	uint32_t stamp = 1;
+	// state of the reference's loop: seed_state 0 = '' (no seed yet), 1 = valid seed, 2 = '+' (rejected seed)
+	int seed_state = 0;
+	uint32_t seed_name = 0;
+	uint64_t total_length = 0, seed_length = 0;
+	int64_t last_seed = -1;
+	size_t pile_start = 0;
+	auto close_pile = [&](bool keep) {
+		if (keep) { off.push_back(out.size() / 8); names.push_back(seed_name); }
+		else out.resize(pile_start * 8);
+		pile_start = out.size() / 8;
+		++stamp;
+	};
+	for (int64_t k = 0; k < n; ++k) {
+		const ndgpu_ovl_rec &r = sorted[k]; // qname = the seed (field 0 of a sorted.ovl record), tname = the other read
+		const uint32_t t_name = r.qname, t_s = r.qs, t_e = r.qe, q_name = r.tname;
+		if (seed_state == 2 || (last_seed != -1 && (int64_t)t_name != last_seed)) {
+			close_pile(seed_length && (double)total_length / (double)seed_length >= (double)min_cov_seed && seed_state == 1);
+			seed_state = 0, total_length = seed_length = 0;
+		}
+		if (seed_state == 0) {
+			seed_length = (uint64_t)t_e + 1;
+			total_length = 0;
+			seed_name = t_name;
+			seed_state = (seed_length >= min_len_seed && !(t_name < n_ids && skip[t_name])) ? 1 : 2;
+		}
+		if (t_e - t_s < min_len_aln || (double)total_length / (double)seed_length > lim || (q_name < n_ids && used[q_name] == stamp) || seed_state == 2)
+			continue;
+		const uint32_t row[8] = {r.qname, r.rev, r.qs, r.qe, r.tname, r.ts, r.te, r.match};
+		out.insert(out.end(), row, row + 8);
+		if (q_name < n_ids) used[q_name] = stamp;
+		total_length += (uint64_t)(t_e - t_s) + 1;
+		last_seed = (int64_t)t_name;
+	}
+	close_pile(seed_length && (double)total_length / (double)seed_length >= (double)min_cov_seed && seed_state == 1);
+	const size_t np = names.size(), nr = off.back();
+	*recs8 = (uint32_t*)malloc(sizeof(uint32_t) * 8 * (nr ? nr : 1));
+	*pile_off = (uint64_t*)malloc(sizeof(uint64_t) * (np + 1));
+	*seeds = (uint32_t*)malloc(sizeof(uint32_t) * (np ? np : 1));
+	if (nr) memcpy(*recs8, out.data(), sizeof(uint32_t) * 8 * nr);
+	memcpy(*pile_off, off.data(), sizeof(uint64_t) * (np + 1));
+	if (np) memcpy(*seeds, names.data(), sizeof(uint32_t) * np);
+	*n_piles = (int64_t)np;
+	return (int64_t)nr;
+}

@@ -185,6 +185,27 @@ class Index:
         self.lib.ndgpu_ovl_reset_stats(self.h)
 
 
+def assemble_piles(srt: np.ndarray, n_ids: int, min_len_seed: int, min_len_aln: int = 500, max_cov_aln: int = 130, min_cov_seed: int = 10,
+                   skip=()):
+    """lib/nextcorrect.py:92-143 on sorted.ovl records (ndgpu_assemble_piles, host logic of libndgpu_overlap.so).
+    Returns (recs uint32[n,8] in nextcorrect's field order, pile_off uint64[p+1], seeds uint32[p])."""
+    lib = load()
+    if not hasattr(lib.ndgpu_assemble_piles, "_bound"):
+        P = C.c_void_p
+        lib.ndgpu_assemble_piles.argtypes = [P, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int64,
+                                             C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(C.c_int64)]
+        lib.ndgpu_assemble_piles.restype = C.c_int64
+        lib.ndgpu_assemble_piles._bound = True
+    srt = np.ascontiguousarray(srt, dtype=REC)
+    sk = np.ascontiguousarray(np.fromiter(skip, dtype=np.uint32, count=len(skip)) if len(skip) else np.zeros(0, dtype=np.uint32))
+    r8, off, seeds = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    npiles = C.c_int64(0)
+    n = lib.ndgpu_assemble_piles(_ptr(srt), srt.size, int(n_ids), int(min_len_seed), int(min_len_aln), int(max_cov_aln), int(min_cov_seed),
+                                 _ptr(sk), sk.size, C.byref(r8), C.byref(off), C.byref(seeds), C.byref(npiles))
+    recs = _take(lib, r8, n * 8, np.uint32).reshape(-1, 8)
+    return recs, _take(lib, off, npiles.value + 1, np.uint64), _take(lib, seeds, npiles.value, np.uint32)
+
+
 def pack_2bit(ascii_buf: np.ndarray, ascii_off: np.ndarray, lens: np.ndarray):
     """seq2bit (lib/bseq.c:114-139) of a batch of reads on the device -> (words uint32, word_off uint64[n])."""
     lib = load()
