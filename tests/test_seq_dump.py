@@ -111,3 +111,23 @@ def test_seq_dump_files_equal_reference(tmp_path, argv):
     assert names == sorted(os.listdir(mine)) and len(names) >= 4
     for n in names:
         assert open(os.path.join(ref, n), "rb").read() == open(os.path.join(mine, n), "rb").read(), n
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "seq_stat")), reason="oracle/_ref not built")
+@pytest.mark.parametrize("argv", [("-f", "1k", "-g", "20k", "-d", "3"), ("-f", "500", "-g", "5k", "-d", "45"), ("-f", "16", "-g", "100k", "-d", "30", "-a"),
+                                  ("-f", "2k", "-g", "1m", "-d", "40"), ()])
+def test_seq_stat_report_equals_reference(tmp_path, argv):
+    """The db_stat report (histogram, N-stat table, suggested seed cut-off) against the compiled reference seq_stat."""
+    from nextdenovo_amd import seq_stat
+    fofn, _ = _make_inputs(str(tmp_path))
+    rng = np.random.default_rng(9)
+    big = tmp_path / "many.fa"          # enough reads for several histogram bins and every N-stat row
+    with open(big, "w") as f:
+        for i, n in enumerate(np.clip(rng.lognormal(8.3, 0.6, 2600).astype(int), 30, 60000)):
+            f.write(">m%d\n%s\n" % (i, "ACGT" * (int(n) // 4) + "A" * (int(n) % 4)))
+    with open(fofn, "a") as f:
+        f.write("many.fa\n")
+    ref, mine = str(tmp_path / "ref.stat"), str(tmp_path / "mine.stat")
+    subprocess.run([os.path.join(REFDIR, "seq_stat"), *argv, "-o", ref, fofn], check=True, stderr=subprocess.DEVNULL)
+    assert seq_stat.run([*argv, "-o", mine, fofn]) == 0
+    assert open(mine, "rb").read() == open(ref, "rb").read() and os.path.getsize(ref) > 500
