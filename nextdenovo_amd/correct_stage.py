@@ -13,6 +13,7 @@ memory: the step-1 overlaps never get varint-coded, sorted.ovl is never written 
 index is built once for all of its jobs, and the reads are uploaded once.
 
     python -m nextdenovo_amd.correct_stage -d 01.raw_align -x ava-ont -k 40 -r ont -min_len_seed 5000 -o cns
+    python -m nextdenovo_amd.correct_stage --fofn input.fofn --read-cutoff 1k --seed-cutoff 10k --seed-cutfiles 2 -d 01.raw_align ...   (db_split too)
 
 writes `cns.NNN.fasta` (+ `.idx`) per seed file, byte-identical to what the three reference programs produce when the
 sort's input list names the `.ovl` files in job order (the reference lists them in directory order, which only matters
@@ -88,6 +89,11 @@ def read_db_from_sets(sets):
 def run(argv) -> int:
     ap = argparse.ArgumentParser(prog="correct_stage", description=__doc__.split("\n")[0])
     ap.add_argument("-d", dest="dir", required=True, help="seq_dump output directory (input.seed.*.2bit, input.part.*.2bit)")
+    ap.add_argument("--fofn", default=None, metavar="FILE", help="start from FASTA/FASTQ[.gz] files: run seq_dump into -d first")
+    ap.add_argument("--read-cutoff", default="1k", help="seq_dump -f (with --fofn)")
+    ap.add_argument("--seed-cutoff", default=None, help="seq_dump -s (with --fofn)")
+    ap.add_argument("--blocksize", default="0", help="seq_dump -b (with --fofn)")
+    ap.add_argument("--seed-cutfiles", type=int, default=1, help="seq_dump -n (with --fofn)")
     ap.add_argument("-x", dest="preset", required=True, choices=["ava-ont", "ava-pb", "ava-hifi"])
     ap.add_argument("-f", dest="occ", default=None, help="minimap2-nd -f (FLOAT < 1 or INT)")
     ap.add_argument("-k", dest="sort_k", type=int, default=40, help="ovl_sort -k")
@@ -112,6 +118,12 @@ def run(argv) -> int:
     a.min_len_aln = nextcorrect.parse_num_unit(a.min_len_aln)
     a.read_type = {"ont": 1, "clr": 2, "hifi": 3}[a.read_type]
 
+    if a.fofn:  # db_split (nextDenovo:536-551) first: the same files seq_dump writes, packed on the device
+        from nextdenovo_amd import seq_dump
+        if a.seed_cutoff is None:
+            raise SystemExit("[ERROR] --fofn needs --seed-cutoff")
+        if seq_dump.run(["-f", a.read_cutoff, "-s", a.seed_cutoff, "-b", a.blocksize, "-n", str(a.seed_cutfiles), "-d", a.dir, a.fofn]) != 0:
+            raise SystemExit("[ERROR] seq_dump failed")
     seed_paths = sorted(glob.glob(os.path.join(a.dir, "input.seed.*.2bit")))
     part_paths = [p for p in sorted(glob.glob(os.path.join(a.dir, "input.part.*.2bit"))) if os.path.getsize(p) > 2]
     if not seed_paths:

@@ -289,3 +289,27 @@ def test_fused_stage_two_seed_files_matches_reference_programs(tmp_path):
         assert os.path.getsize(file_out) > 50000
         assert open(out + ".%s.fasta" % tag, "rb").read() == open(file_out, "rb").read()
         assert open(out + ".%s.fasta.idx" % tag, "rb").read() == open(file_out + ".idx", "rb").read()
+
+
+def test_fused_stage_from_fasta(tmp_path):
+    """`correct_stage --fofn`: db_split (seq_dump with the device packing) + the fused stage in one command == the fused stage on
+    a directory the same reads were dumped into beforehand."""
+    from nextdenovo_amd import correct_stage, seq_dump, synth
+    import refpipe
+    g = synth.make_genome(40000, seed=51, n_repeats=2, repeat_len=1200)
+    rs = synth.simulate_reads(g, 30, "ont", seed=52, mu=8.4, sigma=0.4, min_len=700)
+    wd = str(tmp_path)
+    fa = os.path.join(wd, "reads.fa")
+    refpipe.write_fasta(fa, [synth.codes_to_ascii(s) for s in rs.seqs])
+    fofn = os.path.join(wd, "input.fofn")
+    with open(fofn, "w") as f:
+        f.write("reads.fa\n")
+    common = ["-x", "ava-ont", "-k", "25", "-r", "ont", "-min_len_seed", "2000", "-p", "4"]
+    a, b = os.path.join(wd, "a"), os.path.join(wd, "b")
+    assert correct_stage.run(["--fofn", fofn, "--read-cutoff", "500", "--seed-cutoff", "4k", "--seed-cutfiles", "2", "-d", a, "-o",
+                              os.path.join(wd, "one")] + common) == 0
+    assert seq_dump.run(["-f", "500", "-s", "4k", "-b", "0", "-n", "2", "-d", b, fofn]) == 0
+    assert correct_stage.run(["-d", b, "-o", os.path.join(wd, "two")] + common) == 0
+    for tag in ("001", "002"):
+        x = open(os.path.join(wd, "one.%s.fasta" % tag), "rb").read()
+        assert len(x) > 20000 and x == open(os.path.join(wd, "two.%s.fasta" % tag), "rb").read()
