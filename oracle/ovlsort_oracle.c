@@ -92,10 +92,10 @@ typedef struct {
 	uint32_t n_bins, cap_bins;
 } seed_state;
 
-static void seed_begin(seed_state *s, uint32_t qlen)
+static void seed_begin(seed_state *s, uint32_t qlen, int hq)
 {
 	s->qlen = qlen;
-	s->n_bins = (qlen >> BIN_SHIFT) + 1;
+	s->n_bins = (qlen >> BIN_SHIFT) + (hq ? 2 : 1); /* ovl_sort.c:622 vs :663 */
 	if (s->n_bins > s->cap_bins) {
 		s->cap_bins = s->n_bins;
 		s->bins = (uint16_t*)realloc(s->bins, 2 * (size_t)s->cap_bins);
@@ -103,7 +103,7 @@ static void seed_begin(seed_state *s, uint32_t qlen)
 	memset(s->bins, 0, 2 * (size_t)s->n_bins);
 	s->repeat_run = 1;
 	s->qcov = s->bins_sum = s->bins_touched = s->contained = s->chimera = s->n_kept = 0;
-	s->qcap = qlen * COV_CAP;
+	s->qcap = qlen * COV_CAP * (hq ? 6 : 1);        /* ovl_sort.c:630 */
 }
 
 static void keep(seed_state *s, const nd_ovl *o, int flank)
@@ -146,6 +146,68 @@ static void admit(seed_state *s, const nd_ovl *o, int max_bin_cov, int flank)
 		s->bins_sum += (uint32_t)(k - j);
 	}
 	keep(s, o, flank);
+}
+
+/* -H (high-quality reads), ovl_sort.c:616-655 encode_ovl_filter_hq: every candidate is collected (up to the caps); the two
+ * halves of bins[] count alignment starts and ends per 128 bases */
+static void admit_hq(seed_state *s, const nd_ovl *o, int flank)
+{
+	if (s->qcov > s->qcap || s->n_kept > 65535 - 1000) return;
+	{
+		const int off = 1 + (int)(s->qlen >> (BIN_SHIFT + 1));
+		s->bins[(o->qs + 10) >> (BIN_SHIFT + 1)]++;
+		s->bins[((o->qe - 10) >> (BIN_SHIFT + 1)) + off]++;
+	}
+	keep(s, o, flank);
+}
+
+/* ovl_sort.c:389-431 del_repeat_alns: overlaps that start AND end where >= 5 overlaps start / end are repeat-induced;
+ * the 64-base coverage is then rebuilt over the rest, dropping what would push a whole span above 2 x max_bin_cov */
+static void drop_repeat_alignments(seed_state *s, int max_bin_cov, int flank)
+{
+	int i, t;
+	const int off = 1 + (int)(s->qlen >> (BIN_SHIFT + 1)), hot = 5;
+	const uint32_t fl = flank > 100 ? (uint32_t)flank * 3 : 300;
+	for (i = 1; i < (int)s->n_kept; ++i) {
+		nd_ovl *o = &s->kept[i];
+		if (o->qs <= fl && o->qe + fl >= s->qlen) continue;
+		if (s->bins[(o->qs + 10) >> (BIN_SHIFT + 1)] >= hot && s->bins[((o->qe - 10) >> (BIN_SHIFT + 1)) + off] >= hot) o->qe = 0;
+	}
+	memset(s->bins, 0, 2 * (size_t)s->n_bins);
+	for (i = 1; i < (int)s->n_kept; ++i) {
+		nd_ovl *o = &s->kept[i];
+		int lowest = UINT16_MAX;
+		const int j = (int)((o->qs + 10) >> BIN_SHIFT), k = (int)((o->qe - 10) >> BIN_SHIFT);
+		if (!o->qe) continue;
+		for (t = j + 1; t <= k; ++t) {
+			if (++s->bins[t] > UINT16_MAX - 1000) s->bins[t]--;
+			if (s->bins[t] < lowest) lowest = s->bins[t];
+		}
+		if (lowest > 2 * max_bin_cov) {
+			for (t = j + 1; t <= k; ++t) s->bins[t]--;
+			o->qe = 0;
+		}
+	}
+}
+
+/* ovl_sort.c:287-314 check_chimer_hq: a bin covered at most once, inside the covered part, that no kept overlap spans
+ * with 15 bins to spare on both sides */
+static int chimera_hq(const seed_state *s)
+{
+	int i, j, l = 0, r = (int)s->n_bins;
+	const int pad = 15;
+	while (l < (int)s->n_bins && s->bins[l] < 2) ++l;
+	while (r > 0 && s->bins[r - 1] < 2) --r;
+	for (i = l + 1; i < r - 1; ++i) {
+		if (s->bins[i] <= 1) {
+			const int lo = i > l + pad ? (i - pad) << BIN_SHIFT : l << BIN_SHIFT;
+			const int hi = i + pad < r ? (i + pad) << BIN_SHIFT : r << BIN_SHIFT;
+			for (j = 1; j < (int)s->n_kept; ++j)
+				if (s->kept[j].qs < (uint32_t)lo && s->kept[j].qe > (uint32_t)hi) break;
+			if (j >= (int)s->n_kept) return i;
+		}
+	}
+	return 0;
 }
 
 static int chimera_by_coverage(const seed_state *s)
@@ -201,13 +263,14 @@ static int chimera_by_ends(seed_state *s)
 
 /* end of a seed: trimming decisions; survivors (qe != 0) go to `out`, a verdict may go to `bl` */
 static int64_t finish_seed(seed_state *s, int max_bin_cov, int flank, int min_seed_len, nd_ovl *out, uint32_t *bl_id, uint8_t *bl_kind,
-                           int64_t *n_bl)
+                           int64_t *n_bl, int hq)
 {
 	int i, lo = 0, hi = 0;
 	int64_t n = 0;
 	const int nb = (int)s->n_bins;
-	s->chimera = (uint32_t)chimera_by_coverage(s);
-	if (s->chimera || !s->contained) {
+	if (hq) drop_repeat_alignments(s, max_bin_cov, flank);
+	s->chimera = (uint32_t)(hq ? chimera_hq(s) : chimera_by_coverage(s));
+	if (s->chimera || !(s->contained || hq)) {
 		int j = 0, k, m;
 		uint16_t *b = s->bins; /* the list of (first, last) low-coverage bin runs overwrites the front of bins[] */
 		if (s->qcov > s->qlen * 10) {
@@ -256,7 +319,7 @@ static int64_t finish_seed(seed_state *s, int max_bin_cov, int flank, int min_se
 			} else lo = hi = 0;
 		}
 	}
-	if (s->qcov > s->qlen * 20 && !s->chimera && s->contained < CONTAINED_MIN) {
+	if (!hq && s->qcov > s->qlen * 20 && !s->chimera && s->contained < CONTAINED_MIN) {
 		s->chimera = (uint32_t)chimera_by_ends(s);
 		if (!hi) hi = (int)s->qlen;
 		if (s->chimera <= (uint32_t)(lo + (15 << BIN_SHIFT)) || s->chimera + (15 << BIN_SHIFT) >= (uint32_t)hi) s->chimera = 0;
@@ -266,7 +329,10 @@ static int64_t finish_seed(seed_state *s, int max_bin_cov, int flank, int min_se
 		const nd_ovl *o = &s->kept[i];
 		if (!o->qe) continue;
 		out[n++] = *o;
-		if (o->qname != o->tname && o->qs <= (uint32_t)flank && o->qe + (uint32_t)flank >= s->qlen) s->contained++;
+		if (o->qname != o->tname && o->qs <= (uint32_t)flank && o->qe + (uint32_t)flank >= s->qlen) {
+			if (!hq) s->contained++;
+			else if (o->match >= (o->qe - o->qs + 1) * 0.9) s->contained++; /* a containing overlap of HQ reads must be >= 90 % matches */
+		}
 	}
 	if (s->contained >= CONTAINED_MIN) bl_id[*n_bl] = s->kept[0].qname, bl_kind[(*n_bl)++] = 'c';
 	else if (s->chimera) bl_id[*n_bl] = s->kept[0].qname, bl_kind[(*n_bl)++] = 'k';
@@ -277,8 +343,18 @@ static int64_t finish_seed(seed_state *s, int max_bin_cov, int flank, int min_se
 
 /* cand[perm[0..n)] = candidates in merge order.  out: room for n + number of seeds records; bl_*: room for the
  * number of seeds.  Returns records written. */
+int64_t nd_os_filter2(const nd_ovl *cand, const uint32_t *perm, int64_t n, const uint32_t *seed_len, int max_bin_cov, int flank,
+                      int min_seed_len, nd_ovl *out, uint32_t *bl_id, uint8_t *bl_kind, int64_t *n_bl, int hq);
+
 int64_t nd_os_filter(const nd_ovl *cand, const uint32_t *perm, int64_t n, const uint32_t *seed_len, int max_bin_cov, int flank,
                      int min_seed_len, nd_ovl *out, uint32_t *bl_id, uint8_t *bl_kind, int64_t *n_bl)
+{
+	return nd_os_filter2(cand, perm, n, seed_len, max_bin_cov, flank, min_seed_len, out, bl_id, bl_kind, n_bl, 0);
+}
+
+/* hq != 0: the -H variant (ovl_sort.c:27,1045) */
+int64_t nd_os_filter2(const nd_ovl *cand, const uint32_t *perm, int64_t n, const uint32_t *seed_len, int max_bin_cov, int flank,
+                      int min_seed_len, nd_ovl *out, uint32_t *bl_id, uint8_t *bl_kind, int64_t *n_bl, int hq)
 {
 	seed_state s;
 	int64_t i, n_out = 0;
@@ -290,17 +366,18 @@ int64_t nd_os_filter(const nd_ovl *cand, const uint32_t *perm, int64_t n, const 
 		const nd_ovl *o = &cand[perm[i]];
 		if (!open || o->qname != cur) {
 			nd_ovl self;
-			if (open) n_out += finish_seed(&s, max_bin_cov, flank, min_seed_len, out + n_out, bl_id, bl_kind, n_bl);
+			if (open) n_out += finish_seed(&s, max_bin_cov, flank, min_seed_len, out + n_out, bl_id, bl_kind, n_bl, hq);
 			cur = o->qname, open = 1;
-			seed_begin(&s, seed_len[cur]);
+			seed_begin(&s, seed_len[cur], hq);
 			memset(&self, 0, sizeof(self));
 			self.qname = self.tname = cur;
 			self.qe = self.te = seed_len[cur] - 1;
 			keep(&s, &self, flank);
 		}
-		admit(&s, o, max_bin_cov, flank);
+		if (hq) admit_hq(&s, o, flank);
+		else admit(&s, o, max_bin_cov, flank);
 	}
-	if (open) n_out += finish_seed(&s, max_bin_cov, flank, min_seed_len, out + n_out, bl_id, bl_kind, n_bl);
+	if (open) n_out += finish_seed(&s, max_bin_cov, flank, min_seed_len, out + n_out, bl_id, bl_kind, n_bl, hq);
 	free(s.bins); free(s.kept);
 	return n_out;
 }

@@ -20,6 +20,8 @@ def bind(lib):
     lib.nd_os_order.argtypes = [P, C.c_int64, P]
     lib.nd_os_filter.argtypes = [P, P, C.c_int64, P, C.c_int, C.c_int, C.c_int, P, P, P, P]
     lib.nd_os_filter.restype = C.c_int64
+    lib.nd_os_filter2.argtypes = [P, P, C.c_int64, P, C.c_int, C.c_int, C.c_int, P, P, P, P, C.c_int]
+    lib.nd_os_filter2.restype = C.c_int64
     lib.nd_os_encode.argtypes = [P, C.c_int64, P]
     lib.nd_os_encode.restype = C.c_int64
     return lib
@@ -38,7 +40,7 @@ def read_idx(path):
     return sl, int(tab[:, 2].min()) if tab.size else 0
 
 
-def oracle_sort(lib, raw_files, seed_len, min_seed_len, max_bin_cov=40, flank=300):
+def oracle_sort(lib, raw_files, seed_len, min_seed_len, max_bin_cov=40, flank=300, hq=False):
     """raw_files: list of uint32[n,8] arrays (decode_ovl order), one per input .ovl in fofn order.
     Returns (sorted.ovl bytes, .bl text)."""
     cands = []
@@ -56,15 +58,15 @@ def oracle_sort(lib, raw_files, seed_len, min_seed_len, max_bin_cov=40, flank=30
     bl_id = np.zeros(n_seeds + 1, dtype=np.uint32)
     bl_kind = np.zeros(n_seeds + 1, dtype=np.uint8)
     n_bl = C.c_int64(0)
-    n_out = lib.nd_os_filter(ptr(cand), ptr(perm), n, ptr(seed_len), max_bin_cov, flank, min_seed_len, ptr(out), ptr(bl_id),
-                             ptr(bl_kind), C.byref(n_bl))
+    n_out = lib.nd_os_filter2(ptr(cand), ptr(perm), n, ptr(seed_len), max_bin_cov, flank, min_seed_len, ptr(out), ptr(bl_id),
+                              ptr(bl_kind), C.byref(n_bl), 1 if hq else 0)
     buf = np.zeros(40 * max(1, n_out), dtype=np.uint8)
     nb = lib.nd_os_encode(ptr(out), n_out, ptr(buf))
     bl = "".join("%d %s\n" % (int(bl_id[i]), chr(int(bl_kind[i]))) for i in range(n_bl.value))
     return buf[:nb].tobytes(), bl, out[:n_out].copy()
 
 
-def ref_sort(workdir, idx, ovl_files, k=40, threads=2, mem="2g", flank=None):
+def ref_sort(workdir, idx, ovl_files, k=40, threads=2, mem="2g", flank=None, hq=False):
     """Run oracle/_ref/ovl_sort; returns (sorted.ovl bytes, .bl text)."""
     fofn = os.path.join(workdir, "sort.fofn")
     with open(fofn, "w") as f:
@@ -73,6 +75,8 @@ def ref_sort(workdir, idx, ovl_files, k=40, threads=2, mem="2g", flank=None):
     cmd = [os.path.join(REFDIR, "ovl_sort"), "-m", mem, "-t", str(threads), "-k", str(k), "-i", idx, "-o", out]
     if flank is not None:
         cmd += ["-l", str(flank)]
+    if hq:
+        cmd.append("-H")
     cmd.append(fofn)
     subprocess.run(cmd, cwd=workdir, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     with open(os.path.join(workdir, out), "rb") as f:
