@@ -94,6 +94,12 @@ typedef struct ndgpu_ovl_sort_stats { double gpu_ms; uint64_t raw_records, candi
 int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
                        uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
                        uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats);
+/* the same with `-H` (high-quality reads, util/ovl_sort.c:27,1045): every candidate is collected, overlaps that start and end at hot
+ * break points (del_repeat_alns, :389-431) are dropped, chimeras come from uncovered bins no overlap spans (check_chimer_hq,
+ * :287-314), a containing overlap counts only with >= 90 % matches (:555) */
+int64_t ndgpu_ovl_sort_hq(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
+                          uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
+                          uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats);
 
 /* ---- pile admission between the sort and the consensus: read_seq_data of lib/nextcorrect.py:92-143 on the records of a sorted.ovl
  * (what ndgpu_ovl_sort returned).  One pile per seed whose length is >= min_len_seed and that is not in skip_ids (the `.bl` list /

@@ -43,7 +43,7 @@ int sort_pairs_u32(void *tmp, size_t &tmp_bytes, const uint32_t *kin, uint32_t *
                    hipStream_t s);
 void launch_seed_filter(const OvlRec *cand, const uint32_t *perm, const uint64_t *seed_start, uint32_t n_seeds, uint64_t n_cand,
                         const uint32_t *seed_len, int max_bin_cov, int flank, int min_seed_len, uint32_t max_bins, uint32_t *kept, OvlRec *out,
-                        uint32_t *n_out, uint32_t *bl_id, uint8_t *bl_kind, hipStream_t s);
+                        uint32_t *n_out, uint32_t *bl_id, uint8_t *bl_kind, bool hq, hipStream_t s);
 void launch_compact_seed_recs(const uint64_t *seed_start, uint32_t n_seeds, const OvlRec *out, const uint32_t *n_out, const uint64_t *off,
                               OvlRec *dense, hipStream_t s);
 
@@ -78,9 +78,9 @@ struct SortRun {
 
 using namespace ndovl;
 
-extern "C" int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
-                                  uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
-                                  uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats)
+static int64_t sort_impl(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
+                         uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
+                         uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats, bool hq_mode)
 {
 	*out = nullptr, *bl_id = nullptr, *bl_kind = nullptr, *n_bl = 0;
 	if (stats) memset(stats, 0, sizeof(*stats));
@@ -165,7 +165,7 @@ extern "C" int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64
 		Buf<OvlRec> outrec(nc + n_seeds + 1);
 		HIP_OK(hipMemsetAsync(n_out.p, 0, (n_seeds + 1) * 4, R.st));
 		launch_seed_filter(cand.p, perm.p, sstart.p, (uint32_t)n_seeds, nc, d_seed.p, max_bin_cov, max_flank_len, min_seed_len, max_bins, kept.p,
-		                   outrec.p, n_out.p, d_bl_id.p, d_bl_kind.p, R.st);
+		                   outrec.p, n_out.p, d_bl_id.p, d_bl_kind.p, hq_mode, R.st);
 		Buf<uint64_t> off(n_seeds + 1);
 		R.exscan(n_out.p, off.p, n_seeds + 1);
 		uint64_t total = 0;
@@ -199,6 +199,20 @@ extern "C" int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64
 	} catch (...) {
 		return -2;
 	}
+}
+
+extern "C" int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
+                                  uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
+                                  uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats)
+{
+	return sort_impl(files, n_per_file, n_files, seed_len, n_ids, min_seed_len, max_bin_cov, max_flank_len, out, bl_id, bl_kind, n_bl, stats, false);
+}
+
+extern "C" int64_t ndgpu_ovl_sort_hq(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
+                                     uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
+                                     uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats)
+{
+	return sort_impl(files, n_per_file, n_files, seed_len, n_ids, min_seed_len, max_bin_cov, max_flank_len, out, bl_id, bl_kind, n_bl, stats, true);
 }
 
 

@@ -344,11 +344,173 @@ __global__ void __launch_bounds__(64) seed_filter_kernel(const OvlRec *__restric
 	}
 }
 
+// S3 for `ovl_sort -H` (high-quality reads): encode_ovl_filter_hq (ovl_sort.c:616-655), del_repeat_alns (:389-431),
+// check_chimer_hq (:287-314) and the -H branches of ovl_filter (:433-571).  Every candidate is collected (up to the caps)
+// while the two halves of bins[] count alignment starts / ends per 128 bases; overlaps that start and end at hot break
+// points are repeat-induced and dropped, the 64-base coverage is rebuilt over the rest (spans that would sit above
+// 2 x max_bin_cov everywhere are dropped), a bin covered at most once that no overlap spans with 15 bins to spare marks a
+// chimera, and the low-coverage trimming of the raw-read path follows.  The chain is sequential per seed (lane 0 walks it;
+// seeds are independent wavefronts).
+__global__ void __launch_bounds__(64) seed_filter_hq_kernel(const OvlRec *__restrict__ cand, const uint32_t *__restrict__ perm,
+                                                             const uint64_t *__restrict__ seed_start, uint32_t n_seeds, uint64_t n_cand,
+                                                             const uint32_t *__restrict__ seed_len, int max_bin_cov, int flank, int min_seed_len,
+                                                             uint32_t max_bins, uint32_t *__restrict__ kept, OvlRec *__restrict__ out,
+                                                             uint32_t *__restrict__ n_out, uint32_t *__restrict__ bl_id, uint8_t *__restrict__ bl_kind)
+{
+	extern __shared__ uint16_t bins[];
+	const uint32_t sd = blockIdx.x;
+	if (sd >= n_seeds) return;
+	const int lane = threadIdx.x;
+	const uint64_t c0 = seed_start[sd], c1 = sd + 1 < n_seeds ? seed_start[sd + 1] : n_cand;
+	const uint32_t seed = cand[perm[c0]].qname;
+	const uint32_t qlen = seed_len[seed];
+	const int nb = (int)(qlen >> kBinShift) + 2;
+	uint32_t *K = kept + c0 + sd;
+	OvlRec *O = out + c0 + sd;
+	for (int i = lane; i < nb && i < (int)max_bins; i += 64) bins[i] = 0;
+	__syncthreads();
+	if (lane != 0) return;
+
+	// collection + break-point histogram
+	const int sh2 = kBinShift + 1;
+	const int off = 1 + (int)(qlen >> sh2);
+	const uint32_t qcap = qlen * 150u * 6u;
+	uint32_t n_kept = 1, qcov = qlen;
+	K[0] = kSelf;
+	for (uint64_t c = c0; c < c1; ++c) {
+		const uint32_t ci = perm[c];
+		const OvlRec o = cand[ci];
+		if (qcov > qcap || n_kept > 65535u - 1000u) continue;
+		bins[(o.qs + 10) >> sh2]++;
+		bins[((o.qe - 10) >> sh2) + off]++;
+		qcov += o.qe - o.qs + 1;
+		K[n_kept++] = ci;
+	}
+	// repeat-induced overlaps
+	{
+		const uint32_t fl = flank > 100 ? (uint32_t)flank * 3u : 300u;
+		for (uint32_t q = 1; q < n_kept; ++q) {
+			const OvlRec o = cand[K[q]];
+			if (o.qs <= fl && o.qe + fl >= qlen) continue;
+			if (bins[(o.qs + 10) >> sh2] >= 5 && bins[((o.qe - 10) >> sh2) + off] >= 5) K[q] |= kDropped;
+		}
+		for (int i = 0; i < nb; ++i) bins[i] = 0;
+		for (uint32_t q = 1; q < n_kept; ++q) {
+			if (K[q] & kDropped) continue;
+			const OvlRec o = cand[K[q]];
+			const int j = (int)((o.qs + 10) >> kBinShift), k = (int)((o.qe - 10) >> kBinShift);
+			int lowest = 65535;
+			for (int t = j + 1; t <= k; ++t) {
+				int v = (int)bins[t] + 1;
+				if (v > 65535 - 1000) --v;
+				bins[t] = (uint16_t)v;
+				if (v < lowest) lowest = v;
+			}
+			if (lowest > 2 * max_bin_cov) {
+				for (int t = j + 1; t <= k; ++t) bins[t]--;
+				K[q] |= kDropped;
+			}
+		}
+	}
+	// chimera: an uncovered bin inside the covered part that no overlap spans
+	uint32_t chimera = 0;
+	{
+		int l = 0, r = nb;
+		while (l < nb && bins[l] < 2) ++l;
+		while (r > 0 && bins[r - 1] < 2) --r;
+		for (int i = l + 1; i < r - 1 && !chimera; ++i) {
+			if (bins[i] > 1) continue;
+			const uint32_t lo2 = (uint32_t)(i > l + 15 ? (i - 15) << kBinShift : l << kBinShift);
+			const uint32_t hi2 = (uint32_t)(i + 15 < r ? (i + 15) << kBinShift : r << kBinShift);
+			bool spanned = false;
+			for (uint32_t q = 1; q < n_kept && !spanned; ++q) {
+				if (K[q] & kDropped) continue;
+				const OvlRec o = cand[K[q]];
+				spanned = o.qs < lo2 && o.qe > hi2;
+			}
+			if (!spanned) chimera = (uint32_t)i;
+		}
+	}
+	int lo = 0, hi = 0;
+	if (chimera) {
+		int j = 0;
+		uint16_t *b = bins; // (first, last) pairs of low-coverage bin runs overwrite the front of bins[]
+		if (qcov > qlen * 10u) {
+			const int low = 4 > max_bin_cov / 10 ? max_bin_cov / 10 : 4;
+			for (int i = 1; i < nb - 1; ++i) {
+				if (b[i] < low) {
+					if (lo == 0) lo = i;
+					hi = i;
+				} else if (lo) {
+					if (chimera && chimera < (uint32_t)lo && ((!j) || chimera > b[j - 1])) b[j++] = (uint16_t)chimera, b[j++] = (uint16_t)chimera;
+					b[j++] = (uint16_t)lo, b[j++] = (uint16_t)hi;
+					lo = hi = 0;
+				}
+			}
+			if (lo) {
+				if (chimera && chimera < (uint32_t)lo && ((!j) || chimera > b[j - 1])) b[j++] = (uint16_t)chimera, b[j++] = (uint16_t)chimera;
+				b[j++] = (uint16_t)lo, b[j++] = (uint16_t)hi;
+			}
+			if (chimera && (j == 0 || chimera > b[j - 1])) b[j++] = (uint16_t)chimera, b[j++] = (uint16_t)chimera;
+		} else b[j++] = (uint16_t)chimera, b[j++] = (uint16_t)chimera;
+		if (j) {
+			int m = j, k = 0, i;
+			if (b[0] < 5) m -= 2;
+			if (b[j - 1] > nb - 5) m -= 2;
+			if (m > 0) {
+				m = b[0];
+				for (i = 2; i < j; i += 2)
+					if (b[i] - b[i - 1] > m) m = b[i] - b[i - 1], k = i;
+				if (nb - b[i - 1] > m) {
+					m = nb - b[i - 1];
+					lo = b[i - 1], hi = nb;
+				} else if (b[k + 1] > nb - 5) {
+					lo = b[k - 1], hi = nb;
+				} else if (k == 0 || b[k - 2] < 5) {
+					lo = 0, hi = b[k];
+				} else {
+					lo = b[k - 1], hi = b[k];
+				}
+				lo = lo > 5 ? (lo - 5) << kBinShift : 0;
+				hi = (hi + 5) << kBinShift;
+				if (m > (min_seed_len >> kBinShift) * 2 / 3) {
+					chimera = 0;
+					for (uint32_t q = 1; q < n_kept; ++q) {
+						if (K[q] & kDropped) continue;
+						const OvlRec o = cand[K[q]];
+						if (o.qs < (uint32_t)lo || o.qe > (uint32_t)hi) K[q] |= kDropped;
+					}
+				} else chimera = 1;
+			}
+		}
+	}
+	// survivors, in order; the self record first.  A containing overlap of high-quality reads must be >= 90 % matches.
+	uint32_t n = 0, cont = 0;
+	for (uint32_t q = 0; q < n_kept; ++q) {
+		const uint32_t e = K[q];
+		OvlRec o;
+		if (e == kSelf) {
+			o.rev = 0, o.qname = o.tname = seed, o.qs = o.ts = 0, o.qe = o.te = qlen - 1, o.match = 0;
+			if (!o.qe) continue;
+		} else {
+			if (e & kDropped) continue;
+			o = cand[e];
+		}
+		O[n++] = o;
+		if (o.qname != o.tname && o.qs <= (uint32_t)flank && o.qe + (uint32_t)flank >= qlen && (double)o.match >= (double)(o.qe - o.qs + 1) * 0.9) ++cont;
+	}
+	n_out[sd] = n;
+	bl_id[sd] = seed;
+	bl_kind[sd] = cont >= 2 ? (uint8_t)'c' : chimera ? (uint8_t)'k' : (uint8_t)0;
+}
+
 void launch_seed_filter(const OvlRec *cand, const uint32_t *perm, const uint64_t *seed_start, uint32_t n_seeds, uint64_t n_cand,
                         const uint32_t *seed_len, int max_bin_cov, int flank, int min_seed_len, uint32_t max_bins, uint32_t *kept, OvlRec *out,
-                        uint32_t *n_out, uint32_t *bl_id, uint8_t *bl_kind, hipStream_t s)
+                        uint32_t *n_out, uint32_t *bl_id, uint8_t *bl_kind, bool hq, hipStream_t s)
 {
-	if (n_seeds) hipLaunchKernelGGL(seed_filter_kernel, dim3(n_seeds), dim3(64), (size_t)max_bins * 2, s, cand, perm, seed_start, n_seeds, n_cand,
+	if (n_seeds && hq) hipLaunchKernelGGL(seed_filter_hq_kernel, dim3(n_seeds), dim3(64), (size_t)max_bins * 2, s, cand, perm, seed_start, n_seeds,
+	                                      n_cand, seed_len, max_bin_cov, flank, min_seed_len, max_bins, kept, out, n_out, bl_id, bl_kind);
+	else if (n_seeds) hipLaunchKernelGGL(seed_filter_kernel, dim3(n_seeds), dim3(64), (size_t)max_bins * 2, s, cand, perm, seed_start, n_seeds, n_cand,
 	                                seed_len, max_bin_cov, flank, min_seed_len, max_bins, kept, out, n_out, bl_id, bl_kind);
 }
 

@@ -244,15 +244,16 @@ def from_decoded(a: np.ndarray) -> np.ndarray:
     return r
 
 
-def sort_overlaps(files, seed_len: np.ndarray, min_seed_len: int, max_bin_cov: int = 40, max_flank_len: int = 300):
+def sort_overlaps(files, seed_len: np.ndarray, min_seed_len: int, max_bin_cov: int = 40, max_flank_len: int = 300, hq: bool = False):
     """The `ovl_sort` step on the device (ndgpu_ovl_sort).  files = list of record arrays (step-1 overlaps, one per
     input file, fofn order).  Returns (sorted records, [(seed id, 'c'|'k'), ...], stats dict)."""
     lib = load()
     if not hasattr(lib.ndgpu_ovl_sort, "_bound"):
-        lib.ndgpu_ovl_sort.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_uint32, C.c_int32,
-                                       C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                       C.POINTER(C.c_int64), C.POINTER(SortStats)]
-        lib.ndgpu_ovl_sort.restype = C.c_int64
+        for fn in (lib.ndgpu_ovl_sort, lib.ndgpu_ovl_sort_hq):
+            fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_uint32, C.c_int32,
+                           C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                           C.POINTER(C.c_int64), C.POINTER(SortStats)]
+            fn.restype = C.c_int64
         lib.ndgpu_ovl_sort._bound = True
     files = [np.ascontiguousarray(f, dtype=REC) for f in files]
     nf = len(files)
@@ -262,7 +263,7 @@ def sort_overlaps(files, seed_len: np.ndarray, min_seed_len: int, max_bin_cov: i
     out, bid, bkind = C.c_void_p(), C.c_void_p(), C.c_void_p()
     nbl = C.c_int64(0)
     st = SortStats()
-    n = lib.ndgpu_ovl_sort(ptrs, cnts, nf, _ptr(seed_len), seed_len.size, int(min_seed_len), int(max_bin_cov), int(max_flank_len),
+    n = (lib.ndgpu_ovl_sort_hq if hq else lib.ndgpu_ovl_sort)(ptrs, cnts, nf, _ptr(seed_len), seed_len.size, int(min_seed_len), int(max_bin_cov), int(max_flank_len),
                            C.byref(out), C.byref(bid), C.byref(bkind), C.byref(nbl), C.byref(st))
     if n < 0:
         raise RuntimeError("ndgpu_ovl_sort failed (%d): no usable HIP device?" % n)

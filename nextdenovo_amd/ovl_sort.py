@@ -8,7 +8,7 @@ util/ovl_sort.c:1040-1078):
 
 `-m`, `-t`, `-d` only shape the reference's external merge sort and are accepted and ignored: the device sort is
 in-memory (equal (seed, match, span) keys keep input order, which is what the reference produces when its buffers
-are not spilled).  `-H` (HiFi filter variant) and `-l 0` are not built and are refused.
+are not spilled).  `-H` selects the high-quality-read variant of the filter (`ndgpu_ovl_sort_hq`); `-l 0` is refused.
 """
 from __future__ import annotations
 
@@ -60,13 +60,11 @@ def run(argv) -> int:
     ap.add_argument("-d", dest="tmpdir", default=None)
     ap.add_argument("fofn")
     a = ap.parse_args(argv)
-    if a.hq:
-        raise SystemExit("[ERROR] -H (HiFi overlap filter) is not built in this engine")
     if a.flank <= 0:
         raise SystemExit("[ERROR] -l must be > 0")
     seed_len, min_len = read_idx(a.idx)
     files = [overlap.from_decoded(ovl.decode_ovl(p)) for p in read_fofn(a.fofn)]
-    recs, bl, _ = overlap.sort_overlaps(files, seed_len, min_len, a.k, a.flank)
+    recs, bl, _ = overlap.sort_overlaps(files, seed_len, min_len, a.k, a.flank, hq=a.hq)
     with open(a.out, "wb") as f:
         f.write(overlap.encode(recs, np.zeros(2, dtype=np.uint32)))
     with open(a.out + ".bl", "w") as f:

@@ -313,3 +313,23 @@ def test_fused_stage_from_fasta(tmp_path):
     for tag in ("001", "002"):
         x = open(os.path.join(wd, "one.%s.fasta" % tag), "rb").read()
         assert len(x) > 20000 and x == open(os.path.join(wd, "two.%s.fasta" % tag), "rb").read()
+
+
+@pytest.mark.skipif(not all(os.path.exists(os.path.join(O.REFDIR, n)) for n in ("minimap2-nd", "ovl_sort", "seq_dump")),
+                    reason="oracle/_ref not built")
+@pytest.mark.parametrize("profile,preset,k,flank", [("hifi", "ava-hifi", 28, None), ("hifi", "ava-hifi", 6, 120), ("ont", "ava-ont", 30, None)])
+def test_sort_hq_variant_matches_reference(tmp_path, profile, preset, k, flank):
+    """`ovl_sort -H` on the device (ndgpu_ovl_sort_hq through the stage command line) against the compiled reference
+    `ovl_sort -H`: sorted.ovl and .bl, byte for byte (HiFi reads, and noisy reads with chimeras for the 'k' path)."""
+    from test_ovlsort_oracle import _hq_inputs
+    from nextdenovo_amd import ovl_sort
+    wd, files, idx = _hq_inputs(profile, preset, 14, 8500 if profile == "hifi" else 7000, extra=("-f", "700") if profile == "hifi" else ())
+    want, want_bl = O.ref_sort(wd, idx, files, k=k, flank=flank, hq=True)
+    fofn = os.path.join(wd, "mine.fofn")
+    with open(fofn, "w") as f:
+        f.write("\n".join(files) + "\n")
+    so = os.path.join(wd, "mine.sorted.ovl")
+    argv = ["-H", "-m", "2g", "-t", "4", "-k", str(k)] + (["-l", str(flank)] if flank else []) + ["-i", idx, "-o", so, fofn]
+    assert ovl_sort.run(argv) == 0
+    assert len(want) > 10000 and open(so, "rb").read() == want
+    assert open(so + ".bl").read() == want_bl
