@@ -84,3 +84,83 @@ def test_oracle_shift(oracle_lib):
     ts2, te2 = C.c_uint(0), C.c_uint(9)
     assert oracle_lib.nd_oracle_shift(bad.ctypes.data_as(C.POINTER(C.c_uint8)), bad.size, 8, C.byref(ts2),
                                       C.byref(te2), C.byref(sh)) == 0
+
+
+@pytest.mark.skipif(not refpipe.have_ref("nextcorrect.so"), reason="compiled reference not present")
+def test_prefix_and_extension_variants_vs_reference(oracle_lib):
+    """oracle/ond_ext_oracle.c against the reference's exported `ide`, `alnpos`, `extend_fwd`, `extend_rev`
+    (lib/align.h:51-58) with the call patterns of the HiFi mode-3 overlap path (minimap2/map.c:385-482, 941-956):
+    extensions of unaligned read ends (d_factor 0.1, band 500) and trimmed alignments of homopolymer-compressed blocks."""
+    from nextdenovo_amd import synth
+    lib = refpipe.ref_cns()
+    P = C.c_void_p
+    lib.malloc_vd.argtypes = [C.POINTER(C.POINTER(C.c_int)), C.POINTER(P), C.c_uint64]
+    lib.clean_V.argtypes = [C.POINTER(C.c_int), C.c_int]
+    lib.destory_vd.argtypes = [C.POINTER(C.c_int), P]
+    lib.ide.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.alnpos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), P, C.c_int, C.c_int, C.POINTER(C.c_uint * 6)]
+    for f in (lib.extend_fwd, lib.extend_rev):
+        f.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), P, C.c_int, C.c_int, C.c_float,
+                      C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for f in (lib.ide, lib.alnpos, lib.extend_fwd, lib.extend_rev):
+        f.restype = None
+    o = oracle_lib
+    o.nd_oracle_ide.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    o.nd_oracle_alnpos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint * 6)]
+    o.nd_oracle_extend.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]
+    mem_d = 6000                                    # opt->ide_ml (minimap2/options.c:60)
+    V = C.POINTER(C.c_int)()
+    D = P()
+    lib.malloc_vd(C.byref(V), C.byref(D), mem_d)
+    assert D.value
+    rng = np.random.default_rng(123)
+    seen = {"ide": 0, "alnpos": 0, "ext_peak": 0, "ext_stop": 0, "ext_end": 0, "unaligned": 0}
+    try:
+        for it in range(400):
+            L = int(rng.integers(10, 4000))
+            base = rng.integers(0, 4 if it % 9 else 2, L, dtype=np.uint8)
+            prof = ("hifi", "hifi", "ont", "clr")[it % 4]
+            q = synth.mutate(base, np.random.default_rng(3 * it), prof)[0]
+            t = synth.mutate(base, np.random.default_rng(3 * it + 1), prof)[0]
+            if it % 5 == 0:                          # the sequences diverge after a common prefix: the peak ends the extension
+                cut = int(rng.integers(5, max(6, L // 2)))
+                t = np.concatenate([t[:cut], rng.integers(0, 4, int(rng.integers(50, 1500)), dtype=np.uint8)])
+            if it % 7 == 0:
+                q = q[: max(1, q.size - int(rng.integers(0, 300)))]
+            qa, ta = util.ASC[q].tobytes(), util.ASC[t].tobytes()
+            ql, tl = len(qa), len(ta)
+            minlen = min(ql, tl)
+            # nd_extend_ends' budgets (map.c:404-406): max_d = minlen/4 capped at ide_ml (minlen itself when <= 20), band 500
+            max_d = min(mem_d, minlen // 4 if minlen > 20 else minlen)
+            for rev, fn in ((0, lib.extend_fwd), (1, lib.extend_rev)):
+                lib.clean_V(V, mem_d)
+                bx, by, ox, oy = C.c_int(-7), C.c_int(-7), C.c_int(-9), C.c_int(-9)
+                fn(qa, ql, ta, tl, V, D, max_d, 500, 0.1, C.byref(bx), C.byref(by))
+                o.nd_oracle_extend(qa, ql, ta, tl, max_d, 500, 0.1, rev, C.byref(ox), C.byref(oy))
+                assert (bx.value, by.value) == (ox.value, oy.value), (it, rev)
+                if bx.value >= ql or by.value >= tl:
+                    seen["ext_end"] += 1
+                elif bx.value or by.value:
+                    seen["ext_peak"] += 1
+                else:
+                    seen["ext_stop"] += 1
+            # the trimmed re-alignment of map.c:941-956: max_d = alnlen/5 capped, band = max_d > 1500 ? 500 : max_d/3
+            alnlen = max(ql, tl)
+            md = min(mem_d, alnlen // 5)
+            band = 500 if md > 1500 else md // 3
+            lib.clean_V(V, mem_d)
+            ra, oa = (C.c_uint * 6)(*([4242] * 6)), (C.c_uint * 6)(*([4242] * 6))
+            lib.alnpos(qa, ql, ta, tl, V, D, md, band, C.byref(ra))
+            o.nd_oracle_alnpos(qa, ql, ta, tl, md, band, C.byref(oa))
+            assert list(ra) == list(oa), it
+            seen["alnpos" if ra[0] != 4242 else "unaligned"] += 1
+            lib.clean_V(V, mem_d)
+            m1, b1, m2, b2 = C.c_int(-1), C.c_int(-1), C.c_int(-1), C.c_int(-1)
+            lib.ide(qa, ql, ta, tl, V, D, md, band, C.byref(m1), C.byref(b1))
+            o.nd_oracle_ide(qa, ql, ta, tl, md, band, C.byref(m2), C.byref(b2))
+            assert (m1.value, b1.value) == (m2.value, b2.value), it
+            seen["ide"] += m1.value >= 0
+    finally:
+        lib.destory_vd(V, D)
+    assert seen["ide"] > 150 and seen["alnpos"] > 150 and seen["ext_end"] > 100 and seen["ext_peak"] > 50 and seen["unaligned"] > 5, seen
