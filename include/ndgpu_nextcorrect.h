@@ -67,6 +67,45 @@ void revcomp_bseq(char *str, int len);
 void reverse_str(char *str, int len);
 void str_tolower(char *p);
 void str_toupper(char *p);
+/* ---- the prefix / extension members of the O(ND) family (reference lib/align.h:36-58, lib/align.c:80-426; callers
+ *      minimap2/map.c:385-482, 941-956 and lib/ctg_cns.c).  GPU-backed (csrc/ext_kernels.hip); V and D are ignored. ---- */
+typedef struct {
+    unsigned int aln_len;  /* alignment columns */
+    unsigned int aln_mlen; /* matching columns */
+    unsigned int aln_t_s;
+    unsigned int aln_t_e;  /* exclusive */
+    unsigned int aln_q_s;
+    unsigned int aln_q_e;  /* exclusive */
+} alignpos;
+/* replaces lib/align.c:80-141: *mlen / *blen are written when either sequence is exhausted within max_d steps and the band cap */
+void ide(const char *query_seq, int q_len, const char *target_seq, int t_len, int *V, uint8_t **D, int max_d, int band_size,
+         int *mlen, int *blen);
+/* replaces lib/align.c:146-253: *aln is written under the same condition */
+void alnpos(const char *query_seq, int q_len, const char *target_seq, int t_len, int *V, uint8_t **D, int max_d, int band_size,
+            alignpos *aln);
+/* replace lib/align.c:256-340 / :343-426: (*bstx, *bsty) = query / target bases covered at the peak of (x + y) * d_factor - d */
+void extend_fwd(const char *query_seq, int q_len, const char *target_seq, int t_len, int *V, uint8_t **D, int max_d, int band_size,
+                float d_factor, int *bstx, int *bsty);
+void extend_rev(const char *query_seq, int q_len, const char *target_seq, int t_len, int *V, uint8_t **D, int max_d, int band_size,
+                float d_factor, int *bstx, int *bsty);
+/* additive: a batch of such problems in one launch (one lane per problem) -- what nd_extend_ends' loop over the overlaps of a read
+ * (minimap2/map.c:385-482) would hand over.  kind: 0 ide, 1 alnpos, 2 extend_fwd, 3 extend_rev.  result: done = an end condition
+ * fired; (a, b) = (mlen, blen) or (bstx, bsty); pos[6] = the fields of `alignpos` (alnpos only).  Returns 0, < 0 on error. */
+typedef struct ndgpu_ext_job {
+    const char *q;
+    int32_t q_len;
+    const char *t;
+    int32_t t_len;
+    int32_t max_d, band_size;
+    float d_factor;
+    int32_t kind;
+} ndgpu_ext_job;
+typedef struct ndgpu_ext_result {
+    int32_t done, a, b;
+    uint32_t pos[6];
+} ndgpu_ext_result;
+int ndgpu_ext_batch(const ndgpu_ext_job *jobs, int n, ndgpu_ext_result *res);
+
 /* replaces: reference lib/nextcorrect.h:166 / lib/dag.c:658-694.  `seqs` points at
  * `seq_count` records laid out as the reference's `struct seq_`
  * (lib/nextcorrect.h:63-68: u16 order, u16 kscore, u16 len, char seq[10000]). */

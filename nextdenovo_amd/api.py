@@ -161,6 +161,34 @@ class ReadDB:
         return [_take(self._lib, out[i]) for i in range(n)]
 
 
+class ExtJob(C.Structure):
+    _fields_ = [("q", C.c_char_p), ("q_len", C.c_int32), ("t", C.c_char_p), ("t_len", C.c_int32), ("max_d", C.c_int32),
+                ("band_size", C.c_int32), ("d_factor", C.c_float), ("kind", C.c_int32)]
+
+
+class ExtResult(C.Structure):
+    _fields_ = [("done", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("pos", C.c_uint32 * 6)]
+
+
+EXT_KINDS = {"ide": 0, "alnpos": 1, "extend_fwd": 2, "extend_rev": 3}
+
+
+def ext_batch(jobs):
+    """jobs: [(kind, q bytes, t bytes, max_d, band_size, d_factor)] -> [(done, a, b, pos[6])] through ndgpu_ext_batch
+    (the ide / alnpos / extend_fwd / extend_rev family of lib/align.h:51-58, one device launch)."""
+    lib = load()
+    n = len(jobs)
+    arr = (ExtJob * max(1, n))()
+    for i, (kind, q, t, max_d, band, f) in enumerate(jobs):
+        arr[i] = ExtJob(q, len(q), t, len(t), max_d, band, f, EXT_KINDS[kind])
+    res = (ExtResult * max(1, n))()
+    lib.ndgpu_ext_batch.argtypes = [C.POINTER(ExtJob), C.c_int, C.POINTER(ExtResult)]
+    lib.ndgpu_ext_batch.restype = C.c_int
+    if lib.ndgpu_ext_batch(arr, n, res) != 0:
+        raise RuntimeError("ndgpu_ext_batch failed: no usable HIP device?")
+    return [(r.done, r.a, r.b, list(r.pos)) for r in res[:n]]
+
+
 def stats() -> dict:
     lib = load()
     s = Stats()

@@ -254,3 +254,77 @@ print("FORK_OK")
 ''' % (os.path.dirname(util.HERE), util.HERE)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "FORK_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_prefix_and_extension_family_vs_oracle(lib, oracle_lib):
+    """`ide`, `alnpos`, `extend_fwd`, `extend_rev` on the device (ndgpu_ext_batch, one lane per problem, and the single-call
+    exports with the reference's signatures) against oracle/ond_ext_oracle.c, which tests/test_oracle.py pins to the compiled
+    reference: budgets and bands of the HiFi mode-3 overlap path (minimap2/map.c:404-406, 941-943)."""
+    from nextdenovo_amd import api, synth
+    o = oracle_lib
+    o.nd_oracle_ide.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    o.nd_oracle_alnpos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint * 6)]
+    o.nd_oracle_extend.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]
+    rng = np.random.default_rng(321)
+    jobs, want = [], []
+    for it in range(260):
+        L = int(rng.integers(10, 5000))
+        base = rng.integers(0, 4 if it % 9 else 2, L, dtype=np.uint8)
+        prof = ("hifi", "hifi", "ont", "clr")[it % 4]
+        q = synth.mutate(base, np.random.default_rng(5 * it), prof)[0]
+        t = synth.mutate(base, np.random.default_rng(5 * it + 1), prof)[0]
+        if it % 5 == 0:
+            cut = int(rng.integers(5, max(6, L // 2)))
+            t = np.concatenate([t[:cut], rng.integers(0, 4, int(rng.integers(50, 1500)), dtype=np.uint8)])
+        if it % 7 == 0:
+            q = q[: max(1, q.size - int(rng.integers(0, 300)))]
+        qa, ta = util.ASC[q].tobytes(), util.ASC[t].tobytes()
+        minlen = min(len(qa), len(ta))
+        max_d = min(6000, minlen // 4 if minlen > 20 else minlen)
+        for rev, kind in ((0, "extend_fwd"), (1, "extend_rev")):
+            x, y = C.c_int(0), C.c_int(0)
+            o.nd_oracle_extend(qa, len(qa), ta, len(ta), max_d, 500, 0.1, rev, C.byref(x), C.byref(y))
+            jobs.append((kind, qa, ta, max_d, 500, 0.1))
+            want.append((None, x.value, y.value, None))
+        md = min(6000, max(len(qa), len(ta)) // 5)
+        band = 500 if md > 1500 else md // 3
+        pos = (C.c_uint * 6)(*([4242] * 6))
+        o.nd_oracle_alnpos(qa, len(qa), ta, len(ta), md, band, C.byref(pos))
+        jobs.append(("alnpos", qa, ta, md, band, 0.0))
+        want.append((int(pos[0] != 4242), None, None, list(pos)))
+        m, b = C.c_int(-1), C.c_int(-1)
+        o.nd_oracle_ide(qa, len(qa), ta, len(ta), md, band, C.byref(m), C.byref(b))
+        jobs.append(("ide", qa, ta, md, band, 0.0))
+        want.append((int(m.value >= 0), m.value, b.value, None))
+    got = api.ext_batch(jobs)
+    n_aln = 0
+    for i, ((kind, *_), w, g) in enumerate(zip(jobs, want, got)):
+        done, a, b, pos = g
+        if kind.startswith("extend"):
+            assert (a, b) == (w[1], w[2]), (i, kind)
+        elif kind == "ide":
+            assert done == w[0] and (not done or (a, b) == (w[1], w[2])), (i, kind)
+        else:
+            assert done == w[0] and (not done or pos == w[3]), (i, kind)
+            n_aln += done
+    assert n_aln > 100
+    # the single-call exports (lib/align.h:51-58 signatures; V / D ignored)
+    P = C.c_void_p
+    lib.extend_fwd.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, P, P, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.alnpos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, P, P, C.c_int, C.c_int, C.POINTER(C.c_uint * 6)]
+    lib.ide.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, P, P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for f in (lib.extend_fwd, lib.alnpos, lib.ide):
+        f.restype = None
+    for i in (0, 3, 6):
+        kind, qa, ta, md, band, f = jobs[i * 4 + 0]
+        x, y = C.c_int(-5), C.c_int(-5)
+        lib.extend_fwd(qa, len(qa), ta, len(ta), None, None, md, band, 0.1, C.byref(x), C.byref(y))
+        assert (x.value, y.value) == (want[i * 4][1], want[i * 4][2])
+        kind, qa, ta, md, band, f = jobs[i * 4 + 2]
+        pos = (C.c_uint * 6)(*([4242] * 6))
+        lib.alnpos(qa, len(qa), ta, len(ta), None, None, md, band, C.byref(pos))
+        assert list(pos) == want[i * 4 + 2][3]
+        m, b = C.c_int(-1), C.c_int(-1)
+        lib.ide(qa, len(qa), ta, len(ta), None, None, md, band, C.byref(m), C.byref(b))
+        assert (m.value, b.value) == (want[i * 4 + 3][1], want[i * 4 + 3][2])
