@@ -537,8 +537,61 @@ int nd_mm_gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const nd
 
 /* regs needs room for the chain count (<= number of anchors / min_cnt); returns the number of hits.
  * work buffers are allocated inside. */
+/* --mode 3, align_regs (minimap2/map.c:484-497): nd_fix_bad_ends (:327-373) drops the anchors at either end of a chain that sit
+ * off the chain's diagonal by more than half the length walked so far (within the first / last 2 x bw bases or until enough
+ * matches are seen), nd_update_coors (:313-325) recomputes the coordinates from what is left; mlen / blen keep their values */
+static void trim_bad_chain_ends(nd_mm_reg *r, const nd_mm128 *a, int qlen, int bw, int min_match)
+{
+	int32_t i, l, m, as = r->as, cnt = r->cnt;
+	if (r->cnt < 3) return;
+	m = l = (int32_t)(a[r->as].y >> 32 & 0xff);
+	for (i = r->as + 1; i < r->as + r->cnt - 1; ++i) {
+		const int32_t span = (int32_t)(a[i].y >> 32 & 0xff);
+		const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+		const int32_t lo = lr < lq ? lr : lq, hi = lr > lq ? lr : lq;
+		if (hi - lo > l >> 1) as = i;
+		l += lo;
+		m += lo < span ? lo : span;
+		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r->mlen >> 1) break;
+	}
+	cnt = r->as + r->cnt - as;
+	m = l = (int32_t)(a[r->as + r->cnt - 1].y >> 32 & 0xff);
+	for (i = r->as + r->cnt - 2; i > as; --i) {
+		const int32_t span = (int32_t)(a[i + 1].y >> 32 & 0xff);
+		const int32_t lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+		const int32_t lo = lr < lq ? lr : lq, hi = lr > lq ? lr : lq;
+		if (hi - lo > l >> 1) cnt = i + 1 - as;
+		l += lo;
+		m += lo < span ? lo : span;
+		if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r->mlen >> 1) break;
+	}
+	if (r->as == as && r->cnt == cnt) return;
+	r->as = as, r->cnt = cnt;
+	{
+		const int32_t k = r->as, span = (int32_t)(a[k].y >> 32 & 0xff);
+		r->rs = (int32_t)a[k].x + 1 > span ? (int32_t)a[k].x + 1 - span : 0;
+		r->re = (int32_t)a[k + r->cnt - 1].x + 1;
+		if (!r->rev) {
+			r->qs = (int32_t)a[k].y + 1 - span;
+			r->qe = (int32_t)a[k + r->cnt - 1].y + 1;
+		} else {
+			r->qs = qlen - ((int32_t)a[k + r->cnt - 1].y + 1);
+			r->qe = qlen - ((int32_t)a[k].y + 1 - span);
+		}
+	}
+}
+
+static int map_read_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
+                         nd_mm_reg *regs, int reg_cap, int mode3);
+
 int nd_mm_map_read(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
                    nd_mm_reg *regs, int reg_cap)
+{
+	return map_read_impl(ix, opt, mid_occ, qid, qcodes, qlen, regs, reg_cap, 0);
+}
+
+static int map_read_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
+                         nd_mm_reg *regs, int reg_cap, int mode3)
 {
 	char qname[12];
 	nd_mm128 *mv, *a;
@@ -560,6 +613,8 @@ int nd_mm_map_read(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uin
 	n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
 	n = n_u <= reg_cap ? n_u : -n_u;
 	if (n > 0) nd_mm_gen_regs(nd_mm_read_hash(qname, qlen, opt->seed), qlen, n_u, u, a, regs);
+	if (n > 0 && mode3)
+		for (i = 0; i < n; ++i) trim_bad_chain_ends(&regs[i], a, qlen, opt->bw, opt->min_sc * 2);
 	free(mv); free(a); free(u);
 	return n;
 }
@@ -623,13 +678,63 @@ int64_t nd_mm_encode(const nd_mm_index *ix, const nd_mm_opt *opt, uint32_t qid, 
 	return n;
 }
 
+/* ---------------------------------------------------------------- --mode 3: extension of the hit ends */
+
+void nd_oracle_extend(const char *q, int q_len, const char *t, int t_len, int max_d, int band, float d_factor, int rev, int *bstx, int *bsty);
+
+/* nd_extend_ends (minimap2/map.c:385-482), run on every query after mm_map_frag when --mode 3 is given (map.c:919-928):
+ * each hit is extended into the unaligned read ends with extend_rev / extend_fwd (oracle/ond_ext_oracle.c) over at most
+ * 2 x the shorter overhang of the target, edit budget overhang / 4 (capped at ide_ml = 6000), band 500, d_factor 0.1 */
+static void extend_hit_ends(const nd_mm_opt *opt, const nd_mm_index *ix, const uint8_t *q, int qlen, uint32_t qid, const uint8_t *tcodes,
+                            const uint64_t *toff, const uint32_t *tids, nd_mm_reg *regs, int n)
+{
+	const int min_clen = 10, mem_d = 6000;
+	const float df = 0.1f;
+	int i, j, bx, by;
+	size_t cap = (size_t)qlen * 2 + 16;
+	uint8_t *buf = (uint8_t*)malloc(cap);
+	for (i = 0; i < n; ++i) {
+		nd_mm_reg *r = &regs[i];
+		const uint8_t *T = tcodes + toff[r->rid];
+		const int tl = (int)ix->len[r->rid];
+		int side;
+		if (tids[r->rid] == qid) continue;
+		if (opt->dvt && !dovetail_class(r->rev, (uint32_t)r->qs, (uint32_t)r->qe, (uint32_t)qlen, (uint32_t)r->rs, (uint32_t)r->re,
+		                                (uint32_t)tl, opt->maxhan1 * 3, opt->maxhan2 * 3)) continue;
+		if ((size_t)tl + 16 > cap) { cap = (size_t)tl + 16; buf = (uint8_t*)realloc(buf, cap); }
+		for (side = 0; side < 2; ++side) {
+			/* side 0 extends the query's 5' end (extend_rev), side 1 its 3' end (extend_fwd); on a reverse hit the query's
+			 * 5' end faces the target's 3' end and the target slice is reverse-complemented */
+			const int left_q = side == 0;
+			const int t_low = r->rev ? !left_q : left_q;  /* the target overhang below rs (1) or above re (0) */
+			int subq = left_q ? r->qs : qlen - r->qe;
+			int subt = t_low ? r->rs : tl - r->re;
+			int minlen = subt > subq ? subq : subt, max_d, st, en;
+			if (minlen < min_clen) continue;
+			max_d = minlen / 4 > mem_d ? mem_d : (minlen > 20 ? minlen / 4 : minlen);
+			if (subt > (minlen << 1)) {
+				subt = minlen << 1;
+				if (t_low) st = r->rs - subt, en = r->rs; else st = r->re, en = r->re + subt;
+			} else {
+				if (t_low) st = 0, en = r->rs; else st = r->re, en = tl;
+			}
+			if (r->rev) for (j = st; j < en; ++j) buf[en - 1 - j] = (uint8_t)(3 - T[j]);
+			else for (j = st; j < en; ++j) buf[j - st] = T[j];
+			nd_oracle_extend((const char*)(left_q ? q : q + r->qe), subq, (const char*)buf, subt, max_d, 500, df, left_q, &bx, &by);
+			if (left_q) r->qs -= bx; else r->qe += bx;
+			if (t_low) r->rs -= by; else r->re += by;
+		}
+	}
+	free(buf);
+}
+
 /* Whole `minimap2-nd --step 1 target query` run for ONE index part (prev_io carries the delta state of
  * encode_ovl from part to part; the caller fixes mid_occ after the first part, options.c:70-71).
  * Returns the number of .ovl bytes written (or -needed if out_cap is too small). */
-int64_t nd_mm_step1(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
-                    int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
-                    int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
-                    uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io)
+static int64_t step1_impl(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
+                          int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
+                          int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
+                          uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io, int mode3)
 {
 	nd_mm_index *ix = nd_mm_index_build(n_t, tcodes, toff, tlen, tids, opt->w, opt->k, opt->hpc);
 	int mid_occ = mid_occ_fixed > 0 ? mid_occ_fixed : nd_mm_index_mid_occ(ix, mid_occ_frac);
@@ -639,12 +744,13 @@ int64_t nd_mm_step1(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
 	nd_mm_reg *regs = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * reg_cap);
 	if (mid_occ_out) *mid_occ_out = mid_occ;
 	for (i = 0; i < n_q; ++i) {
-		int n_regs = nd_mm_map_read(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)qlen[i], regs, reg_cap);
+		int n_regs = map_read_impl(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)qlen[i], regs, reg_cap, mode3);
 		if (n_regs < 0) {
 			reg_cap = -n_regs + 1024;
 			regs = (nd_mm_reg*)realloc(regs, sizeof(nd_mm_reg) * reg_cap);
-			n_regs = nd_mm_map_read(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)qlen[i], regs, reg_cap);
+			n_regs = map_read_impl(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)qlen[i], regs, reg_cap, mode3);
 		}
+		if (mode3 && n_regs > 0) extend_hit_ends(opt, ix, qcodes + qoff[i], (int)qlen[i], qids[i], tcodes, toff, tids, regs, n_regs);
 		if (n + 40LL * n_regs > out_cap) { n = -(n + 40LL * n_regs); break; }
 		n += nd_mm_encode(ix, opt, qids[i], (int)qlen[i], tids, regs, n_regs, prev, out + n);
 	}
@@ -652,4 +758,23 @@ int64_t nd_mm_step1(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
 	nd_mm_index_free(ix);
 	if (prev_io && n >= 0) prev_io[0] = prev[0], prev_io[1] = prev[1];
 	return n;
+}
+
+int64_t nd_mm_step1(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
+                    int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
+                    int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
+                    uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io)
+{
+	return step1_impl(opt, mid_occ_frac, mid_occ_fixed, n_t, tcodes, toff, tlen, tids, n_q, qcodes, qoff, qlen, qids, out, out_cap, mid_occ_out,
+	                  prev_io, 0);
+}
+
+/* the same with `--mode 3` (HiFi: the ends of every hit are extended before the step-1 filter, minimap2/map.c:919-928) */
+int64_t nd_mm_step1_mode3(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_fixed,
+                          int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
+                          int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
+                          uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io)
+{
+	return step1_impl(opt, mid_occ_frac, mid_occ_fixed, n_t, tcodes, toff, tlen, tids, n_q, qcodes, qoff, qlen, qids, out, out_cap, mid_occ_out,
+	                  prev_io, 1);
 }

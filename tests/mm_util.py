@@ -73,6 +73,8 @@ def bind(lib):
     lib.nd_mm_step1.argtypes = [C.POINTER(MMOpt), C.c_float, C.c_int, C.c_int32, P, P, P, P, C.c_int32, P, P, P, P, P,
                                 C.c_int64, P, P]
     lib.nd_mm_step1.restype = C.c_int64
+    lib.nd_mm_step1_mode3.argtypes = lib.nd_mm_step1.argtypes
+    lib.nd_mm_step1_mode3.restype = C.c_int64
     return lib
 
 
@@ -88,7 +90,7 @@ def sketch(lib, codes: np.ndarray, w, k, rid=0, hpc=0) -> np.ndarray:
     return out[:n].copy()
 
 
-def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0, batch_size=None):
+def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0, batch_size=None, mode3=False):
     """tset/qset = (ids, lens, codes, off).  Returns (.ovl bytes, mid_occ).  batch_size = the -I value: the
     target set is indexed in parts (nextdenovo_amd.minimap2_nd.index_parts restates mm_idx_gen's rule)."""
     tid, tl, tc, to = tset
@@ -105,7 +107,7 @@ def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0, batch_size=
             out = np.zeros(cap, dtype=np.uint8)
             mo = C.c_int32(0)
             pv = prev.copy()
-            n = lib.nd_mm_step1(C.byref(opt), np.float32(mid_occ_frac), mid_occ, hi - lo, ptr(tc), ptr(to[lo:hi]), ptr(tl[lo:hi]),
+            n = (lib.nd_mm_step1_mode3 if mode3 else lib.nd_mm_step1)(C.byref(opt), np.float32(mid_occ_frac), mid_occ, hi - lo, ptr(tc), ptr(to[lo:hi]), ptr(tl[lo:hi]),
                                 ptr(tid[lo:hi]), qid.size, ptr(qc), ptr(qo), ptr(ql), ptr(qid), ptr(out), cap, C.byref(mo), ptr(pv))
             if n >= 0:
                 break

@@ -84,3 +84,21 @@ def test_oracle_matches_live_reference(lib, profile, preset):
         want = M.ref_step1(t, q, os.path.join(wd, "o.ovl"), preset, dual)
         got, _ = M.step1(lib, M.preset(preset, dual), S, S if q == seed else P, **case_kwargs((), preset))
         assert len(want) > 1000 and got == want
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(M.REFDIR, "minimap2-nd")), reason="oracle/_ref not built")
+@pytest.mark.parametrize("extra", [(), ("--dvt",), ("-f", "40")])
+def test_oracle_mode3_end_extension_matches_live_reference(lib, sets, extra):
+    """`--step 1 --mode 3` (HiFi: nd_extend_ends stretches every hit into the unaligned read ends with extend_rev / extend_fwd
+    before the step-1 filter, minimap2/map.c:385-482, 919-928): the oracle's `.ovl` against the compiled reference's, on the
+    committed HiFi read sets, both strands, with and without the dovetail pre-filter."""
+    wd = tempfile.mkdtemp(prefix="ndm3")
+    for t, q, dual in (("hseed", "hseed", False), ("hseed", "hpart", True)):
+        want = M.ref_step1(os.path.join(GOLD, t + ".2bit"), os.path.join(GOLD, q + ".2bit"), os.path.join(wd, "o.ovl"), "ava-hifi", dual,
+                           extra=("--mode", "3") + tuple(extra))
+        plain = M.ref_step1(os.path.join(GOLD, t + ".2bit"), os.path.join(GOLD, q + ".2bit"), os.path.join(wd, "p.ovl"), "ava-hifi", dual,
+                            extra=tuple(extra))
+        kw = case_kwargs(extra, "ava-hifi")
+        got, _ = M.step1(lib, M.preset("ava-hifi", dual, dvt=1 if "--dvt" in extra else 0), sets[t], sets[q], mode3=True, **kw)
+        assert len(want) > 5000 and got == want
+        assert want != plain   # the extension really moves coordinates on this set
