@@ -183,7 +183,13 @@ def main(args):
     words, word_off, lens = ovl.load_read_db(args.idxs)
     db = api.ReadDB(words, word_off, lens)
     recs = ovl.decode_ovl(args.ovl)
-    piles = list(assemble_piles(recs, args, skip))
+    # pile admission (lib/nextcorrect.py:92-143): one native pass (ndgpu_assemble_piles) instead of a Python loop over every
+    # record; `assemble_piles` above is the line-by-line restatement the tests hold it against
+    from nextdenovo_amd import overlap
+    n_ids = max(int(lens.size), int(recs[:, [0, 4]].max()) + 1 if recs.size else 0)
+    recs, off, names = overlap.assemble_piles(overlap.from_decoded(recs), n_ids, args.min_len_seed, args.min_len_aln, args.max_cov_aln,
+                                              args.min_cov_seed, sorted(skip))
+    piles = [(int(names[p]), np.arange(int(off[p]), int(off[p + 1]))) for p in range(names.size)]
 
     fail_seed = correct_and_write(db, recs, piles, args, OUT, IDX)
     db.close()
