@@ -164,3 +164,87 @@ def test_prefix_and_extension_variants_vs_reference(oracle_lib):
     finally:
         lib.destory_vd(V, D)
     assert seen["ide"] > 150 and seen["alnpos"] > 150 and seen["ext_end"] > 100 and seen["ext_peak"] > 50 and seen["unaligned"] > 5, seen
+
+
+@pytest.mark.skipif(not refpipe.have_ref("ovlseq.so"), reason="compiled reference not present")
+@pytest.mark.parametrize("seed,n_reads,n_ovl,han1,han2", [(1, 40, 1500, 500, 50), (2, 300, 6000, 5000, 500), (3, 9, 400, 200, 20), (4, 1200, 9000, 800, 100)])
+def test_step2_filter_and_bl_vs_reference(oracle_lib, tmp_path, seed, n_reads, n_ovl, han1, han2):
+    """oracle/step2_oracle.c against the reference's exported `filter_ovl` and `out_bl` (lib/ovl.c:449-563, 339-362): every
+    verdict of a random stream of dovetail / contained / internal overlaps, and the `.bl` table at the end byte for byte
+    (the order of its lines is the reference hash table's bucket order)."""
+    ref = C.CDLL(os.path.join(refpipe.REFDIR, "ovlseq.so"))
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+
+    class OvlI(C.Structure):       # overlap_i, lib/ovl.h:27-32
+        _fields_ = [("rev", C.c_uint8), ("qname", C.c_uint32), ("qs", C.c_uint32), ("qe", C.c_uint32), ("qlen", C.c_uint32),
+                    ("tname", C.c_uint32), ("ts", C.c_uint32), ("te", C.c_uint32), ("tlen", C.c_uint32), ("identity", C.c_uint32)]
+
+    class S2(C.Structure):
+        _fields_ = [(n, C.c_uint32) for n in ("rev", "qname", "qs", "qe", "qlen", "tname", "ts", "te", "tlen", "identity")]
+
+    ref.filter_ovl.argtypes = [C.POINTER(OvlI), C.c_void_p, C.c_int32, C.c_int32]
+    ref.filter_ovl.restype = C.c_int
+    ref.out_bl.argtypes = [C.c_void_p, C.c_void_p]
+    o = oracle_lib
+    o.nd_s2_new.restype = C.c_void_p
+    o.nd_s2_free.argtypes = [C.c_void_p]
+    o.nd_s2_filter.argtypes = [C.c_void_p, C.POINTER(S2), C.c_int32, C.c_int32]
+    o.nd_s2_out_bl.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    o.nd_s2_out_bl.restype = C.c_int64
+    rng = np.random.default_rng(seed)
+    names = rng.permutation(50000)[:n_reads] + 1            # scattered ids: the table's probing and growth are exercised
+    lens = rng.integers(max(3 * han1 // 2, 300), 8 * han1, n_reads)
+    table = (C.c_uint8 * 64)()                              # a zeroed khash_t is an empty table (kh_init = calloc)
+    st = o.nd_s2_new()
+    kept = 0
+    try:
+        for it in range(n_ovl):
+            a, b = rng.choice(n_reads, 2, replace=False)
+            ql, tl = int(lens[a]), int(lens[b])
+            kind = it % 6
+
+            def piece(L, where):
+                if where == "lo":
+                    s = int(rng.integers(0, han1 + han1 // 2)); e = int(min(L, s + rng.integers(han1 // 2, L)))
+                elif where == "hi":
+                    e = L - int(rng.integers(0, han1 + han1 // 2)); s = int(max(0, e - rng.integers(han1 // 2, L)))
+                elif where == "all":
+                    s = int(rng.integers(0, han2 * 2)); e = L - int(rng.integers(0, han2 * 2))
+                else:
+                    s = int(rng.integers(0, L // 2)); e = int(min(L, s + rng.integers(han2 + 21, L // 2 + han2 + 22)))
+                if e - s < 21:
+                    s, e = 0, min(L, 40)
+                return s, e
+            rev = int(rng.integers(0, 2))
+            if kind == 0:
+                (qs, qe), (ts, te) = (piece(ql, "lo"), piece(tl, "lo")) if rev else (piece(ql, "hi"), piece(tl, "lo"))
+            elif kind == 1:
+                (qs, qe), (ts, te) = (piece(ql, "hi"), piece(tl, "hi")) if rev else (piece(ql, "lo"), piece(tl, "hi"))
+            elif kind == 2:
+                (qs, qe), (ts, te) = piece(ql, "all"), piece(tl, "mid")
+            elif kind == 3:
+                (qs, qe), (ts, te) = piece(ql, "mid"), piece(tl, "all")
+            else:
+                (qs, qe), (ts, te) = piece(ql, "mid"), piece(tl, "mid")
+            ide = int(rng.integers(500, 10001))
+            r1 = OvlI(rev, int(names[a]), qs, qe, ql, int(names[b]), ts, te, tl, ide)
+            r2 = S2(rev, int(names[a]), qs, qe, ql, int(names[b]), ts, te, tl, ide)
+            v1 = ref.filter_ovl(C.byref(r1), table, han1, han2)
+            v2 = o.nd_s2_filter(st, C.byref(r2), han1, han2)
+            assert v1 == v2, it
+            kept += v1
+        path = str(tmp_path / "ref.bl").encode()
+        fp = libc.fopen(path, b"w")
+        ref.out_bl(table, fp)
+        libc.fclose(fp)
+        buf = C.create_string_buffer(64 * n_reads + 40 * n_ovl + 1024)
+        n = o.nd_s2_out_bl(st, buf, len(buf))
+        want = open(path, "rb").read()
+        assert n > 0 and buf.raw[:n] == want
+        assert 0 < kept < n_ovl and 0 < want.count(b"\n") <= n_reads
+        assert b"\t2\n" in want                  # reads dropped as contained (two containing overlaps) are listed without their state
+    finally:
+        o.nd_s2_free(st)
