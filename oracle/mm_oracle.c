@@ -778,3 +778,92 @@ int64_t nd_mm_step1_mode3(const nd_mm_opt *opt, float mid_occ_frac, int mid_occ_
 	return step1_impl(opt, mid_occ_frac, mid_occ_fixed, n_t, tcodes, toff, tlen, tids, n_q, qcodes, qoff, qlen, qids, out, out_cap, mid_occ_out,
 	                  prev_io, 1);
 }
+
+/* ---------------------------------------------------------------- --step 2 --mode 0 (corrected reads, no re-alignment) */
+
+typedef struct { uint32_t rev, qname, qs, qe, qlen, tname, ts, te, tlen, identity; } nd_s2_ovl;
+int nd_s2_filter(void *state, const nd_s2_ovl *o, int32_t maxhan1, int32_t maxhan2); /* oracle/step2_oracle.c */
+
+/* encode_ovl_i (lib/ovl.c:205-253): ten varints per record; the read lengths travel only when the name changes */
+static int put_record10(uint8_t *out, const nd_s2_ovl *o, uint32_t *prev)
+{
+	uint32_t f[10], flags = o->rev, tspan = o->te - o->ts;
+	int n = 0, i;
+	f[3] = o->qe - o->qs;
+	if (o->qname >= prev[0]) f[0] = o->qname - prev[0]; else flags |= 2, f[0] = prev[0] - o->qname;
+	if (o->tname >= prev[1]) f[4] = o->tname - prev[1]; else flags |= 4, f[4] = prev[1] - o->tname;
+	f[7] = o->qname == prev[0] ? 0 : o->qlen;
+	f[8] = o->tname == prev[1] ? 0 : o->tlen;
+	if (f[3] >= tspan) f[6] = f[3] - tspan; else flags |= 8, f[6] = tspan - f[3];
+	prev[0] = o->qname, prev[1] = o->tname;
+	f[1] = flags & 0xff, f[2] = o->qs, f[5] = o->ts, f[9] = o->identity;
+	for (i = 0; i < 10; ++i) n += put_varint(out + n, f[i]);
+	return n;
+}
+
+/* One index part of `minimap2-nd --step 2 --mode 0 target query` (worker_for, minimap2/map.c:988-1031 with the re-alignment
+ * switched off, and the writer, :1305-1330): hits are marked per target (the first hit of a target carries the verdict, later
+ * hits of the same target count only when they are nearly as long), then filtered by length / identity / minimum block length
+ * and by the dovetail / contained filter whose state `s2_state` (nd_s2_new) lives for the whole run.  The caller writes the
+ * 00 FF header (init_ovl_mode, lib/ovl.c:70-75) and, at the end, the .bl table (nd_s2_out_bl). */
+int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, float mid_occ_frac, int mid_occ_fixed,
+                          int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
+                          int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
+                          uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io, void *s2_state)
+{
+	nd_mm_index *ix = nd_mm_index_build(n_t, tcodes, toff, tlen, tids, opt->w, opt->k, opt->hpc);
+	int mid_occ = mid_occ_fixed > 0 ? mid_occ_fixed : nd_mm_index_mid_occ(ix, mid_occ_frac);
+	uint32_t prev[2] = { prev_io ? prev_io[0] : 0, prev_io ? prev_io[1] : 0 };
+	int64_t n = 0;
+	int reg_cap = 1 << 16, i, k;
+	nd_mm_reg *regs = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * reg_cap);
+	int32_t *first = (int32_t*)malloc(sizeof(int32_t) * (n_t > 0 ? n_t : 1));
+	for (i = 0; i < n_t; ++i) first[i] = -1;
+	if (mid_occ_out) *mid_occ_out = mid_occ;
+	for (i = 0; i < n_q; ++i) {
+		const uint32_t ql = qlen[i];
+		int n_regs = map_read_impl(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)ql, regs, reg_cap, 0), c = 0;
+		if (n_regs < 0) {
+			reg_cap = -n_regs + 1024;
+			regs = (nd_mm_reg*)realloc(regs, sizeof(nd_mm_reg) * reg_cap);
+			n_regs = map_read_impl(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)ql, regs, reg_cap, 0);
+		}
+		if (n + 50LL * n_regs > out_cap) { n = -(n + 50LL * n_regs); break; }
+		for (k = 0; k < n_regs; ++k) { /* marking, map.c:997-1030 */
+			nd_mm_reg *r = &regs[k], *head;
+			const uint32_t tl = ix->len[r->rid], tp = (uint32_t)r->mlen, longer = tl > ql ? tl : ql;
+			int l;
+			if (tids[r->rid] == qids[i]) { r->mlen = 0; continue; }
+			if (first[r->rid] < 0) first[r->rid] = k; else r->mlen = 1;
+			l = first[r->rid], head = &regs[l];
+			if (l != k && (head->mlen == 2 || r->blen < head->blen * 0.8 || (uint32_t)r->blen < longer / 3)) continue;
+			if (r->qe - r->qs >= opt->minlen && tp >= r->blen * minide && tp >= (uint32_t)minmatch) {
+				if (dovetail_class(r->rev, (uint32_t)r->qs, (uint32_t)r->qe, ql, (uint32_t)r->rs, (uint32_t)r->re, tl, opt->maxhan1, 0)) {
+					if (head->mlen == 3) c--;
+					head->mlen = (int32_t)tp; /* --mode 0: the match count itself (a re-alignment mode would mark it 2) */
+				} else if ((uint32_t)r->qs <= (uint32_t)opt->maxhan2 && (uint32_t)r->qe + (uint32_t)opt->maxhan2 >= ql) {
+					head->mlen = 3;
+					if (++c >= 2) break; /* MAX_CON */
+				}
+			}
+		}
+		for (k = 0; k < n_regs; ++k) if (first[regs[k].rid] >= 0) first[regs[k].rid] = -1;
+		for (k = 0; k < n_regs; ++k) { /* writer, map.c:1296-1330 (outctn off) */
+			const nd_mm_reg *r = &regs[k];
+			const uint32_t tl = ix->len[r->rid];
+			nd_s2_ovl o;
+			if (tids[r->rid] == qids[i]) continue;
+			if (!((r->qe - r->qs >= opt->minlen || r->mlen == r->blen) && (r->mlen == 3 || (r->mlen >= r->blen * minide && r->mlen >= minmatch)) &&
+			      r->blen >= (int32_t)ql / 50 && r->blen >= (int32_t)tl / 50)) continue;
+			o.rev = (uint32_t)r->rev, o.qname = qids[i], o.qs = (uint32_t)r->qs, o.qe = (uint32_t)r->qe, o.qlen = ql;
+			o.tname = tids[r->rid], o.ts = (uint32_t)r->rs, o.te = (uint32_t)r->re, o.tlen = tl;
+			o.identity = (uint32_t)((uint64_t)r->mlen * 10000 / (uint64_t)r->blen);
+			if (nd_s2_filter(s2_state, &o, opt->maxhan1, opt->maxhan2)) n += put_record10(out + n, &o, prev);
+		}
+	}
+	free(first); free(regs);
+	nd_mm_index_free(ix);
+	if (prev_io && n >= 0) prev_io[0] = prev[0], prev_io[1] = prev[1];
+	return n;
+}
+

@@ -118,6 +118,40 @@ def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0, batch_size=
     return blob, mid_occ
 
 
+def step2_mode0(lib, opt: MMOpt, tset, qsets, minide=0.05, minmatch=100, mid_occ_frac=2e-4):
+    """`minimap2-nd --step 2 --mode 0 target query...` with the oracle: returns (.ovl bytes incl. the 00 FF header, .bl text)."""
+    lib.nd_mm_step2_mode0.argtypes = [C.POINTER(MMOpt), C.c_float, C.c_int32, C.c_float, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.nd_mm_step2_mode0.restype = C.c_int64
+    lib.nd_s2_new.restype = C.c_void_p
+    lib.nd_s2_free.argtypes = [C.c_void_p]
+    lib.nd_s2_out_bl.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.nd_s2_out_bl.restype = C.c_int64
+    tid, tl, tc, to = tset
+    st = lib.nd_s2_new()
+    prev = np.zeros(2, dtype=np.uint32)
+    blob = bytes([0, 255])
+    try:
+        for qid, ql, qc, qo in qsets:
+            cap = 1 << 22
+            while True:
+                out = np.zeros(cap, dtype=np.uint8)
+                mo = C.c_int32(0)
+                n = lib.nd_mm_step2_mode0(C.byref(opt), np.float32(minide), minmatch, np.float32(mid_occ_frac), 0, tid.size, ptr(tc), ptr(to),
+                                          ptr(tl), ptr(tid), qid.size, ptr(qc), ptr(qo), ptr(ql), ptr(qid), ptr(out), cap, C.byref(mo),
+                                          ptr(prev), st)
+                if n >= 0:
+                    break
+                raise RuntimeError("output buffer too small (the filter state has already advanced)")
+            blob += out[:n].tobytes()
+        buf = C.create_string_buffer(1 << 24)
+        nb = lib.nd_s2_out_bl(st, buf, len(buf))
+        return blob, buf.raw[:nb].decode()
+    finally:
+        lib.nd_s2_free(st)
+
+
 def load_set(path):
     """One .2bit file -> (ids, lens, codes, off) as the oracle wants them."""
     from nextdenovo_amd import ovl

@@ -102,3 +102,49 @@ def test_oracle_mode3_end_extension_matches_live_reference(lib, sets, extra):
         got, _ = M.step1(lib, M.preset("ava-hifi", dual, dvt=1 if "--dvt" in extra else 0), sets[t], sets[q], mode3=True, **kw)
         assert len(want) > 5000 and got == want
         assert want != plain   # the extension really moves coordinates on this set
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(M.REFDIR, "minimap2-nd")), reason="oracle/_ref not built")
+@pytest.mark.parametrize("preset,extra", [("ava-ont", ("-k", "17", "-w", "17", "--minlen", "1000", "--maxhan1", "2000")),
+                                          ("ava-pb", ("-k", "17", "-w", "10", "--minlen", "700", "--maxhan1", "1500", "--maxhan2", "300"))])
+def test_oracle_step2_mode0_matches_live_reference(lib, preset, extra):
+    """`minimap2-nd --step 2 --mode 0` on corrected reads (the cns_align command of nextDenovo:356-366 with the re-alignment
+    switched off): per-target marking of the hits, the length / identity / block-length filters, the dovetail / contained
+    filter (oracle/step2_oracle.c) and the 10-field encoder -- `.ovl` and `.bl` byte for byte against the compiled reference."""
+    from nextdenovo_amd import synth
+    import refpipe
+    g = synth.make_genome(60000, seed=61, n_repeats=3, repeat_len=1500)
+    rs = synth.simulate_reads(g, 28, "hifi", seed=62, mu=8.6, sigma=0.35, min_len=2500)
+    seqs = list(rs.seqs)
+    rng = np.random.default_rng(5)
+    for t in range(25):                      # short reads inside longer ones: contained verdicts
+        a = int(rng.integers(0, len(seqs)))
+        if seqs[a].size > 3000:
+            s0 = int(rng.integers(0, seqs[a].size - 2600))
+            seqs.append(seqs[a][s0:s0 + 2600].copy())
+    wd = tempfile.mkdtemp(prefix="nds2")
+    half = len(seqs) // 2
+    files, sets = [], []
+    for tag, lo, hi in (("a", 0, half), ("b", half, len(seqs))):
+        p = os.path.join(wd, tag + ".fasta")
+        with open(p, "w") as f:
+            for i in range(lo, hi):
+                f.write(">%d %d 0.99\n%s\n" % (i + 1, seqs[i].size, synth.codes_to_ascii(seqs[i]).decode()))
+        files.append(p)
+        ids = np.arange(lo + 1, hi + 1, dtype=np.uint32)
+        lens = np.asarray([seqs[i].size for i in range(lo, hi)], dtype=np.uint32)
+        off = np.zeros(hi - lo, dtype=np.uint64)
+        off[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+        sets.append((ids, lens, np.concatenate([seqs[i] for i in range(lo, hi)]).astype(np.uint8), off))
+    out = os.path.join(wd, "o.ovl")
+    cmd = [os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", "--mode", "0", "--dual=yes", "-t", "3", "-x", preset, *extra, files[0], files[1],
+           files[0], "-o", out]
+    refpipe.run(cmd)
+    want, want_bl = open(out, "rb").read(), open(out + ".bl").read()
+    kw = {}
+    for k_, name in (("-k", "k"), ("-w", "w"), ("--minlen", "minlen"), ("--maxhan1", "maxhan1"), ("--maxhan2", "maxhan2")):
+        if k_ in extra:
+            kw[name] = int(extra[extra.index(k_) + 1])
+    got, got_bl = M.step2_mode0(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]])
+    assert len(want) > 3000 and got == want
+    assert got_bl == want_bl and want_bl.count("\n") > 20
