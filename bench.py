@@ -25,8 +25,10 @@ RCCL is used only for the final corrected-base-count / max-time reduction.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import struct
 import sys
 import time
 
@@ -77,38 +79,72 @@ def _ref_worker(item):
     cs[:] = seqs
     r = lib.nextCorrect(cs, (C.c_uint * n)(*st), (C.c_uint * n)(*en), n, mal, 500, 130, 4, mlq, 0.8, 0, 0, rt)
     ln, ide = r.contents.len, r.contents.identity
+    # what the parity block compares: length, the float32 identity bit for bit, md5 of the corrected bases
+    # (error seeds -- len 2 / 3 / 4 -- carry no sequence: lib/nextcorrect.c:261-266, 2126)
+    digest = hashlib.md5(C.string_at(r.contents.seq, ln)).hexdigest() if ln > 4 else ""
+    bits = struct.unpack("<I", struct.pack("<f", ide))[0] if ln > 4 else 0
     lib.free_consensus_trimed(r)
-    return ln if (ln > 4 and ide >= 0.8) else 0
+    return ln, bits, digest, ide
 
 
-def cpu_baseline(rs, piles, read_type, n_sample):
+def cpu_baseline(rs, piles, read_type, n_sample, n_longest=16):
     """Reference CPU path on a bounded sample of the same workload, all sample piles in
-    flight over a fork pool of `cores` workers (the reference's own parallelism model)."""
+    flight over a fork pool of `cores` workers (the reference's own parallelism model).
+    The sample = every k-th pile + the `n_longest` longest seeds (where the device's wide tables, its int32
+    guard and its segment stitching matter); the rate is taken over the every-k-th part only, so that it
+    stays a representative sample of the workload.  Returns (record, {pile index: (len, identity bits, md5)})."""
     from multiprocessing import get_context
     from nextdenovo_amd import synth
     ref_so = os.path.join(ROOT, "oracle", "_ref", "nextcorrect.so")
     if not os.path.exists(ref_so):
-        return None
+        return None, {}
     cores = max(1, min(os.cpu_count() or 1, 64))
     if n_sample <= 0:
         n_sample = min(len(piles), 4 * cores)
     step = max(1, len(piles) // n_sample)
-    sample = piles[::step][:n_sample]
-    items = []
-    for p in sample:
-        seqs, st, en, mal = synth.pile_sequences(rs, p)
-        items.append((seqs, st, en, mal, min(en[0] // 2, 10000), read_type))
+    idx = list(range(0, len(piles), step))[:n_sample]
+    by_len = sorted(range(len(piles)), key=lambda i: -int(piles[i]["recs"][0][3]))
+    extra = [i for i in by_len[:n_longest] if i not in set(idx)]
+
+    def item(i):
+        seqs, st, en, mal = synth.pile_sequences(rs, piles[i])
+        return (seqs, st, en, mal, min(en[0] // 2, 10000), read_type)
+
+    items = [item(i) for i in idx]
     ctx = get_context("fork")
     with ctx.Pool(cores) as pool:
         pool.map(_ref_worker, items[:cores])  # warm: dlopen + page in
         t0 = time.perf_counter()
-        lens = pool.map(_ref_worker, items, chunksize=1)
+        got = pool.map(_ref_worker, items, chunksize=1)
         dt = time.perf_counter() - t0
-    bases = int(sum(lens))
+        got_extra = pool.map(_ref_worker, [item(i) for i in extra], chunksize=1) if extra else []
+    bases = int(sum(ln for ln, _b, _d, ide in got if ln > 4 and ide >= 0.8))
+    ref = {i: g[:3] for i, g in zip(idx + extra, got + got_extra)}
     return {"value": bases / dt, "unit": "corrected bases/s", "cores": cores, "kind": "reference",
             "sample": "%d of %d piles (every %d-th), %d corrected bases in %.2f s wall; compiled reference "
-                      "nextcorrect.so via fork pool" % (len(sample), len(piles), step, bases, dt),
-            "per_core": bases / dt / cores}
+                      "nextcorrect.so via fork pool" % (len(idx), len(piles), step, bases, dt),
+            "per_core": bases / dt / cores}, ref
+
+
+def parity_block(ref, gpu_full, piles):
+    """Compare the device's records of the CPU-sample piles (taken from a whole-batch call, the very call shape
+    the timed steps make) with the compiled reference's: length, float32 identity bits, md5 of the bases."""
+    bad = []
+    for i, (ln, bits, digest) in sorted(ref.items()):
+        g_ln, g_ide, g_seq = gpu_full[i]
+        if ln > 4 or g_ln > 4:
+            g_bits = struct.unpack("<I", struct.pack("<f", g_ide))[0] if g_ln > 4 else 0
+            g_dig = hashlib.md5(g_seq).hexdigest() if g_ln > 4 else ""
+            same = (ln, bits, digest) == (g_ln, g_bits, g_dig)
+        else:
+            same = ln == g_ln  # error seeds: the convention code only (2 uncorrectable, 3 memory, 4 all clipped)
+        if not same:
+            bad.append({"pile": i, "seed": int(piles[i]["seed"]), "ref_len": ln, "gpu_len": g_ln})
+    lens = [int(piles[i]["recs"][0][3]) + 1 for i in ref]
+    return {"piles": len(ref), "mismatch": len(bad), "against": "oracle/_ref/nextcorrect.so (compiled reference)",
+            "compared": "len, float32 identity bits, md5(seq)", "longest_seed": max(lens) if lens else 0,
+            "seeds_ge_100kb": sum(1 for x in lens if x >= 100000), "error_seeds": sum(1 for v in ref.values() if v[0] <= 4),
+            "mismatches": bad[:8]}
 
 
 def cpu_baseline_overlap(rs_dev, preset):
@@ -364,11 +400,20 @@ def main():
                                           "kept": int(ovl_state["sort_stats"]["kept"]), "blacklisted": int(ovl_state["last"][3]),
                                           "k": ovl_state["k"]}
                 out["overlap"]["pile_assembly_ms_per_step"] = ovl_state["asm_wall"] / args.steps * 1e3
+        parity_fail = False
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(rs, piles, read_type, args.cpu_sample)
+            out["cpu_baseline"], ref = cpu_baseline(rs, piles, read_type, args.cpu_sample)
+            if ref:  # one more (untimed) whole-batch call that keeps the sequences: what the timed steps computed
+                full = db.correct_piles(recs, off if not analytic else pile_off, read_type=read_type,
+                                        host_threads=args.host_threads)
+                out["parity"] = parity_block(ref, full, piles)
+                parity_fail = out["parity"]["mismatch"] != 0
             if ovl_state is not None:
                 out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(ovl_state["set"], ovl_state["preset"])
         print(json.dumps(out))
+        if parity_fail:
+            db.close()
+            sys.exit("bench.py: the device's records differ from the reference's (see \"parity\")")
     db.close()
     if dist is not None:
         dist.barrier()
