@@ -154,6 +154,9 @@ typedef struct {
     double traceback_ms, tags_ms, links_ms, score_ms, extract_ms;
     uint64_t piles, tags, cells_msa, path_items, links, score_launches;
     double backtrack_ms;
+    uint64_t score_segments;   /* scoring-DP segments (K10) */
+    uint64_t score_repairs;    /* of which scored again after a failed boundary check */
+    uint64_t score_slow_piles; /* piles scored by the int64 HBM-resident kernel */
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

@@ -396,6 +396,9 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->links = s.links;
     o->score_launches = s.score_launches;
     o->backtrack_ms = s.backtrack_ms;
+    o->score_segments = s.score_segments;
+    o->score_repairs = s.score_repairs;
+    o->score_slow_piles = s.score_slow_piles;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

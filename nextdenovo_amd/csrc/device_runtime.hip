@@ -135,6 +135,9 @@ struct DeviceAligner::State {
     DevBuf<uint32_t> d_read_pile, d_acc, d_tags, d_colidx, d_cov, d_inscnt, d_insmax, d_cellbase, d_entbase;
     DevBuf<uint32_t> d_cell_start, d_cell_len, d_cell_bpp, d_cell_blink, d_ent_pp, d_ent_ppp, d_ent_cnt, d_err;
     DevBuf<long long> d_ent_score;
+    DevBuf<int32_t> d_cell_best, d_spec, d_fin;  // K10 segments: cell bests, boundary scores (kSegEnts per segment)
+    DevBuf<SegSum> d_sums;
+    DevBuf<SegItem> d_items;
     DevBuf<PathItem> d_path;
     DevBuf<ColBlock> d_blocks;
     DevBuf<RegionDev> d_regions;
@@ -253,6 +256,7 @@ RuntimeStats DeviceAligner::total_stats() {
         t.tags_ms += s.tags_ms; t.links_ms += s.links_ms; t.score_ms += s.score_ms; t.extract_ms += s.extract_ms;
         t.piles += s.piles; t.tags += s.tags; t.cells_msa += s.cells_msa; t.path_items += s.path_items;
         t.links += s.links; t.score_launches += s.score_launches; t.backtrack_ms += s.backtrack_ms;
+        t.score_segments += s.score_segments; t.score_repairs += s.score_repairs; t.score_slow_piles += s.score_slow_piles;
     }
     return t;
 }
@@ -775,6 +779,43 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     g_prof.m_tags += tp3 - tp2;
     uint64_t cells = 0, ents = 0, paths = 0;
     std::vector<ColBlock> blocks;
+    // scoring segments (K10): `seg_len` columns each, the last one takes the remainder; the two table tiers get a work
+    // list each.  Test hooks: NDGPU_K10_FORCE = large (every pile through the large tables) | slow (every pile through the
+    // int64 HBM-resident kernel) | seq (one segment per pile: no speculation) | repair (every second segment is scored
+    // again by the stitch kernel as if its check had failed); NDGPU_K10_SEG / NDGPU_K10_WARM / NDGPU_K10_GUARD set the
+    // segment length, the warm-up length and the raw-score guard.
+    struct K10Cfg {
+        uint32_t seg_len = 1024, warm = 128, force_repair = 0;
+        int32_t guard = 1 << 30;
+        bool large = false, slow = false;
+        K10Cfg() {
+            if (const char *e = getenv("NDGPU_K10_SEG")) seg_len = (uint32_t)std::max(16, atoi(e));
+            if (const char *e = getenv("NDGPU_K10_WARM")) warm = (uint32_t)std::max(1, atoi(e));
+            if (const char *e = getenv("NDGPU_K10_GUARD")) guard = atoi(e);
+            if (const char *e = getenv("NDGPU_K10_FORCE")) {
+                large = !strcmp(e, "large"), slow = !strcmp(e, "slow");
+                if (!strcmp(e, "seq")) seg_len = 0x7fffffffu;
+                if (!strcmp(e, "repair")) force_repair = 2;
+            }
+            if (warm >= seg_len) warm = seg_len - 1;
+        }
+    };
+    static const K10Cfg k10;
+    std::vector<SegItem> items_small, items_large;
+    uint32_t n_segs = 0;
+    for (size_t p = 0; p < np; p++) {
+        PileDev &P = piles[p];
+        if (k10.large) P.err = 3;
+        if (k10.slow) P.err = 2;
+        P.n_seg = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)P.seed_len + k10.seg_len / 2) / k10.seg_len));
+        P.seg_off = n_segs;
+        n_segs += P.n_seg;
+        P.n_repair = 0;
+        if (P.err != 2) {
+            std::vector<SegItem> &dst = P.err == 3 ? items_large : items_small;
+            for (uint32_t g = 0; g < P.n_seg; g++) dst.push_back(SegItem{(uint32_t)p, g});
+        }
+    }
     for (size_t p = 0; p < np; p++) {
         PileDev &P = piles[p];
         P.cell_off = cells;
@@ -798,14 +839,30 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_ent_score.reserve(ents + 1);
     S.d_path.reserve(paths + 1);
     S.d_blocks.reserve(blocks.size() + 1);
+    S.d_cell_best.reserve(cells + 1);
+    S.d_sums.reserve(n_segs + 1);
+    S.d_spec.reserve((size_t)n_segs * kSegEnts + 1);
+    S.d_fin.reserve((size_t)n_segs * kSegEnts + 1);
+    S.d_items.reserve(items_small.size() + items_large.size() + 1);
     HIP_CHECK(hipMemcpyAsync(S.d_blocks.p, blocks.data(), blocks.size() * sizeof(ColBlock), hipMemcpyHostToDevice, st));
+    if (!items_small.empty())
+        HIP_CHECK(hipMemcpyAsync(S.d_items.p, items_small.data(), items_small.size() * sizeof(SegItem), hipMemcpyHostToDevice, st));
+    if (!items_large.empty())
+        HIP_CHECK(hipMemcpyAsync(S.d_items.p + items_small.size(), items_large.data(), items_large.size() * sizeof(SegItem),
+                                 hipMemcpyHostToDevice, st));
     std::vector<PathItem> hpath(paths + 1);
     std::vector<PileDev> piles_out(np);
     uint32_t herr[4] = {0, 0, 0, 0};
     // attempt 0 counts links with the small LDS lists; a cell with more distinct links than they hold raises err[0] and the
     // sub-batch is counted and scored again with the full capacity (everything the kernels write is rewritten)
-    bool any_large = false;  // the column scan flagged piles (err = 3) whose columns need the large scoring tables
-    for (size_t p = 0; p < np; p++) any_large = any_large || piles[p].err == 3;
+    K10Args ka;
+    ka.piles = S.d_piles.p;
+    ka.coverage = S.d_cov.p, ka.max_size = S.d_insmax.p, ka.cell_base = S.d_cellbase.p, ka.ent_base = S.d_entbase.p;
+    ka.cell_start = S.d_cell_start.p, ka.cell_len = S.d_cell_len.p;
+    ka.ent_pp = S.d_ent_pp.p, ka.ent_ppp = S.d_ent_ppp.p, ka.ent_cnt = S.d_ent_cnt.p;
+    ka.cell_best_pp = S.d_cell_bpp.p, ka.cell_best_link = S.d_cell_blink.p, ka.cell_best = S.d_cell_best.p;
+    ka.sums = S.d_sums.p, ka.spec = S.d_spec.p, ka.fin = S.d_fin.p;
+    ka.seg_len = k10.seg_len, ka.warm = k10.warm, ka.guard = k10.guard, ka.force_repair = k10.force_repair;
     for (int attempt = 0; attempt < 2; attempt++) {
         HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
         if (attempt) HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
@@ -822,10 +879,9 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             HIP_CHECK(hipStreamWaitEvent(sst, S.ev_lat0, 0));
             HIP_CHECK(hipEventRecord(S.evs[3], sst));
         }
-        launch_score_backtrack(S.d_piles.p, S.d_cov.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p,
-                               S.d_ent_pp.p, S.d_ent_ppp.p, S.d_ent_cnt.p, S.d_ent_score.p, S.d_cell_bpp.p,
-                               S.d_cell_blink.p, S.d_path.p, (int)np, sst, S.evs[7], any_large, on_reserved ? nullptr : S.stream2,
-                               S.ev_fork, S.ev_join);
+        launch_score_backtrack(ka, S.d_items.p, (int)items_small.size(), S.d_items.p + items_small.size(), (int)items_large.size(),
+                               S.d_ent_score.p, S.d_path.p, (int)np, sst, S.evs[7], on_reserved ? nullptr : S.stream2, S.ev_fork,
+                               S.ev_join);
         HIP_CHECK(hipEventRecord(S.evs[4], sst));
         if (on_reserved) {
             HIP_CHECK(hipEventRecord(S.ev_lat1, sst));
@@ -867,20 +923,13 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             (void)hipEventElapsedTime(&t_back, S.evs[7], S.evs[4]);
             uint32_t longest = 0;
             for (size_t p = 0; p < np; p++) longest = std::max(longest, piles[p].seed_len);
-#ifdef NDGPU_K10_PROF
-            {
-                unsigned long long b[4] = {0, 0, 0, 0}, cols = 0;
-                for (size_t p = 0; p < np; p++) {
-                    for (int k = 0; k < 4; k++) b[k] += piles[p].prof[k];
-                    cols += piles[p].seed_len;
-                }
-                if (cols)
-                    fprintf(stderr, "[ndgpu k10prof] %zu piles %llu positions | cycles per position: loader %.0f scorer %.0f folder %.0f total %.0f\n",
-                            np, cols, (double)b[0] / cols, (double)b[1] / cols, (double)b[2] / cols, (double)b[3] / cols);
+            uint32_t rep = 0, slow = 0;
+            for (size_t p = 0; p < np; p++) {
+                if (piles[p].n_repair == 0xffffffffu) slow++;
+                else rep += piles[p].n_repair;
             }
-#endif
-            fprintf(stderr, "[ndgpu trace] run_main %zu piles longest %u | host prep %.1f align %.1f tags %.1f msa %.1f ms | K9 %.1f K10 %.1f backtrack %.1f ms\n",
-                    np, longest, (tp1 - tp0) * 1e-6, (tp2 - tp1) * 1e-6, (tp3 - tp2) * 1e-6, (tp4 - tp3) * 1e-6, t_links, t_score, t_back);
+            fprintf(stderr, "[ndgpu trace] run_main %zu piles longest %u | host prep %.1f align %.1f tags %.1f msa %.1f ms | K9 %.1f K10 %.1f backtrack %.1f ms | %u segments, %u repaired, %u piles through the int64 kernel\n",
+                    np, longest, (tp1 - tp0) * 1e-6, (tp2 - tp1) * 1e-6, (tp3 - tp2) * 1e-6, (tp4 - tp3) * 1e-6, t_links, t_score, t_back, n_segs, rep, slow);
         }
     }
     for (size_t p = 0; p < np; p++) {
@@ -900,6 +949,9 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         }
         S.stats.path_items += P.path_len;
         S.stats.links += P.n_links;
+        S.stats.score_segments += P.n_seg;
+        if (P.n_repair == 0xffffffffu) S.stats.score_slow_piles++;  // marker left by the int64 kernel
+        else S.stats.score_repairs += P.n_repair;
     }
     g_prof.m_post += wall_ns() - tp4;
 }

@@ -452,26 +452,34 @@ __device__ __forceinline__ long long shfl_i64(long long v, int src) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// Fast path: one wave per pile.  The scoring DP is a dependent chain over (column, delta)
-// steps, ~10^4-10^6 long, so the kernel is organised around the latency of one step:
-//   * the link tables of the current and the previous column live in LDS (a link's pp tag
-//     always lies in column p or p-1); the next column's tables are prefetched into
-//     registers while the current one is scored;
-//   * once per column every link is "resolved" lane-parallel (where its predecessor cell
-//     is, its gain 10*count - factor*coverage);
-//   * per step each link sits on its own lane and reduces its matching predecessor scores
-//     to four numbers; the reference's sequential tie-break state of the five symbol cells
-//     (lib/nextcorrect.c:2164-2192) is then advanced link by link with scalar lane reads;
-//   * scores are int32 here (a 10^6-column seed at depth 200 stays below 2^31); any pile
-//     that gets near the limit, or whose columns exceed the LDS tables, is redone by the
-//     int64 HBM-resident kernel below.
-// LDS table capacities of the fast kernel, two tiers: a pile whose columns all fit the small tables (25 KB per pile: 6 piles
-// resident per compute unit instead of 3) is scored with them, the others (flagged err = 3 by the column scan) with the
-// large ones by a second launch that runs at the same time on another stream; a pile that does not fit those either (or
-// whose int32 scores get near the limit) goes to the HBM-resident kernel.
+// Scoring DP, segment-parallel.  The DP is a dependent chain over (column, delta) steps, 10^4-10^6 long per seed, and
+// one step costs microseconds whatever the hardware does (a handful of dependent LDS round trips), so a seed is cut into
+// segments of `seg_len` columns that are scored AT THE SAME TIME by different workgroups and stitched afterwards:
+//   * segment 0 starts at column 0 and is exact as it stands;
+//   * segment i > 0 does not know the scores its first column reads (those of the links of column c0 - 1).  It starts
+//     `warm` columns early with every predecessor score set to one constant (kBig) and scores forward.  In this DP the best
+//     paths of all links of a column join within a few dozen columns (reads share three consecutive tags with the majority
+//     almost everywhere), so by column c0 - 1 the scores it holds differ from the true ones by ONE constant -- and every
+//     decision of the DP compares scores with scores, so the decisions from c0 on are the true ones;
+//   * nothing of this is assumed: the stitch kernel CHECKS it.  Segment i stores the scores it held for column c0 - 1
+//     (`spec`), segment i - 1 the ones it computed for the same column (`fin`); the segment is accepted iff the two differ
+//     by one constant over all offset-carrying links (and are equal for the others), which also yields its offset
+//     off_i = off_{i-1} + that constant.  The DP also has absolute values -- a read's first link scores 10 * count -
+//     factor * coverage from nothing, a link score is floored at 0, a cell's best starts at -10 -- and a comparison of an
+//     offset-carrying score with an absolute one is decided by the guess kBig in the segment and by off_i in truth; both
+//     give "the offset-carrying one is larger" iff the smallest true offset-carrying score of the segment exceeds its
+//     largest absolute one, which is tracked (vmin, amax) and checked.  A segment that fails any check is scored again by
+//     the stitch kernel from the true scores of its predecessor (`repair`), and the check of its successor is redone;
+//   * the global pick (lib/nextcorrect.c:2194-2199) needs true values of every cell's best score: the cell bests are
+//     stored, and the stitch kernel finds the last segment whose maximum reaches the running maximum - 3000 and scans it.
+// Scores are int32 (raw); true score = raw + off (int64) for raw > kRelThr in an offset-carrying segment.  A pile with a
+// column that does not fit the LDS tables, a raw score beyond the guard or a failed absolute-value check goes to the
+// int64 HBM-resident kernel below.
 constexpr int kColCells = 192, kColEnts = 512;            // max_size <= 32, <= 512 link slots per column
 constexpr int32_t kNoScore = INT32_MIN;
-constexpr int32_t kScoreGuard = 1 << 30;
+constexpr int32_t kBig = 1 << 29;      // the constant a speculative segment starts from
+constexpr int32_t kRelThr = 1 << 28;   // raw score above: carries the segment's offset; at or below: absolute
+constexpr int32_t kAbsLim = 1 << 27;   // absolute values must stay below (the band up to kRelThr is nobody's)
 
 template <int CELLS, int ENTS>
 struct ColTab {
@@ -489,47 +497,68 @@ struct LinkAux {
     uint32_t cnt;
 };
 
-// Three wavefronts per pile, one barrier per column:
+template <int CELLS, int ENTS>
+struct K10Smem {
+    ColTab<CELLS, ENTS> tab[3];                                   // columns p-1, p, p+1 (slot = column mod 3)
+    __attribute__((aligned(16))) LinkAux aux[3][ENTS];            // same slots
+    uint32_t bpp[2][CELLS], blink[2][CELLS];                      // slot = column & 1
+    int32_t best[2][CELLS];
+    uint32_t meta[2][5][64];                                      // width, cell0, e0, ecap, coverage of 2 x 64 columns
+    uint32_t colw[3], colc0[3], stop[3];                          // per prepared column: width, first cell, "does not fit"
+    uint32_t r_links, r_flags, r_nfin;                            // results of a range
+    int32_t r_vmin, r_amax, r_brel, r_babs;
+};
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+    for (int o = 32; o; o >>= 1) {
+        const int32_t u = __shfl_xor(v, o, 64);
+        v = u < v ? u : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+    for (int o = 32; o; o >>= 1) {
+        const int32_t u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+
+// Scores the columns [mode 0: c0, else w0) .. c1 of one pile and keeps the results of [c0, c1).  Three wavefronts, one
+// barrier per column:
 //   loader (wave 1), one column ahead: the column's cell / link tables HBM -> registers (prefetch) -> LDS, every link
 //     resolved (predecessor cell range, gain, mask of the predecessor links it continues), finished results stored;
 //   scorer (wave 0), the dependent chain: one link per lane takes the best of its matching predecessors' scores;
 //   folder (wave 2), one column behind: the five symbol cells of every step fold their links with the reference's
-//     sequential tie-break rules (lib/nextcorrect.c:2164-2192) and the global pick (:2194-2199) is updated -- nothing a
-//     later score depends on, so it is off the chain.
-template <int CELLS, int ENTS, bool REDO /* launch with the large tables */>
-__global__ __launch_bounds__(192) void score_fast_kernel(
-    PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ max_size,
-    const uint32_t *__restrict__ cell_base, const uint32_t *__restrict__ ent_base,
-    const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_len,
-    const uint32_t *__restrict__ ent_pp, const uint32_t *__restrict__ ent_ppp, const uint32_t *__restrict__ ent_cnt,
-    uint32_t *__restrict__ cell_best_pp, uint32_t *__restrict__ cell_best_link) {
+//     sequential tie-break rules (lib/nextcorrect.c:2164-2192).
+// mode 0: the range starts at the seed's first column (w0 = c0 = 0), scores are true values;
+// mode 1: speculative start: column w0 - 1 is loaded with every score = kBig, columns [w0, c0) are the warm-up;
+// mode 2: exact restart (w0 = c0): column c0 - 1 is loaded with `init_scores` (the predecessor segment's `fin`).
+// enc: scores above kRelThr carry an offset (always in mode 1; in mode 2 what the predecessor's scores are).
+// The summary goes to A.sums[sidx], the scores of column c1 - 1 to A.fin, in mode 1 those of column c0 - 1 to A.spec.
+template <int CELLS, int ENTS>
+__device__ void score_range(K10Smem<CELLS, ENTS> &S, const K10Args &A, const PileDev &P, const uint32_t sidx, const uint32_t c0,
+                            const uint32_t c1, const uint32_t w0, const int mode, const bool enc,
+                            const int32_t *__restrict__ init_scores) {
     using Tab = ColTab<CELLS, ENTS>;
-    __shared__ Tab tab[3];                                          // columns p-1, p, p+1 (slot = column mod 3)
-    __shared__ __attribute__((aligned(16))) LinkAux s_aux[3][ENTS];  // same slots
-    __shared__ uint32_t s_bpp[2][CELLS], s_blink[2][CELLS];      // slot = column & 1
-    __shared__ uint32_t s_meta[2][5][64];                       // width, cell0, e0, ecap, coverage of 2 x 64 columns
-    __shared__ uint32_t s_colw[3], s_colc0[3], s_stop[3];       // per prepared column: width, first cell, "does not fit"
-    __shared__ uint32_t s_links, s_sc_ovf;
-    __shared__ int32_t s_ot;
-    __shared__ uint32_t s_odb;
-    PileDev &P = piles[blockIdx.x];
-    if (REDO != (P.err == 3)) return;  // REDO: the launch with the large tables; the column scan chose the tier of every pile
-    __builtin_amdgcn_s_setprio(3);  // latency-bound waves: issue priority over co-resident kernels
     const int wave = (int)(threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
-    const uint32_t L = P.seed_len;
-    const uint32_t *cov = coverage + P.col_off;
-    const uint32_t *ms = max_size + P.col_off;
-    const uint32_t *cb = cell_base + P.col_off;
-    const uint32_t *eb = ent_base + P.col_off;
-    const uint32_t *cs = cell_start + P.cell_off;
-    const uint32_t *cl = cell_len + P.cell_off;
-    const uint32_t *epp = ent_pp + P.ent_off;
-    const uint32_t *eppp = ent_ppp + P.ent_off;
-    const uint32_t *ecnt = ent_cnt + P.ent_off;
-    uint32_t *bpp_out = cell_best_pp + P.cell_off;
-    uint32_t *blk_out = cell_best_link + P.cell_off;
+    const uint32_t L = c1;
+    const uint32_t first = mode == 0 ? c0 : w0 - 1u;  // first column whose tables are loaded
+    const uint32_t *cov = A.coverage + P.col_off;
+    const uint32_t *ms = A.max_size + P.col_off;
+    const uint32_t *cb = A.cell_base + P.col_off;
+    const uint32_t *eb = A.ent_base + P.col_off;
+    const uint32_t *cs = A.cell_start + P.cell_off;
+    const uint32_t *cl = A.cell_len + P.cell_off;
+    const uint32_t *epp = A.ent_pp + P.ent_off;
+    const uint32_t *eppp = A.ent_ppp + P.ent_off;
+    const uint32_t *ecnt = A.ent_cnt + P.ent_off;
+    uint32_t *bpp_out = A.cell_best_pp + P.cell_off;
+    uint32_t *blk_out = A.cell_best_link + P.cell_off;
+    int32_t *best_out = A.cell_best + P.cell_off;
     const int32_t factor = P.factor;
+    const int32_t guard = A.guard;
 
     // ---- loader state
     uint32_t pf_cs = 0, pf_cl = 0, pf_pp[4] = {0, 0, 0, 0}, pf_ppp[4] = {0, 0, 0, 0}, pf_cnt[4] = {0, 0, 0, 0};
@@ -545,8 +574,8 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             v_ = cov[p];
         }
         const uint32_t par = (p0 >> 6) & 1u;
-        s_meta[par][0][lane] = w_, s_meta[par][1][lane] = c_, s_meta[par][2][lane] = e_, s_meta[par][3][lane] = k_;
-        s_meta[par][4][lane] = v_;
+        S.meta[par][0][lane] = w_, S.meta[par][1][lane] = c_, S.meta[par][2][lane] = e_, S.meta[par][3][lane] = k_;
+        S.meta[par][4][lane] = v_;
     };
     auto prefetch = [&](uint32_t cell0, uint32_t ncell, uint32_t e0, uint32_t ecap) {
         if ((uint32_t)lane < ncell) {
@@ -563,18 +592,19 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             }
         }
     };
-    // prepare column q: tables -> LDS, links resolved.  Runs on the loader wave only.
-    auto prepare = [&](uint32_t q) {
+    // prepare column q: tables -> LDS, links resolved (not for the start column of modes 1 / 2: its links are never
+    // scored and the column before it is not loaded).  Runs on the loader wave only.
+    auto prepare = [&](uint32_t q, bool resolve) {
         const int ml = (int)(q & 63u);
         const uint32_t mp = (q >> 6) & 1u, slot = q % 3u;
-        const uint32_t width = s_meta[mp][0][ml], cell0 = s_meta[mp][1][ml], e0 = s_meta[mp][2][ml], ecap = s_meta[mp][3][ml];
-        const int32_t pen = factor * (int32_t)s_meta[mp][4][ml];
+        const uint32_t width = S.meta[mp][0][ml], cell0 = S.meta[mp][1][ml], e0 = S.meta[mp][2][ml], ecap = S.meta[mp][3][ml];
+        const int32_t pen = factor * (int32_t)S.meta[mp][4][ml];
         const uint32_t ncell = width * 6u;
         const bool fits = ncell <= (uint32_t)CELLS && ecap <= (uint32_t)ENTS;
-        if (lane == 0) s_colw[slot] = width, s_colc0[slot] = cell0, s_stop[slot] = fits ? 0u : 1u;
-        Tab &cur = tab[slot];
-        const Tab &prv = tab[(q + 2u) % 3u];
-        LinkAux *aux = s_aux[slot];
+        if (lane == 0) S.colw[slot] = width, S.colc0[slot] = cell0, S.stop[slot] = fits ? 0u : 1u;
+        Tab &cur = S.tab[slot];
+        const Tab &prv = S.tab[(q + 2u) % 3u];
+        LinkAux *aux = S.aux[slot];
         if (fits) {
             if ((uint32_t)lane < ncell) {
                 cur.cstart[lane] = pf_cs - e0;
@@ -605,13 +635,13 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             __builtin_amdgcn_wave_barrier();
             const int nl = (int)((q + 1) & 63u);
             const uint32_t np_ = ((q + 1) >> 6) & 1u;
-            prefetch(s_meta[np_][1][nl], s_meta[np_][0][nl] * 6u, s_meta[np_][2][nl], s_meta[np_][3][nl]);
+            prefetch(S.meta[np_][1][nl], S.meta[np_][0][nl] * 6u, S.meta[np_][2][nl], S.meta[np_][3][nl]);
         }
-        if (!fits || ncell == 0) return;
+        if (!fits || ncell == 0 || !resolve) return;
         __builtin_amdgcn_wave_barrier();
         // resolve every link of the column once
         const uint32_t nent = cur.cstart[ncell - 1u] + cur.clen[ncell - 1u];
-        n_links += nent;
+        if (q >= c0) n_links += nent;
         for (uint32_t e = (uint32_t)lane; e < nent; e += 64) {
             const uint32_t mpp = cur.ps[e].x;
             uint32_t res = 0;
@@ -637,67 +667,79 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
             aux[e].c = 10 * (int32_t)aux[e].cnt - pen;
         }
     };
-    auto store_results = [&](uint32_t q) {  // best_pp / best_link of column q (folded one iteration ago)
-        const uint32_t pw = s_colw[q % 3u] * 6u, pc0 = s_colc0[q % 3u], sl = q & 1u;
+    auto store_results = [&](uint32_t q) {  // best_pp / best_link / best score of column q (folded one iteration ago)
+        const uint32_t pw = S.colw[q % 3u] * 6u, pc0 = S.colc0[q % 3u], sl = q & 1u;
         for (uint32_t c = (uint32_t)lane; c < pw; c += 64)
             if (c % 6u < 5u) {
-                bpp_out[pc0 + c] = s_bpp[sl][c];
-                blk_out[pc0 + c] = s_blink[sl][c];
+                bpp_out[pc0 + c] = S.bpp[sl][c];
+                blk_out[pc0 + c] = S.blink[sl][c];
+                best_out[pc0 + c] = S.best[sl][c];
             }
     };
 
-    // ---- folder state
-    int32_t gbest = -10;
-    int32_t o_t = -1;
-    uint32_t o_db = 0;
-    // ---- scorer state
+    // ---- scorer state: overflow / band flag, smallest offset-carrying and largest absolute link score seen from column
+    // c0 - 1 on (what the absolute-value check of the stitch needs)
     bool sc_overflow = false;
+    int32_t t_vmin = INT32_MAX, t_amax = 0;
+    // ---- folder state: largest cell best of the owned columns, by kind
+    int32_t f_brel = INT32_MIN, f_babs = INT32_MIN;
 
-    if (threadIdx.x == 0) s_links = 0, s_sc_ovf = 0, s_ot = -1, s_odb = 0;
+    __syncthreads();  // the previous user of S is done
+    if (threadIdx.x == 0) S.r_links = 0, S.r_flags = 0, S.r_nfin = 0, S.r_vmin = INT32_MAX, S.r_amax = 0, S.r_brel = INT32_MIN, S.r_babs = INT32_MIN;
     if (wave == 1) {
-        load_meta(0);
+        load_meta(first & ~63u);
         __builtin_amdgcn_wave_barrier();
-        prefetch(s_meta[0][1][0], s_meta[0][0][0] * 6u, s_meta[0][2][0], s_meta[0][3][0]);
-        prepare(0);
+        const int fl = (int)(first & 63u);
+        const uint32_t fp = (first >> 6) & 1u;
+        prefetch(S.meta[fp][1][fl], S.meta[fp][0][fl] * 6u, S.meta[fp][2][fl], S.meta[fp][3][fl]);
+        prepare(first, mode == 0);
     }
     __syncthreads();
 
     bool stopped = false;
-#ifdef NDGPU_K10_PROF
-    unsigned long long prof_busy = 0;
-    const unsigned long long prof_start = clock64();
-#endif
     // iteration p: loader prepares column p+1 and stores column p-2, scorer scores column p, folder folds column p-1
-    for (uint32_t p = 0; p <= L; p++) {
-        if (p < L && s_stop[p % 3u]) {  // column p does not fit the LDS tables: the pile goes to the HBM-resident kernel
+    for (uint32_t p = first; p <= L; p++) {
+        if (p < L && S.stop[p % 3u]) {  // column p does not fit the LDS tables: the pile goes to the HBM-resident kernel
             stopped = true;
             break;
         }
-#ifdef NDGPU_K10_PROF
-        const unsigned long long prof_t0 = clock64();
-#endif
         if (wave == 1) {
             // (column p+1 first: its commit drains the memory counter, nothing younger than the prefetched loads may be
             // in flight; the stores come after)
-            const bool st_ok = p >= 2;
+            const bool st_ok = p >= c0 + 2u;
             uint32_t sw = 0, sc0 = 0;
-            if (st_ok) sw = s_colw[(p - 2u) % 3u] * 6u, sc0 = s_colc0[(p - 2u) % 3u];  // slot p+1 = slot p-2: read before prepare
-            if (p + 1 < L) prepare(p + 1);
+            if (st_ok) sw = S.colw[(p - 2u) % 3u] * 6u, sc0 = S.colc0[(p - 2u) % 3u];  // slot p+1 = slot p-2: read before prepare
+            if (p + 1 < L) prepare(p + 1, true);
             if (st_ok) {
                 const uint32_t sl = (p - 2u) & 1u;
                 for (uint32_t c = (uint32_t)lane; c < sw; c += 64)
                     if (c % 6u < 5u) {
-                        bpp_out[sc0 + c] = s_bpp[sl][c];
-                        blk_out[sc0 + c] = s_blink[sl][c];
+                        bpp_out[sc0 + c] = S.bpp[sl][c];
+                        blk_out[sc0 + c] = S.blink[sl][c];
+                        best_out[sc0 + c] = S.best[sl][c];
                     }
             }
         } else if (wave == 0) {
             const uint32_t slot = p % 3u;
-            const uint32_t width = p < L ? s_colw[slot] : 0u;
-            if (width) {
-                Tab &cur = tab[slot];
-                const Tab &prv = tab[(p + 2u) % 3u];
-                LinkAux *aux = s_aux[slot];
+            const uint32_t width = p < L ? S.colw[slot] : 0u;
+            Tab &cur = S.tab[slot];
+            const uint32_t nent = width ? cur.cstart[width * 6u - 1u] + cur.clen[width * 6u - 1u] : 0u;
+            const bool track = enc && p + 1u >= c0;
+            if (mode != 0 && p == first) {
+                // start column: scores are given, not computed
+                for (uint32_t e = (uint32_t)lane; e < nent; e += 64) {
+                    const int32_t v = mode == 1 ? kBig : init_scores[e];
+                    cur.ps[e].y = (uint32_t)v;
+                    if (track) {
+                        if (v > kRelThr) t_vmin = v < t_vmin ? v : t_vmin;
+                        else t_amax = v > t_amax ? v : t_amax;
+                        if (v > kAbsLim && v <= kRelThr) sc_overflow = true;
+                    }
+                    if (v > guard) sc_overflow = true;
+                }
+            } else if (width) {
+                const Tab &prv = S.tab[(p + 2u) % 3u];
+                LinkAux *aux = S.aux[slot];
                 uint32_t step_est = 0, step_n = 0;
                 if ((uint32_t)lane < width) {
                     step_est = cur.cstart[(uint32_t)lane * 6u];
@@ -770,26 +812,37 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
                             LinkAux wr;
                             wr.a = (uint32_t)r_scmax, wr.b_ = (uint32_t)r_impr, wr.c = r_nsmax, wr.cnt = ax.cnt;
                             aux[idx] = wr;
-                            if (r_sc > kScoreGuard) sc_overflow = true;
+                            if (r_sc > guard) sc_overflow = true;
+                            if (track) {
+                                if (r_sc > kRelThr) t_vmin = r_sc < t_vmin ? r_sc : t_vmin;
+                                else t_amax = r_sc > t_amax ? r_sc : t_amax;
+                                if (r_sc > kAbsLim && r_sc <= kRelThr) sc_overflow = true;
+                            }
                         }
                     }
                     __builtin_amdgcn_wave_barrier();  // scores of (p,d) in LDS before (p,d+1) reads them (one wave, in order)
                 }
             }
-        } else if (p > 0) {
+            // the scores of the two columns the stitch compares
+            if (p < L && (p + 1u == L || (mode == 1 && p + 1u == c0))) {
+                __builtin_amdgcn_wave_barrier();
+                int32_t *dst = (p + 1u == L ? A.fin : A.spec) + (size_t)sidx * (size_t)kColEnts;
+                for (uint32_t e = (uint32_t)lane; e < nent; e += 64) dst[e] = (int32_t)cur.ps[e].y;
+                if (p + 1u == L && lane == 0) S.r_nfin = nent;
+            }
+        } else if (p > first && p - 1u >= c0) {
             const uint32_t q = p - 1u, slot = q % 3u, sl = q & 1u;
-            const uint32_t width = s_colw[slot];
+            const uint32_t width = S.colw[slot];
             if (width) {
-                const Tab &cur = tab[slot];
-                const LinkAux *aux = s_aux[slot];
-                // every (delta, symbol) cell of the column folds its links on its own lane (12 deltas x 5 symbols per pass):
-                // the cells are independent, only the global pick below walks them in order
+                const Tab &cur = S.tab[slot];
+                const LinkAux *aux = S.aux[slot];
+                // every (delta, symbol) cell of the column folds its links on its own lane (12 deltas x 5 symbols per pass)
                 for (uint32_t d0 = 0; d0 < width; d0 += 12u) {
                     const uint32_t dl = (uint32_t)lane / 5u, d = d0 + dl, cb_ = (uint32_t)lane - dl * 5u;
                     const uint32_t n_d = width - d0 < 12u ? width - d0 : 12u;
-                    int32_t best = -10;                  // state of cell (d, cb_)
-                    uint32_t bpp = kTagHead, blink = 0;  // best_pp / best_link of the cell
                     if (dl < n_d) {
+                        int32_t best = -10;                  // state of cell (d, cb_)
+                        uint32_t bpp = kTagHead, blink = 0;  // best_pp / best_link of the cell
                         const uint32_t cst = cur.cstart[d * 6u + cb_], cn = cur.clen[d * 6u + cb_];
                         int32_t via = kNoScore, via_next = kNoScore;
                         for (uint32_t m0 = 0; m0 < cn; m0 += 4) {  // 4 links per LDS round trip
@@ -821,50 +874,274 @@ __global__ __launch_bounds__(192) void score_fast_kernel(
                                 }
                             }
                         }
-                        s_bpp[sl][d * 6u + cb_] = bpp;
-                        s_blink[sl][d * 6u + cb_] = blink;
-                    }
-                    const int n_act = (int)(n_d * 5u);
-                    for (int l = 0; l < n_act; l++) {  // global pick in (delta, symbol) order (lib/nextcorrect.c:2194-2199)
-                        const int32_t v = __builtin_amdgcn_readlane(best, l);
-                        if (v >= gbest - 3000) {
-                            o_t = (int32_t)q;
-                            o_db = ((d0 + (uint32_t)l / 5u) << 3) | ((uint32_t)l % 5u);
-                            if (v > gbest) gbest = v;
-                        }
+                        S.bpp[sl][d * 6u + cb_] = bpp;
+                        S.blink[sl][d * 6u + cb_] = blink;
+                        S.best[sl][d * 6u + cb_] = best;
+                        if (enc && best > kRelThr) f_brel = best > f_brel ? best : f_brel;
+                        else f_babs = best > f_babs ? best : f_babs;
                     }
                 }
             }
         }
-#ifdef NDGPU_K10_PROF
-        prof_busy += clock64() - prof_t0;
-#endif
         __syncthreads();
     }
-#ifdef NDGPU_K10_PROF
-    if (lane == 0) {
-        P.prof[wave == 1 ? 0 : wave == 0 ? 1 : 2] = prof_busy;
-        if (wave == 0) P.prof[3] = clock64() - prof_start;
-    }
-#endif
     if (wave == 1) {
-        if (!stopped) {  // columns L-2 was stored in the last iteration (p = L); L-1 is left
-            if (L >= 1) store_results(L - 1u);
-        }
-        if (lane == 0) s_links = n_links;
+        if (!stopped && L > c0) store_results(L - 1u);  // column L-2 was stored in the last iteration (p = L)
+        if (lane == 0) S.r_links = n_links;
     } else if (wave == 0) {
-        if (__ballot(sc_overflow) && lane == 0) s_sc_ovf = 1;
-    } else if (lane == 0) s_ot = o_t, s_odb = o_db;
+        const int32_t vmin = wave_min_i32(t_vmin), amax = wave_max_i32(t_amax);
+        const bool ovf = __ballot(sc_overflow) != 0ull;
+        if (lane == 0) {
+            S.r_vmin = vmin, S.r_amax = amax;
+            if (ovf) atomicOr(&S.r_flags, 2u);
+        }
+    } else {
+        const int32_t brel = wave_max_i32(f_brel), babs = wave_max_i32(f_babs);
+        if (lane == 0) {
+            S.r_brel = brel, S.r_babs = babs;
+            if (stopped) atomicOr(&S.r_flags, 1u);
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (stopped || s_sc_ovf) {
-            P.err = 2;  // redo this pile in the int64 / HBM-resident kernel
-        } else {
-            if (REDO) P.err = 0;
-            P.origin_t = s_ot;
-            P.origin_db = s_odb;
-            P.n_links = s_links;
+        SegSum &R = A.sums[sidx];
+        R.vmin = S.r_vmin, R.amax = S.r_amax, R.bmax_rel = S.r_brel, R.bmax_abs = S.r_babs;
+        R.links = S.r_links, R.n_fin = S.r_nfin, R.flags = S.r_flags;
+    }
+}
+
+// Phase A: one workgroup per (pile, segment) of this table tier.
+template <int CELLS, int ENTS>
+__global__ __launch_bounds__(192) void score_seg_kernel(const K10Args A, const SegItem *__restrict__ items) {
+    __shared__ K10Smem<CELLS, ENTS> S;
+    const SegItem it = items[blockIdx.x];
+    const PileDev &P = A.piles[it.pile];
+    const uint32_t c0 = it.seg * A.seg_len;
+    const uint32_t c1 = it.seg + 1u == P.n_seg ? P.seed_len : c0 + A.seg_len;
+    if (it.seg == 0) score_range<CELLS, ENTS>(S, A, P, P.seg_off, 0u, c1, 0u, 0, false, nullptr);
+    else score_range<CELLS, ENTS>(S, A, P, P.seg_off + it.seg, c0, c1, c0 - A.warm, 1, true, nullptr);
+}
+
+// The boundary check of segment i (see the head comment): `fin` of its predecessor against its own `spec`, n links.
+// All threads of the wave call it; returns ok, *dlt = the constant (0 when no link carries an offset).
+__device__ __forceinline__ bool check_boundary(const int32_t *__restrict__ fin_prev, const int32_t *__restrict__ spec,
+                                               uint32_t n, bool pred_enc, int lane, int32_t *dlt) {
+    bool bad = false, have = false;
+    int32_t d0 = 0;
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        bool rel = false;
+        int32_t d = 0;
+        if (e < n) {
+            const int32_t u = fin_prev[e], v = spec[e];
+            if (v > kRelThr) {
+                rel = true;
+                d = (int32_t)((uint32_t)u - (uint32_t)v);
+                if (pred_enc && u <= kRelThr) bad = true;
+            } else if (u != v) {
+                bad = true;
+            }
         }
+        const unsigned long long rm = __ballot(rel);
+        if (rm) {
+            const int32_t dl = __shfl(d, __ffsll((long long)rm) - 1, 64);
+            if (!have) d0 = dl, have = true;
+            if (rel && d != d0) bad = true;
+        }
+    }
+    *dlt = have ? d0 : 0;
+    return __ballot(bad) == 0ull;
+}
+
+// Phase B + C: one workgroup per pile checks its segments, repairs the ones that fail, and makes the global pick.
+template <int CELLS, int ENTS, bool REDO>
+__global__ __launch_bounds__(192) void score_stitch_kernel(const K10Args A) {
+    __shared__ K10Smem<CELLS, ENTS> S;
+    __shared__ long long sh_off, sh_g, sh_pm[192];
+    __shared__ uint32_t sh_enc, sh_i, sh_fail, sh_flags, sh_links, sh_repairs, sh_seg;
+    __shared__ int sh_last;
+    PileDev &P = A.piles[blockIdx.x];
+    if (REDO != (P.err == 3) || P.err == 2) return;  // the column scan chose the tier of every pile; 2: HBM-resident kernel
+    const int wave = (int)(threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_seg = P.n_seg, sg = A.seg_len;
+    SegSum *sums = A.sums + P.seg_off;
+    const int32_t *fin = A.fin + (size_t)P.seg_off * kColEnts;
+    const int32_t *spec = A.spec + (size_t)P.seg_off * kColEnts;
+    auto seg_end = [&](uint32_t i) { return i + 1u == n_seg ? P.seed_len : (i + 1u) * sg; };
+
+    if (threadIdx.x == 0) sh_off = 0, sh_enc = 0, sh_i = 1, sh_fail = 0, sh_flags = 0, sh_links = 0, sh_repairs = 0;
+    __syncthreads();
+    // pass 0 / 1 (parallel over segments): flags, link totals, boundary checks
+    {
+        uint32_t fl = 0, lk = 0;
+        for (uint32_t i = threadIdx.x; i < n_seg; i += 192) {
+            fl |= sums[i].flags;
+            lk += sums[i].links;
+        }
+        if (fl) atomicOr(&sh_flags, fl);
+        atomicAdd(&sh_links, lk);
+        for (uint32_t i = 1u + (uint32_t)wave; i < n_seg; i += 3u) {
+            int32_t dlt;
+            const bool ok = check_boundary(fin + (size_t)(i - 1u) * kColEnts, spec + (size_t)i * kColEnts, sums[i - 1u].n_fin,
+                                           i > 1u, lane, &dlt);
+            if (lane == 0) sums[i].ok = ok ? 1u : 0u, sums[i].dlt = dlt;
+        }
+        if (threadIdx.x == 0) sums[0].off = 0, sums[0].enc = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (sh_flags) {
+        if (threadIdx.x == 0) P.err = 2;
+        return;
+    }
+    // pass 2: offsets in segment order, 64 segments per round; the first segment that fails a check is repaired
+    for (;;) {
+        const uint32_t i0 = sh_i;
+        if (i0 >= n_seg) break;
+        if (wave == 0) {
+            const uint32_t seg = i0 + (uint32_t)lane;
+            const bool have = seg < n_seg;
+            uint32_t ok = 0;
+            int32_t dlt = 0, vmin = INT32_MAX, amax = 0;
+            if (have) ok = sums[seg].ok, dlt = sums[seg].dlt, vmin = sums[seg].vmin, amax = sums[seg].amax;
+            long long pre = have ? (long long)dlt : 0ll;
+            for (int o = 1; o < 64; o <<= 1) {
+                const long long u = shfl_i64(pre, lane >= o ? lane - o : lane);
+                if (lane >= o) pre += u;
+            }
+            const long long offs = sh_off + pre;
+            bool valid = have && ok && (vmin == INT32_MAX || (long long)vmin + offs > (long long)amax);
+            if (A.force_repair && have && (seg % A.force_repair) == 1u) valid = false;
+            const unsigned long long badm = __ballot(have && !valid), havem = __ballot(have);
+            const int nvalid = badm ? __ffsll((long long)badm) - 1 : __popcll(havem);
+            if (lane < nvalid) sums[seg].off = offs, sums[seg].enc = 1u;
+            const long long last_off = shfl_i64(offs, nvalid > 0 ? nvalid - 1 : 0);
+            if (lane == 0) {
+                if (nvalid > 0) sh_off = last_off, sh_enc = 1u;
+                sh_i = i0 + (uint32_t)nvalid;
+                sh_fail = badm ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        if (sh_fail) {
+            const uint32_t f = sh_i;
+            const bool enc = sh_enc != 0u;
+            score_range<CELLS, ENTS>(S, A, P, P.seg_off + f, f * sg, seg_end(f), f * sg, 2, enc, fin + (size_t)(f - 1u) * kColEnts);
+            __threadfence_block();
+            __syncthreads();
+            const SegSum R = sums[f];
+            const bool dead = R.flags != 0u || (enc && R.vmin != INT32_MAX && !((long long)R.vmin + sh_off > (long long)R.amax));
+            if (dead) {  // a column that does not fit / a raw score out of range / absolute values in reach: int64 kernel
+                if (threadIdx.x == 0) P.err = 2;
+                return;
+            }
+            if (wave == 0 && f + 1u < n_seg) {
+                int32_t dlt;
+                const bool ok = check_boundary(fin + (size_t)f * kColEnts, spec + (size_t)(f + 1u) * kColEnts, R.n_fin, enc, lane, &dlt);
+                if (lane == 0) sums[f + 1u].ok = ok ? 1u : 0u, sums[f + 1u].dlt = dlt;
+            }
+            if (threadIdx.x == 0) {
+                sums[f].off = sh_off, sums[f].enc = sh_enc;
+                sh_i = f + 1u, sh_fail = 0, sh_repairs++;
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
+    }
+    // Phase C: the global pick.  True maximum of every segment, running maximum before it (g), the last segment whose
+    // maximum reaches g - 3000 holds the answer (its maximum cell passes the test, and no later cell does).
+    if (wave == 0) {
+        long long carry = -10;
+        int last = -1;
+        long long g_last = -10;
+        for (uint32_t i0 = 0; i0 < n_seg; i0 += 64) {
+            const uint32_t seg = i0 + (uint32_t)lane;
+            long long tm = LLONG_MIN;
+            if (seg < n_seg) {
+                const SegSum R = sums[seg];
+                if (R.bmax_abs != INT32_MIN) tm = R.bmax_abs;
+                if (R.bmax_rel != INT32_MIN) {
+                    const long long t2 = (long long)R.bmax_rel + R.off;
+                    tm = t2 > tm ? t2 : tm;
+                }
+            }
+            long long pm = tm;  // inclusive prefix maximum
+            for (int o = 1; o < 64; o <<= 1) {
+                const long long u = shfl_i64(pm, lane >= o ? lane - o : lane);
+                if (lane >= o && u > pm) pm = u;
+            }
+            long long g = shfl_i64(pm, lane ? lane - 1 : 0);
+            if (lane == 0 || g < carry) g = lane == 0 ? carry : (g < carry ? carry : g);
+            const bool q = tm != LLONG_MIN && tm >= g - 3000;
+            const unsigned long long qm = __ballot(q);
+            if (qm) {
+                const int hl = 63 - __clzll((long long)qm);
+                last = (int)i0 + hl;
+                g_last = shfl_i64(g, hl);
+            }
+            const long long top = shfl_i64(pm, 63);
+            carry = top > carry ? top : carry;
+        }
+        if (lane == 0) sh_last = last, sh_g = g_last;
+    }
+    __syncthreads();
+    const int last = sh_last;
+    int32_t o_t = -1;
+    uint32_t o_db = 0;
+    if (last >= 0) {
+        const uint32_t *cb = A.cell_base + P.col_off;
+        const int32_t *best = A.cell_best + P.cell_off;
+        const SegSum R = sums[last];
+        const uint32_t ca = cb[(uint32_t)last * sg], ce = cb[seg_end((uint32_t)last)];
+        const uint32_t n = ce - ca, per = (n + 191u) / 192u;
+        const uint32_t a = ca + threadIdx.x * per < ce ? ca + threadIdx.x * per : ce;
+        const uint32_t b = a + per < ce ? a + per : ce;
+        auto val = [&](uint32_t c) -> long long {
+            const int32_t raw = best[c];
+            return (R.enc && raw > kRelThr) ? (long long)raw + R.off : (long long)raw;
+        };
+        long long mx = LLONG_MIN;
+        for (uint32_t c = a; c < b; c++)
+            if (c % 6u < 5u) {
+                const long long v = val(c);
+                mx = v > mx ? v : mx;
+            }
+        sh_pm[threadIdx.x] = mx;
+        if (threadIdx.x == 0) sh_seg = 0;
+        __syncthreads();
+        long long run = sh_g;
+        for (uint32_t t = 0; t < threadIdx.x; t++) run = sh_pm[t] > run ? sh_pm[t] : run;
+        uint32_t hit = 0;  // cell index + 1 of the last cell of this thread's chunk that passes
+        for (uint32_t c = a; c < b; c++)
+            if (c % 6u < 5u) {
+                const long long v = val(c);
+                if (v >= run - 3000) {
+                    hit = c + 1u;
+                    if (v > run) run = v;
+                }
+            }
+        if (hit) atomicMax(&sh_seg, hit);
+        __syncthreads();
+        if (threadIdx.x == 0 && sh_seg) {
+            const uint32_t cell = sh_seg - 1u;
+            uint32_t lo = (uint32_t)last * sg, hi = seg_end((uint32_t)last);  // greatest column t in [lo, hi) with cb[t] <= cell
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cb[mid] <= cell) lo = mid;
+                else hi = mid;
+            }
+            o_t = (int32_t)lo;
+            const uint32_t r = cell - cb[lo];
+            o_db = ((r / 6u) << 3) | (r % 6u);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (REDO) P.err = 0;
+        P.origin_t = o_t;
+        P.origin_db = o_db;
+        P.n_links = sh_links;
+        P.n_repair = sh_repairs;
     }
 }
 
@@ -960,6 +1237,7 @@ __global__ __launch_bounds__(64) void score_slow_kernel(
         P.origin_t = o_t;
         P.origin_db = o_db;
         P.err = 0;
+        P.n_repair = 0xffffffffu;  // marker for the host's counters: scored by this kernel
     }
 }
 
@@ -1150,36 +1428,32 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
                            ent_ppp, ent_cnt, err);
 }
 
-void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,
-                            const uint32_t *cell_base, const uint32_t *ent_base, const uint32_t *cell_start,
-                            const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
-                            const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
-                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream,
-                            void *ev_after_fast, bool any_large, void *stream_large, void *ev_fork, void *ev_join) {
+void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_small, const SegItem *items_large, int n_large,
+                            long long *ent_score, PathItem *path, int n_piles, void *stream, void *ev_after_fast,
+                            void *stream_large, void *ev_fork, void *ev_join) {
     if (n_piles <= 0) return;
     hipStream_t st = (hipStream_t)stream;
-    const bool forked = any_large && stream_large && stream_large != stream;
-    if (any_large) {  // the piles that need the large tables are scored at the same time on a second stream
+    const bool forked = n_large > 0 && stream_large && stream_large != stream;
+    if (n_large > 0) {  // the piles that need the large tables are scored at the same time on a second stream
         hipStream_t s2 = forked ? (hipStream_t)stream_large : st;
         if (forked) {
             (void)hipEventRecord((hipEvent_t)ev_fork, st);
             (void)hipStreamWaitEvent(s2, (hipEvent_t)ev_fork, 0);
         }
-        hipLaunchKernelGGL((score_fast_kernel<kColCells, kColEnts, true>), dim3((unsigned)n_piles), dim3(192), 0, s2, piles,
-                           coverage, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
-                           cell_best_link);
+        hipLaunchKernelGGL((score_seg_kernel<kColCells, kColEnts>), dim3((unsigned)n_large), dim3(192), 0, s2, a, items_large);
+        hipLaunchKernelGGL((score_stitch_kernel<kColCells, kColEnts, true>), dim3((unsigned)n_piles), dim3(192), 0, s2, a);
         if (forked) (void)hipEventRecord((hipEvent_t)ev_join, s2);
     }
-    hipLaunchKernelGGL((score_fast_kernel<kColCellsSmall, kColEntsSmall, false>), dim3((unsigned)n_piles), dim3(192), 0, st, piles,
-                       coverage, max_size, cell_base, ent_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, cell_best_pp,
-                       cell_best_link);
+    if (n_small > 0)
+        hipLaunchKernelGGL((score_seg_kernel<kColCellsSmall, kColEntsSmall>), dim3((unsigned)n_small), dim3(192), 0, st, a, items_small);
+    hipLaunchKernelGGL((score_stitch_kernel<kColCellsSmall, kColEntsSmall, false>), dim3((unsigned)n_piles), dim3(192), 0, st, a);
     if (forked) (void)hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0);
     if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
-    hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage, max_size,
-                       cell_base, cell_start, cell_len, ent_pp, ent_ppp, ent_cnt, ent_score, cell_best_pp,
-                       cell_best_link);
-    hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, piles, coverage,
-                       cell_base, cell_best_pp, cell_best_link, path, n_piles);
+    hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, a.piles, a.coverage, a.max_size,
+                       a.cell_base, a.cell_start, a.cell_len, a.ent_pp, a.ent_ppp, a.ent_cnt, ent_score, a.cell_best_pp,
+                       a.cell_best_link);
+    hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, a.piles, a.coverage,
+                       a.cell_base, a.cell_best_pp, a.cell_best_link, path, n_piles);
 }
 
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,

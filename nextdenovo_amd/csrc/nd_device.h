@@ -97,10 +97,43 @@ struct PileDev {
     uint32_t origin_db;     // delta << 3 | base
     uint32_t err;           // nonzero: device-side capacity error
     uint32_t n_links;       // distinct (pp,ppp) links of the pile (written by the scoring kernel)
-#ifdef NDGPU_K10_PROF
-    unsigned long long prof[4];  // busy cycles of the loader / scorer / folder wave and the kernel's total (NDGPU_TRACE prints them)
-#endif
+    // scoring segments (K10): filled by the host with the cell / link offsets
+    uint32_t seg_off;       // index of the pile's first segment record
+    uint32_t n_seg;
+    uint32_t n_repair;      // segments the stitch kernel scored again (written by it)
+    uint32_t pad_;
 };
+
+// ---- scoring DP (K10), segment-parallel: see the head comment of the K10 section in msa_kernels.hip ----
+struct SegItem {            // work item of the segment kernel
+    uint32_t pile;
+    uint32_t seg;
+};
+struct SegSum {             // one per (pile, segment)
+    // written by the kernel that scored the segment
+    int32_t vmin, amax;           // smallest offset-carrying / largest absolute link score from the column before the segment on
+    int32_t bmax_rel, bmax_abs;   // largest cell best of the segment by kind (INT32_MIN: none)
+    uint32_t links;               // distinct links of the segment's columns
+    uint32_t n_fin;               // links of its last column (entries of `fin`)
+    uint32_t flags;               // 1: a column does not fit the LDS tables, 2: a raw score left the int32 working range
+    // written by the stitch kernel
+    int32_t dlt;                  // constant between the predecessor's `fin` and this segment's `spec`
+    uint32_t ok;                  // the boundary check passed
+    uint32_t enc;                 // 1: raw scores above kRelThr carry `off`
+    long long off;                // true score = raw + off
+};
+struct K10Args {
+    PileDev *piles;
+    const uint32_t *coverage, *max_size, *cell_base, *ent_base, *cell_start, *cell_len, *ent_pp, *ent_ppp, *ent_cnt;
+    uint32_t *cell_best_pp, *cell_best_link;
+    int32_t *cell_best;           // best score of every cell (raw)
+    SegSum *sums;
+    int32_t *spec, *fin;          // kSegEnts raw scores per segment: what it held for the column before its first / computed for its last
+    uint32_t seg_len, warm;       // columns per segment, warm-up columns of a speculative segment (< seg_len)
+    int32_t guard;                // raw scores beyond it send the pile to the int64 kernel
+    uint32_t force_repair;        // test hook: every segment with index % force_repair == 1 is treated as failed
+};
+constexpr int kSegEnts = 512;     // = the large tier's link slots per column
 
 struct PathItem {           // one visited cell of the best_pp walk (origin first)
     uint32_t tag;           // packed (t_pos, delta, base)
@@ -145,12 +178,11 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
                         const uint32_t *cell_base, const uint32_t *ent_base, uint32_t *cell_start, uint32_t *cell_len,
                         uint32_t *ent_pp, uint32_t *ent_ppp, uint32_t *ent_cnt, uint32_t *err, int n_blocks, bool full_capacity,
                         void *stream);
-void launch_score_backtrack(PileDev *piles, const uint32_t *coverage, const uint32_t *max_size,
-                            const uint32_t *cell_base, const uint32_t *ent_base, const uint32_t *cell_start,
-                            const uint32_t *cell_len, const uint32_t *ent_pp, const uint32_t *ent_ppp,
-                            const uint32_t *ent_cnt, long long *ent_score, uint32_t *cell_best_pp,
-                            uint32_t *cell_best_link, PathItem *path, int n_piles, void *stream,
-                            void *ev_after_fast, bool any_large, void *stream_large, void *ev_fork, void *ev_join);
+// segment kernels of both table tiers (the large one on stream_large at the same time) -> stitch -> int64 kernel for
+// the piles they left (err == 2) -> best_pp walk
+void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_small, const SegItem *items_large, int n_large,
+                            long long *ent_score, PathItem *path, int n_piles, void *stream, void *ev_after_fast,
+                            void *stream_large, void *ev_fork, void *ev_join);
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,
                     const uint32_t *colidx, RegionDev *regions, char *strpool, unsigned long long *strpool_cursor,
                     unsigned long long strpool_cap, int n_regions, void *stream);

@@ -35,6 +35,9 @@ struct RuntimeStats {
     uint64_t links = 0;            // distinct MSA links
     uint64_t score_launches = 0;
     double backtrack_ms = 0;
+    uint64_t score_segments = 0;   // K10 segments scored
+    uint64_t score_repairs = 0;    // of which the stitch kernel scored again (a boundary check failed)
+    uint64_t score_slow_piles = 0; // piles that went through the int64 HBM-resident scoring kernel
 };
 
 class DeviceAligner {
