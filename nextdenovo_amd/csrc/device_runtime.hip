@@ -35,16 +35,39 @@ namespace {
         }                                                                                                     \
     } while (0)
 
+static const bool g_debug_alloc = getenv("NDGPU_DEBUG_ALLOC") != nullptr;  // log every device buffer range (fault triage)
+static const bool g_debug_launch = getenv("NDGPU_DEBUG_LAUNCH") != nullptr;  // triage: name + synchronise every launch group
+#define NDGPU_DBG(st, ...)                                                                  \
+    do {                                                                                    \
+        if (g_debug_launch) {                                                               \
+            (void)hipStreamSynchronize(st);                                                 \
+            fprintf(stderr, "[ndgpu dbg %p] ", (void *)(st));                               \
+            fprintf(stderr, __VA_ARGS__);                                                   \
+            fprintf(stderr, "\n");                                                          \
+            fflush(stderr);                                                                 \
+        }                                                                                   \
+    } while (0)
+static std::mutex g_dbg_mu;  // NDGPU_DEBUG_LAUNCH=2: one device phase at a time over all contexts
+static const bool g_debug_exclusive = getenv("NDGPU_DEBUG_LAUNCH") && atoi(getenv("NDGPU_DEBUG_LAUNCH")) >= 2;
+static const bool g_debug_nofree = getenv("NDGPU_DEBUG_NOFREE") != nullptr;  // triage: outgrown buffers are leaked, not freed
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
+    const char *name = "";
     void reserve(size_t n) {
         if (n <= cap) return;
-        if (p) HIP_CHECK(hipFree(p));
+        if (p) {
+            if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] free %s %p\n", name, (void *)p);
+            if (!g_debug_nofree) HIP_CHECK(hipFree(p));
+        }
         size_t want = n + n / 4 + 1024;
         HIP_CHECK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
+        if (g_debug_alloc)
+            fprintf(stderr, "[ndgpu alloc] %s %p .. %p (%zu bytes, asked %zu)\n", name, (void *)p, (void *)((char *)p + want * sizeof(T)),
+                    want * sizeof(T), n * sizeof(T));
     }
     ~DevBuf() {
         if (p) (void)hipFree(p);
@@ -57,10 +80,11 @@ struct PinBuf {
     size_t cap = 0;
     void reserve(size_t n) {
         if (n <= cap) return;
-        if (p) HIP_CHECK(hipHostFree(p));
+        if (p && !g_debug_nofree) HIP_CHECK(hipHostFree(p));
         size_t want = n + n / 4 + 1024;
         HIP_CHECK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
         cap = want;
+        if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] pinned %p .. %p\n", (void *)p, (void *)((char *)p + want * sizeof(T)));
     }
     ~PinBuf() {
         if (p) (void)hipHostFree(p);
@@ -138,6 +162,7 @@ struct DeviceAligner::State {
     DevBuf<int32_t> d_cell_best, d_spec, d_fin;  // K10 segments: cell bests, boundary scores (kSegEnts per segment)
     DevBuf<SegSum> d_sums;
     DevBuf<SegItem> d_items;
+    DevBuf<uint32_t> d_bt_exit, d_bt_steps, d_bt_entry, d_bt_off;  // best_pp walk by segments
     DevBuf<PathItem> d_path;
     DevBuf<ColBlock> d_blocks;
     DevBuf<RegionDev> d_regions;
@@ -156,6 +181,58 @@ struct DeviceAligner::State {
     int host_threads = 1;
     bool k9_full_capacity = getenv("NDGPU_K9_FULL") != nullptr;  // skip the small-capacity first attempt of K9
     uint64_t k9_retries = 0;
+
+    // Host <-> device transfers go through two pinned arenas of the context.  An asynchronous copy from / to pageable
+    // memory makes the runtime pin the caller's pages for the duration of the copy; with eight contexts doing that at
+    // the same time from neighbouring heap blocks, one context's unpin took a page another context's copy was still
+    // using (GPU memory access faults on host heap addresses).  Everything a kernel or a copy engine touches is now
+    // either device memory or these arenas.
+    PinBuf<char> up, down;
+    size_t up_used = 0, down_used = 0;
+    struct Pending {
+        void *dst;
+        size_t off, bytes;
+    };
+    std::vector<Pending> pending;
+    void drain() {  // the stream is idle: hand the downloaded bytes to their owners, recycle both arenas
+        for (const Pending &q : pending) memcpy(q.dst, down.p + q.off, q.bytes);
+        pending.clear();
+        up_used = down_used = 0;
+    }
+    void sync_drain(hipStream_t st) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        drain();
+    }
+    void reserve_down(size_t bytes, hipStream_t st) {  // room for `bytes` of downloads without moving the arena (views stay valid)
+        if (down_used + bytes + 4096 <= down.cap) return;
+        sync_drain(st);
+        down.reserve(bytes + 4096);
+    }
+    void h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
+        if (!bytes) return;
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (up_used + need > up.cap) {
+            sync_drain(st);
+            up.reserve(std::max(need, up.cap * 2));
+        }
+        memcpy(up.p + up_used, src, bytes);
+        HIP_CHECK(hipMemcpyAsync(dst, up.p + up_used, bytes, hipMemcpyHostToDevice, st));
+        up_used += need;
+    }
+    // device -> host: the bytes land in the arena; dst_host (if given) receives them at the next drain; the returned
+    // pointer is valid from the next stream synchronisation until the next drain / reserve
+    void *d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st) {
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (down_used + need > down.cap) {
+            sync_drain(st);
+            down.reserve(std::max(need, down.cap * 2));
+        }
+        char *at = down.p + down_used;
+        if (bytes) HIP_CHECK(hipMemcpyAsync(at, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        if (dst_host && bytes) pending.push_back(Pending{dst_host, down_used, bytes});
+        down_used += need;
+        return at;
+    }
 };
 
 static int g_ctx_creating = -1;  // index of the context under construction (guarded by g_ctx_mu)
@@ -208,6 +285,15 @@ DeviceAligner::DeviceAligner() : s_(new State) {
             HIP_CHECK(hipEventCreateWithFlags(&s_->ev_join, hipEventDisableTiming));
         }
     }
+#define NDGPU_NAME(x) s_->x.name = #x;
+    NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_mink) NDGPU_NAME(d_v)
+    NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
+    NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_inscnt) NDGPU_NAME(d_insmax) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
+    NDGPU_NAME(d_cell_start) NDGPU_NAME(d_cell_len) NDGPU_NAME(d_cell_bpp) NDGPU_NAME(d_cell_blink) NDGPU_NAME(d_ent_pp)
+    NDGPU_NAME(d_ent_ppp) NDGPU_NAME(d_ent_cnt) NDGPU_NAME(d_err) NDGPU_NAME(d_ent_score) NDGPU_NAME(d_cell_best) NDGPU_NAME(d_spec)
+    NDGPU_NAME(d_fin) NDGPU_NAME(d_sums) NDGPU_NAME(d_items) NDGPU_NAME(d_bt_exit) NDGPU_NAME(d_bt_steps) NDGPU_NAME(d_bt_entry)
+    NDGPU_NAME(d_bt_off) NDGPU_NAME(d_path) NDGPU_NAME(d_blocks) NDGPU_NAME(d_regions) NDGPU_NAME(d_strpool) NDGPU_NAME(d_cursor)
+#undef NDGPU_NAME
     HIP_CHECK(hipEventCreate(&s_->ev0));
     HIP_CHECK(hipEventCreate(&s_->ev1));
     for (auto &e : s_->evs) HIP_CHECK(hipEventCreate(&e));
@@ -274,6 +360,7 @@ void DeviceAligner::set_db(const uint32_t *pool_words, size_t n_words) {
         if (g_db_pool) HIP_CHECK(hipFree(g_db_pool));
         HIP_CHECK(hipMalloc((void **)&g_db_pool, (n_words + 2) * sizeof(uint32_t)));
         g_db_cap = n_words + 2;
+        if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] db_pool %p .. %p\n", (void *)g_db_pool, (void *)(g_db_pool + g_db_cap));
     }
     HIP_CHECK(hipMemcpy(g_db_pool, pool_words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(g_db_pool + n_words, 0, 2 * sizeof(uint32_t)));
@@ -296,6 +383,8 @@ static void limits_for(int total, int hq, int *max_d, int *band) {
 
 void DeviceAligner::align_batch(AlnJob **jobs, size_t n) {
     if (n == 0) return;
+    std::unique_lock<std::mutex> dbg_lock;
+    if (g_debug_exclusive) dbg_lock = std::unique_lock<std::mutex>(g_dbg_mu);
     std::lock_guard<std::mutex> lock(s_->mu);
     HIP_CHECK(hipSetDevice(s_->device));
     size_t done = 0;
@@ -430,15 +519,18 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.h_outs.reserve(n);
 
     hipStream_t st = S.stream;
-    HIP_CHECK(hipMemcpyAsync(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), hipMemcpyHostToDevice, st));
+    S.h2d(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), st);
+    S.h2d(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), st);
     HIP_CHECK(hipEventRecord(S.ev0, st));
+    NDGPU_DBG(st, "chunk: forward %zu tasks", n);
     launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p, (int)n, st);
     HIP_CHECK(hipEventRecord(S.ev1, st));
+    NDGPU_DBG(st, "chunk: traceback");
     launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
+    NDGPU_DBG(st, "chunk: done");
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, n * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(S.h_ops.p, S.d_ops.p, ops_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    S.sync_drain(st);
     HIP_CHECK(hipGetLastError());
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, S.ev0, S.ev1));
@@ -540,13 +632,12 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
         hipStream_t st = S.stream;
         for (size_t i = 0; i < take; i++) {
             S.tasks[ids[at + i]] = patch[i];
-            HIP_CHECK(hipMemcpyAsync(S.d_tasks.p + ids[at + i], &S.tasks[ids[at + i]], sizeof(AlnTask),
-                                     hipMemcpyHostToDevice, st));
+            S.h2d(S.d_tasks.p + ids[at + i], &S.tasks[ids[at + i]], sizeof(AlnTask), st);
         }
-        HIP_CHECK(hipMemcpyAsync(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        S.h2d(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), st);
         launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
         launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
-        HIP_CHECK(hipStreamSynchronize(st));
+        S.sync_drain(st);
         for (size_t i = 0; i < take; i++) {
             const int32_t id = ids[at + i];
             const AlnTask &t = S.tasks[id];
@@ -576,6 +667,8 @@ static inline uint64_t wall_ns() {
 void DeviceAligner::run_main(MainPile **mp, size_t np) {
     State &S = *s_;
     uint64_t tp0 = wall_ns();
+    std::unique_lock<std::mutex> dbg_lock;
+    if (g_debug_exclusive) dbg_lock = std::unique_lock<std::mutex>(g_dbg_mu);
     std::lock_guard<std::mutex> lock(S.mu);
     HIP_CHECK(hipSetDevice(S.device));
     hipStream_t st = S.stream;
@@ -716,11 +809,11 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
 
     uint64_t tp1 = wall_ns();
     g_prof.m_prep += tp1 - tp0;
-    HIP_CHECK(hipMemcpyAsync(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    if (nt) HIP_CHECK(hipMemcpyAsync(S.d_tasks.p, tasks.data(), nt * sizeof(AlnTask), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(S.d_reads.p, reads.data(), nr * sizeof(ReadDev), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(S.d_read_pile.p, read_pile.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    S.h2d(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), st);
+    if (nt) S.h2d(S.d_tasks.p, tasks.data(), nt * sizeof(AlnTask), st);
+    S.h2d(S.d_reads.p, reads.data(), nr * sizeof(ReadDev), st);
+    S.h2d(S.d_piles.p, piles.data(), np * sizeof(PileDev), st);
+    S.h2d(S.d_read_pile.p, read_pile.data(), nr * sizeof(uint32_t), st);
     HIP_CHECK(hipMemsetAsync(S.d_cov.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(S.d_inscnt.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(S.d_insmax.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
@@ -731,11 +824,14 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         for (size_t b : chunk_end) {
             if (b > a) {
                 HIP_CHECK(hipEventRecord(S.evs[0], st));
+                NDGPU_DBG(st, "main: forward %zu..%zu of %zu tasks, %zu piles", a, b, nt, np);
                 launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p,
                                    (int)(b - a), st);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
+                NDGPU_DBG(st, "main: traceback");
                 launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p,
                                      S.d_ops.p, nullptr, (int)(b - a), st);
+                NDGPU_DBG(st, "main: traceback done");
                 HIP_CHECK(hipEventRecord(S.evs[2], st));
                 HIP_CHECK(hipEventSynchronize(S.evs[2]));
                 float ms = 0;
@@ -750,7 +846,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     }
     if (nt) {
         HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, nt * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        S.sync_drain(st);
         std::vector<int32_t> wide;
         for (size_t i = 0; i < nt; i++) {
             const AlnOut &o = S.h_outs.p[i];
@@ -766,14 +862,19 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     uint64_t tp2 = wall_ns();
     g_prof.m_aln += tp2 - tp1;
     HIP_CHECK(hipEventRecord(S.evs[0], st));
+    NDGPU_DBG(st, "main: shift_scan");
     launch_shift_scan(S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_reads.p, (int)nr, st);
+    NDGPU_DBG(st, "main: pile_accept");
     launch_pile_accept(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_cov.p, (int)np, st);
+    NDGPU_DBG(st, "main: make_tags");
     launch_make_tags(S.d_piles.p, S.d_reads.p, S.d_tasks.p, S.d_ops.p, S.d_pool.p, g_db_pool, S.d_read_pile.p,
                      S.d_tags.p, S.d_colidx.p, S.d_inscnt.p, S.d_insmax.p, (int)nr, st);
+    NDGPU_DBG(st, "main: col_scan");
     launch_col_scan(S.d_piles.p, S.d_cov.p, S.d_inscnt.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, (int)np, st);
+    NDGPU_DBG(st, "main: col_scan done");
     HIP_CHECK(hipEventRecord(S.evs[1], st));
-    HIP_CHECK(hipMemcpyAsync(piles.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    S.d2h(piles.data(), S.d_piles.p, np * sizeof(PileDev), st);
+    S.sync_drain(st);
 
     uint64_t tp3 = wall_ns();
     g_prof.m_tags += tp3 - tp2;
@@ -801,7 +902,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         }
     };
     static const K10Cfg k10;
-    std::vector<SegItem> items_small, items_large;
+    std::vector<SegItem> items_small, items_large, items_slow;  // (slow: piles of the int64 kernel; only the walk uses them)
     uint32_t n_segs = 0;
     for (size_t p = 0; p < np; p++) {
         PileDev &P = piles[p];
@@ -811,10 +912,9 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         P.seg_off = n_segs;
         n_segs += P.n_seg;
         P.n_repair = 0;
-        if (P.err != 2) {
-            std::vector<SegItem> &dst = P.err == 3 ? items_large : items_small;
-            for (uint32_t g = 0; g < P.n_seg; g++) dst.push_back(SegItem{(uint32_t)p, g});
-        }
+        P.tier = P.err == 3 ? 1u : 0u;
+        std::vector<SegItem> &dst = P.err == 2 ? items_slow : P.err == 3 ? items_large : items_small;
+        for (uint32_t g = 0; g < P.n_seg; g++) dst.push_back(SegItem{(uint32_t)p, g});
     }
     for (size_t p = 0; p < np; p++) {
         PileDev &P = piles[p];
@@ -843,14 +943,17 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_sums.reserve(n_segs + 1);
     S.d_spec.reserve((size_t)n_segs * kSegEnts + 1);
     S.d_fin.reserve((size_t)n_segs * kSegEnts + 1);
-    S.d_items.reserve(items_small.size() + items_large.size() + 1);
-    HIP_CHECK(hipMemcpyAsync(S.d_blocks.p, blocks.data(), blocks.size() * sizeof(ColBlock), hipMemcpyHostToDevice, st));
-    if (!items_small.empty())
-        HIP_CHECK(hipMemcpyAsync(S.d_items.p, items_small.data(), items_small.size() * sizeof(SegItem), hipMemcpyHostToDevice, st));
-    if (!items_large.empty())
-        HIP_CHECK(hipMemcpyAsync(S.d_items.p + items_small.size(), items_large.data(), items_large.size() * sizeof(SegItem),
-                                 hipMemcpyHostToDevice, st));
-    std::vector<PathItem> hpath(paths + 1);
+    const size_t n_items_all = items_small.size() + items_large.size() + items_slow.size();
+    S.d_items.reserve(n_items_all + 1);
+    S.d_bt_exit.reserve((size_t)n_segs * kBtSlots + 1);
+    S.d_bt_steps.reserve((size_t)n_segs * kBtSlots + 1);
+    S.d_bt_entry.reserve(n_segs + 1);
+    S.d_bt_off.reserve(n_segs + 1);
+    S.h2d(S.d_blocks.p, blocks.data(), blocks.size() * sizeof(ColBlock), st);
+    S.h2d(S.d_items.p, items_small.data(), items_small.size() * sizeof(SegItem), st);
+    S.h2d(S.d_items.p + items_small.size(), items_large.data(), items_large.size() * sizeof(SegItem), st);
+    S.h2d(S.d_items.p + items_small.size() + items_large.size(), items_slow.data(), items_slow.size() * sizeof(SegItem), st);
+    const PathItem *hpath = nullptr;  // view into the download arena
     std::vector<PileDev> piles_out(np);
     uint32_t herr[4] = {0, 0, 0, 0};
     // attempt 0 counts links with the small LDS lists; a cell with more distinct links than they hold raises err[0] and the
@@ -864,13 +967,17 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     ka.sums = S.d_sums.p, ka.spec = S.d_spec.p, ka.fin = S.d_fin.p;
     ka.seg_len = k10.seg_len, ka.warm = k10.warm, ka.guard = k10.guard, ka.force_repair = k10.force_repair;
     for (int attempt = 0; attempt < 2; attempt++) {
-        HIP_CHECK(hipMemcpyAsync(S.d_piles.p, piles.data(), np * sizeof(PileDev), hipMemcpyHostToDevice, st));
+        S.reserve_down(np * sizeof(PileDev) + paths * sizeof(PathItem) + 1024, st);
+        S.h2d(S.d_piles.p, piles.data(), np * sizeof(PileDev), st);
         if (attempt) HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
         HIP_CHECK(hipEventRecord(S.evs[2], st));
+        NDGPU_DBG(st, "main: count_links %zu blocks, cells %llu ents %llu segs %u", blocks.size(), (unsigned long long)cells,
+                  (unsigned long long)ents, n_segs);
         launch_count_links(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_blocks.p, S.d_tags.p, S.d_colidx.p, S.d_insmax.p,
                            S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
                            S.d_ent_cnt.p, S.d_err.p, (int)blocks.size(), attempt != 0 || S.k9_full_capacity, st);
         HIP_CHECK(hipEventRecord(S.evs[3], st));
+        NDGPU_DBG(st, "main: score + walk");
         // a sub-batch small enough for the reserved compute units (4 two-wave blocks each) scores there
         const bool on_reserved = S.lat_stream && np <= (size_t)S.reserved_cus * 2;
         hipStream_t sst = on_reserved ? S.lat_stream : st;
@@ -880,18 +987,22 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             HIP_CHECK(hipEventRecord(S.evs[3], sst));
         }
         launch_score_backtrack(ka, S.d_items.p, (int)items_small.size(), S.d_items.p + items_small.size(), (int)items_large.size(),
-                               S.d_ent_score.p, S.d_path.p, (int)np, sst, S.evs[7], on_reserved ? nullptr : S.stream2, S.ev_fork,
+                               S.d_items.p, (int)n_items_all, S.d_ent_score.p, S.d_path.p, S.d_bt_exit.p, S.d_bt_steps.p,
+                               S.d_bt_entry.p, S.d_bt_off.p, (int)np, sst, S.evs[7], on_reserved ? nullptr : S.stream2, S.ev_fork,
                                S.ev_join);
         HIP_CHECK(hipEventRecord(S.evs[4], sst));
+        NDGPU_DBG(st, "main: score + walk done");
         if (on_reserved) {
             HIP_CHECK(hipEventRecord(S.ev_lat1, sst));
             HIP_CHECK(hipStreamWaitEvent(st, S.ev_lat1, 0));
         }
-        HIP_CHECK(hipMemcpyAsync(piles_out.data(), S.d_piles.p, np * sizeof(PileDev), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(hpath.data(), S.d_path.p, paths * sizeof(PathItem), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(herr, S.d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
+        const void *v_piles = S.d2h(nullptr, S.d_piles.p, np * sizeof(PileDev), st);
+        hpath = (const PathItem *)S.d2h(nullptr, S.d_path.p, paths * sizeof(PathItem), st);
+        const void *v_err = S.d2h(nullptr, S.d_err.p, sizeof(herr), st);
         HIP_CHECK(hipStreamSynchronize(st));
         HIP_CHECK(hipGetLastError());
+        memcpy(piles_out.data(), v_piles, np * sizeof(PileDev));
+        memcpy(herr, v_err, sizeof(herr));
         static const bool force_retry = getenv("NDGPU_K9_FORCE_RETRY") != nullptr;  // test hook: take the overflow path
         if ((!herr[0] && !force_retry) || attempt || S.k9_full_capacity) break;
         S.k9_retries++;
@@ -938,7 +1049,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         M.n_aligned = P.n_acc;
         if (bad_pile[p]) continue;
         M.path.resize(P.path_len);
-        const PathItem *src = hpath.data() + P.path_off;
+        const PathItem *src = hpath + P.path_off;
         for (uint32_t k = 0; k < P.path_len; k++) {
             PathStep &d = M.path[k];
             d.t_pos = tag_tpos(src[k].tag);
@@ -958,6 +1069,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
 
 void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
     State &S = *s_;
+    std::unique_lock<std::mutex> dbg_lock;
+    if (g_debug_exclusive) dbg_lock = std::unique_lock<std::mutex>(g_dbg_mu);
     std::lock_guard<std::mutex> lock(S.mu);
     HIP_CHECK(hipSetDevice(S.device));
     hipStream_t st = S.stream;
@@ -981,23 +1094,24 @@ void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
     for (;;) {
         S.d_strpool.reserve(cap);
         cap = S.d_strpool.cap;
-        HIP_CHECK(hipMemcpyAsync(S.d_regions.p, regs.data(), regs.size() * sizeof(RegionDev), hipMemcpyHostToDevice, st));
+        S.h2d(S.d_regions.p, regs.data(), regs.size() * sizeof(RegionDev), st);
         HIP_CHECK(hipMemsetAsync(S.d_cursor.p, 0, sizeof(unsigned long long), st));
         HIP_CHECK(hipEventRecord(S.evs[5], st));
+        NDGPU_DBG(st, "extract: %zu regions", regs.size());
         launch_extract(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_tags.p, S.d_colidx.p, S.d_regions.p, S.d_strpool.p,
                        S.d_cursor.p, (unsigned long long)cap, (int)regs.size(), st);
         HIP_CHECK(hipEventRecord(S.evs[6], st));
         unsigned long long used = 0;
-        HIP_CHECK(hipMemcpyAsync(&used, S.d_cursor.p, sizeof(used), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        S.d2h(&used, S.d_cursor.p, sizeof(used), st);
+        S.sync_drain(st);
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, S.evs[5], S.evs[6]));
         S.stats.extract_ms += ms;
         if (used <= cap) {
             hstr.resize((size_t)used + 1);
-            HIP_CHECK(hipMemcpyAsync(regs.data(), S.d_regions.p, regs.size() * sizeof(RegionDev), hipMemcpyDeviceToHost, st));
-            if (used) HIP_CHECK(hipMemcpyAsync(hstr.data(), S.d_strpool.p, (size_t)used, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
+            S.d2h(regs.data(), S.d_regions.p, regs.size() * sizeof(RegionDev), st);
+            if (used) S.d2h(hstr.data(), S.d_strpool.p, (size_t)used, st);
+            S.sync_drain(st);
             break;
         }
         cap = (size_t)used + ((size_t)16 << 20);  // pool too small: rerun with the exact size

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 
 #include "nd_device.h"
 
@@ -824,11 +826,15 @@ __device__ void score_range(K10Smem<CELLS, ENTS> &S, const K10Args &A, const Pil
                 }
             }
             // the scores of the two columns the stitch compares
-            if (p < L && (p + 1u == L || (mode == 1 && p + 1u == c0))) {
+            if (p + 1u == L) {
                 __builtin_amdgcn_wave_barrier();
-                int32_t *dst = (p + 1u == L ? A.fin : A.spec) + (size_t)sidx * (size_t)kColEnts;
+                int32_t *dst = A.fin + (size_t)sidx * (size_t)kColEnts;
                 for (uint32_t e = (uint32_t)lane; e < nent; e += 64) dst[e] = (int32_t)cur.ps[e].y;
-                if (p + 1u == L && lane == 0) S.r_nfin = nent;
+                if (lane == 0) S.r_nfin = nent;
+            } else if (mode == 1 && p + 1u == c0) {
+                __builtin_amdgcn_wave_barrier();
+                int32_t *dst = A.spec + (size_t)sidx * (size_t)kColEnts;
+                for (uint32_t e = (uint32_t)lane; e < nent; e += 64) dst[e] = (int32_t)cur.ps[e].y;
             }
         } else if (p > first && p - 1u >= c0) {
             const uint32_t q = p - 1u, slot = q % 3u, sl = q & 1u;
@@ -961,7 +967,7 @@ __global__ __launch_bounds__(192) void score_stitch_kernel(const K10Args A) {
     __shared__ uint32_t sh_enc, sh_i, sh_fail, sh_flags, sh_links, sh_repairs, sh_seg;
     __shared__ int sh_last;
     PileDev &P = A.piles[blockIdx.x];
-    if (REDO != (P.err == 3) || P.err == 2) return;  // the column scan chose the tier of every pile; 2: HBM-resident kernel
+    if (REDO != (P.tier != 0u) || P.err == 2) return;  // the column scan chose the tier of every pile; 2: HBM-resident kernel
     const int wave = (int)(threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t n_seg = P.n_seg, sg = A.seg_len;
@@ -998,6 +1004,7 @@ __global__ __launch_bounds__(192) void score_stitch_kernel(const K10Args A) {
     // pass 2: offsets in segment order, 64 segments per round; the first segment that fails a check is repaired
     for (;;) {
         const uint32_t i0 = sh_i;
+        __syncthreads();  // every wavefront has read sh_i before wavefront 0 moves it on
         if (i0 >= n_seg) break;
         if (wave == 0) {
             const uint32_t seg = i0 + (uint32_t)lane;
@@ -1137,7 +1144,7 @@ __global__ __launch_bounds__(192) void score_stitch_kernel(const K10Args A) {
         }
     }
     if (threadIdx.x == 0) {
-        if (REDO) P.err = 0;
+        P.err = 0;
         P.origin_t = o_t;
         P.origin_db = o_db;
         P.n_links = sh_links;
@@ -1241,75 +1248,135 @@ __global__ __launch_bounds__(64) void score_slow_kernel(
     }
 }
 
-// best_pp walk from the origin (lib/nextcorrect.c:1907-1982 visits exactly these cells).  One wavefront per
-// pile: the walk is a pointer chase (each step needs the cell the previous one named), so the 64 columns below
-// the current one are staged in LDS with coalesced loads -- cell base, coverage and the (best_pp, best_link) of
-// the six delta-0 cells -- and the chase runs out of LDS; only insertion cells (delta > 0) go to HBM.
-__global__ __launch_bounds__(64) void backtrack_kernel(PileDev *__restrict__ piles, const uint32_t *__restrict__ coverage,
-                                                        const uint32_t *__restrict__ cell_base,
-                                                        const uint32_t *__restrict__ cell_best_pp,
-                                                        const uint32_t *__restrict__ cell_best_link,
-                                                        PathItem *__restrict__ path, int n_piles) {
-    __shared__ uint32_t s_cb[64], s_cov[64], s_bpp[64 * 6], s_blk[64 * 6];
-    const int i = (int)blockIdx.x;
-    if (i >= n_piles) return;
-    const int lane = (int)threadIdx.x;
-    PileDev &P = piles[i];
-    const uint32_t *cov = coverage + P.col_off;
-    const uint32_t *cb = cell_base + P.col_off;
-    const uint32_t *bpp = cell_best_pp + P.cell_off;
-    const uint32_t *blk = cell_best_link + P.cell_off;
-    PathItem *out = path + P.path_off;
-    const uint32_t cap = P.n_cells / 6u;
-    uint32_t len = 0;
-    int32_t t = P.origin_t;
-    uint32_t db = P.origin_db;
-    while (t >= 0 && len < cap) {
-        const int32_t hi = t, lo = t > 63 ? t - 63 : 0;
-        {
-            const int32_t c = hi - lane;
-            if (c >= lo) {
-                const uint32_t base = cb[c];
-                s_cb[lane] = base;
-                s_cov[lane] = cov[c];
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    s_bpp[lane * 6 + k] = bpp[base + k];
-                    s_blk[lane * 6 + k] = blk[base + k];
-                }
-            }
-        }
-        __syncthreads();
-        while (t >= lo && len < cap) {
-            const int rel = hi - t;
-            const uint32_t dl = db >> 3, bs = db & 7u;
-            uint32_t g, lk;
-            if (dl == 0) {
-                g = s_bpp[rel * 6 + (int)bs];
-                lk = s_blk[rel * 6 + (int)bs];
-            } else {
-                const uint32_t cell = s_cb[rel] + dl * 6u + bs;
-                g = bpp[cell];
-                lk = blk[cell];
-            }
-            if (lane == 0) {
-                PathItem it;
-                it.tag = tag_pack(t, dl, bs);
-                it.link = (uint16_t)lk;
-                it.cov = (uint16_t)s_cov[rel];
-                out[len] = it;
-            }
-            len++;
-            if (g == kTagHead) {
-                t = -1;
-                break;
-            }
-            t = tag_tpos(g);
-            db = g & 0x7ffu;
-        }
-        __syncthreads();
+// best_pp walk from the origin (lib/nextcorrect.c:1907-1982 visits exactly these cells).  The walk is a pointer chase
+// (each step needs the cell the previous one named) of one step per consensus position, so -- like the scoring DP -- it is
+// cut at the scoring segments and done in three passes:
+//   bt_spec   one workgroup per (pile, segment): where does the walk leave the segment, and after how many steps, for EVERY
+//             cell of the segment's last column it could enter through (one lane per cell; the chases are independent, so
+//             their memory latencies overlap); the segment that holds the origin walks from the origin instead;
+//   bt_stitch one lane per pile chains the segments from the origin's downwards: entry cell, step count, output offset;
+//   bt_emit   one lane per (pile, segment) repeats its segment's walk from the now known entry and writes the path items.
+// A walk's state is the packed tag of the current cell (t_pos + 1, delta, base), exactly what best_pp stores.
+constexpr uint32_t kBtCand = 192;        // entry cells tabulated per segment (6 x 32 deltas); wider last columns: see bt_stitch
+constexpr uint32_t kBtUnspec = 0xffffffffu;
+static_assert(kBtCand == (uint32_t)kBtSlots && kSegEnts == kColEnts, "host-side buffer sizes");
+
+struct BtWalk {
+    const uint32_t *cb, *bpp;
+    // one step: cell of tag g -> its best_pp
+    __device__ __forceinline__ uint32_t next(uint32_t g) const {
+        const uint32_t t = (uint32_t)tag_tpos(g);
+        return bpp[cb[t] + (g & 0x7ffu) - ((g & 0x7ffu) >> 3) * 2u];  // delta * 6 + base = (delta << 3 | base) - 2 * delta
     }
-    if (lane == 0) P.path_len = len;
+};
+
+__global__ __launch_bounds__(192) void bt_spec_kernel(const PileDev *__restrict__ piles, const SegItem *__restrict__ items,
+                                                       const uint32_t *__restrict__ max_size, const uint32_t *__restrict__ cell_base,
+                                                       const uint32_t *__restrict__ cell_best_pp, uint32_t seg_len,
+                                                       uint32_t *__restrict__ bt_exit, uint32_t *__restrict__ bt_steps) {
+    const SegItem it = items[blockIdx.x];
+    const PileDev &P = piles[it.pile];
+    if (P.origin_t < 0) return;
+    const uint32_t c0 = it.seg * seg_len, c1 = it.seg + 1u == P.n_seg ? P.seed_len : c0 + seg_len;
+    const uint32_t ot = (uint32_t)P.origin_t;
+    if (ot < c0) return;  // the walk starts below this segment
+    const size_t sidx = (size_t)(P.seg_off + it.seg);
+    BtWalk W{cell_base + P.col_off, cell_best_pp + P.cell_off};
+    uint32_t *ex = bt_exit + sidx * kBtCand, *stp = bt_steps + sidx * kBtCand;
+    if (ot < c1) {  // the origin's segment: one walk, from the origin, result in slot 0
+        if (threadIdx.x == 0) {
+            uint32_t g = tag_pack((int32_t)ot, P.origin_db >> 3, P.origin_db & 7u), n = 0;
+            do {
+                g = W.next(g);
+                n++;
+            } while (g != kTagHead && (uint32_t)tag_tpos(g) >= c0);
+            ex[0] = g, stp[0] = n;
+        }
+        return;
+    }
+    const uint32_t ncell = (max_size + P.col_off)[c1 - 1u] * 6u;
+    if (ncell > kBtCand) {  // too many entry cells to tabulate: bt_stitch walks this segment itself
+        if (threadIdx.x == 0) stp[0] = kBtUnspec;
+        return;
+    }
+    const uint32_t r = threadIdx.x;
+    if (r < ncell && r % 6u < 5u) {
+        uint32_t g = tag_pack((int32_t)(c1 - 1u), r / 6u, r % 6u), n = 0;
+        do {
+            g = W.next(g);
+            n++;
+        } while (g != kTagHead && (uint32_t)tag_tpos(g) >= c0);
+        ex[r] = g, stp[r] = n;
+    }
+}
+
+__global__ __launch_bounds__(64) void bt_stitch_kernel(PileDev *__restrict__ piles, const uint32_t *__restrict__ cell_base,
+                                                        const uint32_t *__restrict__ cell_best_pp, uint32_t seg_len,
+                                                        const uint32_t *__restrict__ bt_exit, const uint32_t *__restrict__ bt_steps,
+                                                        uint32_t *__restrict__ bt_entry, uint32_t *__restrict__ bt_off, int n_piles) {
+    const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (i >= n_piles) return;
+    PileDev &P = piles[i];
+    uint32_t *entry = bt_entry + P.seg_off, *off = bt_off + P.seg_off;
+    for (uint32_t s_ = 0; s_ < P.n_seg; s_++) entry[s_] = kTagHead;  // segments the walk does not visit emit nothing
+    if (P.origin_t < 0) {
+        P.path_len = 0;
+        return;
+    }
+    BtWalk W{cell_base + P.col_off, cell_best_pp + P.cell_off};
+    uint32_t seg = (uint32_t)P.origin_t / seg_len;
+    if (seg >= P.n_seg) seg = P.n_seg - 1u;  // the last segment takes the remainder
+    uint32_t g = tag_pack(P.origin_t, P.origin_db >> 3, P.origin_db & 7u), len = 0, slot = 0;
+    for (;;) {
+        const size_t sidx = (size_t)(P.seg_off + seg);
+        entry[seg] = g;
+        off[seg] = len;
+        uint32_t n = 0, gx;
+        if (slot >= kBtCand || bt_steps[sidx * kBtCand] == kBtUnspec) {  // not tabulated: walk it here
+            const uint32_t c0 = seg * seg_len;
+            gx = g, n = 0;
+            do {
+                gx = W.next(gx);
+                n++;
+            } while (gx != kTagHead && (uint32_t)tag_tpos(gx) >= c0);
+        } else {
+            gx = bt_exit[sidx * kBtCand + slot];
+            n = bt_steps[sidx * kBtCand + slot];
+        }
+        len += n;
+        if (gx == kTagHead || seg == 0) break;
+        g = gx;
+        seg--;
+        slot = tag_delta(g) * 6u + tag_base(g);
+    }
+    P.path_len = len;
+}
+
+__global__ __launch_bounds__(64) void bt_emit_kernel(const PileDev *__restrict__ piles, const SegItem *__restrict__ items, int n_items,
+                                                      const uint32_t *__restrict__ coverage, const uint32_t *__restrict__ cell_base,
+                                                      const uint32_t *__restrict__ cell_best_pp, const uint32_t *__restrict__ cell_best_link,
+                                                      uint32_t seg_len, const uint32_t *__restrict__ bt_entry,
+                                                      const uint32_t *__restrict__ bt_off, PathItem *__restrict__ path) {
+    const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (i >= n_items) return;
+    const SegItem it = items[i];
+    const PileDev &P = piles[it.pile];
+    uint32_t g = bt_entry[P.seg_off + it.seg];
+    if (g == kTagHead) return;
+    const uint32_t c0 = it.seg * seg_len;
+    const uint32_t *cb = cell_base + P.col_off, *cov = coverage + P.col_off;
+    const uint32_t *bpp = cell_best_pp + P.cell_off, *blk = cell_best_link + P.cell_off;
+    PathItem *out = path + P.path_off + bt_off[P.seg_off + it.seg];
+    do {
+        const uint32_t t = (uint32_t)tag_tpos(g);
+        const uint32_t cell = cb[t] + tag_delta(g) * 6u + tag_base(g);
+        PathItem pi;
+        pi.tag = g;
+        pi.link = (uint16_t)blk[cell];
+        pi.cov = (uint16_t)cov[t];
+        *out++ = pi;
+        g = bpp[cell];
+    } while (g != kTagHead && (uint32_t)tag_tpos(g) >= c0);
 }
 
 // ---- K11 -------------------------------------------------------------------------
@@ -1429,10 +1496,20 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
 }
 
 void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_small, const SegItem *items_large, int n_large,
-                            long long *ent_score, PathItem *path, int n_piles, void *stream, void *ev_after_fast,
-                            void *stream_large, void *ev_fork, void *ev_join) {
+                            const SegItem *items_all, int n_all, long long *ent_score, PathItem *path, uint32_t *bt_exit,
+                            uint32_t *bt_steps, uint32_t *bt_entry, uint32_t *bt_off, int n_piles, void *stream,
+                            void *ev_after_fast, void *stream_large, void *ev_fork, void *ev_join) {
     if (n_piles <= 0) return;
     hipStream_t st = (hipStream_t)stream;
+    static const bool dbg = getenv("NDGPU_DEBUG_LAUNCH") != nullptr;
+    auto mark = [&](const char *what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(st);
+        if (stream_large) (void)hipStreamSynchronize((hipStream_t)stream_large);
+        fprintf(stderr, "[ndgpu dbg %p] k10: %s (small %d large %d all %d piles %d)\n", (void *)st, what, n_small, n_large, n_all, n_piles);
+        fflush(stderr);
+    };
+    mark("begin");
     const bool forked = n_large > 0 && stream_large && stream_large != stream;
     if (n_large > 0) {  // the piles that need the large tables are scored at the same time on a second stream
         hipStream_t s2 = forked ? (hipStream_t)stream_large : st;
@@ -1444,16 +1521,30 @@ void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_
         hipLaunchKernelGGL((score_stitch_kernel<kColCells, kColEnts, true>), dim3((unsigned)n_piles), dim3(192), 0, s2, a);
         if (forked) (void)hipEventRecord((hipEvent_t)ev_join, s2);
     }
+    mark("large tier launched");
     if (n_small > 0)
         hipLaunchKernelGGL((score_seg_kernel<kColCellsSmall, kColEntsSmall>), dim3((unsigned)n_small), dim3(192), 0, st, a, items_small);
+    mark("small seg done");
     hipLaunchKernelGGL((score_stitch_kernel<kColCellsSmall, kColEntsSmall, false>), dim3((unsigned)n_piles), dim3(192), 0, st, a);
+    mark("small stitch done");
     if (forked) (void)hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0);
     if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
     hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, a.piles, a.coverage, a.max_size,
                        a.cell_base, a.cell_start, a.cell_len, a.ent_pp, a.ent_ppp, a.ent_cnt, ent_score, a.cell_best_pp,
                        a.cell_best_link);
-    hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, a.piles, a.coverage,
-                       a.cell_base, a.cell_best_pp, a.cell_best_link, path, n_piles);
+    mark("slow done");
+    // best_pp walk: every item of both lists (the segments of all piles the scoring kernels handled), plus the piles of
+    // the int64 kernel, whose segments are in `items_all` too
+    if (n_all > 0) {
+        hipLaunchKernelGGL(bt_spec_kernel, dim3((unsigned)n_all), dim3(192), 0, st, a.piles, items_all, a.max_size, a.cell_base,
+                           a.cell_best_pp, a.seg_len, bt_exit, bt_steps);
+        mark("bt_spec done");
+        hipLaunchKernelGGL(bt_stitch_kernel, dim3((unsigned)((n_piles + 63) / 64)), dim3(64), 0, st, a.piles, a.cell_base,
+                           a.cell_best_pp, a.seg_len, bt_exit, bt_steps, bt_entry, bt_off, n_piles);
+        mark("bt_stitch done");
+        hipLaunchKernelGGL(bt_emit_kernel, dim3((unsigned)((n_all + 63) / 64)), dim3(64), 0, st, a.piles, items_all, n_all, a.coverage,
+                           a.cell_base, a.cell_best_pp, a.cell_best_link, a.seg_len, bt_entry, bt_off, path);
+    }
 }
 
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,

@@ -101,7 +101,7 @@ struct PileDev {
     uint32_t seg_off;       // index of the pile's first segment record
     uint32_t n_seg;
     uint32_t n_repair;      // segments the stitch kernel scored again (written by it)
-    uint32_t pad_;
+    uint32_t tier;          // 1: scored with the large LDS tables (the column scan's verdict, fixed for the launch)
 };
 
 // ---- scoring DP (K10), segment-parallel: see the head comment of the K10 section in msa_kernels.hip ----
@@ -180,9 +180,13 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
                         void *stream);
 // segment kernels of both table tiers (the large one on stream_large at the same time) -> stitch -> int64 kernel for
 // the piles they left (err == 2) -> best_pp walk
+// then the best_pp walk, cut at the same segments: items_all = every (pile, segment) of the launch, bt_exit / bt_steps =
+// kBtSlots entries per segment, bt_entry / bt_off = one per segment
 void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_small, const SegItem *items_large, int n_large,
-                            long long *ent_score, PathItem *path, int n_piles, void *stream, void *ev_after_fast,
-                            void *stream_large, void *ev_fork, void *ev_join);
+                            const SegItem *items_all, int n_all, long long *ent_score, PathItem *path, uint32_t *bt_exit,
+                            uint32_t *bt_steps, uint32_t *bt_entry, uint32_t *bt_off, int n_piles, void *stream,
+                            void *ev_after_fast, void *stream_large, void *ev_fork, void *ev_join);
+constexpr int kBtSlots = 192;
 void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *acc_list, const uint32_t *tags,
                     const uint32_t *colidx, RegionDev *regions, char *strpool, unsigned long long *strpool_cursor,
                     unsigned long long strpool_cap, int n_regions, void *stream);
