@@ -1,26 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- corrected bases / s of the MI355X read-correction hot path.
 
-One "step" = one full pass of the correction hot path over a synthetic read set that is resident in HBM:
-  (1) overlap stage (`minimap2-nd --step 1` path): minimizer sketch, index, seeds, anchor sort, chain DP, hits of
-      the all-vs-all job;
-  (2) sort stage (`ovl_sort` path): both directions of every overlap, (seed, match, span) order, coverage-bin
-      admission and chimera trimming per seed, `.bl` verdicts -- then the pile admission rules of
-      lib/nextcorrect.py:92-143 on the host (vectorised);
-  (3) consensus stage (`nextcorrect` path): every pile that came out of (2) -- O(ND) alignments -> MSA -> scoring DP
-      -> consensus.
-`value` = corrected bases / wall time of (1) + (2) + (3): the whole raw_align -> sort_align -> seed_cns chain of the
-reference, with no file in between.  Each stage is checked byte-for-byte against the reference in tests/
-(`--no-overlap` / `--analytic-piles` run stage (3) on piles derived from the true read positions instead).
+One "step" = one full pass of the correction stage over a synthetic read set whose 2-bit reads are resident in HBM:
+  (1) overlap stage (`minimap2-nd --step 1` path): minimizer sketch, index, seeds, anchor sort, chain DP, hits of every
+      raw_align job of the rank's seed file (nextDenovo:426-467);
+  (2) sort stage (`ovl_sort` path): both directions of every overlap, (seed, match, span) order, coverage-bin admission and
+      chimera trimming per seed, `.bl` verdicts -- then the pile admission rules of lib/nextcorrect.py:92-143;
+  (3) consensus stage (`nextcorrect` path): every pile that came out of (2) -- O(ND) alignments -> MSA -> scoring DP ->
+      consensus.
+`value` = corrected bases / wall time of (1) + (2) + (3): the whole raw_align -> sort_align -> seed_cns chain of the reference
+with no file in between.  Each stage is checked byte-for-byte against the reference in tests/, and the run itself compares the
+records of its CPU-sample piles with the compiled reference (`parity`).
 
-Workload (BASELINE.json configs[1]): synthetic E. coli-sized genome 4.6 Mb, 50x
-ONT-profile reads (lognormal, N50 ~ 20-25 kb, sub 3 % / ins 4 % / del 5 %), seed_cutoff 1k (every read is a seed),
-`-x ava-ont`, `ovl_sort -k 40` (nextdenovo_amd/synth.py generates the reads).
+Workloads = BASELINE.json configs, `--config N`:
+  2 (default)  E. coli-like 4.6 Mb, 50x ONT, N50 ~ 20 kb, seed_cutoff 1k, -x ava-ont, ovl_sort -k 40
+  3            D. melanogaster-like 140 Mb with 20 % interspersed repeats, 40x ONT (large pile depth)
+  4            A. thaliana-like 120 Mb, 60x PacBio CLR, -x ava-pb
+  5            human chr1-like 250 Mb with 45 % repeats, 30x ultra-long ONT (N50 ~ 100 kb, <= 1 Mb)
+(nextdenovo_amd/synth.py generates the reads; configs 3-5 on all host cores.)
 
-Launch contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
-started by torch.distributed.run with one rank per GPU.  Piles shard across ranks
-with no data-path collective (every rank corrects its own read set: weak scaling);
-RCCL is used only for the final corrected-base-count / max-time reduction.
+Sharding = the reference's own (nextdenovo_amd/stage.py): seeds are dealt round robin into `seed_cutfiles` seed files
+(util/seq_dump.c:87-92) and a seed file is corrected from the overlaps between its seeds and every read.  `--gpus N` makes
+N seed files of ONE read set and gives seed file r to rank r (strong scaling: the total work is fixed); no rank needs
+anything another rank computed, RCCL carries only the final {corrected bases, seeds, wall time} reduction.
+`--seed-files M` on one GPU corrects seed file `--shard` of M: the single-GPU share of an M-GPU run (how configs 4 and 5,
+which BASELINE.json places on 8 GPUs, are run on the one MI355X at hand).
+
+Launch contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 started by torch.distributed.run, one rank per GPU.
 """
 from __future__ import annotations
 
@@ -36,21 +42,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-size", type=float, default=4.6e6)
-    ap.add_argument("--depth", type=float, default=50.0)
-    ap.add_argument("--profile", default="ont")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[N-1]")
+    ap.add_argument("--seed-files", type=int, default=0, help="seed_cutfiles (default: the number of GPUs)")
+    ap.add_argument("--shard", type=int, default=0, help="with one GPU and --seed-files M: which seed file to correct")
+    ap.add_argument("--genome-size", type=float, default=0, help="override: uniform random genome of this size")
+    ap.add_argument("--depth", type=float, default=0)
+    ap.add_argument("--profile", default="")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="consensus stage only, on analytically derived piles")
     ap.add_argument("--analytic-piles", action="store_true",
                     help="run the overlap stage but feed the consensus stage with piles derived from the true read positions")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ---- CPU baseline leg (the ONLY place bench.py touches oracle/) ---------------------------------
@@ -87,7 +96,7 @@ def _ref_worker(item):
     return ln, bits, digest, ide
 
 
-def cpu_baseline(rs, piles, read_type, n_sample, n_longest=16):
+def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16):
     """Reference CPU path on a bounded sample of the same workload, all sample piles in
     flight over a fork pool of `cores` workers (the reference's own parallelism model).
     The sample = every k-th pile + the `n_longest` longest seeds (where the device's wide tables, its int32
@@ -96,7 +105,7 @@ def cpu_baseline(rs, piles, read_type, n_sample, n_longest=16):
     from multiprocessing import get_context
     from nextdenovo_amd import synth
     ref_so = os.path.join(ROOT, "oracle", "_ref", "nextcorrect.so")
-    if not os.path.exists(ref_so):
+    if not os.path.exists(ref_so) or not piles:
         return None, {}
     cores = max(1, min(os.cpu_count() or 1, 64))
     if n_sample <= 0:
@@ -108,7 +117,7 @@ def cpu_baseline(rs, piles, read_type, n_sample, n_longest=16):
 
     def item(i):
         seqs, st, en, mal = synth.pile_sequences(rs, piles[i])
-        return (seqs, st, en, mal, min(en[0] // 2, 10000), read_type)
+        return (seqs, st, en, mal, min(en[0] // 2, max_lq), read_type)
 
     items = [item(i) for i in idx]
     ctx = get_context("fork")
@@ -128,10 +137,14 @@ def cpu_baseline(rs, piles, read_type, n_sample, n_longest=16):
 
 def parity_block(ref, gpu_full, piles):
     """Compare the device's records of the CPU-sample piles (taken from a whole-batch call, the very call shape
-    the timed steps make) with the compiled reference's: length, float32 identity bits, md5 of the bases."""
-    bad = []
+    the timed steps make) with the compiled reference's: length, float32 identity bits, md5 of the bases.  Seeds the
+    reference itself could not hold in memory (its len 3, lib/nextcorrect.c:2254-2261) are counted, not compared."""
+    bad, ref_oom = [], 0
     for i, (ln, bits, digest) in sorted(ref.items()):
         g_ln, g_ide, g_seq = gpu_full[i]
+        if ln == 3:
+            ref_oom += 1
+            continue
         if ln > 4 or g_ln > 4:
             g_bits = struct.unpack("<I", struct.pack("<f", g_ide))[0] if g_ln > 4 else 0
             g_dig = hashlib.md5(g_seq).hexdigest() if g_ln > 4 else ""
@@ -141,10 +154,12 @@ def parity_block(ref, gpu_full, piles):
         if not same:
             bad.append({"pile": i, "seed": int(piles[i]["seed"]), "ref_len": ln, "gpu_len": g_ln})
     lens = [int(piles[i]["recs"][0][3]) + 1 for i in ref]
+    depth = [int(piles[i]["recs"].shape[0]) for i in ref]
     return {"piles": len(ref), "mismatch": len(bad), "against": "oracle/_ref/nextcorrect.so (compiled reference)",
             "compared": "len, float32 identity bits, md5(seq)", "longest_seed": max(lens) if lens else 0,
-            "seeds_ge_100kb": sum(1 for x in lens if x >= 100000), "error_seeds": sum(1 for v in ref.values() if v[0] <= 4),
-            "mismatches": bad[:8]}
+            "seeds_ge_100kb": sum(1 for x in lens if x >= 100000), "deepest_pile": max(depth) if depth else 0,
+            "error_seeds": sum(1 for v in ref.values() if v[0] <= 4), "reference_out_of_memory_seeds": ref_oom,
+            "device_out_of_memory_seeds": sum(1 for i in ref if gpu_full[i][0] == 3), "mismatches": bad[:8]}
 
 
 def cpu_baseline_overlap(rs_dev, preset):
@@ -174,14 +189,51 @@ def cpu_baseline_overlap(rs_dev, preset):
                       % (len(rs_dev), bases, cores, preset)}
 
 
-def reduce_over_ranks(dist, torch, bases: int, dt: float, device):
-    """The path's only collective: sum of corrected bases, max of wall
+def reduce_over_ranks(dist, torch, bases: int, dt: float, device, seeds: int = 0):
+    """The path's only collective: sum of corrected bases (and corrected seeds), max of wall
     time.  RCCL over xGMI on the GPU box ("nccl" backend), gloo in the CPU tests."""
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    b = torch.tensor([bases], dtype=torch.int64, device=device)
+    b = torch.tensor([bases, seeds], dtype=torch.int64, device=device)
     dist.all_reduce(b, op=dist.ReduceOp.SUM)
-    return int(b.item()), float(t.item())
+    reduce_over_ranks.seeds = int(b[1].item())
+    return int(b[0].item()), float(t.item())
+
+
+def shard_of_rank(world: int, rank: int, seed_files: int, shard: int):
+    """(seed_cutfiles, the seed file this rank corrects): rank r of N takes seed file r of N; one GPU with --seed-files M
+    takes seed file --shard of M."""
+    if world > 1:
+        return world, rank
+    m = max(1, seed_files)
+    return m, shard % m
+
+
+def make_workload(args):
+    """(name, ReadSet, words, word_off, lens, preset, read_type, max_lq_length, sort -k, genome size, depth, profile):
+    the same read set on every rank."""
+    from nextdenovo_amd import synth
+    cfg = dict(synth.CONFIGS[args.config])
+    custom = bool(args.genome_size or args.depth or args.profile)
+    depth = args.depth or cfg["depth"]
+    profile = args.profile or cfg["profile"]
+    if custom:
+        gs = int(args.genome_size or 4.6e6)
+        genome = synth.make_genome(gs, seed=42)
+        name = "synthetic uniform %.2f Mb, %gx %s reads (lognormal mu %.2f sigma %.2f)" % (gs / 1e6, depth, profile, cfg["mu"], cfg["sigma"])
+    else:
+        genome = cfg["genome"]()
+        name = cfg["name"]
+    if args.config == 2:  # the round-1 read set, generated in one stream
+        rs = synth.simulate_reads(genome, depth, profile, seed=43, mu=cfg["mu"], sigma=cfg["sigma"], max_len=cfg["max_len"])
+        words, word_off, lens = synth.pack_db(rs)
+    else:
+        rs, words, word_off, lens = synth.simulate_reads_mp(genome, depth, profile, 43 + args.config, cfg["mu"], cfg["sigma"], cfg["max_len"])
+    d = int(round(depth))
+    sort_k = (d - 2) if d <= 30 else min(d - 5, 40)  # lib/config_parser.py:44
+    preset = "ava-hifi" if profile == "hifi" else "ava-ont" if profile == "ont" else "ava-pb"
+    max_lq = cfg["max_lq"] if not args.profile else (10000 if profile == "ont" else 1000)  # lib/config_parser.py:217-221
+    return name, rs, words, word_off, lens, preset, {"ont": 1, "clr": 2, "hifi": 3}[profile], max_lq, sort_k, genome.size, depth, profile
 
 
 def main():
@@ -193,7 +245,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
-    from nextdenovo_amd import api, synth
+    from nextdenovo_amd import api, stage, synth
 
     dist = None
     torch = None
@@ -203,136 +255,95 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    read_type = {"ont": 1, "clr": 2, "hifi": 3}[args.profile]
     analytic = args.analytic_piles or args.no_overlap
     if args.host_threads <= 0:  # the ranks of one node share its cores
         args.host_threads = max(8, (os.cpu_count() or 8) // max(1, world))
     t_gen = time.perf_counter()
-    genome = synth.make_genome(int(args.genome_size), seed=42 + 1000 * rank)
-    rs = synth.simulate_reads(genome, args.depth, args.profile, seed=43 + 1000 * rank)
-    piles = synth.build_piles(rs, seed_cutoff=1000) if analytic else []
-    recs, pile_off = synth.flatten_piles(piles) if analytic else (None, None)
-    words, word_off, lens = synth.pack_db(rs)
+    name, rs, words, word_off, lens, preset, read_type, max_lq, sort_k, genome_size, depth, profile = make_workload(args)
+    n_files, my_file = shard_of_rank(world, rank, args.seed_files or world, args.shard)
     t_gen = time.perf_counter() - t_gen
 
-    db = api.ReadDB(words, word_off, lens)  # reads resident in HBM from here on
-
-    # overlap + sort stages: the same reads as a .2bit-layout set (read id = index in the DB), all-vs-all; every read is
-    # a seed (seed_cutoff 1k <= shortest read), so the run is the single `seed x seed` job of nextDenovo:456-464
-    ovl_state = None
-    if not args.no_overlap:
-        from nextdenovo_amd import overlap
-        preset = "ava-ont" if args.profile == "ont" else "ava-pb"
-        n_r = len(rs)
-        rs_dev = overlap.ReadSet(np.arange(n_r, dtype=np.uint32), lens, words, word_off)
-        depth = int(round(args.depth))
-        ovl_state = {"opt": overlap.preset(preset), "set": rs_dev, "preset": preset, "stats": None, "bytes": 0, "recs": 0,
-                     "wall": 0.0, "sort_wall": 0.0, "asm_wall": 0.0, "sort_stats": None,
-                     "k": (depth - 2) if depth <= 30 else min(depth - 5, 40),  # lib/config_parser.py:44
-                     "seed_len": lens.astype(np.uint32), "min_seed": int(lens.min()), "last": None}
-
-    def overlap_step():
-        """one `minimap2-nd --step 1 seed seed` job (index, map) and, in pipeline mode, `ovl_sort` + the pile assembly
-        of lib/nextcorrect.py:92-143 on its records"""
-        from nextdenovo_amd import nextcorrect as nc, overlap
-        t0 = time.perf_counter()
-        with overlap.Index(ovl_state["opt"], ovl_state["set"]) as ix:
-            raw = ix.map(ovl_state["set"], ix.mid_occ())
-            st = ix.stats()
-        ovl_state["recs"] = int(raw.size)
-        if analytic:  # stand-alone overlap job: the records are encoded as the .ovl file would be
-            ovl_state["bytes"] = len(overlap.encode(raw, np.zeros(2, dtype=np.uint32)))
-        t1 = time.perf_counter()
-        ovl_state["wall"] += t1 - t0
-        if ovl_state["stats"] is None:
-            ovl_state["stats"] = st
-        else:
-            for k, v in st.items():
-                ovl_state["stats"][k] += v
-        if analytic:
-            return None
-        srt, bl, sst = overlap.sort_overlaps([raw], ovl_state["seed_len"], ovl_state["min_seed"], ovl_state["k"], 300)
-        t2 = time.perf_counter()
-        skip = [i for i, kind in bl]  # the .bl blacklist is honoured as lib/nextcorrect.py does by default
-        sub, off, seeds = overlap.assemble_piles(srt, ovl_state["seed_len"].size, 500, 500, 130, 10, skip)
-        t3 = time.perf_counter()
-        ovl_state["sort_wall"] += t2 - t1
-        ovl_state["asm_wall"] += t3 - t2
-        ovl_state["sort_stats"] = sst
-        ovl_state["last"] = (sub, off, seeds, len(bl))
-        return sub, off
+    db = api.ReadDB(words, word_off, lens)  # every read, both strands, resident in HBM from here on
+    sh = stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k)
+    a_piles = a_recs = a_off = None
+    if analytic:  # piles from the true read positions, for the seeds of this rank's seed file
+        a_piles = synth.build_piles(rs, seed_cutoff=1000, seed_ids=[int(i) for i in sh.seed_ids[my_file]])
+        a_recs, a_off = synth.flatten_piles(a_piles)
+    last = {}
+    cns_wall = [0.0]
 
     def sync():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    cns_wall = [0.0]
-
     def step():
-        r_, o_ = recs, pile_off
-        if ovl_state is not None:
-            got = overlap_step()
-            if got is not None:
-                r_, o_ = got
+        if args.no_overlap:
+            r_, o_ = a_recs, a_off
+        else:
+            sub, off, seeds, n_bl = sh.piles(my_file)
+            last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
+            r_, o_ = (a_recs, a_off) if analytic else (sub, off)
         t_c = time.perf_counter()
-        res = db.correct_piles(r_, o_, read_type=read_type, host_threads=args.host_threads, lengths_only=True)
+        res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads, lengths_only=True)
         cns_wall[0] += time.perf_counter() - t_c
         # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
-        return sum(ln for ln, ide in res if ln >= 500 and ln > 4 and ide >= 0.8)
+        ok = [ln for ln, ide in res if ln >= 500 and ln > 4 and ide >= 0.8]
+        return sum(ok), len(ok)
 
     for _ in range(args.warmup):
         step()
     cns_wall[0] = 0.0
     api.reset_stats()
-    if ovl_state is not None:
-        ovl_state["stats"], ovl_state["wall"], ovl_state["sort_wall"], ovl_state["asm_wall"] = None, 0.0, 0.0, 0.0
+    for k in sh.stats:
+        sh.stats[k] = 0
     sync()
     t0 = time.perf_counter()
-    bases = 0
+    bases = n_ok = 0
     for _ in range(args.steps):
-        bases += step()
+        b, n = step()
+        bases += b
+        n_ok += n
     sync()
     dt = time.perf_counter() - t0
     st = api.stats()
 
-    total_bases = bases
-    max_dt = dt
+    total_bases, max_dt, total_seeds = bases, dt, n_ok
     if dist is not None:
-        total_bases, max_dt = reduce_over_ranks(dist, torch, bases, dt, "cuda")
+        total_bases, max_dt = reduce_over_ranks(dist, torch, bases, dt, "cuda", n_ok)
+        total_seeds = reduce_over_ranks.seeds
 
     if rank == 0:
-        if not analytic:  # the piles the last step really corrected (for the config line and the CPU sample)
-            sub, off, seeds, n_bl = ovl_state["last"]
-            piles = [{"seed": int(seeds[i]), "recs": sub[int(off[i]):int(off[i + 1])]} for i in range(seeds.size)]
-            recs = sub
-        # Roofline of the dominant kernel by GPU time: K10 score_fast (scoring DP).  Algorithmic
-        # bytes per launch = every MSA cell table entry read once (start,len: 8 B) and its best_pp /
-        # best_link written once (8 B) + every link read once (pp, ppp, count: 12 B) + the per-column
-        # metadata (5 x 4 B).  K7 (O(ND) forward) is reported alongside: 2-bit operands read once +
-        # 1 trace bit per evaluated cell + 4 B min_k per edit step.
-        k10_launches = max(1, st["score_launches"])
-        k10_bytes = (16.0 * st["cells_msa"] + 12.0 * st["links"] + 20.0 * st["path_items"]) / k10_launches
-        k10_ms = st["score_ms"] / k10_launches
-        achieved = k10_bytes / (k10_ms * 1e-3) / 1e9 if k10_ms > 0 else 0.0
-        # HBM bytes per K10 launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself):
-        # used only when this run is the workload those passes profiled (seeded data: the launches are the same ones)
-        traffic, traffic_note = None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_k10_traffic.json")) as f:
-                pm = json.load(f)
-            w_ = pm["workload"]
-            if (not analytic and ovl_state is not None and int(args.genome_size) == w_["genome_size"] and int(args.depth) == w_["depth"]
-                    and args.profile == w_["profile"] and abs(k10_launches / args.steps - pm["launches_per_step"]) < 0.5):
-                traffic = (pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024.0
-                traffic_note = pm["source"]
-        except (OSError, KeyError, ValueError):
-            pass
+        if analytic:
+            piles, recs, off = a_piles, a_recs, a_off
+        else:
+            recs, off = last["sub"], last["off"]
+            piles = [{"seed": int(last["seeds"][i]), "recs": recs[int(off[i]):int(off[i + 1])]} for i in range(last["seeds"].size)]
+        # Roofline of the dominant kernel by GPU time: K7 ond_forward (banded O(ND) forward sweep).  Algorithmic bytes per
+        # launch = 2-bit operands read once + 1 trace bit per evaluated cell + 4 B min_k per edit step.
+        # K10 (scoring DP, segment-parallel since round 2) is reported alongside with its own algorithmic bytes: every MSA
+        # cell table entry read once (start, len: 8 B), its best_pp / best_link / best score written once (12 B), every
+        # link read once (pp, ppp, count: 12 B), 20 B of column metadata.
         launches = max(1, st["forward_launches"])
         alg_bytes = (st["seq_bases"] / 4.0 + st["cells"] / 8.0 + 4.0 * st["d_steps"]) / launches
         avg_ms = st["forward_ms"] / launches
         k7_achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        k10_launches = max(1, st["score_launches"])
+        k10_bytes = (20.0 * st["cells_msa"] + 12.0 * st["links"] + 20.0 * st["path_items"]) / k10_launches
+        k10_ms = st["score_ms"] / k10_launches
+        k10_achieved = k10_bytes / (k10_ms * 1e-3) / 1e9 if k10_ms > 0 else 0.0
+        traffic, traffic_note = None, None
+        try:  # HBM bytes per K7 launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself)
+            with open(os.path.join(ROOT, "profiles", "pmc_k7_traffic.json")) as f:
+                pm = json.load(f)
+            if not analytic and args.config == pm["workload"]["config"] and world == 1 and n_files == 1 and \
+                    abs(launches / args.steps - pm["launches_per_step"]) < 0.5:
+                traffic = (pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024.0
+                traffic_note = pm["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         peak = 8000.0
+        n_cols = max(1, st["path_items"])
         out = {
             "metric": "corrected bases/sec",
             "value": total_bases / max_dt,
@@ -342,74 +353,66 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": max_dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "synthetic E. coli-like %.1f Mb, %gx %s reads (lognormal mu 9.55 sigma 0.75), "
-                                   "seed_cutoff 1k, 1 read set per GPU" % (args.genome_size / 1e6, args.depth,
-                                                                          args.profile),
-                       "reads_per_gpu": len(rs), "read_bases_per_gpu": rs.total_bases(), "piles_per_gpu": len(piles),
-                       "overlaps_per_gpu": int(recs.shape[0]), "sharding": "piles, weak (one read set per rank)",
+            "config": {"workload": "BASELINE config %d: %s, seed_cutoff 1k, -x %s, ovl_sort -k %d" % (args.config, name, preset, sort_k),
+                       "reads": len(rs), "read_bases": int(lens.sum()), "genome_size": int(genome_size), "depth": depth, "profile": profile,
+                       "seed_files": n_files, "sharding": "seed file r of %d on rank r (one read set; util/seq_dump.c:87-92 dealing)" % n_files
+                       if world > 1 else "seed file %d of %d on the one GPU" % (my_file, n_files),
+                       "piles_rank0": len(piles), "overlaps_rank0": int(recs.shape[0]), "corrected_seeds_per_step": total_seeds / args.steps,
                        "piles_from": "analytic (true read positions)" if analytic else
                        "the step's own overlap -> ovl_sort -> pile assembly chain on the device",
+                       "longest_chain_bound": "none since round 2: the scoring DP and the best_pp walk are cut into 1024-column segments "
+                                              "scored at the same time (DESIGN section 5); a seed's length no longer bounds a step",
                        "datagen_s": round(t_gen, 1)},
-            "roofline": {"bound": "hbm", "kernel": "score_fast_kernel (K10 scoring DP)", "achieved": achieved,
-                         "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": "ond_forward_kernel (K7, banded O(ND) forward sweep)", "achieved": k7_achieved,
+                         "peak": peak, "unit": "GB/s", "frac": k7_achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_note,
-                         "traffic_over_algorithmic": (traffic / k10_bytes) if traffic and k10_bytes else None,
-                         "alg_bytes_per_launch": k10_bytes, "avg_launch_ms": k10_ms, "launches": int(k10_launches),
-                         "note": "latency-bound dependent chain (one wave per seed), not bandwidth-bound",
-                         "k7_ond_forward": {"achieved": k7_achieved, "frac": k7_achieved / peak,
-                                            "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-                                            "launches": int(launches),
-                                            "cells_per_s": st["cells"] / (st["forward_ms"] * 1e-3)
-                                            if st["forward_ms"] > 0 else 0.0}},
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic and alg_bytes else None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": int(launches),
+                         "cells_per_s": st["cells"] / (st["forward_ms"] * 1e-3) if st["forward_ms"] > 0 else 0.0,
+                         "note": "latency-bound (dependent edit steps, ~13 of 64 lanes live), not bandwidth-bound; launch times are "
+                                 "HIP-event times with up to 8 contexts' launches in flight at once",
+                         "k10_scoring_dp": {"achieved": k10_achieved, "frac": k10_achieved / peak, "alg_bytes_per_launch": k10_bytes,
+                                            "avg_launch_ms": k10_ms, "launches": int(k10_launches),
+                                            "segments": int(st["score_segments"]), "repaired_segments": int(st["score_repairs"]),
+                                            "piles_through_int64_kernel": int(st["score_slow_piles"]),
+                                            "us_per_column_contended": st["score_ms"] * 1e3 / n_cols,
+                                            "note": "segment-parallel: a column's cost is throughput (GPU time / columns), no longer a chain"}},
             "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "max_band", "piles", "tags",
-                                            "cells_msa", "links", "path_items")},
+                                            "cells_msa", "links", "path_items", "score_segments", "score_repairs", "score_slow_piles")},
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
         }
-        if ovl_state is not None:
-            ost = ovl_state["stats"]
-            q_bases = int(ovl_state["set"].lens.sum())
-            o_ms = ovl_state["wall"] / args.steps * 1e3
-            # dominant overlap kernels by time; algorithmic bytes of the anchor pipeline:
-            # 16 B per anchor written by K3, sorted (LSD passes of 8 bits: 2 x 16 B per pass), read once by K4
-            passes = 6
-            a_bytes = ost["anchors"] / args.steps * (16.0 + passes * 32.0 + 16.0)
-            gpu_ms = sum(ost[k] for k in ("sketch_ms", "index_sort_ms", "seed_ms", "sort_ms", "exact_sort_ms", "chain_ms", "hits_ms")) / args.steps
-            out["overlap"] = {
-                "included_in_value": True,
-                "value": q_bases * world / (o_ms * 1e-3), "unit": "query bases/s (all-vs-all, index build included)",
-                "ms_per_step": o_ms, "gpu_kernel_ms_per_step": gpu_ms,
-                "kernel_ms": {k: round(ost[k] / args.steps, 3) for k in ("sketch_ms", "index_sort_ms", "seed_ms", "sort_ms", "exact_sort_ms",
-                                                                        "chain_ms", "hits_ms")},
-                "counters": {k: int(ost[k] // args.steps) for k in ("bases_sketched", "minimizers", "anchors", "tie_reads", "chain_cells",
-                                                                    "chains", "overlaps")},
-                "ovl_bytes": ovl_state["bytes"], "records": ovl_state["recs"],
-                "sketch_gsymbols_per_s": ost["bases_sketched"] / (ost["sketch_ms"] * 1e-3) / 1e9 if ost["sketch_ms"] > 0 else 0.0,
-                "anchor_pipeline_alg_GBps": a_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0,
-                "chain_gcells_per_s": ost["chain_cells"] / (ost["chain_ms"] * 1e-3) / 1e9 if ost["chain_ms"] > 0 else 0.0,
-            }
-            if not analytic:
-                out["overlap"]["sort"] = {"ms_per_step": ovl_state["sort_wall"] / args.steps * 1e3,
-                                          "gpu_ms": ovl_state["sort_stats"]["gpu_ms"],
-                                          "candidates": int(ovl_state["sort_stats"]["candidates"]),
-                                          "kept": int(ovl_state["sort_stats"]["kept"]), "blacklisted": int(ovl_state["last"][3]),
-                                          "k": ovl_state["k"]}
-                out["overlap"]["pile_assembly_ms_per_step"] = ovl_state["asm_wall"] / args.steps * 1e3
+        if not args.no_overlap:
+            q_bases = int(lens.sum())
+            o_ms = sh.stats["overlap_s"] / args.steps * 1e3
+            out["overlap"] = {"included_in_value": True, "ms_per_step": o_ms, "jobs_per_step": sh.stats["jobs"] / args.steps,
+                              "records_per_step": sh.stats["records"] / args.steps,
+                              "value": q_bases / (o_ms * 1e-3) if o_ms > 0 else 0.0,
+                              "unit": "query bases/s (this rank's raw_align jobs, index builds included)",
+                              "sort": {"ms_per_step": sh.stats["sort_s"] / args.steps * 1e3, "blacklisted": int(last.get("n_bl", 0)), "k": sort_k},
+                              "pile_assembly_ms_per_step": sh.stats["assemble_s"] / args.steps * 1e3}
+            ost = sh.ovl_stats
+            if ost:
+                out["overlap"]["kernel_ms_last_index"] = {k: round(ost[k], 3) for k in ("sketch_ms", "index_sort_ms", "seed_ms", "sort_ms",
+                                                                                         "exact_sort_ms", "chain_ms", "hits_ms") if k in ost}
+                out["overlap"]["counters_last_index"] = {k: int(ost[k]) for k in ("bases_sketched", "minimizers", "anchors", "tie_reads",
+                                                                                  "chain_cells", "chains", "overlaps") if k in ost}
         parity_fail = False
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
-            out["cpu_baseline"], ref = cpu_baseline(rs, piles, read_type, args.cpu_sample)
+            out["cpu_baseline"], ref = cpu_baseline(rs, piles, read_type, args.cpu_sample, max_lq)
             if ref:  # one more (untimed) whole-batch call that keeps the sequences: what the timed steps computed
-                full = db.correct_piles(recs, off if not analytic else pile_off, read_type=read_type,
-                                        host_threads=args.host_threads)
+                full = db.correct_piles(recs, off, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads)
                 out["parity"] = parity_block(ref, full, piles)
                 parity_fail = out["parity"]["mismatch"] != 0
-            if ovl_state is not None:
-                out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(ovl_state["set"], ovl_state["preset"])
+            if not args.no_overlap and n_files == 1 and args.config == 2:
+                from nextdenovo_amd import overlap
+                out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(
+                    overlap.ReadSet(np.arange(len(rs), dtype=np.uint32), lens, words, word_off), preset)
         print(json.dumps(out))
         if parity_fail:
             db.close()

@@ -18,6 +18,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these are its only exports */
 
 /* replaces: reference lib/nextcorrect.h:70-74 (`consensus_trimed`), mirrored by
  * lib/nextcorrect.py:19-24.  `seq` is malloc'd, NUL-terminated, mixed case
@@ -59,6 +60,10 @@ typedef struct {
 void align(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *V, uint8_t **D);
 /* replaces: reference lib/align.h:59-60 / lib/align.c:563-570 */
 void align_hq(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *V, uint8_t **D);
+/* replaces: reference lib/nextcorrect.h:157 / lib/align.c:580-679: full-matrix global alignment (match 2, mismatch -4, gap
+ * open -4, gap extend -2).  s1 indexes the columns and is written to q_aln_str, s2 to t_aln_str; only aln_len and the two
+ * strings (caller-allocated, s1_l + s2_l + 1 bytes each) are set.  Host routine: the reference calls it from nowhere. */
+void align_nd(const char *s1, const uint32_t s1_l, const char *s2, const uint32_t s2_l, alignment *aln);
 /* replaces: reference lib/align.h:45-50 / lib/align.c:22-78 (host-only helpers) */
 void malloc_vd(int **V, uint8_t ***D, uint64_t max_mem_d);
 void clean_V(int *V, int max_mem_d);
@@ -131,6 +136,7 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
  * bits); read i starts at words[word_off[i]] and has len[i] bases.  The DB is uploaded to
  * HBM once (forward + reverse complement) and stays there. */
 typedef struct ndgpu_db ndgpu_db;
+/* NULL when the DB does not fit the device memory */
 ndgpu_db *ndgpu_db_create(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off, const uint32_t *len);
 void ndgpu_db_destroy(ndgpu_db *db);
 
@@ -140,7 +146,10 @@ void ndgpu_db_destroy(ndgpu_db *db);
  * seed, rev, t_s, t_e, query read, q_s, q_e, match; coordinates inclusive); pile i owns
  * records [pile_off[i], pile_off[i+1]) and its first record is the seed self record.
  * max_aln_length and the per-pile max_lq_length = min(seed_len/2, max_lq_length) are
- * derived exactly as lib/nextcorrect.py:117,135-137,188 does.  Returns 0. */
+ * derived exactly as lib/nextcorrect.py:117,135-137,188 does.  Returns 0; -1 for a dead handle; -2 (nothing computed) when
+ * a record names a read that is not in `db` or a window outside its read.  Sub-batches that do not fit the device memory
+ * are halved; a single pile that still does not fit comes back as the reference's out-of-memory seed (len 3,
+ * lib/nextcorrect.c:2254-2261).  Several handles may be alive; every call works against the one it is given. */
 int ndgpu_correct_piles(ndgpu_db *db, int n_piles, const uint32_t *recs, const uint64_t *pile_off,
                         unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
                         unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
@@ -163,6 +172,7 @@ void ndgpu_reset_stats(void);
 /* Number of HIP devices visible (0 if none); does not create a context. */
 int ndgpu_device_count(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these are its only exports */
 
 typedef struct ndgpu_ovl_opt {
 	int32_t k, w, hpc;                  /* mm_idxopt_t::k, ::w, ::flag & MM_I_HPC          (minimap.h) */
@@ -76,6 +77,14 @@ int64_t ndgpu_ovl_map(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mi
  * prev[2] = running (qname, tname) state (`prev_t pid`, minimap2/main.c:29).  out needs 40 bytes per record.
  * Returns bytes written. */
 int64_t ndgpu_ovl_encode(const ndgpu_ovl_rec *recs, int64_t n, uint32_t prev[2], uint8_t *out);
+
+/* decode_ovl() over a whole buffer (lib/ovl.c:152-203, the routine lib/nextcorrect.py:105 calls per record through ovlseq.so):
+ * out[8 * k ..] = qname, rev, qs, qe, tname, ts, te, match of record k; prev[2] = running (qname, tname) state; a trailing
+ * partial record is not consumed (*consumed = bytes used, may be NULL).  Returns the records decoded (<= cap). */
+int64_t ndgpu_ovl_decode(const uint8_t *buf, uint64_t n_bytes, uint32_t prev[2], uint32_t *out, int64_t cap, uint64_t *consumed);
+/* the walk of kbit_read() (lib/bseq.c:257-299) over a .2bit payload without its 2 magic bytes: ids, lengths and the word
+ * index of every read's sequence.  Returns the number of reads in the payload (cap = 0: count only). */
+int64_t ndgpu_2bit_index(const uint32_t *words, uint64_t n_words, uint32_t *ids, uint32_t *lens, uint64_t *word_off, int64_t cap);
 
 void ndgpu_ovl_free(void *p);
 
@@ -140,6 +149,7 @@ typedef struct ndgpu_ovl_stats {
 void ndgpu_ovl_get_stats(const ndgpu_ovl_index *idx, ndgpu_ovl_stats *st);
 void ndgpu_ovl_reset_stats(ndgpu_ovl_index *idx);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

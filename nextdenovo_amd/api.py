@@ -137,6 +137,8 @@ class ReadDB:
         self.n_reads = int(self._len.size)
         self._h = self._lib.ndgpu_db_create(self.n_reads, self._words.ctypes.data, self._off.ctypes.data,
                                             self._len.ctypes.data)
+        if not self._h:
+            raise MemoryError("ndgpu_db_create: the read DB does not fit the device memory")
 
     def close(self):
         if self._h:
@@ -150,9 +152,14 @@ class ReadDB:
         pile_off = np.ascontiguousarray(pile_off, dtype=np.uint64)
         n = int(pile_off.size) - 1
         out = (C.POINTER(ConsensusTrimed) * n)()
-        self._lib.ndgpu_correct_piles(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
-                                      min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
-                                      host_threads, out)
+        rc = self._lib.ndgpu_correct_piles(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
+                                           min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
+                                           host_threads, out)
+        if rc == -2:
+            raise ValueError("ndgpu_correct_piles: an overlap record names a read or a window that is not in this read DB "
+                             "(sorted.ovl and the .idx / .2bit files do not belong together?)")
+        if rc != 0:
+            raise RuntimeError("ndgpu_correct_piles failed (%d)" % rc)
         if lengths_only:
             res = []
             for i in range(n):

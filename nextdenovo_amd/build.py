@@ -36,11 +36,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    for lib, srcs, hdrs in ((LIB, SOURCES, HEADERS), (OVL_LIB, OVL_SOURCES, OVL_HEADERS)):
-        if not force and not _stale(lib, srcs + hdrs):
+    for lib, srcs, hdrs, exports in ((LIB, SOURCES, HEADERS, "exports_nextcorrect.map"), (OVL_LIB, OVL_SOURCES, OVL_HEADERS, "exports_overlap.map")):
+        if not force and not _stale(lib, srcs + hdrs + [exports]):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wall", "-Wno-unused-function", "-o", lib] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in srcs]
+               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, exports), "-o", lib] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in srcs]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -95,6 +96,22 @@ void run_single_alignment(char *q, int q_len, char *t, int t_len, alignment *a, 
 
 }  // namespace
 
+namespace {
+std::mutex g_reap_mu;
+std::vector<std::thread> g_reapers;
+void join_reapers() {
+    std::vector<std::thread> v;
+    {
+        std::lock_guard<std::mutex> lock(g_reap_mu);
+        v.swap(g_reapers);
+    }
+    for (auto &t : v) t.join();
+}
+struct ReaperAtExit {
+    ~ReaperAtExit() { join_reapers(); }
+} g_reaper_at_exit;
+}  // namespace
+
 extern "C" {
 
 consensus_trimed *nextCorrect(char **seqs, unsigned int *aln_start, unsigned int *aln_end, unsigned int seq_count,
@@ -105,8 +122,13 @@ consensus_trimed *nextCorrect(char **seqs, unsigned int *aln_start, unsigned int
                    make_params(max_mem_len, min_len_aln, max_cov_aln, min_cov, lqseq_max_length,
                                min_error_corrected_ratio, split, fast, read_type));
     PileEngine *ep = &eng;
-    HipBackend be;
-    run_engines(&ep, 1, be, 1);
+    try {
+        HipBackend be;
+        run_engines(&ep, 1, be, 1);
+    } catch (const DeviceOom &) {  // lib/nextcorrect.c:2254-2261: a seed whose working memory cannot be had is reported, not fatal
+        DeviceAligner::context(0).release_memory();
+        return (consensus_trimed *)make_error_seed(3);
+    }
     return (consensus_trimed *)eng.take_result();
 }
 
@@ -129,60 +151,87 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
                                 make_params(max_mem_len[i], min_len_aln, max_cov_aln, min_cov, lqseq_max_length[i],
                                             min_error_corrected_ratio, split, fast, read_type));
     });
-    {
-        HipBackend be(0, host_threads);
-        run_engines(eng.data(), eng.size(), be, host_threads);
+    // (out of device memory: the batch is halved until it fits; a single pile that does not fit is an out-of-memory seed)
+    std::vector<std::pair<size_t, size_t>> todo{{0, (size_t)n_piles}};
+    while (!todo.empty()) {
+        const auto [a, b] = todo.back();
+        todo.pop_back();
+        try {
+            HipBackend be(0, host_threads);
+            run_engines(eng.data() + a, b - a, be, host_threads);
+            for (size_t i = a; i < b; i++) out[i] = (consensus_trimed *)eng[i]->take_result();
+        } catch (const DeviceOom &) {
+            DeviceAligner::context(0).release_memory();
+            for (size_t i = a; i < b; i++) {  // engines restart from scratch
+                delete eng[i];
+                eng[i] = new PileEngine(seqs[i], aln_start[i], aln_end[i], seq_count[i],
+                                        make_params(max_mem_len[i], min_len_aln, max_cov_aln, min_cov, lqseq_max_length[i],
+                                                    min_error_corrected_ratio, split, fast, read_type));
+            }
+            if (b - a == 1) out[a] = (consensus_trimed *)make_error_seed(3);
+            else {
+                todo.push_back({a + (b - a) / 2, b});
+                todo.push_back({a, a + (b - a) / 2});
+            }
+        }
     }
-    for (size_t i = 0; i < (size_t)n_piles; i++) {
-        out[i] = (consensus_trimed *)eng[i]->take_result();
-        delete eng[i];
-    }
+    for (size_t i = 0; i < (size_t)n_piles; i++) delete eng[i];
     return 0;
 }
 
 struct ndgpu_db {
     ReadDb *db;
+    uint32_t *dev_pool;  // this handle's copy in HBM (forward + reverse complement), handed to every batch that names it
 };
 
 ndgpu_db *ndgpu_db_create(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off, const uint32_t *len) {
     ndgpu_db *h = new ndgpu_db;
     h->db = new ReadDb(n_reads, words, word_off, len);
-    DeviceAligner::instance().set_db(h->db->pool().data(), h->db->pool().size());
+    h->dev_pool = DeviceAligner::upload_db(h->db->pool().data(), h->db->pool().size(), DeviceAligner::instance().device());
+    if (!h->dev_pool) {
+        fprintf(stderr, "[ndgpu] ndgpu_db_create: out of device memory for a read DB of %llu bases\n",
+                (unsigned long long)h->db->total_bases());
+        delete h->db;
+        delete h;
+        return nullptr;
+    }
     return h;
 }
 
 void ndgpu_db_destroy(ndgpu_db *h) {
     if (!h) return;
+    join_reapers();
+    DeviceAligner::free_db(h->dev_pool);
     delete h->db;
     delete h;
 }
 
-namespace {
-std::mutex g_reap_mu;
-std::vector<std::thread> g_reapers;
-void join_reapers() {
-    std::vector<std::thread> v;
-    {
-        std::lock_guard<std::mutex> lock(g_reap_mu);
-        v.swap(g_reapers);
-    }
-    for (auto &t : v) t.join();
-}
-struct ReaperAtExit {
-    ~ReaperAtExit() { join_reapers(); }
-} g_reaper_at_exit;
-}  // namespace
 
 int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const uint64_t *pile_off,
                         unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
                         unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
                         unsigned int fast, int read_type, int host_threads, consensus_trimed **out) {
     if (n_piles <= 0) return 0;
+    if (!h || !h->db || !h->dev_pool) return -1;
     if (host_threads <= 0) host_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const ReadDb &db = *h->db;
+    // every record must name reads of this DB and windows inside them (a sorted.ovl written against other .idx files
+    // would otherwise index the host tables and the device pool out of bounds): -2, nothing is computed
+    for (int i = 0; i < n_piles; i++) {
+        if (pile_off[i + 1] < pile_off[i]) return -2;
+        for (uint64_t r = pile_off[i]; r < pile_off[i + 1]; r++) {
+            const uint32_t *c = recs + r * 8;
+            if (c[0] >= db.n_reads() || c[4] >= db.n_reads() || c[5] > c[6] || c[6] >= db.length(c[4]) || c[2] > c[3] ||
+                c[3] >= db.length(c[0])) {
+                fprintf(stderr, "[ndgpu] ndgpu_correct_piles: record %llu of pile %d names read %u / %u or a window outside them "
+                                "(DB holds %u reads)\n", (unsigned long long)(r - pile_off[i]), i, c[0], c[4], db.n_reads());
+                return -2;
+            }
+        }
+    }
     join_reapers();  // the previous call's teardown
     const auto t_call0 = std::chrono::steady_clock::now();
     std::atomic<uint64_t> build_ns{0}, take_ns{0};
-    const ReadDb &db = *h->db;
     size_t sub = 384;
     if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
     // longest seeds first: the scoring DP is a sequential chain per seed, so similar lengths
@@ -227,57 +276,79 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     // and its grow-only device buffers stop being re-allocated (a hipFree / hipMalloc stalls every context)
     // (dealt in snake order -- 0..D-1, D-1..0, ... -- so that the context that got the longest chains of a round
     // gets the lightest sub-batch of the next)
+    std::atomic<uint64_t> oom_seeds{0};
+    // one range of the length-sorted piles through one context; out of device memory -> the context's buffers are
+    // dropped and the range is halved, down to a single pile, which is then an out-of-memory seed (len 3)
+    std::function<void(int, size_t, size_t)> run_range = [&](int ctx, size_t base, size_t cnt) {
+        std::vector<PileEngine *> eng(cnt, nullptr);
+        const auto t_b0 = std::chrono::steady_clock::now();
+        CoreLease *build_lease = new CoreLease(threads_each);
+        parallel_for(cnt, build_lease->n, [&](size_t k) {
+            const uint32_t pid = order[base + k];
+            const uint64_t r0 = pile_off[pid], r1 = pile_off[pid + 1];
+            const size_t n = (size_t)(r1 - r0);
+            std::vector<unsigned> st(n), en(n), len(n);
+            std::vector<int64_t> dev(n);
+            unsigned max_aln = n ? recs[r0 * 8 + 3] + 1 : 0;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t *r = recs + (r0 + i) * 8;
+                dev[i] = db.window_offset(r[4], r[5], r[6], (int)r[1]);
+                len[i] = r[6] - r[5] + 1;
+                st[i] = r[2];
+                en[i] = r[3];
+                const unsigned v = r[3] - r[2] + r[6] - r[5] + 2;
+                if (v > max_aln && r[0] != r[4]) max_aln = v;
+            }
+            const unsigned lq = n ? std::min<unsigned>(en[0] / 2, max_lq_length) : max_lq_length;
+            std::string seed;  // only the HiFi consensus compares against the seed's own bases
+            if (read_type == 3 && n) seed = db.window(recs[r0 * 8 + 4], recs[r0 * 8 + 5], recs[r0 * 8 + 6], 0);
+            eng[k] = new PileEngine(len.data(), dev.data(), st.data(), en.data(), (unsigned)n,
+                                    make_params(max_aln, min_len_aln, max_cov_aln, min_cov, lq,
+                                                min_error_corrected_ratio, split, fast, read_type),
+                                    read_type == 3 ? seed.c_str() : nullptr);
+        });
+        delete build_lease;
+        build_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_b0).count();
+        bool oom = false;
+        try {
+            HipBackend be(ctx, threads_each, h->dev_pool);
+            run_engines(eng.data(), cnt, be, threads_each);
+        } catch (const DeviceOom &e) {
+            oom = true;
+            if (getenv("NDGPU_TRACE"))
+                fprintf(stderr, "[ndgpu trace] out of device memory (%zu bytes wanted) in a sub-batch of %zu piles: %s\n", e.bytes, cnt,
+                        cnt > 1 ? "halved" : "reported as an out-of-memory seed (len 3)");
+        }
+        if (oom) {
+            DeviceAligner::context(ctx).release_memory();
+            for (PileEngine *e : eng) delete e;
+            if (cnt == 1) {
+                out[order[base]] = (consensus_trimed *)make_error_seed(3);
+                oom_seeds++;
+            } else {
+                run_range(ctx, base, cnt / 2);
+                run_range(ctx, base + cnt / 2, cnt - cnt / 2);
+            }
+            return;
+        }
+        const auto t_t0 = std::chrono::steady_clock::now();
+        for (size_t k = 0; k < cnt; k++) out[order[base + k]] = (consensus_trimed *)eng[k]->take_result();
+        // tearing down the per-pile host state (thousands of small vectors per pile, ~0.3 ms each; parallel frees
+        // only fight over the allocator) is not on anybody's critical path: a reaper thread does it while the caller
+        // goes on, and the next call (or the library's unload) waits for it
+        {
+            std::lock_guard<std::mutex> lock(g_reap_mu);
+            g_reapers.emplace_back([v = std::move(eng)] {
+                for (PileEngine *e : v) delete e;
+            });
+        }
+        take_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_t0).count();
+    };
     auto drive = [&](int ctx) {
         for (size_t round = 0; round * (size_t)drivers < n_sub; round++) {
             const size_t sb = round * (size_t)drivers + (size_t)((round & 1) ? drivers - 1 - ctx : ctx);
             if (sb >= n_sub) continue;
-            const size_t base = sub_start[sb];
-            const size_t cnt = sub_start[sb + 1] - base;
-            std::vector<PileEngine *> eng(cnt, nullptr);
-            const auto t_b0 = std::chrono::steady_clock::now();
-            CoreLease *build_lease = new CoreLease(threads_each);
-            parallel_for(cnt, build_lease->n, [&](size_t k) {
-                const uint32_t pid = order[base + k];
-                const uint64_t r0 = pile_off[pid], r1 = pile_off[pid + 1];
-                const size_t n = (size_t)(r1 - r0);
-                std::vector<unsigned> st(n), en(n), len(n);
-                std::vector<int64_t> dev(n);
-                unsigned max_aln = n ? recs[r0 * 8 + 3] + 1 : 0;
-                for (size_t i = 0; i < n; i++) {
-                    const uint32_t *r = recs + (r0 + i) * 8;
-                    dev[i] = db.window_offset(r[4], r[5], r[6], (int)r[1]);
-                    len[i] = r[6] - r[5] + 1;
-                    st[i] = r[2];
-                    en[i] = r[3];
-                    const unsigned v = r[3] - r[2] + r[6] - r[5] + 2;
-                    if (v > max_aln && r[0] != r[4]) max_aln = v;
-                }
-                const unsigned lq = n ? std::min<unsigned>(en[0] / 2, max_lq_length) : max_lq_length;
-                std::string seed;  // only the HiFi consensus compares against the seed's own bases
-                if (read_type == 3 && n) seed = db.window(recs[r0 * 8 + 4], recs[r0 * 8 + 5], recs[r0 * 8 + 6], 0);
-                eng[k] = new PileEngine(len.data(), dev.data(), st.data(), en.data(), (unsigned)n,
-                                        make_params(max_aln, min_len_aln, max_cov_aln, min_cov, lq,
-                                                    min_error_corrected_ratio, split, fast, read_type),
-                                        read_type == 3 ? seed.c_str() : nullptr);
-            });
-            delete build_lease;
-            build_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_b0).count();
-            {
-                HipBackend be(ctx, threads_each);
-                run_engines(eng.data(), cnt, be, threads_each);
-            }
-            const auto t_t0 = std::chrono::steady_clock::now();
-            for (size_t k = 0; k < cnt; k++) out[order[base + k]] = (consensus_trimed *)eng[k]->take_result();
-            // tearing down the per-pile host state (thousands of small vectors per pile, ~0.3 ms each; parallel frees
-            // only fight over the allocator) is not on anybody's critical path: a reaper thread does it while the caller
-            // goes on, and the next call (or the library's unload) waits for it
-            {
-                std::lock_guard<std::mutex> lock(g_reap_mu);
-                g_reapers.emplace_back([v = std::move(eng)] {
-                    for (PileEngine *e : v) delete e;
-                });
-            }
-            take_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_t0).count();
+            run_range(ctx, sub_start[sb], sub_start[sb + 1] - sub_start[sb]);
         }
     };
     std::vector<std::thread> th;
@@ -308,6 +379,71 @@ void align(char *query_seq, int q_len, char *target_seq, int t_len, alignment *a
 
 void align_hq(char *query_seq, int q_len, char *target_seq, int t_len, alignment *align_rtn, int *, uint8_t **) {
     run_single_alignment(query_seq, q_len, target_seq, t_len, align_rtn, 1);
+}
+
+// replaces lib/align.c:580-679 (`align_nd`: global alignment, match 2 / mismatch -4 / gap open -4 / gap extend -2, two
+// traceback bits per cell packed four to a byte).  Exported by the reference's nextcorrect.so but called from nowhere
+// (its one call site, lib/ctg_cns.c:1357, is commented out), so it stays a host routine.  The definition names its
+// parameters (s2, s2_l, s1, s1_l): the FIRST sequence indexes the columns; rows are written to t_aln_str.
+void align_nd(const char *s2, const uint32_t s2_l, const char *s1, const uint32_t s1_l, alignment *aln) {
+    static const uint8_t MMH[4] = {64, 16, 4, 1}, INS[4] = {128, 32, 8, 2}, DEL[4] = {192, 48, 12, 3};
+    const int mas = 2, mis = -4, gos = -4, ges = -2;
+    const size_t row = ((size_t)s2_l >> 2) + 1;
+    std::vector<uint8_t> dm(row * ((size_t)s1_l + 1), 0);
+    auto d = [&](uint32_t i) { return dm.data() + row * (size_t)i; };
+    std::vector<int32_t> sc((size_t)s2_l + 1, 0);
+    int32_t cs = 0;
+    d(0)[0] |= MMH[0];
+    for (uint32_t j = 1; j <= s2_l; j++) {
+        sc[j] = sc[j - 1] + ((d(0)[(j - 1) >> 2] & DEL[(j - 1) & 3]) == DEL[(j - 1) & 3] ? ges : gos);
+        d(0)[j >> 2] |= DEL[j & 3];
+    }
+    for (uint32_t i = 1; i <= s1_l; i++) {
+        uint8_t *di = d(i);
+        const uint8_t *dp = d(i - 1);
+        for (uint32_t j = 0; j <= s2_l; j++) {
+            if (j == 0) {
+                cs = sc[0] + ((dp[0] & DEL[0]) == INS[0] ? ges : gos);
+                di[0] = INS[0];
+            } else {
+                const uint32_t k = j & 3;
+                const int32_t ms = sc[j - 1] + (s1[i - 1] == s2[j - 1] ? mas : mis);
+                const int32_t is = sc[j] + ((dp[j >> 2] & DEL[k]) == INS[k] ? ges : gos);
+                const int32_t ds = cs + ((di[(j - 1) >> 2] & DEL[(j - 1) & 3]) == DEL[(j - 1) & 3] ? ges : gos);
+                sc[j - 1] = cs;
+                uint8_t mv;
+                if (ms > is) {
+                    if (ms > ds) cs = ms, mv = MMH[k];
+                    else cs = ds, mv = DEL[k];
+                } else {
+                    if (is > ds) cs = is, mv = INS[k];
+                    else cs = ds, mv = DEL[k];
+                }
+                di[j >> 2] |= mv;
+                if (j == s2_l) sc[j] = cs;
+            }
+        }
+    }
+    uint32_t a = s1_l, b = s2_l, n = 0;
+    while (a != 0 || b != 0) {
+        const uint32_t k = b & 3;
+        const uint8_t mv = d(a)[b >> 2] & DEL[k];
+        if (mv == MMH[k]) {
+            aln->t_aln_str[n] = s1[--a];
+            aln->q_aln_str[n] = s2[--b];
+        } else if (mv == DEL[k]) {
+            aln->q_aln_str[n] = s2[--b];
+            aln->t_aln_str[n] = '-';
+        } else {
+            aln->t_aln_str[n] = s1[--a];
+            aln->q_aln_str[n] = '-';
+        }
+        n++;
+    }
+    aln->aln_len = n;
+    aln->t_aln_str[n] = aln->q_aln_str[n] = '\0';
+    reverse_str(aln->t_aln_str, (int)n);
+    reverse_str(aln->q_aln_str, (int)n);
 }
 
 // The device owns the DP state; these exist so that code written against

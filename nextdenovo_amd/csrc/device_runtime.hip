@@ -7,6 +7,7 @@
 // no host round trip between the forward sweep and the traceback.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -51,6 +52,12 @@ static std::mutex g_dbg_mu;  // NDGPU_DEBUG_LAUNCH=2: one device phase at a time
 static const bool g_debug_exclusive = getenv("NDGPU_DEBUG_LAUNCH") && atoi(getenv("NDGPU_DEBUG_LAUNCH")) >= 2;
 static const bool g_debug_nofree = getenv("NDGPU_DEBUG_NOFREE") != nullptr;  // triage: outgrown buffers are leaked, not freed
 
+// Test hook: NDGPU_OOM_ABOVE=bytes makes every device allocation larger than that fail as if the memory were exhausted.
+static inline bool oom_injected(size_t bytes) {
+    static const size_t lim = getenv("NDGPU_OOM_ABOVE") ? (size_t)strtoull(getenv("NDGPU_OOM_ABOVE"), nullptr, 10) : 0;
+    return lim && bytes > lim;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -62,12 +69,29 @@ struct DevBuf {
             if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] free %s %p\n", name, (void *)p);
             if (!g_debug_nofree) HIP_CHECK(hipFree(p));
         }
+        p = nullptr;
+        cap = 0;
         size_t want = n + n / 4 + 1024;
-        HIP_CHECK(hipMalloc((void **)&p, want * sizeof(T)));
+        hipError_t rc = oom_injected(want * sizeof(T)) ? hipErrorOutOfMemory : hipMalloc((void **)&p, want * sizeof(T));
+        if (rc == hipErrorOutOfMemory && want > n + 1024) {  // without the growth slack
+            want = n + 1024;
+            rc = oom_injected(want * sizeof(T)) ? hipErrorOutOfMemory : hipMalloc((void **)&p, want * sizeof(T));
+        }
+        if (rc == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            p = nullptr;
+            throw DeviceOom{want * sizeof(T)};
+        }
+        HIP_CHECK(rc);
         cap = want;
         if (g_debug_alloc)
             fprintf(stderr, "[ndgpu alloc] %s %p .. %p (%zu bytes, asked %zu)\n", name, (void *)p, (void *)((char *)p + want * sizeof(T)),
                     want * sizeof(T), n * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
     }
     ~DevBuf() {
         if (p) (void)hipFree(p);
@@ -81,10 +105,23 @@ struct PinBuf {
     void reserve(size_t n) {
         if (n <= cap) return;
         if (p && !g_debug_nofree) HIP_CHECK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
         size_t want = n + n / 4 + 1024;
-        HIP_CHECK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+        const hipError_t rc = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (rc == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            p = nullptr;
+            throw DeviceOom{want * sizeof(T)};
+        }
+        HIP_CHECK(rc);
         cap = want;
         if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] pinned %p .. %p\n", (void *)p, (void *)((char *)p + want * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
     }
     ~PinBuf() {
         if (p) (void)hipHostFree(p);
@@ -135,13 +172,10 @@ bool pack_append(std::vector<uint32_t> &pool, const char *s, size_t n) {
 
 }  // namespace
 
-// one resident read DB per process, shared by every context
-static uint32_t *g_db_pool = nullptr;
-static size_t g_db_cap = 0;
-static std::mutex g_db_mu;
 
 struct DeviceAligner::State {
     int device = 0;
+    const uint32_t *db_pool = nullptr;  // resident read DB of the batch in progress (owned by its ndgpu_db handle)
     hipStream_t stream = nullptr, lat_stream = nullptr;  // lat_stream: reserved compute units (see the constructor)
     hipStream_t stream2 = nullptr;                        // scoring launch of the piles that need the large LDS tables
     hipEvent_t ev_lat0 = nullptr, ev_lat1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
@@ -352,18 +386,49 @@ void DeviceAligner::reset_all_stats() {
         if (DeviceAligner *c = peek(i)) c->reset_stats();
 }
 
-void DeviceAligner::set_db(const uint32_t *pool_words, size_t n_words) {
-    std::lock_guard<std::mutex> lock(s_->mu);
-    HIP_CHECK(hipSetDevice(s_->device));
-    std::lock_guard<std::mutex> dbl(g_db_mu);
-    if (n_words + 2 > g_db_cap) {
-        if (g_db_pool) HIP_CHECK(hipFree(g_db_pool));
-        HIP_CHECK(hipMalloc((void **)&g_db_pool, (n_words + 2) * sizeof(uint32_t)));
-        g_db_cap = n_words + 2;
-        if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] db_pool %p .. %p\n", (void *)g_db_pool, (void *)(g_db_pool + g_db_cap));
+uint32_t *DeviceAligner::upload_db(const uint32_t *pool_words, size_t n_words, int device) {
+    HIP_CHECK(hipSetDevice(device));
+    uint32_t *d = nullptr;
+    const hipError_t e = hipMalloc((void **)&d, (n_words + 2) * sizeof(uint32_t));
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    HIP_CHECK(hipMemcpy(g_db_pool, pool_words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemset(g_db_pool + n_words, 0, 2 * sizeof(uint32_t)));
+    HIP_CHECK(e);
+    if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] db_pool %p .. %p\n", (void *)d, (void *)(d + n_words + 2));
+    HIP_CHECK(hipMemcpy(d, pool_words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(d + n_words, 0, 2 * sizeof(uint32_t)));
+    return d;
+}
+
+void DeviceAligner::free_db(uint32_t *dev_pool) {
+    if (!dev_pool) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(dev_pool);
+}
+
+void DeviceAligner::use_db(const uint32_t *dev_pool) { s_->db_pool = dev_pool; }
+int DeviceAligner::device() const { return s_->device; }
+
+void DeviceAligner::release_memory() {
+    State &S = *s_;
+    std::lock_guard<std::mutex> lock(S.mu);
+    (void)hipSetDevice(S.device);
+    (void)hipStreamSynchronize(S.stream);
+    if (S.stream2) (void)hipStreamSynchronize(S.stream2);
+    (void)hipGetLastError();
+    S.pending.clear();
+    S.up_used = S.down_used = 0;
+#define NDGPU_REL(x) S.x.release();
+    NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_mink) NDGPU_REL(d_v)
+    NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
+    NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_inscnt) NDGPU_REL(d_insmax) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
+    NDGPU_REL(d_cell_start) NDGPU_REL(d_cell_len) NDGPU_REL(d_cell_bpp) NDGPU_REL(d_cell_blink) NDGPU_REL(d_ent_pp)
+    NDGPU_REL(d_ent_ppp) NDGPU_REL(d_ent_cnt) NDGPU_REL(d_err) NDGPU_REL(d_ent_score) NDGPU_REL(d_cell_best) NDGPU_REL(d_spec)
+    NDGPU_REL(d_fin) NDGPU_REL(d_sums) NDGPU_REL(d_items) NDGPU_REL(d_bt_exit) NDGPU_REL(d_bt_steps) NDGPU_REL(d_bt_entry)
+    NDGPU_REL(d_bt_off) NDGPU_REL(d_path) NDGPU_REL(d_blocks) NDGPU_REL(d_regions) NDGPU_REL(d_strpool) NDGPU_REL(d_cursor)
+    NDGPU_REL(h_ops) NDGPU_REL(h_outs) NDGPU_REL(up) NDGPU_REL(down)
+#undef NDGPU_REL
 }
 
 void *DeviceAligner::stream() const { return s_->stream; }
@@ -523,10 +588,10 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.h2d(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), st);
     HIP_CHECK(hipEventRecord(S.ev0, st));
     NDGPU_DBG(st, "chunk: forward %zu tasks", n);
-    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p, (int)n, st);
+    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p, (int)n, st);
     HIP_CHECK(hipEventRecord(S.ev1, st));
     NDGPU_DBG(st, "chunk: traceback");
-    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
+    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
     NDGPU_DBG(st, "chunk: done");
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, n * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(S.h_ops.p, S.d_ops.p, ops_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -635,8 +700,8 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
             S.h2d(S.d_tasks.p + ids[at + i], &S.tasks[ids[at + i]], sizeof(AlnTask), st);
         }
         S.h2d(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), st);
-        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
-        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, g_db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
+        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
+        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
         S.sync_drain(st);
         for (size_t i = 0; i < take; i++) {
             const int32_t id = ids[at + i];
@@ -825,11 +890,11 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             if (b > a) {
                 HIP_CHECK(hipEventRecord(S.evs[0], st));
                 NDGPU_DBG(st, "main: forward %zu..%zu of %zu tasks, %zu piles", a, b, nt, np);
-                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p,
+                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p,
                                    (int)(b - a), st);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
                 NDGPU_DBG(st, "main: traceback");
-                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, g_db_pool, S.d_trace.p, S.d_mink.p,
+                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p,
                                      S.d_ops.p, nullptr, (int)(b - a), st);
                 NDGPU_DBG(st, "main: traceback done");
                 HIP_CHECK(hipEventRecord(S.evs[2], st));
@@ -867,7 +932,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     NDGPU_DBG(st, "main: pile_accept");
     launch_pile_accept(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_cov.p, (int)np, st);
     NDGPU_DBG(st, "main: make_tags");
-    launch_make_tags(S.d_piles.p, S.d_reads.p, S.d_tasks.p, S.d_ops.p, S.d_pool.p, g_db_pool, S.d_read_pile.p,
+    launch_make_tags(S.d_piles.p, S.d_reads.p, S.d_tasks.p, S.d_ops.p, S.d_pool.p, S.db_pool, S.d_read_pile.p,
                      S.d_tags.p, S.d_colidx.p, S.d_inscnt.p, S.d_insmax.p, (int)nr, st);
     NDGPU_DBG(st, "main: col_scan");
     launch_col_scan(S.d_piles.p, S.d_cov.p, S.d_inscnt.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, (int)np, st);
@@ -1045,24 +1110,45 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     }
     for (size_t p = 0; p < np; p++) {
         const PileDev &P = piles[p];
-        MainPile &M = *mp[p];
-        M.n_aligned = P.n_acc;
+        mp[p]->n_aligned = P.n_acc;
         if (bad_pile[p]) continue;
-        M.path.resize(P.path_len);
-        const PathItem *src = hpath + P.path_off;
-        for (uint32_t k = 0; k < P.path_len; k++) {
-            PathStep &d = M.path[k];
-            d.t_pos = tag_tpos(src[k].tag);
-            d.delta = (uint16_t)tag_delta(src[k].tag);
-            d.base = (uint8_t)tag_base(src[k].tag);
-            d.link = src[k].link;
-            d.cov = src[k].cov;
-        }
         S.stats.path_items += P.path_len;
         S.stats.links += P.n_links;
         S.stats.score_segments += P.n_seg;
         if (P.n_repair == 0xffffffffu) S.stats.score_slow_piles++;  // marker left by the int64 kernel
         else S.stats.score_repairs += P.n_repair;
+    }
+    {  // unpack the walk of every pile (one step per consensus position): piles dealt to the context's host threads
+        std::atomic<size_t> next(0);
+        auto work = [&] {
+            for (;;) {
+                const size_t p = next.fetch_add(1);
+                if (p >= np) break;
+                if (bad_pile[p]) continue;
+                const PileDev &P = piles[p];
+                MainPile &M = *mp[p];
+                M.path.resize(P.path_len);
+                const PathItem *src = hpath + P.path_off;
+                for (uint32_t k = 0; k < P.path_len; k++) {
+                    PathStep &d = M.path[k];
+                    d.t_pos = tag_tpos(src[k].tag);
+                    d.delta = (uint16_t)tag_delta(src[k].tag);
+                    d.base = (uint8_t)tag_base(src[k].tag);
+                    d.link = src[k].link;
+                    d.cov = src[k].cov;
+                }
+            }
+        };
+        if (S.host_threads <= 1 || np < 4) {
+            work();
+        } else {
+            CoreLease lease(S.host_threads);
+            const size_t nth = std::min<size_t>((size_t)lease.n, np);
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nth; t++) th.emplace_back(work);
+            work();
+            for (auto &x : th) x.join();
+        }
     }
     g_prof.m_post += wall_ns() - tp4;
 }

@@ -40,6 +40,13 @@ struct RuntimeStats {
     uint64_t score_slow_piles = 0; // piles that went through the int64 HBM-resident scoring kernel
 };
 
+// Thrown when a device (or pinned host) allocation fails for lack of memory.  The C ABI catches it, releases the
+// context's buffers, retries with half the piles and -- for a single pile that still does not fit -- reports the
+// reference's out-of-memory seed (len == 3, lib/nextcorrect.c:2254-2261).  Every other HIP error aborts with a message.
+struct DeviceOom {
+    size_t bytes;
+};
+
 class DeviceAligner {
   public:
     static constexpr int kMaxContexts = 16;
@@ -55,9 +62,15 @@ class DeviceAligner {
     void run_main(MainPile **piles, size_t n);
     void run_extract(ExtractPile **piles, size_t n);
     void end_batch();
-    // upload (or replace) the resident read DB pool; AlnJob::q_dev/t_dev index into it
-    void set_db(const uint32_t *pool_words, size_t n_words);
+    // resident read DB: every ndgpu_db handle owns its device copy (upload_db / free_db); a batch names the one its
+    // AlnJob::q_dev / t_dev and MainPile::dev_off index into (use_db; nullptr: sequences come with the batch)
+    static uint32_t *upload_db(const uint32_t *pool_words, size_t n_words, int device);  // nullptr: out of device memory
+    static void free_db(uint32_t *dev_pool);
+    void use_db(const uint32_t *dev_pool);
+    int device() const;
     void set_host_threads(int n);   // threads used for packing / decoding inside a batch
+    // after a DeviceOom: wait for the stream, drop every grow-only buffer of this context (they are re-created on demand)
+    void release_memory();
     void *stream() const;
     RuntimeStats stats() const;
     void reset_stats();
@@ -74,9 +87,10 @@ class DeviceAligner {
 // The product's only Backend: every request runs in HIP kernels on the device.
 class HipBackend : public Backend {
   public:
-    explicit HipBackend(int ctx = 0, int host_threads = 1) : dev_(DeviceAligner::context(ctx)) {
+    explicit HipBackend(int ctx = 0, int host_threads = 1, const uint32_t *db_pool = nullptr) : dev_(DeviceAligner::context(ctx)) {
         dev_.begin_batch();
         dev_.set_host_threads(host_threads);
+        dev_.use_db(db_pool);
     }
     ~HipBackend() override { finish(); }
     void run_main(MainPile **piles, size_t n) override { dev_.run_main(piles, n); }

@@ -726,6 +726,57 @@ int64_t ndgpu_ovl_encode(const ndgpu_ovl_rec *recs, int64_t n, uint32_t prev[2],
 	return nb;
 }
 
+// decode_ovl() over a whole buffer (lib/ovl.c:152-203): `n_bytes` of 8-varint records -> out[8 * k] in decode_ovl's field order
+// (qname, rev, qs, qe, tname, ts, te, match), prev[2] = the running (qname, tname) state.  A trailing partial record is left
+// alone (*consumed tells where it starts).  Returns the number of records (at most cap).
+int64_t ndgpu_ovl_decode(const uint8_t *buf, uint64_t n_bytes, uint32_t prev[2], uint32_t *out, int64_t cap, uint64_t *consumed)
+{
+	int64_t n = 0;
+	uint64_t at = 0, rec_start = 0;
+	while (n < cap) {
+		uint32_t f[8];
+		int k = 0;
+		rec_start = at;
+		for (; k < 8; ++k) {
+			uint32_t v = 0;
+			bool done = false;
+			while (at < n_bytes) {
+				const uint8_t c = buf[at++];
+				v = (v << 7) | (c & 127u);
+				if (c < 128) { done = true; break; }
+			}
+			if (!done) break;
+			f[k] = v;
+		}
+		if (k < 8) { at = rec_start; break; }
+		const uint32_t fl = f[1];
+		uint32_t *o = out + 8 * n;
+		prev[0] = (fl & 2) ? prev[0] - f[0] : prev[0] + f[0];
+		prev[1] = (fl & 4) ? prev[1] - f[4] : prev[1] + f[4];
+		o[0] = prev[0], o[1] = fl & 1, o[2] = f[2], o[3] = f[2] + f[3], o[4] = prev[1], o[5] = f[5];
+		o[6] = (fl & 8) ? f[5] + f[3] + f[6] : f[5] + f[3] - f[6];
+		o[7] = f[7];
+		++n;
+	}
+	if (consumed) *consumed = at;
+	return n;
+}
+
+// kbit_read()'s walk over a `.2bit` payload (lib/bseq.c:257-299): per read u32 id, u32 len, ceil(len / 16) words.
+// Returns the number of reads (call with cap = 0 to count); word_off[i] = index of read i's first sequence word.
+int64_t ndgpu_2bit_index(const uint32_t *w, uint64_t n_words, uint32_t *ids, uint32_t *lens, uint64_t *word_off, int64_t cap)
+{
+	int64_t n = 0;
+	uint64_t p = 0;
+	while (p + 2 <= n_words) {
+		const uint32_t ln = w[p + 1];
+		if (n < cap) ids[n] = w[p], lens[n] = ln, word_off[n] = p + 2;
+		++n;
+		p += 2 + (((uint64_t)ln + 15) >> 4);
+	}
+	return n;
+}
+
 void ndgpu_ovl_free(void *p) { free(p); }
 
 int64_t ndgpu_pack_2bit(uint32_t n_reads, const uint8_t *ascii, uint64_t n_bytes, const uint64_t *ascii_off, const uint32_t *lens,

@@ -1,6 +1,10 @@
 // Resident read database (see nd_host.h).  Host copy + the pool that is uploaded
 // once to HBM.  Input is the reference's .2bit payload (lib/bseq.c:114-139).
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "nd_host.h"
 
@@ -33,7 +37,8 @@ ReadDb::ReadDb(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off
         total_ += len[r];
     }
     pool_.assign(nw + 2, 0);
-    for (uint32_t r = 0; r < n_reads; r++) {
+    // reads are independent: blocks of 256 reads dealt to the host's cores (a 5.6 Gb DB is ~10^10 base moves)
+    auto one = [&](uint32_t r) {
         const uint32_t L = len[r];
         const uint64_t w = ((uint64_t)L + 15) / 16;
         uint32_t *f = pool_.data() + fwd_off_[r] / 16;
@@ -46,6 +51,24 @@ ReadDb::ReadDb(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off
             const uint32_t c = 3u - code_at(f, L - 1 - i);
             rc[i >> 4] |= c << ((i & 15u) * 2u);
         }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nth = (unsigned)std::min<uint64_t>(hw, total_ / 2000000 + 1);
+    if (nth <= 1) {
+        for (uint32_t r = 0; r < n_reads; r++) one(r);
+    } else {
+        std::atomic<uint32_t> next(0);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; t++)
+            th.emplace_back([&] {
+                for (;;) {
+                    const uint32_t a = next.fetch_add(256);
+                    if (a >= n_reads) break;
+                    const uint32_t b = std::min<uint32_t>(n_reads, a + 256);
+                    for (uint32_t r = a; r < b; r++) one(r);
+                }
+            });
+        for (auto &x : th) x.join();
     }
 }
 

@@ -32,8 +32,46 @@ def decode_varints(raw: np.ndarray) -> np.ndarray:
     return vals
 
 
+def _native():
+    import ctypes as C
+    from . import overlap
+    lib = overlap.load()
+    lib.ndgpu_ovl_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ndgpu_ovl_decode.restype = C.c_int64
+    lib.ndgpu_2bit_index.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ndgpu_2bit_index.restype = C.c_int64
+    return lib
+
+
 def decode_ovl(path: str) -> np.ndarray:
-    """Whole 8-field .ovl file -> uint32 array [n, 8] in decode_ovl order (lib/ovl.c:189-200)."""
+    """Whole 8-field .ovl file -> uint32 array [n, 8] in decode_ovl order (lib/ovl.c:189-200): one native pass
+    (ndgpu_ovl_decode) over the memory-mapped file."""
+    if os.path.getsize(path) == 0:
+        return np.zeros((0, 8), dtype=np.uint32)
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    n_rec = int(np.count_nonzero(np.asarray(raw) < 128)) // 8
+    out = np.empty((n_rec, 8), dtype=np.uint32)
+    prev = np.zeros(2, dtype=np.uint32)
+    buf = np.ascontiguousarray(raw)
+    got = _native().ndgpu_ovl_decode(buf.ctypes.data, buf.size, prev.ctypes.data, out.ctypes.data, n_rec, None)
+    return out[:got]
+
+
+def decode_bytes(blob: bytes) -> np.ndarray:
+    """decode_ovl() of an in-memory .ovl image."""
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    if buf.size == 0:
+        return np.zeros((0, 8), dtype=np.uint32)
+    n_rec = int(np.count_nonzero(buf < 128)) // 8
+    out = np.empty((n_rec, 8), dtype=np.uint32)
+    prev = np.zeros(2, dtype=np.uint32)
+    buf = np.ascontiguousarray(buf)
+    got = _native().ndgpu_ovl_decode(buf.ctypes.data, buf.size, prev.ctypes.data, out.ctypes.data, n_rec, None)
+    return out[:got]
+
+
+def decode_ovl_numpy(path: str) -> np.ndarray:
+    """The same decoder in numpy (kept as the cross-check of the native one in tests)."""
     raw = np.fromfile(path, dtype=np.uint8)
     v = decode_varints(raw)
     n = v.size // 8
@@ -90,16 +128,11 @@ def read_2bit(path: str):
     order (lib/bseq.c:257-299 kbit_read: u32 id, u32 len, ceil(len/16) words per read)."""
     data = np.fromfile(path, dtype=np.uint8)
     w = np.frombuffer(data[2:2 + ((data.size - 2) // 4) * 4].tobytes(), dtype=np.uint32)
-    ids, lens, offs = [], [], []
-    p = 0
-    while p + 2 <= w.size:
-        rid, ln = int(w[p]), int(w[p + 1])
-        ids.append(rid)
-        lens.append(ln)
-        offs.append(p + 2)
-        p += 2 + ((ln - 1) >> 4) + 1
-    return (np.asarray(ids, dtype=np.uint32), np.asarray(lens, dtype=np.uint32), w,
-            np.asarray(offs, dtype=np.uint64))
+    lib = _native()
+    n = int(lib.ndgpu_2bit_index(w.ctypes.data, w.size, None, None, None, 0))
+    ids, lens, offs = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint64)
+    lib.ndgpu_2bit_index(w.ctypes.data, w.size, ids.ctypes.data, lens.ctypes.data, offs.ctypes.data, n)
+    return ids, lens, w, offs
 
 
 def unpack_codes(words: np.ndarray, word_off: np.ndarray, lens: np.ndarray):
@@ -120,10 +153,21 @@ def unpack_codes(words: np.ndarray, word_off: np.ndarray, lens: np.ndarray):
 
 def write_2bit(path: str, ids, lens, words, word_off):
     """Writer of the `.2bit` container (lib/bseq.c:93-139): magic {0,254}, then u32 id, u32 len, words per read."""
+    ids = np.asarray(ids, dtype=np.uint32)
+    lens = np.asarray(lens, dtype=np.uint32)
+    word_off = np.asarray(word_off, dtype=np.int64)
+    cnt = (lens.astype(np.int64) + 15) >> 4
+    start = np.zeros(ids.size + 1, dtype=np.int64)
+    np.cumsum(cnt + 2, out=start[1:])
+    out = np.empty(int(start[-1]), dtype=np.uint32)
+    out[start[:-1]] = ids
+    out[start[:-1] + 1] = lens
+    # sequence words of all reads in one gather
+    total = int(cnt.sum())
+    if total:
+        r = np.repeat(np.arange(ids.size, dtype=np.int64), cnt)
+        within = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        out[start[:-1][r] + 2 + within] = np.asarray(words, dtype=np.uint32)[word_off[r] + within]
     with open(path, "wb") as f:
         f.write(bytes([0, 254]))
-        for i in range(len(ids)):
-            n = int(lens[i])
-            cnt = (n + 15) >> 4
-            f.write(np.asarray([ids[i], n], dtype=np.uint32).tobytes())
-            f.write(np.ascontiguousarray(words[int(word_off[i]): int(word_off[i]) + cnt], dtype=np.uint32).tobytes())
+        f.write(out.tobytes())

@@ -1,0 +1,137 @@
+"""The correction stage of one read set in memory, sharded the way nextDenovo shards it.
+
+`seq_dump` deals the seeds (reads >= seed_cutoff) round robin into `seed_cutfiles` seed files and the shorter reads into
+part files (util/seq_dump.c:74-114); raw_align runs one `minimap2-nd --step 1` job per (seed file, other file) pair
+(nextDenovo:426-467), sort_align one `ovl_sort` and seed_cns one `nextcorrect.py` per seed file (nextDenovo:344-354,
+77-84).  A seed file is therefore the unit that shards: everything it needs is the overlaps between its seeds and every
+read.  `Shard.piles(i)` computes exactly the jobs whose `.ovl` files the sort of seed file i reads -- its own
+(i, part j), (i, seed t >= i), and the mirrors (t < i, seed i) that the reference reaches through `ln -sf`
+(nextDenovo:459) -- hands them to `ndgpu_ovl_sort` in job order and applies the pile admission of lib/nextcorrect.py:92-143.
+No rank needs anything another rank computed: bench.py --gpus N and the multi-GPU tests give seed file r to rank r.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import minimap2_nd, overlap
+from .correct_stage import _IndexCache, job_matrix
+
+
+class DeviceBackend:
+    """The product path: indexes and maps on the device (libndgpu_overlap.so), sorts with ndgpu_ovl_sort."""
+
+    def __init__(self, opt):
+        self.opt, self.caches, self.last_stats = opt, {}, None
+
+    def map(self, key, target, query, batch_size, dual):
+        if key not in self.caches:
+            self.caches[key] = _IndexCache(self.opt, target)
+        return self.caches[key].map(query, batch_size, dual)
+
+    def release(self, key, keep_stats=False):
+        c = self.caches.pop(key, None)
+        if c is not None:
+            if keep_stats:
+                st = [ix.stats() for ix in c.parts.values()]
+                self.last_stats = {k_: sum(s[k_] for s in st) for k_ in st[0]} if st else None
+            c.close()
+
+    def sort(self, files, seed_len, min_seed_len, k, flank):
+        return overlap.sort_overlaps(files, seed_len, min_seed_len, k, flank)
+
+
+def deal(lens: np.ndarray, read_cutoff: int, seed_cutoff: int, n_seed_files: int, block_size: int = 0):
+    """Read ids (dense, in input order over the reads >= read_cutoff) of every seed file and part file, as seq_dump
+    deals them (util/seq_dump.c:74-114; the FILE_MAX_SIZE overflow files are not modelled: 2^31-ish bases per file)."""
+    lens = np.asarray(lens, dtype=np.int64)
+    kept = np.nonzero(lens >= read_cutoff)[0]
+    ids = np.arange(kept.size, dtype=np.uint32)
+    is_seed = lens[kept] >= seed_cutoff
+    seed_ids = ids[is_seed]
+    seed_files = [seed_ids[k::n_seed_files] for k in range(n_seed_files)]
+    part_ids = ids[~is_seed]
+    parts = []
+    if part_ids.size:
+        if block_size <= 0:
+            parts = [part_ids]
+        else:  # a part file closes once its total would exceed the block size
+            tot, lo = 0, 0
+            pl = lens[kept][~is_seed]
+            for j in range(part_ids.size):
+                tot += int(pl[j])
+                if tot > block_size:
+                    parts.append(part_ids[lo:j])
+                    lo, tot = j, int(pl[j])
+            parts.append(part_ids[lo:])
+    return kept, seed_files, parts
+
+
+class Shard:
+    """One read set (2-bit words as in a .2bit file, read i at words[word_off[i]], lens[i] bases; read id = index) and
+    the parameters of the stage."""
+
+    def __init__(self, words, word_off, lens, preset="ava-ont", seed_cutoff=1000, read_cutoff=500, n_seed_files=1, sort_k=40,
+                 flank=300, min_len_seed=None, min_len_aln=500, max_cov_aln=130, min_cov_seed=10, blacklist=True, occ=None,
+                 backend=None):
+        self.words = np.ascontiguousarray(words, dtype=np.uint32)
+        self.word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        kept, self.seed_ids, self.part_ids = deal(self.lens, read_cutoff, seed_cutoff, n_seed_files)
+        if kept.size != self.lens.size:
+            raise ValueError("reads below read_cutoff must be dropped by the caller (ids are dense over the kept reads)")
+        argv = ["--step", "1", "-x", preset] + (["-f", str(occ)] if occ else []) + ["a", "b"]
+        self.opt = minimap2_nd.build_opt(minimap2_nd.parse_argv(argv))
+        self.seed_batch = 6000000000 if preset == "ava-hifi" else 3000000000   # -I of the seed x seed jobs (nextDenovo:430,456)
+        self.sort_k, self.flank = sort_k, flank
+        self.min_len_seed = seed_cutoff // 2 if min_len_seed is None else min_len_seed   # nextDenovo passes seed_cutoff / 2... see config_parser
+        self.min_len_aln, self.max_cov_aln, self.min_cov_seed, self.blacklist = min_len_aln, max_cov_aln, min_cov_seed, blacklist
+        self.stats = {"overlap_s": 0.0, "sort_s": 0.0, "assemble_s": 0.0, "records": 0, "jobs": 0}
+        self.ovl_stats = None
+        # tests plug a CPU backend built from oracle/ here (same two calls); the product has the device backend only
+        self.backend = backend if backend is not None else DeviceBackend(self.opt)
+
+    def _set(self, ids):
+        return overlap.ReadSet(ids, self.lens[ids], self.words, self.word_off[ids])
+
+    def jobs_of(self, i):
+        """[(k, target seed file, query kind, query index, dual)] whose records the sort of seed file i reads, in job order."""
+        return [j for j in job_matrix(len(self.seed_ids), len(self.part_ids))
+                if j[1] == i or (j[2] == "seed" and j[3] == i)]
+
+    def overlaps(self, i):
+        """Step-1 records of every job of seed file i, job order."""
+        import time
+        t0 = time.perf_counter()
+        out = []
+        be = self.backend
+        try:
+            for k, tgt, kind, j, dual in self.jobs_of(i):
+                query = self._set(self.part_ids[j] if kind == "part" else self.seed_ids[j])
+                out.append(be.map(tgt, self._set(self.seed_ids[tgt]), query, minimap2_nd.IDX_BATCH if kind == "part" else self.seed_batch, dual))
+                if tgt != i:  # a mirror job: that index is not needed again by this shard
+                    be.release(tgt)
+        finally:
+            be.release(i, keep_stats=True)
+            self.ovl_stats = getattr(be, "last_stats", None)
+        self.stats["overlap_s"] += time.perf_counter() - t0
+        self.stats["records"] += int(sum(r.size for r in out))
+        self.stats["jobs"] += len(out)
+        return out
+
+    def piles(self, i, files=None):
+        """(records [n, 8] uint32, pile_off, seed ids, blacklisted) of seed file i: what `nextcorrect.py -i sorted.ovl` corrects."""
+        import time
+        files = self.overlaps(i) if files is None else files
+        t0 = time.perf_counter()
+        seed_len = np.zeros(self.lens.size, dtype=np.uint32)
+        sid = self.seed_ids[i]
+        seed_len[sid] = self.lens[sid]
+        srt, bl, sst = self.backend.sort(files, seed_len, int(self.lens[sid].min()) if sid.size else 0, self.sort_k, self.flank)
+        t1 = time.perf_counter()
+        skip = [rid for rid, _ in bl] if self.blacklist else []
+        sub, off, seeds = overlap.assemble_piles(srt, int(self.lens.size), self.min_len_seed, self.min_len_aln, self.max_cov_aln,
+                                                 self.min_cov_seed, skip)
+        self.stats["sort_s"] += t1 - t0
+        self.stats["assemble_s"] += time.perf_counter() - t1
+        self.sort_stats = sst
+        return sub, off, seeds, len(bl)

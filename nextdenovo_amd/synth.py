@@ -279,3 +279,109 @@ def pile_sequences(rs: ReadSet, pile) -> tuple[list[bytes], list[int], list[int]
         if v > max_aln and t != q:
             max_aln = v
     return seqs, st, en, max_aln
+
+
+# ---- BASELINE configs 3-5: genomes with repeat families, read sets generated on all host cores ----
+
+def make_genome_repeats(size: int, seed: int, families, frac: float) -> np.ndarray:
+    """Uniform random ACGT with `frac` of it covered by copies of repeat families.  families = [(unit length range,
+    divergence range, weight)]: every copy is its family's unit with substitutions at a rate drawn from the divergence
+    range (plus one-base indels at a tenth of it), dropped at a random place."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=size, dtype=np.uint8)
+    units = []
+    for (lo, hi), div, weight in families:
+        n_units = max(1, int(weight))
+        for _ in range(n_units):
+            units.append((rng.integers(0, 4, size=int(rng.integers(lo, hi + 1)), dtype=np.uint8), div))
+    covered, target = 0, int(frac * size)
+    while covered < target:
+        unit, (d0, d1) = units[int(rng.integers(0, len(units)))]
+        cp = unit.copy()
+        d = rng.uniform(d0, d1)
+        m = rng.random(cp.size) < d
+        cp[m] = (cp[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        drop = rng.random(cp.size) < d * 0.1
+        cp = cp[~drop]
+        pos = int(rng.integers(0, size - cp.size))
+        g[pos:pos + cp.size] = cp
+        covered += cp.size
+    return g
+
+
+CONFIGS = {
+    # name: genome builder, depth, read profile, lognormal mu / sigma, longest read, overlap preset, max_lq_length, sort -k
+    # (BASELINE.json configs[1..4]; lognormal N50 ~ exp(mu + sigma^2); sort -k as lib/config_parser.py:44)
+    2: dict(genome=lambda: make_genome(4600000, seed=42), depth=50.0, profile="ont", mu=9.55, sigma=0.75, max_len=200000,
+            preset="ava-ont", max_lq=10000, name="synthetic E. coli-like 4.6 Mb, 50x ONT (N50 ~ 20 kb)"),
+    3: dict(genome=lambda: make_genome_repeats(140000000, 342, [((1000, 6000), (0.02, 0.08), 400)], 0.20), depth=40.0, profile="ont",
+            mu=9.55, sigma=0.75, max_len=200000, preset="ava-ont", max_lq=10000,
+            name="synthetic D. melanogaster-like 140 Mb with 20 % interspersed repeats (1-6 kb families, 2-8 % divergence), 40x ONT"),
+    4: dict(genome=lambda: make_genome_repeats(120000000, 442, [((1000, 8000), (0.03, 0.10), 300)], 0.12), depth=60.0, profile="clr",
+            mu=9.03, sigma=0.6, max_len=100000, preset="ava-pb", max_lq=1000,
+            name="synthetic A. thaliana-like 120 Mb, 60x PacBio CLR (N50 ~ 12 kb)"),
+    5: dict(genome=lambda: make_genome_repeats(250000000, 542, [((280, 320), (0.05, 0.15), 40), ((900, 6500), (0.02, 0.12), 200),
+                                                                 ((2000, 9000), (0.01, 0.06), 60)], 0.45), depth=30.0, profile="ont",
+            mu=10.51, sigma=1.0, max_len=1000000, preset="ava-ont", max_lq=10000,
+            name="synthetic human chr1-like 250 Mb with 45 % repeats (Alu / L1-style families), 30x ultra-long ONT (N50 ~ 100 kb, <= 1 Mb)"),
+}
+
+_MP_GENOME = None
+
+
+def _mp_chunk(args):
+    """One chunk of a read set: its own random stream, the error model of simulate_reads, reads packed on the spot."""
+    depth, profile, seed, mu, sigma, min_len, max_len = args
+    rng = np.random.default_rng(seed)
+    genome = _MP_GENOME
+    G = genome.size
+    target, tot = depth * G, 0
+    seqs, gstart, gend, revs = [], [], [], []
+    while tot < target:
+        L = int(np.clip(rng.lognormal(mu, sigma), min_len, min(max_len, G)))
+        s = int(rng.integers(0, G - L + 1))
+        codes, _ck = mutate(genome[s:s + L], rng, profile, 0)
+        if codes.size < min_len:
+            continue
+        rev = int(rng.random() < 0.5)
+        seqs.append(revcomp_codes(codes) if rev else codes)
+        gstart.append(s)
+        gend.append(s + L)
+        revs.append(rev)
+        tot += codes.size
+    words = [pack_2bit_msb(s) for s in seqs]
+    return seqs, gstart, gend, revs, words
+
+
+def simulate_reads_mp(genome: np.ndarray, depth: float, profile: str, seed: int, mu: float, sigma: float, max_len: int,
+                      min_len: int = 1000, chunks: int = 96, procs: int = 0):
+    """The read set of simulate_reads() generated as `chunks` independent streams (seed + chunk number) on the host's cores:
+    the same set whatever the core count.  Returns (ReadSet without the analytic-pile checkpoints, words, word_off, lens)."""
+    import multiprocessing as mp
+    import os
+    global _MP_GENOME
+    _MP_GENOME = genome
+    procs = procs or min(chunks, os.cpu_count() or 1)
+    jobs = [(depth / chunks, profile, seed * 1000 + c, mu, sigma, min_len, max_len) for c in range(chunks)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_mp_chunk, jobs, chunksize=1)
+    _MP_GENOME = None
+    rs = ReadSet()
+    wl = []
+    for seqs, gs, ge, rv, words in parts:
+        rs.seqs += seqs
+        rs.gstart += gs
+        rs.gend += ge
+        rs.rev += rv
+        wl += words
+    n = len(rs.seqs)
+    lens = np.asarray([s.size for s in rs.seqs], dtype=np.uint32)
+    word_off = np.zeros(n, dtype=np.uint64)
+    if n:
+        word_off[1:] = np.cumsum([w.size for w in wl])[:-1]
+    return rs, (np.concatenate(wl) if wl else np.zeros(0, dtype=np.uint32)), word_off, lens
+
+
+def pile_sequences_from_recs(rs: ReadSet, recs):
+    """pile_sequences() for a bare record array."""
+    return pile_sequences(rs, {"recs": recs})

@@ -24,6 +24,55 @@ def test_exports(native_lib):
         assert hasattr(native_lib, n), "missing export: " + n
 
 
+def _dynamic_exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
+def test_nothing_but_the_abi_is_exported():
+    """The libraries export the functions their headers declare and nothing else (runtime globals, template instantiations and
+    kernel stubs stay local: a process may load them next to the reference's ovlseq.so / other libraries)."""
+    from nextdenovo_amd import build
+    root = os.path.dirname(util.HERE)
+    for lib, header in ((build.LIB, "ndgpu_nextcorrect.h"), (build.OVL_LIB, "ndgpu_overlap.h")):
+        exp = {n for n in _dynamic_exports(lib) if not n.startswith("__hip_cuid_")}
+        assert exp == _declared_functions(os.path.join(root, "include", header)), (lib, sorted(exp ^ _declared_functions(os.path.join(root, "include", header))))
+
+
+def test_align_nd_matches_reference(native_lib):
+    """align_nd (lib/align.c:580-679, exported by the reference's nextcorrect.so, no caller): same strings on random pairs."""
+    import ctypes as C
+    import random
+    import pytest
+    import refpipe
+    if not refpipe.have_ref("nextcorrect.so"):
+        pytest.skip("compiled reference not built")
+    ref = C.CDLL(os.path.join(refpipe.REFDIR, "nextcorrect.so"))
+    rng = random.Random(5)
+    for it in range(300):
+        n1, n2 = rng.randint(0, 60), rng.randint(0, 60)
+        if it < 5:
+            n1, n2 = [(0, 0), (0, 7), (9, 0), (1, 1), (4, 4)][it]
+        a = "".join(rng.choice("ACGT") for _ in range(n1))
+        b = list(a)
+        for _ in range(rng.randint(0, 8)):  # b = a with a few edits, or unrelated
+            if b and rng.random() < 0.6:
+                k = rng.randrange(len(b))
+                b[k:k + 1] = rng.choice(["", "A", "CG", "T"])
+        b = ("".join(b) if rng.random() < 0.8 else "".join(rng.choice("ACGT") for _ in range(n2)))[:60]
+        out = []
+        for lib in (native_lib, ref):
+            al = util.Aln()
+            tb, qb = C.create_string_buffer(len(a) + len(b) + 2), C.create_string_buffer(len(a) + len(b) + 2)
+            al.t_aln_str, al.q_aln_str = C.cast(tb, C.c_char_p), C.cast(qb, C.c_char_p)
+            lib.align_nd.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(util.Aln)]
+            lib.align_nd.restype = None
+            lib.align_nd(a.encode(), len(a), b.encode(), len(b), C.byref(al))
+            out.append((al.aln_len, tb.value, qb.value))
+        assert out[0] == out[1], (a, b, out)
+
+
 def test_host_helpers(native_lib):
     import ctypes as C
     b = C.create_string_buffer(b"ACGTNacgtMK")

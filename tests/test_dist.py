@@ -1,6 +1,9 @@
-"""N > 1 path of bench.py on CPU: world_size 2 over gloo.  Each rank builds its own read
-set (weak scaling: one read set per rank, piles never cross ranks), corrects it with the
-host engine + oracle backend, and the ranks meet only in the final sum/max reduction."""
+"""N > 1 path of bench.py on CPU: world_size 2 over gloo, STRONG scaling.  ONE read set; its seeds are dealt round robin
+into two seed files (util/seq_dump.c:87-92); rank r computes the raw_align jobs of seed file r (its own and the mirrors
+it needs, nextDenovo:426-467), sorts them, assembles the piles and corrects them -- here with the oracle overlap / sort
+backend and the host engine + oracle aligner, since there is no GPU.  The ranks meet only in the final reduction, and the
+union of their records is the single-process run over both seed files."""
+import hashlib
 import os
 import socket
 import sys
@@ -19,52 +22,78 @@ def _free_port():
     return p
 
 
+def _correct_file(i, n_files):
+    """{seed id: (len, md5)} of seed file i of n_files of the shared read set, CPU backends."""
+    import ctypes as C
+
+    import numpy as np
+
+    import stage_util
+    import util
+    from nextdenovo_amd import stage, synth
+    olib = C.CDLL(os.path.join(ROOT, "oracle", "libndoracle.so"))
+    h = C.CDLL(os.path.join(HERE, "csrc", "libndhost_test.so"))
+    fn, fr = util.bind_correct(h, "ndtest_correct", "ndtest_free")
+    g = synth.make_genome(30000, seed=42, n_repeats=0)
+    rs = synth.simulate_reads(g, 22, "ont", seed=43, mu=8.0, sigma=0.35)
+    words, word_off, lens = synth.pack_db(rs)
+    sh = stage.Shard(words, word_off, lens, preset="ava-ont", seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=17,
+                     blacklist=False, backend=stage_util.OracleBackend(olib, "ava-ont"))
+    sub, off, seeds, _n_bl = sh.piles(i)
+    out = {}
+    for p in range(seeds.size):
+        pile = {"seed": int(seeds[p]), "recs": sub[int(off[p]):int(off[p + 1])]}
+        seqs, st, en, mal = synth.pile_sequences(rs, pile)
+        ln, ide, seq = util.call_correct(fn, fr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal, max_lq=min(en[0] // 2, 10000),
+                                                     read_type=1, fast=0, split=0))
+        out[int(seeds[p])] = (int(ln), hashlib.md5(seq).hexdigest())
+    return out, [int(x) for x in sh.seed_ids[i]], sh.jobs_of(i)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
-    import ctypes as C
-
     import torch
     import torch.distributed as dist
 
     import bench
-    import util
-    from nextdenovo_amd import synth
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    h = C.CDLL(os.path.join(HERE, "csrc", "libndhost_test.so"))
-    fn, fr = util.bind_correct(h, "ndtest_correct", "ndtest_free")
-    g = synth.make_genome(12000, seed=42 + 1000 * rank, n_repeats=0)
-    rs = synth.simulate_reads(g, 25, "ont", seed=43 + 1000 * rank, mu=7.8, sigma=0.3)
-    piles = synth.build_piles(rs, seed_cutoff=1000)[:3]
-    bases = 0
-    for p in piles:
-        seqs, st, en, mal = synth.pile_sequences(rs, p)
-        ln, ide, _ = util.call_correct(fn, fr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal,
-                                                    max_lq=min(en[0] // 2, 10000), read_type=1, fast=0, split=0))
-        if ln > 4 and ide >= 0.8:
-            bases += ln
-    total, tmax = bench.reduce_over_ranks(dist, torch, bases, 1.0 + rank, "cpu")
-    q.put((rank, bases, total, tmax))
+    n_files, mine = bench.shard_of_rank(world, rank, 0, 0)
+    recs, seed_ids, jobs = _correct_file(mine, n_files)
+    bases = sum(ln for ln, _ in recs.values() if ln > 4)
+    total, tmax = bench.reduce_over_ranks(dist, torch, bases, 1.0 + rank, "cpu", len(recs))
+    q.put((rank, recs, seed_ids, jobs, bases, total, tmax, bench.reduce_over_ranks.seeds))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_reduce(host_harness):
+def test_two_ranks_share_one_read_set(host_harness, oracle_lib):
     import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = sorted(q.get(timeout=900) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    res.sort()
-    (r0, b0, t0, m0), (r1, b1, t1, m1) = res
-    assert b0 > 0 and b1 > 0 and b0 != b1          # different read sets per rank
-    assert t0 == t1 == b0 + b1                      # sum over ranks
-    assert m0 == m1 == 2.0                          # max over ranks
+    (_, rec0, ids0, jobs0, b0, t0, m0, s0), (_, rec1, ids1, jobs1, b1, t1, m1, s1) = res
+    # the two seed files partition the seeds, dealt alternately in read order
+    assert not set(ids0) & set(ids1) and sorted(ids0 + ids1) == list(range(len(ids0) + len(ids1)))
+    assert ids0 == list(range(0, len(ids0) + len(ids1), 2)) and ids1 == list(range(1, len(ids0) + len(ids1), 2))
+    # rank 0 runs (0, seed 0) and (0, seed 1); rank 1 needs the mirror (0, seed 1) and its own (1, seed 1): job order kept
+    assert [j[:4] for j in jobs0] == [(0, 0, "seed", 0), (1, 0, "seed", 1)]
+    assert [j[:4] for j in jobs1] == [(1, 0, "seed", 1), (2, 1, "seed", 1)]
+    assert b0 > 0 and b1 > 0 and t0 == t1 == b0 + b1 and m0 == m1 == 2.0 and s0 == s1 == len(rec0) + len(rec1)
+    # union of the ranks' records == one process correcting both seed files
+    single = {}
+    for i in range(2):
+        single.update(_correct_file(i, 2)[0])
+    both = dict(rec0)
+    both.update(rec1)
+    assert both == single and len(single) >= 6 and sum(1 for ln, _ in single.values() if ln > 1000) >= 6

@@ -96,3 +96,21 @@ def test_int64_kernel_agrees(default_run):
     assert a["stats"]["score_slow_piles"] == a["stats"]["piles"] and b["stats"]["score_slow_piles"] == 0
     pos = {s: i for i, s in enumerate(default_run["seeds"])}
     assert all(tuple(d) == tuple(default_run["digests"][pos[s]]) for s, d in zip(a["seeds"], a["digests"]))
+
+
+def test_sharded_stage_on_device_equals_oracle_backend(oracle_lib):
+    """nextdenovo_amd.stage.Shard (what bench.py --gpus N gives every rank) with three seed files: the device backend's piles
+    == the oracle backend's (overlap oracle + sort oracle, both pinned to the compiled reference), seed file by seed file."""
+    import stage_util
+    from nextdenovo_amd import stage, synth
+    g = synth.make_genome(60000, seed=5, n_repeats=0)
+    rs = synth.simulate_reads(g, 25, "ont", seed=6, mu=8.2, sigma=0.4)
+    words, word_off, lens = synth.pack_db(rs)
+    dev = stage.Shard(words, word_off, lens, n_seed_files=3, sort_k=20)
+    ora = stage.Shard(words, word_off, lens, n_seed_files=3, sort_k=20, backend=stage_util.OracleBackend(oracle_lib, "ava-ont"))
+    n_piles = 0
+    for i in range(3):
+        a, b = dev.piles(i), ora.piles(i)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+        n_piles += a[2].size
+    assert n_piles >= 10
