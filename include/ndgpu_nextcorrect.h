@@ -138,6 +138,9 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
 typedef struct ndgpu_db ndgpu_db;
 /* NULL when the DB does not fit the device memory */
 ndgpu_db *ndgpu_db_create(uint32_t n_reads, const uint32_t *words, const uint64_t *word_off, const uint32_t *len);
+/* The same DB from the files the stage already has: `idx_fofn` as given to `nextcorrect.py -f` (one `.NAME.idx` path per line;
+ * the `.2bit` next to each is read, as init_ovls() does: lib/ovlseq.c:24-37,50-138).  NULL on I/O / format errors. */
+ndgpu_db *ndgpu_db_open(const char *idx_fofn);
 void ndgpu_db_destroy(ndgpu_db *db);
 
 /* Correct piles given as overlap records against a resident DB: the batched

@@ -198,6 +198,65 @@ ndgpu_db *ndgpu_db_create(uint32_t n_reads, const uint32_t *words, const uint64_
     return h;
 }
 
+// init_ovls()'s view of the read DB (lib/ovlseq.c:50-138, lib/index.c:7-36): `idx_fofn` lists one `.idx` per line, the
+// `.2bit` of `/dir/.NAME.idx` is `/dir/NAME.2bit` (lib/ovlseq.c:24-37); a `.2bit` holds {0, 254}, then per read u32 id,
+// u32 length, ceil(length / 16) words (lib/bseq.c:93-139).  Read ids index the DB.  NULL on any I/O or format error.
+ndgpu_db *ndgpu_db_open(const char *idx_fofn) {
+    FILE *f = fopen(idx_fofn, "r");
+    if (!f) {
+        fprintf(stderr, "[ndgpu] ndgpu_db_open: cannot open %s\n", idx_fofn);
+        return nullptr;
+    }
+    std::vector<std::string> idx_files;
+    char line[4096];
+    while (fgets(line, sizeof(line), f)) {
+        std::string s(line);
+        while (!s.empty() && (s.back() == '\n' || s.back() == '\r' || s.back() == ' ')) s.pop_back();
+        if (!s.empty() && s[0] != '#') idx_files.push_back(s);
+    }
+    fclose(f);
+    std::vector<uint32_t> words, lens;
+    std::vector<uint64_t> word_off;
+    for (const std::string &idx : idx_files) {
+        const size_t slash = idx.find_last_of('/');
+        const std::string dir = slash == std::string::npos ? "" : idx.substr(0, slash + 1);
+        std::string name = slash == std::string::npos ? idx : idx.substr(slash + 1);
+        if (name.size() < 6 || name[0] != '.' || name.substr(name.size() - 4) != ".idx") {
+            fprintf(stderr, "[ndgpu] ndgpu_db_open: %s is not a .NAME.idx path\n", idx.c_str());
+            return nullptr;
+        }
+        const std::string path = dir + name.substr(1, name.size() - 5) + ".2bit";
+        FILE *b = fopen(path.c_str(), "rb");
+        if (!b) {
+            fprintf(stderr, "[ndgpu] ndgpu_db_open: cannot open %s\n", path.c_str());
+            return nullptr;
+        }
+        fseek(b, 0, SEEK_END);
+        const long sz = ftell(b);
+        fseek(b, 2, SEEK_SET);
+        const size_t nw = sz > 2 ? (size_t)(sz - 2) / 4 : 0;
+        const size_t base = words.size();
+        words.resize(base + nw);
+        if (nw && fread(words.data() + base, 4, nw, b) != nw) {
+            fclose(b);
+            fprintf(stderr, "[ndgpu] ndgpu_db_open: short read on %s\n", path.c_str());
+            return nullptr;
+        }
+        fclose(b);
+        for (size_t p = base; p + 2 <= base + nw;) {
+            const uint32_t id = words[p], ln = words[p + 1];
+            if (id >= lens.size()) {
+                lens.resize((size_t)id + 1, 0);
+                word_off.resize((size_t)id + 1, 0);
+            }
+            lens[id] = ln;
+            word_off[id] = p + 2;
+            p += 2 + (((size_t)ln + 15) >> 4);
+        }
+    }
+    return ndgpu_db_create((uint32_t)lens.size(), words.data(), word_off.data(), lens.data());
+}
+
 void ndgpu_db_destroy(ndgpu_db *h) {
     if (!h) return;
     join_reapers();
@@ -232,7 +291,8 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     join_reapers();  // the previous call's teardown
     const auto t_call0 = std::chrono::steady_clock::now();
     std::atomic<uint64_t> build_ns{0}, take_ns{0};
-    size_t sub = 384;
+    // piles per sub-batch at most (the cost target below normally cuts earlier)
+    size_t sub = 4096;
     if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
     // longest seeds first: the scoring DP is a sequential chain per seed, so similar lengths
     // share a launch and the long chains start early
@@ -246,24 +306,37 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     // sub-batches: at most `sub` piles and at most `tag_budget` estimated alignment columns each, so that the
     // device buffers of a context (sized by the largest sub-batch it has seen) stay bounded whatever the seed lengths
     uint64_t tag_budget = 900000000ull;
+    DeviceAligner::plan_memory(drivers, &tag_budget);  // what the device has free now decides it
     if (const char *e = getenv("NDGPU_SUBBATCH_TAGS")) tag_budget = std::max<uint64_t>(1000000ull, strtoull(e, nullptr, 10));
+    // Sub-batches = consecutive ranges of the length-sorted piles of (about) equal cost, two per context, pulled from one
+    // queue by whichever context is free.  Cost = estimated alignment columns (what every device phase and the host's
+    // low-quality-region stage scale with).  A context alternates device-heavy phases (alignment, MSA, scoring) with
+    // host-heavy ones (candidate ranking, POA, second MSA, splicing): with several sub-batches per context the phases of
+    // different contexts interleave instead of all contexts being on the host -- and the device idle -- at the end of a call.
+    // (Until round 2 the first sub-batches were small and held the longest seeds, because a seed's scoring chain bounded
+    // the call; the segment-parallel scoring DP removed that.)
     std::vector<size_t> sub_start{0};
     {
+        std::vector<uint64_t> est((size_t)n_piles);
+        uint64_t total = 0;
+        for (size_t k = 0; k < (size_t)n_piles; k++) {
+            const uint32_t pid = order[k];
+            uint64_t e = 0;
+            for (uint64_t r = pile_off[pid]; r < pile_off[pid + 1]; r++) e += (uint64_t)(recs[r * 8 + 3] - recs[r * 8 + 2] + 1);
+            est[k] = e + e / 6;
+            total += est[k];
+        }
+        int per_ctx = 2;  // (measured on config 2: 1, 2, 3, 4, 6 per context = 1147, 1095, 1181, 1269, 1376 ms per step)
+        if (const char *e = getenv("NDGPU_SUBBATCHES_PER_CONTEXT")) per_ctx = std::max(1, atoi(e));
+        const uint64_t piece = std::min<uint64_t>(tag_budget, std::max<uint64_t>(total / (uint64_t)(drivers * per_ctx) + 1, 2000000ull));
         uint64_t acc = 0;
         size_t cnt = 0;
         for (size_t k = 0; k < (size_t)n_piles; k++) {
-            const uint32_t pid = order[k];
-            uint64_t est = 0;
-            for (uint64_t r = pile_off[pid]; r < pile_off[pid + 1]; r++) est += (uint64_t)(recs[r * 8 + 3] - recs[r * 8 + 2] + 1);
-            est += est / 6;
-            // the first sub-batches are small (16, 32, 64, ... piles): they hold the longest seeds, whose scoring
-            // chains bound the whole call, so their alignment / MSA phases must not wait for hundreds of other piles
-            const size_t ramp = std::min<size_t>(sub, (size_t)16 << std::min<size_t>(sub_start.size() - 1, 16));
-            if (cnt && (cnt >= ramp || acc + est > tag_budget)) {
+            if (cnt && (cnt >= sub || acc + est[k] > piece)) {
                 sub_start.push_back(k);
                 acc = 0, cnt = 0;
             }
-            acc += est, cnt++;
+            acc += est[k], cnt++;
         }
         sub_start.push_back((size_t)n_piles);
     }
@@ -272,10 +345,6 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     int threads_each = std::max(1, host_threads / drivers);  // (measured: more threads per context is slower)
     if (const char *e = getenv("NDGPU_THREADS_PER_CONTEXT")) threads_each = std::max(1, atoi(e));
     CoreGovernor::set_total(getenv("NDGPU_NO_BORROW") ? 0 : host_threads);
-    // sub-batch j always goes to context j mod drivers: a context then sees the same sub-batch sizes call after call
-    // and its grow-only device buffers stop being re-allocated (a hipFree / hipMalloc stalls every context)
-    // (dealt in snake order -- 0..D-1, D-1..0, ... -- so that the context that got the longest chains of a round
-    // gets the lightest sub-batch of the next)
     std::atomic<uint64_t> oom_seeds{0};
     // one range of the length-sorted piles through one context; out of device memory -> the context's buffers are
     // dropped and the range is halved, down to a single pile, which is then an out-of-memory seed (len 3)
@@ -344,10 +413,11 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
         }
         take_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_t0).count();
     };
+    std::atomic<size_t> next_sub{0};
     auto drive = [&](int ctx) {
-        for (size_t round = 0; round * (size_t)drivers < n_sub; round++) {
-            const size_t sb = round * (size_t)drivers + (size_t)((round & 1) ? drivers - 1 - ctx : ctx);
-            if (sb >= n_sub) continue;
+        for (;;) {
+            const size_t sb = next_sub.fetch_add(1);
+            if (sb >= n_sub) break;
             run_range(ctx, sub_start[sb], sub_start[sb + 1] - sub_start[sb]);
         }
     };
@@ -355,6 +425,18 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     for (int c = 1; c < drivers; c++) th.emplace_back(drive, c);
     drive(0);
     for (auto &t : th) t.join();
+    // The contexts keep their buffers between calls (re-allocating them costs more than a small step).  When that leaves
+    // the device nearly full -- genome-scale read sets -- they are handed back, so that whatever runs between two calls
+    // (the next step's overlap stage builds a multi-GB index) finds memory; the next call's plan starts from what is free then.
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < total_b / 4) {
+            for (int c = 0; c < drivers; c++) DeviceAligner::context(c).release_memory();
+            if (getenv("NDGPU_TRACE"))
+                fprintf(stderr, "[ndgpu trace] %.1f of %.1f GB free after the call: the contexts' buffers are released\n",
+                        free_b / 1073741824.0, total_b / 1073741824.0);
+        }
+    }
     if (getenv("NDGPU_TRACE"))
         fprintf(stderr, "[ndgpu trace] correct_piles %d piles in %zu sub-batches: %.1f ms wall | engine build %.1f ms, result take %.1f ms (summed over contexts)\n",
                 n_piles, n_sub, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_call0).count() * 1e-3,

@@ -7,6 +7,7 @@
 // no host round trip between the forward sweep and the traceback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -58,6 +59,19 @@ static inline bool oom_injected(size_t bytes) {
     return lim && bytes > lim;
 }
 
+static std::atomic<long long> g_dev_bytes{0};  // device memory held by the grow-only buffers of all contexts
+// The runtime itself allocates on the device (kernel arguments, staging, scratch): a device filled to the last byte makes
+// launches and copies fail where nothing can be done about it.  Allocations that would leave less than this are refused
+// like an exhausted device (-> DeviceOom -> the sub-batch is halved).
+constexpr size_t kDeviceHeadroom = (size_t)3 << 30;
+static inline hipError_t guarded_malloc(void **p, size_t bytes) {
+    if (oom_injected(bytes)) return hipErrorOutOfMemory;
+    size_t free_b = 0, total_b = 0;
+    if (bytes > ((size_t)64 << 20) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < bytes + kDeviceHeadroom)
+        return hipErrorOutOfMemory;
+    return hipMalloc(p, bytes);
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -68,14 +82,15 @@ struct DevBuf {
         if (p) {
             if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] free %s %p\n", name, (void *)p);
             if (!g_debug_nofree) HIP_CHECK(hipFree(p));
+            g_dev_bytes -= (long long)(cap * sizeof(T));
         }
         p = nullptr;
         cap = 0;
         size_t want = n + n / 4 + 1024;
-        hipError_t rc = oom_injected(want * sizeof(T)) ? hipErrorOutOfMemory : hipMalloc((void **)&p, want * sizeof(T));
+        hipError_t rc = guarded_malloc((void **)&p, want * sizeof(T));
         if (rc == hipErrorOutOfMemory && want > n + 1024) {  // without the growth slack
             want = n + 1024;
-            rc = oom_injected(want * sizeof(T)) ? hipErrorOutOfMemory : hipMalloc((void **)&p, want * sizeof(T));
+            rc = guarded_malloc((void **)&p, want * sizeof(T));
         }
         if (rc == hipErrorOutOfMemory) {
             (void)hipGetLastError();
@@ -84,17 +99,24 @@ struct DevBuf {
         }
         HIP_CHECK(rc);
         cap = want;
+        g_dev_bytes += (long long)(cap * sizeof(T));
         if (g_debug_alloc)
             fprintf(stderr, "[ndgpu alloc] %s %p .. %p (%zu bytes, asked %zu)\n", name, (void *)p, (void *)((char *)p + want * sizeof(T)),
                     want * sizeof(T), n * sizeof(T));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipFree(p);
+            g_dev_bytes -= (long long)(cap * sizeof(T));
+        }
         p = nullptr;
         cap = 0;
     }
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipFree(p);
+            g_dev_bytes -= (long long)(cap * sizeof(T));
+        }
     }
 };
 
@@ -429,6 +451,29 @@ void DeviceAligner::release_memory() {
     NDGPU_REL(d_bt_off) NDGPU_REL(d_path) NDGPU_REL(d_blocks) NDGPU_REL(d_regions) NDGPU_REL(d_strpool) NDGPU_REL(d_cursor)
     NDGPU_REL(h_ops) NDGPU_REL(h_outs) NDGPU_REL(up) NDGPU_REL(down)
 #undef NDGPU_REL
+}
+
+// How much of the device the consensus contexts may use, decided at the start of every batch call from what is free NOW
+// (the overlap library's cache, the read DB and everything else stay where they are) plus what the contexts already
+// hold: per context a trace budget (the forward / traceback chunk size) and a budget of alignment columns per sub-batch
+// (~40 bytes of tags, column indexes, link tables and cell tables per column, growth slack included).
+void DeviceAligner::plan_memory(int drivers, uint64_t *tag_budget) {
+    size_t free_b = 0, total_b = 0;
+    const int dev = context(0).device();
+    (void)hipSetDevice(dev);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const long long held = g_dev_bytes.load();
+    long long avail = (long long)free_b + held - (long long)((size_t)10 << 30);  // headroom: runtime, pinned staging, the next overlap stage's growth
+    if (const char *e = getenv("NDGPU_DEVICE_BUDGET_GB")) avail = std::min<long long>(avail, atoll(e) << 30);
+    if (avail < ((long long)4 << 30)) avail = (long long)4 << 30;
+    const long long per_ctx = avail / std::max(1, drivers);
+    const size_t trace = (size_t)std::min<long long>((long long)8 << 30, std::max<long long>(per_ctx / 5, (long long)256 << 20));
+    const long long cols = (per_ctx - (long long)trace - ((long long)1 << 30)) / 40;
+    *tag_budget = (uint64_t)std::min<long long>(900000000ll, std::max<long long>(20000000ll, cols));
+    for (int i = 0; i < drivers && i < kMaxContexts; i++) context(i).s_->trace_budget_bytes = trace;
+    if (getenv("NDGPU_TRACE"))
+        fprintf(stderr, "[ndgpu trace] memory plan: %.1f GB free + %.1f GB held by the contexts -> %d contexts x (%.1f GB trace + %llu M columns)\n",
+                free_b / 1073741824.0, held / 1073741824.0, drivers, trace / 1073741824.0, (unsigned long long)(*tag_budget / 1000000));
 }
 
 void *DeviceAligner::stream() const { return s_->stream; }
@@ -1001,7 +1046,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_ent_pp.reserve(ents + 1);
     S.d_ent_ppp.reserve(ents + 1);
     S.d_ent_cnt.reserve(ents + 1);
-    S.d_ent_score.reserve(ents + 1);
+    // (d_ent_score, 8 bytes per link, belongs to the int64 kernel: allocated only when a pile needs it -- see the rescue pass)
     S.d_path.reserve(paths + 1);
     S.d_blocks.reserve(blocks.size() + 1);
     S.d_cell_best.reserve(cells + 1);
@@ -1052,7 +1097,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             HIP_CHECK(hipEventRecord(S.evs[3], sst));
         }
         launch_score_backtrack(ka, S.d_items.p, (int)items_small.size(), S.d_items.p + items_small.size(), (int)items_large.size(),
-                               S.d_items.p, (int)n_items_all, S.d_ent_score.p, S.d_path.p, S.d_bt_exit.p, S.d_bt_steps.p,
+                               S.d_items.p, (int)n_items_all, S.d_ent_score.cap >= ents + 1 ? S.d_ent_score.p : nullptr, false,
+                               S.d_path.p, S.d_bt_exit.p, S.d_bt_steps.p,
                                S.d_bt_entry.p, S.d_bt_off.p, (int)np, sst, S.evs[7], on_reserved ? nullptr : S.stream2, S.ev_fork,
                                S.ev_join);
         HIP_CHECK(hipEventRecord(S.evs[4], sst));
@@ -1061,13 +1107,29 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             HIP_CHECK(hipEventRecord(S.ev_lat1, sst));
             HIP_CHECK(hipStreamWaitEvent(st, S.ev_lat1, 0));
         }
-        const void *v_piles = S.d2h(nullptr, S.d_piles.p, np * sizeof(PileDev), st);
+        const void *v_piles = S.d2h(nullptr, S.d_piles.p, np * sizeof(PileDev), st);  // (re-taken by the rescue pass)
         hpath = (const PathItem *)S.d2h(nullptr, S.d_path.p, paths * sizeof(PathItem), st);
         const void *v_err = S.d2h(nullptr, S.d_err.p, sizeof(herr), st);
         HIP_CHECK(hipStreamSynchronize(st));
         HIP_CHECK(hipGetLastError());
         memcpy(piles_out.data(), v_piles, np * sizeof(PileDev));
         memcpy(herr, v_err, sizeof(herr));
+        // rescue pass: piles the segment kernels handed to the int64 HBM-resident kernel (err == 2: a column wider than the
+        // LDS tables, raw scores out of the int32 working range) when its 8-byte-per-link score array was not there yet
+        bool rescue = false;
+        for (size_t p = 0; p < np; p++) rescue = rescue || piles_out[p].err == 2;
+        if (rescue) {
+            S.d_ent_score.reserve(ents + 1);
+            launch_score_backtrack(ka, nullptr, 0, nullptr, 0, S.d_items.p, (int)n_items_all, S.d_ent_score.p, true, S.d_path.p,
+                                   S.d_bt_exit.p, S.d_bt_steps.p, S.d_bt_entry.p, S.d_bt_off.p, (int)np, st, nullptr, nullptr, nullptr,
+                                   nullptr);
+            S.reserve_down(np * sizeof(PileDev) + paths * sizeof(PathItem) + 1024, st);
+            v_piles = S.d2h(nullptr, S.d_piles.p, np * sizeof(PileDev), st);
+            hpath = (const PathItem *)S.d2h(nullptr, S.d_path.p, paths * sizeof(PathItem), st);
+            HIP_CHECK(hipStreamSynchronize(st));
+            HIP_CHECK(hipGetLastError());
+            memcpy(piles_out.data(), v_piles, np * sizeof(PileDev));
+        }
         static const bool force_retry = getenv("NDGPU_K9_FORCE_RETRY") != nullptr;  // test hook: take the overflow path
         if ((!herr[0] && !force_retry) || attempt || S.k9_full_capacity) break;
         S.k9_retries++;

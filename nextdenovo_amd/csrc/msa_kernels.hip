@@ -1496,7 +1496,7 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
 }
 
 void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_small, const SegItem *items_large, int n_large,
-                            const SegItem *items_all, int n_all, long long *ent_score, PathItem *path, uint32_t *bt_exit,
+                            const SegItem *items_all, int n_all, long long *ent_score, bool rescue, PathItem *path, uint32_t *bt_exit,
                             uint32_t *bt_steps, uint32_t *bt_entry, uint32_t *bt_off, int n_piles, void *stream,
                             void *ev_after_fast, void *stream_large, void *ev_fork, void *ev_join) {
     if (n_piles <= 0) return;
@@ -1510,8 +1510,8 @@ void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_
         fflush(stderr);
     };
     mark("begin");
-    const bool forked = n_large > 0 && stream_large && stream_large != stream;
-    if (n_large > 0) {  // the piles that need the large tables are scored at the same time on a second stream
+    const bool forked = !rescue && n_large > 0 && stream_large && stream_large != stream;
+    if (!rescue && n_large > 0) {  // the piles that need the large tables are scored at the same time on a second stream
         hipStream_t s2 = forked ? (hipStream_t)stream_large : st;
         if (forked) {
             (void)hipEventRecord((hipEvent_t)ev_fork, st);
@@ -1522,14 +1522,16 @@ void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_
         if (forked) (void)hipEventRecord((hipEvent_t)ev_join, s2);
     }
     mark("large tier launched");
-    if (n_small > 0)
+    if (!rescue && n_small > 0)
         hipLaunchKernelGGL((score_seg_kernel<kColCellsSmall, kColEntsSmall>), dim3((unsigned)n_small), dim3(192), 0, st, a, items_small);
     mark("small seg done");
-    hipLaunchKernelGGL((score_stitch_kernel<kColCellsSmall, kColEntsSmall, false>), dim3((unsigned)n_piles), dim3(192), 0, st, a);
+    if (!rescue)
+        hipLaunchKernelGGL((score_stitch_kernel<kColCellsSmall, kColEntsSmall, false>), dim3((unsigned)n_piles), dim3(192), 0, st, a);
     mark("small stitch done");
     if (forked) (void)hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0);
     if (ev_after_fast) (void)hipEventRecord((hipEvent_t)ev_after_fast, st);
-    hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, a.piles, a.coverage, a.max_size,
+    if (ent_score)  // (nullptr: the int64 kernel's score array is not allocated; piles left at err == 2 get the rescue pass)
+        hipLaunchKernelGGL(score_slow_kernel, dim3((unsigned)n_piles), dim3(64), 0, st, a.piles, a.coverage, a.max_size,
                        a.cell_base, a.cell_start, a.cell_len, a.ent_pp, a.ent_ppp, a.ent_cnt, ent_score, a.cell_best_pp,
                        a.cell_best_link);
     mark("slow done");

@@ -180,10 +180,11 @@ void launch_count_links(const PileDev *piles, const ReadDev *reads, const uint32
                         void *stream);
 // segment kernels of both table tiers (the large one on stream_large at the same time) -> stitch -> int64 kernel for
 // the piles they left (err == 2) -> best_pp walk
-// then the best_pp walk, cut at the same segments: items_all = every (pile, segment) of the launch, bt_exit / bt_steps =
+// (ent_score == nullptr: the int64 kernel is not launched and leaves err == 2 piles for a second call with rescue = true,
+// which launches only that kernel and the walk) then the best_pp walk, cut at the same segments: items_all = every (pile, segment) of the launch, bt_exit / bt_steps =
 // kBtSlots entries per segment, bt_entry / bt_off = one per segment
 void launch_score_backtrack(const K10Args &a, const SegItem *items_small, int n_small, const SegItem *items_large, int n_large,
-                            const SegItem *items_all, int n_all, long long *ent_score, PathItem *path, uint32_t *bt_exit,
+                            const SegItem *items_all, int n_all, long long *ent_score, bool rescue, PathItem *path, uint32_t *bt_exit,
                             uint32_t *bt_steps, uint32_t *bt_entry, uint32_t *bt_off, int n_piles, void *stream,
                             void *ev_after_fast, void *stream_large, void *ev_fork, void *ev_join);
 constexpr int kBtSlots = 192;

@@ -54,6 +54,8 @@ class DeviceAligner {
     static DeviceAligner &context(int i);
     static DeviceAligner *peek(int i);  // nullptr if context i was never used
     static RuntimeStats total_stats();
+    // device memory plan of one batch call over `drivers` contexts: sets their trace budgets, returns the column budget of a sub-batch
+    static void plan_memory(int drivers, uint64_t *tag_budget);
     static void reset_all_stats();
     void align_batch(AlnJob **jobs, size_t n);
     // device main phase / candidate extraction of a batch of piles (see Backend in nd_host.h);

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <type_traits>
 
 #include "nd_device.h"
 
@@ -37,13 +38,25 @@ __device__ __forceinline__ uint32_t fetch16(const uint32_t *__restrict__ pool, u
     return (uint32_t)(v >> s);
 }
 
+// maximum over the 64 lanes (all of them active) with data-parallel-primitive moves instead of six LDS permutes: the
+// forward kernel is bound by instruction issue, and this reduction sits on every edit step
+__device__ __forceinline__ uint32_t fetch16_rel(const uint32_t *__restrict__ seq, uint32_t pos) {  // pos: base index from seq's first word
+    const uint64_t v = *(const u64_a4 *)(seq + (pos >> 4));
+    return (uint32_t)(v >> ((pos & 15u) * 2u));
+}
+
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
+    auto step = [](int x, auto ctrl, auto rows) {
+        const int y = __builtin_amdgcn_update_dpp(INT_MIN, x, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+        return y > x ? y : x;
+    };
+    v = step(v, std::integral_constant<int, 0xb1>{}, std::integral_constant<int, 0xf>{});   // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4e>{}, std::integral_constant<int, 0xf>{});   // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});  // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});  // row_mirror: every row of 16 reduced
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 template <bool WIDE>
@@ -69,10 +82,12 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
     int d_steps = 0, max_band = 0;
     long long cells = 0;
     const int q_len = T.q_len, t_len = T.t_len;
-    // bit 63 of an offset selects the resident read DB instead of the per-batch pool
-    const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
-    const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
+    // bit 63 of an offset selects the resident read DB instead of the per-batch pool; inside the kernel a base is addressed
+    // by a 32-bit word index relative to its sequence's first word (a sequence is < 2^31 bases)
     const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
+    const uint32_t *__restrict__ qp = ((T.q_off >> 63) ? db_pool : pool) + (q_off >> 4);
+    const uint32_t *__restrict__ tp = ((T.t_off >> 63) ? db_pool : pool) + (t_off >> 4);
+    const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
     const uint64_t row0 = T.trace_off, mk0 = T.mink_off;
     const uint32_t row_words = WIDE ? T.row_words : (uint32_t)kFastRowWords;
 
@@ -111,8 +126,8 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
                     const int rt = t_len - y;
                     rem = rt < rem ? rt : rem;
                     if (rem <= 0) break;
-                    const uint32_t a = fetch16(qp, q_off + (uint64_t)(uint32_t)x);
-                    const uint32_t b = fetch16(tp, t_off + (uint64_t)(uint32_t)y);
+                    const uint32_t a = fetch16_rel(qp, q_sh + (uint32_t)x);
+                    const uint32_t b = fetch16_rel(tp, t_sh + (uint32_t)y);
                     const uint32_t diff = a ^ b;
                     int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
                     m = m < rem ? m : rem;

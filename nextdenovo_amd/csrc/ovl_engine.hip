@@ -72,12 +72,26 @@ void *pool_alloc(size_t bytes)
 	return p;
 }
 
+// the cache may hold this much (NDGPU_OVL_POOL_GB, default 24): what comes back beyond it is freed at once, so that a
+// genome-scale index build does not leave the whole HBM parked in size classes nobody asks for again while the consensus
+// contexts run out of memory
+static size_t pool_cap()
+{
+	static const size_t cap = (size_t)(getenv("NDGPU_OVL_POOL_GB") ? atof(getenv("NDGPU_OVL_POOL_GB")) : 24.0) << 30;
+	return cap;
+}
+
 void pool_free(void *p)
 {
 	if (!p) return;
 	std::lock_guard<std::mutex> g(g_pool_mu);
 	auto it = g_pool_size.find(p);
 	if (it == g_pool_size.end()) { (void)hipFree(p); return; }
+	if (g_pool_cached + it->second > pool_cap()) {
+		(void)hipFree(p);
+		g_pool_size.erase(it);
+		return;
+	}
 	g_pool_free.emplace(it->second, p);
 	g_pool_cached += it->second;
 }
@@ -778,6 +792,14 @@ int64_t ndgpu_2bit_index(const uint32_t *w, uint64_t n_words, uint32_t *ids, uin
 }
 
 void ndgpu_ovl_free(void *p) { free(p); }
+
+// release the device blocks the library keeps cached between calls (returns the bytes released)
+uint64_t ndgpu_ovl_trim(void)
+{
+	const uint64_t b = ndovl::pool_cached_bytes();
+	ndovl::pool_trim();
+	return b;
+}
 
 int64_t ndgpu_pack_2bit(uint32_t n_reads, const uint8_t *ascii, uint64_t n_bytes, const uint64_t *ascii_off, const uint32_t *lens,
                         const uint64_t *word_off, uint32_t *words)

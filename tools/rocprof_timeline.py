@@ -55,3 +55,34 @@ print("# %s: window %.1f ms, some kernel running %.1f ms (%.0f %%), mean kernels
 print("%-58s %7s %12s %12s %7s" % ("kernel", "calls", "sum_ms", "share_ms", "share%"))
 for n in sorted(share, key=lambda k: -share[k]):
     print("%-58s %7d %12.2f %12.2f %7.2f" % (n, calls[n], tot[n] * 1e-6, share[n] * 1e-6, 100.0 * share[n] / wall))
+
+# coarse timeline: per bin the share of time with a kernel running, mean kernels in flight, and the kernels that own the bin
+BIN = 25e6
+nb = int((T1 - T0) / BIN) + 1
+busy = [0.0] * nb
+conc = [0.0] * nb
+own = [defaultdict(float) for _ in range(nb)]
+live = set()
+prev = ev[0][0]
+for t, k, i in ev:
+    if t > prev and live:
+        a = prev
+        while a < t:
+            b_i = int((a - T0) / BIN)
+            e = min(t, T0 + (b_i + 1) * BIN)
+            if 0 <= b_i < nb:
+                busy[b_i] += e - a
+                conc[b_i] += (e - a) * len(live)
+                for j in live:
+                    own[b_i][short(rows[j][0])[:22]] += (e - a) / len(live)
+            a = e
+    prev = t
+    if k > 0:
+        live.add(i)
+    else:
+        live.discard(i)
+print("\n# timeline, %d ms bins: busy %%, kernels in flight while busy, owners (share of the bin)" % (BIN / 1e6))
+for b_i in range(nb):
+    top = sorted(own[b_i].items(), key=lambda kv: -kv[1])[:4]
+    print("%7.0f ms  %3.0f%%  %4.1f  %s" % (b_i * BIN / 1e6, 100.0 * busy[b_i] / BIN, conc[b_i] / max(busy[b_i], 1),
+                                          "  ".join("%s %.0f%%" % (n, 100.0 * v / BIN) for n, v in top)))
