@@ -87,7 +87,8 @@ int64_t ndgpu_ovl_decode(const uint8_t *buf, uint64_t n_bytes, uint32_t prev[2],
 int64_t ndgpu_2bit_index(const uint32_t *words, uint64_t n_words, uint32_t *ids, uint32_t *lens, uint64_t *word_off, int64_t cap);
 
 void ndgpu_ovl_free(void *p);
-/* The library keeps freed device blocks cached between calls (at most NDGPU_OVL_POOL_GB, default 24); this releases them.
+/* The library keeps freed device blocks cached between calls (at most 1.25 x the most it ever had in use at once, and
+ * NDGPU_OVL_POOL_GB if set); this releases them.
  * Returns the bytes released. */
 uint64_t ndgpu_ovl_trim(void);
 

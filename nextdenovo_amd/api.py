@@ -204,6 +204,13 @@ def stats() -> dict:
     return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
 
 
+def release_device_memory() -> int:
+    """Hand the consensus contexts' device buffers back (ndgpu_release_memory); returns the bytes released."""
+    lib = load()
+    lib.ndgpu_release_memory.restype = C.c_uint64
+    return int(lib.ndgpu_release_memory())
+
+
 def reset_stats():
     load().ndgpu_reset_stats()
 

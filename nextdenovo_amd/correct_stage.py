@@ -51,19 +51,23 @@ class _IndexCache:
     """The index parts of one target file, built on first use and shared by every job that maps against it."""
 
     def __init__(self, opt, target):
-        self.opt, self.target, self.parts, self.mid_occ = opt, target, {}, opt.mid_occ
+        self.opt, self.target, self.parts, self.mid_occ = opt, target, {}, {}
 
     def map(self, query, batch_size, dual):
         o = overlap.Opt.from_buffer_copy(self.opt)
         o.no_dual = 0 if dual else 1
         out = []
-        for lo, hi in minimap2_nd.index_parts(self.target.lens, batch_size):
+        layout = minimap2_nd.index_parts(self.target.lens, batch_size)
+        # every reference job is its own process: its occurrence threshold comes from the FIRST index part of ITS -I
+        # split (main.c:489, options.c:70-71) -- kept per split layout, not per target file
+        key = tuple(layout)
+        for lo, hi in layout:
             ix = self.parts.get((lo, hi))
             if ix is None:
                 ix = self.parts[(lo, hi)] = overlap.Index(self.opt, self.target.subset(lo, hi))
-            if self.mid_occ <= 0:
-                self.mid_occ = ix.mid_occ()  # the first part's threshold is kept (options.c:70-71)
-            out.append(ix.map(query, self.mid_occ, opt=o))
+            if key not in self.mid_occ:
+                self.mid_occ[key] = self.opt.mid_occ if self.opt.mid_occ > 0 else ix.mid_occ()
+            out.append(ix.map(query, self.mid_occ[key], opt=o))
         return np.concatenate(out) if len(out) > 1 else out[0]
 
     def close(self):

@@ -292,7 +292,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     const auto t_call0 = std::chrono::steady_clock::now();
     std::atomic<uint64_t> build_ns{0}, take_ns{0};
     // piles per sub-batch at most (the cost target below normally cuts earlier)
-    size_t sub = 4096;
+    size_t sub = 384;
     if (const char *e = getenv("NDGPU_SUBBATCH")) sub = (size_t)std::max(1, atoi(e));
     // longest seeds first: the scoring DP is a sequential chain per seed, so similar lengths
     // share a launch and the long chains start early
@@ -425,18 +425,6 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     for (int c = 1; c < drivers; c++) th.emplace_back(drive, c);
     drive(0);
     for (auto &t : th) t.join();
-    // The contexts keep their buffers between calls (re-allocating them costs more than a small step).  When that leaves
-    // the device nearly full -- genome-scale read sets -- they are handed back, so that whatever runs between two calls
-    // (the next step's overlap stage builds a multi-GB index) finds memory; the next call's plan starts from what is free then.
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < total_b / 4) {
-            for (int c = 0; c < drivers; c++) DeviceAligner::context(c).release_memory();
-            if (getenv("NDGPU_TRACE"))
-                fprintf(stderr, "[ndgpu trace] %.1f of %.1f GB free after the call: the contexts' buffers are released\n",
-                        free_b / 1073741824.0, total_b / 1073741824.0);
-        }
-    }
     if (getenv("NDGPU_TRACE"))
         fprintf(stderr, "[ndgpu trace] correct_piles %d piles in %zu sub-batches: %.1f ms wall | engine build %.1f ms, result take %.1f ms (summed over contexts)\n",
                 n_piles, n_sub, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_call0).count() * 1e-3,
@@ -620,6 +608,16 @@ void ndgpu_get_stats(ndgpu_stats *o) {
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }
+
+uint64_t ndgpu_release_memory(void) {
+    size_t f0 = 0, f1 = 0, t = 0;
+    (void)hipMemGetInfo(&f0, &t);
+    join_reapers();
+    for (int c = 0; c < DeviceAligner::kMaxContexts; c++)
+        if (DeviceAligner *d = DeviceAligner::peek(c)) d->release_memory();
+    (void)hipMemGetInfo(&f1, &t);
+    return f1 > f0 ? (uint64_t)(f1 - f0) : 0;
+}
 
 int ndgpu_device_count(void) {
     int n = 0;

@@ -54,6 +54,8 @@ void *pool_alloc(size_t bytes)
 			void *p = it->second;
 			g_pool_free.erase(it);
 			g_pool_cached -= c;
+			g_pool_live += c;
+			if (g_pool_live > g_pool_peak) g_pool_peak = g_pool_live;
 			return p;
 		}
 	}
@@ -69,15 +71,19 @@ void *pool_alloc(size_t bytes)
 	}
 	std::lock_guard<std::mutex> g(g_pool_mu);
 	g_pool_size[p] = c;
+	g_pool_live += c;
+	if (g_pool_live > g_pool_peak) g_pool_peak = g_pool_live;
 	return p;
 }
 
-// the cache may hold this much (NDGPU_OVL_POOL_GB, default 24): what comes back beyond it is freed at once, so that a
-// genome-scale index build does not leave the whole HBM parked in size classes nobody asks for again while the consensus
-// contexts run out of memory
+// What the cache may hold: blocks come back in many size classes (every query batch asks for slightly different sizes),
+// and a cache that keeps them all ends up owning the whole HBM while the consensus contexts starve.  The cache is therefore
+// bounded by the library's own working set: live + cached bytes stay below 1.25 x the most that was ever live at once
+// (and below NDGPU_OVL_POOL_GB if that is set); what comes back beyond it is freed at once.
+static size_t g_pool_live = 0, g_pool_peak = 0;
 static size_t pool_cap()
 {
-	static const size_t cap = (size_t)(getenv("NDGPU_OVL_POOL_GB") ? atof(getenv("NDGPU_OVL_POOL_GB")) : 24.0) << 30;
+	static const size_t cap = getenv("NDGPU_OVL_POOL_GB") ? (size_t)atof(getenv("NDGPU_OVL_POOL_GB")) << 30 : ~(size_t)0;
 	return cap;
 }
 
@@ -87,7 +93,8 @@ void pool_free(void *p)
 	std::lock_guard<std::mutex> g(g_pool_mu);
 	auto it = g_pool_size.find(p);
 	if (it == g_pool_size.end()) { (void)hipFree(p); return; }
-	if (g_pool_cached + it->second > pool_cap()) {
+	g_pool_live -= it->second;
+	if (g_pool_live + g_pool_cached + it->second > g_pool_peak + g_pool_peak / 4 || g_pool_cached + it->second > pool_cap()) {
 		(void)hipFree(p);
 		g_pool_size.erase(it);
 		return;

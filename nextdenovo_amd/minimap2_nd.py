@@ -83,18 +83,21 @@ def parse_argv(argv) -> Args:
 
 
 def build_opt(a: Args) -> overlap.Opt:
+    # first pass, as minimap2/main.c:185-200 does: -x and --step before everything else, so that --step's minlen = 500
+    # default never overrides an explicit --minlen, wherever that appears on the command line
     for name, val in a.ops:
         if name == "-x":
             a.preset = val
     opt = overlap.preset(a.preset)  # raises for unsupported presets
     for name, val in a.ops:
-        if name == "-x" or name == "-t":
-            continue
-        elif name == "--step":
+        if name == "--step":
             a.step = int(val)
             if a.step != 1:
                 raise SystemExit("[ERROR] only --step 1 is built in this engine")
             opt.minlen = 500
+    for name, val in a.ops:
+        if name in ("-x", "-t", "--step"):
+            continue
         elif name == "--dual":
             opt.no_dual = 0 if yes_no(val) else 1
         elif name == "-X":

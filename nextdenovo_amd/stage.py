@@ -121,7 +121,18 @@ class Shard:
     def piles(self, i, files=None):
         """(records [n, 8] uint32, pile_off, seed ids, blacklisted) of seed file i: what `nextcorrect.py -i sorted.ovl` corrects."""
         import time
-        files = self.overlaps(i) if files is None else files
+        if files is None:
+            try:
+                files = self.overlaps(i)
+            except RuntimeError:
+                # the overlap stage ran out of device memory: the consensus contexts still hold the buffers of the last call
+                # (they keep them between calls on purpose).  Hand those back and run the stage once more.
+                from . import api
+                if isinstance(self.backend, DeviceBackend) and api.release_device_memory() > 0:
+                    overlap.trim()
+                    files = self.overlaps(i)
+                else:
+                    raise
         t0 = time.perf_counter()
         seed_len = np.zeros(self.lens.size, dtype=np.uint32)
         sid = self.seed_ids[i]

@@ -146,6 +146,9 @@ def test_minimap2_nd_cli_host_logic():
     a = m.parse_argv("-x ava-pb --step 1 -f 0.0005 --minlen 1k a b".split())
     o = m.build_opt(a)
     assert (o.no_dual, o.mid_occ, o.minlen, o.hpc) == (1, 0, 1000, 1) and abs(o.mid_occ_frac - 0.0005) < 1e-9
+    # --step is handled before the ordered options (main.c:185-200): its minlen default never overrides an explicit --minlen
+    assert m.build_opt(m.parse_argv("-x ava-ont --minlen 1000 --step 1 a b".split())).minlen == 1000
+    assert m.build_opt(m.parse_argv("--step 1 -x ava-ont a b".split())).minlen == 500
     assert m.parse_num("4G") == 4000000000 and m.parse_num("150k") == 150000 and m.parse_num("2.5m") == 2500000
     lens = np.asarray([60, 60, 60, 60, 60, 10], dtype=np.uint32)
     assert m.index_parts(lens, 100, mini_batch=50) == [(0, 2), (2, 4), (4, 6)]   # a part closes once its total exceeds -I

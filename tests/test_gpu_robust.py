@@ -26,8 +26,8 @@ def _driver(env_extra, genome=300000, depth=30):
 def test_out_of_device_memory_is_survived():
     want, _ = _driver({})
     assert len(want["digests"]) > 50 and all(d[0] > 4 for d in want["digests"])
-    # allocations above 192 MB fail: whole sub-batches do not fit, halves / quarters do -> identical records
-    got, err = _driver({"NDGPU_OOM_ABOVE": str(192 << 20)})
+    # one sub-batch of all piles, allocations above 100 MB fail: it does not fit, its halves / quarters / ... do -> identical records
+    got, err = _driver({"NDGPU_OOM_ABOVE": str(100 << 20), "NDGPU_CONTEXTS": "1", "NDGPU_SUBBATCHES_PER_CONTEXT": "1"})
     assert "out of device memory" in err and "halved" in err
     same = sum(1 for a, b in zip(got["digests"], want["digests"]) if a == b)
     oom = sum(1 for a in got["digests"] if a[0] == 3)
