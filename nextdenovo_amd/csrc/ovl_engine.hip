@@ -34,6 +34,7 @@ std::mutex g_pool_mu;
 std::multimap<size_t, void*> g_pool_free;        // size class -> block
 std::unordered_map<void*, size_t> g_pool_size;   // live + cached blocks -> size class
 size_t g_pool_cached = 0;
+size_t g_pool_live = 0, g_pool_peak = 0;         // bytes handed out now / the most that ever were
 size_t size_class(size_t b)
 {
 	if (b < 4096) return 4096;
@@ -80,7 +81,6 @@ void *pool_alloc(size_t bytes)
 // and a cache that keeps them all ends up owning the whole HBM while the consensus contexts starve.  The cache is therefore
 // bounded by the library's own working set: live + cached bytes stay below 1.25 x the most that was ever live at once
 // (and below NDGPU_OVL_POOL_GB if that is set); what comes back beyond it is freed at once.
-static size_t g_pool_live = 0, g_pool_peak = 0;
 static size_t pool_cap()
 {
 	static const size_t cap = getenv("NDGPU_OVL_POOL_GB") ? (size_t)atof(getenv("NDGPU_OVL_POOL_GB")) << 30 : ~(size_t)0;

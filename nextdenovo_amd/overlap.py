@@ -149,7 +149,10 @@ class Index:
 
     def mid_occ(self, frac=None) -> int:
         f = self.opt.mid_occ_frac if frac is None else frac
-        return int(self.lib.ndgpu_ovl_index_mid_occ(self.h, np.float32(f)))
+        m = int(self.lib.ndgpu_ovl_index_mid_occ(self.h, np.float32(f)))
+        if m < 0:  # (a threshold of -1 would silently filter every minimizer: no overlaps at all)
+            raise RuntimeError("ndgpu_ovl_index_mid_occ failed (%d): out of device memory?" % m)
+        return m
 
     def dump(self):
         s = self.stat()

@@ -122,14 +122,18 @@ class Shard:
         """(records [n, 8] uint32, pile_off, seed ids, blacklisted) of seed file i: what `nextcorrect.py -i sorted.ovl` corrects."""
         import time
         if files is None:
+            from . import api
+            if getattr(self, "_release_first", False):
+                api.release_device_memory()   # learned below: on this device the two stages do not fit side by side
             try:
                 files = self.overlaps(i)
             except RuntimeError:
                 # the overlap stage ran out of device memory: the consensus contexts still hold the buffers of the last call
-                # (they keep them between calls on purpose).  Hand those back and run the stage once more.
-                from . import api
+                # (they keep them between calls on purpose).  Hand those back, run the stage once more, and from now on hand
+                # them back before the stage starts instead of finding out halfway through it.
                 if isinstance(self.backend, DeviceBackend) and api.release_device_memory() > 0:
                     overlap.trim()
+                    self._release_first = True
                     files = self.overlaps(i)
                 else:
                     raise
