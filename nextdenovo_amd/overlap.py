@@ -276,53 +276,12 @@ def sort_overlaps(files, seed_len: np.ndarray, min_seed_len: int, max_bin_cov: i
     n = (lib.ndgpu_ovl_sort_hq if hq else lib.ndgpu_ovl_sort)(ptrs, cnts, nf, _ptr(seed_len), seed_len.size, int(min_seed_len), int(max_bin_cov), int(max_flank_len),
                            C.byref(out), C.byref(bid), C.byref(bkind), C.byref(nbl), C.byref(st))
     if n < 0:
-        raise RuntimeError({-1: "ndgpu_ovl_sort: no usable HIP device", -2: "ndgpu_ovl_sort: out of device memory (partition the input: "
-                            "sort_overlaps_partitioned / ovl_sort -m)", -3: "ndgpu_ovl_sort: more than 2^31 candidate overlaps in one call "
-                            "(partition the input: sort_overlaps_partitioned / ovl_sort -m)"}.get(int(n), "ndgpu_ovl_sort failed (%d)" % n))
+        raise RuntimeError({-1: "ndgpu_ovl_sort: no usable HIP device", -2: "ndgpu_ovl_sort: out of device memory (about 150 bytes per candidate "
+                            "overlap are needed; use more seed files: seed_cutfiles)", -3: "ndgpu_ovl_sort: more than 2^31 candidate overlaps in "
+                            "one call (use more seed files: seed_cutfiles)"}.get(int(n), "ndgpu_ovl_sort failed (%d)" % n))
     recs = _take(lib, out, n, REC)
     ids = _take(lib, bid, nbl.value, np.uint32)
     kinds = _take(lib, bkind, nbl.value, np.uint8)
     bl = [(int(i), chr(int(k))) for i, k in zip(ids, kinds)]
     return recs, bl, {n_: getattr(st, n_) for n_, _ in SortStats._fields_}
 
-
-def sort_overlaps_partitioned(files, seed_len: np.ndarray, min_seed_len: int, max_bin_cov: int = 40, max_flank_len: int = 300,
-                              hq: bool = False, max_records: int = 200_000_000):
-    """sort_overlaps() for inputs of any size: the seed id is the primary sort key and every verdict of the filter is per seed,
-    so the seeds are cut into id ranges whose overlaps (either direction) stay under `max_records`, each range is sorted and
-    filtered on its own (records that touch no seed of the range are left out, the other seeds' lengths are masked) and the
-    results are concatenated -- the same records, in the same order, as one call over everything (util/ovl_sort.c:1040-1110
-    reaches the same end with an external merge)."""
-    files = [np.ascontiguousarray(f, dtype=REC) for f in files]
-    seed_len = np.ascontiguousarray(seed_len, dtype=np.uint32)
-    n_ids = seed_len.size
-    total = sum(f.size for f in files)
-    if total <= max_records or n_ids == 0:
-        return sort_overlaps(files, seed_len, min_seed_len, max_bin_cov, max_flank_len, hq)
-    # overlaps per seed id (a record counts for its query and for its target when they are seeds)
-    per = np.zeros(n_ids + 1, dtype=np.int64)
-    for f in files:
-        for name in ("qname", "tname"):
-            ids = f[name][f[name] < n_ids]
-            ids = ids[seed_len[ids] > 0]
-            per += np.bincount(ids, minlength=n_ids + 1)
-    cum = np.cumsum(per)
-    bounds, lo = [0], 0
-    while lo < n_ids:
-        hi = int(np.searchsorted(cum, (cum[lo - 1] if lo else 0) + max_records, side="right"))
-        hi = max(hi, lo + 1)
-        bounds.append(min(hi, n_ids))
-        lo = bounds[-1]
-    out_r, out_bl, stats = [], [], None
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        sl = np.zeros_like(seed_len)
-        sl[a:b] = seed_len[a:b]
-        part = []
-        for f in files:
-            q, t = f["qname"], f["tname"]
-            part.append(f[((q >= a) & (q < b)) | ((t >= a) & (t < b))])
-        r, bl, st = sort_overlaps(part, sl, min_seed_len, max_bin_cov, max_flank_len, hq)
-        out_r.append(r)
-        out_bl += bl
-        stats = st if stats is None else {k: stats[k] + st[k] for k in st}
-    return np.concatenate(out_r), out_bl, stats

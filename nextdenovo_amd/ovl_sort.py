@@ -6,11 +6,12 @@ util/ovl_sort.c:1040-1078):
 
     python -m nextdenovo_amd.ovl_sort -m 40g -t 8 -k 40 -i .input.seed.001.idx -o input.seed.001.sorted.ovl input.fofn
 
-`-m` bounds the memory of a sort as in the reference: the device needs about 150 bytes per candidate overlap, so inputs with
-more than `-m` / 150 overlaps are cut into seed-id ranges that are sorted and filtered one after the other
-(overlap.sort_overlaps_partitioned: the seed is the primary key and every verdict is per seed, so the concatenation is the same
-file).  `-t` and `-d` only shape the reference's external merge and are accepted and ignored.  Equal (seed, match, span) keys keep
-input order, which is what the reference produces when its buffers are not spilled.  `-H` selects the high-quality-read variant of the filter (`ndgpu_ovl_sort_hq`); `-l 0` is refused.
+`-m`, `-t`, `-d` only shape the reference's external merge sort and are accepted and ignored: the device sort is in-memory
+(about 150 bytes of HBM per candidate overlap: 1.9 G overlaps per call on a 288 GB MI355X, 2^31 at most) and says so plainly when
+a seed file exceeds that -- the remedy is the reference's own knob, more seed files (`seed_cutfiles`).  Cutting one seed file
+into seed-id ranges is NOT equivalent (measured: the filter's verdicts for a seed depend on overlaps filed under other seeds), so
+no such fallback is offered.  Equal (seed, match, span) keys keep input order, which is what the reference produces when its
+buffers are not spilled.  `-H` selects the high-quality-read variant of the filter (`ndgpu_ovl_sort_hq`); `-l 0` is refused.
 """
 from __future__ import annotations
 
@@ -66,9 +67,7 @@ def run(argv) -> int:
         raise SystemExit("[ERROR] -l must be > 0")
     seed_len, min_len = read_idx(a.idx)
     files = [overlap.from_decoded(ovl.decode_ovl(p)) for p in read_fofn(a.fofn)]
-    from .nextcorrect import parse_num_unit
-    budget = max(1 << 20, parse_num_unit(a.mem) // 150)
-    recs, bl, _ = overlap.sort_overlaps_partitioned(files, seed_len, min_len, a.k, a.flank, hq=a.hq, max_records=budget)
+    recs, bl, _ = overlap.sort_overlaps(files, seed_len, min_len, a.k, a.flank, hq=a.hq)
     with open(a.out, "wb") as f:
         f.write(overlap.encode(recs, np.zeros(2, dtype=np.uint32)))
     with open(a.out + ".bl", "w") as f:

@@ -49,20 +49,6 @@ def test_device_overlap_then_sort_matches_reference_sorted_ovl():
     assert st["seeds"] > 10 and st["kept"] == recs.size
 
 
-def test_partitioned_sort_equals_one_call():
-    """overlap.sort_overlaps_partitioned (what `ovl_sort -m` runs when the input exceeds the budget): seed-id ranges sorted one
-    after the other == one call over everything == the reference's sorted.ovl / .bl."""
-    from nextdenovo_amd import overlap, ovl_sort
-    files = _device_raw([("seed", "part", True), ("seed", "seed", False)])
-    sl, mn = ovl_sort.read_idx(os.path.join(STAGE, ".input.seed.001.idx"))
-    total = sum(f.size for f in files)
-    for budget in (total // 3, total // 11, 500):
-        recs, bl, st = overlap.sort_overlaps_partitioned(files, sl, mn, 40, 300, max_records=budget)
-        assert overlap.encode(recs, np.zeros(2, dtype=np.uint32)) == _golden("input.seed.001.sorted.ovl"), budget
-        assert "".join("%d %s\n" % x for x in bl).encode() == _golden("input.seed.001.sorted.ovl.bl"), budget
-        assert st["kept"] == recs.size
-
-
 @pytest.mark.parametrize("k", [40, 18])
 def test_sort_matches_oracle_on_chimeric_set(oracle_lib, k):
     """Deeper set with glued (chimeric) reads: every admission / trimming branch, against the sort oracle."""
