@@ -131,3 +131,39 @@ def test_seq_stat_report_equals_reference(tmp_path, argv):
     subprocess.run([os.path.join(REFDIR, "seq_stat"), *argv, "-o", ref, fofn], check=True, stderr=subprocess.DEVNULL)
     assert seq_stat.run([*argv, "-o", mine, fofn]) == 0
     assert open(mine, "rb").read() == open(ref, "rb").read() and os.path.getsize(ref) > 500
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "seq_dump")), reason="compiled reference not built")
+@pytest.mark.parametrize("n_seed,block", [(1, 0), (3, 0), (2, 20000)])
+def test_in_memory_dealing_matches_reference_seq_dump(tmp_path, n_seed, block):
+    """nextdenovo_amd.stage.deal (what bench.py --gpus N and the sharded stage use to give every rank its seed file) against the
+    files the compiled reference seq_dump writes: which read id lands in which seed / part file (util/seq_dump.c:74-114)."""
+    from nextdenovo_amd import stage
+    rng = np.random.default_rng(11)
+    lens = [int(x) for x in rng.integers(300, 9000, 60)] + [999, 1000, 1001, 2999, 3000, 3001]
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "w") as f:
+        for i, n in enumerate(lens):
+            f.write(">r%d\n%s\n" % (i, "".join(rng.choice(list("ACGT"), n))))
+    fofn = str(tmp_path / "input.fofn")
+    open(fofn, "w").write(fa + "\n")
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    cmd = [os.path.join(REFDIR, "seq_dump"), "-f", "1000", "-s", "3000", "-n", str(n_seed), "-d", out]
+    if block:
+        cmd += ["-b", str(block)]
+    subprocess.run(cmd + [fofn], check=True, capture_output=True)
+
+    def ids_of(path):
+        return [int(l.split()[0]) for l in open(path)] if os.path.exists(path) else []
+
+    kept, seed_files, parts = stage.deal(np.asarray(lens), 1000, 3000, n_seed, block_size=block)
+    assert kept.tolist() == [i for i, n in enumerate(lens) if n >= 1000]
+    for k in range(n_seed):
+        assert seed_files[k].tolist() == ids_of(os.path.join(out, ".input.seed.%03d.idx" % (k + 1))), k
+    ref_parts = []
+    k = 1
+    while os.path.exists(os.path.join(out, ".input.part.%03d.idx" % k)):
+        ref_parts.append(ids_of(os.path.join(out, ".input.part.%03d.idx" % k)))
+        k += 1
+    assert [p.tolist() for p in parts] == [p for p in ref_parts if p]
