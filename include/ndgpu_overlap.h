@@ -86,6 +86,17 @@ int64_t ndgpu_ovl_decode(const uint8_t *buf, uint64_t n_bytes, uint32_t prev[2],
  * index of every read's sequence.  Returns the number of reads in the payload (cap = 0: count only). */
 int64_t ndgpu_2bit_index(const uint32_t *words, uint64_t n_words, uint32_t *ids, uint32_t *lens, uint64_t *word_off, int64_t cap);
 
+/* ---- read ingestion: the FASTA / FASTQ[.gz] reader of `seq_dump` (util/seq_dump.c:60-118 over kseq_read, util/kseq.h:178-222) ----
+ * Streams the file (1 MB inflate window).  ndgpu_fastx_read appends the next records' sequences back to back into buf (cap bytes),
+ * off[k] / len[k] = where record k starts / its length, at most max_recs records and never a partial one.  Returns the number of
+ * records; 0 = the stream is over (end of file, or the point where kseq_read gives up: a quality string of another length than its
+ * sequence); -3 = read error; -4 = the next record alone exceeds cap (ndgpu_fastx_pending = its length; call again with room). */
+typedef struct ndgpu_fastx ndgpu_fastx;
+ndgpu_fastx *ndgpu_fastx_open(const char *path);
+int64_t ndgpu_fastx_read(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *off, uint32_t *len, int64_t max_recs);
+uint64_t ndgpu_fastx_pending(const ndgpu_fastx *h);
+void ndgpu_fastx_close(ndgpu_fastx *h);
+
 void ndgpu_ovl_free(void *p);
 /* The library keeps freed device blocks cached between calls (at most 1.25 x the most it ever had in use at once, and
  * NDGPU_OVL_POOL_GB if set); this releases them.

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libndgpu_nextcorrect.so")
 SOURCES = ["ond_kernels.hip", "msa_kernels.hip", "ext_kernels.hip", "device_runtime.hip", "consensus.cpp", "poa.cpp", "readdb.cpp", "capi.cpp"]
 HEADERS = ["nd_device.h", "nd_host.h", "nd_runtime.h", os.path.join("..", "..", "include", "ndgpu_nextcorrect.h")]
 OVL_LIB = os.path.join(HERE, "libndgpu_overlap.so")
-OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip", "ovlsort_kernels.hip", "ovlsort_engine.hip"]
+OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip", "ovlsort_kernels.hip", "ovlsort_engine.hip", "fastx_reader.cpp"]
 OVL_HEADERS = ["ovl_device.h", os.path.join("..", "..", "include", "ndgpu_overlap.h")]
 
 
@@ -40,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not force and not _stale(lib, srcs + hdrs + [exports]):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, exports), "-o", lib] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in srcs]
+               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, exports), "-o", lib] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in srcs] + (["-lz"] if lib == OVL_LIB else [])
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -437,6 +437,9 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
         fprintf(stderr, "[ndgpu prof] run_main: prep %.3f  align(K7+K8a) %.3f  tags %.3f  msa(K9+K10) %.3f  post %.3f s\n",
                 g_prof.m_prep * 1e-9, g_prof.m_aln * 1e-9, g_prof.m_tags * 1e-9, g_prof.m_msa * 1e-9,
                 g_prof.m_post * 1e-9);
+        fprintf(stderr, "[ndgpu prof] advance, CPU seconds by phase: after main %.3f  after extract %.3f  after LQ round 1 %.3f  after round 2 + splice %.3f\n",
+                g_prof.adv_ns[0] * 1e-9, g_prof.adv_ns[1] * 1e-9, g_prof.adv_ns[2] * 1e-9, g_prof.adv_ns[3] * 1e-9);
+        for (auto &a : g_prof.adv_ns) a = 0;
         g_prof.main_ns = g_prof.extract_ns = g_prof.align_ns = g_prof.advance_ns = g_prof.jobs = 0;
         g_prof.m_prep = g_prof.m_aln = g_prof.m_tags = g_prof.m_msa = g_prof.m_post = 0;
     }

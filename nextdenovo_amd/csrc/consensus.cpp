@@ -26,6 +26,7 @@
 #include <thread>
 
 namespace ndgpu {
+static inline uint64_t now_ns();
 
 ConsensusTrimed *make_error_seed(unsigned len) {
     // lib/nextcorrect.c:261-266.  The reference leaves the buffer uninitialised;
@@ -509,9 +510,12 @@ class PileImpl {
     }
 
     void advance() {
+        const uint64_t t0 = now_ns();
+        const int ph = phase == PileEngine::MAIN ? 0 : phase == PileEngine::EXTRACT ? 1 : lq_iter <= 1 ? 2 : 3;
         if (phase == PileEngine::MAIN) after_main();
         else if (phase == PileEngine::EXTRACT) after_extract();
         else if (phase == PileEngine::LQ_ROUND) after_lq_round();
+        g_prof.adv_ns[ph] += now_ns() - t0;  // per-thread sums: after main / after extract / after LQ round 1 / after round 2 + splice
     }
 
     // -- main phase: the device returns the best_pp walk --------------------------------

@@ -150,6 +150,7 @@ class PileEngine {
 struct HostProf {
     std::atomic<uint64_t> main_ns{0}, extract_ns{0}, align_ns{0}, advance_ns{0}, build_ns{0}, jobs{0};
     std::atomic<uint64_t> m_prep{0}, m_aln{0}, m_tags{0}, m_msa{0}, m_post{0};  // inside run_main
+    std::atomic<uint64_t> adv_ns[4] = {{0}, {0}, {0}, {0}};  // CPU time inside PileEngine::advance by phase (summed over threads)
 };
 extern HostProf g_prof;
 

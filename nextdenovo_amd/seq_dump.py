@@ -10,8 +10,10 @@ whenever the running length exceeds -b), reads of at least -s (and shorter than 
 -n seed files, ids are assigned in input order over both kinds (util/seq_dump.c:74-114); every read is stored as
 `u32 id, u32 len, ceil(len/16) u32` with 16 bases per word, first base in the top bits (lib/bseq.c:114-139), and indexed
 as `id \\t offset + 8 \\t len` (util/seq_dump.c:36-41).  Parsing follows kseq.h (multi-line FASTA / FASTQ, `\\r\\n`,
-a FASTQ record whose quality length differs from its sequence length ends the file).  The packing of each input file's
-reads is one device launch (`ndgpu_pack_2bit`); there is no CPU packing path.
+a FASTQ record whose quality length differs from its sequence length ends the file) and is native: `ndgpu_fastx_*`
+(csrc/fastx_reader.cpp) streams the file through a 1 MB inflate window and hands the reads out in chunks of at most 1 Gb, so a
+multi-GB `.fastq.gz` never sits in memory; every chunk is packed by one device launch (`ndgpu_pack_2bit`); there is no CPU
+packing path.  (`read_records_py` is the same parser in Python, kept as the cross-check of the native one in the tests.)
 """
 from __future__ import annotations
 
@@ -43,9 +45,57 @@ def parse_num(s: str) -> int:
     return int(x + .499)
 
 
+CHUNK_BASES = 1 << 30   # bases handed to one packing launch
+CHUNK_RECS = 1 << 20
+
+
+def iter_chunks(path: str, chunk_bases: int = CHUNK_BASES, chunk_recs: int = CHUNK_RECS):
+    """kseq_read over one file through the native streaming reader: yields (buffer uint8, offsets uint64, lengths uint32) per
+    chunk -- the sequences copied back to back, line breaks removed."""
+    import ctypes as C
+    lib = overlap.load()
+    lib.ndgpu_fastx_open.argtypes = [C.c_char_p]
+    lib.ndgpu_fastx_open.restype = C.c_void_p
+    lib.ndgpu_fastx_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ndgpu_fastx_read.restype = C.c_int64
+    lib.ndgpu_fastx_pending.argtypes = [C.c_void_p]
+    lib.ndgpu_fastx_pending.restype = C.c_uint64
+    lib.ndgpu_fastx_close.argtypes = [C.c_void_p]
+    h = lib.ndgpu_fastx_open(os.fsencode(path))
+    if not h:
+        raise OSError("Error! %s does not exist!" % path)
+    try:
+        buf = np.empty(chunk_bases, dtype=np.uint8)
+        off = np.empty(chunk_recs, dtype=np.uint64)
+        ln = np.empty(chunk_recs, dtype=np.uint32)
+        while True:
+            n = lib.ndgpu_fastx_read(h, buf.ctypes.data, buf.size, off.ctypes.data, ln.ctypes.data, chunk_recs)
+            if n == -4:  # one read longer than the chunk: make room for it
+                buf = np.empty(int(lib.ndgpu_fastx_pending(h)) + 16, dtype=np.uint8)
+                continue
+            if n < 0:
+                raise OSError("read error in %s" % path)
+            if n == 0:
+                return
+            used = int(off[n - 1]) + int(ln[n - 1])
+            yield buf[:used].copy(), off[:n].copy(), ln[:n].copy()
+    finally:
+        lib.ndgpu_fastx_close(h)
+
+
 def read_records(path: str):
-    """kseq_read over one file (lib/kseq.h:180-222): returns (buffer uint8, [(offset, length)]) -- the sequences are
-    copied back to back into the buffer, line breaks removed."""
+    """The whole file at once: (buffer uint8, [(offset, length)])."""
+    bufs, recs, base = [], [], 0
+    for b, off, ln in iter_chunks(path):
+        bufs.append(b)
+        recs += [(int(o) + base, int(l)) for o, l in zip(off, ln)]
+        base += b.size
+    return (np.concatenate(bufs) if bufs else np.zeros(0, dtype=np.uint8)), recs
+
+
+def read_records_py(path: str):
+    """kseq_read over one file (util/kseq.h:178-222) in Python: returns (buffer uint8, [(offset, length)]) -- the sequences are
+    copied back to back into the buffer, line breaks removed.  Reads the whole file; the cross-check of the native reader."""
     with open(path, "rb") as f:
         magic = f.read(2)
     opener = gzip.open if magic == b"\x1f\x8b" else open
@@ -163,35 +213,44 @@ def run(argv) -> int:
         if len(line) == 0 or line.startswith("#"):
             continue
         path = line if line.startswith("/") else os.path.join(base, line)
-        buf, recs = read_records(path)
-        keep = [(s, l) for s, l in recs if (flt <= l < seed_flt) or (seed_flt <= l < LEN_LIMIT)]
-        if not keep:
-            continue
-        a_off = np.asarray([s for s, _ in keep], dtype=np.uint64)
-        lens = np.asarray([min(l, LEN_LIMIT) for _, l in keep], dtype=np.uint32)   # convert_2bit truncates (seq_dump.c:38)
-        words, w_off = overlap.pack_2bit(buf, a_off, lens)                         # one device launch per input file
-        for k, (_, l) in enumerate(keep):
-            n = int(lens[k])
-            w = words[int(w_off[k]): int(w_off[k]) + (n + 15) // 16]
-            if l < seed_flt:
-                part.length += l
-                if part.length > block:
-                    part.close()
-                    part_cnt += 1
-                    part = _Out(part_pre, part_idx, part_cnt)
-                    part.length = l
-                part.put(next_id, n, w)
-            else:
-                if seed_cnt > seed_n:
-                    seed_cnt = 1
-                seeds[seed_cnt - 1].put(next_id, n, w)
-                seeds[seed_cnt - 1].length += l
-                seed_cnt += 1
-            next_id += 1
+        for chunk in iter_chunks(path):
+            next_id, seed_cnt, part, part_cnt = _put_chunk(chunk, flt, seed_flt, block, seeds, seed_n, part, part_cnt, part_pre, part_idx,
+                                                           next_id, seed_cnt)
     for s in seeds:
         s.close()
     part.close()
     return 0
+
+
+def _put_chunk(chunk, flt, seed_flt, block, seeds, seed_n, part, part_cnt, part_pre, part_idx, next_id, seed_cnt):
+    """The body of split_data()'s loop (util/seq_dump.c:74-114) for the reads of one chunk."""
+    buf, offs, lns = chunk
+    sel = ((lns >= flt) & (lns < seed_flt)) | ((lns >= seed_flt) & (lns < LEN_LIMIT))
+    keep = [(int(s), int(l)) for s, l in zip(offs[sel], lns[sel])]
+    if not keep:
+        return next_id, seed_cnt, part, part_cnt
+    a_off = np.asarray([s for s, _ in keep], dtype=np.uint64)
+    lens = np.asarray([min(l, LEN_LIMIT) for _, l in keep], dtype=np.uint32)   # convert_2bit truncates (seq_dump.c:38)
+    words, w_off = overlap.pack_2bit(buf, a_off, lens)                         # one device launch per chunk
+    for k, (_, l) in enumerate(keep):
+        n = int(lens[k])
+        w = words[int(w_off[k]): int(w_off[k]) + (n + 15) // 16]
+        if l < seed_flt:
+            part.length += l
+            if part.length > block:
+                part.close()
+                part_cnt += 1
+                part = _Out(part_pre, part_idx, part_cnt)
+                part.length = l
+            part.put(next_id, n, w)
+        else:
+            if seed_cnt > seed_n:
+                seed_cnt = 1
+            seeds[seed_cnt - 1].put(next_id, n, w)
+            seeds[seed_cnt - 1].length += l
+            seed_cnt += 1
+        next_id += 1
+    return next_id, seed_cnt, part, part_cnt
 
 
 if __name__ == "__main__":

@@ -168,3 +168,12 @@ extern "C" int ndtest_poa(const char **seqs, int n, char *out, int cap) {
     memcpy(out, r.c_str(), r.size() + 1);
     return (int)r.size();
 }
+
+// CPU seconds the engine spent in PileEngine::advance since the last call, by phase (after main / after extract / after LQ
+// round 1 / after round 2 + splice): where the host side of the low-quality-region stage goes (tools/host_profile.py).
+extern "C" void ndtest_advance_profile(double out[4]) {
+    for (int i = 0; i < 4; i++) {
+        out[i] = g_prof.adv_ns[i].load() * 1e-9;
+        g_prof.adv_ns[i] = 0;
+    }
+}

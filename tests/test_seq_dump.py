@@ -167,3 +167,97 @@ def test_in_memory_dealing_matches_reference_seq_dump(tmp_path, n_seed, block):
         ref_parts.append(ids_of(os.path.join(out, ".input.part.%03d.idx" % k)))
         k += 1
     assert [p.tolist() for p in parts] == [p for p in ref_parts if p]
+
+
+def test_native_reader_equals_python_parser_and_streams(tmp_path):
+    """ndgpu_fastx_* (csrc/fastx_reader.cpp) against the Python restatement of kseq_read on the parser fixtures, on files built to
+    hit the corners (CR-only lines, header-only records, '+' / '@' inside quality, truncated tails, junk before the first
+    header, empty files), on a random mix -- and in small chunks: the records are the same whatever the chunk size, and a read
+    longer than the chunk is handed over once the buffer has room."""
+    from nextdenovo_amd import seq_dump
+    fofn, _ = _make_inputs(str(tmp_path))
+    cases = [str(tmp_path / n) for n in ("a.fa", "b.fq", "c.fa.gz")]
+    rng = np.random.default_rng(8)
+    texts = [b"", b"\n\n", b"no header at all\nACGT\n", b">only_header", b">h\n", b">h\n\n\nACGT\n\n>g\nAC\r\nGT\r\n", b">a\r\nA\r\n\r\nC\r\n",
+             b"@q\nACGT\n+\nII\nII\n@r\nAC\n+\n@+\n", b"@q\nACGT\n+", b"@q\nACGT\n+\n", b"@q\nACGT\n+\nIII", b">a b c\tx\nAC GT\n>b\n@\n",
+             b"junk\n>x\nAAAA\n+\nIIII\n>y\nCC\n", b">a\n" + b"ACGT" * 5000 + b"\n>b\nA\n", b">\nACG\n", b"@\nAC\n+\nII\n"]
+    for k in range(12):
+        parts = []
+        for _ in range(int(rng.integers(1, 9))):
+            n = int(rng.integers(0, 400))
+            s = "".join(rng.choice(list("ACGTNacgt"), n))
+            w = int(rng.integers(1, 90))
+            nl = "\r\n" if rng.random() < 0.3 else "\n"
+            body = nl.join(s[i:i + w] for i in range(0, n, w))
+            if rng.random() < 0.5:
+                parts.append(">r%d c\n%s%s" % (k, body, nl if rng.random() < 0.9 else ""))
+            else:
+                q = "".join(rng.choice(list("@+>I#5"), n if rng.random() < 0.85 else max(0, n - 1)))
+                parts.append("@r%d\n%s%s+\n%s%s" % (k, body, nl, q, nl))
+        texts.append("".join(parts).encode())
+    for i, t in enumerate(texts):
+        p = str(tmp_path / ("t%d.fx" % i))
+        open(p, "wb").write(t)
+        cases.append(p)
+    ref_exe = os.path.join(REFDIR, "seq_dump")
+    for ci, p in enumerate(cases):
+        b0, r0 = seq_dump.read_records_py(p)
+        want = [b0[s:s + l].tobytes() for s, l in r0]
+        if os.path.exists(ref_exe):  # the compiled reference on the same file: the lengths its .idx lists, in order
+            d = str(tmp_path / ("ref%d" % ci))
+            f1 = str(tmp_path / ("one%d.fofn" % ci))
+            open(f1, "w").write(p + "\n")
+            subprocess.run([ref_exe, "-f", "1", "-s", "999999", "-n", "1", "-d", d, f1], check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            ref_len = []
+            k = 1
+            while os.path.exists(os.path.join(d, ".input.part.%03d.idx" % k)):
+                ref_len += [int(l.split("\t")[2]) for l in open(os.path.join(d, ".input.part.%03d.idx" % k))]
+                k += 1
+            assert ref_len == [len(w) for w in want if 1 <= len(w) < 999999], (p, ref_len)
+        for cb, cr in ((1 << 20, 1 << 10), (257, 3), (64, 1)):
+            got = []
+            for buf, off, ln in seq_dump.iter_chunks(p, cb, cr):
+                got += [buf[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, ln)]
+            assert got == want, (p, cb, cr, len(got), len(want))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "seq_dump")), reason="oracle/_ref not built")
+@pytest.mark.parametrize("argv", [("-f", "1k", "-s", "3k", "-b", "6k", "-n", "2"), ("-f", "500", "-s", "1001", "-b", "0", "-n", "3")])
+def test_command_file_layout_with_a_stand_in_packer(tmp_path, argv, monkeypatch):
+    """The command's file logic -- ids, .idx offsets, seed dealing, part splitting, chunked reading -- without a GPU: the device
+    packer is replaced by a numpy one (test-only; exact for ACGT reads) and the files are compared with the compiled reference's."""
+    from nextdenovo_amd import overlap, seq_dump, synth
+    rng = np.random.default_rng(21)
+    fa = tmp_path / "r.fa"
+    with open(fa, "w") as f:
+        for i in range(40):
+            n = int(rng.integers(200, 9000))
+            s = "".join(rng.choice(list("ACGT"), n))
+            f.write(">r%d\n" % i + "\n".join(s[k:k + 70] for k in range(0, n, 70)) + "\n")
+    fofn = tmp_path / "in.fofn"
+    fofn.write_text(str(fa) + "\n")
+
+    def fake_pack(buf, a_off, lens):
+        code = np.zeros(256, dtype=np.uint8)
+        for ch, v in zip(b"ACGT", range(4)):
+            code[ch] = v
+        words, woff, at = [], [], 0
+        for o, l in zip(a_off, lens):
+            w = synth.pack_2bit_msb(code[buf[int(o):int(o) + int(l)]])
+            words.append(w)
+            woff.append(at)
+            at += w.size
+        return np.concatenate(words), np.asarray(woff, dtype=np.uint64)
+
+    monkeypatch.setattr(overlap, "pack_2bit", fake_pack)
+    monkeypatch.setattr(seq_dump, "CHUNK_BASES", 20000)   # several chunks per file
+    monkeypatch.setattr(seq_dump, "CHUNK_RECS", 7)
+    ref, mine = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([os.path.join(REFDIR, "seq_dump"), *argv, "-d", ref, str(fofn)], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    assert seq_dump.run([*argv, "-d", mine, str(fofn)]) == 0
+    names = sorted(os.listdir(ref))
+    assert names == sorted(os.listdir(mine)) and len(names) >= 4
+    for n in names:
+        assert open(os.path.join(ref, n), "rb").read() == open(os.path.join(mine, n), "rb").read(), n
