@@ -15,6 +15,12 @@ index is built once for all of its jobs, and the reads are uploaded once.
     python -m nextdenovo_amd.correct_stage -d 01.raw_align -x ava-ont -k 40 -r ont -min_len_seed 5000 -o cns
     python -m nextdenovo_amd.correct_stage --fofn input.fofn --read-cutoff 1k --seed-cutoff 10k --seed-cutfiles 2 -d 01.raw_align ...   (db_split too)
 
+Several GPUs: start it once per GPU with torch.distributed.run (`python -m torch.distributed.run --nproc-per-node 8 --master-addr
+127.0.0.1 -m nextdenovo_amd.correct_stage ...`): rank r takes the seed files r, r + N, ... (one `seed_cns` subtask per GPU, as
+nextDenovo shards the stage: `seed_cutfiles = pa_correction = n_gpu`), computes every raw_align job their sorts read -- the mirrors
+`(t < i, seed i)` too, so no rank waits for another -- and the ranks meet once, in an all-reduce of {corrected bases, corrected
+seeds} (RCCL on a GPU node) that rank 0 prints.
+
 writes `cns.NNN.fasta` (+ `.idx`) per seed file, byte-identical to what the three reference programs produce when the
 sort's input list names the `.ovl` files in job order (the reference lists them in directory order, which only matters
 for overlaps with equal (seed, match, span) keys).  `--keep DIR` also writes the `.ovl`, `sorted.ovl` and `.bl` files
@@ -135,6 +141,10 @@ def run(argv) -> int:
     seeds = [overlap.ReadSet.from_2bit(p) for p in seed_paths]
     parts = [overlap.ReadSet.from_2bit(p) for p in part_paths]
     want = set(range(len(seeds))) if a.seed_files is None else {int(x) - 1 for x in a.seed_files.split(",")}
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:  # one rank per GPU: seed file i goes to rank i mod N (nextDenovo:77-84 runs one seed_cns subtask per seed file)
+        os.environ.setdefault("NDGPU_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+        want = {i for i in want if i % world == rank}
 
     argv_mm = ["--step", "1", "-x", a.preset] + (["-f", a.occ] if a.occ else []) + ["a", "b"]
     opt = minimap2_nd.build_opt(minimap2_nd.parse_argv(argv_mm))
@@ -167,6 +177,7 @@ def run(argv) -> int:
     words, word_off, lens = read_db_from_sets(seeds + parts)
     db = api.ReadDB(words, word_off, lens)
     fail = 0
+    totals = [0, 0]  # corrected bases, corrected records of this rank
     try:
         for i in sorted(want):
             s = seeds[i]
@@ -188,8 +199,28 @@ def run(argv) -> int:
             out = "%s.%s.fasta" % (a.out, tag)
             with open(out, "w") as OUT, open(out + ".idx", "w") as IDX:
                 fail += nextcorrect.correct_and_write(db, dec, piles, a, OUT, IDX)
+            for line in open(out + ".idx"):
+                ln = int(line.split("\t")[2])
+                if ln > 0:
+                    totals[0] += ln
+                    totals[1] += 1
     finally:
         db.close()
+    if world > 1:  # the stage's only collective: the final counts (RCCL over xGMI on a GPU node, gloo without one)
+        import torch
+        import torch.distributed as dist
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl" if use_gpu else "gloo")
+        t = torch.tensor(totals, dtype=torch.int64, device="cuda" if use_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        totals = [int(x) for x in t.tolist()]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        sys.stderr.write("[correct_stage] %d corrected seeds, %d corrected bases over %d rank%s\n"
+                         % (totals[1], totals[0], world, "" if world == 1 else "s"))
     return 1 if fail > 5 else 0
 
 

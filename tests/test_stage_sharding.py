@@ -1,0 +1,75 @@
+"""nextdenovo_amd.stage.Shard (what bench.py --gpus N gives every rank) against the reference PROGRAMS on the CPU: reads ->
+compiled `seq_dump -n 2` (two seed files + a part file) -> compiled `minimap2-nd --step 1` for the five raw_align jobs of
+nextDenovo:426-467 -> compiled `ovl_sort` per seed file -> the pile assembly of lib/nextcorrect.py:92-143 through the stock
+ovlseq.so.  The shard runs with the oracle backend (overlap oracle + sort oracle, no GPU here): the records of every job it
+computes for a seed file -- its own and the mirror it needs -- are the bytes of the reference's `.ovl` for that job, and the
+piles it hands to the consensus are the reference's piles."""
+import os
+
+import numpy as np
+import pytest
+
+import mm_util as M
+import os_util as O
+import refpipe
+import stage_util
+
+NEED = ("minimap2-nd", "ovl_sort", "seq_dump", "ovlseq.so")
+
+
+@pytest.mark.skipif(not refpipe.have_ref(*NEED), reason="compiled reference not built")
+def test_shard_jobs_and_piles_equal_reference_programs(tmp_path, oracle_lib):
+    from nextdenovo_amd import overlap, stage, synth
+    g = synth.make_genome(45000, seed=141, n_repeats=2, repeat_len=1200)
+    rs = synth.simulate_reads(g, 24, "ont", seed=142, mu=8.3, sigma=0.5, min_len=700)
+    wd = str(tmp_path)
+    fa = os.path.join(wd, "reads.fa")
+    refpipe.write_fasta(fa, [synth.codes_to_ascii(s) for s in rs.seqs])
+    fofn = os.path.join(wd, "input.fofn")
+    open(fofn, "w").write(fa + "\n")
+    db = os.path.join(wd, "db")
+    os.makedirs(db)
+    R = lambda n: os.path.join(refpipe.REFDIR, n)  # noqa: E731
+    refpipe.run([R("seq_dump"), "-f", "500", "-s", "4000", "-b", "2g", "-n", "2", "-d", db, fofn])
+    s1, s2, p1 = (os.path.join(db, n) for n in ("input.seed.001.2bit", "input.seed.002.2bit", "input.part.001.2bit"))
+    assert os.path.getsize(s2) > 500 and os.path.getsize(p1) > 500
+    ra = os.path.join(wd, "ra")
+    os.makedirs(ra)
+    jobs = [(0, s1, p1, True, None), (1, s1, s1, False, "3G"), (2, s1, s2, True, "3G"), (3, s2, p1, True, None), (4, s2, s2, False, "3G")]
+    ref_ovl = {}
+    for k, t, q, dual, batch in jobs:
+        o = os.path.join(ra, "%s.%d.ovl" % (os.path.basename(t), k))
+        refpipe.run([R("minimap2-nd"), "--step", "1"] + (["-I", batch] if batch else []) + (["--dual=yes"] if dual else []) +
+                    ["-t", "4", "-x", "ava-ont", t, q, "-o", o])
+        ref_ovl[k] = open(o, "rb").read()
+        assert len(ref_ovl[k]) > 500
+    words, word_off, lens = synth.pack_db(rs)   # read id = input order: every read is >= the 500-base read cut-off
+    sh = stage.Shard(words, word_off, lens, preset="ava-ont", seed_cutoff=4000, read_cutoff=500, n_seed_files=2, sort_k=17,
+                     backend=stage_util.OracleBackend(oracle_lib, "ava-ont"))
+    assert len(sh.part_ids) == 1 and sh.part_ids[0].size > 3
+    assert [j[0] for j in sh.jobs_of(0)] == [0, 1, 2] and [j[0] for j in sh.jobs_of(1)] == [2, 3, 4]
+    idxs = os.path.join(wd, "idxs.fofn")
+    with open(idxs, "w") as f:
+        for n in sorted(os.listdir(db)):
+            if n.startswith(".input.") and n.endswith(".idx"):
+                f.write(os.path.join(db, n) + "\n")
+    n_piles = 0
+    for i, tag in ((0, "001"), (1, "002")):
+        files = sh.overlaps(i)
+        ks = [j[0] for j in sh.jobs_of(i)]
+        for k, recs in zip(ks, files):   # every job's records == the bytes the reference program wrote for that job
+            assert overlap.encode(recs, np.zeros(2, dtype=np.uint32)) == ref_ovl[k], "seed file %d, job %d" % (i, k)
+        with open(os.path.join(ra, "in%s.fofn" % tag), "w") as f:
+            f.write("\n".join(os.path.join(ra, "%s.%d.ovl" % (os.path.basename(jobs[k][1]), k)) for k in ks) + "\n")
+        refpipe.run([R("ovl_sort"), "-m", "2g", "-t", "2", "-k", "17", "-i", os.path.join(db, ".input.seed.%s.idx" % tag), "-o",
+                     "ref.%s.sorted.ovl" % tag, "in%s.fofn" % tag], cwd=ra)
+        so = os.path.join(ra, "ref.%s.sorted.ovl" % tag)
+        bl = {int(l.split()[0]) for l in open(so + ".bl")}
+        want = list(refpipe.read_piles(idxs, so, min_len_seed=2000, min_len_aln=500, max_cov_aln=130, min_cov_seed=10, blacklist=bl))
+        sub, off, seeds, n_bl = sh.piles(i, files=files)
+        assert n_bl == len(bl)
+        assert [int(s) for s in seeds] == [w[0] for w in want]
+        for p, w in enumerate(want):
+            assert np.array_equal(sub[int(off[p]):int(off[p + 1])], w[5]), (i, p)
+        n_piles += len(want)
+    assert n_piles >= 6
