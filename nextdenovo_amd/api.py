@@ -43,7 +43,12 @@ def load(build_if_missing: bool = True):
         if not build_if_missing:
             raise RuntimeError("libndgpu_nextcorrect.so is not built; run `python -m nextdenovo_amd.build`")
         _build.build()
-    lib = C.CDLL(path)
+    _LIB = _bind(C.CDLL(path))
+    return _LIB
+
+
+def _bind(lib):
+    """Argument / result types of the entry points declared in include/ndgpu_nextcorrect.h."""
     lib.nextCorrect.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_uint, C.c_uint,
                                 C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int]
     lib.nextCorrect.restype = C.POINTER(ConsensusTrimed)
@@ -63,7 +68,6 @@ def load(build_if_missing: bool = True):
     lib.ndgpu_get_stats.argtypes = [C.POINTER(Stats)]
     lib.ndgpu_reset_stats.argtypes = []
     lib.ndgpu_device_count.restype = C.c_int
-    _LIB = lib
     return lib
 
 

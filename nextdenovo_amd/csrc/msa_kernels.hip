@@ -711,6 +711,7 @@ __device__ void score_range(K10Smem<CELLS, ENTS> &S, const K10Args &A, const Pil
             const bool st_ok = p >= c0 + 2u;
             uint32_t sw = 0, sc0 = 0;
             if (st_ok) sw = S.colw[(p - 2u) % 3u] * 6u, sc0 = S.colc0[(p - 2u) % 3u];  // slot p+1 = slot p-2: read before prepare
+            ND_LOCKSTEP();
             if (p + 1 < L) prepare(p + 1, true);
             if (st_ok) {
                 const uint32_t sl = (p - 2u) & 1u;

@@ -1,0 +1,57 @@
+"""TEST INFRASTRUCTURE ONLY.  Builds tests/simt/_build/libnextcorrect_simt.so: the consensus library's own sources
+(nextdenovo_amd/csrc, unmodified) compiled with g++ against the lane-accurate interpreter in tests/simt/include, so that the
+kernels' logic can be run against the oracle on a machine without a GPU.  Nothing under nextdenovo_amd/ knows this file
+exists; only tests load it."""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "nextdenovo_amd", "csrc")
+OUT_DIR = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT_DIR, "libnextcorrect_simt.so")
+SOURCES = ["ond_kernels.hip", "msa_kernels.hip", "ext_kernels.hip", "device_runtime.hip", "consensus.cpp", "poa.cpp", "readdb.cpp",
+           "capi.cpp"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "simt_runtime.cpp"),
+                                                                   os.path.join(HERE, "include", "hip", "hip_runtime.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-I", os.path.join(HERE, "include"), "-I", CSRC, "-w"]
+    objs = []
+    procs = []
+    for src in SOURCES + ["simt_runtime.cpp"]:
+        path = os.path.join(HERE if src == "simt_runtime.cpp" else CSRC, src)
+        if src.endswith(".hip"):
+            # the one textual change: GCN inline assembly (memory-ordering waits) has no host meaning and is blanked
+            text = open(path).read()
+            text, n_asm = re.subn(r'asm volatile\("s_[^;]*;', ";", text)
+            path = os.path.join(OUT_DIR, src + ".cpp")
+            with open(path, "w") as f:
+                f.write('#line 1 "%s"\n' % os.path.join(CSRC, src) + text)
+        obj = os.path.join(OUT_DIR, src + ".o")
+        objs.append(obj)
+        procs.append((src, subprocess.Popen(["g++", *flags, "-x", "c++", "-c", path, "-o", obj], stderr=subprocess.PIPE, text=True)))
+    for src, p in procs:
+        _, err = p.communicate()
+        if p.returncode:
+            raise RuntimeError("simt build of %s failed:\n%s" % (src, err[-6000:]))
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,168 @@
+"""Kernel LOGIC on a machine without a GPU: the consensus library's own HIP sources, compiled with g++ against the lane-accurate
+interpreter under tests/simt (every lane a fibre, wave-wide operations and barriers as rendezvous points), against the reference's
+golden vectors and the oracle.  This is test infrastructure: it says nothing about speed, it is not a backend of the product
+(nothing under nextdenovo_amd/ can load it), and the `-m gpu` tests remain the parity tests proper -- what it adds is that a
+change to a kernel is checked for logic, barrier placement and inter-wave races before it ever reaches a GPU.
+
+The scoring kernel's forced paths read their switches once per process, so they run in child processes."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "simt"))
+
+
+@pytest.fixture(scope="module")
+def simt_lib():
+    import build_simt
+    os.environ.setdefault("NDGPU_CONTEXTS", "1")  # one device context: the interpreter brings its own host threads
+    return C.CDLL(build_simt.build())
+
+
+@pytest.fixture()
+def simt_api(simt_lib, monkeypatch):
+    """nextdenovo_amd.api bound to the interpreted library for the duration of one test."""
+    from nextdenovo_amd import api
+    monkeypatch.setattr(api, "_LIB", api._bind(simt_lib))
+    return api
+
+
+def test_interpreter_semantics(simt_lib):
+    """The interpreter itself: data-parallel-primitive moves, shuffles and ballots against their definitions."""
+    simt_lib.simt_selftest.restype = C.c_int
+    assert simt_lib.simt_selftest() == 0
+
+
+def test_align_golden_vectors(simt_lib):
+    """K7 / K7-wide / K8a as compiled from ond_kernels.hip: the reference's align()/align_hq() outputs, bit exact, incl. failures,
+    the > 250-gap marker and a live band beyond the LDS fast path (same assertions as the GPU test of the same name)."""
+    for i, p in enumerate(util.load_pairs()):
+        n, tu, qu, ts, qs = util.gpu_align(simt_lib, p["q"], p["t"], p["hq"])
+        assert n == p["aln_len"], i
+        if n > 2:
+            assert np.array_equal(util.strings_to_ops(ts, qs), p["ops"]), i
+            assert (tu, qu) == (p["t_used"], p["q_used"]), i
+
+
+def test_align_fuzz_vs_oracle(simt_lib, oracle_lib):
+    from nextdenovo_amd import synth
+    rng = np.random.default_rng(77)
+    ok = 0
+    for it in range(40):
+        L = int(rng.integers(1, 2500))
+        base = rng.integers(0, 4 if it % 9 else 2, L, dtype=np.uint8)
+        prof = ("ont", "clr", "hifi")[it % 3]
+        q = synth.mutate(base, np.random.default_rng(3 * it), prof)[0]
+        t = synth.mutate(base, np.random.default_rng(3 * it + 1), prof)[0]
+        if it % 10 == 0:
+            q = q[int(rng.integers(0, 40)):]
+        hq = int(it % 4 == 0)
+        qa, ta = util.ASC[q].tobytes(), util.ASC[t].tobytes()
+        o, ots, oqs, _ = util.oracle_align(oracle_lib, qa, ta, hq)
+        n, tu, qu, ts, qs = util.gpu_align(simt_lib, qa, ta, hq)
+        assert n == o.aln_len, it
+        if o.status == 1:
+            assert ts == ots and qs == oqs and (tu, qu) == (o.t_used, o.q_used), it
+            ok += 1
+    assert ok > 20
+
+
+@pytest.mark.parametrize("schedule", [0, 1, 2, 7])
+def test_golden_piles_nextcorrect(simt_lib, schedule):
+    """nextCorrect() end to end (K7 ... K11, the three-wave scoring pipeline with its default segments, the segmented walk)
+    on the reference's golden piles.  Which wavefront of a workgroup runs when is not defined: schedule 0 gives every
+    wavefront a slice in turn, 1 / 2 let the lowest / highest numbered runnable wavefront run ahead to its next workgroup
+    barrier, larger values pick at random -- a missing barrier between wavefronts (the fault that cost round 2 thirty
+    GPU-minutes, in the stitch kernel's segment loop) passes under 0 and 2 and fails under 1 and the random ones."""
+    fn, fr = util.bind_correct(simt_lib)
+    simt_lib.simt_set_schedule(schedule)
+    for i, p in enumerate(util.load_piles()):
+        if schedule and i % 3 != schedule % 3:
+            continue
+        ln, ide, seq = util.call_correct(fn, fr, p)
+        assert ln == p["exp_len"], i
+        if ln > 4:
+            assert seq == p["exp_seq"], i
+            assert np.float32(ide) == np.float32(p["exp_ide"]), i
+    simt_lib.simt_set_schedule(0)
+
+
+_CHILD = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, util, build_simt
+from nextdenovo_amd import api
+lib = api._bind(C.CDLL(build_simt.build()))
+fn, fr = util.bind_correct(lib)
+bad = []
+for i, p in enumerate(util.load_piles()):
+    if i %% %d:
+        continue
+    ln, ide, seq = util.call_correct(fn, fr, p)
+    if ln != p["exp_len"] or (ln > 4 and (seq != p["exp_seq"] or np.float32(ide) != np.float32(p["exp_ide"]))):
+        bad.append(i)
+st = api.Stats()
+lib.ndgpu_get_stats(C.byref(st))
+print(json.dumps(dict(bad=bad, segments=int(st.score_segments), repairs=int(st.score_repairs), slow=int(st.score_slow_piles))))
+"""
+
+
+def _forced(env, stride=2):
+    e = dict(os.environ, NDGPU_CONTEXTS="1", **env)
+    out = subprocess.run([sys.executable, "-c", _CHILD % (os.path.dirname(HERE), HERE, os.path.join(HERE, "simt"), stride)], env=e,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("env,expect", [
+    ({"NDGPU_K10_SEG": "256", "NDGPU_K10_WARM": "3"}, "repairs"),       # warm-up too short: boundary checks fail, in-kernel repair
+    ({"NDGPU_K10_FORCE": "repair", "NDGPU_K10_SEG": "512", "SIMT_SCHEDULE": "1"}, "repairs"),  # every other segment repaired
+    ({"NDGPU_K10_FORCE": "repair", "NDGPU_K10_SEG": "300", "SIMT_SCHEDULE": "9"}, "repairs"),
+    ({"NDGPU_K10_FORCE": "slow"}, "slow"),                               # the int64 HBM-resident kernel
+    ({"NDGPU_K10_FORCE": "large", "NDGPU_K10_SEG": "300", "NDGPU_K10_WARM": "64"}, "segments"),
+])
+def test_scoring_forced_paths(simt_lib, env, expect):
+    """The scoring kernel's other paths (see tests/test_gpu_k10.py for the same switches on the GPU)."""
+    r = _forced(env)
+    assert r["bad"] == [], r
+    assert r[expect] > 0, r
+
+
+def _synth_set(gsize, mu, sigma, seed, depth=30, profile="ont"):
+    from nextdenovo_amd import synth
+    g = synth.make_genome(gsize, seed=seed, n_repeats=0)
+    rs = synth.simulate_reads(g, depth, profile, seed=seed + 1, mu=mu, sigma=sigma)
+    return rs, synth.build_piles(rs, seed_cutoff=1000)
+
+
+@pytest.mark.parametrize("profile,read_type,max_lq", [("ont", 1, 10000), ("hifi", 3, 1000)])
+def test_db_path_equals_ascii_path_and_host_oracle(simt_api, host_harness, profile, read_type, max_lq):
+    """Resident-DB batched entry (sub-batches, both strands, LQ-stage alignments) == per-pile ASCII entry == the host engine with
+    the oracle's aligner, for raw and for high-quality reads."""
+    from nextdenovo_amd import synth
+    rs, piles = _synth_set(20000, 7.9, 0.3, 31 if read_type == 1 else 71, profile=profile)
+    piles = piles[:6]
+    words, off, lens = synth.pack_db(rs)
+    db = simt_api.ReadDB(words, off, lens)
+    recs, poff = synth.flatten_piles(piles)
+    got = db.correct_piles(recs, poff, read_type=read_type, max_lq_length=max_lq, host_threads=4)
+    db.close()
+    fn, fr = util.bind_correct(host_harness, "ndtest_correct", "ndtest_free")
+    assert any(int(p["recs"][:, 1].max()) == 1 for p in piles)
+    for p, g in zip(piles, got):
+        seqs, st, en, mal = synth.pile_sequences(rs, p)
+        mlq = min(en[0] // 2, max_lq)
+        c = util.call_correct(fn, fr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal, max_lq=mlq, read_type=read_type,
+                                           fast=0, split=0))
+        assert g[0] == c[0] and g[0] > 1000
+        assert g[2] == c[2]
+        assert np.float32(g[1]) == np.float32(c[1])
