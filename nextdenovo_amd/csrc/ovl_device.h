@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <hip/hip_runtime.h>
 
+#include "nd_lockstep.h"
+
 namespace ndovl {
 
 constexpr uint64_t kSeedTandem = 1ULL << 42; // MM_SEED_TANDEM (minimap2/mmpriv.h:20)

@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(64) seed_filter_kernel(const OvlRec *__restric
 		const bool reject = (lowest > max_bin_cov || (double)lhs > 1.3 * (double)lim) && ((double)(o.qe - o.qs) <= qlen * 0.8);
 		if (reject) {
 			for (int i = j + 1 + lane; i <= k; i += 64) bins[i]--;
+			ND_LOCKSTEP();  // the next record's lanes own other bins
 			continue;
 		}
 		if (label != 2) repeat_run = 1;

@@ -42,7 +42,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         from . import build
         build.build()
-    lib = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _bind(lib):
+    """Argument / result types of the entry points declared in include/ndgpu_overlap.h."""
     P = C.c_void_p
     lib.ndgpu_ovl_opt_preset.argtypes = [C.c_char_p, C.POINTER(Opt)]
     lib.ndgpu_ovl_index_create.argtypes = [C.POINTER(Opt), C.c_uint32, P, C.c_uint64, P, P, P]
@@ -65,7 +70,6 @@ def load():
     lib.ndgpu_pack_2bit.restype = C.c_int64
     lib.ndgpu_ovl_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.ndgpu_ovl_reset_stats.argtypes = [P]
-    _lib = lib
     return lib
 
 

@@ -13,32 +13,45 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "nextdenovo_amd", "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "libnextcorrect_simt.so")
+OVL_LIB = os.path.join(OUT_DIR, "liboverlap_simt.so")
 SOURCES = ["ond_kernels.hip", "msa_kernels.hip", "ext_kernels.hip", "device_runtime.hip", "consensus.cpp", "poa.cpp", "readdb.cpp",
            "capi.cpp"]
+OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip", "ovlsort_kernels.hip", "ovlsort_engine.hip", "fastx_reader.cpp"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "simt_runtime.cpp"),
-                                                                   os.path.join(HERE, "include", "hip", "hip_runtime.h")]
+                                                                   os.path.join(HERE, "include", "hip", "hip_runtime.h"),
+                                                                   os.path.join(HERE, "include", "rocprim", "rocprim.hpp")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+    return _build(LIB, SOURCES, [], force)
+
+
+def build_overlap(force: bool = False) -> str:
+    return _build(OVL_LIB, OVL_SOURCES, ["-lz"], force)
+
+
+def _build(lib, sources, libs, force) -> str:
+    if not force and not _stale(lib):
+        return lib
     os.makedirs(OUT_DIR, exist_ok=True)
     flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-I", os.path.join(HERE, "include"), "-I", CSRC, "-w"]
     objs = []
     procs = []
-    for src in SOURCES + ["simt_runtime.cpp"]:
+    for src in sources + ["simt_runtime.cpp"]:
         path = os.path.join(HERE if src == "simt_runtime.cpp" else CSRC, src)
         if src.endswith(".hip"):
             # the one textual change: GCN inline assembly (memory-ordering waits) has no host meaning and is blanked
             text = open(path).read()
             text, n_asm = re.subn(r'asm volatile\("s_[^;]*;', ";", text)
+            # and the workgroup's dynamically sized LDS array is the interpreter's per-workgroup buffer
+            text = re.sub(r'extern __shared__ (\w+) (\w+)\[\];', r'\1 *\2 = (\1 *)simt::dynamic_lds();', text)
             path = os.path.join(OUT_DIR, src + ".cpp")
             with open(path, "w") as f:
                 f.write('#line 1 "%s"\n' % os.path.join(CSRC, src) + text)
@@ -49,9 +62,10 @@ def build(force: bool = False) -> str:
         _, err = p.communicate()
         if p.returncode:
             raise RuntimeError("simt build of %s failed:\n%s" % (src, err[-6000:]))
-    subprocess.check_call(["g++", "-shared", "-pthread", "-o", LIB, *objs])
-    return LIB
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", lib, *objs, *libs])
+    return lib
 
 
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_overlap(force=True))

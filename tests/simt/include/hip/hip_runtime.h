@@ -68,7 +68,8 @@ struct Snap {
 };
 Snap wave_sync(uint64_t v);  // rendezvous of the live lanes of the calling lane's wavefront
 void block_sync();           // rendezvous of the live lanes of the workgroup
-void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+void launch(dim3 grid, dim3 block, size_t dynamic_lds, const std::function<void()> &body);
+void *dynamic_lds();         // the workgroup's `extern __shared__` array (build_simt.py rewrites the declaration to a call of this)
 
 template <class T> inline uint64_t bits(T v) {
     static_assert(sizeof(T) <= 8, "wave exchange of a type wider than 64 bits");
@@ -252,6 +253,9 @@ hipError_t hipEventRecord(hipEvent_t, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t);
 hipError_t hipEventElapsedTime(float *, hipEvent_t, hipEvent_t);
 
-template <class... A> struct simt_args {};
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    simt::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+namespace simt {
+template <class F, class... A> inline void launch_v(F f, dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args) {
+    launch(grid, block, shmem, [&]() { f(args...); });
+}
+}  // namespace simt
+#define hipLaunchKernelGGL(kernel, ...) simt::launch_v([](auto... a_) { kernel(a_...); }, __VA_ARGS__)

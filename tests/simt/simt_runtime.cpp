@@ -20,9 +20,44 @@ constexpr size_t kStack = 256u << 10;
 
 enum State { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
 
+// Context switch between the scheduler and a lane.  swapcontext() costs a signal-mask system call per switch, which is most of
+// the interpreter's run time, so on x86-64 the switch is the six callee-saved registers and the stack pointer.
+#if defined(__x86_64__)
+extern "C" void simt_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl simt_switch
+.type simt_switch,@function
+simt_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size simt_switch,.-simt_switch
+)");
+struct Context {
+    void *sp;
+};
+#else
+struct Context {
+    ucontext_t uc;
+};
+#endif
+
 struct Fibre {
     Lane lane;
-    ucontext_t ctx;
+    Context ctx;
     State state;
     char *stack;
 };
@@ -40,7 +75,7 @@ struct Block {
     BlockIds ids;
     std::vector<Fibre> fibres;
     std::vector<Wave> waves;
-    ucontext_t sched;
+    Context sched;
     const std::function<void()> *body;
     unsigned live;
 };
@@ -51,9 +86,17 @@ static std::atomic<int> g_schedule{getenv("SIMT_SCHEDULE") ? atoi(getenv("SIMT_S
 
 const BlockIds &block_ids() { return g_block->ids; }
 
+static inline void switch_context(Context &from, Context &to) {
+#if defined(__x86_64__)
+    simt_switch(&from.sp, to.sp);
+#else
+    swapcontext(&from.uc, &to.uc);
+#endif
+}
+
 static void yield_to_scheduler() {
     Fibre *f = (Fibre *)((char *)g_lane - offsetof(Fibre, lane));
-    swapcontext(&f->ctx, &g_block->sched);
+    switch_context(f->ctx, g_block->sched);
 }
 
 Snap wave_sync(uint64_t v) {
@@ -79,7 +122,7 @@ static void trampoline() {
     f->state = DONE;
     B->waves[f->lane.wave].live &= ~(1ull << f->lane.lane);
     B->live--;
-    // uc_link returns to the scheduler
+    for (;;) switch_context(f->ctx, B->sched);  // a finished lane is never resumed
 }
 
 namespace {
@@ -117,11 +160,21 @@ void run_block(Block &B, StackPool &pool, unsigned n_threads) {
         f.lane.tidx = dim3(t % B.ids.bdim.x, (t / B.ids.bdim.x) % B.ids.bdim.y, t / (B.ids.bdim.x * B.ids.bdim.y));
         f.state = RUNNABLE;
         f.stack = pool.get(t);
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = &B.sched;
-        makecontext(&f.ctx, trampoline, 0);
+#if defined(__x86_64__)
+        {   // what simt_switch pops: six registers, then `ret` into trampoline with the stack as after a call
+            void **top = (void **)(f.stack + kStack);
+            top[-1] = nullptr;
+            top[-2] = (void *)trampoline;
+            for (int r = 3; r <= 8; r++) top[-r] = nullptr;
+            f.ctx.sp = (void *)(top - 8);
+        }
+#else
+        getcontext(&f.ctx.uc);
+        f.ctx.uc.uc_stack.ss_sp = f.stack;
+        f.ctx.uc.uc_stack.ss_size = kStack;
+        f.ctx.uc.uc_link = &B.sched.uc;
+        makecontext(&f.ctx.uc, trampoline, 0);
+#endif
         B.waves[f.lane.wave].live |= 1ull << f.lane.lane;
     }
     // Which wavefront runs next is not defined by the programming model.  Schedule 0 gives every wavefront one slice in turn;
@@ -139,7 +192,7 @@ void run_block(Block &B, StackPool &pool, unsigned n_threads) {
                 Fibre &f = B.fibres[t];
                 if (f.state != RUNNABLE) continue;
                 g_lane = &f.lane;
-                swapcontext(&B.sched, &f.ctx);
+                switch_context(B.sched, f.ctx);
                 ran = true;
             }
             Wave &W = B.waves[w];
@@ -202,7 +255,10 @@ unsigned worker_count() {
 
 }  // namespace
 
-void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+static thread_local std::vector<uint64_t> g_dyn_lds;
+void *dynamic_lds() { return g_dyn_lds.data(); }
+
+void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()> &body) {
     const unsigned long long n_blocks = (unsigned long long)grid.x * grid.y * grid.z;
     const unsigned n_threads = block.x * block.y * block.z;
     if (!n_blocks || !n_threads) return;
@@ -210,6 +266,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     auto work = [&]() {
         StackPool pool;
         Block B;
+        g_dyn_lds.assign(dynamic_lds_bytes / 8 + 1, 0);
         B.body = &body;
         B.ids.bdim = block;
         B.ids.gdim = grid;

@@ -1,0 +1,100 @@
+"""The overlap library's kernel LOGIC on a machine without a GPU (see test_simt_kernels.py and tests/simt): its unmodified HIP
+sources under the lane-accurate interpreter, rocPRIM's device primitives replaced by host stand-ins, against the compiled
+reference's golden files and the oracles.  The bodies are the GPU tests' own (imported from test_gpu_overlap / test_gpu_ovlsort),
+run with nextdenovo_amd.overlap bound to the interpreted library for the duration of a test."""
+import ctypes as C
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(HERE, "simt"))
+import mm_util as M  # noqa: E402
+import test_gpu_overlap as GO  # noqa: E402  (gpu-marked as a module; its functions are called from here)
+import test_gpu_ovlsort as GS  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def simt_libs():
+    import build_simt
+    os.environ.setdefault("NDGPU_CONTEXTS", "1")
+    return C.CDLL(build_simt.build_overlap()), C.CDLL(build_simt.build())
+
+
+@pytest.fixture()
+def interpreted(simt_libs, monkeypatch):
+    from nextdenovo_amd import api, overlap
+    monkeypatch.setattr(overlap, "_lib", overlap._bind(simt_libs[0]))
+    monkeypatch.setattr(api, "_LIB", api._bind(simt_libs[1]))
+    return simt_libs
+
+
+@pytest.fixture(scope="module")
+def olib(oracle_lib):
+    return M.bind(oracle_lib)
+
+
+@pytest.fixture()
+def sets(interpreted):
+    from nextdenovo_amd import overlap
+    out = {}
+    for k in GO.SETS:
+        p = os.path.join(GO.GOLD, k + ".2bit")
+        out[k] = (overlap.ReadSet.from_2bit(p), M.load_set(p))
+    return out
+
+
+_FAST_CASES = [c for c in GO.CASES if "-I" not in c[5]]
+
+
+@pytest.mark.parametrize("case", _FAST_CASES, ids=[c[0] for c in _FAST_CASES])
+def test_ovl_bytes_match_reference_golden(sets, case):
+    """K1 ... K6 end to end: the `.ovl` bytes of the compiled reference's minimap2-nd --step 1."""
+    GO.test_ovl_bytes_match_reference_golden(sets, case)
+
+
+def test_sketch_and_index_match_oracle(olib, sets):
+    GO.test_sketch_matches_oracle(olib, sets, "ava-ont", True)
+    GO.test_index_matches_oracle(olib, sets, "ava-pb")
+
+
+def test_anchors_and_chain_arrays_match_oracle(olib, sets, monkeypatch):
+    GO.test_anchors_and_chain_arrays_match_oracle(olib, sets, "ava-ont", True, ("seed", "part"), monkeypatch)
+
+
+def test_overlap_then_sort_matches_reference_sorted_ovl(interpreted):
+    """ovl_sort's device path (radix sorts, one wavefront per seed for the admission chain, the `.bl` table)."""
+    GS.test_device_overlap_then_sort_matches_reference_sorted_ovl()
+
+
+def test_whole_stage_from_2bit_to_cns_fasta(interpreted, tmp_path):
+    """raw_align x2 -> sort_align -> seed_cns, every kernel of both libraries, in process: `cns.fasta` / `.idx` equal to what the
+    reference chain wrote (the GPU test of the same name runs the last command as a child process)."""
+    from nextdenovo_amd import minimap2_nd, nextcorrect, ovl_sort
+    d = str(tmp_path / "w")
+    shutil.copytree(GS.STAGE, d)
+    seed, part = os.path.join(d, "input.seed.001.2bit"), os.path.join(d, "input.part.001.2bit")
+    o0, o1 = os.path.join(d, "raw0.ovl"), os.path.join(d, "raw1.ovl")
+    assert minimap2_nd.run(["--step", "1", "--dual=yes", "-t", "8", "-x", "ava-ont", seed, part, "-o", o0]) == 0
+    assert minimap2_nd.run(["--step", "1", "-I", "3G", "-t", "8", "-x", "ava-ont", seed, seed, "-o", o1]) == 0
+    fofn = os.path.join(d, "ovl.fofn")
+    with open(fofn, "w") as f:
+        f.write(o0 + "\n" + o1 + "\n")
+    so = os.path.join(d, "mine.sorted.ovl")
+    assert ovl_sort.run(["-m", "2g", "-t", "4", "-k", "40", "-i", os.path.join(d, ".input.seed.001.idx"), "-o", so, fofn]) == 0
+    assert open(so, "rb").read() == GS._golden("input.seed.001.sorted.ovl")
+    assert open(so + ".bl", "rb").read() == GS._golden("input.seed.001.sorted.ovl.bl")
+    idxs = os.path.join(d, "idxs.fofn")
+    with open(idxs, "w") as f:
+        for n in sorted(os.listdir(d)):
+            if n.startswith(".input.") and n.endswith(".idx"):
+                f.write(os.path.join(d, n) + "\n")
+    out = os.path.join(d, "cns.fasta")
+    nextcorrect.cli(["-f", idxs, "-i", so, "-r", "ont", "-p", "4", "-min_len_seed", "1250", "-o", out])
+    assert open(out, "rb").read() == GS._golden("cns.default.fasta", gz=True)
+    assert open(out + ".idx", "rb").read() == GS._golden("cns.default.fasta.idx", gz=True)
