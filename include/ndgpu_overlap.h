@@ -43,6 +43,9 @@ typedef struct ndgpu_ovl_opt {
 	int32_t dvt, maxhan1, maxhan2;      /* --dvt, --maxhan1, --maxhan2 */
 	float   mid_occ_frac;               /* -f FLOAT (< 1) */
 	int32_t mid_occ;                    /* -f INT (>= 1); 0 = derive from mid_occ_frac */
+	int32_t mode;                       /* --mode (2); 3 = HiFi: chain ends trimmed (nd_fix_bad_ends, map.c:340-373) and every hit
+	                                       extended into the unaligned read ends (nd_extend_ends, map.c:385-482) before the filter */
+	float   d_factor;                   /* --df (0.1): weight of the extension's running score (x + y) * d_factor - d */
 } ndgpu_ovl_opt;
 
 typedef struct ndgpu_ovl_index ndgpu_ovl_index;
@@ -160,6 +163,8 @@ int64_t ndgpu_ovl_debug_anchors(ndgpu_ovl_index *idx, uint32_t q, uint64_t **ax,
 typedef struct ndgpu_ovl_stats {
 	double sketch_ms, index_sort_ms, seed_ms, sort_ms, exact_sort_ms, chain_ms, hits_ms;
 	uint64_t bases_sketched, minimizers, anchors, tie_reads, chain_cells, chains, overlaps, map_calls, batches;
+	uint64_t ext_problems, ext_launches; /* --mode 3: end extensions run (two candidates per hit), launches they took */
+	double ext_ms;
 } ndgpu_ovl_stats;
 void ndgpu_ovl_get_stats(const ndgpu_ovl_index *idx, ndgpu_ovl_stats *st);
 void ndgpu_ovl_reset_stats(ndgpu_ovl_index *idx);

@@ -12,12 +12,16 @@ namespace ndovl {
 
 constexpr uint64_t kSeedTandem = 1ULL << 42; // MM_SEED_TANDEM (minimap2/mmpriv.h:20)
 constexpr uint64_t kSeedSelf = 1ULL << 43;   // MM_SEED_SELF   (minimap2/mmpriv.h:21)
+constexpr uint64_t kSeedLongJoin = 1ULL << 40; // MM_SEED_LONG_JOIN (minimap2/mmpriv.h:18)
 
 struct OvlParams {
 	int32_t k, w, hpc;
 	int32_t no_diag, no_dual;
 	int32_t min_cnt, min_sc, bw, max_gap, max_skip, max_iter;
 	int32_t minlen, dvt, maxhan1, maxhan2;
+	int32_t mode3;     // --mode 3: chain ends trimmed, hits extended into the unaligned read ends before the output filter
+	int32_t ide_ml;    // mm_mapopt_t::ide_ml (6000): cap of the extension's edit budget
+	float d_factor;    // --df (0.1)
 };
 
 // minimizer index of the target reads, resident in HBM
@@ -112,5 +116,15 @@ void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, c
 void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,
                          const uint64_t *rec_off, OvlRec *dense, hipStream_t s);
 size_t sort_job_bytes();
+
+// --mode 3 (minimap2/map.c:385-482): two extension problems per hit (the query's 5' side, its 3' side)
+void launch_ext_size(const OvlRec *recs, uint64_t n, const uint32_t *qlen, const uint32_t *tlen, const OvlParams &P, uint32_t *need,
+                     hipStream_t s);
+void launch_ext_ends(const OvlRec *recs, uint64_t t0, uint64_t t1, const uint32_t *qwords, const uint64_t *qwoff, const uint32_t *qlen,
+                     const uint32_t *twords, const uint64_t *twoff, const uint32_t *tlen, const OvlParams &P, const uint64_t *fr_off,
+                     uint64_t fr_base, int32_t *fr_pool, int32_t *ext_x, int32_t *ext_y, hipStream_t s);
+void launch_ext_apply(OvlRec *recs, uint64_t n, const int32_t *ext_x, const int32_t *ext_y, const uint32_t *qid, const uint32_t *qlen,
+                      const uint32_t *tid, const uint32_t *tlen, const OvlParams &P, uint32_t *keep, hipStream_t s);
+void launch_scatter_recs(const OvlRec *recs, uint64_t n, const uint32_t *keep, const uint64_t *pos, OvlRec *out, hipStream_t s);
 
 } // namespace ndovl

@@ -412,6 +412,7 @@ static OvlParams to_params(const ndgpu_ovl_opt &o)
 	P.k = o.k, P.w = o.w, P.hpc = o.hpc, P.no_diag = o.no_diag, P.no_dual = o.no_dual, P.min_cnt = o.min_cnt, P.min_sc = o.min_chain_score;
 	P.bw = o.bw, P.max_gap = o.max_gap, P.max_skip = o.max_chain_skip, P.max_iter = o.max_chain_iter, P.minlen = o.minlen, P.dvt = o.dvt;
 	P.maxhan1 = o.maxhan1, P.maxhan2 = o.maxhan2;
+	P.mode3 = o.mode == 3, P.ide_ml = 6000 /* mm_mapopt_t::ide_ml, options.c:60: no command-line switch */, P.d_factor = o.d_factor;
 	return P;
 }
 
@@ -603,6 +604,48 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		launch_compact_recs(r_aoff.p, nb, P.min_cnt, recs.p, n_rec.p, rec_off.p, dense.p, stream);
 		HIP_OK(hipGetLastError());
 		st.hits_ms += tm.stop();
+		if (P.mode3 && n_out) {
+			// --mode 3: the records are provisional (see K5); extend both ends of every hit, then filter and name them
+			tm.start();
+			const uint64_t n_task = 2 * n_out;
+			DevBuf<uint32_t> need(n_task + 1);
+			need.zero(stream);
+			launch_ext_size(dense.p, n_out, Q.len.p, T.len.p, P, need.p, stream);
+			DevBuf<uint64_t> fr_off(n_task + 1);
+			exscan(need.p, fr_off.p, n_task + 1);
+			std::vector<uint64_t> h_off(n_task + 1);
+			fr_off.download(h_off.data(), n_task + 1, stream);
+			HIP_OK(hipStreamSynchronize(stream));
+			DevBuf<int32_t> ext_x(n_task), ext_y(n_task), fr;
+			uint64_t scratch = 256ULL << 20; // ints of furthest-reaching scratch per launch (1 GB)
+			if (const char *e = getenv("NDGPU_OVL_EXT_SCRATCH")) scratch = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
+			for (uint64_t t0 = 0; t0 < n_task;) {
+				uint64_t t1 = t0;
+				while (t1 < n_task && (t1 == t0 || h_off[t1 + 1] - h_off[t0] <= scratch)) ++t1;
+				const uint64_t ints = h_off[t1] - h_off[t0];
+				if (fr.n < ints + 1) fr.alloc(ints + 1);
+				if (ints) HIP_OK(hipMemsetAsync(fr.p, 0, ints * sizeof(int32_t), stream));
+				launch_ext_ends(dense.p, t0, t1, Q.words.p, Q.woff.p, Q.len.p, T.words.p, T.woff.p, T.len.p, P, fr_off.p, h_off[t0], fr.p,
+				                ext_x.p, ext_y.p, stream);
+				++st.ext_launches;
+				t0 = t1;
+			}
+			for (uint64_t t = 0; t < n_task; ++t) st.ext_problems += h_off[t + 1] != h_off[t];
+			DevBuf<uint32_t> keep(n_out + 1);
+			keep.zero(stream);
+			launch_ext_apply(dense.p, n_out, ext_x.p, ext_y.p, Q.id.p, Q.len.p, T.id.p, T.len.p, P, keep.p, stream);
+			DevBuf<uint64_t> pos(n_out + 1);
+			exscan(keep.p, pos.p, n_out + 1);
+			uint64_t n_keep = 0;
+			pos.download(&n_keep, 1, stream, n_out);
+			HIP_OK(hipStreamSynchronize(stream));
+			DevBuf<OvlRec> fin(n_keep + 1);
+			launch_scatter_recs(dense.p, n_out, keep.p, pos.p, fin.p, stream);
+			HIP_OK(hipGetLastError());
+			dense = std::move(fin);
+			n_out = n_keep;
+			st.ext_ms += tm.stop();
+		}
 		const size_t old = out.size();
 		out.resize(old + n_out);
 		if (n_out) HIP_OK(hipMemcpyAsync(out.data() + old, dense.p, n_out * sizeof(OvlRec), hipMemcpyDeviceToHost, stream));
@@ -636,6 +679,7 @@ int ndgpu_ovl_opt_preset(const char *preset, ndgpu_ovl_opt *o)
 	o->k = 15, o->w = 10, o->hpc = 0;
 	o->seed = 11, o->mid_occ_frac = 2e-4f, o->min_cnt = 3, o->min_chain_score = 40, o->bw = 500, o->max_gap = 5000;
 	o->max_chain_skip = 25, o->max_chain_iter = 5000, o->minlen = 500, o->maxhan1 = 5000, o->maxhan2 = 500, o->dvt = 0;
+	o->mode = 2, o->d_factor = 0.1f; // options.c:56,62 (--step 1 looks at the mode only to see whether it is 3)
 	if (!preset) return 0;
 	if (strcmp(preset, "ava-ont") == 0) { // options.c:84-88
 		o->k = 15, o->w = 5, o->hpc = 0, o->no_diag = 1, o->no_dual = 1;

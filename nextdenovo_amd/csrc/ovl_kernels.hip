@@ -1345,9 +1345,6 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 		else qs = (int32_t)qlen - ((int32_t)BY[last] + 1), qe = (int32_t)qlen - ((int32_t)BY[first] + 1 - span0);
 		const uint32_t tid = ix.id[rid];
 		if (tid == qid) continue;
-		if (qe - qs < P.minlen) continue;
-		if (P.dvt && !dovetail_class((int)rev, (uint32_t)qs, (uint32_t)qe, qlen, (uint32_t)rs, (uint32_t)re, ix.len[rid], P.maxhan1,
-		                             P.maxhan2)) continue;
 		int32_t mlen = span0;
 		for (int32_t m = first + 1; m <= last; ++m) {
 			const int sp = (int)(BY[m] >> 32 & 0xff);
@@ -1356,6 +1353,53 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 			mlen += tl > sp && ql > sp ? sp : tl < ql ? tl : ql;
 		}
 		OvlRec r;
+		if (P.mode3) {
+			// nd_fix_bad_ends + nd_update_coors (minimap2/map.c:313-373): anchors at either end of the chain that sit off its
+			// diagonal by more than half the length walked so far are dropped; the match length keeps the whole chain's value.
+			// The record is provisional: local read indices instead of names, no length / dovetail filter yet -- both follow
+			// the end extension (ext_apply_kernel).
+			int32_t as = first, ce = first + cnt; // anchors [as, ce) survive
+			if (cnt >= 3) {
+				const int32_t bw = P.bw, min_match = P.min_sc * 2;
+				int32_t l = span0, mm = span0;
+				for (int32_t i = first + 1; i < first + cnt - 1; ++i) {
+					if (BY[i] & kSeedLongJoin) break;
+					const int32_t sp = (int32_t)(BY[i] >> 32 & 0xff);
+					const int32_t lr = (int32_t)BX[i] - (int32_t)BX[i - 1], lq = (int32_t)BY[i] - (int32_t)BY[i - 1];
+					const int32_t lo = lr < lq ? lr : lq, hi = lr > lq ? lr : lq;
+					if (hi - lo > l >> 1) as = i;
+					l += lo;
+					mm += lo < sp ? lo : sp;
+					if (l >= bw << 1 || (mm >= min_match && mm >= bw) || mm >= mlen >> 1) break;
+				}
+				l = mm = (int32_t)(BY[last] >> 32 & 0xff);
+				for (int32_t i = last - 1; i > as; --i) {
+					if (BY[i + 1] & kSeedLongJoin) break;
+					const int32_t sp = (int32_t)(BY[i + 1] >> 32 & 0xff);
+					const int32_t lr = (int32_t)BX[i + 1] - (int32_t)BX[i], lq = (int32_t)BY[i + 1] - (int32_t)BY[i];
+					const int32_t lo = lr < lq ? lr : lq, hi = lr > lq ? lr : lq;
+					if (hi - lo > l >> 1) ce = i + 1;
+					l += lo;
+					mm += lo < sp ? lo : sp;
+					if (l >= bw << 1 || (mm >= min_match && mm >= bw) || mm >= mlen >> 1) break;
+				}
+			}
+			int32_t ts = rs, te = re, q0 = qs, q1 = qe;
+			if (as != first || ce != first + cnt) {
+				const int32_t sp = (int32_t)(BY[as] >> 32 & 0xff), lz = ce - 1;
+				ts = (int32_t)BX[as] + 1 > sp ? (int32_t)BX[as] + 1 - sp : 0;
+				te = (int32_t)BX[lz] + 1;
+				if (!rev) q0 = (int32_t)BY[as] + 1 - sp, q1 = (int32_t)BY[lz] + 1;
+				else q0 = (int32_t)qlen - ((int32_t)BY[lz] + 1), q1 = (int32_t)qlen - ((int32_t)BY[as] + 1 - sp);
+			}
+			r.rev = rev, r.qname = rd, r.qs = (uint32_t)q0, r.qe = (uint32_t)q1, r.tname = rid, r.ts = (uint32_t)ts, r.te = (uint32_t)te,
+			r.match = (uint32_t)mlen;
+			out[n_out++] = r;
+			continue;
+		}
+		if (qe - qs < P.minlen) continue;
+		if (P.dvt && !dovetail_class((int)rev, (uint32_t)qs, (uint32_t)qe, qlen, (uint32_t)rs, (uint32_t)re, ix.len[rid], P.maxhan1,
+		                             P.maxhan2)) continue;
 		r.rev = rev, r.qname = qid, r.qs = (uint32_t)qs, r.qe = (uint32_t)qe, r.tname = tid, r.ts = (uint32_t)rs, r.te = (uint32_t)re,
 		r.match = (uint32_t)mlen;
 		out[n_out++] = r;
@@ -1388,5 +1432,179 @@ void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, 
 {
 	if (n_reads) hipLaunchKernelGGL(compact_recs_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, min_cnt, recs, n_rec, rec_off, dense);
 }
+
+// ------------------------------------------------------------------------------------------------
+// --mode 3 (HiFi): nd_extend_ends (minimap2/map.c:385-482, called from map.c:919-928).  Every hit is extended into the
+// unaligned read ends with the greedy O(ND) extension (extend_rev on the query's 5' side, extend_fwd on its 3' side,
+// lib/align.c:256-426): over at most 2 x the shorter overhang of the target, edit budget overhang / 4 capped at ide_ml,
+// band 500.  Two independent problems per hit; one lane owns one problem (they are short: the overhang left by a chain's
+// last minimizer), its furthest-reaching array in an HBM slice that the host zeroes (clean_V).  Bases come straight from
+// the resident 2-bit reads; on a reverse hit the target slice is read backwards and complemented.
+
+struct ExtGeom {
+	int32_t subq, subt, max_d; // problem sizes (subt already cut to 2 x the shorter overhang)
+	int32_t t_st, t_en;        // target slice [t_st, t_en)
+	int32_t q_st;              // first query base of the query slice
+	bool t_low;                // the target overhang below ts (else above te)
+};
+
+__device__ __forceinline__ bool ext_geometry(const OvlRec &r, int side, uint32_t qlen, uint32_t tlen, const OvlParams &P, ExtGeom &g)
+{
+	if (P.dvt && !dovetail_class((int)r.rev, r.qs, r.qe, qlen, r.ts, r.te, tlen, P.maxhan1 * 3, P.maxhan2 * 3)) return false;
+	const bool left_q = side == 0;
+	g.t_low = r.rev ? !left_q : left_q;
+	g.subq = left_q ? (int32_t)r.qs : (int32_t)(qlen - r.qe);
+	g.subt = g.t_low ? (int32_t)r.ts : (int32_t)(tlen - r.te);
+	const int32_t minlen = g.subt > g.subq ? g.subq : g.subt;
+	if (minlen < 10) return false;
+	g.max_d = minlen / 4 > P.ide_ml ? P.ide_ml : (minlen > 20 ? minlen / 4 : minlen);
+	if (g.subt > (minlen << 1)) {
+		g.subt = minlen << 1;
+		if (g.t_low) g.t_st = (int32_t)r.ts - g.subt, g.t_en = (int32_t)r.ts;
+		else g.t_st = (int32_t)r.te, g.t_en = (int32_t)r.te + g.subt;
+	} else {
+		if (g.t_low) g.t_st = 0, g.t_en = (int32_t)r.ts;
+		else g.t_st = (int32_t)r.te, g.t_en = (int32_t)tlen;
+	}
+	g.q_st = left_q ? 0 : (int32_t)r.qe;
+	return true;
+}
+
+__global__ void ext_size_kernel(const OvlRec *__restrict__ recs, uint64_t n, const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tlen,
+                                OvlParams P, uint32_t *__restrict__ need)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= 2 * n) return;
+	const OvlRec r = recs[t >> 1];
+	ExtGeom g;
+	need[t] = ext_geometry(r, (int)(t & 1), qlen[r.qname], tlen[r.tname], P, g) ? 2u * (uint32_t)(g.max_d + 2) + 2u : 0u;
+}
+
+// (x + y) * d_factor - d with the product rounded to float before the subtraction, as the host code computes it (a fused
+// multiply-add would keep the exact product and flip near-ties of the peak test)
+__device__ __forceinline__ float ext_score(int xy, float f, int d)
+{
+#pragma clang fp contract(off)
+	float p = (float)xy * f;
+	asm volatile("" : "+v"(p));
+	return p - (float)d;
+}
+
+__device__ __forceinline__ int base2(const uint32_t *__restrict__ w, int i) { return (int)(w[i >> 4] >> (30 - 2 * (i & 15)) & 3u); }
+
+__global__ void __launch_bounds__(64) ext_ends_kernel(const OvlRec *__restrict__ recs, uint64_t t0, uint64_t t1, const uint32_t *__restrict__ qwords,
+                                                       const uint64_t *__restrict__ qwoff, const uint32_t *__restrict__ qlen,
+                                                       const uint32_t *__restrict__ twords, const uint64_t *__restrict__ twoff,
+                                                       const uint32_t *__restrict__ tlen, OvlParams P, const uint64_t *__restrict__ fr_off,
+                                                       uint64_t fr_base, int32_t *__restrict__ fr_pool, int32_t *__restrict__ ext_x,
+                                                       int32_t *__restrict__ ext_y)
+{
+	const uint64_t t = t0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= t1) return;
+	const OvlRec r = recs[t >> 1];
+	ExtGeom g;
+	const int side = (int)(t & 1);
+	if (!ext_geometry(r, side, qlen[r.qname], tlen[r.tname], P, g)) { ext_x[t] = 0, ext_y[t] = 0; return; }
+	const uint32_t *__restrict__ Q = qwords + qwoff[r.qname];
+	const uint32_t *__restrict__ T = twords + twoff[r.tname];
+	int32_t *fr = fr_pool + (fr_off[t] - fr_base);
+	const bool back = side == 0; // extend_rev: both strings are consumed from their 3' ends
+	const int ql = g.subq, tl = g.subt, off = g.max_d + 2;
+	// string positions -> read positions: query char j = Q[q_st + j]; target char j = T[t_st + j], or on a reverse hit the
+	// complement of T[t_en - 1 - j]
+	const int comp = r.rev ? 3 : 0;
+	int lo = 0, hi = 0, reach = -1, done = 0, o1 = 0, o2 = 0;
+	float peak = 0;
+	for (int d = 0; d < g.max_d && hi - lo <= 500 && !done; ++d) {
+		for (int k = lo; k <= hi; k += 2) {
+			int x;
+			if (k == lo || (k != hi && fr[k - 1 + off] < fr[k + 1 + off])) x = fr[k + 1 + off];
+			else x = fr[k - 1 + off] + 1;
+			int y = x - k;
+			while (x < ql && y < tl) {
+				const int jq = back ? ql - x - 1 : x, jt = back ? tl - y - 1 : y;
+				const int cq = base2(Q, g.q_st + jq);
+				const int ct = r.rev ? base2(T, g.t_en - 1 - jt) ^ comp : base2(T, g.t_st + jt);
+				if (cq != ct) break;
+				++x, ++y;
+			}
+			fr[k + off] = x;
+			if (x + y > reach) {
+				reach = x + y;
+				const float score = ext_score(x + y, P.d_factor, d);
+				if (score > peak) peak = score, o1 = x, o2 = y;
+				else if (score < peak - 30) { done = 2; break; }
+			}
+			if (x >= ql || y >= tl) {
+				if (ext_score(x + y, P.d_factor, d) > 0) o1 = x, o2 = y;
+				done = 1;
+				break;
+			}
+		}
+		if (done) break;
+		int nlo = hi, nhi = lo; // band re-centring (lib/align.c:473-489)
+		for (int k2 = lo; k2 < nlo; k2 += 2)
+			if (fr[k2 + off] * 2 - k2 >= reach - 150) nlo = k2;
+		for (int k2 = hi; k2 > nhi; k2 -= 2)
+			if (fr[k2 + off] * 2 - k2 >= reach - 150) nhi = k2;
+		hi = nhi + 1, lo = nlo - 1;
+	}
+	ext_x[t] = o1, ext_y[t] = o2;
+}
+
+// coordinates moved by the two extensions, names restored, then the step-1 output filter (minimap2/map.c:1297-1304)
+__global__ void ext_apply_kernel(OvlRec *__restrict__ recs, uint64_t n, const int32_t *__restrict__ ext_x, const int32_t *__restrict__ ext_y,
+                                 const uint32_t *__restrict__ qid, const uint32_t *__restrict__ qlen, const uint32_t *__restrict__ tid,
+                                 const uint32_t *__restrict__ tlen, OvlParams P, uint32_t *__restrict__ keep)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	OvlRec r = recs[i];
+	const uint32_t ql = qlen[r.qname], tl = tlen[r.tname];
+	// 5' side of the query: qs moves down; the target moves below ts (forward hit) or above te (reverse hit)
+	r.qs -= (uint32_t)ext_x[2 * i];
+	if (r.rev) r.te += (uint32_t)ext_y[2 * i]; else r.ts -= (uint32_t)ext_y[2 * i];
+	r.qe += (uint32_t)ext_x[2 * i + 1];
+	if (r.rev) r.ts -= (uint32_t)ext_y[2 * i + 1]; else r.te += (uint32_t)ext_y[2 * i + 1];
+	bool ok = (int32_t)(r.qe - r.qs) >= P.minlen;
+	if (ok && P.dvt && !dovetail_class((int)r.rev, r.qs, r.qe, ql, r.ts, r.te, tl, P.maxhan1, P.maxhan2)) ok = false;
+	r.qname = qid[r.qname], r.tname = tid[r.tname];
+	recs[i] = r;
+	keep[i] = ok ? 1u : 0u;
+}
+
+__global__ void scatter_recs_kernel(const OvlRec *__restrict__ recs, uint64_t n, const uint32_t *__restrict__ keep, const uint64_t *__restrict__ pos,
+                                    OvlRec *__restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && keep[i]) out[pos[i]] = recs[i];
+}
+
+void launch_ext_size(const OvlRec *recs, uint64_t n, const uint32_t *qlen, const uint32_t *tlen, const OvlParams &P, uint32_t *need,
+                     hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(ext_size_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, recs, n, qlen, tlen, P, need);
+}
+
+void launch_ext_ends(const OvlRec *recs, uint64_t t0, uint64_t t1, const uint32_t *qwords, const uint64_t *qwoff, const uint32_t *qlen,
+                     const uint32_t *twords, const uint64_t *twoff, const uint32_t *tlen, const OvlParams &P, const uint64_t *fr_off,
+                     uint64_t fr_base, int32_t *fr_pool, int32_t *ext_x, int32_t *ext_y, hipStream_t s)
+{
+	if (t1 > t0) hipLaunchKernelGGL(ext_ends_kernel, dim3((unsigned)((t1 - t0 + 63) / 64)), dim3(64), 0, s, recs, t0, t1, qwords, qwoff, qlen,
+	                                twords, twoff, tlen, P, fr_off, fr_base, fr_pool, ext_x, ext_y);
+}
+
+void launch_ext_apply(OvlRec *recs, uint64_t n, const int32_t *ext_x, const int32_t *ext_y, const uint32_t *qid, const uint32_t *qlen,
+                      const uint32_t *tid, const uint32_t *tlen, const OvlParams &P, uint32_t *keep, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(ext_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, ext_x, ext_y, qid, qlen, tid, tlen,
+	                          P, keep);
+}
+
+void launch_scatter_recs(const OvlRec *recs, uint64_t n, const uint32_t *keep, const uint64_t *pos, OvlRec *out, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(scatter_recs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, keep, pos, out);
+}
+
 
 } // namespace ndovl

@@ -3,14 +3,15 @@
 
 Takes the command line nextDenovo writes for the raw-align subtasks (reference nextDenovo:436-466):
 
-    python -m nextdenovo_amd.minimap2_nd --step 1 [--dual=yes] -t 8 -x ava-ont|ava-pb|ava-hifi [-f N] [-I 4G] target.2bit query.2bit -o out.ovl
+    python -m nextdenovo_amd.minimap2_nd --step 1 [--dual=yes] [--mode 3] -t 8 -x ava-ont|ava-pb|ava-hifi [-f N] [-I 4G] target.2bit query.2bit -o out.ovl
 
 and writes the byte-identical overlap file.  Mirrors minimap2/main.c for the options of this path (preset
 first, then the remaining options in order: main.c:140-366); the index is split into parts exactly as
 mm_idx_gen does with -I (index.c:284-287,351-360), the occurrence threshold comes from the first part
 (options.c:70-71), every query file is mapped against every part in turn (main.c:474-507).
 
-Options of other paths (-a, -c, --step 2/3, --mode 3, FASTA input) are rejected, not approximated.
+`--mode 3` (HiFi: chain ends trimmed, every hit extended into the unaligned read ends, minimap2/map.c:340-482) is built in.
+Options of other paths (-a, -c, --step 2/3, FASTA input) are rejected, not approximated.
 """
 from __future__ import annotations
 
@@ -50,7 +51,7 @@ class Args:
         self.ops = []  # (name, value) in command-line order, applied after the preset
 
 
-LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode"}
+LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df"}
 SHORT_WITH_ARG = set("xtfIKkwornmgsNpM")
 
 
@@ -139,6 +140,10 @@ def build_opt(a: Args) -> overlap.Opt:
             opt.dvt = 1
         elif name == "--seed":
             opt.seed = int(val)
+        elif name == "--mode":
+            opt.mode = int(val)  # --step 1 only asks whether it is 3 (minimap2/map.c:488,919)
+        elif name == "--df":
+            opt.d_factor = float(val)
         elif name == "-o":
             a.out = val
         else:

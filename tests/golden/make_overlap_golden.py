@@ -30,6 +30,12 @@ CASES = [  # (file tag, preset, target, query, dual, extra argv)
     ("hifi.sxs", "ava-hifi", "hseed", "hseed", False, ()),
     ("hifi.sxp.dual", "ava-hifi", "hseed", "hpart", True, ()),
     ("hifi.sxs.f40", "ava-hifi", "hseed", "hseed", False, ("-f", "40")),   # nextDenovo passes -f seed_depth*20 (config_parser.py:46-47)
+    # --mode 3: chain ends trimmed (nd_fix_bad_ends) and every hit extended into the unaligned read ends (nd_extend_ends,
+    # minimap2/map.c:340-482) before the step-1 filter; with --dvt the extension is skipped for hits that are not near-dovetails
+    ("hifi.sxs.m3", "ava-hifi", "hseed", "hseed", False, ("--mode", "3")),
+    ("hifi.sxp.dual.dvt.m3", "ava-hifi", "hseed", "hpart", True, ("--mode", "3", "--dvt")),
+    ("ont.sxp.dual.m3", "ava-ont", "seed", "part", True, ("--mode", "3")),
+    ("pb.sxs.m3", "ava-pb", "seed", "seed", False, ("--mode", "3")),
 ]
 SETS = ("seed", "part", "hseed", "hpart")
 

@@ -158,7 +158,7 @@ def test_minimap2_nd_cli_host_logic():
     o = m.build_opt(a)
     assert (o.k, o.w, o.hpc, o.mid_occ, o.bw, o.min_chain_score) == (51, 51, 1, 800, 500, 100)
     assert abs(m.build_opt(m.parse_argv("--step 1 -x ava-hifi a b".split())).mid_occ_frac - 1e-4) < 1e-9
-    for bad in ("--step 2 -x ava-ont a b", "--step 1 -x ava-hifi --mode 3 a b", "--step 1 -x map-ont a b", "--step 1 -x ava-ont -c a b"):
+    for bad in ("--step 2 -x ava-ont a b", "--step 1 -x map-ont a b", "--step 1 -x ava-ont -c a b"):
         with pytest.raises((SystemExit, ValueError)):
             m.build_opt(m.parse_argv(bad.split()))
 

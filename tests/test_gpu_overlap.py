@@ -44,6 +44,10 @@ def dev_opt(preset, dual, extra=()):
         o.mid_occ_frac = kw["mid_occ_frac"]
     if "mid_occ" in kw:
         o.mid_occ = kw["mid_occ"]
+    if kw.get("mode3"):
+        o.mode = 3
+    if "--dvt" in extra:
+        o.dvt = 1
     return o
 
 

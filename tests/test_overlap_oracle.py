@@ -41,6 +41,8 @@ def case_kwargs(extra, preset=None):
     if "-I" in extra:
         from nextdenovo_amd.minimap2_nd import parse_num
         kw["batch_size"] = parse_num(extra[extra.index("-I") + 1])
+    if "--mode" in extra and extra[extra.index("--mode") + 1] == "3":
+        kw["mode3"] = True
     return kw
 
 
@@ -49,7 +51,7 @@ def test_oracle_matches_golden_ovl(lib, sets, case):
     tag, preset, t, q, dual, extra = case
     with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
         want = f.read()
-    got, _ = M.step1(lib, M.preset(preset, dual), sets[t], sets[q], **case_kwargs(extra, preset))
+    got, _ = M.step1(lib, M.preset(preset, dual, dvt=1 if "--dvt" in extra else 0), sets[t], sets[q], **case_kwargs(extra, preset))
     assert got == want
 
 

@@ -58,6 +58,16 @@ def test_ovl_bytes_match_reference_golden(sets, case):
     GO.test_ovl_bytes_match_reference_golden(sets, case)
 
 
+_CLI_CASES = [c for c in GO.CASES if "-I" in c[5] or "--mode" in c[5]]
+
+
+@pytest.mark.parametrize("case", _CLI_CASES, ids=[c[0] for c in _CLI_CASES])
+def test_stage_cli_writes_reference_bytes(interpreted, case, tmp_path, monkeypatch):
+    """The command line itself, for the multi-part index runs and `--mode 3` (HiFi end extension, several extension launches)."""
+    monkeypatch.setenv("NDGPU_OVL_EXT_SCRATCH", "20000")
+    GO.test_stage_cli_writes_reference_bytes(case, tmp_path)
+
+
 def test_sketch_and_index_match_oracle(olib, sets):
     GO.test_sketch_matches_oracle(olib, sets, "ava-ont", True)
     GO.test_index_matches_oracle(olib, sets, "ava-pb")
