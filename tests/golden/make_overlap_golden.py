@@ -30,8 +30,10 @@ CASES = [  # (file tag, preset, target, query, dual, extra argv)
     ("hifi.sxs", "ava-hifi", "hseed", "hseed", False, ()),
     ("hifi.sxp.dual", "ava-hifi", "hseed", "hpart", True, ()),
     ("hifi.sxs.f40", "ava-hifi", "hseed", "hseed", False, ("-f", "40")),   # nextDenovo passes -f seed_depth*20 (config_parser.py:46-47)
-    # --mode 3: chain ends trimmed (nd_fix_bad_ends) and every hit extended into the unaligned read ends (nd_extend_ends,
-    # minimap2/map.c:340-482) before the step-1 filter; with --dvt the extension is skipped for hits that are not near-dovetails
+]
+# --mode 3: chain ends trimmed (nd_fix_bad_ends) and every hit extended into the unaligned read ends (nd_extend_ends,
+# minimap2/map.c:340-482) before the step-1 filter; with --dvt the extension is skipped for hits that are not near-dovetails
+CASES_M3 = [
     ("hifi.sxs.m3", "ava-hifi", "hseed", "hseed", False, ("--mode", "3")),
     ("hifi.sxp.dual.dvt.m3", "ava-hifi", "hseed", "hpart", True, ("--mode", "3", "--dvt")),
     ("ont.sxp.dual.m3", "ava-ont", "seed", "part", True, ("--mode", "3")),
@@ -63,7 +65,7 @@ def main():
     files["hseed"], files["hpart"] = hs, hp
     for k in ("hseed", "hpart"):
         shutil.copy(files[k], os.path.join(out, k + ".2bit"))
-    for tag, preset, t, q, dual, extra in CASES:
+    for tag, preset, t, q, dual, extra in CASES + CASES_M3:
         b = M.ref_step1(files[t], files[q], os.path.join(out, tag + ".ovl"), preset, dual, extra)
         print(tag, len(b), "bytes")
 

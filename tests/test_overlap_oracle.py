@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import mm_util as M  # noqa: E402
-from make_overlap_golden import CASES, SETS  # noqa: E402
+from make_overlap_golden import CASES, CASES_M3, SETS  # noqa: E402
 
 GOLD = os.path.join(HERE, "golden", "overlap")
 
@@ -46,7 +46,7 @@ def case_kwargs(extra, preset=None):
     return kw
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("case", CASES + CASES_M3, ids=[c[0] for c in CASES + CASES_M3])
 def test_oracle_matches_golden_ovl(lib, sets, case):
     tag, preset, t, q, dual, extra = case
     with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:

@@ -49,7 +49,9 @@ def sets(interpreted):
     return out
 
 
-_FAST_CASES = [c for c in GO.CASES if "-I" not in c[5]]
+from make_overlap_golden import CASES_M3  # noqa: E402
+
+_FAST_CASES = [c for c in GO.CASES + CASES_M3 if "-I" not in c[5]]
 
 
 @pytest.mark.parametrize("case", _FAST_CASES, ids=[c[0] for c in _FAST_CASES])
@@ -58,7 +60,7 @@ def test_ovl_bytes_match_reference_golden(sets, case):
     GO.test_ovl_bytes_match_reference_golden(sets, case)
 
 
-_CLI_CASES = [c for c in GO.CASES if "-I" in c[5] or "--mode" in c[5]]
+_CLI_CASES = [c for c in GO.CASES + CASES_M3 if "-I" in c[5] or "--mode" in c[5]]
 
 
 @pytest.mark.parametrize("case", _CLI_CASES, ids=[c[0] for c in _CLI_CASES])
