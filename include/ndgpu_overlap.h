@@ -46,6 +46,9 @@ typedef struct ndgpu_ovl_opt {
 	int32_t mode;                       /* --mode (2); 3 = HiFi: chain ends trimmed (nd_fix_bad_ends, map.c:340-373) and every hit
 	                                       extended into the unaligned read ends (nd_extend_ends, map.c:385-482) before the filter */
 	float   d_factor;                   /* --df (0.1): weight of the extension's running score (x + y) * d_factor - d */
+	int32_t step;                       /* --step: 1 (raw reads, 8-field records) or 2 (corrected reads, `cns_align`, 10-field records) */
+	float   minide;                     /* --step 2: --minide (0.05) */
+	int32_t minmatch;                   /* --step 2: --minmatch (100) */
 } ndgpu_ovl_opt;
 
 typedef struct ndgpu_ovl_index ndgpu_ovl_index;
@@ -97,6 +100,9 @@ int64_t ndgpu_2bit_index(const uint32_t *words, uint64_t n_words, uint32_t *ids,
 typedef struct ndgpu_fastx ndgpu_fastx;
 ndgpu_fastx *ndgpu_fastx_open(const char *path);
 int64_t ndgpu_fastx_read(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *off, uint32_t *len, int64_t max_recs);
+/* the same, also handing out strtoul(name) of every record (the numeric read names of the corrected-read files that
+ * minimap2-nd --step 2 maps, minimap2/map.c:1298-1300); ids may be NULL */
+int64_t ndgpu_fastx_read_named(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *off, uint32_t *len, uint32_t *ids, int64_t max_recs);
 uint64_t ndgpu_fastx_pending(const ndgpu_fastx *h);
 void ndgpu_fastx_close(ndgpu_fastx *h);
 
@@ -166,6 +172,29 @@ typedef struct ndgpu_ovl_stats {
 	uint64_t ext_problems, ext_launches; /* --mode 3: end extensions run (two candidates per hit), launches they took */
 	double ext_ms;
 } ndgpu_ovl_stats;
+/* ---- `minimap2-nd --step 2 --mode 0` (the cns_align command of nextDenovo:356-366 with the re-alignment switched off) ----
+ * one --step 2 overlap before varint coding: the fields of `overlap_i` (lib/ovl.h); identity = matches * 10000 / block length */
+typedef struct ndgpu_ovl_rec10 {
+	uint32_t rev, qname, qs, qe, qlen, tname, ts, te, tlen, identity;
+} ndgpu_ovl_rec10;
+/* replaces: worker_for without re-alignment + the writer's record filter (minimap2/map.c:988-1031, 1305-1309) for the reads of one
+ * query file against one index part: hits marked per target, filtered by length / identity / minimum block length.  opt->step must
+ * be 2 and opt->mode 0.  *recs is malloc'd (ndgpu_ovl_free).  Returns the record count, < 0 on error. */
+int64_t ndgpu_ovl_map2(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                       uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, ndgpu_ovl_rec10 **recs);
+/* replaces: filter_ovl (lib/ovl.c:449-563), whose per-read state lives for the whole run (opt.os, main.c:272), encode_ovl_i
+ * (lib/ovl.c:205-253) and out_bl (lib/ovl.c:339-362).  Host code: a record's verdict depends on every record before it. */
+typedef struct ndgpu_s2_state ndgpu_s2_state;
+ndgpu_s2_state *ndgpu_s2_new(void);
+void ndgpu_s2_free(ndgpu_s2_state *st);
+/* the records of one ndgpu_ovl_map2 call, in order: verdicts (kept[i], may be NULL) and the bytes of the kept ones (*out, malloc'd,
+ * ndgpu_ovl_free); prev[2] is the encoder's delta state, carried from call to call (start: 0, 0).  The file starts with the two
+ * bytes 00 FF (init_ovl_mode, lib/ovl.c:70-75), the caller's to write.  Returns the byte count, < 0 on error. */
+int64_t ndgpu_s2_filter_encode(ndgpu_s2_state *st, const ndgpu_ovl_rec10 *recs, int64_t n, int32_t maxhan1, int32_t maxhan2,
+                               uint32_t prev[2], uint8_t **out, uint8_t *kept);
+/* the `.bl` text written when the run ends (*text malloc'd, ndgpu_ovl_free); the state is spent afterwards */
+int64_t ndgpu_s2_bl(ndgpu_s2_state *st, char **text);
+
 void ndgpu_ovl_get_stats(const ndgpu_ovl_index *idx, ndgpu_ovl_stats *st);
 void ndgpu_ovl_reset_stats(ndgpu_ovl_index *idx);
 

@@ -10,6 +10,7 @@
 // multi-GB .fastq.gz never sits in memory (the Python parser this replaces read the whole file).
 #include <zlib.h>
 
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -59,9 +60,10 @@ struct Stream {
         return 0;
     }
     // the header's name: up to the first white-space character; *delim = that character (0 at the end of the stream)
-    int name(int *delim) {
+    int name(int *delim, std::string *keep) {
         bool got = false;
         *delim = 0;
+        keep->clear();
         for (;;) {
             if (err) return -3;
             if (begin >= end) {
@@ -74,6 +76,7 @@ struct Stream {
             int i = begin;
             while (i < end && !(buf[i] == ' ' || (buf[i] >= '\t' && buf[i] <= '\r'))) i++;
             got = true;
+            keep->append((const char *)buf + begin, (size_t)(i - begin));
             begin = i + 1;
             if (i < end) {
                 *delim = buf[i];
@@ -90,7 +93,7 @@ struct ndgpu_fastx {
     Stream st;
     int last_char = 0;
     bool done = false, have = false;   // have: `seq` holds a record that did not fit the caller's last buffer
-    std::string seq, qual, skip;
+    std::string seq, qual, skip, name;
 
     // kseq_read: 1 = a record is in `seq`, 0 = the stream is over for the caller (end, truncated quality), -3 = read error
     int next() {
@@ -103,7 +106,7 @@ struct ndgpu_fastx {
         seq.clear();
         qual.clear();
         int delim;
-        const int r = st.name(&delim);
+        const int r = st.name(&delim, &name);
         if (r < 0) return r == -3 ? -3 : 0;
         if (delim != '\n') {
             skip.clear();
@@ -139,6 +142,10 @@ ndgpu_fastx *ndgpu_fastx_open(const char *path) {
 }
 
 int64_t ndgpu_fastx_read(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *off, uint32_t *len, int64_t max_recs) {
+    return ndgpu_fastx_read_named(h, buf, cap, off, len, nullptr, max_recs);
+}
+
+int64_t ndgpu_fastx_read_named(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *off, uint32_t *len, uint32_t *ids, int64_t max_recs) {
     int64_t n = 0;
     uint64_t used = 0;
     while (n < max_recs) {
@@ -159,6 +166,7 @@ int64_t ndgpu_fastx_read(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *o
         }
         memcpy(buf + used, h->seq.data(), (size_t)l);
         off[n] = used;
+        if (ids) ids[n] = (uint32_t)strtoul(h->name.c_str(), nullptr, 10);  // minimap2-nd names reads by number (map.c:1298-1300)
         len[n] = (uint32_t)(l > 0xffffffffull ? 0xffffffffull : l);
         used += l;
         n++;

@@ -22,6 +22,9 @@ struct OvlParams {
 	int32_t mode3;     // --mode 3: chain ends trimmed, hits extended into the unaligned read ends before the output filter
 	int32_t ide_ml;    // mm_mapopt_t::ide_ml (6000): cap of the extension's edit budget
 	float d_factor;    // --df (0.1)
+	int32_t step2;     // --step 2 (corrected reads): per-target marking + length / identity / block filters, 10-field records
+	int32_t minmatch;  // --step 2: 100
+	float minide;      // --step 2: 0.05
 };
 
 // minimizer index of the target reads, resident in HBM
@@ -56,6 +59,7 @@ struct KeyLayout {
 };
 
 struct OvlRec { uint32_t rev, qname, qs, qe, tname, ts, te, match; };
+struct OvlRec10 { uint32_t rev, qname, qs, qe, qlen, tname, ts, te, tlen, identity; }; // `overlap_i`, lib/ovl.h (the --step 2 record)
 struct SketchTile { uint32_t read, start; }; // one block of K1: symbols [start, start + tile) of a read
 
 size_t sketch_smem(int w);
@@ -112,7 +116,9 @@ void launch_chain_ends(const uint64_t *r_aoff, uint32_t n_reads, const OvlParams
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
                  const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
                  uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
-                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, hipStream_t s);
+                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, hipStream_t s);
+void launch_compact_recs10(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec10 *recs, const uint32_t *n_rec,
+                           const uint64_t *rec_off, OvlRec10 *dense, hipStream_t s);
 void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,
                          const uint64_t *rec_off, OvlRec *dense, hipStream_t s);
 size_t sort_job_bytes();

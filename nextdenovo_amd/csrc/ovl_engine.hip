@@ -403,7 +403,7 @@ struct Engine {
 	}
 
 	int64_t map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
-	            const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out);
+	            const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10 = nullptr);
 };
 
 static OvlParams to_params(const ndgpu_ovl_opt &o)
@@ -413,6 +413,7 @@ static OvlParams to_params(const ndgpu_ovl_opt &o)
 	P.bw = o.bw, P.max_gap = o.max_gap, P.max_skip = o.max_chain_skip, P.max_iter = o.max_chain_iter, P.minlen = o.minlen, P.dvt = o.dvt;
 	P.maxhan1 = o.maxhan1, P.maxhan2 = o.maxhan2;
 	P.mode3 = o.mode == 3, P.ide_ml = 6000 /* mm_mapopt_t::ide_ml, options.c:60: no command-line switch */, P.d_factor = o.d_factor;
+	P.step2 = o.step == 2, P.minmatch = o.minmatch, P.minide = o.minide;
 	return P;
 }
 
@@ -424,11 +425,12 @@ static const char *check_opt(const ndgpu_ovl_opt &o)
 	if (o.min_cnt < 2) return "min_cnt must be >= 2";
 	if (o.max_chain_iter < 1 || o.max_chain_iter >= 8192) return "max_chain_iter must be in 1..8191";
 	if (o.max_gap < 0 || o.bw < 0) return "negative max_gap / bw";
+	if (o.step == 2 && o.mode != 0) return "--step 2 is built for --mode 0 (no re-alignment) only";
 	return nullptr;
 }
 
 int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
-                    const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out)
+                    const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10)
 {
 	OvlParams Pm = to_params(o);
 	Pm.k = P.k, Pm.w = P.w, Pm.hpc = P.hpc; // the sketch parameters belong to the index
@@ -437,6 +439,8 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	struct Restore { Engine *e; OvlParams p; ~Restore() { e->P = p; } } restore{this, Pi};
 	++st.map_calls;
 	out.clear();
+	if (out10) out10->clear();
+	if ((P.step2 != 0) != (out10 != nullptr)) return -1; // the two record types have an entry point each
 	if (!n_q) return 0;
 
 	ReadSetDev Q;
@@ -587,10 +591,11 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		DevBuf<uint64_t> wx(na), wy(na);
 		DevBuf<uint32_t> tables((size_t)nb * 512), n_rec(nb + 1), n_chain(nb);
 		DevBuf<OvlRec> recs(rec_cap);
+		DevBuf<OvlRec10> recs10(P.step2 ? rec_cap : 0);
 		n_rec.zero(stream);
 		tm.start();
 		launch_hits(r_aoff.p, nb, r0, ax.p, ay.p, ix, qd, P, f.p, p.p, v.p, t.p, u.p, bx.p, by.p, wx.p, wy.p, tables.p, stacks.p, n_end.p,
-		            recs.p, n_rec.p, n_chain.p, stream);
+		            recs.p, n_rec.p, n_chain.p, recs10.p, stream);
 		DevBuf<uint64_t> rec_off(nb + 1);
 		tb = 0;
 		exscan_u32_to_u64(nullptr, tb, n_rec.p, rec_off.p, nb + 1, stream);
@@ -600,6 +605,21 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		std::vector<uint32_t> h_chain(nb);
 		n_chain.download(h_chain.data(), nb, stream);
 		HIP_OK(hipStreamSynchronize(stream));
+		if (P.step2) {
+			DevBuf<OvlRec10> dense10(n_out + 1);
+			launch_compact_recs10(r_aoff.p, nb, P.min_cnt, recs10.p, n_rec.p, rec_off.p, dense10.p, stream);
+			HIP_OK(hipGetLastError());
+			st.hits_ms += tm.stop();
+			const size_t old10 = out10->size();
+			out10->resize(old10 + n_out);
+			if (n_out) HIP_OK(hipMemcpyAsync(out10->data() + old10, dense10.p, n_out * sizeof(OvlRec10), hipMemcpyDeviceToHost, stream));
+			HIP_OK(hipStreamSynchronize(stream));
+			st.chain_cells += h_cells;
+			for (uint32_t c : h_chain) st.chains += c;
+			st.overlaps += n_out;
+			r0 = r1;
+			continue;
+		}
 		DevBuf<OvlRec> dense(n_out + 1);
 		launch_compact_recs(r_aoff.p, nb, P.min_cnt, recs.p, n_rec.p, rec_off.p, dense.p, stream);
 		HIP_OK(hipGetLastError());
@@ -661,7 +681,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		dbg_ax = std::move(ax); dbg_ay = std::move(ay); dbg_f = std::move(f); dbg_p = std::move(p);
 		r0 = r1;
 	}
-	return (int64_t)out.size();
+	return out10 ? (int64_t)out10->size() : (int64_t)out.size();
 }
 
 } // namespace ndovl
@@ -680,6 +700,7 @@ int ndgpu_ovl_opt_preset(const char *preset, ndgpu_ovl_opt *o)
 	o->seed = 11, o->mid_occ_frac = 2e-4f, o->min_cnt = 3, o->min_chain_score = 40, o->bw = 500, o->max_gap = 5000;
 	o->max_chain_skip = 25, o->max_chain_iter = 5000, o->minlen = 500, o->maxhan1 = 5000, o->maxhan2 = 500, o->dvt = 0;
 	o->mode = 2, o->d_factor = 0.1f; // options.c:56,62 (--step 1 looks at the mode only to see whether it is 3)
+	o->step = 1, o->minide = 0.05f, o->minmatch = 100; // --step 2 (main.c:194-197) also sets minlen = 2000: the caller's to do
 	if (!preset) return 0;
 	if (strcmp(preset, "ava-ont") == 0) { // options.c:84-88
 		o->k = 15, o->w = 5, o->hpc = 0, o->no_diag = 1, o->no_dual = 1;
@@ -741,11 +762,33 @@ int32_t ndgpu_ovl_index_mid_occ(ndgpu_ovl_index *h, float frac)
 
 void ndgpu_ovl_index_stat(const ndgpu_ovl_index *h, uint64_t n[3]) { n[0] = h->e.n_min, n[1] = h->e.n_keys, n[2] = h->e.T.n; }
 
+int64_t ndgpu_ovl_map2(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                       uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, ndgpu_ovl_rec10 **recs)
+{
+	*recs = nullptr;
+	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return -1; }
+	if (opt->step != 2) { fprintf(stderr, "[ndgpu_overlap] ndgpu_ovl_map2 is the --step 2 entry (opt->step = 2)\n"); return -1; }
+	try {
+		HIP_OK(hipSetDevice(h->e.device));
+		std::vector<OvlRec> none;
+		std::vector<OvlRec10> out;
+		int64_t n = h->e.map(*opt, mid_occ, n_reads, words, n_words, word_off, lens, ids, none, &out);
+		if (n < 0) return n;
+		static_assert(sizeof(OvlRec10) == sizeof(ndgpu_ovl_rec10), "record layout");
+		*recs = (ndgpu_ovl_rec10*)malloc(sizeof(ndgpu_ovl_rec10) * (size_t)(n ? n : 1));
+		if (n) memcpy(*recs, out.data(), sizeof(ndgpu_ovl_rec10) * (size_t)n);
+		return n;
+	} catch (...) {
+		return -2;
+	}
+}
+
 int64_t ndgpu_ovl_map(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
                       uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, ndgpu_ovl_rec **recs)
 {
 	*recs = nullptr;
 	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return -1; }
+	if (opt->step == 2) { fprintf(stderr, "[ndgpu_overlap] --step 2 records come from ndgpu_ovl_map2\n"); return -1; }
 	try {
 		HIP_OK(hipSetDevice(h->e.device));
 		std::vector<OvlRec> out;

@@ -1270,7 +1270,8 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
                             const int32_t *__restrict__ p, int32_t *__restrict__ v, int32_t *__restrict__ t, uint64_t *__restrict__ u,
                             uint64_t *__restrict__ bx, uint64_t *__restrict__ by, uint64_t *__restrict__ wx, uint64_t *__restrict__ wy,
                             uint32_t *__restrict__ tables, SortJob *__restrict__ stacks, const uint32_t *__restrict__ n_end,
-                            OvlRec *__restrict__ recs, uint32_t *__restrict__ n_rec, uint32_t *__restrict__ n_chain)
+                            OvlRec *__restrict__ recs, uint32_t *__restrict__ n_rec, uint32_t *__restrict__ n_chain,
+                            OvlRec10 *__restrict__ recs10)
 {
 	const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rl >= n_reads) return;
@@ -1345,14 +1346,21 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 		else qs = (int32_t)qlen - ((int32_t)BY[last] + 1), qe = (int32_t)qlen - ((int32_t)BY[first] + 1 - span0);
 		const uint32_t tid = ix.id[rid];
 		if (tid == qid) continue;
-		int32_t mlen = span0;
+		int32_t mlen = span0, blen = span0; // mm_cal_fuzzy_len (minimap2/hit.c): matching bases, block length
 		for (int32_t m = first + 1; m <= last; ++m) {
 			const int sp = (int)(BY[m] >> 32 & 0xff);
 			const int tl = (int32_t)BX[m] - (int32_t)BX[m - 1];
 			const int ql = (int32_t)BY[m] - (int32_t)BY[m - 1];
+			blen += tl > ql ? tl : ql;
 			mlen += tl > sp && ql > sp ? sp : tl < ql ? tl : ql;
 		}
 		OvlRec r;
+		if (P.step2) { // provisional: local target index and block length in the name fields, judged below
+			r.rev = rev, r.qname = rid, r.qs = (uint32_t)qs, r.qe = (uint32_t)qe, r.tname = (uint32_t)blen, r.ts = (uint32_t)rs, r.te = (uint32_t)re,
+			r.match = (uint32_t)mlen;
+			out[n_out++] = r;
+			continue;
+		}
 		if (P.mode3) {
 			// nd_fix_bad_ends + nd_update_coors (minimap2/map.c:313-373): anchors at either end of the chain that sit off its
 			// diagonal by more than half the length walked so far are dropped; the match length keeps the whole chain's value.
@@ -1404,16 +1412,57 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 		r.match = (uint32_t)mlen;
 		out[n_out++] = r;
 	}
+	if (P.step2) {
+		// worker_for with the re-alignment switched off (--mode 0, minimap2/map.c:988-1031): the first hit of a target carries
+		// the verdict of that target -- the match count of a dovetail hit, 3 = the query looks contained -- later hits of the
+		// same target are marked 1 and count only when they are nearly as long; two contained verdicts end the marking.
+		int32_t c = 0;
+		for (uint32_t k2 = 0; k2 < n_out; ++k2) {
+			OvlRec &r = out[k2];
+			const uint32_t rid = r.qname, tl = ix.len[rid], tp = r.match, longer = tl > qlen ? tl : qlen;
+			uint32_t l = k2;
+			for (uint32_t j = 0; j < k2; ++j)
+				if (out[j].qname == rid) { l = j; break; }
+			if (l != k2) r.match = 1;
+			OvlRec &head = out[l];
+			if (l != k2 && (head.match == 2u || (double)(int32_t)r.tname < (double)(int32_t)head.tname * 0.8 || r.tname < longer / 3)) continue;
+			if ((int32_t)(r.qe - r.qs) >= P.minlen && (float)tp >= (float)(int32_t)r.tname * P.minide && tp >= (uint32_t)P.minmatch) {
+				if (dovetail_class((int)r.rev, r.qs, r.qe, qlen, r.ts, r.te, tl, P.maxhan1, 0)) {
+					if (head.match == 3u) c--;
+					head.match = tp;
+				} else if (r.qs <= (uint32_t)P.maxhan2 && r.qe + (uint32_t)P.maxhan2 >= qlen) {
+					head.match = 3u;
+					if (++c >= 2) break; // MAX_CON
+				}
+			}
+		}
+		// the writer's record filter (map.c:1305-1309); the dovetail / contained filter that follows it keeps state over the
+		// whole run and stays on the host (csrc/ovl_step2.cpp)
+		OvlRec10 *out10 = recs10 + (out - recs);
+		uint32_t n10 = 0;
+		for (uint32_t k2 = 0; k2 < n_out; ++k2) {
+			const OvlRec r = out[k2];
+			const uint32_t tl = ix.len[r.qname];
+			const int32_t ml = (int32_t)r.match, bl = (int32_t)r.tname;
+			if (!(((int32_t)(r.qe - r.qs) >= P.minlen || ml == bl) && (ml == 3 || ((float)ml >= (float)bl * P.minide && ml >= P.minmatch)) &&
+			      bl >= (int32_t)qlen / 50 && bl >= (int32_t)tl / 50)) continue;
+			OvlRec10 o;
+			o.rev = r.rev, o.qname = qid, o.qs = r.qs, o.qe = r.qe, o.qlen = qlen, o.tname = ix.id[r.qname], o.ts = r.ts, o.te = r.te, o.tlen = tl;
+			o.identity = (uint32_t)((uint64_t)(uint32_t)ml * 10000ull / (uint64_t)(uint32_t)bl);
+			out10[n10++] = o;
+		}
+		n_out = n10;
+	}
 	n_rec[rl] = n_out, n_chain[rl] = (uint32_t)n_u;
 }
 
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
                  const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
                  uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
-                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, hipStream_t s)
+                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, hipStream_t s)
 {
 	if (n_reads) hipLaunchKernelGGL(hits_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
-	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain);
+	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain, recs10);
 }
 
 // gather per-read record runs into one dense array
@@ -1425,6 +1474,22 @@ __global__ void compact_recs_kernel(const uint64_t *__restrict__ r_aoff, uint32_
 	const OvlRec *src = recs + r_aoff[rl] / (uint64_t)(min_cnt > 1 ? min_cnt : 1) + rl;
 	OvlRec *dst = dense + rec_off[rl];
 	for (uint32_t i = threadIdx.x; i < n_rec[rl]; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ void compact_recs10_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, int min_cnt, const OvlRec10 *__restrict__ recs,
+                                      const uint32_t *__restrict__ n_rec, const uint64_t *__restrict__ rec_off, OvlRec10 *__restrict__ dense)
+{
+	const uint32_t rl = blockIdx.x;
+	if (rl >= n_reads) return;
+	const OvlRec10 *src = recs + r_aoff[rl] / (uint64_t)(min_cnt > 1 ? min_cnt : 1) + rl;
+	OvlRec10 *dst = dense + rec_off[rl];
+	for (uint32_t i = threadIdx.x; i < n_rec[rl]; i += blockDim.x) dst[i] = src[i];
+}
+
+void launch_compact_recs10(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec10 *recs, const uint32_t *n_rec,
+                           const uint64_t *rec_off, OvlRec10 *dense, hipStream_t s)
+{
+	if (n_reads) hipLaunchKernelGGL(compact_recs10_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, min_cnt, recs, n_rec, rec_off, dense);
 }
 
 void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,

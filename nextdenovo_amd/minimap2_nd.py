@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""`minimap2-nd --step 1` on the MI355X: all-vs-all raw-read overlap, `.ovl` out.
+"""`minimap2-nd --step 1` (and `--step 2 --mode 0`) on the MI355X: all-vs-all read overlap, `.ovl` out.
 
 Takes the command line nextDenovo writes for the raw-align subtasks (reference nextDenovo:436-466):
 
@@ -11,7 +11,10 @@ mm_idx_gen does with -I (index.c:284-287,351-360), the occurrence threshold come
 (options.c:70-71), every query file is mapped against every part in turn (main.c:474-507).
 
 `--mode 3` (HiFi: chain ends trimmed, every hit extended into the unaligned read ends, minimap2/map.c:340-482) is built in.
-Options of other paths (-a, -c, --step 2/3, FASTA input) are rejected, not approximated.
+`--step 2 --mode 0` (the `cns_align` command of nextDenovo:356-366 on corrected reads, re-alignment switched off) is built in too:
+FASTA input with numeric names, per-target marking and the record filters on the device, the dovetail / contained filter, the
+10-field encoder and the `.bl` table on the host (csrc/ovl_step2.cpp).  The re-alignment modes 1 / 2 are not.
+Options of other paths (-a, -c, --step 3) are rejected, not approximated.
 """
 from __future__ import annotations
 
@@ -51,7 +54,7 @@ class Args:
         self.ops = []  # (name, value) in command-line order, applied after the preset
 
 
-LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df"}
+LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df", "--minide", "--minmatch"}
 SHORT_WITH_ARG = set("xtfIKkwornmgsNpM")
 
 
@@ -93,9 +96,12 @@ def build_opt(a: Args) -> overlap.Opt:
     for name, val in a.ops:
         if name == "--step":
             a.step = int(val)
-            if a.step != 1:
-                raise SystemExit("[ERROR] only --step 1 is built in this engine")
-            opt.minlen = 500
+            if a.step == 1:
+                opt.minlen = 500
+            elif a.step == 2:  # main.c:194-197
+                opt.step, opt.minide, opt.minlen, opt.maxhan1, opt.maxhan2, opt.minmatch = 2, 0.05, 2000, 5000, 500, 100
+            else:
+                raise SystemExit("[ERROR] only --step 1 and --step 2 are built in this engine")
     for name, val in a.ops:
         if name in ("-x", "-t", "--step"):
             continue
@@ -144,12 +150,20 @@ def build_opt(a: Args) -> overlap.Opt:
             opt.mode = int(val)  # --step 1 only asks whether it is 3 (minimap2/map.c:488,919)
         elif name == "--df":
             opt.d_factor = float(val)
+        elif name == "--minide":
+            opt.minide = float(val)
+        elif name == "--minmatch":
+            opt.minmatch = parse_num(val)
         elif name == "-o":
             a.out = val
         else:
             raise SystemExit("[ERROR] option %s is outside the --step 1 overlap path of this engine" % name)
-    if a.step != 1:
-        raise SystemExit("[ERROR] --step 1 is required")
+    if a.step not in (1, 2):
+        raise SystemExit("[ERROR] --step 1 or --step 2 is required")
+    if a.step == 2 and opt.mode != 0:
+        raise SystemExit("[ERROR] --step 2 is built for --mode 0 (no re-alignment) only: pass --mode 0")
+    if a.step == 2 and not a.out:
+        raise SystemExit("[ERROR] --step 2 needs -o FILE (the .bl table is written next to it, main.c:262-272)")
     return opt
 
 
@@ -172,25 +186,52 @@ def index_parts(lens: np.ndarray, batch_size: int, mini_batch=IDX_MINI_BATCH):
     return parts
 
 
+def load_reads(path: str) -> overlap.ReadSet:
+    """`.2bit` as seq_dump writes it, or FASTA / FASTQ[.gz] whose names are numbers (the corrected-read files `cns.fasta` that
+    --step 2 maps: minimap2-nd takes strtoul of the name, minimap2/map.c:1298-1300), packed on the device."""
+    if path.endswith(".2bit"):
+        return overlap.ReadSet.from_2bit(path)
+    from . import seq_dump
+    bufs, offs, lens, ids, base = [], [], [], [], 0
+    for b, off, ln, nm in seq_dump.iter_chunks(path, names=True):
+        bufs.append(b), offs.append(off + np.uint64(base)), lens.append(ln), ids.append(nm)
+        base += b.size
+    if not bufs:
+        return overlap.ReadSet(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(1, np.uint32), np.zeros(0, np.uint64))
+    buf, off, ln, nm = np.concatenate(bufs), np.concatenate(offs), np.concatenate(lens), np.concatenate(ids)
+    words, word_off = overlap.pack_2bit(buf, off, ln)
+    return overlap.ReadSet(nm, ln, words, word_off)
+
+
 def run(argv) -> int:
     a = parse_argv(argv)
     opt = build_opt(a)
     if len(a.files) < 2:
-        raise SystemExit("[ERROR] missing input: target.2bit query.2bit")
-    target = overlap.ReadSet.from_2bit(a.files[0])
-    queries = [overlap.ReadSet.from_2bit(f) if f != a.files[0] else target for f in a.files[1:]]
+        raise SystemExit("[ERROR] missing input: target query [query ...]")
+    target = load_reads(a.files[0])
+    queries = [load_reads(f) if f != a.files[0] else target for f in a.files[1:]]
     prev = np.zeros(2, dtype=np.uint32)  # `prev_t pid` lives for the whole run (main.c:29)
     mid_occ = opt.mid_occ
     out = open(a.out, "wb") if a.out else sys.stdout.buffer
+    flt = overlap.Step2Filter() if a.step == 2 else None
     try:
+        if flt:
+            out.write(b"\x00\xff")  # init_ovl_mode(stdout, 10), lib/ovl.c:70-75
         for lo, hi in index_parts(target.lens, a.batch_size):
             with overlap.Index(opt, target.subset(lo, hi)) as ix:
                 if mid_occ <= 0:
                     mid_occ = ix.mid_occ()
                 for q in queries:
-                    recs = ix.map(q, mid_occ)
-                    out.write(overlap.encode(recs, prev))
+                    if flt:
+                        out.write(flt.feed(ix.map2(q, mid_occ), opt.maxhan1, opt.maxhan2))
+                    else:
+                        out.write(overlap.encode(ix.map(q, mid_occ), prev))
+        if flt:
+            with open(a.out + ".bl", "w") as f:
+                f.write(flt.bl())
     finally:
+        if flt:
+            flt.close()
         if a.out:
             out.close()
     return 0

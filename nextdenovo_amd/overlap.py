@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(HERE, "libndgpu_overlap.so")
 class Opt(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "no_diag", "no_dual", "min_cnt", "min_chain_score", "bw", "max_gap",
                                          "max_chain_skip", "max_chain_iter", "minlen", "seed", "dvt", "maxhan1", "maxhan2")] \
-        + [("mid_occ_frac", C.c_float), ("mid_occ", C.c_int32), ("mode", C.c_int32), ("d_factor", C.c_float)]
+        + [("mid_occ_frac", C.c_float), ("mid_occ", C.c_int32), ("mode", C.c_int32), ("d_factor", C.c_float), ("step", C.c_int32),
+           ("minide", C.c_float), ("minmatch", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -32,6 +33,7 @@ class Stats(C.Structure):
 
 
 REC = np.dtype([(n, np.uint32) for n in ("rev", "qname", "qs", "qe", "tname", "ts", "te", "match")])
+REC10 = np.dtype([(n, np.uint32) for n in ("rev", "qname", "qs", "qe", "qlen", "tname", "ts", "te", "tlen", "identity")])  # --step 2
 
 _lib = None
 
@@ -71,6 +73,14 @@ def _bind(lib):
     lib.ndgpu_pack_2bit.restype = C.c_int64
     lib.ndgpu_ovl_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.ndgpu_ovl_reset_stats.argtypes = [P]
+    lib.ndgpu_ovl_map2.argtypes = lib.ndgpu_ovl_map.argtypes
+    lib.ndgpu_ovl_map2.restype = C.c_int64
+    lib.ndgpu_s2_new.restype = P
+    lib.ndgpu_s2_free.argtypes = [P]
+    lib.ndgpu_s2_filter_encode.argtypes = [P, P, C.c_int64, C.c_int32, C.c_int32, P, C.POINTER(P), P]
+    lib.ndgpu_s2_filter_encode.restype = C.c_int64
+    lib.ndgpu_s2_bl.argtypes = [P, C.POINTER(P)]
+    lib.ndgpu_s2_bl.restype = C.c_int64
     return lib
 
 
@@ -176,6 +186,17 @@ class Index:
             raise RuntimeError("ndgpu_ovl_map failed (%d)" % n)
         return _take(self.lib, recs, n, REC)
 
+    def map2(self, rs: ReadSet, mid_occ: int, opt: Opt | None = None) -> np.ndarray:
+        """--step 2 (--mode 0): the 10-field records that passed the mapper's own filters, in output order; the dovetail /
+        contained filter and the encoder follow on the host (Step2Filter)."""
+        opt = opt or self.opt
+        recs = C.c_void_p()
+        n = self.lib.ndgpu_ovl_map2(self.h, C.byref(opt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off),
+                                    _ptr(rs.lens), _ptr(rs.ids), C.byref(recs))
+        if n < 0:
+            raise RuntimeError("ndgpu_ovl_map2 failed (%d)" % n)
+        return _take(self.lib, recs, n, REC10)
+
     def debug_anchors(self, q: int):
         ax, ay, f, p = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         n = self.lib.ndgpu_ovl_debug_anchors(self.h, q, C.byref(ax), C.byref(ay), C.byref(f), C.byref(p))
@@ -236,6 +257,47 @@ def pack_2bit(ascii_buf: np.ndarray, ascii_off: np.ndarray, lens: np.ndarray):
     if n < 0:
         raise RuntimeError("ndgpu_pack_2bit failed (%d): no usable HIP device?" % n)
     return words[:n], word_off
+
+
+class Step2Filter:
+    """filter_ovl / encode_ovl_i / out_bl of one `minimap2-nd --step 2` run (lib/ovl.c:449-563, 205-253, 339-362): the state
+    lives from the first record to the `.bl` table."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = self.lib.ndgpu_s2_new()
+        if not self.h:
+            raise MemoryError("ndgpu_s2_new")
+        self.prev = np.zeros(2, dtype=np.uint32)
+
+    def feed(self, recs: np.ndarray, maxhan1: int, maxhan2: int, want_verdicts: bool = False):
+        """Records of one map2 call -> bytes of the kept ones (and their verdicts)."""
+        recs = np.ascontiguousarray(recs, dtype=REC10)
+        out = C.c_void_p()
+        kept = np.zeros(max(1, recs.size), dtype=np.uint8)
+        n = self.lib.ndgpu_s2_filter_encode(self.h, _ptr(recs), recs.size, maxhan1, maxhan2, _ptr(self.prev), C.byref(out), _ptr(kept))
+        if n < 0:
+            raise RuntimeError("ndgpu_s2_filter_encode failed (%d)" % n)
+        b = _take(self.lib, out, n, np.uint8).tobytes()
+        return (b, kept[:recs.size].astype(bool)) if want_verdicts else b
+
+    def bl(self) -> str:
+        text = C.c_void_p()
+        n = self.lib.ndgpu_s2_bl(self.h, C.byref(text))
+        if n < 0:
+            raise RuntimeError("ndgpu_s2_bl failed")
+        return _take(self.lib, text, n, np.uint8).tobytes().decode()
+
+    def close(self):
+        if self.h:
+            self.lib.ndgpu_s2_free(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def encode(recs: np.ndarray, prev: np.ndarray) -> bytes:

@@ -49,15 +49,17 @@ CHUNK_BASES = 1 << 30   # bases handed to one packing launch
 CHUNK_RECS = 1 << 20
 
 
-def iter_chunks(path: str, chunk_bases: int = CHUNK_BASES, chunk_recs: int = CHUNK_RECS):
+def iter_chunks(path: str, chunk_bases: int = CHUNK_BASES, chunk_recs: int = CHUNK_RECS, names: bool = False):
     """kseq_read over one file through the native streaming reader: yields (buffer uint8, offsets uint64, lengths uint32) per
-    chunk -- the sequences copied back to back, line breaks removed."""
+    chunk -- the sequences copied back to back, line breaks removed; with names=True also strtoul(name) of every record."""
     import ctypes as C
     lib = overlap.load()
     lib.ndgpu_fastx_open.argtypes = [C.c_char_p]
     lib.ndgpu_fastx_open.restype = C.c_void_p
     lib.ndgpu_fastx_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64]
     lib.ndgpu_fastx_read.restype = C.c_int64
+    lib.ndgpu_fastx_read_named.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ndgpu_fastx_read_named.restype = C.c_int64
     lib.ndgpu_fastx_pending.argtypes = [C.c_void_p]
     lib.ndgpu_fastx_pending.restype = C.c_uint64
     lib.ndgpu_fastx_close.argtypes = [C.c_void_p]
@@ -68,8 +70,10 @@ def iter_chunks(path: str, chunk_bases: int = CHUNK_BASES, chunk_recs: int = CHU
         buf = np.empty(chunk_bases, dtype=np.uint8)
         off = np.empty(chunk_recs, dtype=np.uint64)
         ln = np.empty(chunk_recs, dtype=np.uint32)
+        ids = np.empty(chunk_recs, dtype=np.uint32) if names else None
         while True:
-            n = lib.ndgpu_fastx_read(h, buf.ctypes.data, buf.size, off.ctypes.data, ln.ctypes.data, chunk_recs)
+            n = lib.ndgpu_fastx_read_named(h, buf.ctypes.data, buf.size, off.ctypes.data, ln.ctypes.data, ids.ctypes.data if names else None,
+                                           chunk_recs)
             if n == -4:  # one read longer than the chunk: make room for it
                 buf = np.empty(int(lib.ndgpu_fastx_pending(h)) + 16, dtype=np.uint8)
                 continue
@@ -78,7 +82,10 @@ def iter_chunks(path: str, chunk_bases: int = CHUNK_BASES, chunk_recs: int = CHU
             if n == 0:
                 return
             used = int(off[n - 1]) + int(ln[n - 1])
-            yield buf[:used].copy(), off[:n].copy(), ln[:n].copy()
+            if names:
+                yield buf[:used].copy(), off[:n].copy(), ln[:n].copy(), ids[:n].copy()
+            else:
+                yield buf[:used].copy(), off[:n].copy(), ln[:n].copy()
     finally:
         lib.ndgpu_fastx_close(h)
 

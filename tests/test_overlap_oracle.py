@@ -150,3 +150,41 @@ def test_oracle_step2_mode0_matches_live_reference(lib, preset, extra):
     got, got_bl = M.step2_mode0(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]])
     assert len(want) > 3000 and got == want
     assert got_bl == want_bl and want_bl.count("\n") > 20
+
+
+def _fasta_set(path):
+    """FASTA[.gz] with numeric names -> (ids, lens, codes, off) as the oracle wants them."""
+    import gzip
+    ids, seqs = [], []
+    with (gzip.open(path, "rt") if path.endswith(".gz") else open(path)) as f:
+        for line in f:
+            if line.startswith(">"):
+                ids.append(int(line[1:].split()[0]))
+                seqs.append([])
+            else:
+                seqs[-1].append(line.strip())
+    code = np.full(256, 0, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i
+    arrs = [code[np.frombuffer("".join(s).encode(), dtype=np.uint8)] for s in seqs]
+    lens = np.asarray([a.size for a in arrs], dtype=np.uint32)
+    off = np.zeros(len(arrs), dtype=np.uint64)
+    off[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+    return (np.asarray(ids, dtype=np.uint32), lens, np.concatenate(arrs).astype(np.uint8), off)
+
+
+@pytest.mark.parametrize("tag", ["ont", "pb"])
+def test_oracle_step2_mode0_matches_golden(lib, tag):
+    """The step-2 oracle on the committed fixtures of the compiled reference (tests/golden/step2): what the GPU tests of the device
+    path compare with on a box that has no reference."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_step2_golden import CASES as S2, OUT
+    argv = dict(S2)[tag]
+    kw = {}
+    for k_, name in (("-k", "k"), ("-w", "w"), ("--minlen", "minlen"), ("--maxhan1", "maxhan1"), ("--maxhan2", "maxhan2")):
+        if k_ in argv:
+            kw[name] = int(argv[argv.index(k_) + 1])
+    a, b = _fasta_set(os.path.join(OUT, "a.fa.gz")), _fasta_set(os.path.join(OUT, "b.fa.gz"))
+    got, got_bl = M.step2_mode0(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, [b, a])
+    assert got == open(os.path.join(OUT, tag + ".ovl"), "rb").read()
+    assert got_bl == open(os.path.join(OUT, tag + ".ovl.bl")).read()

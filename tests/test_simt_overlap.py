@@ -70,6 +70,20 @@ def test_stage_cli_writes_reference_bytes(interpreted, case, tmp_path, monkeypat
     GO.test_stage_cli_writes_reference_bytes(case, tmp_path)
 
 
+def test_step2_mode0_cli_and_abi(interpreted, tmp_path):
+    """`--step 2 --mode 0` (corrected reads): K5's per-target marking and record filters, the host's dovetail / contained filter,
+    10-field encoder and `.bl` table -- the compiled reference's bytes, through the command line (FASTA.gz input, multi-part
+    index, one file against itself) and through the C ABI."""
+    import test_zz_gpu_step2 as S2
+    for i, (tag, argv) in enumerate(S2.CASES):
+        if tag not in ("ont", "hifi.self"):   # (the k = 17 cases chain many anchors: 20-30 s each under the interpreter)
+            continue
+        d = tmp_path / str(i)
+        d.mkdir()
+        S2.run_case(tag, argv, d)
+    S2.test_step2_records_and_verdicts(tmp_path)
+
+
 def test_sketch_and_index_match_oracle(olib, sets):
     GO.test_sketch_matches_oracle(olib, sets, "ava-ont", True)
     GO.test_index_matches_oracle(olib, sets, "ava-pb")
