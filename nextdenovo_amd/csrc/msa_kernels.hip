@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(192) void bt_spec_kernel(const PileDev *__restrict_
                                                        uint32_t *__restrict__ bt_exit, uint32_t *__restrict__ bt_steps) {
     const SegItem it = items[blockIdx.x];
     const PileDev &P = piles[it.pile];
-    if (P.origin_t < 0) return;
+    if (P.err == 2u || P.origin_t < 0) return;  // 2: not scored yet (waits for the int64 kernel's pass): nothing to walk
     const uint32_t c0 = it.seg * seg_len, c1 = it.seg + 1u == P.n_seg ? P.seed_len : c0 + seg_len;
     const uint32_t ot = (uint32_t)P.origin_t;
     if (ot < c0) return;  // the walk starts below this segment
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(64) void bt_stitch_kernel(PileDev *__restrict__ pil
     PileDev &P = piles[i];
     uint32_t *entry = bt_entry + P.seg_off, *off = bt_off + P.seg_off;
     for (uint32_t s_ = 0; s_ < P.n_seg; s_++) entry[s_] = kTagHead;  // segments the walk does not visit emit nothing
-    if (P.origin_t < 0) {
+    if (P.err == 2u || P.origin_t < 0) {
         P.path_len = 0;
         return;
     }

@@ -68,7 +68,7 @@ struct Snap {
 };
 Snap wave_sync(uint64_t v);  // rendezvous of the live lanes of the calling lane's wavefront
 void block_sync();           // rendezvous of the live lanes of the workgroup
-void launch(dim3 grid, dim3 block, size_t dynamic_lds, const std::function<void()> &body);
+void launch(const char *kernel_name, dim3 grid, dim3 block, size_t dynamic_lds, const std::function<void()> &body);
 void *dynamic_lds();         // the workgroup's `extern __shared__` array (build_simt.py rewrites the declaration to a call of this)
 
 template <class T> inline uint64_t bits(T v) {
@@ -254,8 +254,8 @@ hipError_t hipEventSynchronize(hipEvent_t);
 hipError_t hipEventElapsedTime(float *, hipEvent_t, hipEvent_t);
 
 namespace simt {
-template <class F, class... A> inline void launch_v(F f, dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args) {
-    launch(grid, block, shmem, [&]() { f(args...); });
+template <class F, class... A> inline void launch_v(const char *name, F f, dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args) {
+    launch(name, grid, block, shmem, [&]() { f(args...); });
 }
 }  // namespace simt
-#define hipLaunchKernelGGL(kernel, ...) simt::launch_v([](auto... a_) { kernel(a_...); }, __VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, ...) simt::launch_v(#kernel, [](auto... a_) { kernel(a_...); }, __VA_ARGS__)

@@ -2,8 +2,10 @@
 // host-heap stand-ins for the HIP runtime calls the consensus library makes.
 #include <hip/hip_runtime.h>
 
+#include <signal.h>
 #include <sys/mman.h>
 #include <ucontext.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -258,7 +260,33 @@ unsigned worker_count() {
 static thread_local std::vector<uint64_t> g_dyn_lds;
 void *dynamic_lds() { return g_dyn_lds.data(); }
 
-void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()> &body) {
+static thread_local const char *g_kernel_name = nullptr;
+
+// a wild access inside a kernel: say which kernel and which thread before dying (there is no debugger on the box)
+static void on_fault(int sig, siginfo_t *info, void *) {
+    char msg[256];
+    int n;
+    if (g_kernel_name && g_block && g_lane)
+        n = snprintf(msg, sizeof(msg), "simt: signal %d (address %p) in kernel %s, workgroup (%u,%u,%u), thread %u\n", sig, info->si_addr,
+                     g_kernel_name, g_block->ids.bidx.x, g_block->ids.bidx.y, g_block->ids.bidx.z, g_lane->tid);
+    else n = snprintf(msg, sizeof(msg), "simt: signal %d outside a kernel (host code of the library)\n", sig);
+    if (write(2, msg, (size_t)n) < 0) {}
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
+void launch(const char *kernel_name, dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()> &body) {
+    static const bool handlers = [] {
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = on_fault;
+        sa.sa_flags = SA_SIGINFO;
+        sigaction(SIGSEGV, &sa, nullptr);
+        sigaction(SIGBUS, &sa, nullptr);
+        sigaction(SIGFPE, &sa, nullptr);
+        return true;
+    }();
+    (void)handlers;
     const unsigned long long n_blocks = (unsigned long long)grid.x * grid.y * grid.z;
     const unsigned n_threads = block.x * block.y * block.z;
     if (!n_blocks || !n_threads) return;
@@ -266,6 +294,7 @@ void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function
     auto work = [&]() {
         StackPool pool;
         Block B;
+        g_kernel_name = kernel_name;
         g_dyn_lds.assign(dynamic_lds_bytes / 8 + 1, 0);
         B.body = &body;
         B.ids.bdim = block;
@@ -306,6 +335,14 @@ void *alloc_tracked(size_t n) {
     char *raw = (char *)malloc(n + 256);
     if (!raw) return nullptr;
     char *p = (char *)(((uintptr_t)raw + 256) & ~(uintptr_t)255);
+    // device memory comes uninitialised: poison it, so that a kernel that relies on zeroes it never wrote fails here too
+    // (large buffers: the first and last megabyte only -- the tests' working sets are far smaller than the planned capacities)
+    static const bool poison = !getenv("SIMT_NO_POISON");
+    if (poison) {
+        const size_t edge = 1u << 20;
+        if (n <= 2 * edge) memset(p, 0xcd, n);
+        else memset(p, 0xcd, edge), memset(p + n - edge, 0xcd, edge);
+    }
     ((size_t *)p)[-1] = n;
     ((char **)p)[-2] = raw;
     g_allocated += n;
