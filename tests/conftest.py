@@ -27,7 +27,7 @@ def oracle_lib():
     """oracle/libndoracle.so (plain-C restatement; test infrastructure)."""
     import ctypes as C
     so = os.path.join(ROOT, "oracle", "libndoracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("ond_oracle.c", "ond_ext_oracle.c", "msa_oracle.c", "mm_oracle.c", "ovlsort_oracle.c", "step2_oracle.c", "nd_oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("ond_oracle.c", "ond_ext_oracle.c", "msa_oracle.c", "mm_oracle.c", "ovlsort_oracle.c", "step2_oracle.c", "ksw2_oracle.c", "nd_oracle.h")]
     if _stale(so, srcs):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
     return C.CDLL(so)

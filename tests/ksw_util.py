@@ -1,0 +1,117 @@
+"""ctypes views of the ksw2 entry points: the compiled reference (oracle/_ref/libksw2ref.so), the oracle, the product."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libksw2ref.so")
+
+F_SCORE_ONLY, F_RIGHT, F_GENERIC_SC, F_APPROX_MAX, F_APPROX_DROP, F_EXTZ_ONLY, F_REV_CIGAR = 0x01, 0x02, 0x04, 0x08, 0x10, 0x40, 0x80
+
+
+class Extz(C.Structure):  # ksw_extz_t (minimap2/ksw2.h:23-32)
+    _fields_ = [("max_zd", C.c_uint32), ("max_q", C.c_int), ("max_t", C.c_int), ("mqe", C.c_int), ("mqe_t", C.c_int), ("mte", C.c_int),
+                ("mte_q", C.c_int), ("score", C.c_int), ("m_cigar", C.c_int), ("n_cigar", C.c_int), ("reach_end", C.c_int),
+                ("cigar", C.POINTER(C.c_uint32))]
+
+
+class Result(C.Structure):  # nd_ksw_result (oracle/ksw2_oracle.c)
+    _fields_ = [(n, C.c_int32) for n in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "n_cigar", "reach_end")]
+
+
+FIELDS = ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "n_cigar", "reach_end")
+
+
+def matrix(a=1, b=4, sc_ambi=1):
+    """ksw_gen_simple_mat (minimap2/align.c:12-24) for m = 5."""
+    m = np.zeros((5, 5), dtype=np.int8)
+    m[:4, :4] = -abs(b)
+    for i in range(4):
+        m[i, i] = a
+    m[4, :] = -abs(sc_ambi)
+    m[:, 4] = -abs(sc_ambi)
+    return np.ascontiguousarray(m.reshape(-1))
+
+
+def _as_tuple(d, cigar):
+    return tuple(int(d[k]) for k in FIELDS), tuple(int(c) for c in cigar)
+
+
+def call_sse(lib, q, t, mat, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag, free=None):
+    """`ksw_extd2_sse` with the reference's signature (the compiled reference, or the product's export of the same name)."""
+    f = lib.ksw_extd2_sse
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int8, C.c_void_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8, C.c_int,
+                  C.c_int, C.c_int, C.c_int, C.POINTER(Extz)]
+    f.restype = None
+    ez = Extz()
+    q, t = np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8)
+    f(None, q.size, q.ctypes.data, t.size, t.ctypes.data, 5, mat.ctypes.data, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag, C.byref(ez))
+    d = dict(max=ez.max_zd & 0x7fffffff, zdropped=ez.max_zd >> 31, max_q=ez.max_q, max_t=ez.max_t, mqe=ez.mqe, mqe_t=ez.mqe_t, mte=ez.mte,
+             mte_q=ez.mte_q, score=ez.score, n_cigar=ez.n_cigar, reach_end=ez.reach_end)
+    cig = [ez.cigar[i] for i in range(ez.n_cigar)] if ez.n_cigar else []
+    if ez.cigar:
+        (free or C.CDLL(None).free)(ez.cigar)
+    return _as_tuple(d, cig)
+
+
+def call_oracle(lib, q, t, mat, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag):
+    f = lib.nd_oracle_ksw_extd2
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int8, C.c_void_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8, C.c_int, C.c_int,
+                  C.c_int, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int]
+    f.restype = C.c_int
+    r = Result()
+    q, t = np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8)
+    cap = q.size + t.size + 4
+    cig = np.zeros(cap, dtype=np.uint32)
+    f(q.size, q.ctypes.data, t.size, t.ctypes.data, 5, mat.ctypes.data, gapo, gape, gapo2, gape2, w, zdrop, end_bonus, flag, C.byref(r),
+      cig.ctypes.data, cap)
+    d = {k: getattr(r, k) for k in FIELDS}
+    return _as_tuple(d, cig[:r.n_cigar])
+
+
+def problems(seed, n, max_len=400):
+    """Fuzzed extension problems in the shapes mm_align_pair hands over (gap filling between anchors, end extension with z-drop):
+    related sequences with substitutions / short and long indels, N bases, all band / z-drop / flag combinations, lengths around
+    the multiples of 16."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(n):
+        L = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 48, 64, 100, int(rng.integers(1, max_len))]))
+        base = rng.integers(0, 4, L).astype(np.uint8)
+        def mutate(x):
+            y = []
+            i = 0
+            rate = float(rng.choice([0.0, 0.02, 0.1, 0.25], p=[.15, .35, .35, .15]))
+            while i < x.size:
+                r = rng.random()
+                if r < rate / 3:
+                    y.append(int(rng.integers(0, 4)))
+                    i += 1
+                elif r < 2 * rate / 3:
+                    i += int(rng.choice([1, 1, 2, 5, 30]))
+                elif r < rate:
+                    y.extend(rng.integers(0, 4, int(rng.choice([1, 1, 2, 5, 30]))).tolist())
+                else:
+                    y.append(int(x[i]))
+                    i += 1
+            y = np.asarray(y if y else [0], dtype=np.uint8)
+            if rng.random() < 0.15:
+                y[rng.integers(0, y.size, max(1, y.size // 20))] = 4
+            return y
+        q, t = mutate(base), mutate(base)
+        if rng.random() < 0.2:
+            t = np.concatenate([t, rng.integers(0, 4, int(rng.integers(1, 80))).astype(np.uint8)])
+        if rng.random() < 0.1:
+            q = rng.integers(0, 4, int(rng.integers(1, 60))).astype(np.uint8)
+        w = int(rng.choice([-1, 751, 50, 10, 3, 1, 0], p=[.3, .25, .2, .1, .05, .05, .05]))
+        zdrop = int(rng.choice([-1, 400, 100, 10, 0], p=[.35, .3, .2, .1, .05]))
+        flag = 0
+        for f, pr in ((F_SCORE_ONLY, .2), (F_RIGHT, .4), (F_GENERIC_SC, .2), (F_APPROX_MAX, .25), (F_APPROX_DROP, .3), (F_EXTZ_ONLY, .5),
+                      (F_REV_CIGAR, .4)):
+            if rng.random() < pr:
+                flag |= f
+        gaps = [(4, 2, 24, 1), (6, 2, 26, 1), (5, 4, 56, 1), (4, 2, 4, 2), (24, 1, 4, 2), (2, 1, 10, 1)][int(rng.integers(0, 6))]
+        mat = matrix(*[(2, 4, 1), (1, 4, 1), (1, 19, 0), (2, 8, 2)][int(rng.integers(0, 4))])
+        out.append(dict(q=q, t=t, mat=mat, gaps=gaps, w=w, zdrop=zdrop, end_bonus=int(rng.choice([-1, 0, 5, 50])), flag=flag))
+    return out

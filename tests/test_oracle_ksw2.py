@@ -1,0 +1,46 @@
+"""The ksw2 oracle (oracle/ksw2_oracle.c: scalar restatement of minimap2's `ksw_extd2_sse`) against the compiled reference function
+and against the committed vectors the reference produced (tests/golden/ksw2.npz: the problems are regenerated from the seed)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import ksw_util as K  # noqa: E402
+from make_ksw2_golden import COUNT, MAX_LEN, SEED  # noqa: E402
+
+
+def golden():
+    d = np.load(os.path.join(HERE, "golden", "ksw2.npz"))
+    ps = K.problems(SEED, COUNT, MAX_LEN)
+    want = []
+    for i in range(len(ps)):
+        want.append((tuple(int(x) for x in d["res"][i]), tuple(int(x) for x in d["cigar"][d["cigar_off"][i]:d["cigar_off"][i + 1]])))
+    return ps, want
+
+
+def test_oracle_matches_golden_vectors(oracle_lib):
+    ps, want = golden()
+    flags = 0
+    for i, (p, w) in enumerate(zip(ps, want)):
+        got = K.call_oracle(oracle_lib, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
+        assert got == w, i
+        flags |= p["flag"]
+    assert flags == 0xdf                                   # every flag of the kernel occurs
+    assert sum(1 for r, _ in want if r[1]) > 30            # z-dropped problems
+    assert sum(1 for r, c in want if len(c) > 3) > 60      # CIGARs with indels
+    assert sum(1 for r, _ in want if r[10]) > 20           # reach_end
+
+
+@pytest.mark.skipif(not os.path.exists(K.REF), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed,count,max_len", [(3, 2500, 300), (4, 250, 2500)])
+def test_oracle_matches_live_reference(oracle_lib, seed, count, max_len):
+    ref = C.CDLL(K.REF)
+    for i, p in enumerate(K.problems(seed, count, max_len)):
+        a = K.call_sse(ref, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
+        b = K.call_oracle(oracle_lib, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
+        assert a == b, i
