@@ -195,6 +195,40 @@ int64_t ndgpu_s2_filter_encode(ndgpu_s2_state *st, const ndgpu_ovl_rec10 *recs, 
 /* the `.bl` text written when the run ends (*text malloc'd, ndgpu_ovl_free); the state is spent afterwards */
 int64_t ndgpu_s2_bl(ndgpu_s2_state *st, char **text);
 
+/* ---- the base-level extension kernel of minimap2's -c / -a path (off the default correction path: `minimap2-nd --step 1` runs
+ *      without -c) ----
+ * replaces: ksw_extz_t (minimap2/ksw2.h:23-32), same layout */
+typedef struct ndgpu_ksw_extz {
+	uint32_t max:31, zdropped:1;
+	int max_q, max_t;      /* max extension coordinate */
+	int mqe, mqe_t;        /* max score when reaching the end of query */
+	int mte, mte_q;        /* max score when reaching the end of target */
+	int score;             /* max score reaching both ends; may be KSW_NEG_INF (-0x40000000) */
+	int m_cigar, n_cigar;
+	int reach_end;
+	uint32_t *cigar;
+} ndgpu_ksw_extz;
+/* replaces: ksw_extd2_sse (minimap2/ksw2.h:60-61, minimap2/ksw2_extd2_sse.c:26-399; caller mm_align_pair, minimap2/align.c:331):
+ * global / extension alignment with the two-piece affine gap cost min(gapo + k * gape, gapo2 + k * gape2), band w, z-drop, the
+ * KSW_EZ_* flags (score only, right-aligned gaps, generic matrix, approximate maximum / z-drop, extension only, reversed CIGAR).
+ * Sequences are codes < m; mat is m x m.  Every field of *ez and the CIGAR are what the reference computes.  km is ignored;
+ * ez->cigar is malloc'd (as the reference does with km == NULL) and replaces a buffer the caller passed in. */
+void ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat, int8_t gapo,
+                   int8_t gape, int8_t gapo2, int8_t gape2, int w, int zdrop, int end_bonus, int flag, ndgpu_ksw_extz *ez);
+/* additive: a batch of such problems in one launch, one wavefront per problem (the gaps between the anchors of the chains of a
+ * batch of reads, their end extensions).  res[i].cigar is malloc'd (free) when n_cigar > 0.  Returns 0, < 0 on error. */
+typedef struct ndgpu_ksw_job {
+	const uint8_t *query, *target;
+	const int8_t *mat;
+	int32_t qlen, tlen, w, zdrop, end_bonus, flag;
+	int8_t m, gapo, gape, gapo2, gape2;
+} ndgpu_ksw_job;
+typedef struct ndgpu_ksw_result {
+	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, n_cigar, reach_end;
+	uint32_t *cigar;
+} ndgpu_ksw_result;
+int ndgpu_ksw_extd2_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res);
+
 void ndgpu_ovl_get_stats(const ndgpu_ovl_index *idx, ndgpu_ovl_stats *st);
 void ndgpu_ovl_reset_stats(ndgpu_ovl_index *idx);
 

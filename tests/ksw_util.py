@@ -115,3 +115,60 @@ def problems(seed, n, max_len=400):
         mat = matrix(*[(2, 4, 1), (1, 4, 1), (1, 19, 0), (2, 8, 2)][int(rng.integers(0, 4))])
         out.append(dict(q=q, t=t, mat=mat, gaps=gaps, w=w, zdrop=zdrop, end_bonus=int(rng.choice([-1, 0, 5, 50])), flag=flag))
     return out
+
+
+class Job(C.Structure):  # ndgpu_ksw_job (include/ndgpu_overlap.h)
+    _fields_ = [("query", C.c_void_p), ("target", C.c_void_p), ("mat", C.c_void_p)] + \
+        [(n, C.c_int32) for n in ("qlen", "tlen", "w", "zdrop", "end_bonus", "flag")] + \
+        [(n, C.c_int8) for n in ("m", "gapo", "gape", "gapo2", "gape2")]
+
+
+class BatchResult(C.Structure):  # ndgpu_ksw_result
+    _fields_ = [(n, C.c_int32) for n in FIELDS] + [("cigar", C.POINTER(C.c_uint32))]
+
+
+def call_batch(lib, ps):
+    """ndgpu_ksw_extd2_batch over a list of problems -> list of (fields, cigar)."""
+    n = len(ps)
+    jobs = (Job * n)()
+    keep = []
+    for j, p in zip(jobs, ps):
+        q, t = np.ascontiguousarray(p["q"], dtype=np.uint8), np.ascontiguousarray(p["t"], dtype=np.uint8)
+        keep.append((q, t, p["mat"]))
+        j.query, j.target, j.mat = q.ctypes.data, t.ctypes.data, p["mat"].ctypes.data
+        j.qlen, j.tlen, j.w, j.zdrop, j.end_bonus, j.flag = q.size, t.size, p["w"], p["zdrop"], p["end_bonus"], p["flag"]
+        j.m, (j.gapo, j.gape, j.gapo2, j.gape2) = 5, p["gaps"]
+    res = (BatchResult * n)()
+    lib.ndgpu_ksw_extd2_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.ndgpu_ksw_extd2_batch.restype = C.c_int
+    rc = lib.ndgpu_ksw_extd2_batch(jobs, n, res)
+    if rc != 0:
+        raise RuntimeError("ndgpu_ksw_extd2_batch failed (%d)" % rc)
+    out, free = [], C.CDLL(None).free
+    for r in res:
+        cig = [r.cigar[i] for i in range(r.n_cigar)] if r.n_cigar else []
+        if r.cigar:
+            free(r.cigar)
+        out.append(_as_tuple({k: getattr(r, k) for k in FIELDS}, cig))
+    return out
+
+
+def long_problems():
+    """Targets beyond the LDS budget of the device kernel (4096): banded, as mm_align_pair calls it (bw 751 / zdrop 400 for
+    ava-ont), one unbanded."""
+    rng = np.random.default_rng(77)
+    out = []
+    for tl, w, zdrop, flag in ((5000, 751, 400, F_EXTZ_ONLY), (9000, 200, -1, 0), (4500, -1, 100, F_RIGHT | F_REV_CIGAR), (4100, 50, 400, F_APPROX_MAX)):
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = t.copy()
+        for k in range(tl // 60):                      # sprinkle substitutions and short indels
+            i = int(rng.integers(0, q.size - 3))
+            r = rng.random()
+            if r < .5:
+                q[i] = (q[i] + 1) % 4
+            elif r < .75:
+                q = np.delete(q, slice(i, i + int(rng.integers(1, 4))))
+            else:
+                q = np.insert(q, i, rng.integers(0, 4, int(rng.integers(1, 4))))
+        out.append(dict(q=q.astype(np.uint8), t=t, mat=matrix(2, 4, 1), gaps=(4, 2, 24, 1), w=w, zdrop=zdrop, end_bonus=5, flag=flag))
+    return out

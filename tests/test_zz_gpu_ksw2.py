@@ -1,0 +1,56 @@
+"""The two-piece affine-gap extension kernel on the MI355X (csrc/ksw2_kernels.hip: `ksw_extd2_sse` with the reference's signature,
+`ndgpu_ksw_extd2_batch`) against the vectors the compiled reference function produced (tests/golden/ksw2.npz) and against the
+oracle on targets longer than the kernel's LDS budget.  (Named to run after the other GPU tests.)"""
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ksw_util as K  # noqa: E402
+from test_oracle_ksw2 import golden  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ovl_lib():
+    from nextdenovo_amd import overlap
+    return overlap.load()
+
+
+def check_golden_single_calls(lib, stride=1):
+    ps, want = golden()
+    for i in range(0, len(ps), stride):
+        p = ps[i]
+        got = K.call_sse(lib, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
+        assert got == want[i], i
+
+
+def check_golden_batch(lib):
+    ps, want = golden()
+    got = K.call_batch(lib, ps)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, i
+
+
+def check_long(lib, oracle_lib):
+    ps = K.long_problems()
+    got = K.call_batch(lib, ps)
+    for i, p in enumerate(ps):
+        want = K.call_oracle(oracle_lib, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
+        assert got[i] == want, i
+        assert want[0][0] > 1000 or want[0][1] or want[0][8] > 1000   # a real alignment (max or end-to-end score), or a z-drop
+
+
+def test_ksw_extd2_sse_matches_reference_vectors(ovl_lib):
+    check_golden_single_calls(ovl_lib)
+
+
+def test_ksw_batch_matches_reference_vectors(ovl_lib):
+    check_golden_batch(ovl_lib)
+
+
+def test_ksw_long_targets_match_oracle(ovl_lib, oracle_lib):
+    check_long(ovl_lib, oracle_lib)
