@@ -24,7 +24,6 @@
 #include <vector>
 
 #include "../../include/ndgpu_overlap.h"
-#include "nd_lockstep.h"
 
 namespace {
 
@@ -218,7 +217,8 @@ __global__ void __launch_bounds__(64) ksw_extd2_kernel(const KswJobDev *__restri
                 xt1 = t > st ? x[t - 1] : x1, vt1 = t > st ? v[t - 1] : v1, x2t1 = t > st ? x2[t - 1] : x21;
                 ut = u[t], yt = y[t], y2t = y2[t];
             }
-            ND_LOCKSTEP();  // every lane has read its neighbour's cell before that neighbour overwrites it
+            __builtin_amdgcn_wave_barrier();  // every lane has read its neighbour's cell before that neighbour overwrites it (the
+                                              // wavefront runs in lock step; this only keeps the compiler from moving a store up)
             if (act) {
                 int8_t a = (int8_t)(xt1 + vt1), b = (int8_t)(yt + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2t + ut);
                 uint8_t d;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(64) ksw_extd2_kernel(const KswJobDev *__restri
                 // maxima is the one the reference's four-at-a-time search finds: en0, then position classes (t - st0) mod 4 in
                 // order, each from the left, then the remainder from the left
                 const int32_t h_top = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + v[en0];
-                ND_LOCKSTEP();
+                __builtin_amdgcn_wave_barrier();
                 const int en1 = st0 + (en0 - st0) / 4 * 4, n_grp = (en1 - st0) / 4;
                 long long best = ((long long)h_top << 32) | (unsigned int)0x7fffffff;
                 for (int t = st0 + lane; t < en0; t += 64) {
