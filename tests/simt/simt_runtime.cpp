@@ -85,6 +85,7 @@ struct Block {
 thread_local Lane *g_lane = nullptr;
 static thread_local Block *g_block = nullptr;
 static std::atomic<int> g_schedule{getenv("SIMT_SCHEDULE") ? atoi(getenv("SIMT_SCHEDULE")) : 0};
+static std::atomic<int> g_lanes_descending{getenv("SIMT_LANES_DESCENDING") ? atoi(getenv("SIMT_LANES_DESCENDING")) : 0};
 
 const BlockIds &block_ids() { return g_block->ids; }
 
@@ -190,7 +191,10 @@ void run_block(Block &B, StackPool &pool, unsigned n_threads) {
         for (;;) {
             bool ran = false;
             const unsigned t1 = std::min(n_threads, w * 64 + 64);
-            for (unsigned t = w * 64; t < t1; t++) {
+            for (unsigned k = w * 64; k < t1; k++) {
+                // (the lanes of a wavefront between two rendezvous points run one after the other: lowest first, or highest first
+                // -- code that relies on lock step without saying so passes under at most one of the two orders)
+                const unsigned t = g_lanes_descending.load() ? t1 - 1 - (k - w * 64) : k;
                 Fibre &f = B.fibres[t];
                 if (f.state != RUNNABLE) continue;
                 g_lane = &f.lane;
@@ -462,6 +466,7 @@ void selftest_kernel(int *bad) {
 }  // namespace
 
 extern "C" void simt_set_schedule(int policy) { simt::g_schedule.store(policy); }
+extern "C" void simt_set_lane_order(int descending) { simt::g_lanes_descending.store(descending); }
 
 extern "C" int simt_selftest() {
     int *bad = nullptr;

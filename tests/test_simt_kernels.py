@@ -84,6 +84,7 @@ def test_golden_piles_nextcorrect(simt_lib, schedule):
     GPU-minutes, in the stitch kernel's segment loop) passes under 0 and 2 and fails under 1 and the random ones."""
     fn, fr = util.bind_correct(simt_lib)
     simt_lib.simt_set_schedule(schedule)
+    simt_lib.simt_set_lane_order(1 if schedule in (2, 7) else 0)   # lanes of a wavefront highest first: see simt_runtime.cpp
     for i, p in enumerate(util.load_piles()):
         if schedule and i % 3 != schedule % 3:
             continue
@@ -93,6 +94,7 @@ def test_golden_piles_nextcorrect(simt_lib, schedule):
             assert seq == p["exp_seq"], i
             assert np.float32(ide) == np.float32(p["exp_ide"]), i
     simt_lib.simt_set_schedule(0)
+    simt_lib.simt_set_lane_order(0)
 
 
 _CHILD = r"""

@@ -93,9 +93,18 @@ def test_anchors_and_chain_arrays_match_oracle(olib, sets, monkeypatch):
     GO.test_anchors_and_chain_arrays_match_oracle(olib, sets, "ava-ont", True, ("seed", "part"), monkeypatch)
 
 
-def test_overlap_then_sort_matches_reference_sorted_ovl(interpreted):
-    """ovl_sort's device path (radix sorts, one wavefront per seed for the admission chain, the `.bl` table)."""
-    GS.test_device_overlap_then_sort_matches_reference_sorted_ovl()
+@pytest.mark.parametrize("descending", [0, 1])
+def test_overlap_then_sort_matches_reference_sorted_ovl(interpreted, descending):
+    """ovl_sort's device path (radix sorts, one wavefront per seed for the admission chain, the `.bl` table); once with the lanes
+    of a wavefront run lowest first, once highest first (code that leans on lock step without an ND_LOCKSTEP() mark passes under at
+    most one of the two)."""
+    for lib in interpreted:
+        lib.simt_set_lane_order(descending)
+    try:
+        GS.test_device_overlap_then_sort_matches_reference_sorted_ovl()
+    finally:
+        for lib in interpreted:
+            lib.simt_set_lane_order(0)
 
 
 def test_whole_stage_from_2bit_to_cns_fasta(interpreted, tmp_path):
