@@ -342,7 +342,34 @@ template <class T> struct Dev {
 
 }  // namespace
 
+static int run_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res);
+
+// device bytes one problem needs beyond its sequences: the backtrack matrix dominates ((qlen + tlen) x (band + 16) bytes)
+static uint64_t scratch_of(const ndgpu_ksw_job &J) {
+    const uint64_t tl16 = ((uint64_t)(J.tlen > 0 ? J.tlen : 0) + 15) / 16 * 16, diags = (uint64_t)(J.qlen > 0 ? J.qlen : 0) + (uint64_t)(J.tlen > 0 ? J.tlen : 0);
+    const int w = J.w < 0 ? (J.tlen > J.qlen ? J.tlen : J.qlen) : J.w;
+    uint64_t n_col = (uint64_t)(J.qlen < J.tlen ? J.qlen : J.tlen);
+    n_col = (((n_col < (uint64_t)w + 1 ? n_col : (uint64_t)w + 1) + 15) / 16 + 1) * 16;
+    return ((J.flag & F_SCORE_ONLY) ? 0 : diags * (n_col + 8)) + 11 * tl16 + 5 * diags;
+}
+
 extern "C" int ndgpu_ksw_extd2_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res) {
+    // sub-batches bounded by device scratch (NDGPU_KSW_SCRATCH_GB, default 8): a caller may hand over every gap of a read set
+    uint64_t budget = 8ull << 30;
+    if (const char *e = getenv("NDGPU_KSW_SCRATCH_GB")) budget = (uint64_t)(atof(e) * (double)(1ull << 30));
+    int a = 0;
+    while (a < n) {
+        int b = a;
+        uint64_t used = 0;
+        while (b < n && (b == a || used + scratch_of(jobs[b]) <= budget)) used += scratch_of(jobs[b++]);
+        const int rc = run_batch(jobs + a, b - a, res + a);
+        if (rc != 0) return rc;
+        a = b;
+    }
+    return 0;
+}
+
+static int run_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res) {
     if (n <= 0) return 0;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {

@@ -52,5 +52,7 @@ def test_ksw_batch_matches_reference_vectors(ovl_lib):
     check_golden_batch(ovl_lib)
 
 
-def test_ksw_long_targets_match_oracle(ovl_lib, oracle_lib):
+def test_ksw_long_targets_match_oracle(ovl_lib, oracle_lib, monkeypatch):
     check_long(ovl_lib, oracle_lib)
+    monkeypatch.setenv("NDGPU_KSW_SCRATCH_GB", "0.001")   # sub-batches of one or two problems
+    check_golden_batch(ovl_lib)
