@@ -439,6 +439,10 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                 g_prof.m_post * 1e-9);
         fprintf(stderr, "[ndgpu prof] advance, CPU seconds by phase: after main %.3f  after extract %.3f  after LQ round 1 %.3f  after round 2 + splice %.3f\n",
                 g_prof.adv_ns[0] * 1e-9, g_prof.adv_ns[1] * 1e-9, g_prof.adv_ns[2] * 1e-9, g_prof.adv_ns[3] * 1e-9);
+        fprintf(stderr, "[ndgpu prof] LQ-stage alignment batches (%llu jobs): host packing %.3f s, device round trip %.3f s, host decoding %.3f s "
+                        "(wall sums over contexts)\n", (unsigned long long)g_prof.c_jobs.load(), g_prof.c_pack * 1e-9, g_prof.c_dev * 1e-9,
+                g_prof.c_decode * 1e-9);
+        g_prof.c_pack = g_prof.c_dev = g_prof.c_decode = g_prof.c_jobs = 0;
         for (auto &a : g_prof.adv_ns) a = 0;
         g_prof.main_ns = g_prof.extract_ns = g_prof.align_ns = g_prof.advance_ns = g_prof.jobs = 0;
         g_prof.m_prep = g_prof.m_aln = g_prof.m_tags = g_prof.m_msa = g_prof.m_post = 0;

@@ -480,6 +480,12 @@ void *DeviceAligner::stream() const { return s_->stream; }
 RuntimeStats DeviceAligner::stats() const { return s_->stats; }
 void DeviceAligner::reset_stats() { s_->stats = RuntimeStats(); }
 
+static inline uint64_t wall_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
 static void limits_for(int total, int hq, int *max_d, int *band) {
     // lib/align.c:567-568,575-576 -- double arithmetic on the host, exactly as the reference
     if (hq) {
@@ -563,6 +569,7 @@ void DeviceAligner::set_host_threads(int n) { s_->host_threads = n < 1 ? 1 : n; 
 
 void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     State &S = *s_;
+    const uint64_t tc0 = wall_ns();
     std::vector<uint32_t> &pool = S.pool;
     std::vector<AlnTask> &tasks = S.tasks;
     tasks.assign(n, AlnTask());
@@ -629,6 +636,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.h_outs.reserve(n);
 
     hipStream_t st = S.stream;
+    const uint64_t tc1 = wall_ns();
     S.h2d(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), st);
     S.h2d(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), st);
     HIP_CHECK(hipEventRecord(S.ev0, st));
@@ -653,6 +661,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     for (size_t i = 0; i < n; i++)
         if (S.h_outs.p[i].status == ST_NEED_WIDE) wide.push_back((int32_t)i);
     if (!wide.empty()) run_wide(jobs, n, wide);
+    const uint64_t tc2 = wall_ns();
 
     for (size_t i = 0; i < n; i++) {
         const AlnOut &o = S.h_outs.p[i];
@@ -704,6 +713,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
             }
         }
     });
+    g_prof.c_pack += tc1 - tc0, g_prof.c_dev += tc2 - tc1, g_prof.c_decode += wall_ns() - tc2, g_prof.c_jobs += n;
 }
 
 void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t> &ids) {
@@ -768,11 +778,6 @@ void DeviceAligner::end_batch() { s_->batch_mu.unlock(); }
 // Main phase of a batch of piles, entirely on the device:
 //   K7 forward -> K8a traceback -> K8s shift scan -> accept -> K8b tags -> column scan
 //   -> [one host sync: exact cell / link totals] -> K9 link counting -> K10 scoring + walk.
-static inline uint64_t wall_ns() {
-    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
-               std::chrono::steady_clock::now().time_since_epoch())
-        .count();
-}
 
 void DeviceAligner::run_main(MainPile **mp, size_t np) {
     State &S = *s_;

@@ -151,6 +151,7 @@ struct HostProf {
     std::atomic<uint64_t> main_ns{0}, extract_ns{0}, align_ns{0}, advance_ns{0}, build_ns{0}, jobs{0};
     std::atomic<uint64_t> m_prep{0}, m_aln{0}, m_tags{0}, m_msa{0}, m_post{0};  // inside run_main
     std::atomic<uint64_t> adv_ns[4] = {{0}, {0}, {0}, {0}};  // CPU time inside PileEngine::advance by phase (summed over threads)
+    std::atomic<uint64_t> c_pack{0}, c_dev{0}, c_decode{0}, c_jobs{0};  // LQ-stage alignment batches: host packing / device round trip / host decoding
 };
 extern HostProf g_prof;
 
