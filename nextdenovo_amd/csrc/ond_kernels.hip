@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "nd_device.h"
@@ -290,6 +292,135 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     outs[gid].status = aborted ? ST_GAP_ABORT : ST_ALIGNED;
 }
 
+
+// K8a, wavefront-per-alignment form (NDGPU_K8A=wave; the default is the lane-per-alignment kernel above until the two have been
+// compared inside the full pipeline on the device).  The walk is one dependent chain per alignment; in the kernel above each link
+// of it is a round trip to HBM / L2 and a wavefront lasts as long as the longest of its 64 chains.  Here a wavefront owns ONE
+// alignment: it stages the next 128 trace rows (move bits + min_k) and the next 1024 bases of both sequences in LDS with
+// coalesced loads, and walks them there -- every lane holds the same walk state, so the loop is uniform and a link costs an LDS
+// broadcast read instead of a memory round trip; lane 0 writes the packed columns.  Same output, bit for bit.
+constexpr int kTbRows = 128;
+constexpr int kTbSeqWords = 64;  // 16 bases each; + 2 words of slack for the unaligned 64-bit fetch
+
+__device__ __forceinline__ uint32_t fetch16_win(const uint32_t *win, uint64_t w0, uint64_t off) {  // off: absolute base offset
+    const uint32_t i = (uint32_t)((off >> 4) - w0), sh = (uint32_t)(off & 15u) * 2u;
+    const uint64_t v = (uint64_t)win[i] | ((uint64_t)win[i + 1] << 32);
+    return (uint32_t)(v >> sh);
+}
+
+__global__ __launch_bounds__(64) void ond_traceback_wave_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
+                                                                 const uint32_t *__restrict__ pool,
+                                                                 const uint32_t *__restrict__ db_pool,
+                                                                 const uint64_t *__restrict__ trace,
+                                                                 const int32_t *__restrict__ trace_mink,
+                                                                 uint32_t *__restrict__ ops, int n_tasks) {
+    __shared__ uint64_t s_tr[kTbRows * kFastRowWords];
+    __shared__ int32_t s_mk[kTbRows];
+    __shared__ uint32_t s_q[kTbSeqWords + 2], s_t[kTbSeqWords + 2];
+    const int gid = (int)blockIdx.x;
+    if (gid >= n_tasks) return;
+    if (outs[gid].status != ST_FINISHED) return;
+    const int lane = (int)threadIdx.x;
+    const AlnTask T = tasks[gid];
+    const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
+    const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
+    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
+    int x = outs[gid].x_final - 1, k = outs[gid].k_final, d = outs[gid].d_final;
+    int gap = 0;
+    uint32_t col = T.ops_cap, acc = 0;
+    uint32_t *W = ops + T.ops_off;
+    bool aborted = false;
+    int d_lo = 0, d_hi = -1;            // trace rows staged: [d_lo, d_hi]
+    uint64_t qw0 = 0, tw0 = 0;          // first staged word of either sequence
+    bool q_ok = false, t_ok = false;
+
+    for (;;) {
+        for (;;) {  // match run, back to front (lib/align.c:502-507), 16 bases per compare
+            const int yy = x - k;
+            const int avail = (x < yy ? x : yy) + 1;
+            if (avail <= 0) break;
+            const int n = avail < 16 ? avail : 16;
+            const uint64_t qa = q_off + (uint64_t)(uint32_t)(x - n + 1), ta = t_off + (uint64_t)(uint32_t)(yy - n + 1);
+            if (!q_ok || (qa >> 4) < qw0) {  // the window ends two words above the current position and reaches 1024 bases down
+                __syncthreads();
+                const uint64_t we = ((q_off + (uint64_t)(uint32_t)x) >> 4) + 2;
+                qw0 = we > (uint64_t)(kTbSeqWords + 2) ? we - (uint64_t)(kTbSeqWords + 2) : 0;
+                for (int i = lane; i < kTbSeqWords + 2; i += 64) s_q[i] = qp[qw0 + (uint64_t)i];
+                q_ok = true;
+                __syncthreads();
+            }
+            if (!t_ok || (ta >> 4) < tw0) {
+                __syncthreads();
+                const uint64_t we = ((t_off + (uint64_t)(uint32_t)yy) >> 4) + 2;
+                tw0 = we > (uint64_t)(kTbSeqWords + 2) ? we - (uint64_t)(kTbSeqWords + 2) : 0;
+                for (int i = lane; i < kTbSeqWords + 2; i += 64) s_t[i] = tp[tw0 + (uint64_t)i];
+                t_ok = true;
+                __syncthreads();
+            }
+            const uint32_t a = fetch16_win(s_q, qw0, qa), b = fetch16_win(s_t, tw0, ta);
+            uint32_t diff = a ^ b;
+            if (n < 16) diff &= (1u << (2 * n)) - 1u;
+            const int m = diff ? n - 1 - ((31 - __builtin_clz(diff)) >> 1) : n;
+            if (m) {
+                int left_to_emit = m;  // match columns are code 0: only the cursor moves
+                while (left_to_emit > 0) {
+                    const uint32_t room = ((col - 1u) & 15u) + 1u;
+                    const uint32_t take = (uint32_t)left_to_emit < room ? (uint32_t)left_to_emit : room;
+                    col -= take;
+                    left_to_emit -= (int)take;
+                    if ((col & 15u) == 0) {
+                        if (lane == 0) W[col >> 4] = acc;
+                        acc = 0;
+                    }
+                }
+                x -= m;
+                gap = 0;
+            }
+            if (m < n) break;
+        }
+        if (x < 0 && x - k < 0) break;
+        bool left;
+        if (x < k) left = true;  // lib/align.c:512: forced query-consuming move
+        else if (x >= 0) {
+            if (d < d_lo || d > d_hi) {
+                __syncthreads();
+                d_hi = d, d_lo = d - kTbRows + 1 > 0 ? d - kTbRows + 1 : 0;
+                const int nr = d_hi - d_lo + 1;
+                for (int i = lane; i < nr * kFastRowWords; i += 64)
+                    s_tr[i] = trace[T.trace_off + (uint64_t)(uint32_t)d_lo * kFastRowWords + (uint64_t)i];
+                for (int i = lane; i < nr; i += 64) s_mk[i] = trace_mink[T.mink_off + (uint64_t)(uint32_t)(d_lo + i)];
+                __syncthreads();
+            }
+            const int idx = (k - s_mk[d - d_lo]) >> 1;
+            left = (s_tr[(d - d_lo) * kFastRowWords + (idx >> 6)] >> (idx & 63)) & 1ull;
+        } else left = false;
+        uint32_t code;
+        int nk, nx;
+        if (left) { nk = k - 1; nx = x - 1; code = 1u; if (x < 0) gap = 260; }
+        else { nk = k + 1; nx = x; code = 2u; if (x - k < 0) gap = 260; }
+        if (gap < 260) {
+            col--;
+            acc |= code << ((col & 15u) * 2u);
+            if ((col & 15u) == 0) {
+                if (lane == 0) W[col >> 4] = acc;
+                acc = 0;
+            }
+        }
+        if (gap++ > 250) {  // lib/align.c:542-545
+            aborted = true;
+            break;
+        }
+        d--;
+        k = nk;
+        x = nx;
+    }
+    if (lane == 0) {
+        if ((col & 15u) != 0) W[col >> 4] = acc;
+        outs[gid].n_cols = aborted ? 2 : (int32_t)(T.ops_cap - col);
+        outs[gid].status = aborted ? ST_GAP_ABORT : ST_ALIGNED;
+    }
+}
+
 }  // namespace
 
 void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
@@ -312,6 +443,12 @@ void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *po
                           const uint64_t *trace,
                           const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream) {
     if (n_tasks <= 0) return;
+    static const bool wave_form = getenv("NDGPU_K8A") && !strcmp(getenv("NDGPU_K8A"), "wave");
+    if (wave_form && !task_ids) {  // (the rare wide-band tasks, addressed through task_ids, have wider trace rows: lane kernel)
+        hipLaunchKernelGGL(ond_traceback_wave_kernel, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs, pool,
+                           db_pool, trace, trace_mink, ops, n_tasks);
+        return;
+    }
     hipLaunchKernelGGL(ond_traceback_kernel, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                        tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
 }

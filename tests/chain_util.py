@@ -66,4 +66,5 @@ if __name__ == "__main__":
     max_piles = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rs, sub, off, seeds, res, st = run(gs, depth, max_piles=max_piles)
     print(json.dumps({"seeds": [int(s) for s in seeds], "digests": [digest(r) for r in res],
-                      "stats": {k: st[k] for k in ("piles", "score_segments", "score_repairs", "score_slow_piles", "cells_msa", "links")}}))
+                      "stats": {k: st[k] for k in ("piles", "score_segments", "score_repairs", "score_slow_piles", "cells_msa", "links", "forward_ms",
+                                                    "traceback_ms")}}))
