@@ -293,6 +293,185 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
 }
 
 
+// K7, two alignments per wavefront (NDGPU_K7=pair; the default is the kernel above until the two have been compared inside the
+// full pipeline on the device).  The live band of a raw-read alignment is mostly narrower than 64 diagonals, so half of a
+// wavefront's lanes idle in the kernel above and every alignment pays for a whole wavefront's issue slots.  Here lanes 0-31 own
+// task 2b and lanes 32-63 task 2b + 1 of workgroup b: a pass covers 32 diagonals, each half has its own furthest-reaching ring
+// in LDS, reads its own 32 bits of the wave ballots and reduces its own maximum; the loops run while either half is busy.  The
+// trace layout is the one the traceback kernels read (bit c of a row = diagonal min_k + 2c), so nothing downstream changes.
+__device__ __forceinline__ int half_max_i32(int v) {  // maximum over the 32 lanes of the caller's half, in every lane of it
+    auto step = [](int x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(INT_MIN, x, decltype(ctrl)::value, 0xf, 0xf, false);
+        return y > x ? y : x;
+    };
+    v = step(v, std::integral_constant<int, 0xb1>{});   // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4e>{});   // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane holds its row's maximum
+    const int o = __shfl_xor(v, 16, 64);                // the other row of the half
+    return o > v ? o : v;
+}
+
+__global__ __launch_bounds__(64) void ond_forward_pair_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
+                                                               const uint32_t *__restrict__ pool,
+                                                               const uint32_t *__restrict__ db_pool,
+                                                               uint64_t *__restrict__ trace, int32_t *__restrict__ trace_mink,
+                                                               int n_tasks) {
+    __shared__ int32_t v_lds[2][kFastVSize];
+    const int lane = (int)threadIdx.x, h = lane >> 5, l = lane & 31;
+    const int tid = 2 * (int)blockIdx.x + h;
+    const bool have = tid < n_tasks;
+    const AlnTask T = tasks[have ? tid : 2 * (int)blockIdx.x];
+    int32_t *V = v_lds[h];
+    const uint32_t vmask = (uint32_t)(kFastVSize - 1);
+    for (uint32_t i = (uint32_t)l; i <= vmask; i += 32) V[i] = 0;
+    __syncthreads();
+
+    int min_k = 0, max_k = 0, best_m = -1;
+    int status = ST_NONE, fin_k = 0, fin_x = 0, fin_d = -1;
+    int d_steps = 0, max_band = 0, d = 0;
+    long long cells = 0;
+    bool alive = have;
+    const int q_len = T.q_len, t_len = T.t_len;
+    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
+    const uint32_t *__restrict__ qp = ((T.q_off >> 63) ? db_pool : pool) + (q_off >> 4);
+    const uint32_t *__restrict__ tp = ((T.t_off >> 63) ? db_pool : pool) + (t_off >> 4);
+    const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
+    const uint64_t row0 = T.trace_off, mk0 = T.mink_off;
+    const int hs = 32 * h;  // first lane of this half
+
+    for (;;) {
+        // one edit step of either half that still has one to do (the conditions of the loop head above, lib/align.c:437)
+        bool go = alive && d < T.max_d && max_k - min_k <= T.band;
+        const int band = max_k - min_k;
+        if (go && band > kFastMaxBand) {
+            status = ST_NEED_WIDE;
+            go = false;
+        }
+        if (!go) alive = false;
+        if (__ballot(go) == 0ull) break;
+        const int ncell = band >= 0 ? (band >> 1) + 1 : 0;
+        const int npass = go ? (ncell + 31) >> 5 : 0;
+        const int np0 = __shfl(npass, 0, 64), np1 = __shfl(npass, 32, 64);
+        const int np_max = np0 > np1 ? np0 : np1;
+        if (go) {
+            d_steps++;
+            cells += ncell;
+            max_band = band > max_band ? band : max_band;
+            if (l == 0) trace_mink[mk0 + d] = min_k;
+        }
+        int row_best = -1, x_keep = 0;
+        bool done = false;
+        uint64_t row_acc = 0;
+        for (int ps = 0; ps < np_max; ps++) {
+            const bool pact = go && !done && ps < npass;
+            const int k = min_k + 2 * (ps * 32 + l);
+            const bool act = pact && k <= max_k;
+            int x = 0;
+            bool left = false;
+            if (act) {
+                const int vm = V[(uint32_t)(k - 1) & vmask];
+                const int vp = V[(uint32_t)(k + 1) & vmask];
+                const bool down = (k == min_k) || (k != max_k && vm < vp);  // lib/align.c:443
+                x = down ? vp : vm + 1;
+                left = !down;
+                int y = x - k;
+                for (;;) {  // snake: 16 bases per XOR (lib/align.c:452-455)
+                    int rem = q_len - x;
+                    const int rt = t_len - y;
+                    rem = rt < rem ? rt : rem;
+                    if (rem <= 0) break;
+                    const uint32_t a = fetch16_rel(qp, q_sh + (uint32_t)x);
+                    const uint32_t b = fetch16_rel(tp, t_sh + (uint32_t)y);
+                    const uint32_t diff = a ^ b;
+                    int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
+                    m = m < rem ? m : rem;
+                    x += m;
+                    y += m;
+                    if (m < 16) break;
+                }
+            }
+            const uint32_t lb = (uint32_t)(__ballot(act && left) >> hs);
+            const int y = x - k;
+            const uint32_t fb = (uint32_t)(__ballot(act && x >= q_len && y >= t_len) >> hs);
+            if (pact) {
+                row_acc |= (uint64_t)lb << (32 * (ps & 1));
+                if (((ps & 1) || ps == npass - 1) && l == 0) trace[row0 + (uint64_t)d * kFastRowWords + (uint32_t)(ps >> 1)] = row_acc;
+                if (ps & 1) row_acc = 0;
+            }
+            if (act) {
+                V[(uint32_t)k & vmask] = x;
+                const int m = x + y;
+                row_best = m > row_best ? m : row_best;
+            }
+            if (pact) x_keep = x;  // (a pass run only for the other half must not disturb this half's register copy)
+            const int fl = fb ? __ffs((int)fb) - 1 : 0;
+            const int fx = __shfl(x, hs + fl, 64);
+            if (pact && fb) {  // several diagonals may finish in one step: the smallest k wins (lib/align.c:467-470)
+                // (the row's word may still be pending: the passes that would have completed it are not run)
+                if (!(ps & 1) && ps != npass - 1 && l == 0) trace[row0 + (uint64_t)d * kFastRowWords + (uint32_t)(ps >> 1)] = row_acc;
+                fin_k = min_k + 2 * (ps * 32 + fl);
+                fin_x = fx;
+                fin_d = d;
+                status = ST_FINISHED;
+                done = true;
+            }
+        }
+        if (go && done) alive = false, go = false;
+        const int rb = half_max_i32(row_best);
+        if (go) best_m = rb > best_m ? rb : best_m;
+        __syncthreads();  // V[] of this step visible to every lane
+
+        // band re-centring (lib/align.c:473-489)
+        int new_min = max_k, new_max = min_k;
+        const int thr = best_m - 150;
+        bool found = false;
+        for (int ps = 0; ps < np_max; ps++) {
+            const int k = min_k + 2 * (ps * 32 + l);
+            const bool in = go && !found && ps < npass;
+            const int xv = npass == 1 ? x_keep : (in ? V[(uint32_t)k & vmask] : 0);
+            const bool q = in && k < max_k && (2 * xv - k >= thr);
+            const uint32_t qb = (uint32_t)(__ballot(q) >> hs);
+            if (in && qb) {
+                new_min = min_k + 2 * (ps * 32 + (__ffs((int)qb) - 1));
+                found = true;
+            }
+        }
+        found = false;
+        for (int ps = np_max - 1; ps >= 0; ps--) {
+            const int k = min_k + 2 * (ps * 32 + l);
+            const bool in = go && !found && ps < npass;
+            const int xv = npass == 1 ? x_keep : (in ? V[(uint32_t)k & vmask] : 0);
+            const bool q = in && k <= max_k && k > min_k && (2 * xv - k >= thr);
+            const uint32_t qb = (uint32_t)(__ballot(q) >> hs);
+            if (in && qb) {
+                new_max = min_k + 2 * (ps * 32 + (31 - __clz((int)qb)));
+                found = true;
+            }
+        }
+        if (go) {
+            max_k = new_max + 1;
+            min_k = new_min - 1;
+            d++;
+        }
+        __syncthreads();  // the next step's first reads of V[] come after this step's last ones
+    }
+
+    if (have && l == 0) {
+        AlnOut o;
+        o.status = status;
+        o.d_final = fin_d;
+        o.k_final = fin_k;
+        o.x_final = fin_x;
+        o.y_final = fin_x - fin_k;
+        o.n_cols = 0;
+        o.d_steps = d_steps;
+        o.max_band = max_band;
+        o.cells = cells;
+        outs[tid] = o;
+    }
+}
+
 // K8a, wavefront-per-alignment form (NDGPU_K8A=wave; the default is the lane-per-alignment kernel above until the two have been
 // compared inside the full pipeline on the device).  The walk is one dependent chain per alignment; in the kernel above each link
 // of it is a round trip to HBM / L2 and a wavefront lasts as long as the longest of its 64 chains.  Here a wavefront owns ONE
@@ -427,6 +606,12 @@ void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool
                         uint64_t *trace, int32_t *trace_mink,
                         int n_tasks, void *stream) {
     if (n_tasks <= 0) return;
+    static const bool pair_form = getenv("NDGPU_K7") && !strcmp(getenv("NDGPU_K7"), "pair");
+    if (pair_form) {
+        hipLaunchKernelGGL(ond_forward_pair_kernel, dim3((unsigned)((n_tasks + 1) / 2)), dim3(64), 0, (hipStream_t)stream, tasks, outs,
+                           pool, db_pool, trace, trace_mink, n_tasks);
+        return;
+    }
     hipLaunchKernelGGL(ond_forward_kernel<false>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs,
                        pool, db_pool, trace, trace_mink, (int32_t *)nullptr, (const int32_t *)nullptr);
 }
