@@ -940,8 +940,19 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             if (b > a) {
                 HIP_CHECK(hipEventRecord(S.evs[0], st));
                 NDGPU_DBG(st, "main: forward %zu..%zu of %zu tasks, %zu piles", a, b, nt, np);
+                const int32_t *order = nullptr;
+                if (ond_forward_pairs()) {  // the two alignments of a wavefront should be about equally long
+                    std::vector<int32_t> ord(b - a);
+                    for (size_t i = 0; i < ord.size(); i++) ord[i] = (int32_t)i;
+                    std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
+                        return tasks[a + x].q_len + tasks[a + x].t_len > tasks[a + y].q_len + tasks[a + y].t_len;
+                    });
+                    S.d_ids.reserve(ord.size());
+                    S.h2d(S.d_ids.p, ord.data(), ord.size() * sizeof(int32_t), st);
+                    order = S.d_ids.p;
+                }
                 launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p,
-                                   (int)(b - a), st);
+                                   (int)(b - a), st, order);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
                 NDGPU_DBG(st, "main: traceback");
                 launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p,

@@ -203,7 +203,8 @@ constexpr int kFastMaxBand = 253;      // band + 3 <= kFastVSize
 
 // launchers (ond_kernels.hip)
 void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
-                        uint64_t *trace, int32_t *trace_mink, int n_tasks, void *stream);
+                        uint64_t *trace, int32_t *trace_mink, int n_tasks, void *stream, const int32_t *order = nullptr);
+bool ond_forward_pairs();  // NDGPU_K7=pair: two alignments per wavefront; `order` (device, n_tasks indices) pairs them by length
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace, int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream);
 // task_ids == nullptr: tasks [0, n); otherwise the listed tasks only

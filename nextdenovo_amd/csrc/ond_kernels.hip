@@ -316,12 +316,14 @@ __global__ __launch_bounds__(64) void ond_forward_pair_kernel(const AlnTask *__r
                                                                const uint32_t *__restrict__ pool,
                                                                const uint32_t *__restrict__ db_pool,
                                                                uint64_t *__restrict__ trace, int32_t *__restrict__ trace_mink,
-                                                               int n_tasks) {
+                                                               const int32_t *__restrict__ order, int n_tasks) {
     __shared__ int32_t v_lds[2][kFastVSize];
     const int lane = (int)threadIdx.x, h = lane >> 5, l = lane & 31;
-    const int tid = 2 * (int)blockIdx.x + h;
-    const bool have = tid < n_tasks;
-    const AlnTask T = tasks[have ? tid : 2 * (int)blockIdx.x];
+    const int slot = 2 * (int)blockIdx.x + h;
+    const bool have = slot < n_tasks;
+    // `order` lists the tasks by length, so that the two halves of a wavefront finish together; nullptr = as they come
+    const int tid = order ? order[have ? slot : 2 * (int)blockIdx.x] : (have ? slot : 2 * (int)blockIdx.x);
+    const AlnTask T = tasks[tid];
     int32_t *V = v_lds[h];
     const uint32_t vmask = (uint32_t)(kFastVSize - 1);
     for (uint32_t i = (uint32_t)l; i <= vmask; i += 32) V[i] = 0;
@@ -602,14 +604,18 @@ __global__ __launch_bounds__(64) void ond_traceback_wave_kernel(const AlnTask *_
 
 }  // namespace
 
+bool ond_forward_pairs() {
+    static const bool pair_form = getenv("NDGPU_K7") && !strcmp(getenv("NDGPU_K7"), "pair");
+    return pair_form;
+}
+
 void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                         uint64_t *trace, int32_t *trace_mink,
-                        int n_tasks, void *stream) {
+                        int n_tasks, void *stream, const int32_t *order) {
     if (n_tasks <= 0) return;
-    static const bool pair_form = getenv("NDGPU_K7") && !strcmp(getenv("NDGPU_K7"), "pair");
-    if (pair_form) {
+    if (ond_forward_pairs()) {
         hipLaunchKernelGGL(ond_forward_pair_kernel, dim3((unsigned)((n_tasks + 1) / 2)), dim3(64), 0, (hipStream_t)stream, tasks, outs,
-                           pool, db_pool, trace, trace_mink, n_tasks);
+                           pool, db_pool, trace, trace_mink, order, n_tasks);
         return;
     }
     hipLaunchKernelGGL(ond_forward_kernel<false>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs,
