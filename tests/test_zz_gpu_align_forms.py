@@ -9,16 +9,21 @@ from test_gpu_robust import _driver
 pytestmark = pytest.mark.gpu
 
 
-def test_wave_form_traceback_gives_identical_records():
-    want, _ = _driver({})
+@pytest.fixture(scope="module")
+def default_run():
+    return _driver({})[0]
+
+
+def test_wave_form_traceback_gives_identical_records(default_run):
+    want = default_run
     got, _ = _driver({"NDGPU_K8A": "wave"})
     assert len(want["digests"]) > 50 and got["digests"] == want["digests"]
     print("traceback ms: lane-per-alignment %.1f, wavefront-per-alignment %.1f; forward %.1f / %.1f"
           % (want["stats"]["traceback_ms"], got["stats"]["traceback_ms"], want["stats"]["forward_ms"], got["stats"]["forward_ms"]))
 
 
-def test_pair_form_forward_gives_identical_records():
-    want, _ = _driver({})
+def test_pair_form_forward_gives_identical_records(default_run):
+    want = default_run
     got, _ = _driver({"NDGPU_K7": "pair"})
     assert len(want["digests"]) > 50 and got["digests"] == want["digests"]
     both, _ = _driver({"NDGPU_K7": "pair", "NDGPU_K8A": "wave"})
