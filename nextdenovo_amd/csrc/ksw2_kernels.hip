@@ -102,7 +102,7 @@ __device__ int backtrack(bool is_rev, const uint8_t *p, const int32_t *off, cons
 __device__ __forceinline__ long long wave_max_i64(long long v) {
     for (int o = 32; o; o >>= 1) {
         const int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64), hi = __shfl_xor((int)(v >> 32), o, 64);
-        const long long u = ((long long)hi << 32) | (unsigned int)lo;
+        const long long u = (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
         v = u > v ? u : v;
     }
     return v;
@@ -268,12 +268,14 @@ __global__ void __launch_bounds__(64) ksw_extd2_kernel(const KswJobDev *__restri
                 const int32_t h_top = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + v[en0];
                 __builtin_amdgcn_wave_barrier();
                 const int en1 = st0 + (en0 - st0) / 4 * 4, n_grp = (en1 - st0) / 4;
-                long long best = ((long long)h_top << 32) | (unsigned int)0x7fffffff;
+                // key = (score, -rank) as one signed 64-bit number (the score's bits moved up without shifting a negative value)
+                auto pack = [](int32_t hv, int rk) { return (long long)(((unsigned long long)(uint32_t)hv << 32) | (uint32_t)(0x7fffffff - rk)); };
+                long long best = pack(h_top, 0);
                 for (int t = st0 + lane; t < en0; t += 64) {
                     const int32_t h = H[t] + (int32_t)v[t];
                     H[t] = h;
                     const int rank = t < en1 ? 1 + ((t - st0) & 3) * n_grp + ((t - st0) >> 2) : 1 + 4 * n_grp + (t - en1);
-                    const long long key = ((long long)h << 32) | (unsigned int)(0x7fffffff - rank);
+                    const long long key = pack(h, rank);
                     best = key > best ? key : best;
                 }
                 if (lane == 0) H[en0] = h_top;

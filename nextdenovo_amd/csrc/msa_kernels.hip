@@ -446,12 +446,12 @@ __device__ __forceinline__ void st_score(long long *p, long long v) {
 __device__ __forceinline__ long long readlane_i64(long long v, int src) {
     const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), src);
     const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
-    return ((long long)hi << 32) | (unsigned int)lo;
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ long long shfl_i64(long long v, int src) {
     const int lo = __shfl((int)(v & 0xffffffffll), src, 64);
     const int hi = __shfl((int)(v >> 32), src, 64);
-    return ((long long)hi << 32) | (unsigned int)lo;
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
 }
 
 // Scoring DP, segment-parallel.  The DP is a dependent chain over (column, delta) steps, 10^4-10^6 long per seed, and

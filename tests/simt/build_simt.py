@@ -38,10 +38,17 @@ def build_overlap(force: bool = False) -> str:
 
 
 def _build(lib, sources, libs, force) -> str:
+    out_dir = OUT_DIR
+    flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-I", os.path.join(HERE, "include"), "-I", CSRC, "-w"]
+    san = os.environ.get("SIMT_SANITIZE")  # e.g. "undefined": shifts, signed overflow, misaligned / null accesses inside the kernels
+    if san:                                # (a build of its own under _build/<sanitizer>/; load it with libubsan preloaded)
+        out_dir = os.path.join(OUT_DIR, san.replace(",", "_"))
+        flags += ["-fsanitize=" + san, "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"]
+        lib = os.path.join(out_dir, os.path.basename(lib))
+        libs = list(libs) + ["-fsanitize=" + san]
     if not force and not _stale(lib):
         return lib
-    os.makedirs(OUT_DIR, exist_ok=True)
-    flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-I", os.path.join(HERE, "include"), "-I", CSRC, "-w"]
+    os.makedirs(out_dir, exist_ok=True)
     objs = []
     procs = []
     for src in sources + ["simt_runtime.cpp"]:
@@ -52,10 +59,10 @@ def _build(lib, sources, libs, force) -> str:
             text, n_asm = re.subn(r'asm volatile\("s_[^;]*;', ";", text)
             # and the workgroup's dynamically sized LDS array is the interpreter's per-workgroup buffer
             text = re.sub(r'extern __shared__ (\w+) (\w+)\[\];', r'\1 *\2 = (\1 *)simt::dynamic_lds();', text)
-            path = os.path.join(OUT_DIR, src + ".cpp")
+            path = os.path.join(out_dir, src + ".cpp")
             with open(path, "w") as f:
                 f.write('#line 1 "%s"\n' % os.path.join(CSRC, src) + text)
-        obj = os.path.join(OUT_DIR, src + ".o")
+        obj = os.path.join(out_dir, src + ".o")
         objs.append(obj)
         procs.append((src, subprocess.Popen(["g++", *flags, "-x", "c++", "-c", path, "-o", obj], stderr=subprocess.PIPE, text=True)))
     for src, p in procs:
