@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace simt {
@@ -333,31 +334,43 @@ size_t pretend_total() {
     return (size_t)(e ? atof(e) : 24.0) * (1ull << 30);
 }
 
+std::mutex g_alloc_mu;
+std::unordered_map<void *, size_t> g_alloc_size;
+
+// exactly n bytes, 256-byte aligned like hipMalloc: under AddressSanitizer (SIMT_SANITIZE=address) an access one byte past a device
+// buffer is reported
 void *alloc_tracked(size_t n) {
     if (n == 0) n = 1;
     if (g_allocated.load() + n > pretend_total()) return nullptr;
-    char *raw = (char *)malloc(n + 256);
-    if (!raw) return nullptr;
-    char *p = (char *)(((uintptr_t)raw + 256) & ~(uintptr_t)255);
+    void *p = nullptr;
+    if (posix_memalign(&p, 256, n) != 0 || !p) return nullptr;
     // device memory comes uninitialised: poison it, so that a kernel that relies on zeroes it never wrote fails here too
     // (large buffers: the first and last megabyte only -- the tests' working sets are far smaller than the planned capacities)
     static const bool poison = !getenv("SIMT_NO_POISON");
     if (poison) {
         const size_t edge = 1u << 20;
         if (n <= 2 * edge) memset(p, 0xcd, n);
-        else memset(p, 0xcd, edge), memset(p + n - edge, 0xcd, edge);
+        else memset(p, 0xcd, edge), memset((char *)p + n - edge, 0xcd, edge);
     }
-    ((size_t *)p)[-1] = n;
-    ((char **)p)[-2] = raw;
+    {
+        std::lock_guard<std::mutex> lock(g_alloc_mu);
+        g_alloc_size[p] = n;
+    }
     g_allocated += n;
     return p;
 }
 
 void free_tracked(void *q) {
     if (!q) return;
-    char *p = (char *)q;
-    g_allocated -= ((size_t *)p)[-1];
-    free(((char **)p)[-2]);
+    {
+        std::lock_guard<std::mutex> lock(g_alloc_mu);
+        auto it = g_alloc_size.find(q);
+        if (it != g_alloc_size.end()) {
+            g_allocated -= it->second;
+            g_alloc_size.erase(it);
+        }
+    }
+    free(q);
 }
 
 }  // namespace
