@@ -174,7 +174,9 @@ void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);
 /* The device contexts keep their (grow-only) buffers between calls.  This hands them back -- for a caller that alternates
  * the consensus with another memory-hungry stage on the same device (the overlap stage of a genome-scale read set) and
- * finds that stage short of memory.  Returns the bytes released; buffers are re-created on demand. */
+ * finds that stage short of memory.  Safe to call at any time from any thread: a context that is in the middle of a batch
+ * (another thread inside nextCorrect / ndgpu_correct_*) keeps its buffers and is skipped.  Returns the bytes released; buffers
+ * are re-created on demand. */
 uint64_t ndgpu_release_memory(void);
 /* Number of HIP devices visible (0 if none); does not create a context. */
 int ndgpu_device_count(void);

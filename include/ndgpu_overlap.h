@@ -89,7 +89,8 @@ int64_t ndgpu_ovl_encode(const ndgpu_ovl_rec *recs, int64_t n, uint32_t prev[2],
  * partial record is not consumed (*consumed = bytes used, may be NULL).  Returns the records decoded (<= cap). */
 int64_t ndgpu_ovl_decode(const uint8_t *buf, uint64_t n_bytes, uint32_t prev[2], uint32_t *out, int64_t cap, uint64_t *consumed);
 /* the walk of kbit_read() (lib/bseq.c:257-299) over a .2bit payload without its 2 magic bytes: ids, lengths and the word
- * index of every read's sequence.  Returns the number of reads in the payload (cap = 0: count only). */
+ * index of every read's sequence.  Returns the number of reads in the payload (cap = 0: count only), -1 when a record's words
+ * run past the payload (truncated / corrupt file). */
 int64_t ndgpu_2bit_index(const uint32_t *words, uint64_t n_words, uint32_t *ids, uint32_t *lens, uint64_t *word_off, int64_t cap);
 
 /* ---- read ingestion: the FASTA / FASTQ[.gz] reader of `seq_dump` (util/seq_dump.c:60-118 over kseq_read, util/kseq.h:178-222) ----

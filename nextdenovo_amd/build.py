@@ -40,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not force and not _stale(lib, srcs + hdrs + [exports]):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, exports), "-o", lib] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in srcs] + (["-lz"] if lib == OVL_LIB else [])
+               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, exports), "-o", lib] + os.environ.get("NDGPU_CXXFLAGS", "").split() + [os.path.join(CSRC, f) for f in srcs] + (["-lz", "-ldl"] if lib == OVL_LIB else [])
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

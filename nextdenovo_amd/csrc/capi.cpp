@@ -217,6 +217,22 @@ ndgpu_db *ndgpu_db_open(const char *idx_fofn) {
     fclose(f);
     std::vector<uint32_t> words, lens;
     std::vector<uint64_t> word_off;
+    // ids index the DB: bound them by the number of lines of the .idx files (one per read, lib/index.c:7-36) -- a corrupt id
+    // must not size the tables
+    size_t max_reads = 0;
+    for (const std::string &idx : idx_files) {
+        FILE *t = fopen(idx.c_str(), "r");
+        if (!t) {
+            fprintf(stderr, "[ndgpu] ndgpu_db_open: cannot open %s\n", idx.c_str());
+            return nullptr;
+        }
+        char buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), t)) > 0)
+            for (size_t i = 0; i < got; i++) max_reads += buf[i] == '\n';
+        fclose(t);
+        max_reads++;  // a last line without a newline
+    }
     for (const std::string &idx : idx_files) {
         const size_t slash = idx.find_last_of('/');
         const std::string dir = slash == std::string::npos ? "" : idx.substr(0, slash + 1);
@@ -245,6 +261,11 @@ ndgpu_db *ndgpu_db_open(const char *idx_fofn) {
         fclose(b);
         for (size_t p = base; p + 2 <= base + nw;) {
             const uint32_t id = words[p], ln = words[p + 1];
+            if (p + 2 + (((size_t)ln + 15) >> 4) > base + nw || (size_t)id >= max_reads) {  // truncated / corrupt file
+                fprintf(stderr, "[ndgpu] ndgpu_db_open: %s: record at word %zu (id %u, %u bases) %s\n", path.c_str(), p - base, id, ln,
+                        (size_t)id >= max_reads ? "names a read the .idx files do not list" : "runs past the end of the file");
+                return nullptr;
+            }
             if (id >= lens.size()) {
                 lens.resize((size_t)id + 1, 0);
                 word_off.resize((size_t)id + 1, 0);
@@ -621,7 +642,7 @@ uint64_t ndgpu_release_memory(void) {
     (void)hipMemGetInfo(&f0, &t);
     join_reapers();
     for (int c = 0; c < DeviceAligner::kMaxContexts; c++)
-        if (DeviceAligner *d = DeviceAligner::peek(c)) d->release_memory();
+        if (DeviceAligner *d = DeviceAligner::peek(c)) (void)d->release_memory_if_idle();  // a context with a batch open keeps its buffers
     (void)hipMemGetInfo(&f1, &t);
     return f1 > f0 ? (uint64_t)(f1 - f0) : 0;
 }

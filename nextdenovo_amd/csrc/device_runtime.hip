@@ -207,7 +207,8 @@ struct DeviceAligner::State {
     DevBuf<AlnTask> d_tasks;
     DevBuf<AlnOut> d_outs;
     DevBuf<uint64_t> d_trace;
-    DevBuf<int32_t> d_mink, d_v, d_ids;
+    DevBuf<int32_t> d_v, d_ids;
+    std::vector<int32_t> order;
     // main-phase state (alive from run_main to end_batch)
     std::mutex batch_mu;
     DevBuf<ReadDev> d_reads;
@@ -342,7 +343,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
         }
     }
 #define NDGPU_NAME(x) s_->x.name = #x;
-    NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_mink) NDGPU_NAME(d_v)
+    NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
     NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_inscnt) NDGPU_NAME(d_insmax) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
     NDGPU_NAME(d_cell_start) NDGPU_NAME(d_cell_len) NDGPU_NAME(d_cell_bpp) NDGPU_NAME(d_cell_blink) NDGPU_NAME(d_ent_pp)
@@ -442,7 +443,7 @@ void DeviceAligner::release_memory() {
     S.pending.clear();
     S.up_used = S.down_used = 0;
 #define NDGPU_REL(x) S.x.release();
-    NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_mink) NDGPU_REL(d_v)
+    NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
     NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_inscnt) NDGPU_REL(d_insmax) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
     NDGPU_REL(d_cell_start) NDGPU_REL(d_cell_len) NDGPU_REL(d_cell_bpp) NDGPU_REL(d_cell_blink) NDGPU_REL(d_ent_pp)
@@ -451,6 +452,13 @@ void DeviceAligner::release_memory() {
     NDGPU_REL(d_bt_off) NDGPU_REL(d_path) NDGPU_REL(d_blocks) NDGPU_REL(d_regions) NDGPU_REL(d_strpool) NDGPU_REL(d_cursor)
     NDGPU_REL(h_ops) NDGPU_REL(h_outs) NDGPU_REL(up) NDGPU_REL(down)
 #undef NDGPU_REL
+}
+
+bool DeviceAligner::release_memory_if_idle() {
+    if (!s_->batch_mu.try_lock()) return false;
+    release_memory();
+    s_->batch_mu.unlock();
+    return true;
 }
 
 // How much of the device the consensus contexts may use, decided at the start of every batch call from what is free NOW
@@ -464,7 +472,7 @@ void DeviceAligner::plan_memory(int drivers, uint64_t *tag_budget) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
     const long long held = g_dev_bytes.load();
     long long avail = (long long)free_b + held - (long long)((size_t)10 << 30);  // headroom: runtime, pinned staging, the next overlap stage's growth
-    if (const char *e = getenv("NDGPU_DEVICE_BUDGET_GB")) avail = std::min<long long>(avail, atoll(e) << 30);
+    if (const char *e = getenv("NDGPU_DEVICE_BUDGET_GB")) avail = std::min<long long>(avail, (long long)(atof(e) * (double)(1ull << 30)));
     if (avail < ((long long)4 << 30)) avail = (long long)4 << 30;
     const long long per_ctx = avail / std::max(1, drivers);
     const size_t trace = (size_t)std::min<long long>((long long)8 << 30, std::max<long long>(per_ctx / 5, (long long)256 << 20));
@@ -511,7 +519,7 @@ void DeviceAligner::align_batch(AlnJob **jobs, size_t n) {
             const AlnJob &j = *jobs[done + take];
             int md, bd;
             limits_for(j.q_len + j.t_len, j.hq, &md, &bd);
-            const size_t b = (size_t)md * (kFastRowWords * 8 + 4);
+            const size_t b = (size_t)md * (kFastRowWords * 8);
             if (take && bytes + b > s_->trace_budget_bytes) break;
             bytes += b;
             take++;
@@ -576,7 +584,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     std::vector<uint8_t> bad(n, 0);
     // pass 1 (serial, O(1) per job): offsets of every per-task region
     std::vector<uint64_t> qw(n + 1), tw(n + 1);
-    uint64_t trace_words = 0, mink_rows = 0, ops_words = 0, pool_words = 0;
+    uint64_t trace_words = 0, ops_words = 0, pool_words = 0;
     for (size_t i = 0; i < n; i++) {
         const AlnJob &j = *jobs[i];
         AlnTask &t = tasks[i];
@@ -592,11 +600,9 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
         t.band = bd;
         t.row_words = kFastRowWords;
         t.trace_off = trace_words;
-        t.mink_off = mink_rows;
         t.ops_off = ops_words;
         t.ops_cap = (uint32_t)(j.q_len + j.t_len);
         trace_words += (uint64_t)md * kFastRowWords;
-        mink_rows += (uint64_t)md;
         ops_words += (uint64_t)(t.ops_cap + 15) / 16 + 1;
         S.stats.seq_bases += (uint64_t)j.q_len + (uint64_t)j.t_len;
         S.stats.pool_bases += (j.q_dev < 0 ? (uint64_t)j.q_len : 0) + (j.t_dev < 0 ? (uint64_t)j.t_len : 0);
@@ -630,7 +636,6 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.d_tasks.reserve(n);
     S.d_outs.reserve(n);
     S.d_trace.reserve(trace_words + 2);
-    S.d_mink.reserve(mink_rows + 2);
     S.d_ops.reserve(ops_words + 2);
     S.h_ops.reserve(ops_words + 2);
     S.h_outs.reserve(n);
@@ -641,10 +646,10 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.h2d(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), st);
     HIP_CHECK(hipEventRecord(S.ev0, st));
     NDGPU_DBG(st, "chunk: forward %zu tasks", n);
-    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p, (int)n, st);
+    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, (int)n, st);
     HIP_CHECK(hipEventRecord(S.ev1, st));
     NDGPU_DBG(st, "chunk: traceback");
-    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p, S.d_ops.p, nullptr, (int)n, st);
+    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr, S.d_ops.p, nullptr, (int)n, st);
     NDGPU_DBG(st, "chunk: done");
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, n * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(S.h_ops.p, S.d_ops.p, ops_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -875,28 +880,25 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     // forward/traceback chunks bounded by the trace budget
     std::vector<size_t> chunk_end;
     {
-        uint64_t tw = 0, mr = 0;
+        uint64_t tw = 0;
         for (size_t i = 0; i < nt; i++) {
-            const uint64_t need = (uint64_t)tasks[i].max_d * (kFastRowWords * 8 + 4);
-            if (i && (tw * 8 + mr * 4 + need) > S.trace_budget_bytes) {
+            const uint64_t need = (uint64_t)tasks[i].max_d * (kFastRowWords * 8);
+            if (i && (tw * 8 + need) > S.trace_budget_bytes) {
                 chunk_end.push_back(i);
-                tw = mr = 0;
+                tw = 0;
             }
             tasks[i].trace_off = tw;
-            tasks[i].mink_off = mr;
             tw += (uint64_t)tasks[i].max_d * kFastRowWords;
-            mr += (uint64_t)tasks[i].max_d;
         }
         chunk_end.push_back(nt);
     }
-    uint64_t max_tw = 0, max_mr = 0;
+    uint64_t max_tw = 0;
     {
         size_t a = 0;
         for (size_t b : chunk_end) {
             if (b > a) {
                 const AlnTask &l = tasks[b - 1];
                 max_tw = std::max<uint64_t>(max_tw, l.trace_off + (uint64_t)l.max_d * kFastRowWords);
-                max_mr = std::max<uint64_t>(max_mr, l.mink_off + (uint64_t)l.max_d);
             }
             a = b;
         }
@@ -907,7 +909,6 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_outs.reserve(nt + 1);
     S.h_outs.reserve(nt + 1);
     S.d_trace.reserve(max_tw + 2);
-    S.d_mink.reserve(max_mr + 2);
     S.d_ops.reserve(ops_words + 2);
     S.d_reads.reserve(nr);
     S.d_piles.reserve(np);
@@ -941,8 +942,10 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                 HIP_CHECK(hipEventRecord(S.evs[0], st));
                 NDGPU_DBG(st, "main: forward %zu..%zu of %zu tasks, %zu piles", a, b, nt, np);
                 const int32_t *order = nullptr;
-                if (ond_forward_pairs()) {  // the two alignments of a wavefront should be about equally long
-                    std::vector<int32_t> ord(b - a);
+                static const bool lpt = !getenv("NDGPU_K7_NO_ORDER");
+                if (lpt && b - a > 64) {  // longest alignments first (their chains bound the launch)
+                    std::vector<int32_t> &ord = S.order;
+                    ord.resize(b - a);
                     for (size_t i = 0; i < ord.size(); i++) ord[i] = (int32_t)i;
                     std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
                         return tasks[a + x].q_len + tasks[a + x].t_len > tasks[a + y].q_len + tasks[a + y].t_len;
@@ -951,11 +954,10 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                     S.h2d(S.d_ids.p, ord.data(), ord.size() * sizeof(int32_t), st);
                     order = S.d_ids.p;
                 }
-                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p,
-                                   (int)(b - a), st, order);
+                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st, order);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
                 NDGPU_DBG(st, "main: traceback");
-                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_mink.p,
+                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr,
                                      S.d_ops.p, nullptr, (int)(b - a), st);
                 NDGPU_DBG(st, "main: traceback done");
                 HIP_CHECK(hipEventRecord(S.evs[2], st));

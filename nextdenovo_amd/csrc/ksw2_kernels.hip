@@ -16,6 +16,8 @@
 // There is no CPU path: without a HIP device the calls fail loudly.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <climits>
 #include <cstdint>
 #include <cstdio>
@@ -463,7 +465,9 @@ static int run_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res) {
     return 0;
 }
 
-// minimap2/ksw2.h:60-61.  `km` (the reference's arena) is not used: ez->cigar is malloc'd, as it is with km == NULL there.
+// minimap2/ksw2.h:60-61.  ez->cigar is the caller's grow-by-doubling buffer (ksw_push_cigar, ksw2.h:96-110): with km == NULL it
+// belongs to malloc, otherwise to the reference's arena allocator (kalloc.c), whose krealloc is looked up in the host program
+// -- minimap2's mm_align_pair passes an arena -- and never mixed with free().
 extern "C" void ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                               int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2, int w, int zdrop, int end_bonus, int flag,
                               ndgpu_ksw_extz *ez) {
@@ -477,8 +481,24 @@ extern "C" void ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen
     ez->max = (uint32_t)r.max & 0x7fffffffu, ez->zdropped = (uint32_t)r.zdropped & 1u;
     ez->max_q = r.max_q, ez->max_t = r.max_t, ez->mqe = r.mqe, ez->mqe_t = r.mqe_t, ez->mte = r.mte, ez->mte_q = r.mte_q, ez->score = r.score;
     ez->n_cigar = r.n_cigar, ez->reach_end = r.reach_end;
-    if (r.n_cigar > 0) {  // (the reference grows a caller-owned buffer; a fresh one of the exact size replaces it)
-        free(ez->cigar);
-        ez->cigar = r.cigar, ez->m_cigar = r.n_cigar;
+    if (r.n_cigar > 0) {
+        if (!ez->cigar || ez->m_cigar < r.n_cigar) {
+            int cap = ez->m_cigar > 0 ? ez->m_cigar : 4;
+            while (cap < r.n_cigar) cap <<= 1;  // the capacities the reference's doubling would have reached
+            if (!km) ez->cigar = (uint32_t *)realloc(ez->cigar, sizeof(uint32_t) * (size_t)cap);
+            else {
+                typedef void *(*krealloc_t)(void *, void *, size_t);
+                static const krealloc_t kr = (krealloc_t)dlsym(RTLD_DEFAULT, "krealloc");
+                if (!kr) {
+                    fprintf(stderr, "[ndgpu_overlap] ksw_extd2_sse: called with an arena (km != NULL) but the host program exports no krealloc\n");
+                    abort();
+                }
+                ez->cigar = (uint32_t *)kr(km, ez->cigar, sizeof(uint32_t) * (size_t)cap);
+            }
+            if (!ez->cigar) abort();
+            ez->m_cigar = cap;
+        }
+        memcpy(ez->cigar, r.cigar, sizeof(uint32_t) * (size_t)r.n_cigar);
+        free(r.cigar);
     }
 }

@@ -18,11 +18,12 @@ struct AlnTask {
     int32_t t_len;
     int32_t max_d;       // edit budget  (lib/align.c:567,575)
     int32_t band;        // band cap     (lib/align.c:568,576)
-    uint64_t trace_off;  // uint64-word offset of trace row 0 (row d at trace_off + d*row_words)
-    uint64_t mink_off;   // index of row 0 in the per-row min_k array
+    uint64_t trace_off;  // uint64-word offset of the task's trace (register path: a stream of <= 2 * max_d words;
+                         // wide path: row d at trace_off + d*row_words)
+    uint64_t mink_off;   // wide path only: index of row 0 in the per-row min_k array
     uint64_t ops_off;    // first ops word of this task (uint32 units)
     uint32_t ops_cap;    // capacity in columns (= q_len + t_len)
-    uint32_t row_words;  // uint64 words per trace row (2 in the LDS fast path)
+    uint32_t row_words;  // wide path only: uint64 words per trace row
     uint64_t v_off;      // wide path only: first int of this task's global V scratch
     uint32_t v_mask;     // wide path only: V ring size - 1 (power of two - 1)
     uint32_t pad_;
@@ -46,6 +47,8 @@ struct AlnOut {
     int32_t d_steps;   // counters for the roofline accounting
     int32_t max_band;
     int64_t cells;
+    uint32_t trace_end;  // register path: words of trace stream written (the finishing step's record ends here)
+    int32_t fin_idx;     // register path: cell index of k_final in the finishing step
 };
 
 // ---- main-phase consensus on the device (msa_kernels.hip) ---------------------------------
@@ -197,17 +200,16 @@ void launch_extract(const PileDev *piles, const ReadDev *reads, const uint32_t *
 constexpr uint64_t kOffDb = 1ull << 63;   // offset flag: sequence lives in the resident read DB
 constexpr uint64_t kOffMask = kOffDb - 1;
 
-constexpr int kFastVSize = 256;        // LDS ring of furthest-reaching x per diagonal
-constexpr int kFastRowWords = 2;       // 128 same-parity diagonals per row
-constexpr int kFastMaxBand = 253;      // band + 3 <= kFastVSize
+constexpr int kFastRowWords = 2;       // register path: at most two 64-bit trace words per edit step (one up to 56 cells)
+constexpr int kFastMaxBand = 238;      // register path: at most 120 same-parity diagonals per edit step (two per lane, 7-bit offsets)
 
 // launchers (ond_kernels.hip)
 void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
-                        uint64_t *trace, int32_t *trace_mink, int n_tasks, void *stream, const int32_t *order = nullptr);
-bool ond_forward_pairs();  // NDGPU_K7=pair: two alignments per wavefront; `order` (device, n_tasks indices) pairs them by length
+                        uint64_t *trace, int n_tasks, void *stream, const int32_t *order = nullptr);  // order: device, n_tasks ids, longest first
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace, int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream);
-// task_ids == nullptr: tasks [0, n); otherwise the listed tasks only
+// task_ids == nullptr: tasks [0, n), traces in the register path's stream format; otherwise the listed (wide-band) tasks,
+// traces in the wide kernel's row format
 void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                           const uint64_t *trace,
                           const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n, void *stream);

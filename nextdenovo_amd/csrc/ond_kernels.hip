@@ -2,20 +2,19 @@
 // NextDenovo's consensus is built on (reference: core() via align()/align_hq(),
 // lib/align.c:428-578).  Integer DP, no MFMA.
 //
-// K7  ond_forward   : one 64-lane wavefront per alignment.  Lane l of pass p owns
-//                     diagonal k = min_k + 2*(64p + l); all diagonals of one edit
-//                     step d are independent, so a step is: 2 LDS reads of the
-//                     furthest-reaching ring V[], a snake (XOR + ctz over 16-base
-//                     2-bit words fetched from the HBM-resident pool), 1 LDS write,
-//                     two wave ballots (move bits -> trace row, finish test), one
-//                     wave max (best anti-diagonal) and two ballots for the band
-//                     re-centring.  Traceback memory is 1 bit per evaluated cell
-//                     plus min_k per step, instead of the reference's one byte per
-//                     cell of an O(max_d^2) triangle.
-// K7w ond_forward<W>: same code with V[] in a global scratch ring and a wider
-//                     trace row, for the rare alignments whose live band exceeds
-//                     the 253-diagonal LDS fast path (exactness of the band-cap /
-//                     edit-budget failure semantics).
+// K7  ond_forward   : one 64-lane wavefront per alignment, the furthest-reaching values
+//                     of an edit step in registers (lane l = diagonal min_k + 2l, a second
+//                     cell per lane on the steps wider than 64 cells); a step is one wave
+//                     permute + one DPP shift (the reference's V[k-1], V[k+1]), a snake
+//                     (XOR + ctz over 16-base 2-bit words fetched from the HBM-resident
+//                     pool), two ballots (move bits -> trace record, finish test), one wave
+//                     max (best anti-diagonal) and two ballots for the band re-centring.
+//                     Traceback memory is 1 bit per evaluated cell + 8 bits of offset per
+//                     step in a record stream, instead of the reference's one byte per cell
+//                     of an O(max_d^2) triangle.
+// K7w ond_forward_wide: V[] in a global scratch ring and band-cap-wide trace rows, for the
+//                     rare alignments whose live band exceeds the register path (exactness
+//                     of the band-cap / edit-budget failure semantics).
 // K8a ond_traceback : one lane per alignment walks d -> 0 reading the move bits,
 //                     re-deriving match runs with clz over 16-base words, and emits
 //                     2-bit column kinds back to front.
@@ -40,13 +39,13 @@ __device__ __forceinline__ uint32_t fetch16(const uint32_t *__restrict__ pool, u
     return (uint32_t)(v >> s);
 }
 
-// maximum over the 64 lanes (all of them active) with data-parallel-primitive moves instead of six LDS permutes: the
-// forward kernel is bound by instruction issue, and this reduction sits on every edit step
 __device__ __forceinline__ uint32_t fetch16_rel(const uint32_t *__restrict__ seq, uint32_t pos) {  // pos: base index from seq's first word
     const uint64_t v = *(const u64_a4 *)(seq + (pos >> 4));
     return (uint32_t)(v >> ((pos & 15u) * 2u));
 }
 
+// maximum over the 64 lanes (all of them active) with data-parallel-primitive moves instead of six LDS permutes: the
+// forward kernel is bound by instruction issue, and this reduction sits on every edit step
 __device__ __forceinline__ int wave_max_i32(int v) {
     auto step = [](int x, auto ctrl, auto rows) {
         const int y = __builtin_amdgcn_update_dpp(INT_MIN, x, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
@@ -61,20 +60,219 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <bool WIDE>
+// K7: one wavefront per alignment, the furthest-reaching values in REGISTERS.  Lane l owns cell l of an edit step (diagonal
+// min_k + 2l) and, on the steps whose live band is wider than 64 cells, cell 64 + l as well.  Every value a step reads was
+// written by the step before it: cell c' of step d + 1 is diagonal k' = min_k' + 2c' with min_k' = new_min - 1 =
+// min_k + 2j - 1 (j = index of the first diagonal the re-centring keeps), so V[k' + 1] is cell j + c' of step d and V[k' - 1]
+// cell j + c' - 1; the two edge diagonals never look outside (k' == min_k' takes V[k' + 1], k' == max_k' takes V[k' - 1] + 1:
+// lib/align.c:443).  So the reference's V[] array is two registers per lane, moved by one wave permute with a uniform shift
+// (ds_bpermute) and one wave_shr:1 DPP move: no LDS ring, no workgroup barrier, no second look at V[] for the re-centring.
+//
+// Trace: a stream of 64-bit words per alignment, one record per edit step, written front to back and read back to front by
+// the traceback (which visits the steps d, d - 1, d - 2, ... without exception).  The LAST word of a record (the first one the
+// traceback meets) is its header: bits [55:0] = move bits of cells 0..55, bit 56 = "this record has a second word", bits
+// [63:57] = j (above).  Records of steps with more than 56 cells carry the move bits of cells 56..119 in the word before the
+// header.  min_k is never stored: the traceback follows the CELL INDEX of its diagonal, idx(d - 1) = idx(d) + j(d - 1) - left.
+// 8 bytes per step for bands up to 110 diagonals, 16 beyond: the algorithmic 1 bit per evaluated cell + the step's offset.
+constexpr int kStreamBits = 56;                           // move bits in a header word
+constexpr uint64_t kStreamMask = (1ull << kStreamBits) - 1;
+
+__device__ __forceinline__ int wave_shr1(int first, int v) {  // lane l gets v of lane l - 1, lane 0 gets `first`
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int snake16(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint32_t q_sh, uint32_t t_sh,
+                                       int q_len, int t_len, int x, int k) {
+    int y = x - k;
+    for (;;) {  // 16 bases per XOR, first mismatch = ctz / 2 (lib/align.c:452-455)
+        int rem = q_len - x;
+        const int rt = t_len - y;
+        rem = rt < rem ? rt : rem;
+        if (rem <= 0) break;
+        const uint32_t a = fetch16_rel(qp, q_sh + (uint32_t)x);
+        const uint32_t b = fetch16_rel(tp, t_sh + (uint32_t)y);
+        const uint32_t diff = a ^ b;
+        int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
+        m = m < rem ? m : rem;
+        x += m;
+        y += m;
+        if (m < 16) break;
+    }
+    return x;
+}
+
 __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
+                                                          const uint32_t *__restrict__ pool,
+                                                          const uint32_t *__restrict__ db_pool,
+                                                          uint64_t *__restrict__ trace, const int32_t *__restrict__ order) {
+    // `order` lists the launch's tasks longest first: workgroups are dispatched in index order, so the long dependent chains
+    // start first and the short ones fill in behind them
+    const int tid = order ? order[blockIdx.x] : (int)blockIdx.x;
+    const AlnTask T = tasks[tid];
+    const int lane = (int)threadIdx.x;
+    // An alignment is a chain of dependent edit steps, and the launch (and whatever waits for it) lasts as long as its longest
+    // chain; a wavefront that shares its SIMD with seven others gets an eighth of the issue slots.  The long chains therefore
+    // ask the SIMD's arbiter for priority over the short ones -- of this launch and of the other contexts' kernels alike.
+    {
+        const int total = T.q_len + T.t_len;
+        if (total > 160000) __builtin_amdgcn_s_setprio(3);
+        else if (total > 80000) __builtin_amdgcn_s_setprio(2);
+        else if (total > 40000) __builtin_amdgcn_s_setprio(1);
+    }
+
+    int min_k = 0, max_k = 0, best_m = -1;
+    int status = ST_NONE, fin_k = 0, fin_x = 0, fin_d = -1, fin_idx = 0;
+    int d_steps = 0, max_band = 0;
+    long long cells = 0;
+    const int q_len = T.q_len, t_len = T.t_len;
+    // bit 63 of an offset selects the resident read DB instead of the per-batch pool; inside the kernel a base is addressed
+    // by a 32-bit word index relative to its sequence's first word (a sequence is < 2^31 bases)
+    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
+    const uint32_t *__restrict__ qp = ((T.q_off >> 63) ? db_pool : pool) + (q_off >> 4);
+    const uint32_t *__restrict__ tp = ((T.t_off >> 63) ? db_pool : pool) + (t_off >> 4);
+    const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
+    uint64_t *__restrict__ S = trace + T.trace_off;
+    uint32_t pos = 0;
+
+    int px0 = 0, px1 = 0;  // the step before: x of cell `lane` / of cell 64 + `lane` (the reference memsets V: all zero)
+    int pj = 0;            // its j
+    bool pwide = false;    // it had more than 64 cells
+
+    for (int d = 0; d < T.max_d && max_k - min_k <= T.band; d++) {
+        const int band = max_k - min_k;
+        if (band > kFastMaxBand) {
+            status = ST_NEED_WIDE;
+            break;
+        }
+        const int ncell = (band >> 1) + 1;  // (the band never shrinks below 0: the row's best diagonal always survives)
+        const bool two = ncell > 64;
+        d_steps++;
+        cells += ncell;
+        max_band = band > max_band ? band : max_band;
+
+        // ---- cells 0..63
+        const int src = pj + lane;
+        int vp = __shfl(px0, src & 63, 64);
+        if (pwide) {
+            const int hi = __shfl(px1, src & 63, 64);
+            vp = src >= 64 ? hi : vp;
+        }
+        const int vm = wave_shr1(0, vp);
+        const int k0 = min_k + 2 * lane;
+        const bool act0 = k0 <= max_k;
+        int x0 = 0;
+        bool left0 = false;
+        if (act0) {
+            const bool down = (k0 == min_k) || (k0 != max_k && vm < vp);  // lib/align.c:443
+            left0 = !down;
+            x0 = snake16(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp : vm + 1, k0);
+        }
+        const unsigned long long lb0 = __ballot(act0 && left0);
+        const unsigned long long fb0 = __ballot(act0 && x0 >= q_len && x0 - k0 >= t_len);
+        int row_best = act0 ? 2 * x0 - k0 : -1;
+        // ---- cells 64..127 (only the steps whose band is wider than 126 diagonals)
+        int x1 = 0, k1 = 0;
+        bool act1 = false;
+        unsigned long long lb1 = 0, fb1 = 0;
+        if (two && !fb0) {
+            const int vp1 = __shfl(px1, src & 63, 64);       // cell 64 + pj + lane of the step before
+            const int vm1 = wave_shr1(__builtin_amdgcn_readlane(vp, 63), vp1);
+            k1 = k0 + 128;
+            act1 = k1 <= max_k;
+            bool left1 = false;
+            if (act1) {
+                const bool down = k1 != max_k && vm1 < vp1;
+                left1 = !down;
+                x1 = snake16(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp1 : vm1 + 1, k1);
+                const int m1 = 2 * x1 - k1;
+                row_best = m1 > row_best ? m1 : row_best;
+            }
+            lb1 = __ballot(act1 && left1);
+            fb1 = __ballot(act1 && x1 >= q_len && x1 - k1 >= t_len);
+        }
+
+        const bool wide_rec = ncell > kStreamBits;
+        const uint64_t bits_lo = lb0 & kStreamMask, bits_hi = (lb0 >> kStreamBits) | (lb1 << (64 - kStreamBits));
+        if (fb0 | fb1) {
+            // several diagonals may finish in one step: the smallest k wins (lib/align.c:467-470)
+            const int fl = fb0 ? __ffsll((long long)fb0) - 1 : __ffsll((long long)fb1) - 1;
+            fin_idx = fb0 ? fl : 64 + fl;
+            fin_k = min_k + 2 * fin_idx;
+            fin_x = fb0 ? __shfl(x0, fl, 64) : __shfl(x1, fl, 64);
+            fin_d = d;
+            status = ST_FINISHED;
+            if (lane == 0) {
+                if (wide_rec) S[pos] = bits_hi;
+                S[pos + (wide_rec ? 1u : 0u)] = ((uint64_t)wide_rec << kStreamBits) | bits_lo;
+            }
+            pos += wide_rec ? 2u : 1u;
+            break;
+        }
+
+        const int rb = wave_max_i32(row_best);
+        best_m = rb > best_m ? rb : best_m;
+
+        // band re-centring (lib/align.c:473-489): first and last diagonal within 150 of the best anti-diagonal
+        const int thr = best_m - 150;
+        const bool ok0 = act0 && 2 * x0 - k0 >= thr, ok1 = act1 && 2 * x1 - k1 >= thr;
+        const unsigned long long qlo0 = __ballot(ok0 && k0 < max_k), qhi0 = __ballot(ok0 && k0 > min_k);
+        unsigned long long qlo1 = 0, qhi1 = 0;
+        if (two) {
+            qlo1 = __ballot(ok1 && k1 < max_k);
+            qhi1 = __ballot(ok1);
+        }
+        int j = ncell - 1, jmax = 0;  // new_min = max_k, new_max = min_k when nothing qualifies
+        if (qlo0) j = __ffsll((long long)qlo0) - 1;
+        else if (qlo1) j = 64 + __ffsll((long long)qlo1) - 1;
+        if (qhi1) jmax = 64 + 63 - __clzll((long long)qhi1);
+        else if (qhi0) jmax = 63 - __clzll((long long)qhi0);
+
+        if (lane == 0) {
+            if (wide_rec) S[pos] = bits_hi;
+            S[pos + (wide_rec ? 1u : 0u)] = ((uint64_t)j << (kStreamBits + 1)) | ((uint64_t)wide_rec << kStreamBits) | bits_lo;
+        }
+        pos += wide_rec ? 2u : 1u;
+
+        max_k = min_k + 2 * jmax + 1;
+        min_k = min_k + 2 * j - 1;
+        px0 = x0;
+        px1 = x1;
+        pj = j;
+        pwide = two;
+    }
+
+    if (lane == 0) {
+        AlnOut o;
+        o.status = status;
+        o.d_final = fin_d;
+        o.k_final = fin_k;
+        o.x_final = fin_x;
+        o.y_final = fin_x - fin_k;
+        o.n_cols = 0;
+        o.d_steps = d_steps;
+        o.max_band = max_band;
+        o.cells = cells;
+        o.trace_end = pos;
+        o.fin_idx = fin_idx;
+        outs[tid] = o;
+    }
+}
+
+// K7w: the same sweep with V[] in a global scratch ring and trace rows as wide as the band cap, for the rare alignments whose
+// live band exceeds the register path (exactness of the band-cap / edit-budget failure semantics).  Trace: row d = row_words
+// 64-bit words of move bits (bit c = diagonal min_k + 2c) + min_k in a side array.
+__global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
                                                           const uint32_t *__restrict__ pool,
                                                           const uint32_t *__restrict__ db_pool,
                                                           uint64_t *__restrict__ trace,
                                                           int32_t *__restrict__ trace_mink,
                                                           int32_t *__restrict__ vscratch,
                                                           const int32_t *__restrict__ ids) {
-    __shared__ int32_t v_lds[WIDE ? 1 : kFastVSize];
-    const int tid = WIDE ? ids[blockIdx.x] : (int)blockIdx.x;
+    const int tid = ids[blockIdx.x];
     const AlnTask T = tasks[tid];
     const int lane = (int)threadIdx.x;
-    int32_t *V = WIDE ? (vscratch + T.v_off) : v_lds;
-    const uint32_t vmask = WIDE ? T.v_mask : (uint32_t)(kFastVSize - 1);
+    int32_t *V = vscratch + T.v_off;
+    const uint32_t vmask = T.v_mask;
 
     for (uint32_t i = (uint32_t)lane; i <= vmask; i += 64) V[i] = 0;  // the reference memsets V per alignment
     __syncthreads();
@@ -91,14 +289,10 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
     const uint32_t *__restrict__ tp = ((T.t_off >> 63) ? db_pool : pool) + (t_off >> 4);
     const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
     const uint64_t row0 = T.trace_off, mk0 = T.mink_off;
-    const uint32_t row_words = WIDE ? T.row_words : (uint32_t)kFastRowWords;
+    const uint32_t row_words = T.row_words;
 
     for (int d = 0; d < T.max_d && max_k - min_k <= T.band; d++) {
         const int band = max_k - min_k;
-        if (!WIDE && band > kFastMaxBand) {
-            status = ST_NEED_WIDE;
-            break;
-        }
         const int ncell = band >= 0 ? (band >> 1) + 1 : 0;
         const int npass = (ncell + 63) >> 6;
         d_steps++;
@@ -207,6 +401,9 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
     }
 }
 
+// K8a: one lane per alignment walks d -> 0.  STREAM: the register path's record stream (see K7), read back to front -- the
+// header of the current step's record is kept in a register, its cell index follows the walk; otherwise the wide kernel's rows.
+template <bool STREAM>
 __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
                                                             const uint32_t *__restrict__ pool,
                                                             const uint32_t *__restrict__ db_pool,
@@ -217,6 +414,12 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     const int slot = (int)(blockIdx.x * 64 + threadIdx.x);
     if (slot >= n_tasks) return;
     const int gid = ids ? ids[slot] : slot;
+    {  // a wavefront of long walks asks for priority over short ones (see K7); its lanes are neighbours of one pile
+        const int total = (int)__builtin_amdgcn_readfirstlane(tasks[gid].ops_cap);
+        if (total > 160000) __builtin_amdgcn_s_setprio(3);
+        else if (total > 80000) __builtin_amdgcn_s_setprio(2);
+        else if (total > 40000) __builtin_amdgcn_s_setprio(1);
+    }
     if (outs[gid].status != ST_FINISHED) return;
     const AlnTask T = tasks[gid];
     const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
@@ -230,6 +433,10 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     uint32_t acc = 0;
     uint32_t *W = ops + T.ops_off;
     bool aborted = false;
+    const uint64_t *__restrict__ S = trace + T.trace_off;
+    uint32_t pos = STREAM ? (uint32_t)outs[gid].trace_end : 0u;  // one past the record of step d
+    int idx = outs[gid].fin_idx;                                  // cell index of diagonal k in step d
+    uint64_t hdr = (STREAM && pos) ? S[pos - 1] : 0ull;
 
     for (;;) {
         // match run, back to front (lib/align.c:502-507), 16 bases per compare
@@ -264,8 +471,14 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
         bool left;
         if (x < k) left = true;  // lib/align.c:512: forced query-consuming move
         else if (x >= 0) {
-            const int idx = (k - trace_mink[T.mink_off + (uint64_t)(uint32_t)d]) >> 1;
-            left = (trace[T.trace_off + (uint64_t)(uint32_t)d * T.row_words + (uint32_t)(idx >> 6)] >> (idx & 63)) & 1ull;
+            if (STREAM) {
+                const bool second = idx >= kStreamBits && pos >= 2;
+                const uint64_t w = second ? S[pos - 2] : hdr;
+                left = (w >> ((second ? idx - kStreamBits : idx) & 63)) & 1ull;
+            } else {
+                const int ix = (k - trace_mink[T.mink_off + (uint64_t)(uint32_t)d]) >> 1;
+                left = (trace[T.trace_off + (uint64_t)(uint32_t)d * T.row_words + (uint32_t)(ix >> 6)] >> (ix & 63)) & 1ull;
+            }
         } else left = false;
         uint32_t code;
         int nk, nx;
@@ -286,6 +499,12 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
         d--;
         k = nk;
         x = nx;
+        if (STREAM) {  // step d - 1: its record ends where this one began; idx(d - 1) = idx(d) + j(d - 1) - left
+            const uint32_t len = 1u + (uint32_t)((hdr >> kStreamBits) & 1ull);
+            pos = pos > len ? pos - len : 0u;
+            hdr = pos ? S[pos - 1] : 0ull;
+            idx += (int)(hdr >> (kStreamBits + 1)) - (left ? 1 : 0);
+        }
     }
     if ((col & 15u) != 0) W[col >> 4] = acc;
     outs[gid].n_cols = aborted ? 2 : (int32_t)(T.ops_cap - col);
@@ -293,355 +512,35 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
 }
 
 
-// K7, two alignments per wavefront (NDGPU_K7=pair; the default is the kernel above until the two have been compared inside the
-// full pipeline on the device).  The live band of a raw-read alignment is mostly narrower than 64 diagonals, so half of a
-// wavefront's lanes idle in the kernel above and every alignment pays for a whole wavefront's issue slots.  Here lanes 0-31 own
-// task 2b and lanes 32-63 task 2b + 1 of workgroup b: a pass covers 32 diagonals, each half has its own furthest-reaching ring
-// in LDS, reads its own 32 bits of the wave ballots and reduces its own maximum; the loops run while either half is busy.  The
-// trace layout is the one the traceback kernels read (bit c of a row = diagonal min_k + 2c), so nothing downstream changes.
-__device__ __forceinline__ int half_max_i32(int v) {  // maximum over the 32 lanes of the caller's half, in every lane of it
-    auto step = [](int x, auto ctrl) {
-        const int y = __builtin_amdgcn_update_dpp(INT_MIN, x, decltype(ctrl)::value, 0xf, 0xf, false);
-        return y > x ? y : x;
-    };
-    v = step(v, std::integral_constant<int, 0xb1>{});   // quad_perm [1,0,3,2]
-    v = step(v, std::integral_constant<int, 0x4e>{});   // quad_perm [2,3,0,1]
-    v = step(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
-    v = step(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane holds its row's maximum
-    const int o = __shfl_xor(v, 16, 64);                // the other row of the half
-    return o > v ? o : v;
-}
-
-__global__ __launch_bounds__(64) void ond_forward_pair_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
-                                                               const uint32_t *__restrict__ pool,
-                                                               const uint32_t *__restrict__ db_pool,
-                                                               uint64_t *__restrict__ trace, int32_t *__restrict__ trace_mink,
-                                                               const int32_t *__restrict__ order, int n_tasks) {
-    __shared__ int32_t v_lds[2][kFastVSize];
-    const int lane = (int)threadIdx.x, h = lane >> 5, l = lane & 31;
-    const int slot = 2 * (int)blockIdx.x + h;
-    const bool have = slot < n_tasks;
-    // `order` lists the tasks by length, so that the two halves of a wavefront finish together; nullptr = as they come
-    const int tid = order ? order[have ? slot : 2 * (int)blockIdx.x] : (have ? slot : 2 * (int)blockIdx.x);
-    const AlnTask T = tasks[tid];
-    int32_t *V = v_lds[h];
-    const uint32_t vmask = (uint32_t)(kFastVSize - 1);
-    for (uint32_t i = (uint32_t)l; i <= vmask; i += 32) V[i] = 0;
-    __syncthreads();
-
-    int min_k = 0, max_k = 0, best_m = -1;
-    int status = ST_NONE, fin_k = 0, fin_x = 0, fin_d = -1;
-    int d_steps = 0, max_band = 0, d = 0;
-    long long cells = 0;
-    bool alive = have;
-    const int q_len = T.q_len, t_len = T.t_len;
-    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
-    const uint32_t *__restrict__ qp = ((T.q_off >> 63) ? db_pool : pool) + (q_off >> 4);
-    const uint32_t *__restrict__ tp = ((T.t_off >> 63) ? db_pool : pool) + (t_off >> 4);
-    const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
-    const uint64_t row0 = T.trace_off, mk0 = T.mink_off;
-    const int hs = 32 * h;  // first lane of this half
-
-    for (;;) {
-        // one edit step of either half that still has one to do (the conditions of the loop head above, lib/align.c:437)
-        bool go = alive && d < T.max_d && max_k - min_k <= T.band;
-        const int band = max_k - min_k;
-        if (go && band > kFastMaxBand) {
-            status = ST_NEED_WIDE;
-            go = false;
-        }
-        if (!go) alive = false;
-        if (__ballot(go) == 0ull) break;
-        const int ncell = band >= 0 ? (band >> 1) + 1 : 0;
-        const int npass = go ? (ncell + 31) >> 5 : 0;
-        const int np0 = __shfl(npass, 0, 64), np1 = __shfl(npass, 32, 64);
-        const int np_max = np0 > np1 ? np0 : np1;
-        if (go) {
-            d_steps++;
-            cells += ncell;
-            max_band = band > max_band ? band : max_band;
-            if (l == 0) trace_mink[mk0 + d] = min_k;
-        }
-        int row_best = -1, x_keep = 0;
-        bool done = false;
-        uint64_t row_acc = 0;
-        for (int ps = 0; ps < np_max; ps++) {
-            const bool pact = go && !done && ps < npass;
-            const int k = min_k + 2 * (ps * 32 + l);
-            const bool act = pact && k <= max_k;
-            int x = 0;
-            bool left = false;
-            if (act) {
-                const int vm = V[(uint32_t)(k - 1) & vmask];
-                const int vp = V[(uint32_t)(k + 1) & vmask];
-                const bool down = (k == min_k) || (k != max_k && vm < vp);  // lib/align.c:443
-                x = down ? vp : vm + 1;
-                left = !down;
-                int y = x - k;
-                for (;;) {  // snake: 16 bases per XOR (lib/align.c:452-455)
-                    int rem = q_len - x;
-                    const int rt = t_len - y;
-                    rem = rt < rem ? rt : rem;
-                    if (rem <= 0) break;
-                    const uint32_t a = fetch16_rel(qp, q_sh + (uint32_t)x);
-                    const uint32_t b = fetch16_rel(tp, t_sh + (uint32_t)y);
-                    const uint32_t diff = a ^ b;
-                    int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
-                    m = m < rem ? m : rem;
-                    x += m;
-                    y += m;
-                    if (m < 16) break;
-                }
-            }
-            const uint32_t lb = (uint32_t)(__ballot(act && left) >> hs);
-            const int y = x - k;
-            const uint32_t fb = (uint32_t)(__ballot(act && x >= q_len && y >= t_len) >> hs);
-            if (pact) {
-                row_acc |= (uint64_t)lb << (32 * (ps & 1));
-                if (((ps & 1) || ps == npass - 1) && l == 0) trace[row0 + (uint64_t)d * kFastRowWords + (uint32_t)(ps >> 1)] = row_acc;
-                if (ps & 1) row_acc = 0;
-            }
-            if (act) {
-                V[(uint32_t)k & vmask] = x;
-                const int m = x + y;
-                row_best = m > row_best ? m : row_best;
-            }
-            if (pact) x_keep = x;  // (a pass run only for the other half must not disturb this half's register copy)
-            const int fl = fb ? __ffs((int)fb) - 1 : 0;
-            const int fx = __shfl(x, hs + fl, 64);
-            if (pact && fb) {  // several diagonals may finish in one step: the smallest k wins (lib/align.c:467-470)
-                // (the row's word may still be pending: the passes that would have completed it are not run)
-                if (!(ps & 1) && ps != npass - 1 && l == 0) trace[row0 + (uint64_t)d * kFastRowWords + (uint32_t)(ps >> 1)] = row_acc;
-                fin_k = min_k + 2 * (ps * 32 + fl);
-                fin_x = fx;
-                fin_d = d;
-                status = ST_FINISHED;
-                done = true;
-            }
-        }
-        if (go && done) alive = false, go = false;
-        const int rb = half_max_i32(row_best);
-        if (go) best_m = rb > best_m ? rb : best_m;
-        __syncthreads();  // V[] of this step visible to every lane
-
-        // band re-centring (lib/align.c:473-489)
-        int new_min = max_k, new_max = min_k;
-        const int thr = best_m - 150;
-        bool found = false;
-        for (int ps = 0; ps < np_max; ps++) {
-            const int k = min_k + 2 * (ps * 32 + l);
-            const bool in = go && !found && ps < npass;
-            const int xv = npass == 1 ? x_keep : (in ? V[(uint32_t)k & vmask] : 0);
-            const bool q = in && k < max_k && (2 * xv - k >= thr);
-            const uint32_t qb = (uint32_t)(__ballot(q) >> hs);
-            if (in && qb) {
-                new_min = min_k + 2 * (ps * 32 + (__ffs((int)qb) - 1));
-                found = true;
-            }
-        }
-        found = false;
-        for (int ps = np_max - 1; ps >= 0; ps--) {
-            const int k = min_k + 2 * (ps * 32 + l);
-            const bool in = go && !found && ps < npass;
-            const int xv = npass == 1 ? x_keep : (in ? V[(uint32_t)k & vmask] : 0);
-            const bool q = in && k <= max_k && k > min_k && (2 * xv - k >= thr);
-            const uint32_t qb = (uint32_t)(__ballot(q) >> hs);
-            if (in && qb) {
-                new_max = min_k + 2 * (ps * 32 + (31 - __clz((int)qb)));
-                found = true;
-            }
-        }
-        if (go) {
-            max_k = new_max + 1;
-            min_k = new_min - 1;
-            d++;
-        }
-        __syncthreads();  // the next step's first reads of V[] come after this step's last ones
-    }
-
-    if (have && l == 0) {
-        AlnOut o;
-        o.status = status;
-        o.d_final = fin_d;
-        o.k_final = fin_k;
-        o.x_final = fin_x;
-        o.y_final = fin_x - fin_k;
-        o.n_cols = 0;
-        o.d_steps = d_steps;
-        o.max_band = max_band;
-        o.cells = cells;
-        outs[tid] = o;
-    }
-}
-
-// K8a, wavefront-per-alignment form (NDGPU_K8A=wave; the default is the lane-per-alignment kernel above until the two have been
-// compared inside the full pipeline on the device).  The walk is one dependent chain per alignment; in the kernel above each link
-// of it is a round trip to HBM / L2 and a wavefront lasts as long as the longest of its 64 chains.  Here a wavefront owns ONE
-// alignment: it stages the next 128 trace rows (move bits + min_k) and the next 1024 bases of both sequences in LDS with
-// coalesced loads, and walks them there -- every lane holds the same walk state, so the loop is uniform and a link costs an LDS
-// broadcast read instead of a memory round trip; lane 0 writes the packed columns.  Same output, bit for bit.
-constexpr int kTbRows = 128;
-constexpr int kTbSeqWords = 64;  // 16 bases each; + 2 words of slack for the unaligned 64-bit fetch
-
-__device__ __forceinline__ uint32_t fetch16_win(const uint32_t *win, uint64_t w0, uint64_t off) {  // off: absolute base offset
-    const uint32_t i = (uint32_t)((off >> 4) - w0), sh = (uint32_t)(off & 15u) * 2u;
-    const uint64_t v = (uint64_t)win[i] | ((uint64_t)win[i + 1] << 32);
-    return (uint32_t)(v >> sh);
-}
-
-__global__ __launch_bounds__(64) void ond_traceback_wave_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
-                                                                 const uint32_t *__restrict__ pool,
-                                                                 const uint32_t *__restrict__ db_pool,
-                                                                 const uint64_t *__restrict__ trace,
-                                                                 const int32_t *__restrict__ trace_mink,
-                                                                 uint32_t *__restrict__ ops, int n_tasks) {
-    __shared__ uint64_t s_tr[kTbRows * kFastRowWords];
-    __shared__ int32_t s_mk[kTbRows];
-    __shared__ uint32_t s_q[kTbSeqWords + 2], s_t[kTbSeqWords + 2];
-    const int gid = (int)blockIdx.x;
-    if (gid >= n_tasks) return;
-    if (outs[gid].status != ST_FINISHED) return;
-    const int lane = (int)threadIdx.x;
-    const AlnTask T = tasks[gid];
-    const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
-    const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
-    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
-    int x = outs[gid].x_final - 1, k = outs[gid].k_final, d = outs[gid].d_final;
-    int gap = 0;
-    uint32_t col = T.ops_cap, acc = 0;
-    uint32_t *W = ops + T.ops_off;
-    bool aborted = false;
-    int d_lo = 0, d_hi = -1;            // trace rows staged: [d_lo, d_hi]
-    uint64_t qw0 = 0, tw0 = 0;          // first staged word of either sequence
-    bool q_ok = false, t_ok = false;
-
-    for (;;) {
-        for (;;) {  // match run, back to front (lib/align.c:502-507), 16 bases per compare
-            const int yy = x - k;
-            const int avail = (x < yy ? x : yy) + 1;
-            if (avail <= 0) break;
-            const int n = avail < 16 ? avail : 16;
-            const uint64_t qa = q_off + (uint64_t)(uint32_t)(x - n + 1), ta = t_off + (uint64_t)(uint32_t)(yy - n + 1);
-            if (!q_ok || (qa >> 4) < qw0) {  // the window ends two words above the current position and reaches 1024 bases down
-                __syncthreads();
-                const uint64_t we = ((q_off + (uint64_t)(uint32_t)x) >> 4) + 2;
-                qw0 = we > (uint64_t)(kTbSeqWords + 2) ? we - (uint64_t)(kTbSeqWords + 2) : 0;
-                for (int i = lane; i < kTbSeqWords + 2; i += 64) s_q[i] = qp[qw0 + (uint64_t)i];
-                q_ok = true;
-                __syncthreads();
-            }
-            if (!t_ok || (ta >> 4) < tw0) {
-                __syncthreads();
-                const uint64_t we = ((t_off + (uint64_t)(uint32_t)yy) >> 4) + 2;
-                tw0 = we > (uint64_t)(kTbSeqWords + 2) ? we - (uint64_t)(kTbSeqWords + 2) : 0;
-                for (int i = lane; i < kTbSeqWords + 2; i += 64) s_t[i] = tp[tw0 + (uint64_t)i];
-                t_ok = true;
-                __syncthreads();
-            }
-            const uint32_t a = fetch16_win(s_q, qw0, qa), b = fetch16_win(s_t, tw0, ta);
-            uint32_t diff = a ^ b;
-            if (n < 16) diff &= (1u << (2 * n)) - 1u;
-            const int m = diff ? n - 1 - ((31 - __builtin_clz(diff)) >> 1) : n;
-            if (m) {
-                int left_to_emit = m;  // match columns are code 0: only the cursor moves
-                while (left_to_emit > 0) {
-                    const uint32_t room = ((col - 1u) & 15u) + 1u;
-                    const uint32_t take = (uint32_t)left_to_emit < room ? (uint32_t)left_to_emit : room;
-                    col -= take;
-                    left_to_emit -= (int)take;
-                    if ((col & 15u) == 0) {
-                        if (lane == 0) W[col >> 4] = acc;
-                        acc = 0;
-                    }
-                }
-                x -= m;
-                gap = 0;
-            }
-            if (m < n) break;
-        }
-        if (x < 0 && x - k < 0) break;
-        bool left;
-        if (x < k) left = true;  // lib/align.c:512: forced query-consuming move
-        else if (x >= 0) {
-            if (d < d_lo || d > d_hi) {
-                __syncthreads();
-                d_hi = d, d_lo = d - kTbRows + 1 > 0 ? d - kTbRows + 1 : 0;
-                const int nr = d_hi - d_lo + 1;
-                for (int i = lane; i < nr * kFastRowWords; i += 64)
-                    s_tr[i] = trace[T.trace_off + (uint64_t)(uint32_t)d_lo * kFastRowWords + (uint64_t)i];
-                for (int i = lane; i < nr; i += 64) s_mk[i] = trace_mink[T.mink_off + (uint64_t)(uint32_t)(d_lo + i)];
-                __syncthreads();
-            }
-            const int idx = (k - s_mk[d - d_lo]) >> 1;
-            left = (s_tr[(d - d_lo) * kFastRowWords + (idx >> 6)] >> (idx & 63)) & 1ull;
-        } else left = false;
-        uint32_t code;
-        int nk, nx;
-        if (left) { nk = k - 1; nx = x - 1; code = 1u; if (x < 0) gap = 260; }
-        else { nk = k + 1; nx = x; code = 2u; if (x - k < 0) gap = 260; }
-        if (gap < 260) {
-            col--;
-            acc |= code << ((col & 15u) * 2u);
-            if ((col & 15u) == 0) {
-                if (lane == 0) W[col >> 4] = acc;
-                acc = 0;
-            }
-        }
-        if (gap++ > 250) {  // lib/align.c:542-545
-            aborted = true;
-            break;
-        }
-        d--;
-        k = nk;
-        x = nx;
-    }
-    if (lane == 0) {
-        if ((col & 15u) != 0) W[col >> 4] = acc;
-        outs[gid].n_cols = aborted ? 2 : (int32_t)(T.ops_cap - col);
-        outs[gid].status = aborted ? ST_GAP_ABORT : ST_ALIGNED;
-    }
-}
-
 }  // namespace
 
-bool ond_forward_pairs() {
-    static const bool pair_form = getenv("NDGPU_K7") && !strcmp(getenv("NDGPU_K7"), "pair");
-    return pair_form;
-}
-
-void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
-                        uint64_t *trace, int32_t *trace_mink,
+void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, uint64_t *trace,
                         int n_tasks, void *stream, const int32_t *order) {
     if (n_tasks <= 0) return;
-    if (ond_forward_pairs()) {
-        hipLaunchKernelGGL(ond_forward_pair_kernel, dim3((unsigned)((n_tasks + 1) / 2)), dim3(64), 0, (hipStream_t)stream, tasks, outs,
-                           pool, db_pool, trace, trace_mink, order, n_tasks);
-        return;
-    }
-    hipLaunchKernelGGL(ond_forward_kernel<false>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs,
-                       pool, db_pool, trace, trace_mink, (int32_t *)nullptr, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(ond_forward_kernel, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
+                       order);
 }
 
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace,
                              int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream) {
     if (n_ids <= 0) return;
-    hipLaunchKernelGGL(ond_forward_kernel<true>, dim3((unsigned)n_ids), dim3(64), 0, (hipStream_t)stream, tasks, outs,
+    hipLaunchKernelGGL(ond_forward_wide_kernel, dim3((unsigned)n_ids), dim3(64), 0, (hipStream_t)stream, tasks, outs,
                        pool, db_pool, trace, trace_mink, vscratch, task_ids);
 }
 
+// task_ids == nullptr: every task of the table, traces in the register path's stream format; otherwise the listed (wide-band)
+// tasks, traces in the wide kernel's row format
 void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                           const uint64_t *trace,
                           const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream) {
     if (n_tasks <= 0) return;
-    static const bool wave_form = getenv("NDGPU_K8A") && !strcmp(getenv("NDGPU_K8A"), "wave");
-    if (wave_form && !task_ids) {  // (the rare wide-band tasks, addressed through task_ids, have wider trace rows: lane kernel)
-        hipLaunchKernelGGL(ond_traceback_wave_kernel, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs, pool,
-                           db_pool, trace, trace_mink, ops, n_tasks);
-        return;
-    }
-    hipLaunchKernelGGL(ond_traceback_kernel, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                       tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
+    if (task_ids)
+        hipLaunchKernelGGL(ond_traceback_kernel<false>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                           tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
+    else
+        hipLaunchKernelGGL(ond_traceback_kernel<true>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                           tasks, outs, pool, db_pool, trace, (const int32_t *)nullptr, ops, task_ids, n_tasks);
 }
 
 }  // namespace ndgpu

@@ -83,7 +83,7 @@ void *pool_alloc(size_t bytes)
 // (and below NDGPU_OVL_POOL_GB if that is set); what comes back beyond it is freed at once.
 static size_t pool_cap()
 {
-	static const size_t cap = getenv("NDGPU_OVL_POOL_GB") ? (size_t)atof(getenv("NDGPU_OVL_POOL_GB")) << 30 : ~(size_t)0;
+	static const size_t cap = getenv("NDGPU_OVL_POOL_GB") ? (size_t)(atof(getenv("NDGPU_OVL_POOL_GB")) * (double)(1ull << 30)) : ~(size_t)0;
 	return cap;
 }
 
@@ -878,6 +878,7 @@ int64_t ndgpu_2bit_index(const uint32_t *w, uint64_t n_words, uint32_t *ids, uin
 	uint64_t p = 0;
 	while (p + 2 <= n_words) {
 		const uint32_t ln = w[p + 1];
+		if (p + 2 + (((uint64_t)ln + 15) >> 4) > n_words) return -1;  // the record's words run past the buffer: truncated / corrupt
 		if (n < cap) ids[n] = w[p], lens[n] = ln, word_off[n] = p + 2;
 		++n;
 		p += 2 + (((uint64_t)ln + 15) >> 4);

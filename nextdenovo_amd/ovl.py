@@ -130,6 +130,8 @@ def read_2bit(path: str):
     w = np.frombuffer(data[2:2 + ((data.size - 2) // 4) * 4].tobytes(), dtype=np.uint32)
     lib = _native()
     n = int(lib.ndgpu_2bit_index(w.ctypes.data, w.size, None, None, None, 0))
+    if n < 0:
+        raise ValueError("%s: truncated or corrupt .2bit file (a record runs past the end of the file)" % path)
     ids, lens, offs = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint64)
     lib.ndgpu_2bit_index(w.ctypes.data, w.size, ids.ctypes.data, lens.ctypes.data, offs.ctypes.data, n)
     return ids, lens, w, offs

@@ -34,7 +34,7 @@ def build(force: bool = False) -> str:
 
 
 def build_overlap(force: bool = False) -> str:
-    return _build(OVL_LIB, OVL_SOURCES, ["-lz"], force)
+    return _build(OVL_LIB, OVL_SOURCES, ["-lz", "-ldl"], force)
 
 
 def _build(lib, sources, libs, force) -> str:

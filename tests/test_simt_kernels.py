@@ -131,8 +131,7 @@ def _forced(env, stride=2):
     ({"NDGPU_K10_FORCE": "repair", "NDGPU_K10_SEG": "300", "SIMT_SCHEDULE": "9"}, "repairs"),
     ({"NDGPU_K10_FORCE": "slow"}, "slow"),                               # the int64 HBM-resident kernel
     ({"NDGPU_K10_FORCE": "large", "NDGPU_K10_SEG": "300", "NDGPU_K10_WARM": "64"}, "segments"),
-    ({"NDGPU_K8A": "wave", "SIMT_SCHEDULE": "1"}, "segments"),      # the wavefront-per-alignment form of the traceback kernel
-    ({"NDGPU_K7": "pair", "SIMT_LANES_DESCENDING": "1"}, "segments"),  # two alignments per wavefront in the forward kernel
+    ({"SIMT_LANES_DESCENDING": "1", "SIMT_SCHEDULE": "1"}, "segments"),  # lane order / schedule must not matter to the register-path K7
 ])
 def test_scoring_forced_paths(simt_lib, env, expect):
     """The scoring kernel's other paths (see tests/test_gpu_k10.py for the same switches on the GPU)."""
