@@ -332,6 +332,9 @@ def main():
         # link read once (pp, ppp, count: 12 B), 20 B of column metadata.
         launches = max(1, st["forward_launches"])
         alg_bytes = (st["seq_bases"] / 4.0 + st["cells"] / 8.0 + 4.0 * st["d_steps"]) / launches
+        # what the kernel is built to move, from this run's own counters: operands once, the trace records it wrote (8 bytes per
+        # edit step up to 56 cells, 16 beyond: `trace_words`), one 48-byte result per task -- to hold against the PMC figure
+        k7_model = (st["seq_bases"] / 4.0 + 8.0 * st["trace_words"] + 48.0 * st["tasks"]) / launches
         avg_ms = st["forward_ms"] / launches
         k7_achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         k10_launches = max(1, st["score_launches"])
@@ -377,17 +380,19 @@ def main():
                          "peak": peak, "unit": "GB/s", "frac": k7_achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_note,
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic and alg_bytes else None,
+                         "modelled_bytes_per_launch": k7_model, "modelled_trace_write_bytes_per_launch": 8.0 * st["trace_words"] / launches,
+                         "modelled_over_algorithmic": k7_model / alg_bytes if alg_bytes else None,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": int(launches),
                          "cells_per_s": st["cells"] / (st["forward_ms"] * 1e-3) if st["forward_ms"] > 0 else 0.0,
-                         "note": "latency-bound (dependent edit steps, ~13 of 64 lanes live), not bandwidth-bound; launch times are "
-                                 "HIP-event times with up to 8 contexts' launches in flight at once",
+                         "note": "latency-bound (dependent edit steps, 33 of 64 lanes live on average), not bandwidth-bound; launch "
+                                 "times are HIP-event times with up to 8 contexts' launches in flight at once",
                          "k10_scoring_dp": {"achieved": k10_achieved, "frac": k10_achieved / peak, "alg_bytes_per_launch": k10_bytes,
                                             "avg_launch_ms": k10_ms, "launches": int(k10_launches),
                                             "segments": int(st["score_segments"]), "repaired_segments": int(st["score_repairs"]),
                                             "piles_through_int64_kernel": int(st["score_slow_piles"]),
                                             "us_per_column_contended": st["score_ms"] * 1e3 / n_cols,
                                             "note": "segment-parallel: a column's cost is throughput (GPU time / columns), no longer a chain"}},
-            "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "max_band", "piles", "tags",
+            "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "trace_words", "max_band", "piles", "tags",
                                             "cells_msa", "links", "path_items", "score_segments", "score_repairs", "score_slow_piles")},
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms")},

@@ -169,6 +169,7 @@ typedef struct {
     uint64_t score_segments;   /* scoring-DP segments (K10) */
     uint64_t score_repairs;    /* of which scored again after a failed boundary check */
     uint64_t score_slow_piles; /* piles scored by the int64 HBM-resident kernel */
+    uint64_t trace_words;      /* 64-bit words of move-bit records K7 wrote (8 bytes per edit step up to 56 cells, 16 beyond) */
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

@@ -108,6 +108,9 @@ uint64_t ndgpu_fastx_pending(const ndgpu_fastx *h);
 void ndgpu_fastx_close(ndgpu_fastx *h);
 
 void ndgpu_ovl_free(void *p);
+/* Why an entry point of this library failed: 1 = out of device memory (release memory, e.g. ndgpu_ovl_trim() and the consensus
+ * library's ndgpu_release_memory(), and call again), 2 = another allocation error, 0 = not an allocation failure.  Cleared by the call. */
+int ndgpu_ovl_last_error(void);
 /* The library keeps freed device blocks cached between calls (at most 1.25 x the most it ever had in use at once, and
  * NDGPU_OVL_POOL_GB if set); this releases them.
  * Returns the bytes released. */

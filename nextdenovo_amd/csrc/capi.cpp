@@ -633,6 +633,7 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->score_segments = s.score_segments;
     o->score_repairs = s.score_repairs;
     o->score_slow_piles = s.score_slow_piles;
+    o->trace_words = s.trace_words;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

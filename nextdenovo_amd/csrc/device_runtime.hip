@@ -393,7 +393,7 @@ RuntimeStats DeviceAligner::total_stats() {
         DeviceAligner &c = *cp;
         const RuntimeStats &s = c.s_->stats;
         t.tasks += s.tasks; t.wide_tasks += s.wide_tasks; t.cells += s.cells; t.d_steps += s.d_steps;
-        t.trace_bits += s.trace_bits; t.columns += s.columns; t.pool_bases += s.pool_bases; t.seq_bases += s.seq_bases;
+        t.trace_bits += s.trace_bits; t.trace_words += s.trace_words; t.columns += s.columns; t.pool_bases += s.pool_bases; t.seq_bases += s.seq_bases;
         t.max_band = s.max_band > t.max_band ? s.max_band : t.max_band;
         t.forward_launches += s.forward_launches; t.forward_ms += s.forward_ms; t.traceback_ms += s.traceback_ms;
         t.tags_ms += s.tags_ms; t.links_ms += s.links_ms; t.score_ms += s.score_ms; t.extract_ms += s.extract_ms;
@@ -672,6 +672,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
         const AlnOut &o = S.h_outs.p[i];
         S.stats.cells += (uint64_t)o.cells;
         S.stats.d_steps += (uint64_t)o.d_steps;
+        S.stats.trace_words += (uint64_t)o.trace_end;
         if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
         if (o.status == ST_ALIGNED) {
             S.stats.trace_bits += (uint64_t)o.cells;
@@ -980,6 +981,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             const AlnOut &o = S.h_outs.p[i];
             S.stats.cells += (uint64_t)o.cells;
             S.stats.d_steps += (uint64_t)o.d_steps;
+            S.stats.trace_words += (uint64_t)o.trace_end;
             if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
             if (o.status == ST_NEED_WIDE) wide.push_back((int32_t)i);
         }

@@ -38,6 +38,7 @@ struct RuntimeStats {
     uint64_t score_segments = 0;   // K10 segments scored
     uint64_t score_repairs = 0;    // of which the stitch kernel scored again (a boundary check failed)
     uint64_t score_slow_piles = 0; // piles that went through the int64 HBM-resident scoring kernel
+    uint64_t trace_words = 0;      // 64-bit words of trace records the register-path forward kernel wrote
 };
 
 // Thrown when a device (or pinned host) allocation fails for lack of memory.  The C ABI catches it, releases the

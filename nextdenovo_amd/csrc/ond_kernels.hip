@@ -397,6 +397,8 @@ __global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__r
         o.d_steps = d_steps;
         o.max_band = max_band;
         o.cells = cells;
+        o.trace_end = 0;
+        o.fin_idx = 0;
         outs[tid] = o;
     }
 }

@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "../../include/ndgpu_overlap.h"
 #include "ovl_device.h"
 #include "ovl_pool.h"
@@ -30,6 +32,7 @@ namespace ndovl {
 
 // ---- caching allocator (ovl_pool.h) ----
 namespace {
+std::atomic<int> g_last_error{0};  // why the last failed entry point failed: 1 = out of device memory, 2 = anything else
 std::mutex g_pool_mu;
 std::multimap<size_t, void*> g_pool_free;        // size class -> block
 std::unordered_map<void*, size_t> g_pool_size;   // live + cached blocks -> size class
@@ -68,6 +71,8 @@ void *pool_alloc(size_t bytes)
 	}
 	if (e != hipSuccess) {
 		fprintf(stderr, "[ndgpu_overlap] hipMalloc of %zu bytes failed: %s\n", c, hipGetErrorString(e));
+		g_last_error = e == hipErrorOutOfMemory ? 1 : 2;
+		(void)hipGetLastError();
 		throw std::runtime_error("hipMalloc");
 	}
 	std::lock_guard<std::mutex> g(g_pool_mu);
@@ -81,6 +86,8 @@ void *pool_alloc(size_t bytes)
 // and a cache that keeps them all ends up owning the whole HBM while the consensus contexts starve.  The cache is therefore
 // bounded by the library's own working set: live + cached bytes stay below 1.25 x the most that was ever live at once
 // (and below NDGPU_OVL_POOL_GB if that is set); what comes back beyond it is freed at once.
+int last_error_take() { return g_last_error.exchange(0); }
+
 static size_t pool_cap()
 {
 	static const size_t cap = getenv("NDGPU_OVL_POOL_GB") ? (size_t)(atof(getenv("NDGPU_OVL_POOL_GB")) * (double)(1ull << 30)) : ~(size_t)0;
@@ -887,6 +894,10 @@ int64_t ndgpu_2bit_index(const uint32_t *w, uint64_t n_words, uint32_t *ids, uin
 }
 
 void ndgpu_ovl_free(void *p) { free(p); }
+
+// 1 if an entry point has failed for lack of device memory since the last call of this function (the caller may free
+// memory and try again), 2 for another allocation error, 0 otherwise; reading it clears it
+int ndgpu_ovl_last_error(void) { return ndovl::last_error_take(); }
 
 // release the device blocks the library keeps cached between calls (returns the bytes released)
 uint64_t ndgpu_ovl_trim(void)

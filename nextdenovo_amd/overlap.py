@@ -137,6 +137,15 @@ def sketch(opt: Opt, rs: ReadSet, rid_is_index=False):
     return _take(lib, x, n, np.uint64), _take(lib, y, n, np.uint64), off
 
 
+def _fail(lib, what):
+    """MemoryError when the library says the call ran out of device memory (the caller may release memory and retry),
+    RuntimeError otherwise."""
+    lib.ndgpu_ovl_last_error.restype = C.c_int
+    if int(lib.ndgpu_ovl_last_error()) == 1:
+        return MemoryError(what + ": out of device memory")
+    return RuntimeError(what)
+
+
 class Index:
     def __init__(self, opt: Opt, rs: ReadSet):
         self.lib = load()
@@ -144,7 +153,7 @@ class Index:
         self.h = self.lib.ndgpu_ovl_index_create(C.byref(opt), len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off),
                                                  _ptr(rs.lens), _ptr(rs.ids))
         if not self.h:
-            raise RuntimeError("ndgpu_ovl_index_create failed: the overlap engine needs a HIP device (no CPU path)")
+            raise _fail(self.lib, "ndgpu_ovl_index_create failed (the overlap engine needs a HIP device: no CPU path)")
 
     def close(self):
         if self.h:
@@ -166,7 +175,7 @@ class Index:
         f = self.opt.mid_occ_frac if frac is None else frac
         m = int(self.lib.ndgpu_ovl_index_mid_occ(self.h, np.float32(f)))
         if m < 0:  # (a threshold of -1 would silently filter every minimizer: no overlaps at all)
-            raise RuntimeError("ndgpu_ovl_index_mid_occ failed (%d): out of device memory?" % m)
+            raise _fail(self.lib, "ndgpu_ovl_index_mid_occ failed (%d)" % m)
         return m
 
     def dump(self):
@@ -183,7 +192,7 @@ class Index:
         n = self.lib.ndgpu_ovl_map(self.h, C.byref(opt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off),
                                    _ptr(rs.lens), _ptr(rs.ids), C.byref(recs))
         if n < 0:
-            raise RuntimeError("ndgpu_ovl_map failed (%d)" % n)
+            raise _fail(self.lib, "ndgpu_ovl_map failed (%d)" % n)
         return _take(self.lib, recs, n, REC)
 
     def map2(self, rs: ReadSet, mid_occ: int, opt: Opt | None = None) -> np.ndarray:
@@ -194,7 +203,7 @@ class Index:
         n = self.lib.ndgpu_ovl_map2(self.h, C.byref(opt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off),
                                     _ptr(rs.lens), _ptr(rs.ids), C.byref(recs))
         if n < 0:
-            raise RuntimeError("ndgpu_ovl_map2 failed (%d)" % n)
+            raise _fail(self.lib, "ndgpu_ovl_map2 failed (%d)" % n)
         return _take(self.lib, recs, n, REC10)
 
     def debug_anchors(self, q: int):

@@ -113,6 +113,8 @@ class Shard:
         finally:
             be.release(i, keep_stats=True)
             self.ovl_stats = getattr(be, "last_stats", None)
+            for key in list(getattr(be, "caches", {})):   # a failed attempt must not leave the indexes of its mirror jobs cached
+                be.release(key)
         self.stats["overlap_s"] += time.perf_counter() - t0
         self.stats["records"] += int(sum(r.size for r in out))
         self.stats["jobs"] += len(out)
@@ -127,8 +129,9 @@ class Shard:
                 api.release_device_memory()   # learned below: on this device the two stages do not fit side by side
             try:
                 files = self.overlaps(i)
-            except RuntimeError:
-                # the overlap stage ran out of device memory: the consensus contexts still hold the buffers of the last call
+            except MemoryError:
+                # the overlap stage ran out of device memory (any other failure -- a bad option, a failed occurrence-threshold
+                # query -- is raised as it is): the consensus contexts still hold the buffers of the last call
                 # (they keep them between calls on purpose).  Hand those back, run the stage once more, and from now on hand
                 # them back before the stage starts instead of finding out halfway through it.
                 if isinstance(self.backend, DeviceBackend) and api.release_device_memory() > 0:

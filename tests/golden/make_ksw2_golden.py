@@ -16,18 +16,22 @@ import ksw_util as K  # noqa: E402
 SEED, COUNT, MAX_LEN = 20260925, 600, 260
 
 
-def main():
-    ref = C.CDLL(K.REF)
-    ps = K.problems(SEED, COUNT, MAX_LEN)
+def write(ref, ps, name):
     res, cig, cig_off = [], [], [0]
     for p in ps:
         r, c = K.call_sse(ref, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
         res.append(r)
         cig.extend(c)
         cig_off.append(len(cig))
-    np.savez_compressed(os.path.join(HERE, "ksw2.npz"), res=np.asarray(res, dtype=np.int64), cigar=np.asarray(cig, dtype=np.uint32),
+    np.savez_compressed(os.path.join(HERE, name), res=np.asarray(res, dtype=np.int64), cigar=np.asarray(cig, dtype=np.uint32),
                         cigar_off=np.asarray(cig_off, dtype=np.int64))
-    print(len(ps), "problems,", len(cig), "cigar operations,", os.path.getsize(os.path.join(HERE, "ksw2.npz")), "bytes")
+    print(name, len(ps), "problems,", len(cig), "cigar operations,", os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
+def main():
+    ref = C.CDLL(K.REF)
+    write(ref, K.problems(SEED, COUNT, MAX_LEN), "ksw2.npz")
+    write(ref, K.mid_problems(), "ksw2_mid.npz")   # targets of 1,025 .. 4,096 bases (the kernel's large LDS tier)
 
 
 if __name__ == "__main__":

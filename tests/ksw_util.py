@@ -172,3 +172,37 @@ def long_problems():
                 q = np.insert(q, i, rng.integers(0, 4, int(rng.integers(1, 4))))
         out.append(dict(q=q.astype(np.uint8), t=t, mat=matrix(2, 4, 1), gaps=(4, 2, 24, 1), w=w, zdrop=zdrop, end_bonus=5, flag=flag))
     return out
+
+
+def mid_problems():
+    """Targets of 1,025 .. 4,096 bases: the device kernel's large LDS tier (11 bytes a target position in 44 KB of dynamic LDS),
+    which neither the short fuzzed problems nor long_problems() reach.  Related sequences at the divergence of raw-read overlaps
+    (gap filling / end extension as mm_align1 hands them over), every flag, banded and unbanded, z-drop on and off."""
+    rng = np.random.default_rng(4099)
+    out = []
+    lens = [1025, 1030, 1100, 1500, 1600, 2047, 2048, 2500, 3000, 3333, 4000, 4080, 4090, 4095, 4096]
+    flags = [0, F_EXTZ_ONLY, F_RIGHT | F_REV_CIGAR, F_APPROX_MAX, F_APPROX_DROP | F_EXTZ_ONLY, F_SCORE_ONLY, F_GENERIC_SC | F_EXTZ_ONLY,
+             F_RIGHT | F_EXTZ_ONLY | F_APPROX_MAX | F_REV_CIGAR]
+    for n, tl in enumerate(lens * 8):
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = t.copy()
+        rate = [0.01, 0.05, 0.12, 0.2][n % 4]
+        for k in range(int(tl * rate)):
+            i = int(rng.integers(0, q.size - 3))
+            r = rng.random()
+            if r < .4:
+                q[i] = (q[i] + 1 + int(rng.integers(0, 3))) % 4
+            elif r < .7:
+                q = np.delete(q, slice(i, i + int(rng.choice([1, 1, 2, 3, 12]))))
+            else:
+                q = np.insert(q, i, rng.integers(0, 4, int(rng.choice([1, 1, 2, 3, 12]))))
+        if n % 7 == 3:
+            q = q[: q.size * 2 // 3]                      # the query ends first: mte / reach_end cases
+        if n % 11 == 5:
+            q[rng.integers(0, q.size, q.size // 50)] = 4   # N bases
+        w = [-1, 751, 200, 50, 10][n % 5]
+        zdrop = [-1, 400, 100][n % 3]
+        gaps = [(4, 2, 24, 1), (6, 2, 26, 1), (5, 4, 56, 1)][(n // 3) % 3]
+        out.append(dict(q=q.astype(np.uint8), t=t, mat=matrix(*[(2, 4, 1), (1, 4, 1)][n % 2]), gaps=gaps, w=w, zdrop=zdrop,
+                        end_bonus=[-1, 0, 5, 50][n % 4], flag=flags[(n // 2) % len(flags)]))
+    return out

@@ -23,6 +23,25 @@ def golden():
     return ps, want
 
 
+def golden_mid():
+    d = np.load(os.path.join(HERE, "golden", "ksw2_mid.npz"))
+    ps = K.mid_problems()
+    want = [(tuple(int(x) for x in d["res"][i]), tuple(int(x) for x in d["cigar"][d["cigar_off"][i]:d["cigar_off"][i + 1]]))
+            for i in range(len(ps))]
+    return ps, want
+
+
+def test_oracle_matches_mid_length_golden_vectors(oracle_lib):
+    """Targets of 1,025 .. 4,096 bases (the device kernel's large LDS tier): the oracle against the compiled reference's vectors."""
+    ps, want = golden_mid()
+    assert min(p["t"].size for p in ps) > 1024 and max(p["t"].size for p in ps) == 4096
+    for i, (p, w) in enumerate(zip(ps, want)):
+        got = K.call_oracle(oracle_lib, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
+        assert got == w, i
+    assert sum(1 for r, _ in want if r[1]) >= 5             # z-dropped
+    assert sum(1 for r, c in want if len(c) > 20) >= 30     # long CIGARs
+
+
 def test_oracle_matches_golden_vectors(oracle_lib):
     ps, want = golden()
     flags = 0

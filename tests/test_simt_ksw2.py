@@ -31,3 +31,8 @@ def test_reference_vectors_one_batch(simt_ovl):
 
 def test_long_targets(simt_ovl, oracle_lib):
     G.check_long(simt_ovl, oracle_lib)
+
+
+def test_large_lds_tier(simt_ovl):
+    """A sample of the 1,025 .. 4,096-base targets (the kernel's large LDS tier) through the interpreter."""
+    G.check_mid(simt_ovl, stride=17)

@@ -9,7 +9,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ksw_util as K  # noqa: E402
-from test_oracle_ksw2 import golden  # noqa: E402
+from test_oracle_ksw2 import golden, golden_mid  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -56,3 +56,19 @@ def test_ksw_long_targets_match_oracle(ovl_lib, oracle_lib, monkeypatch):
     check_long(ovl_lib, oracle_lib)
     monkeypatch.setenv("NDGPU_KSW_SCRATCH_GB", "0.001")   # sub-batches of one or two problems
     check_golden_batch(ovl_lib)
+
+
+def check_mid(lib, stride=1):
+    ps, want = golden_mid()
+    ps, want = ps[::stride], want[::stride]
+    got = K.call_batch(lib, ps)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, i
+    for i in range(0, len(ps), 8 * stride if stride == 1 else 1):   # and through the single-call entry
+        p = ps[i]
+        assert K.call_sse(lib, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"]) == want[i], i
+
+
+def test_ksw_large_lds_tier_matches_reference_vectors(ovl_lib):
+    """Targets of 1,025 .. 4,096 bases run in the kernel's large LDS tier (44 KB of dynamic LDS per wavefront)."""
+    check_mid(ovl_lib)
