@@ -915,7 +915,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_piles.reserve(np);
     S.d_read_pile.reserve(nr);
     S.d_acc.reserve(acc_slots + 1);
-    S.d_tags.reserve(tag_slots + 1);
+    S.d_tags.reserve(tag_slots + 9);  // (K9 reads 32-byte windows: up to 7 tags past a read's last one)
     S.d_colidx.reserve(colidx_slots + 1);
     S.d_cov.reserve(col_slots + 1);
     S.d_inscnt.reserve(col_slots + 1);

@@ -299,31 +299,27 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
         }
     }
     const uint32_t n_chunks = (P.n_acc + 63u) / 64u;
-    // A register-resident read is scanned strictly in tag order (column by column, delta by delta), so its
-    // stream is read once, 16 bytes at a time, and the two previous tags of every tag are simply carried along.
-    uint4 w_tag[kRegChunks];
-    uint32_t w_i[kRegChunks], w_p1[kRegChunks], w_p2[kRegChunks];
+    // A register-resident read is scanned strictly in tag order (column by column, delta by delta), so its stream is read
+    // once, 32 bytes at a time, and the two previous tags of every tag are simply carried along.  Which (column, delta) a tag
+    // belongs to is written in the tag itself, so the column index of the read is consulted once per column block (where the
+    // read's stream enters the block) and not once per column: a lane's loads stay inside one tag stream, and a 128-byte line
+    // of it is asked for four times instead of eight (the lines of 64 lanes x the resident wavefronts do not fit the caches,
+    // and every further request was another trip to HBM: 18 GB of fetches per launch for ~2.6 GB of tables).
+    uint4 w_lo[kRegChunks], w_hi[kRegChunks];
+    uint32_t w_i[kRegChunks], w_p1[kRegChunks], w_p2[kRegChunks], w_pos[kRegChunks];
 #pragma unroll
     for (int ch = 0; ch < kRegChunks; ch++) {
-        w_tag[ch] = make_uint4(0, 0, 0, 0);
+        w_lo[ch] = w_hi[ch] = make_uint4(0, 0, 0, 0);
         w_i[ch] = 0xffffffffu;  // no window yet
         w_p1[ch] = w_p2[ch] = kTagHead;
+        w_pos[ch] = 0xffffffffu;  // next tag of the read: none inside this block
+        const uint32_t t_first = B.col0 > g_ts[ch] ? B.col0 : g_ts[ch];
+        if (t_first < t_end && t_first <= g_te[ch]) w_pos[ch] = g_ci[ch][t_first - g_ts[ch]];
     }
 
     for (uint32_t t = B.col0; t < t_end; t++) {
         const uint32_t width = ms[t];
         uint64_t e = P.ent_off + eb[t];
-        // tag index range of column t in every register-resident read
-        uint32_t c_i0[kRegChunks], c_nx[kRegChunks];
-#pragma unroll
-        for (int ch = 0; ch < kRegChunks; ch++) {
-            c_i0[ch] = 1;
-            c_nx[ch] = 0;
-            if (t >= g_ts[ch] && t <= g_te[ch]) {
-                c_i0[ch] = g_ci[ch][t - g_ts[ch]];
-                c_nx[ch] = t == g_te[ch] ? g_len[ch] : g_ci[ch][t + 1 - g_ts[ch]];
-            }
-        }
         for (uint32_t d = 0; d < width; d++) {
             uint32_t n_cell[6] = {0, 0, 0, 0, 0, 0};  // links collected so far in the six cells of (t, d): the same in every lane
             for (uint32_t chn = 0; chn < n_chunks; chn++) {
@@ -332,27 +328,35 @@ __global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restri
                 uint32_t i0 = 1, nx = 0;
                 const uint32_t *tg = nullptr;
                 if (chn < (uint32_t)kRegChunks) {
+                    const uint32_t key = ((t + 1u) << 8) | d;  // tag >> 3 of a tag of cell row (t, d)
 #pragma unroll
                     for (int ch = 0; ch < kRegChunks; ch++)
                         if ((uint32_t)ch == chn) {
-                            const uint32_t i = c_i0[ch] + d;
-                            if (i < c_nx[ch]) {
+                            const uint32_t i = w_pos[ch];
+                            if (i < g_len[ch]) {
                                 const uint32_t *tp = g_tg[ch];
                                 if (w_i[ch] == 0xffffffffu) {  // first tag of this read inside the column block
                                     if (i > 0) w_p1[ch] = tp[i - 1];
                                     if (i > 1) w_p2[ch] = tp[i - 2];
                                 }
-                                if (w_i[ch] == 0xffffffffu || i - w_i[ch] >= 4u) {
-                                    w_tag[ch] = *reinterpret_cast<const uint4 *>(tp + i);
+                                if (w_i[ch] == 0xffffffffu || i - w_i[ch] >= 8u) {
+                                    w_lo[ch] = *reinterpret_cast<const uint4 *>(tp + i);
+                                    w_hi[ch] = *reinterpret_cast<const uint4 *>(tp + i + 4);
                                     w_i[ch] = i;
                                 }
                                 const uint32_t k = i - w_i[ch];
-                                cur = k == 0 ? w_tag[ch].x : k == 1 ? w_tag[ch].y : k == 2 ? w_tag[ch].z : w_tag[ch].w;
-                                pp = w_p1[ch];
-                                ppp = w_p2[ch];
-                                w_p2[ch] = w_p1[ch];
-                                w_p1[ch] = cur;
-                                has = true;
+                                const uint4 w = k < 4u ? w_lo[ch] : w_hi[ch];
+                                const uint32_t k4 = k & 3u;
+                                const uint32_t c = k4 == 0 ? w.x : k4 == 1 ? w.y : k4 == 2 ? w.z : w.w;
+                                if ((c >> 3) == key) {  // the read's next tag sits in this cell row: consume it
+                                    cur = c;
+                                    pp = w_p1[ch];
+                                    ppp = w_p2[ch];
+                                    w_p2[ch] = w_p1[ch];
+                                    w_p1[ch] = c;
+                                    w_pos[ch] = i + 1;
+                                    has = true;
+                                }
                             }
                         }
                 } else {
