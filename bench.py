@@ -392,10 +392,10 @@ def main():
                                             "piles_through_int64_kernel": int(st["score_slow_piles"]),
                                             "us_per_column_contended": st["score_ms"] * 1e3 / n_cols,
                                             "note": "segment-parallel: a column's cost is throughput (GPU time / columns), no longer a chain"}},
-            "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "trace_words", "max_band", "piles", "tags",
+            "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "trace_words", "lq_rounds", "lq_declined", "max_band", "piles", "tags",
                                             "cells_msa", "links", "path_items", "score_segments", "score_repairs", "score_slow_piles")},
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
-                                                       "backtrack_ms", "extract_ms")},
+                                                       "backtrack_ms", "extract_ms", "lq_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
         }
         if not args.no_overlap:

@@ -170,6 +170,9 @@ typedef struct {
     uint64_t score_repairs;    /* of which scored again after a failed boundary check */
     uint64_t score_slow_piles; /* piles scored by the int64 HBM-resident kernel */
     uint64_t trace_words;      /* 64-bit words of move-bit records K7 wrote (8 bytes per edit step up to 56 cells, 16 beyond) */
+    uint64_t lq_rounds;        /* low-quality-region rounds (pile x round) handed to K12 */
+    uint64_t lq_declined;      /* of which the kernel declined: the host path took them */
+    double lq_ms;              /* HIP-event time of K12 */
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

@@ -26,7 +26,8 @@ class Stats(C.Structure):
                 ("score_ms", C.c_double), ("extract_ms", C.c_double), ("piles", C.c_uint64), ("tags", C.c_uint64),
                 ("cells_msa", C.c_uint64), ("path_items", C.c_uint64), ("links", C.c_uint64),
                 ("score_launches", C.c_uint64), ("backtrack_ms", C.c_double), ("score_segments", C.c_uint64),
-                ("score_repairs", C.c_uint64), ("score_slow_piles", C.c_uint64), ("trace_words", C.c_uint64)]
+                ("score_repairs", C.c_uint64), ("score_slow_piles", C.c_uint64), ("trace_words", C.c_uint64), ("lq_rounds", C.c_uint64), ("lq_declined", C.c_uint64),
+                ("lq_ms", C.c_double)]
 
 
 def lib_path() -> str:

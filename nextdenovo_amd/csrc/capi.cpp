@@ -634,6 +634,9 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->score_repairs = s.score_repairs;
     o->score_slow_piles = s.score_slow_piles;
     o->trace_words = s.trace_words;
+    o->lq_rounds = s.lq_rounds;
+    o->lq_declined = s.lq_declined;
+    o->lq_ms = s.lq_ms;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

@@ -223,6 +223,7 @@ void tags_from_strings(const std::string &t_str, const std::string &q_str, unsig
 struct LqSeq {
     uint16_t order = 0, kscore = 0, len = 0;
     std::string seq;
+    std::vector<uint32_t> packed;  // seq in the device's 2-bit form, made once for both low-quality-region rounds
 };
 
 struct LqRegion {
@@ -449,6 +450,7 @@ class PileImpl {
     int lq_max_dif_len = 0;
     struct LqSlot { int i, j, job; };  // (row, region) -> job index or -1 ('M' fill)
     std::vector<LqSlot> lq_slots;
+    LqRound lq;               // the round as a device request (HipBackend: K12); lq.ok: its result is in lq.lqc
 
     std::string seed_copy;  // DB form, HiFi only: the seed's own bases
 
@@ -505,7 +507,7 @@ class PileImpl {
     }
 
     void collect(std::vector<AlnJob *> &out) {
-        if (phase != PileEngine::LQ_ROUND) return;
+        if (phase != PileEngine::LQ_ROUND || lq.ok) return;
         for (AlnJob &j : jobs) out.push_back(&j);
     }
 
@@ -1137,6 +1139,9 @@ class PileImpl {
         lq_max_aln_length += lq_max_dif_len;
         jobs.clear();
         lq_slots.clear();
+        lq.pieces.clear();
+        lq.lqc.clear();
+        lq.ok = false;
         const int count = (int)regions.size();
         for (int i = 0; i < kLqSeqMax; i++) {
             for (int j = count - 1; j >= 0; j--) {
@@ -1153,17 +1158,37 @@ class PileImpl {
                     job.t = r.sudoseed.c_str();
                     job.t_len = sl;
                     job.hq = prm.read_type == 3;
+                    LqSeq &qs = r.seqs[i + r.indexs];
+                    if (qs.packed.empty() && ql > 0) {
+                        qs.packed.resize(((size_t)ql + 15) / 16);
+                        if (!pack_2bit_lsb(qs.packed.data(), job.q, (size_t)ql)) qs.packed.clear();  // (bytes outside ACGT: packed per call, reported there)
+                    }
+                    job.q_words = qs.packed.empty() ? nullptr : qs.packed.data();
                     slot.job = (int)jobs.size();
                     jobs.push_back(std::move(job));
                 }
                 lq_slots.push_back(slot);
+                lq.pieces.push_back(LqRound::Piece{slot.job, (unsigned)sl});
             }
         }
+        lq.jobs = &jobs;
+        lq.n_regions = (unsigned)(lq.pieces.size() / kLqSeqMax);
+        lq.factor = prm.read_type == 3 ? 4 : 2;
+        lq.qv_factor = prm.read_type == 3 ? 2 : 5;
         phase = PileEngine::LQ_ROUND;
         if (jobs.empty()) after_lq_round();  // nothing to align: still run the round
     }
 
     void after_lq_round() {
+        if (lq.ok) {  // the device ran the round (K12): its walk is the string the host path builds below
+            jobs.clear();
+            lq_slots.clear();
+            std::string lqc;
+            lqc.swap(lq.lqc);
+            lq.ok = false;
+            rewrite_pseudo_seeds(lqc);
+            return;
+        }
         // generate_consensus_trimed: build the 30 linked rows, second MSA, backtrack
         const int count = (int)regions.size();
         size_t link_len = 1;
@@ -1226,8 +1251,13 @@ class PileImpl {
             cur = Pos{c.best_t, c.best_d, c.best_b};
             if (cur.t == -1) break;
         }
+        rewrite_pseudo_seeds(lqc);
+    }
 
-        // iterate_generate_consensus_trimed body (nextcorrect.c:1684-1710)
+    // iterate_generate_consensus_trimed body (nextcorrect.c:1684-1710): the walk's characters (origin first) become the
+    // regions' new pseudo-seeds; then the second round, or the splice
+    void rewrite_pseudo_seeds(const std::string &lqc) {
+        const int count = (int)regions.size();
         int j = count;
         int psed_len = 0;
         lq_max_dif_len = 0;
@@ -1387,6 +1417,7 @@ PileEngine::Phase PileEngine::phase() const { return impl_->phase; }
 MainPile *PileEngine::main_request() { return &impl_->main; }
 ExtractPile *PileEngine::extract_request() { return &impl_->extract; }
 void PileEngine::collect_jobs(std::vector<AlnJob *> &out) { impl_->collect(out); }
+LqRound *PileEngine::lq_request() { return impl_->phase == LQ_ROUND && !impl_->jobs.empty() ? &impl_->lq : nullptr; }
 void PileEngine::advance() { impl_->advance(); }
 ConsensusTrimed *PileEngine::take_result() { return impl_->take(); }
 
@@ -1414,6 +1445,37 @@ void parallel_for(size_t n, int threads, F f) {
 
 HostProf g_prof;
 
+bool pack_2bit_lsb(uint32_t *out, const char *s, size_t n) {
+    static const struct Lut {
+        uint8_t v[256];
+        Lut() {
+            memset(v, 0xff, sizeof(v));
+            v['A'] = 0, v['C'] = 1, v['G'] = 2, v['T'] = 3;  // lib/bseq.c:11-20
+        }
+    } lut;
+    unsigned bad = 0;
+    size_t i = 0, w = 0;
+    for (; i + 16 <= n; w++, i += 16) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 16; b++) {
+            const uint8_t c = lut.v[(unsigned char)s[i + b]];
+            bad |= c;
+            acc |= (uint32_t)(c & 3u) << (2 * b);
+        }
+        out[w] = acc;
+    }
+    if (i < n) {
+        uint32_t acc = 0;
+        for (int b = 0; i + b < n; b++) {
+            const uint8_t c = lut.v[(unsigned char)s[i + b]];
+            bad |= c;
+            acc |= (uint32_t)(c & 3u) << (2 * b);
+        }
+        out[w] = acc;
+    }
+    return (bad & 0x80u) == 0;
+}
+
 static std::atomic<int> g_cores_total(0), g_cores_used(0);
 void CoreGovernor::set_total(int total) { g_cores_total.store(total < 0 ? 0 : total); }
 int CoreGovernor::acquire(int base) {
@@ -1439,17 +1501,23 @@ void run_engines(PileEngine **eng, size_t n, Backend &be, int threads) {
     std::vector<MainPile *> mains;
     std::vector<ExtractPile *> extracts;
     std::vector<AlnJob *> jobs;
-    std::vector<size_t> live;
+    std::vector<LqRound *> lqs;
+    std::vector<size_t> live, in_lq;
     for (;;) {
         mains.clear();
         extracts.clear();
         jobs.clear();
+        lqs.clear();
         live.clear();
+        in_lq.clear();
         for (size_t i = 0; i < n; i++) {
             switch (eng[i]->phase()) {
                 case PileEngine::MAIN: mains.push_back(eng[i]->main_request()); break;
                 case PileEngine::EXTRACT: extracts.push_back(eng[i]->extract_request()); break;
-                case PileEngine::LQ_ROUND: eng[i]->collect_jobs(jobs); break;
+                case PileEngine::LQ_ROUND:
+                    in_lq.push_back(i);
+                    if (LqRound *r = eng[i]->lq_request()) lqs.push_back(r);
+                    break;
                 default: continue;
             }
             live.push_back(i);
@@ -1460,6 +1528,10 @@ void run_engines(PileEngine **eng, size_t n, Backend &be, int threads) {
         uint64_t t1 = now_ns();
         if (!extracts.empty()) be.run_extract(extracts.data(), extracts.size());
         uint64_t t2 = now_ns();
+        // low-quality-region rounds: whole rounds on the backend where it offers that; what it does not take (or declines)
+        // goes the host way -- the alignments as a batch, the second MSA in the engine
+        if (!lqs.empty()) (void)be.run_lq(lqs.data(), lqs.size());
+        for (size_t i : in_lq) eng[i]->collect_jobs(jobs);
         if (!jobs.empty()) be.run_align(jobs.data(), jobs.size());
         uint64_t t3 = now_ns();
         {

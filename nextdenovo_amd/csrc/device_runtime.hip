@@ -225,6 +225,11 @@ struct DeviceAligner::State {
     DevBuf<RegionDev> d_regions;
     DevBuf<char> d_strpool;
     DevBuf<unsigned long long> d_cursor;
+    // low-quality-region rounds (K12)
+    DevBuf<LqPileDev> d_lq_piles;
+    DevBuf<LqPieceDev> d_lq_pieces;
+    DevBuf<uint32_t> d_lq_bpp, d_lq_blink, d_lq_row0, d_lq_cov;
+    DevBuf<char> d_lq_out;
     std::vector<ReadDev> reads;
     std::vector<PileDev> piles;
     hipEvent_t evs[8] = {nullptr};
@@ -343,6 +348,8 @@ DeviceAligner::DeviceAligner() : s_(new State) {
         }
     }
 #define NDGPU_NAME(x) s_->x.name = #x;
+    NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_bpp) NDGPU_NAME(d_lq_blink) NDGPU_NAME(d_lq_row0) NDGPU_NAME(d_lq_cov)
+    NDGPU_NAME(d_lq_out)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
     NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_inscnt) NDGPU_NAME(d_insmax) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
@@ -393,7 +400,7 @@ RuntimeStats DeviceAligner::total_stats() {
         DeviceAligner &c = *cp;
         const RuntimeStats &s = c.s_->stats;
         t.tasks += s.tasks; t.wide_tasks += s.wide_tasks; t.cells += s.cells; t.d_steps += s.d_steps;
-        t.trace_bits += s.trace_bits; t.trace_words += s.trace_words; t.columns += s.columns; t.pool_bases += s.pool_bases; t.seq_bases += s.seq_bases;
+        t.trace_bits += s.trace_bits; t.trace_words += s.trace_words; t.lq_rounds += s.lq_rounds; t.lq_declined += s.lq_declined; t.lq_ms += s.lq_ms; t.columns += s.columns; t.pool_bases += s.pool_bases; t.seq_bases += s.seq_bases;
         t.max_band = s.max_band > t.max_band ? s.max_band : t.max_band;
         t.forward_launches += s.forward_launches; t.forward_ms += s.forward_ms; t.traceback_ms += s.traceback_ms;
         t.tags_ms += s.tags_ms; t.links_ms += s.links_ms; t.score_ms += s.score_ms; t.extract_ms += s.extract_ms;
@@ -443,6 +450,8 @@ void DeviceAligner::release_memory() {
     S.pending.clear();
     S.up_used = S.down_used = 0;
 #define NDGPU_REL(x) S.x.release();
+    NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_bpp) NDGPU_REL(d_lq_blink) NDGPU_REL(d_lq_row0) NDGPU_REL(d_lq_cov)
+    NDGPU_REL(d_lq_out)
     NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
     NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_inscnt) NDGPU_REL(d_insmax) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
@@ -776,6 +785,222 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
         at += take;
     }
     (void)n;
+}
+
+// Low-quality-region rounds of a batch of piles on the device: K7 / K8a over every (row, region) alignment, then K12 (lq_msa:
+// linked pseudo-seed, second MSA, DP, walk) -- the column streams stay in HBM, what comes back is each pile's walk string.
+// A round the kernel declines (r->ok stays false) is left to the caller's host path.
+void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
+    if (n == 0) return;
+    State &S = *s_;
+    std::unique_lock<std::mutex> dbg_lock;
+    if (g_debug_exclusive) dbg_lock = std::unique_lock<std::mutex>(g_dbg_mu);
+    std::lock_guard<std::mutex> lock(S.mu);
+    HIP_CHECK(hipSetDevice(S.device));
+    hipStream_t st = S.stream;
+    const uint64_t tc0 = wall_ns();
+
+    // ---- layout: per round its pieces, tasks (one per piece with a job), sequence words (candidates once each, pseudo-seeds once
+    //      per region) and output regions
+    std::vector<LqPileDev> piles(n);
+    std::vector<LqPieceDev> pieces;
+    std::vector<AlnTask> &tasks = S.tasks;
+    tasks.clear();
+    struct Src {
+        const uint32_t *words;  // packed already, or
+        const char *ascii;
+        uint32_t len;
+        uint64_t word_off;
+    };
+    std::vector<Src> srcs;
+    std::vector<uint8_t> usable(n, 1);
+    uint64_t pool_words = 0, ops_words = 0, cell_rows = 0, col_slots = 0, out_bytes = 0;
+    size_t n_piece_total = 0;
+    for (size_t r = 0; r < n; r++) n_piece_total += rounds[r]->pieces.size();
+    pieces.reserve(n_piece_total);
+    for (size_t r = 0; r < n; r++) {
+        LqRound &R = *rounds[r];
+        R.ok = false;
+        R.lqc.clear();
+        LqPileDev &P = piles[r];
+        memset(&P, 0, sizeof(P));
+        const uint32_t nr = R.n_regions;
+        if (nr == 0 || R.pieces.size() != (size_t)nr * 30u) {
+            usable[r] = 0;
+            continue;
+        }
+        P.first_piece = (uint32_t)pieces.size();
+        P.n_regions = nr;
+        P.factor = R.factor;
+        P.qv_factor = R.qv_factor;
+        uint64_t link_len = 1, ins_cap = 0;
+        std::vector<uint64_t> t_off(nr, ~0ull);  // word offset of every region's pseudo-seed, packed on first use
+        for (uint32_t g = 0; g < nr; g++) link_len += (uint64_t)R.pieces[g].sl + 1;
+        for (size_t k = 0; k < R.pieces.size(); k++) {
+            const LqRound::Piece &pc = R.pieces[k];
+            LqPieceDev d;
+            d.task = -1;
+            d.sl = pc.sl;
+            if (pc.job >= 0) {
+                const AlnJob &j = (*R.jobs)[(size_t)pc.job];
+                const uint32_t g = (uint32_t)(k % nr);
+                AlnTask t;
+                memset(&t, 0, sizeof(t));
+                t.q_len = j.q_len;
+                t.t_len = j.t_len;
+                srcs.push_back(Src{j.q_words, j.q, (uint32_t)j.q_len, pool_words});
+                t.q_off = pool_words * 16;
+                pool_words += ((uint64_t)j.q_len + 15) / 16;
+                if (t_off[g] == ~0ull) {
+                    t_off[g] = pool_words;
+                    srcs.push_back(Src{nullptr, j.t, (uint32_t)j.t_len, pool_words});
+                    pool_words += ((uint64_t)j.t_len + 15) / 16;
+                }
+                t.t_off = t_off[g] * 16;
+                int md, bd;
+                limits_for(j.q_len + j.t_len, j.hq, &md, &bd);
+                t.max_d = md;
+                t.band = bd;
+                t.row_words = kFastRowWords;
+                t.ops_off = ops_words;
+                t.ops_cap = (uint32_t)(j.q_len + j.t_len);
+                ops_words += (uint64_t)(t.ops_cap + 15) / 16 + 1;
+                ins_cap += (uint64_t)j.q_len;
+                d.task = (int32_t)tasks.size();
+                tasks.push_back(t);
+                S.stats.seq_bases += (uint64_t)j.q_len + (uint64_t)j.t_len;
+                S.stats.pool_bases += (uint64_t)j.q_len;
+            }
+            pieces.push_back(d);
+        }
+        if (link_len + ins_cap >= (1ull << 31) || link_len >= (1ull << 20)) {  // beyond the packed tag's column field
+            usable[r] = 0;
+            continue;
+        }
+        P.link_len = (uint32_t)link_len;
+        P.row_cap = (uint32_t)(link_len + ins_cap);
+        P.out_cap = (uint32_t)(2 * link_len + 64);
+        P.cell_off = cell_rows * 6;
+        P.col_off = col_slots;
+        P.out_off = out_bytes;
+        cell_rows += P.row_cap;
+        col_slots += link_len + 1;
+        out_bytes += P.out_cap;
+    }
+    const size_t nt = tasks.size();
+    if (nt == 0) return;
+
+    // ---- sequence words (parallel): memcpy of what is packed already, packing of the rest
+    std::vector<uint32_t> &pool = S.pool;
+    pool.assign(pool_words + 2, 0);  // (+ 2: fetch16 reads one word past the last base)
+    std::atomic<int> bad_any{0};
+    par_ranges(srcs.size(), S.host_threads, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const Src &x = srcs[i];
+            if (x.words) memcpy(pool.data() + x.word_off, x.words, (((size_t)x.len + 15) / 16) * sizeof(uint32_t));
+            else if (!pack_into(pool.data() + x.word_off, x.ascii, x.len)) bad_any = 1;
+        }
+    });
+    if (bad_any.load()) return;  // bytes outside [ACGT]: the host path reports them
+
+    S.d_pool.reserve(pool.size());
+    S.d_tasks.reserve(nt);
+    S.d_outs.reserve(nt);
+    S.d_ops.reserve(ops_words + 2);
+    S.d_lq_piles.reserve(n);
+    S.d_lq_pieces.reserve(pieces.size());
+    S.d_lq_bpp.reserve(cell_rows * 6 + 6);
+    S.d_lq_blink.reserve(cell_rows * 6 + 6);
+    S.d_lq_row0.reserve(col_slots + 1);
+    S.d_lq_cov.reserve(col_slots + 1);
+    S.d_lq_out.reserve(out_bytes + 1);
+
+    // forward / traceback chunks bounded by the trace budget (the column streams of every chunk stay resident)
+    std::vector<size_t> chunk_end;
+    uint64_t max_tw = 0;
+    {
+        uint64_t tw = 0;
+        for (size_t i = 0; i < nt; i++) {
+            const uint64_t need = (uint64_t)tasks[i].max_d * kFastRowWords;
+            if (i && (tw + need) * 8 > S.trace_budget_bytes) {
+                chunk_end.push_back(i);
+                max_tw = std::max(max_tw, tw);
+                tw = 0;
+            }
+            tasks[i].trace_off = tw;
+            tw += need;
+        }
+        chunk_end.push_back(nt);
+        max_tw = std::max(max_tw, tw);
+    }
+    S.d_trace.reserve(max_tw + 2);
+
+    const uint64_t tc1 = wall_ns();
+    S.h2d(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), st);
+    S.h2d(S.d_tasks.p, tasks.data(), nt * sizeof(AlnTask), st);
+    S.h2d(S.d_lq_piles.p, piles.data(), n * sizeof(LqPileDev), st);
+    S.h2d(S.d_lq_pieces.p, pieces.data(), pieces.size() * sizeof(LqPieceDev), st);
+    HIP_CHECK(hipEventRecord(S.evs[0], st));
+    {
+        size_t a = 0;
+        for (size_t b : chunk_end) {
+            NDGPU_DBG(st, "lq: forward / traceback %zu..%zu of %zu tasks", a, b, nt);
+            launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st);
+            launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr, S.d_ops.p, nullptr,
+                                 (int)(b - a), st);
+            a = b;
+        }
+    }
+    HIP_CHECK(hipEventRecord(S.evs[1], st));
+    NDGPU_DBG(st, "lq: msa of %zu piles", n);
+    launch_lq_msa(S.d_lq_piles.p, S.d_lq_pieces.p, S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_pool.p, S.d_lq_bpp.p, S.d_lq_blink.p,
+                  S.d_lq_row0.p, S.d_lq_cov.p, S.d_lq_out.p, (int)n, st);
+    HIP_CHECK(hipEventRecord(S.evs[2], st));
+    S.h_outs.reserve(nt + 1);
+    HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, nt * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
+    std::vector<char> out(out_bytes + 1);
+    S.d2h(piles.data(), S.d_lq_piles.p, n * sizeof(LqPileDev), st);
+    if (out_bytes) S.d2h(out.data(), S.d_lq_out.p, out_bytes, st);
+    S.sync_drain(st);
+    HIP_CHECK(hipGetLastError());
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[0], S.evs[1]));
+    S.stats.forward_ms += ms;  // (K7 + K8a of the rounds, not split)
+    S.stats.forward_launches += chunk_end.size();
+    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[1], S.evs[2]));
+    S.stats.lq_ms += ms;
+    S.stats.tasks += nt;
+    const uint64_t tc2 = wall_ns();
+
+    bool need_wide = false;
+    for (size_t i = 0; i < nt; i++) {
+        const AlnOut &o = S.h_outs.p[i];
+        S.stats.cells += (uint64_t)o.cells;
+        S.stats.d_steps += (uint64_t)o.d_steps;
+        S.stats.trace_words += (uint64_t)o.trace_end;
+        if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
+        if (o.status == ST_ALIGNED) {
+            S.stats.trace_bits += (uint64_t)o.cells;
+            S.stats.columns += (uint64_t)o.n_cols;
+        }
+        if (o.status == ST_NEED_WIDE) need_wide = true;
+    }
+    // (an alignment whose live band left the register path: K12 saw it as unaligned, so its pile must go the host way, where
+    // run_chunk reruns it in the wide kernel; rare enough to send the whole call there)
+    for (size_t r = 0; r < n; r++) {
+        LqRound &R = *rounds[r];
+        S.stats.lq_rounds++;
+        const LqPileDev &P = piles[r];
+        if (!usable[r] || need_wide || P.err != 0) {
+            S.stats.lq_declined++;
+            static const bool trace = getenv("NDGPU_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "[ndgpu trace] K12 declined a pile (code %u): host path\n", usable[r] ? (need_wide ? 1u : P.err) : 9u);
+            continue;
+        }
+        R.lqc.assign(out.data() + P.out_off, P.out_len);
+        R.ok = true;
+    }
+    g_prof.c_pack += tc1 - tc0, g_prof.c_dev += tc2 - tc1, g_prof.c_decode += wall_ns() - tc2, g_prof.c_jobs += nt;
 }
 
 void DeviceAligner::begin_batch() { s_->batch_mu.lock(); }

@@ -1,0 +1,338 @@
+// Low-quality-region rounds on the device (gfx950, wave64).
+//
+// The reference re-assembles every low-quality region of a seed from the pile: <= 30 candidate sequences per region are
+// aligned to the region's pseudo-seed, the regions are joined with 'N' columns into one linked pseudo-seed, and a second,
+// small MSA over these <= 30 rows is scored and walked (generate_consensus_trimed, lib/nextcorrect.c:1538-1669;
+// get_lqseqs_from_align_tags, :1250-1338: six symbols, plain maximum, factor 2 / HiFi 4, origin = the last cell); twice
+// per seed (iterate_generate_consensus_trimed, :1671-1715).  The alignments were on the device already (K7 / K8a); their
+// column streams used to travel to the host, where strings, tags, link lists and the DP were rebuilt per pile -- about 40 %
+// of a correction step's wall time with the device idle.  K12 keeps it here:
+//
+// K12 lq_msa  one wavefront per pile, lanes = rows (<= 30, row order = the reference's first-seen order of links).  The
+//             wavefront walks the linked pseudo-seed column by column; a lane derives its row's next tag on the fly from
+//             the 2-bit column kinds K8a left in HBM and the 2-bit candidate bases (no tag arrays, no strings); per cell row
+//             (column, delta) the six cells' (pp, ppp) links are collected in first-seen order with K9's ballot leader
+//             loop, scored at once (a link's predecessor cell lies in this column or the one before: two column tables in
+//             LDS), every cell's best link chosen with the reference's sequential tie-break, and (best_pp, best_link) written
+//             per cell; lane 0 then walks best_pp from the last cell and emits the consensus characters.  A pile that does
+//             not fit the LDS tables (an insertion run of >= 48 columns, > 384 links in a column) or whose alignments do not
+//             end at both sequence ends is declined (err != 0): the host path (consensus.cpp) takes it.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "nd_device.h"
+
+namespace ndgpu {
+
+namespace {
+
+constexpr int kLqRows = 30;          // LQSEQ_MAX_CAN_COUNT rows of the second MSA (lib/nextcorrect.h)
+constexpr int kLqDeltaCap = 48;      // cell rows per column the LDS tables hold
+constexpr int kLqLinkCap = 384;      // links per column
+constexpr int kLqCellCap = 32;       // links per cell (<= 30 rows)
+
+__device__ __forceinline__ uint32_t lq_op_at(const uint32_t *__restrict__ W, uint32_t col) {
+    return (W[col >> 4] >> ((col & 15u) * 2u)) & 3u;
+}
+__device__ __forceinline__ uint32_t lq_code_at(const uint32_t *__restrict__ pool, uint64_t off) {
+    return (pool[off >> 4] >> ((uint32_t)(off & 15u) * 2u)) & 3u;
+}
+// read code (A0 C1 G2 T3) -> consensus code (A0 T1 G2 C3, lib/nextcorrect.c:52-62)
+__device__ __forceinline__ uint32_t lq_cns_code(uint32_t c) { return (0x1230u >> (c * 4u)) & 7u; }
+
+__global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ piles, const LqPieceDev *__restrict__ pieces,
+                                                     const AlnTask *__restrict__ tasks, const AlnOut *__restrict__ outs,
+                                                     const uint32_t *__restrict__ ops, const uint32_t *__restrict__ pool,
+                                                     uint32_t *__restrict__ cell_bpp, uint32_t *__restrict__ cell_blink,
+                                                     uint32_t *__restrict__ col_row0, uint32_t *__restrict__ col_cov,
+                                                     char *__restrict__ out_chars) {
+    __shared__ uint32_t l_pp[6][kLqCellCap], l_ppp[6][kLqCellCap], l_cnt[6][kLqCellCap];
+    __shared__ uint32_t tab_pp[2][kLqLinkCap];
+    __shared__ int32_t tab_sc[2][kLqLinkCap];
+    __shared__ uint16_t cell_st[2][kLqDeltaCap * 6], cell_n[2][kLqDeltaCap * 6];
+
+    LqPileDev &PD = piles[blockIdx.x];
+    const LqPileDev P = PD;
+    const int lane = (int)threadIdx.x;
+    if (P.link_len == 0) {  // a round the host did not lay out (it takes it itself)
+        if (lane == 0) PD.err = 9u, PD.out_len = 0u;
+        return;
+    }
+    const bool row_ok = lane < kLqRows;
+    const LqPieceDev *__restrict__ my = pieces + P.first_piece + (uint32_t)(row_ok ? lane : 0) * P.n_regions;
+    uint32_t *__restrict__ bpp = cell_bpp + P.cell_off;
+    uint32_t *__restrict__ blink = cell_blink + P.cell_off;
+    uint32_t *__restrict__ row0 = col_row0 + P.col_off;
+    uint32_t *__restrict__ cov_out = col_cov + P.col_off;
+
+    uint32_t err = 0;
+    // the lane's row: current piece
+    bool aligned = false;
+    const uint32_t *W = nullptr;
+    uint32_t col = 0, col_end = 0;
+    uint64_t qo = 0;
+    uint32_t p1 = kTagHead, p2 = kTagHead;  // the row's two previous tags
+    // the word of 16 column kinds / 16 bases the row is reading: a step of the column loop then costs a load only every 16th time
+    // (its latency is the wavefront's: every column waits for the slowest lane)
+    uint32_t ops_wi = 0xffffffffu, ops_w = 0;
+    uint64_t q_wi = ~0ull;
+    uint32_t q_w = 0;
+    auto op_peek = [&]() -> uint32_t {
+        const uint32_t wi = col >> 4;
+        if (wi != ops_wi) {
+            ops_w = W[wi];
+            ops_wi = wi;
+        }
+        return (ops_w >> ((col & 15u) * 2u)) & 3u;
+    };
+    auto q_take = [&]() -> uint32_t {
+        const uint64_t wi = qo >> 4;
+        if (wi != q_wi) {
+            q_w = pool[wi];
+            q_wi = wi;
+        }
+        const uint32_t c = (q_w >> ((uint32_t)(qo & 15u) * 2u)) & 3u;
+        qo++;
+        return lq_cns_code(c);
+    };
+
+    auto load_piece = [&](uint32_t g) {
+        aligned = false;
+        if (!row_ok) return;
+        const LqPieceDev pc = my[g];
+        if (pc.task < 0) return;
+        const AlnOut O = outs[pc.task];
+        if (O.status != ST_ALIGNED || O.n_cols <= 2) return;  // no alignment / the > 250-gap marker: an 'M' row (nextcorrect.c:1601)
+        const AlnTask T = tasks[pc.task];
+        if (O.x_final != T.q_len || O.y_final != T.t_len) {  // (the reference pads the unaligned tails; a finished sweep has none)
+            err = 2;
+            return;
+        }
+        aligned = true;
+        W = ops + T.ops_off;
+        col = T.ops_cap - (uint32_t)O.n_cols;
+        col_end = T.ops_cap;
+        qo = T.q_off & kOffMask;
+        ops_wi = 0xffffffffu;
+        q_wi = ~0ull;
+    };
+
+    for (int i = lane; i < kLqDeltaCap * 6; i += 64) cell_n[0][i] = cell_n[1][i] = 0;
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t row = 0;            // cell rows written so far
+    uint32_t t = 0;              // column
+    int cur_tab = 0;
+    uint32_t used_cur = 0, used_prev = 0;  // cell rows of the current / the other table's last use
+    uint32_t g = 0, c_in = 0;    // region and column inside it; sl_cur == 0xffffffff: the first 'N' column
+    bool sep = true;
+    uint32_t sl_cur = 0;
+    const int32_t factor = P.factor;
+
+    while (t < P.link_len && !__ballot(err != 0)) {
+        // -------- one column
+        if (lane == 0) row0[t] = row;
+        for (uint32_t i = (uint32_t)lane; i < used_cur * 6u; i += 64) cell_n[cur_tab][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t n_tab = 0;      // links in the current column's table
+        uint32_t coverage = 0;
+        uint32_t d = 0;
+        for (;; d++) {
+            // ---- the lane's tag in cell row (t, d), if any
+            bool has = false;
+            uint32_t base = 0;
+            if (d == 0) {
+                has = row_ok;
+                if (sep) base = 5;
+                else if (aligned) {
+                    const uint32_t op = col < col_end ? op_peek() : 1u;
+                    if (op == 1u) err = 3;   // the row has no column for this target base
+                    else {
+                        base = op == 0u ? q_take() : 4u;
+                        col++;
+                    }
+                } else base = 6;
+            } else if (aligned && col < col_end && op_peek() == 1u) {
+                has = true;
+                base = q_take();
+                col++;
+            }
+            if (d > 0 && !__ballot(has)) break;
+            if (d >= (uint32_t)kLqDeltaCap || row >= P.row_cap) {
+                err = 4;
+                break;
+            }
+            const uint32_t cur = tag_pack((int32_t)t, d, base);
+            uint32_t pp = kTagHead, ppp = kTagHead;
+            if (has) {
+                pp = p1;
+                ppp = p2;
+                p2 = p1;
+                p1 = cur;
+            }
+            if (d == 0) coverage = (uint32_t)__popcll(__ballot(has && base != 6u));  // nextcorrect.c:1525
+            const int32_t penalty = factor * (int32_t)coverage;
+            const bool counted = has && base != 6u && (pp & 7u) != 6u;   // update_msa skips 'M' tags (nextcorrect.c:222)
+
+            // ---- links of the six cells, first-seen order (K9's leader loop)
+            uint32_t n_cell[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t bb = 0; bb < 6; bb++) {
+                const bool mine = counted && base == bb;
+                unsigned long long rem = __ballot(mine);
+                uint32_t n0 = 0;
+                while (rem) {
+                    const int ld = __ffsll((long long)rem) - 1;
+                    const uint32_t kp = (uint32_t)__shfl((int)pp, ld, 64);
+                    const uint32_t kpp = (uint32_t)__shfl((int)ppp, ld, 64);
+                    const bool in_rem = (rem >> lane) & 1ull;
+                    const unsigned long long same = __ballot(in_rem && pp == kp && ppp == kpp);
+                    if (lane == ld) {
+                        l_pp[bb][n0] = pp;
+                        l_ppp[bb][n0] = ppp;
+                        l_cnt[bb][n0] = (uint32_t)__popcll(same);
+                    }
+                    n0++;
+                    rem &= ~same;
+                }
+                n_cell[bb] = n0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t n_row = n_cell[0] + n_cell[1] + n_cell[2] + n_cell[3] + n_cell[4] + n_cell[5];
+            if (n_tab + n_row > (uint32_t)kLqLinkCap) {
+                err = 5;
+                break;
+            }
+            // ---- score every link of the row: lane j of cell bb takes link j (nextcorrect.c:1273-1289)
+            uint32_t st_b = n_tab;
+#pragma unroll
+            for (uint32_t bb = 0; bb < 6; bb++) {
+                const uint32_t n = n_cell[bb];
+                if (lane == 0) {
+                    cell_st[cur_tab][d * 6u + bb] = (uint16_t)st_b;
+                    cell_n[cur_tab][d * 6u + bb] = (uint16_t)n;
+                }
+                if ((uint32_t)lane < n) {
+                    const uint32_t mpp = l_pp[bb][lane], mppp = l_ppp[bb][lane];
+                    const int32_t gain = 10 * (int32_t)l_cnt[bb][lane] - penalty;
+                    int32_t sc;
+                    if (mpp == kTagHead) sc = gain;
+                    else {
+                        sc = 0;
+                        const uint32_t pt = (uint32_t)tag_tpos(mpp);
+                        const int tb = pt == t ? cur_tab : cur_tab ^ 1;
+                        if (pt != t && pt + 1u != t) err = 6;  // (every row has a tag in every column: cannot happen)
+                        const uint32_t ci = tag_delta(mpp) * 6u + tag_base(mpp);
+                        if (ci < (uint32_t)kLqDeltaCap * 6u) {
+                            const uint32_t s0 = cell_st[tb][ci], sn = cell_n[tb][ci];
+                            for (uint32_t k = s0; k < s0 + sn; k++)
+                                if (tab_pp[tb][k] == mppp) {
+                                    const int32_t s = tab_sc[tb][k] + gain;
+                                    sc = s > sc ? s : sc;
+                                }
+                        }
+                    }
+                    tab_pp[cur_tab][st_b + (uint32_t)lane] = mpp;
+                    tab_sc[cur_tab][st_b + (uint32_t)lane] = sc;
+                }
+                st_b += n;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- every cell's best link, sequential tie-break (nextcorrect.c:1290-1296): lane bb owns cell bb
+            if (lane < 6) {
+                const uint32_t s0 = cell_st[cur_tab][d * 6u + (uint32_t)lane], n = cell_n[cur_tab][d * 6u + (uint32_t)lane];
+                int32_t best = -10;
+                uint32_t best_pp = kTagHead, best_link = 0;
+                for (uint32_t k = 0; k < n; k++) {
+                    const int32_t sc = tab_sc[cur_tab][s0 + k];
+                    const uint32_t lp = tab_pp[cur_tab][s0 + k];
+                    if (sc > best || (sc == best && (lp & 7u) != 4u)) {
+                        best = sc;
+                        best_pp = lp;
+                        best_link = l_cnt[lane][k];
+                    }
+                }
+                bpp[(uint64_t)row * 6u + (uint32_t)lane] = best_pp;
+                blink[(uint64_t)row * 6u + (uint32_t)lane] = best_link;
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_tab += n_row;
+            row++;
+            // ---- an 'N' column ends a region: the rows move on to their pieces of the next one, whose leading insertions
+            //      hang on this column
+            if (d == 0 && sep) {
+                if (aligned && col != col_end) err = 7;  // columns of the finished piece left over
+                if (g < P.n_regions) {
+                    load_piece(g);
+                    sl_cur = pieces[P.first_piece + g].sl;
+                } else aligned = false;
+            }
+        }
+        if (lane == 0) cov_out[t] = coverage;
+        {  // the tables swap roles
+            const uint32_t u = d < (uint32_t)kLqDeltaCap ? d : (uint32_t)kLqDeltaCap;
+            used_cur = used_prev;
+            used_prev = u;
+            cur_tab ^= 1;
+        }
+        // ---- next column
+        t++;
+        if (sep) {
+            sep = false;
+            c_in = 0;
+            if (sl_cur == 0) {  // an empty pseudo-seed: its closing 'N' follows at once
+                sep = true;
+                g++;
+            }
+        } else if (++c_in == sl_cur) {
+            sep = true;
+            g++;
+        }
+    }
+    const bool failed = __ballot(err != 0) != 0ull;
+    uint32_t out_len = 0;
+    if (!failed && lane == 0) {
+        row0[P.link_len] = row;
+        __threadfence();
+        // ---- the walk (nextcorrect.c:1302-1318): from the last cell along best_pp, one character per non-gap cell
+        char *__restrict__ out = out_chars + P.out_off;
+        uint32_t wt = P.link_len - 1u, wd = row - row0[P.link_len - 1u] - 1u, wb = 5u;
+        const char sym[6] = {'A', 'T', 'G', 'C', '-', 'N'};
+        for (;;) {
+            const uint64_t ci = ((uint64_t)row0[wt] + wd) * 6u + wb;
+            if (wb != 4u) {
+                if (out_len >= P.out_cap) {
+                    err = 8;
+                    break;
+                }
+                const char ch = sym[wb];
+                const bool upper = (int32_t)blink[ci] * P.qv_factor > (int32_t)cov_out[wt] || ch == 'N';
+                out[out_len++] = upper ? ch : (char)(ch + 32);
+            }
+            const uint32_t nx = bpp[ci];
+            if (nx == kTagHead) break;
+            wt = (uint32_t)tag_tpos(nx);
+            wd = tag_delta(nx);
+            wb = tag_base(nx);
+        }
+    }
+    const unsigned long long eb = __ballot(err != 0);
+    const uint32_t e_first = (uint32_t)__shfl((int)err, eb ? __ffsll((long long)eb) - 1 : 0, 64);
+    if (lane == 0) {
+        PD.out_len = out_len;
+        PD.err = e_first;
+    }
+}
+
+}  // namespace
+
+void launch_lq_msa(LqPileDev *piles, const LqPieceDev *pieces, const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops,
+                   const uint32_t *pool, uint32_t *cell_bpp, uint32_t *cell_blink, uint32_t *col_row0, uint32_t *col_cov,
+                   char *out_chars, int n_piles, void *stream) {
+    if (n_piles <= 0) return;
+    hipLaunchKernelGGL(lq_msa_kernel, dim3((unsigned)n_piles), dim3(64), 0, (hipStream_t)stream, piles, pieces, tasks, outs, ops, pool,
+                       cell_bpp, cell_blink, col_row0, col_cov, out_chars);
+}
+
+}  // namespace ndgpu

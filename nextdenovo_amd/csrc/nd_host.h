@@ -38,6 +38,8 @@ struct AlnJob {
     // (ReadDb); when >= 0 nothing is packed or uploaded for that sequence
     int64_t q_dev = -1;
     int64_t t_dev = -1;
+    // optional: q already packed (2 bit per base, 16 bases per word, first base in the low bits: pack_2bit_lsb below)
+    const uint32_t *q_words = nullptr;
     // results
     int status = ALN_NONE;
     int q_used = 0;            // aln_q_len
@@ -89,6 +91,28 @@ struct ExtractPile {
     std::vector<RegionReq> regions;
 };
 
+// One low-quality-region round of a pile (generate_consensus_trimed + get_lqseqs_from_align_tags, lib/nextcorrect.c:1538-1669,
+// 1250-1338) as a device request: align the jobs, link the regions' pseudo-seeds with 'N' columns, second MSA over the
+// <= 30 rows, scoring DP, walk.  A backend that cannot serve it (or declines a pile: ok = false) leaves the round to the host
+// path (run_align on the same jobs + the engine's own MSA).
+struct LqRound {
+    struct Piece {
+        int job;                          // index into *jobs, -1: nothing to align in this (row, region) slot
+        unsigned sl;                      // pseudo-seed length of the region
+    };
+    std::vector<AlnJob> *jobs = nullptr;  // q / q_len / q_words, t / t_len (the region's pseudo-seed), hq
+    std::vector<Piece> pieces;            // row-major: 30 rows x n_regions, regions in the reference's (descending) order
+    unsigned n_regions = 0;
+    int factor = 2, qv_factor = 5;        // lib/nextcorrect.c:1262, 1303
+    // outputs
+    bool ok = false;
+    std::string lqc;                      // the walk's characters, origin first
+};
+
+// ASCII [ACGT]* -> 2 bit per base, 16 bases per word, first base in the low bits (the device's sequence pools); false on any
+// other byte.  out must hold (n + 15) / 16 words.
+bool pack_2bit_lsb(uint32_t *out, const char *s, size_t n);
+
 // Executes the device-side work of a batch of piles.  The product has exactly one
 // implementation (HipBackend, device_runtime.hip); tests plug the CPU oracle here to
 // exercise the host logic without a GPU.
@@ -98,6 +122,8 @@ class Backend {
     virtual void run_main(MainPile **piles, size_t n) = 0;
     virtual void run_extract(ExtractPile **piles, size_t n) = 0;
     virtual void run_align(AlnJob **jobs, size_t n) = 0;
+    // low-quality-region rounds on the backend; false: not offered (every round goes the host way)
+    virtual bool run_lq(LqRound **rounds, size_t n) { (void)rounds; (void)n; return false; }
     virtual void end_batch() = 0;  // releases whatever run_main kept for run_extract
 };
 
@@ -138,7 +164,8 @@ class PileEngine {
     bool done() const { return phase() == DONE; }
     MainPile *main_request();        // valid in MAIN
     ExtractPile *extract_request();  // valid in EXTRACT
-    void collect_jobs(std::vector<AlnJob *> &out);  // LQ_ROUND
+    void collect_jobs(std::vector<AlnJob *> &out);  // LQ_ROUND (host path)
+    LqRound *lq_request();           // LQ_ROUND: the round as one device request (nullptr: nothing to hand over)
     void advance();                  // consume the finished request(s), move on
     ConsensusTrimed *take_result();  // malloc'd, caller frees with free_consensus_trimed
 

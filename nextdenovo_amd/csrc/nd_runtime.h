@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "nd_host.h"
@@ -39,6 +40,9 @@ struct RuntimeStats {
     uint64_t score_repairs = 0;    // of which the stitch kernel scored again (a boundary check failed)
     uint64_t score_slow_piles = 0; // piles that went through the int64 HBM-resident scoring kernel
     uint64_t trace_words = 0;      // 64-bit words of trace records the register-path forward kernel wrote
+    uint64_t lq_rounds = 0;        // low-quality-region rounds (pile x round) handed to K12
+    uint64_t lq_declined = 0;      // of which the kernel declined (host path took them)
+    double lq_ms = 0;              // K12
 };
 
 // Thrown when a device (or pinned host) allocation fails for lack of memory.  The C ABI catches it, releases the
@@ -64,6 +68,7 @@ class DeviceAligner {
     void begin_batch();
     void run_main(MainPile **piles, size_t n);
     void run_extract(ExtractPile **piles, size_t n);
+    void run_lq(LqRound **rounds, size_t n);
     void end_batch();
     // resident read DB: every ndgpu_db handle owns its device copy (upload_db / free_db); a batch names the one its
     // AlnJob::q_dev / t_dev and MainPile::dev_off index into (use_db; nullptr: sequences come with the batch)
@@ -102,6 +107,12 @@ class HipBackend : public Backend {
     void run_main(MainPile **piles, size_t n) override { dev_.run_main(piles, n); }
     void run_extract(ExtractPile **piles, size_t n) override { dev_.run_extract(piles, n); }
     void run_align(AlnJob **jobs, size_t n) override { dev_.align_batch(jobs, n); }
+    bool run_lq(LqRound **rounds, size_t n) override {
+        static const bool host_lq = getenv("NDGPU_LQ_HOST") != nullptr;  // test hook: the host path of the rounds
+        if (host_lq) return false;
+        dev_.run_lq(rounds, n);
+        return true;
+    }
     void end_batch() override { finish(); }
 
   private:

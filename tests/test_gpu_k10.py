@@ -88,6 +88,18 @@ def test_scoring_paths_agree(default_run, env, check):
     assert check(got["stats"]), got["stats"]
 
 
+def test_lq_rounds_host_path_agrees(default_run):
+    """The low-quality-region rounds on the device (K12: every round of the config-2 piles, a handful declined at most) against
+    the host path of the same rounds (NDGPU_LQ_HOST: alignments as a batch, second MSA in the engine)."""
+    st = default_run["stats"]
+    assert st["lq_rounds"] >= 2 * 0.9 * st["piles"] and st["lq_declined"] <= st["lq_rounds"] // 100, st
+    host = _driver({"NDGPU_LQ_HOST": "1"})
+    assert host["stats"]["lq_rounds"] == 0
+    assert host["seeds"] == default_run["seeds"]
+    bad = [i for i, (a, b) in enumerate(zip(host["digests"], default_run["digests"])) if a != b]
+    assert not bad, (len(bad), bad[:5])
+
+
 def test_int64_kernel_agrees(default_run):
     """score_slow (every table in HBM, int64) on an even sample of the same piles incl. the longest seeds."""
     a = _driver({"NDGPU_K10_FORCE": "slow"}, max_piles=160)

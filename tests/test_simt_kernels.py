@@ -113,7 +113,8 @@ for i, p in enumerate(util.load_piles()):
         bad.append(i)
 st = api.Stats()
 lib.ndgpu_get_stats(C.byref(st))
-print(json.dumps(dict(bad=bad, segments=int(st.score_segments), repairs=int(st.score_repairs), slow=int(st.score_slow_piles))))
+print(json.dumps(dict(bad=bad, segments=int(st.score_segments), repairs=int(st.score_repairs), slow=int(st.score_slow_piles),
+                      lq_rounds=int(st.lq_rounds), lq_declined=int(st.lq_declined))))
 """
 
 
@@ -138,6 +139,15 @@ def test_scoring_forced_paths(simt_lib, env, expect):
     r = _forced(env)
     assert r["bad"] == [], r
     assert r[expect] > 0, r
+
+
+def test_lq_rounds_on_the_device_and_on_the_host(simt_lib):
+    """The low-quality-region rounds: K12 takes every round of the golden piles (none declined); with NDGPU_LQ_HOST the same
+    rounds go the host way (alignments as a batch, second MSA in the engine) -- both give the reference's records."""
+    dev = _forced({}, stride=1)
+    assert dev["bad"] == [] and dev["lq_rounds"] >= 10 and dev["lq_declined"] == 0, dev
+    host = _forced({"NDGPU_LQ_HOST": "1", "SIMT_SCHEDULE": "1"}, stride=1)
+    assert host["bad"] == [] and host["lq_rounds"] == 0, host
 
 
 def _synth_set(gsize, mu, sigma, seed, depth=30, profile="ont"):
