@@ -59,6 +59,9 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
         if (lane == 0) PD.err = 9u, PD.out_len = 0u;
         return;
     }
+    // one wavefront per pile and every column waits for the one before: the launch lasts as long as its longest pile, so these
+    // wavefronts ask the SIMD's arbiter for priority over the other contexts' throughput kernels
+    __builtin_amdgcn_s_setprio(3);
     const bool row_ok = lane < kLqRows;
     const LqPieceDev *__restrict__ my = pieces + P.first_piece + (uint32_t)(row_ok ? lane : 0) * P.n_regions;
     uint32_t *__restrict__ bpp = cell_bpp + P.cell_off;
@@ -175,68 +178,75 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
             const int32_t penalty = factor * (int32_t)coverage;
             const bool counted = has && base != 6u && (pp & 7u) != 6u;   // update_msa skips 'M' tags (nextcorrect.c:222)
 
-            // ---- links of the six cells, first-seen order (K9's leader loop)
-            uint32_t n_cell[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (uint32_t bb = 0; bb < 6; bb++) {
-                const bool mine = counted && base == bb;
-                unsigned long long rem = __ballot(mine);
-                uint32_t n0 = 0;
+            // ---- links of the six cells, first-seen order (K9's leader loop, all six cells in one pass: a link is (base, pp,
+            //      ppp), the earliest row that carries an unseen one leads, its cell's list grows by one)
+            unsigned long long cnt6 = 0;  // links per cell so far, 8 bits each (the same in every lane)
+            {
+                unsigned long long rem = __ballot(counted);
                 while (rem) {
                     const int ld = __ffsll((long long)rem) - 1;
-                    const uint32_t kp = (uint32_t)__shfl((int)pp, ld, 64);
-                    const uint32_t kpp = (uint32_t)__shfl((int)ppp, ld, 64);
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)base, ld);
+                    const uint32_t kp = (uint32_t)__builtin_amdgcn_readlane((int)pp, ld);
+                    const uint32_t kpp = (uint32_t)__builtin_amdgcn_readlane((int)ppp, ld);
                     const bool in_rem = (rem >> lane) & 1ull;
-                    const unsigned long long same = __ballot(in_rem && pp == kp && ppp == kpp);
+                    const unsigned long long same = __ballot(in_rem && base == kb && pp == kp && ppp == kpp);
+                    const uint32_t n0 = (uint32_t)(cnt6 >> (8u * kb)) & 0xffu;
                     if (lane == ld) {
-                        l_pp[bb][n0] = pp;
-                        l_ppp[bb][n0] = ppp;
-                        l_cnt[bb][n0] = (uint32_t)__popcll(same);
+                        l_pp[kb][n0] = kp;
+                        l_ppp[kb][n0] = kpp;
+                        l_cnt[kb][n0] = (uint32_t)__popcll(same);
                     }
-                    n0++;
+                    cnt6 += 1ull << (8u * kb);
                     rem &= ~same;
                 }
-                n_cell[bb] = n0;
             }
             __builtin_amdgcn_wave_barrier();
-            uint32_t n_row = n_cell[0] + n_cell[1] + n_cell[2] + n_cell[3] + n_cell[4] + n_cell[5];
+            uint32_t n_cell[6], st_cell[6];
+            uint32_t n_row = 0;
+#pragma unroll
+            for (uint32_t bb = 0; bb < 6; bb++) {
+                n_cell[bb] = (uint32_t)(cnt6 >> (8u * bb)) & 0xffu;
+                st_cell[bb] = n_row;
+                n_row += n_cell[bb];
+            }
             if (n_tab + n_row > (uint32_t)kLqLinkCap) {
                 err = 5;
                 break;
             }
-            // ---- score every link of the row: lane j of cell bb takes link j (nextcorrect.c:1273-1289)
-            uint32_t st_b = n_tab;
-#pragma unroll
-            for (uint32_t bb = 0; bb < 6; bb++) {
-                const uint32_t n = n_cell[bb];
-                if (lane == 0) {
-                    cell_st[cur_tab][d * 6u + bb] = (uint16_t)st_b;
-                    cell_n[cur_tab][d * 6u + bb] = (uint16_t)n;
-                }
-                if ((uint32_t)lane < n) {
-                    const uint32_t mpp = l_pp[bb][lane], mppp = l_ppp[bb][lane];
-                    const int32_t gain = 10 * (int32_t)l_cnt[bb][lane] - penalty;
-                    int32_t sc;
-                    if (mpp == kTagHead) sc = gain;
-                    else {
-                        sc = 0;
-                        const uint32_t pt = (uint32_t)tag_tpos(mpp);
-                        const int tb = pt == t ? cur_tab : cur_tab ^ 1;
-                        if (pt != t && pt + 1u != t) err = 6;  // (every row has a tag in every column: cannot happen)
-                        const uint32_t ci = tag_delta(mpp) * 6u + tag_base(mpp);
-                        if (ci < (uint32_t)kLqDeltaCap * 6u) {
-                            const uint32_t s0 = cell_st[tb][ci], sn = cell_n[tb][ci];
-                            for (uint32_t k = s0; k < s0 + sn; k++)
-                                if (tab_pp[tb][k] == mppp) {
-                                    const int32_t s = tab_sc[tb][k] + gain;
-                                    sc = s > sc ? s : sc;
-                                }
-                        }
+            // ---- score every link of the row (nextcorrect.c:1273-1289): lane j takes the row's j-th link (cells in order)
+            if (lane < 6) {
+                cell_st[cur_tab][d * 6u + (uint32_t)lane] = (uint16_t)(n_tab + (lane == 0 ? st_cell[0] : lane == 1 ? st_cell[1] : lane == 2 ? st_cell[2]
+                                                                                : lane == 3 ? st_cell[3] : lane == 4 ? st_cell[4] : st_cell[5]));
+                cell_n[cur_tab][d * 6u + (uint32_t)lane] = (uint16_t)(lane == 0 ? n_cell[0] : lane == 1 ? n_cell[1] : lane == 2 ? n_cell[2]
+                                                                     : lane == 3 ? n_cell[3] : lane == 4 ? n_cell[4] : n_cell[5]);
+            }
+            if ((uint32_t)lane < n_row) {
+                const uint32_t j = (uint32_t)lane;
+                const uint32_t bb = (j >= st_cell[1]) + (j >= st_cell[2]) + (j >= st_cell[3]) + (j >= st_cell[4]) + (j >= st_cell[5]);
+                // (an empty cell shares its start with the next one: the comparisons step over it)
+                const uint32_t k = j - (bb == 0 ? st_cell[0] : bb == 1 ? st_cell[1] : bb == 2 ? st_cell[2] : bb == 3 ? st_cell[3]
+                                                 : bb == 4 ? st_cell[4] : st_cell[5]);
+                const uint32_t mpp = l_pp[bb][k], mppp = l_ppp[bb][k];
+                const int32_t gain = 10 * (int32_t)l_cnt[bb][k] - penalty;
+                int32_t sc;
+                if (mpp == kTagHead) sc = gain;
+                else {
+                    sc = 0;
+                    const uint32_t pt = (uint32_t)tag_tpos(mpp);
+                    const int tb = pt == t ? cur_tab : cur_tab ^ 1;
+                    if (pt != t && pt + 1u != t) err = 6;  // (every row has a tag in every column: cannot happen)
+                    const uint32_t ci = tag_delta(mpp) * 6u + tag_base(mpp);
+                    if (ci < (uint32_t)kLqDeltaCap * 6u) {
+                        const uint32_t s0 = cell_st[tb][ci], sn = cell_n[tb][ci];
+                        for (uint32_t q = s0; q < s0 + sn; q++)
+                            if (tab_pp[tb][q] == mppp) {
+                                const int32_t s2 = tab_sc[tb][q] + gain;
+                                sc = s2 > sc ? s2 : sc;
+                            }
                     }
-                    tab_pp[cur_tab][st_b + (uint32_t)lane] = mpp;
-                    tab_sc[cur_tab][st_b + (uint32_t)lane] = sc;
                 }
-                st_b += n;
+                tab_pp[cur_tab][n_tab + j] = mpp;
+                tab_sc[cur_tab][n_tab + j] = sc;
             }
             __builtin_amdgcn_wave_barrier();
             // ---- every cell's best link, sequential tie-break (nextcorrect.c:1290-1296): lane bb owns cell bb
