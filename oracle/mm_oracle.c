@@ -341,7 +341,7 @@ int64_t nd_mm_seeds(const nd_mm_index *ix, const nd_mm_opt *opt, const char *qna
 			int32_t rpos = (int32_t)((uint32_t)r >> 1);
 			int is_self = 0;
 			nd_mm128 *p;
-			if (opt->no_diag || opt->no_dual) {
+			if (qname && (opt->no_diag || opt->no_dual)) { /* skip_seed (map.c:126-148) looks at names only when there is one */
 				int cmp = strcmp(qname, ix->name[rid]);
 				if (opt->no_diag && cmp == 0 && (int)ix->len[rid] == qlen) {
 					if ((uint32_t)r >> 1 == q_pos >> 1) continue;
@@ -590,16 +590,27 @@ int nd_mm_map_read(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uin
 	return map_read_impl(ix, opt, mid_occ, qid, qcodes, qlen, regs, reg_cap, 0);
 }
 
+static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, const char *qname, const uint8_t *qcodes, int qlen,
+                          nd_mm_reg *regs, int reg_cap, int mode3);
+
 static int map_read_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
                          nd_mm_reg *regs, int reg_cap, int mode3)
 {
 	char qname[12];
+	sprintf(qname, "%u", qid);
+	return map_named_impl(ix, opt, mid_occ, qname, qcodes, qlen, regs, reg_cap, mode3);
+}
+
+/* qname == NULL: mm_map(mi, len, seq, &n, b, opt, 0) as the re-alignment of --step 2 calls it (map.c:1052, 1088): no name-based
+ * seed skipping, the hit-order hash without the name term */
+static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, const char *qname, const uint8_t *qcodes, int qlen,
+                          nd_mm_reg *regs, int reg_cap, int mode3)
+{
 	nd_mm128 *mv, *a;
 	uint64_t *u;
 	int64_t n_mv, n_a = 0, i, n_b;
 	int n_u, n;
 	if (qlen <= 0) return 0;
-	sprintf(qname, "%u", qid);
 	mv = (nd_mm128*)malloc(sizeof(nd_mm128) * ((size_t)qlen + 1));
 	n_mv = nd_mm_sketch(qcodes, qlen, opt->w, opt->k, 0, opt->hpc, mv);
 	for (i = 0; i < n_mv; ++i) {
@@ -806,10 +817,168 @@ static int put_record10(uint8_t *out, const nd_s2_ovl *o, uint32_t *prev)
  * hits of the same target count only when they are nearly as long), then filtered by length / identity / minimum block length
  * and by the dovetail / contained filter whose state `s2_state` (nd_s2_new) lives for the whole run.  The caller writes the
  * 00 FF header (init_ovl_mode, lib/ovl.c:70-75) and, at the end, the .bl table (nd_s2_out_bl). */
-int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, float mid_occ_frac, int mid_occ_fixed,
-                          int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
-                          int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
-                          uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io, void *s2_state)
+static int cmp_reg_rid(const void *a, const void *b) { return ((const nd_mm_reg*)a)->rid - ((const nd_mm_reg*)b)->rid; } /* cmpfunc_nextdenovo, map.c:793 */
+
+/* glibc's qsort is a merge sort (stable) whenever it can get its temporary buffer, which for these arrays it always can: the
+ * order the reference's qsort(reg_new, ..., cmpfunc_nextdenovo) leaves among equal rids is the order they had */
+static void sort_regs_by_rid(nd_mm_reg *r, int n)
+{
+	nd_mm_reg *t;
+	int w, i;
+	if (n < 2) return;
+	t = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * n);
+	for (w = 1; w < n; w <<= 1) {
+		for (i = 0; i < n; i += 2 * w) {
+			int a = i, am = i + w < n ? i + w : n, b = am, bm = i + 2 * w < n ? i + 2 * w : n, k = i;
+			while (a < am && b < bm) t[k++] = cmp_reg_rid(&r[b], &r[a]) < 0 ? r[b++] : r[a++];
+			while (a < am) t[k++] = r[a++];
+			while (b < bm) t[k++] = r[b++];
+		}
+		memcpy(r, t, sizeof(nd_mm_reg) * n);
+	}
+	free(t);
+}
+
+/* update_reg_nextdenovo (map.c:823-877): the hits of one batch of candidate targets (reg_new, sorted by their number in the
+ * batch) replace the marked hits reg[s..e) of the query; returns how many of them say the query is contained */
+static int update_regs(nd_mm_reg *reg_new, int n_reg_new, nd_mm_reg *reg, int s, int e, int t_l, const uint32_t *batch_len,
+                       int32_t maxhan1, int32_t maxhan2)
+{
+	int i, c, t, l, pi;
+	uint32_t alnlen;
+	for (i = c = 0; s < e; s++) {
+		nd_mm_reg *r = &reg[s];
+		if (r->mlen != 2) continue;
+		for (l = -1, pi = i, alnlen = 0, t = 0; i < n_reg_new && t < 10; i++) {
+			nd_mm_reg *rn = &reg_new[i];
+			if (rn->rid == r->blen) {
+				if (l == -1) l = i, alnlen = (uint32_t)(reg_new[i].blen * 0.8);
+				if ((uint32_t)rn->blen >= alnlen && dovetail_class(rn->rev, (uint32_t)rn->qs, (uint32_t)rn->qe, (uint32_t)t_l, (uint32_t)rn->rs,
+				                                                   (uint32_t)rn->re, batch_len[rn->rid], maxhan1, maxhan2)) {
+					l = i;
+					break;
+				}
+				t++;
+				if ((uint32_t)rn->qs <= (uint32_t)maxhan2 && (uint32_t)rn->qe + (uint32_t)maxhan2 >= (uint32_t)t_l) {
+					l = i;
+					c++;
+					break;
+				}
+			} else if (l >= 0) {
+				i--;
+				break;
+			}
+		}
+		if (l >= 0) {
+			const nd_mm_reg *rn = &reg_new[l];
+			r->rev = rn->rev, r->qs = rn->qs, r->qe = rn->qe, r->rs = rn->rs, r->re = rn->re, r->mlen = rn->mlen, r->blen = rn->blen;
+		} else i = pi;
+	}
+	return c;
+}
+
+/* The re-alignment of `--step 2` (worker_for, map.c:1031-1126; --mode 2 is what the pipeline runs: options.c:56, nextDenovo:361-364).
+ * Every hit the marking left with mlen == 2 is mapped again with the short k-mer sketch (kn, wn: main.c:197):
+ *   fewer than 200 candidates: the QUERY read becomes a one-read index (mm_idx_str_nextdenovo3) and every candidate target is
+ *     mapped against it (mm_map, no name); of its first ten hits the first one nearly as long as the best that passes
+ *     check_realign_nextdenovo -- else the best -- replaces the marked hit, query and target coordinates swapped back;
+ *   200 or more: the candidates are indexed cn at a time (mm_idx_str_nextdenovo2 / mm_idx_post_nextdenovo), the query is mapped
+ *     against each batch, the hits are sorted by their target's number in the batch and update_reg_nextdenovo picks per target.
+ * Two hits that say "the query is contained" (MAX_CON) end it.  `c` comes in from the marking. */
+static int64_t g_s2_one_read_index, g_s2_batched; /* queries re-aligned either way (test instrumentation) */
+void nd_mm_step2_counters(int64_t out[2]) { out[0] = g_s2_one_read_index, out[1] = g_s2_batched; g_s2_one_read_index = g_s2_batched = 0; }
+
+static void realign_mode2(const nd_mm_index *ix, const nd_mm_opt *opt, int kn, int wn, int cn, int mid_occ, const uint8_t *tcodes,
+                          const uint64_t *toff, const uint8_t *q, int ql, nd_mm_reg *regs, int n_regs, int seq_index, int c)
+{
+	nd_mm_opt mo = *opt;
+	int k, reg_cap = 1 << 14;
+	nd_mm_reg *rn = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * reg_cap);
+	mo.k = kn, mo.w = wn;
+	if (seq_index < 200) g_s2_one_read_index++; else g_s2_batched++;
+	if (seq_index < 200) {
+		const uint64_t off0 = 0;
+		const uint32_t len0 = (uint32_t)ql, id0 = 0;
+		nd_mm_index *mi = nd_mm_index_build(1, q, &off0, &len0, &id0, wn, kn, opt->hpc);
+		for (k = 0; k < n_regs; ++k) {
+			nd_mm_reg *r = &regs[k];
+			int n, l;
+			uint32_t alnlen, tl;
+			if (r->mlen != 2) continue;
+			tl = ix->len[r->rid];
+			n = map_named_impl(mi, &mo, mid_occ, 0, tcodes + toff[r->rid], (int)tl, rn, reg_cap, 0);
+			if (n < 0) {
+				reg_cap = -n + 1024;
+				rn = (nd_mm_reg*)realloc(rn, sizeof(nd_mm_reg) * reg_cap);
+				n = map_named_impl(mi, &mo, mid_occ, 0, tcodes + toff[r->rid], (int)tl, rn, reg_cap, 0);
+			}
+			if (n <= 0) continue; /* mm_map returned no hits (NULL): the marked hit stays as it is */
+			alnlen = (uint32_t)(rn[0].blen * 0.8);
+			for (l = 0; l < n && l < 10; l++)
+				if ((uint32_t)rn[l].blen >= alnlen && dovetail_class(rn[l].rev, (uint32_t)rn[l].qs, (uint32_t)rn[l].qe, tl, (uint32_t)rn[l].rs,
+				                                                     (uint32_t)rn[l].re, (uint32_t)ql, opt->maxhan1, opt->maxhan2)) break;
+			if (l == 10 || l == n) l = 0;
+			{
+				const int32_t rid = r->rid;
+				*r = rn[l];
+				r->qs = rn[l].rs, r->qe = rn[l].re, r->rs = rn[l].qs, r->re = rn[l].qe, r->rid = rid;
+			}
+			if ((uint32_t)r->qs <= (uint32_t)opt->maxhan2 && (uint32_t)r->qe + (uint32_t)opt->maxhan2 >= (uint32_t)ql)
+				if (++c >= 2) break;
+		}
+		nd_mm_index_free(mi);
+	} else {
+		const int per = (int)((float)seq_index / ((seq_index + cn - 1) / cn) + 0.999);
+		uint8_t *bc = 0;
+		uint64_t *boff = (uint64_t*)malloc(8 * (cn + 1));
+		uint32_t *blen = (uint32_t*)malloc(4 * (cn + 1)), *bid = (uint32_t*)malloc(4 * (cn + 1));
+		uint64_t bc_cap = 0, bc_n = 0;
+		int tp = 0, si = 0, stop = 0;
+		for (k = 0; k < n_regs && !stop; ++k) {
+			nd_mm_reg *r = &regs[k];
+			uint32_t tl;
+			if (r->mlen != 2) continue;
+			r->blen = si;
+			tl = ix->len[r->rid];
+			if (bc_n + tl > bc_cap) bc_cap = (bc_n + tl) * 2, bc = (uint8_t*)realloc(bc, bc_cap);
+			memcpy(bc + bc_n, tcodes + toff[r->rid], tl);
+			boff[si] = bc_n, blen[si] = tl, bid[si] = (uint32_t)si, bc_n += tl;
+			if (++si >= per) {
+				nd_mm_index *mi = nd_mm_index_build(si, bc, boff, blen, bid, wn, kn, opt->hpc);
+				int n = map_named_impl(mi, &mo, mid_occ, 0, q, ql, rn, reg_cap, 0);
+				if (n < 0) {
+					reg_cap = -n + 1024;
+					rn = (nd_mm_reg*)realloc(rn, sizeof(nd_mm_reg) * reg_cap);
+					n = map_named_impl(mi, &mo, mid_occ, 0, q, ql, rn, reg_cap, 0);
+				}
+				sort_regs_by_rid(rn, n);
+				c += update_regs(rn, n, regs, tp, k + 1, ql, blen, opt->maxhan1, opt->maxhan2);
+				nd_mm_index_free(mi);
+				si = 0, bc_n = 0, tp = k + 1;
+				if (c >= 2) stop = 1;
+			}
+		}
+		if (c < 2 && si) {
+			nd_mm_index *mi = nd_mm_index_build(si, bc, boff, blen, bid, wn, kn, opt->hpc);
+			int n = map_named_impl(mi, &mo, mid_occ, 0, q, ql, rn, reg_cap, 0);
+			if (n < 0) {
+				reg_cap = -n + 1024;
+				rn = (nd_mm_reg*)realloc(rn, sizeof(nd_mm_reg) * reg_cap);
+				n = map_named_impl(mi, &mo, mid_occ, 0, q, ql, rn, reg_cap, 0);
+			}
+			sort_regs_by_rid(rn, n);
+			update_regs(rn, n, regs, tp, n_regs, ql, blen, opt->maxhan1, opt->maxhan2);
+			nd_mm_index_free(mi);
+		}
+		free(bc); free(boff); free(blen); free(bid);
+	}
+	free(rn);
+}
+
+int64_t nd_mm_step2(const nd_mm_opt *opt, int mode, int kn, int wn, int cn, float minide, int32_t minmatch, float mid_occ_frac, int mid_occ_fixed,
+                    int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
+                    int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
+                    uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io, void *s2_state)
 {
 	nd_mm_index *ix = nd_mm_index_build(n_t, tcodes, toff, tlen, tids, opt->w, opt->k, opt->hpc);
 	int mid_occ = mid_occ_fixed > 0 ? mid_occ_fixed : nd_mm_index_mid_occ(ix, mid_occ_frac);
@@ -822,7 +991,7 @@ int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, 
 	if (mid_occ_out) *mid_occ_out = mid_occ;
 	for (i = 0; i < n_q; ++i) {
 		const uint32_t ql = qlen[i];
-		int n_regs = map_read_impl(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)ql, regs, reg_cap, 0), c = 0;
+		int n_regs = map_read_impl(ix, opt, mid_occ, qids[i], qcodes + qoff[i], (int)ql, regs, reg_cap, 0), c = 0, seq_index = 0;
 		if (n_regs < 0) {
 			reg_cap = -n_regs + 1024;
 			regs = (nd_mm_reg*)realloc(regs, sizeof(nd_mm_reg) * reg_cap);
@@ -840,7 +1009,8 @@ int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, 
 			if (r->qe - r->qs >= opt->minlen && tp >= r->blen * minide && tp >= (uint32_t)minmatch) {
 				if (dovetail_class(r->rev, (uint32_t)r->qs, (uint32_t)r->qe, ql, (uint32_t)r->rs, (uint32_t)r->re, tl, opt->maxhan1, 0)) {
 					if (head->mlen == 3) c--;
-					head->mlen = (int32_t)tp; /* --mode 0: the match count itself (a re-alignment mode would mark it 2) */
+					head->mlen = mode ? 2 : (int32_t)tp; /* --mode 0: the match count itself; a re-alignment mode marks the candidate */
+					seq_index++;
 				} else if ((uint32_t)r->qs <= (uint32_t)opt->maxhan2 && (uint32_t)r->qe + (uint32_t)opt->maxhan2 >= ql) {
 					head->mlen = 3;
 					if (++c >= 2) break; /* MAX_CON */
@@ -848,6 +1018,7 @@ int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, 
 			}
 		}
 		for (k = 0; k < n_regs; ++k) if (first[regs[k].rid] >= 0) first[regs[k].rid] = -1;
+		if (mode == 2 && c < 2) realign_mode2(ix, opt, kn, wn, cn, mid_occ, tcodes, toff, qcodes + qoff[i], (int)ql, regs, n_regs, seq_index, c);
 		for (k = 0; k < n_regs; ++k) { /* writer, map.c:1296-1330 (outctn off) */
 			const nd_mm_reg *r = &regs[k];
 			const uint32_t tl = ix->len[r->rid];
@@ -867,3 +1038,12 @@ int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, 
 	return n;
 }
 
+
+int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, float mid_occ_frac, int mid_occ_fixed,
+                          int32_t n_t, const uint8_t *tcodes, const uint64_t *toff, const uint32_t *tlen, const uint32_t *tids,
+                          int32_t n_q, const uint8_t *qcodes, const uint64_t *qoff, const uint32_t *qlen, const uint32_t *qids,
+                          uint8_t *out, int64_t out_cap, int32_t *mid_occ_out, uint32_t *prev_io, void *s2_state)
+{
+	return nd_mm_step2(opt, 0, 17, 10, 20, minide, minmatch, mid_occ_frac, mid_occ_fixed, n_t, tcodes, toff, tlen, tids, n_q, qcodes, qoff, qlen, qids,
+	                   out, out_cap, mid_occ_out, prev_io, s2_state);
+}

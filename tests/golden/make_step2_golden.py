@@ -26,8 +26,18 @@ CASES = [  # (tag, argv between `--step 2 --mode 0` and the files)
 ]
 
 
+# The same commands as nextDenovo writes them (nextDenovo:361-364: no --mode, i.e. --mode 2, minimap2/options.c:56): the marked
+# candidates of every read are mapped again with the short k-mer sketch.  `deep`: 150x reads of a 12 kb genome -- most reads have
+# 200 and more candidates, which the reference re-aligns in batches of --cn targets instead of one by one.
+CASES_M2 = [(tag + ".m2", argv) for tag, argv in CASES] + [
+    ("deep.m2", ("--dual=yes", "-x", "ava-ont", "-k", "17", "-w", "17", "--minlen", "1000", "--maxhan1", "2000")),
+]
+
+
 def files_of(tag):
-    return ["a.fa.gz", "a.fa.gz"] if tag.endswith("self") else ["a.fa.gz", "b.fa.gz", "a.fa.gz"]
+    if tag.startswith("deep"):
+        return ["c.fa.gz", "c.fa.gz"]
+    return ["a.fa.gz", "a.fa.gz"] if ".self" in tag else ["a.fa.gz", "b.fa.gz", "a.fa.gz"]
 
 
 def main():
@@ -46,11 +56,17 @@ def main():
         with gzip.GzipFile(os.path.join(OUT, name), "wb", mtime=0) as f:
             for i in range(lo, hi):
                 f.write(b">%d %d 0.99\n%s\n" % (i + 1, seqs[i].size, synth.codes_to_ascii(seqs[i])))
-    for tag, argv in CASES:
-        out = os.path.join(OUT, tag + ".ovl")
-        refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", "--mode", "0", "-t", "3", *argv,
-                     *[os.path.join(OUT, f) for f in files_of(tag)], "-o", out])
-        print(tag, os.path.getsize(out), os.path.getsize(out + ".bl"))
+    gd = synth.make_genome(12000, seed=71, n_repeats=0)
+    rd = synth.simulate_reads(gd, 150, "hifi", seed=72, mu=8.0, sigma=0.3, min_len=2200)
+    with gzip.GzipFile(os.path.join(OUT, "c.fa.gz"), "wb", mtime=0) as f:
+        for i, sq in enumerate(rd.seqs):
+            f.write(b">%d %d 0.99\n%s\n" % (i + 1, sq.size, synth.codes_to_ascii(sq)))
+    for cases, mode in ((CASES, ("--mode", "0")), (CASES_M2, ())):
+        for tag, argv in cases:
+            out = os.path.join(OUT, tag + ".ovl")
+            refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *mode, "-t", "3", *argv,
+                         *[os.path.join(OUT, f) for f in files_of(tag)], "-o", out])
+            print(tag, os.path.getsize(out), os.path.getsize(out + ".bl"))
 
 
 if __name__ == "__main__":

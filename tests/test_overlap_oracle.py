@@ -107,16 +107,20 @@ def test_oracle_mode3_end_extension_matches_live_reference(lib, sets, extra):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(M.REFDIR, "minimap2-nd")), reason="oracle/_ref not built")
+@pytest.mark.parametrize("mode,genome,depth", [(0, 60000, 28), (2, 60000, 28), (2, 30000, 150)], ids=["mode0", "mode2", "mode2-deep"])
 @pytest.mark.parametrize("preset,extra", [("ava-ont", ("-k", "17", "-w", "17", "--minlen", "1000", "--maxhan1", "2000")),
                                           ("ava-pb", ("-k", "17", "-w", "10", "--minlen", "700", "--maxhan1", "1500", "--maxhan2", "300"))])
-def test_oracle_step2_mode0_matches_live_reference(lib, preset, extra):
-    """`minimap2-nd --step 2 --mode 0` on corrected reads (the cns_align command of nextDenovo:356-366 with the re-alignment
-    switched off): per-target marking of the hits, the length / identity / block-length filters, the dovetail / contained
-    filter (oracle/step2_oracle.c) and the 10-field encoder -- `.ovl` and `.bl` byte for byte against the compiled reference."""
+def test_oracle_step2_matches_live_reference(lib, preset, extra, mode, genome, depth):
+    """`minimap2-nd --step 2` on corrected reads (the cns_align command of nextDenovo:356-366): per-target marking of the hits, the
+    re-alignment of the marked candidates with the short k-mer sketch (the default --mode 2, written as nextDenovo writes it:
+    without --mode; fewer than 200 candidates per read: every candidate against a one-read index of the query; `mode2-deep`: 200
+    and more: the query against batches of cn candidates) or none (--mode 0), the length / identity / block-length filters, the
+    dovetail / contained filter (oracle/step2_oracle.c) and the 10-field encoder -- `.ovl` and `.bl` byte for byte against the
+    compiled reference."""
     from nextdenovo_amd import synth
     import refpipe
-    g = synth.make_genome(60000, seed=61, n_repeats=3, repeat_len=1500)
-    rs = synth.simulate_reads(g, 28, "hifi", seed=62, mu=8.6, sigma=0.35, min_len=2500)
+    g = synth.make_genome(genome, seed=61, n_repeats=3 if genome > 20000 else 0, repeat_len=1500)
+    rs = synth.simulate_reads(g, depth, "hifi", seed=62, mu=8.6, sigma=0.35, min_len=2500)
     seqs = list(rs.seqs)
     rng = np.random.default_rng(5)
     for t in range(25):                      # short reads inside longer ones: contained verdicts
@@ -139,17 +143,23 @@ def test_oracle_step2_mode0_matches_live_reference(lib, preset, extra):
         off[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
         sets.append((ids, lens, np.concatenate([seqs[i] for i in range(lo, hi)]).astype(np.uint8), off))
     out = os.path.join(wd, "o.ovl")
-    cmd = [os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", "--mode", "0", "--dual=yes", "-t", "3", "-x", preset, *extra, files[0], files[1],
-           files[0], "-o", out]
+    cmd = [os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *(("--mode", "0") if mode == 0 else ()), "--dual=yes", "-t", "3", "-x", preset,
+           *extra, files[0], files[1], files[0], "-o", out]
     refpipe.run(cmd)
     want, want_bl = open(out, "rb").read(), open(out + ".bl").read()
     kw = {}
     for k_, name in (("-k", "k"), ("-w", "w"), ("--minlen", "minlen"), ("--maxhan1", "maxhan1"), ("--maxhan2", "maxhan2")):
         if k_ in extra:
             kw[name] = int(extra[extra.index(k_) + 1])
-    got, got_bl = M.step2_mode0(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]])
-    assert len(want) > 3000 and got == want
+    got, got_bl = M.step2(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]], mode)
+    assert len(want) > (3000 if depth < 100 else 1000) and got == want
     assert got_bl == want_bl and want_bl.count("\n") > 20
+    if mode:
+        cnt = (C.c_int64 * 2)()
+        lib.nd_mm_step2_counters(cnt)
+        assert cnt[0] > 20 and (cnt[1] > 20 if depth > 100 else True), list(cnt)   # both forms of the re-alignment ran
+        plain, _ = M.step2(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]], 0)
+        assert plain != got   # the re-alignment really changes records on this set
 
 
 def _fasta_set(path):
@@ -173,18 +183,23 @@ def _fasta_set(path):
     return (np.asarray(ids, dtype=np.uint32), lens, np.concatenate(arrs).astype(np.uint8), off)
 
 
-@pytest.mark.parametrize("tag", ["ont", "pb"])
-def test_oracle_step2_mode0_matches_golden(lib, tag):
-    """The step-2 oracle on the committed fixtures of the compiled reference (tests/golden/step2): what the GPU tests of the device
-    path compare with on a box that has no reference."""
+@pytest.mark.parametrize("tag", ["ont", "pb", "ont.m2", "pb.m2", "deep.m2"])
+def test_oracle_step2_matches_golden(lib, tag):
+    """The step-2 oracle on the committed fixtures of the compiled reference (tests/golden/step2; `.m2`: the command without --mode,
+    i.e. with the re-alignment): what the GPU tests of the device path compare with on a box that has no reference."""
     sys.path.insert(0, os.path.join(HERE, "golden"))
-    from make_step2_golden import CASES as S2, OUT
-    argv = dict(S2)[tag]
+    from make_step2_golden import CASES as S0, CASES_M2, OUT
+    argv = dict(S0 + CASES_M2)[tag]
     kw = {}
     for k_, name in (("-k", "k"), ("-w", "w"), ("--minlen", "minlen"), ("--maxhan1", "maxhan1"), ("--maxhan2", "maxhan2")):
         if k_ in argv:
             kw[name] = int(argv[argv.index(k_) + 1])
-    a, b = _fasta_set(os.path.join(OUT, "a.fa.gz")), _fasta_set(os.path.join(OUT, "b.fa.gz"))
-    got, got_bl = M.step2_mode0(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, [b, a])
+    if tag.startswith("deep"):
+        a = _fasta_set(os.path.join(OUT, "c.fa.gz"))
+        qs = [a]
+    else:
+        a, b = _fasta_set(os.path.join(OUT, "a.fa.gz")), _fasta_set(os.path.join(OUT, "b.fa.gz"))
+        qs = [b, a]
+    got, got_bl = M.step2(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, qs, 2 if tag.endswith(".m2") else 0)
     assert got == open(os.path.join(OUT, tag + ".ovl"), "rb").read()
     assert got_bl == open(os.path.join(OUT, tag + ".ovl.bl")).read()
