@@ -186,6 +186,24 @@ typedef struct ndgpu_ovl_rec10 {
  * be 2 and opt->mode 0.  *recs is malloc'd (ndgpu_ovl_free).  Returns the record count, < 0 on error. */
 int64_t ndgpu_ovl_map2(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
                        uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, ndgpu_ovl_rec10 **recs);
+/* The hits of every query read with nothing judged or filtered, in hit order (mm_map_frag's, minimap2/map.c:506-623): rev, qs, qe,
+ * ts, te as usual; `qname` = the hit's target -- its index-local read number, or, with a wanted list, its POSITION in the read's list
+ * want[want_off[i] .. want_off[i + 1]) (the read is then mapped against those reads only, which are seen in list order: the
+ * per-thread mini-index of the re-alignment, minimap2/index.c:434-575); `tname` = block length, `match` = match count.
+ * nameless != 0: the reads have no names (mm_map(..., qname = 0)): no name-based seed skipping, no self test.  counts[i] = hits
+ * of read i.  Both arrays malloc'd (ndgpu_ovl_free).  Returns the number of hits, < 0 on error. */
+int64_t ndgpu_ovl_map_regs(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                           uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, const uint64_t *want_off,
+                           const uint32_t *want, int nameless, ndgpu_ovl_rec **recs, uint32_t **counts);
+/* replaces: worker_for WITH the re-alignment (minimap2/map.c:988-1126) + the writer's record filter (:1305-1309): `--step 2` as
+ * nextDenovo runs it (no --mode, i.e. --mode 2, options.c:56).  idx = the index part (the preset's k, w); q_mini / t_mini = indexes
+ * with the short sketch (--kn 17 --wn 10, main.c:197) over the query reads / over the part's target reads; cn = --cn (20).
+ * opt->step must be 2 and opt->mode 2.  *recs is malloc'd (ndgpu_ovl_free).  Returns the record count, < 0 on error. */
+int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, ndgpu_ovl_index *t_mini, const ndgpu_ovl_opt *opt,
+                               int32_t mid_occ, int32_t cn, uint32_t n_t, const uint32_t *t_words, uint64_t t_n_words,
+                               const uint64_t *t_word_off, const uint32_t *t_lens, const uint32_t *t_ids, uint32_t n_q,
+                               const uint32_t *q_words, uint64_t q_n_words, const uint64_t *q_word_off, const uint32_t *q_lens,
+                               const uint32_t *q_ids, ndgpu_ovl_rec10 **recs);
 /* replaces: filter_ovl (lib/ovl.c:449-563), whose per-read state lives for the whole run (opt.os, main.c:272), encode_ovl_i
  * (lib/ovl.c:205-253) and out_bl (lib/ovl.c:339-362).  Host code: a record's verdict depends on every record before it. */
 typedef struct ndgpu_s2_state ndgpu_s2_state;

@@ -25,6 +25,9 @@ struct OvlParams {
 	int32_t step2;     // --step 2 (corrected reads): per-target marking + length / identity / block filters, 10-field records
 	int32_t minmatch;  // --step 2: 100
 	float minide;      // --step 2: 0.05
+	int32_t provisional; // K5 stops at the hits themselves (target number, block length and match count in the name / match
+	                     // fields, hit order): the passes of --step 2's re-alignment, whose marking and filters follow on the host
+	int32_t nameless;    // the query has no name (mm_map(..., qname = 0), minimap2/map.c:1052,1088): no self test in K5
 };
 
 // minimizer index of the target reads, resident in HBM
@@ -47,6 +50,11 @@ struct QueryDev {
 	const uint32_t *len, *id, *hash;
 	const uint64_t *namekey;
 	const uint64_t *m_off;   // n_q + 1 offsets into the minimizer arrays
+	// re-alignment (--step 2 --mode 2): query read i is mapped against want[want_off[i] .. want_off[i + 1]) only -- index-local
+	// read numbers in the order the reference puts them into its per-thread mini-index (minimap2/index.c:434-575); a hit's
+	// target number is then the POSITION in that list.  nullptr: the whole index.
+	const uint64_t *want_off;
+	const uint32_t *want;
 };
 
 // sort key of an anchor: | read (batch local) | strand | target read | target position |

@@ -216,6 +216,14 @@ struct Sketch { // minimizers of a read set
 	DevBuf<uint32_t> read;
 };
 
+// the passes of --step 2's re-alignment (ndgpu_ovl_map_regs): the hits themselves, per query read, nothing judged
+struct Regs {
+	const uint64_t *want_off;       // nullptr: every read of the index is a target
+	const uint32_t *want;
+	bool nameless;                  // mm_map(..., qname = 0)
+	std::vector<uint32_t> *counts;  // hits of every query read
+};
+
 struct Engine {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -410,7 +418,8 @@ struct Engine {
 	}
 
 	int64_t map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
-	            const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10 = nullptr);
+	            const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10 = nullptr,
+	            const Regs *regs = nullptr);
 };
 
 static OvlParams to_params(const ndgpu_ovl_opt &o)
@@ -432,15 +441,20 @@ static const char *check_opt(const ndgpu_ovl_opt &o)
 	if (o.min_cnt < 2) return "min_cnt must be >= 2";
 	if (o.max_chain_iter < 1 || o.max_chain_iter >= 8192) return "max_chain_iter must be in 1..8191";
 	if (o.max_gap < 0 || o.bw < 0) return "negative max_gap / bw";
-	if (o.step == 2 && o.mode != 0) return "--step 2 is built for --mode 0 (no re-alignment) only";
+	if (o.step == 2 && o.mode != 0 && o.mode != 2) return "--step 2 is built for --mode 0 (no re-alignment) and --mode 2 (the default)";
 	return nullptr;
 }
 
 int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
-                    const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10)
+                    const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10, const Regs *regs)
 {
 	OvlParams Pm = to_params(o);
 	Pm.k = P.k, Pm.w = P.w, Pm.hpc = P.hpc; // the sketch parameters belong to the index
+	if (regs) {
+		Pm.provisional = 1, Pm.step2 = 0, Pm.mode3 = 0, Pm.dvt = 0, Pm.nameless = regs->nameless;
+		if (regs->nameless) Pm.no_diag = Pm.no_dual = 0; // skip_seed looks at names only when there is one (minimap2/map.c:129)
+		regs->counts->clear();
+	}
 	const OvlParams Pi = P;
 	P = Pm;
 	struct Restore { Engine *e; OvlParams p; ~Restore() { e->P = p; } } restore{this, Pi};
@@ -453,7 +467,8 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	ReadSetDev Q;
 	Q.upload(n_q, words, n_words, woff, lens, ids, stream);
 	std::vector<uint32_t> qh(n_q);
-	for (uint32_t i = 0; i < n_q; ++i) qh[i] = read_hash(ids[i], lens[i], o.seed);
+	for (uint32_t i = 0; i < n_q; ++i)
+		qh[i] = regs && regs->nameless ? wang32(wang32(lens[i]) + wang32((uint32_t)o.seed)) : read_hash(ids[i], lens[i], o.seed);
 	DevBuf<uint32_t> qhash(n_q);
 	qhash.upload(qh.data(), n_q, stream);
 
@@ -461,7 +476,15 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	sketch(Q, 0, true, S);
 	const uint64_t n_m = S.n;
 	const IndexDev ix = index_dev();
-	const QueryDev qd{Q.len.p, Q.id.p, qhash.p, Q.namekey.p, S.off.p};
+	DevBuf<uint64_t> d_want_off;
+	DevBuf<uint32_t> d_want;
+	if (regs && regs->want_off) {
+		const uint64_t nw = regs->want_off[n_q];
+		d_want_off.alloc(n_q + 1), d_want.alloc(nw + 1);
+		d_want_off.upload(regs->want_off, n_q + 1, stream);
+		if (nw) d_want.upload(regs->want, nw, stream);
+	}
+	const QueryDev qd{Q.len.p, Q.id.p, qhash.p, Q.namekey.p, S.off.p, d_want_off.p, regs && regs->want_off ? d_want.p : nullptr};
 
 	// K3a over every query minimizer
 	EvTimer tm(stream);
@@ -501,7 +524,11 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		const uint32_t nb = r1 - r0;
 		const uint64_t a_base = h_raoff[r0], na = h_raoff[r1] - a_base;
 		++st.batches;
-		if (na == 0) { r0 = r1; continue; }
+		if (na == 0) {
+			if (regs) regs->counts->insert(regs->counts->end(), nb, 0u);
+			r0 = r1;
+			continue;
+		}
 		KeyLayout L;
 		L.pos_bits = pos_bits, L.rev_shift = pos_bits + rid_bits, L.read_shift = L.rev_shift + 1, L.read_base = r0;
 		L.total_bits = L.read_shift + bits_for(nb - 1);
@@ -611,6 +638,11 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		rec_off.download(&n_out, 1, stream, nb);
 		std::vector<uint32_t> h_chain(nb);
 		n_chain.download(h_chain.data(), nb, stream);
+		if (regs) {
+			const size_t at = regs->counts->size();
+			regs->counts->resize(at + nb);
+			n_rec.download(regs->counts->data() + at, nb, stream);
+		}
 		HIP_OK(hipStreamSynchronize(stream));
 		if (P.step2) {
 			DevBuf<OvlRec10> dense10(n_out + 1);
@@ -804,6 +836,33 @@ int64_t ndgpu_ovl_map(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_
 		static_assert(sizeof(OvlRec) == sizeof(ndgpu_ovl_rec), "record layout");
 		*recs = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec) * (size_t)(n ? n : 1));
 		if (n) memcpy(*recs, out.data(), sizeof(ndgpu_ovl_rec) * (size_t)n);
+		return n;
+	} catch (...) {
+		return -2;
+	}
+}
+
+// The hits of every query read, nothing judged or filtered: hit order, target = position in the read's wanted list (or the
+// index-local read number when want_off is NULL), block length in `tname`, match count in `match` -- the raw material of
+// --step 2's marking and re-alignment (minimap2/map.c:997-1126), which run on the host (csrc/ovl_step2.cpp).
+int64_t ndgpu_ovl_map_regs(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                           uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, const uint64_t *want_off,
+                           const uint32_t *want, int nameless, ndgpu_ovl_rec **recs, uint32_t **counts)
+{
+	*recs = nullptr, *counts = nullptr;
+	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return -1; }
+	try {
+		HIP_OK(hipSetDevice(h->e.device));
+		std::vector<OvlRec> out;
+		std::vector<uint32_t> cnt;
+		const Regs rg{want_off, want, nameless != 0, &cnt};
+		int64_t n = h->e.map(*opt, mid_occ, n_reads, words, n_words, word_off, lens, ids, out, nullptr, &rg);
+		if (n < 0) return n;
+		if (cnt.size() != n_reads) cnt.resize(n_reads, 0u);
+		*recs = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec) * (size_t)(n ? n : 1));
+		*counts = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n_reads ? n_reads : 1));
+		if (n) memcpy(*recs, out.data(), sizeof(ndgpu_ovl_rec) * (size_t)n);
+		if (n_reads) memcpy(*counts, cnt.data(), sizeof(uint32_t) * n_reads);
 		return n;
 	} catch (...) {
 		return -2;

@@ -587,6 +587,16 @@ __device__ __forceinline__ int seed_skipped(const OvlParams &P, const IndexDev &
 	return 0;
 }
 
+// occurrences [lo, hi) of read `rid` inside one key's position list (ascending read << 32 | position << 1 | strand)
+__device__ __forceinline__ void occ_run(const uint64_t *__restrict__ pos, uint32_t start, uint32_t cnt, uint32_t rid, uint32_t &lo, uint32_t &hi)
+{
+	uint32_t a = 0, b = cnt;
+	while (a < b) { const uint32_t m = (a + b) >> 1; if ((uint32_t)(pos[start + m] >> 32) < rid) a = m + 1; else b = m; }
+	lo = a, b = cnt;
+	while (a < b) { const uint32_t m = (a + b) >> 1; if ((uint32_t)(pos[start + m] >> 32) <= rid) a = m + 1; else b = m; }
+	hi = a;
+}
+
 __global__ void seed_count_kernel(const uint64_t *__restrict__ mx, const uint64_t *__restrict__ my, const uint32_t *__restrict__ m_read,
                                   uint64_t n_m, IndexDev ix, QueryDev q, OvlParams P, int mid_occ, uint32_t *__restrict__ m_start,
                                   uint32_t *__restrict__ m_cnt, uint32_t *__restrict__ m_surv)
@@ -595,6 +605,19 @@ __global__ void seed_count_kernel(const uint64_t *__restrict__ mx, const uint64_
 	if (m >= n_m) return;
 	uint32_t start, cnt, surv = 0;
 	index_lookup(ix, mx[m] >> 8, start, cnt);
+	if (q.want) { // re-alignment: the index the reference looks this minimizer up in holds the wanted reads only
+		const uint32_t rd = m_read[m];
+		uint32_t n_in = 0;
+		if (cnt)
+			for (uint64_t i = q.want_off[rd]; i < q.want_off[rd + 1]; ++i) {
+				uint32_t lo, hi;
+				occ_run(ix.pos, start, cnt, q.want[i], lo, hi);
+				n_in += hi - lo;
+			}
+		if ((int64_t)n_in >= (int64_t)mid_occ) n_in = 0;
+		m_start[m] = start, m_cnt[m] = n_in ? cnt : 0, m_surv[m] = n_in;
+		return;
+	}
 	if ((int64_t)cnt >= (int64_t)mid_occ) cnt = 0; // repetitive minimizer: contributes nothing
 	if (cnt) {
 		const uint32_t rd = m_read[m], q_pos = (uint32_t)my[m];
@@ -630,6 +653,29 @@ __global__ void seed_fill_kernel(const uint64_t *__restrict__ mx, const uint64_t
 	if (m + 1 < q.m_off[rd + 1] && mx[m + 1] >> 8 == minier) tandem = true;
 	uint64_t o = a_off[m] - a_base;
 	const uint64_t rd_bits = (uint64_t)(rd - L.read_base) << L.read_shift;
+	if (q.want) { // re-alignment: occurrences in the order of the mini-index (wanted read by wanted read), numbered by list position
+		for (uint64_t i = q.want_off[rd]; i < q.want_off[rd + 1]; ++i) {
+			uint32_t lo, hi;
+			occ_run(ix.pos, start, cnt, q.want[i], lo, hi);
+			for (uint32_t j = lo; j < hi; ++j) {
+				const uint64_t r = ix.pos[start + j];
+				const uint64_t rid = i - q.want_off[rd], rpos = (uint32_t)r >> 1;
+				uint64_t y, rev;
+				if ((r & 1) == (q_pos & 1)) {
+					rev = 0;
+					y = (uint64_t)q_span << 32 | (uint64_t)(q_pos >> 1);
+				} else {
+					rev = 1;
+					y = (uint64_t)q_span << 32 | (uint64_t)(uint32_t)((int32_t)ql - (int32_t)((q_pos >> 1) + 1 - q_span) - 1);
+				}
+				if (tandem) y |= kSeedTandem;
+				ckey[o] = rd_bits | rev << L.rev_shift | rid << L.pos_bits | rpos;
+				ay[o] = y;
+				++o;
+			}
+		}
+		return;
+	}
 	for (uint32_t j = 0; j < cnt; ++j) {
 		const uint64_t r = ix.pos[start + j];
 		int self;
@@ -1344,8 +1390,8 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 		int32_t qs, qe;
 		if (!rev) qs = (int32_t)BY[first] + 1 - span0, qe = (int32_t)BY[last] + 1;
 		else qs = (int32_t)qlen - ((int32_t)BY[last] + 1), qe = (int32_t)qlen - ((int32_t)BY[first] + 1 - span0);
-		const uint32_t tid = ix.id[rid];
-		if (tid == qid) continue;
+		const uint32_t tid = P.nameless ? 0u : ix.id[rid]; // (re-alignment: `rid` numbers the wanted list, nobody has a name)
+		if (!P.nameless && tid == qid) continue;
 		int32_t mlen = span0, blen = span0; // mm_cal_fuzzy_len (minimap2/hit.c): matching bases, block length
 		for (int32_t m = first + 1; m <= last; ++m) {
 			const int sp = (int)(BY[m] >> 32 & 0xff);
@@ -1355,7 +1401,7 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 			mlen += tl > sp && ql > sp ? sp : tl < ql ? tl : ql;
 		}
 		OvlRec r;
-		if (P.step2) { // provisional: local target index and block length in the name fields, judged below
+		if (P.step2 || P.provisional) { // provisional: local target index and block length in the name fields, judged below / on the host
 			r.rev = rev, r.qname = rid, r.qs = (uint32_t)qs, r.qe = (uint32_t)qe, r.tname = (uint32_t)blen, r.ts = (uint32_t)rs, r.te = (uint32_t)re,
 			r.match = (uint32_t)mlen;
 			out[n_out++] = r;
@@ -1412,7 +1458,7 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 		r.match = (uint32_t)mlen;
 		out[n_out++] = r;
 	}
-	if (P.step2) {
+	if (P.step2 && !P.provisional) {
 		// worker_for with the re-alignment switched off (--mode 0, minimap2/map.c:988-1031): the first hit of a target carries
 		// the verdict of that target -- the match count of a dovetail hit, 3 = the query looks contained -- later hits of the
 		// same target are marked 1 and count only when they are nearly as long; two contained verdicts end the marking.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""`minimap2-nd --step 1` (and `--step 2 --mode 0`) on the MI355X: all-vs-all read overlap, `.ovl` out.
+"""`minimap2-nd --step 1` and `--step 2` on the MI355X: all-vs-all read overlap, `.ovl` out.
 
 Takes the command line nextDenovo writes for the raw-align subtasks (reference nextDenovo:436-466):
 
@@ -10,10 +10,12 @@ first, then the remaining options in order: main.c:140-366); the index is split 
 mm_idx_gen does with -I (index.c:284-287,351-360), the occurrence threshold comes from the first part
 (options.c:70-71), every query file is mapped against every part in turn (main.c:474-507).
 
-`--mode 3` (HiFi: chain ends trimmed, every hit extended into the unaligned read ends, minimap2/map.c:340-482) is built in.
-`--step 2 --mode 0` (the `cns_align` command of nextDenovo:356-366 on corrected reads, re-alignment switched off) is built in too:
-FASTA input with numeric names, per-target marking and the record filters on the device, the dovetail / contained filter, the
-10-field encoder and the `.bl` table on the host (csrc/ovl_step2.cpp).  The re-alignment modes 1 / 2 are not.
+`--step 2` runs as nextDenovo runs it (--mode 2, the default: every marked candidate mapped again with the short k-mer sketch) or
+with `--mode 0`.  `--mode 3` (HiFi: chain ends trimmed, every hit extended into the unaligned read ends, minimap2/map.c:340-482) is built in.
+`--step 2` is the `cns_align` command of nextDenovo:356-366 on corrected reads: FASTA input with numeric names; the hits of every
+read on the device, the per-target marking, the re-alignment's bookkeeping (its mapping passes run on the device again), the record
+filters, the dovetail / contained filter, the 10-field encoder and the `.bl` table on the host (csrc/ovl_step2.cpp).  --mode 1
+(mm_map_nextdenovo1, a chaining variant of its own) is not built.
 Options of other paths (-a, -c, --step 3) are rejected, not approximated.
 """
 from __future__ import annotations
@@ -50,11 +52,12 @@ class Args:
         self.step = 0
         self.out = None
         self.batch_size = IDX_BATCH
+        self.kn, self.wn, self.cn = 17, 10, 20   # --step 2 (main.c:197)
         self.files = []
         self.ops = []  # (name, value) in command-line order, applied after the preset
 
 
-LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df", "--minide", "--minmatch"}
+LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df", "--minide", "--minmatch", "--kn", "--wn", "--cn"}
 SHORT_WITH_ARG = set("xtfIKkwornmgsNpM")
 
 
@@ -154,14 +157,21 @@ def build_opt(a: Args) -> overlap.Opt:
             opt.minide = float(val)
         elif name == "--minmatch":
             opt.minmatch = parse_num(val)
+        elif name == "--kn":
+            a.kn = int(val)   # the re-alignment's short k-mer sketch (main.c:197,219-221)
+        elif name == "--wn":
+            a.wn = int(val)
+        elif name == "--cn":
+            a.cn = int(val)
         elif name == "-o":
             a.out = val
         else:
             raise SystemExit("[ERROR] option %s is outside the --step 1 overlap path of this engine" % name)
     if a.step not in (1, 2):
         raise SystemExit("[ERROR] --step 1 or --step 2 is required")
-    if a.step == 2 and opt.mode != 0:
-        raise SystemExit("[ERROR] --step 2 is built for --mode 0 (no re-alignment) only: pass --mode 0")
+    if a.step == 2 and opt.mode not in (0, 2):
+        raise SystemExit("[ERROR] --step 2 is built for --mode 2 (the default: every marked candidate mapped again) and --mode 0 (no "
+                         "re-alignment); --mode %d is not" % opt.mode)
     if a.step == 2 and not a.out:
         raise SystemExit("[ERROR] --step 2 needs -o FILE (the .bl table is written next to it, main.c:262-272)")
     return opt
@@ -217,15 +227,35 @@ def run(argv) -> int:
     try:
         if flt:
             out.write(b"\x00\xff")  # init_ovl_mode(stdout, 10), lib/ovl.c:70-75
+        realign = a.step == 2 and opt.mode == 2
+        mini_opt, q_minis = None, {}
+        if realign:  # the re-alignment's indexes use the short k-mer sketch (--kn 17 --wn 10, main.c:197), hpc as the preset's
+            mini_opt = overlap.Opt.from_buffer_copy(opt)
+            mini_opt.k, mini_opt.w = a.kn, a.wn
         for lo, hi in index_parts(target.lens, a.batch_size):
-            with overlap.Index(opt, target.subset(lo, hi)) as ix:
+            part = target.subset(lo, hi)
+            with overlap.Index(opt, part) as ix:
                 if mid_occ <= 0:
                     mid_occ = ix.mid_occ()
-                for q in queries:
-                    if flt:
-                        out.write(flt.feed(ix.map2(q, mid_occ), opt.maxhan1, opt.maxhan2))
-                    else:
-                        out.write(overlap.encode(ix.map(q, mid_occ), prev))
+                t_mini = overlap.Index(mini_opt, part) if realign else None
+                try:
+                    for qi, q in enumerate(queries):
+                        if realign:
+                            whole = q is target and lo == 0 and hi == len(target)   # the same reads: one short-sketch index serves both sides
+                            if qi not in q_minis:
+                                q_minis[qi] = t_mini if whole else overlap.Index(mini_opt, q)
+                            out.write(flt.feed(ix.map2_realign(part, q, mid_occ, q_minis[qi], t_mini, a.cn), opt.maxhan1, opt.maxhan2))
+                            if whole:
+                                del q_minis[qi]   # (it is closed with the part)
+                        elif flt:
+                            out.write(flt.feed(ix.map2(q, mid_occ), opt.maxhan1, opt.maxhan2))
+                        else:
+                            out.write(overlap.encode(ix.map(q, mid_occ), prev))
+                finally:
+                    if t_mini is not None:
+                        t_mini.close()
+        for m in q_minis.values():
+            m.close()
         if flt:
             with open(a.out + ".bl", "w") as f:
                 f.write(flt.bl())

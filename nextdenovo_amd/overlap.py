@@ -75,6 +75,11 @@ def _bind(lib):
     lib.ndgpu_ovl_reset_stats.argtypes = [P]
     lib.ndgpu_ovl_map2.argtypes = lib.ndgpu_ovl_map.argtypes
     lib.ndgpu_ovl_map2.restype = C.c_int64
+    lib.ndgpu_ovl_map_regs.argtypes = [P, C.POINTER(Opt), C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, P, P, C.c_int, C.POINTER(P), C.POINTER(P)]
+    lib.ndgpu_ovl_map_regs.restype = C.c_int64
+    lib.ndgpu_ovl_map2_realign.argtypes = [P, P, P, C.POINTER(Opt), C.c_int32, C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, C.c_uint32, P, C.c_uint64,
+                                           P, P, P, C.POINTER(P)]
+    lib.ndgpu_ovl_map2_realign.restype = C.c_int64
     lib.ndgpu_s2_new.restype = P
     lib.ndgpu_s2_free.argtypes = [P]
     lib.ndgpu_s2_filter_encode.argtypes = [P, P, C.c_int64, C.c_int32, C.c_int32, P, C.POINTER(P), P]
@@ -204,6 +209,31 @@ class Index:
                                     _ptr(rs.lens), _ptr(rs.ids), C.byref(recs))
         if n < 0:
             raise _fail(self.lib, "ndgpu_ovl_map2 failed (%d)" % n)
+        return _take(self.lib, recs, n, REC10)
+
+    def map_regs(self, rs: ReadSet, mid_occ: int, want_off=None, want=None, nameless=False, opt: Opt | None = None):
+        """The hits of every read of `rs`, nothing judged (ndgpu_ovl_map_regs) -> (records, hits per read)."""
+        opt = opt or self.opt
+        recs, cnt = C.c_void_p(), C.c_void_p()
+        wo = None if want_off is None else np.ascontiguousarray(want_off, dtype=np.uint64)
+        wa = None if want is None else np.ascontiguousarray(want, dtype=np.uint32)
+        n = self.lib.ndgpu_ovl_map_regs(self.h, C.byref(opt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off), _ptr(rs.lens),
+                                        _ptr(rs.ids), None if wo is None else _ptr(wo), None if wa is None else _ptr(wa), 1 if nameless else 0,
+                                        C.byref(recs), C.byref(cnt))
+        if n < 0:
+            raise _fail(self.lib, "ndgpu_ovl_map_regs failed (%d)" % n)
+        return _take(self.lib, recs, n, REC), _take(self.lib, cnt, len(rs), np.uint32)
+
+    def map2_realign(self, target: ReadSet, rs: ReadSet, mid_occ: int, q_mini: "Index", t_mini: "Index", cn: int = 20, opt: Opt | None = None) -> np.ndarray:
+        """--step 2 as nextDenovo runs it (--mode 2: marked candidates mapped again with the short k-mer sketch,
+        ndgpu_ovl_map2_realign): the 10-field records that passed the mapper's own filters, in output order."""
+        opt = opt or self.opt
+        recs = C.c_void_p()
+        n = self.lib.ndgpu_ovl_map2_realign(self.h, q_mini.h, t_mini.h, C.byref(opt), mid_occ, cn, len(target), _ptr(target.words), target.words.size,
+                                            _ptr(target.word_off), _ptr(target.lens), _ptr(target.ids), len(rs), _ptr(rs.words), rs.words.size,
+                                            _ptr(rs.word_off), _ptr(rs.lens), _ptr(rs.ids), C.byref(recs))
+        if n < 0:
+            raise _fail(self.lib, "ndgpu_ovl_map2_realign failed (%d)" % n)
         return _take(self.lib, recs, n, REC10)
 
     def debug_anchors(self, q: int):
