@@ -878,7 +878,9 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
             continue;
         }
         P.link_len = (uint32_t)link_len;
-        P.row_cap = (uint32_t)(link_len + ins_cap);
+        // cell rows = columns + the longest insertion run after every column; bounded by all the candidates' bases, in practice
+        // a fraction of the columns: three times the columns are laid out, a pile that needs more is declined (host path)
+        P.row_cap = (uint32_t)std::min<uint64_t>(link_len + ins_cap, 3 * link_len + 1024);
         P.out_cap = (uint32_t)(2 * link_len + 64);
         P.cell_off = cell_rows * 6;
         P.col_off = col_slots;
