@@ -206,6 +206,16 @@ def reduce_over_ranks(dist, torch, bases: int, dt: float, device, seeds: int = 0
     return int(b[0].item()), float(t.item())
 
 
+def gather_rank_stats(dist, torch, device, values):
+    """Every rank's (wall s, overlap s, sort + piles s, consensus s, piles, alignment columns): one all_gather of six doubles, so
+    that imbalance between the seed files and the index rebuilds of the mirror jobs show in the one line rank 0 prints."""
+    mine = torch.tensor(values, dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    keys = ("wall_s", "overlap_s", "sort_piles_s", "consensus_s", "piles", "columns")
+    return [{k: (float(v) if k.endswith("_s") else int(v)) for k, v in zip(keys, p.tolist())} for p in parts]
+
+
 def shard_of_rank(world: int, rank: int, seed_files: int, shard: int):
     """(seed_cutfiles, the seed file this rank corrects): rank r of N takes seed file r of N; one GPU with --seed-files M
     takes seed file --shard of M."""
@@ -315,9 +325,13 @@ def main():
     st = api.stats()
 
     total_bases, max_dt, total_seeds = bases, dt, n_ok
+    per_rank = None
     if dist is not None:
         total_bases, max_dt = reduce_over_ranks(dist, torch, bases, dt, "cuda", n_ok)
         total_seeds = reduce_over_ranks.seeds
+        per_rank = gather_rank_stats(dist, torch, "cuda", [dt, sh.stats.get("overlap_s", 0.0) if not args.no_overlap else 0.0,
+                                                           (sh.stats.get("sort_s", 0.0) + sh.stats.get("assemble_s", 0.0)) if not args.no_overlap else 0.0,
+                                                           cns_wall[0], float(st["piles"]), float(st["path_items"])])
 
     if rank == 0:
         if analytic:
@@ -398,6 +412,8 @@ def main():
                                                        "backtrack_ms", "extract_ms", "lq_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank   # over the K timed steps; rank r = seed file r
         if not args.no_overlap:
             q_bases = int(lens.sum())
             o_ms = sh.stats["overlap_s"] / args.steps * 1e3

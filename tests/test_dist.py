@@ -64,6 +64,8 @@ def _worker(rank, world, port, q):
     recs, seed_ids, jobs = _correct_file(mine, n_files)
     bases = sum(ln for ln, _ in recs.values() if ln > 4)
     total, tmax = bench.reduce_over_ranks(dist, torch, bases, 1.0 + rank, "cpu", len(recs))
+    per = bench.gather_rank_stats(dist, torch, "cpu", [1.0 + rank, 0.5, 0.25, 0.125, float(len(recs)), float(bases)])
+    assert len(per) == world and per[rank]["piles"] == len(recs) and per[1 - rank]["wall_s"] == 2.0 - rank
     q.put((rank, recs, seed_ids, jobs, bases, total, tmax, bench.reduce_over_ranks.seeds))
     dist.barrier()
     dist.destroy_process_group()
