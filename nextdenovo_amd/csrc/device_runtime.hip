@@ -228,7 +228,7 @@ struct DeviceAligner::State {
     // low-quality-region rounds (K12)
     DevBuf<LqPileDev> d_lq_piles;
     DevBuf<LqPieceDev> d_lq_pieces;
-    DevBuf<uint32_t> d_lq_bpp, d_lq_blink, d_lq_row0, d_lq_cov;
+    DevBuf<uint32_t> d_lq_rec;
     DevBuf<char> d_lq_out;
     std::vector<ReadDev> reads;
     std::vector<PileDev> piles;
@@ -348,7 +348,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
         }
     }
 #define NDGPU_NAME(x) s_->x.name = #x;
-    NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_bpp) NDGPU_NAME(d_lq_blink) NDGPU_NAME(d_lq_row0) NDGPU_NAME(d_lq_cov)
+    NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec)
     NDGPU_NAME(d_lq_out)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
@@ -450,7 +450,7 @@ void DeviceAligner::release_memory() {
     S.pending.clear();
     S.up_used = S.down_used = 0;
 #define NDGPU_REL(x) S.x.release();
-    NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_bpp) NDGPU_REL(d_lq_blink) NDGPU_REL(d_lq_row0) NDGPU_REL(d_lq_cov)
+    NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec)
     NDGPU_REL(d_lq_out)
     NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
@@ -814,7 +814,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     };
     std::vector<Src> srcs;
     std::vector<uint8_t> usable(n, 1);
-    uint64_t pool_words = 0, ops_words = 0, cell_rows = 0, col_slots = 0, out_bytes = 0;
+    uint64_t pool_words = 0, ops_words = 0, cell_rows = 0, out_bytes = 0;
     size_t n_piece_total = 0;
     for (size_t r = 0; r < n; r++) n_piece_total += rounds[r]->pieces.size();
     pieces.reserve(n_piece_total);
@@ -873,7 +873,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
             }
             pieces.push_back(d);
         }
-        if (link_len + ins_cap >= (1ull << 31) || link_len >= (1ull << 20)) {  // beyond the packed tag's column field
+        if (link_len + ins_cap >= (1ull << 27) || link_len >= (1ull << 20)) {  // beyond the packed tag's column field / the record's row field
             usable[r] = 0;
             continue;
         }
@@ -883,10 +883,8 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         P.row_cap = (uint32_t)std::min<uint64_t>(link_len + ins_cap, 3 * link_len + 1024);
         P.out_cap = (uint32_t)(2 * link_len + 64);
         P.cell_off = cell_rows * 6;
-        P.col_off = col_slots;
         P.out_off = out_bytes;
         cell_rows += P.row_cap;
-        col_slots += link_len + 1;
         out_bytes += P.out_cap;
     }
     const size_t nt = tasks.size();
@@ -911,10 +909,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.d_ops.reserve(ops_words + 2);
     S.d_lq_piles.reserve(n);
     S.d_lq_pieces.reserve(pieces.size());
-    S.d_lq_bpp.reserve(cell_rows * 6 + 6);
-    S.d_lq_blink.reserve(cell_rows * 6 + 6);
-    S.d_lq_row0.reserve(col_slots + 1);
-    S.d_lq_cov.reserve(col_slots + 1);
+    S.d_lq_rec.reserve(cell_rows * 6 + 6);
     S.d_lq_out.reserve(out_bytes + 1);
 
     // forward / traceback chunks bounded by the trace budget (the column streams of every chunk stay resident)
@@ -955,8 +950,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     }
     HIP_CHECK(hipEventRecord(S.evs[1], st));
     NDGPU_DBG(st, "lq: msa of %zu piles", n);
-    launch_lq_msa(S.d_lq_piles.p, S.d_lq_pieces.p, S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_pool.p, S.d_lq_bpp.p, S.d_lq_blink.p,
-                  S.d_lq_row0.p, S.d_lq_cov.p, S.d_lq_out.p, (int)n, st);
+    launch_lq_msa(S.d_lq_piles.p, S.d_lq_pieces.p, S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_pool.p, S.d_lq_rec.p, S.d_lq_out.p, (int)n, st);
     HIP_CHECK(hipEventRecord(S.evs[2], st));
     S.h_outs.reserve(nt + 1);
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, nt * sizeof(AlnOut), hipMemcpyDeviceToHost, st));

@@ -13,8 +13,9 @@
 //             the 2-bit column kinds K8a left in HBM and the 2-bit candidate bases (no tag arrays, no strings); per cell row
 //             (column, delta) the six cells' (pp, ppp) links are collected in first-seen order with K9's ballot leader
 //             loop, scored at once (a link's predecessor cell lies in this column or the one before: two column tables in
-//             LDS), every cell's best link chosen with the reference's sequential tie-break, and (best_pp, best_link) written
-//             per cell; lane 0 then walks best_pp from the last cell and emits the consensus characters.  A pile that does
+//             LDS), every cell's best link chosen with the reference's sequential tie-break, and one word per cell written (the
+//             cell row and symbol of its best predecessor, whether its own character is confident); the wavefront then walks the
+//             best predecessors from the last cell through an LDS window and emits the consensus characters.  A pile that does
 //             not fit the LDS tables (an insertion run of >= 48 columns, > 384 links in a column) or whose alignments do not
 //             end at both sequence ends is declined (err != 0): the host path (consensus.cpp) takes it.
 #include <hip/hip_runtime.h>
@@ -31,6 +32,10 @@ constexpr int kLqRows = 30;          // LQSEQ_MAX_CAN_COUNT rows of the second M
 constexpr int kLqDeltaCap = 48;      // cell rows per column the LDS tables hold
 constexpr int kLqLinkCap = 384;      // links per column
 constexpr int kLqCellCap = 32;       // links per cell (<= 30 rows)
+constexpr int kLqWalkRows = 256;     // cell rows the walk stages in LDS at a time
+// A cell's record, all the walk needs: the cell row and symbol of its best predecessor and whether its own character is
+// confident -- [31:4] cell row (kLqNoRow: none, the walk ends), [3] best_link * qv_factor > coverage, [2:0] symbol.
+constexpr uint32_t kLqNoRow = 0xfffffffu;
 
 __device__ __forceinline__ uint32_t lq_op_at(const uint32_t *__restrict__ W, uint32_t col) {
     return (W[col >> 4] >> ((col & 15u) * 2u)) & 3u;
@@ -44,13 +49,12 @@ __device__ __forceinline__ uint32_t lq_cns_code(uint32_t c) { return (0x1230u >>
 __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ piles, const LqPieceDev *__restrict__ pieces,
                                                      const AlnTask *__restrict__ tasks, const AlnOut *__restrict__ outs,
                                                      const uint32_t *__restrict__ ops, const uint32_t *__restrict__ pool,
-                                                     uint32_t *__restrict__ cell_bpp, uint32_t *__restrict__ cell_blink,
-                                                     uint32_t *__restrict__ col_row0, uint32_t *__restrict__ col_cov,
-                                                     char *__restrict__ out_chars) {
+                                                     uint32_t *__restrict__ cell_rec, char *__restrict__ out_chars) {
     __shared__ uint32_t l_pp[6][kLqCellCap], l_ppp[6][kLqCellCap], l_cnt[6][kLqCellCap];
     __shared__ uint32_t tab_pp[2][kLqLinkCap];
     __shared__ int32_t tab_sc[2][kLqLinkCap];
     __shared__ uint16_t cell_st[2][kLqDeltaCap * 6], cell_n[2][kLqDeltaCap * 6];
+    __shared__ uint32_t win[kLqWalkRows * 6];  // the walk's window of cell records
 
     LqPileDev &PD = piles[blockIdx.x];
     const LqPileDev P = PD;
@@ -64,10 +68,7 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
     __builtin_amdgcn_s_setprio(3);
     const bool row_ok = lane < kLqRows;
     const LqPieceDev *__restrict__ my = pieces + P.first_piece + (uint32_t)(row_ok ? lane : 0) * P.n_regions;
-    uint32_t *__restrict__ bpp = cell_bpp + P.cell_off;
-    uint32_t *__restrict__ blink = cell_blink + P.cell_off;
-    uint32_t *__restrict__ row0 = col_row0 + P.col_off;
-    uint32_t *__restrict__ cov_out = col_cov + P.col_off;
+    uint32_t *__restrict__ rec = cell_rec + P.cell_off;
 
     uint32_t err = 0;
     // the lane's row: current piece
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
     __builtin_amdgcn_wave_barrier();
 
     uint32_t row = 0;            // cell rows written so far
+    uint32_t row_col0 = 0, row_prev0 = 0;  // first cell row of this column / of the one before
     uint32_t t = 0;              // column
     int cur_tab = 0;
     uint32_t used_cur = 0, used_prev = 0;  // cell rows of the current / the other table's last use
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
 
     while (t < P.link_len && !__ballot(err != 0)) {
         // -------- one column
-        if (lane == 0) row0[t] = row;
+        row_prev0 = row_col0;
+        row_col0 = row;
         for (uint32_t i = (uint32_t)lane; i < used_cur * 6u; i += 64) cell_n[cur_tab][i] = 0;
         __builtin_amdgcn_wave_barrier();
         uint32_t n_tab = 0;      // links in the current column's table
@@ -263,8 +266,10 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
                         best_link = l_cnt[lane][k];
                     }
                 }
-                bpp[(uint64_t)row * 6u + (uint32_t)lane] = best_pp;
-                blink[(uint64_t)row * 6u + (uint32_t)lane] = best_link;
+                const uint32_t prow = best_pp == kTagHead ? kLqNoRow
+                                                           : ((uint32_t)tag_tpos(best_pp) == t ? row_col0 : row_prev0) + tag_delta(best_pp);
+                const uint32_t conf = (int32_t)best_link * P.qv_factor > (int32_t)coverage ? 8u : 0u;   // nextcorrect.c:1306
+                rec[(uint64_t)row * 6u + (uint32_t)lane] = prow << 4 | conf | (best_pp & 7u);
             }
             __builtin_amdgcn_wave_barrier();
             n_tab += n_row;
@@ -279,7 +284,6 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
                 } else aligned = false;
             }
         }
-        if (lane == 0) cov_out[t] = coverage;
         {  // the tables swap roles
             const uint32_t u = d < (uint32_t)kLqDeltaCap ? d : (uint32_t)kLqDeltaCap;
             used_cur = used_prev;
@@ -302,29 +306,34 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
     }
     const bool failed = __ballot(err != 0) != 0ull;
     uint32_t out_len = 0;
-    if (!failed && lane == 0) {
-        row0[P.link_len] = row;
+    if (!failed && row > 0 && row < kLqNoRow) {
+        // ---- the walk (nextcorrect.c:1302-1318): from the last cell along the best predecessors, one character per non-gap cell.
+        //      Every lane walks (the state is uniform), the records come through an LDS window of kLqWalkRows cell rows filled with
+        //      coalesced loads -- a predecessor is always an earlier row -- and lane 0 writes the characters.
         __threadfence();
-        // ---- the walk (nextcorrect.c:1302-1318): from the last cell along best_pp, one character per non-gap cell
         char *__restrict__ out = out_chars + P.out_off;
-        uint32_t wt = P.link_len - 1u, wd = row - row0[P.link_len - 1u] - 1u, wb = 5u;
-        const char sym[6] = {'A', 'T', 'G', 'C', '-', 'N'};
+        uint32_t wrow = row - 1u, wb = 5u, w_lo = row;
         for (;;) {
-            const uint64_t ci = ((uint64_t)row0[wt] + wd) * 6u + wb;
+            if (wrow < w_lo) {
+                const uint32_t hi = wrow + 1u, lo = hi > (uint32_t)kLqWalkRows ? hi - (uint32_t)kLqWalkRows : 0u;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = (uint32_t)lane; i < (hi - lo) * 6u; i += 64) win[i] = rec[(uint64_t)lo * 6u + i];
+                __builtin_amdgcn_wave_barrier();
+                w_lo = lo;
+            }
+            const uint32_t v = win[(wrow - w_lo) * 6u + wb];
             if (wb != 4u) {
                 if (out_len >= P.out_cap) {
                     err = 8;
                     break;
                 }
-                const char ch = sym[wb];
-                const bool upper = (int32_t)blink[ci] * P.qv_factor > (int32_t)cov_out[wt] || ch == 'N';
-                out[out_len++] = upper ? ch : (char)(ch + 32);
+                const char ch = wb == 0u ? 'A' : wb == 1u ? 'T' : wb == 2u ? 'G' : wb == 3u ? 'C' : 'N';
+                if (lane == 0) out[out_len] = ((v & 8u) || wb == 5u) ? ch : (char)(ch + 32);
+                out_len++;
             }
-            const uint32_t nx = bpp[ci];
-            if (nx == kTagHead) break;
-            wt = (uint32_t)tag_tpos(nx);
-            wd = tag_delta(nx);
-            wb = tag_base(nx);
+            if ((v >> 4) == kLqNoRow) break;
+            wrow = v >> 4;
+            wb = v & 7u;
         }
     }
     const unsigned long long eb = __ballot(err != 0);
@@ -338,11 +347,10 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
 }  // namespace
 
 void launch_lq_msa(LqPileDev *piles, const LqPieceDev *pieces, const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops,
-                   const uint32_t *pool, uint32_t *cell_bpp, uint32_t *cell_blink, uint32_t *col_row0, uint32_t *col_cov,
-                   char *out_chars, int n_piles, void *stream) {
+                   const uint32_t *pool, uint32_t *cell_rec, char *out_chars, int n_piles, void *stream) {
     if (n_piles <= 0) return;
     hipLaunchKernelGGL(lq_msa_kernel, dim3((unsigned)n_piles), dim3(64), 0, (hipStream_t)stream, piles, pieces, tasks, outs, ops, pool,
-                       cell_bpp, cell_blink, col_row0, col_cov, out_chars);
+                       cell_rec, out_chars);
 }
 
 }  // namespace ndgpu

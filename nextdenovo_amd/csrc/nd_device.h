@@ -122,16 +122,14 @@ struct LqPileDev {
     uint32_t row_cap;        // capacity in cell rows ((column, delta) pairs) of the pile's cell tables
     uint32_t out_cap;        // capacity of the pile's output characters
     uint32_t pad_;
-    uint64_t cell_off;       // first cell (6 per cell row)
-    uint64_t col_off;        // first per-column slot (link_len + 1 slots)
+    uint64_t cell_off;       // first cell record (6 per cell row)
     uint64_t out_off;        // first output character
     // written by the kernel
     uint32_t out_len;
     uint32_t err;            // nonzero: declined (capacity, or an alignment that does not end at both sequence ends)
 };
 void launch_lq_msa(LqPileDev *piles, const LqPieceDev *pieces, const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops,
-                   const uint32_t *pool, uint32_t *cell_bpp, uint32_t *cell_blink, uint32_t *col_row0, uint32_t *col_cov,
-                   char *out_chars, int n_piles, void *stream);
+                   const uint32_t *pool, uint32_t *cell_rec, char *out_chars, int n_piles, void *stream);
 
 // ---- scoring DP (K10), segment-parallel: see the head comment of the K10 section in msa_kernels.hip ----
 struct SegItem {            // work item of the segment kernel
