@@ -168,12 +168,14 @@ def parity_block(ref, gpu_full, piles):
             "device_out_of_memory_seeds": sum(1 for i in ref if gpu_full[i][0] == 3), "mismatches": bad[:8]}
 
 
-def cpu_baseline_overlap(rs_dev, preset):
-    """Reference overlapper (oracle/_ref/minimap2-nd --step 1 -t cores) on the same read set: the whole
-    all-vs-all job (it finishes in seconds on the host cores), wall time including its index build."""
+def cpu_baseline_overlap(rs_dev, preset, device_records=None):
+    """Reference overlapper (oracle/_ref/minimap2-nd --step 1 -I 3G -t cores, the seed x seed job of nextDenovo:456-464) on the
+    same read set: the whole all-vs-all job, wall time including its index build; with `device_records` (what the device's stage
+    produced for the same job) also whether the two `.ovl` byte streams are the same."""
+    import hashlib
     import subprocess
     import tempfile
-    from nextdenovo_amd import ovl
+    from nextdenovo_amd import ovl, overlap
     exe = os.path.join(ROOT, "oracle", "_ref", "minimap2-nd")
     if not os.path.exists(exe):
         return None
@@ -183,16 +185,25 @@ def cpu_baseline_overlap(rs_dev, preset):
     ovl.write_2bit(p, rs_dev.ids, rs_dev.lens, rs_dev.words, rs_dev.word_off)
     out = os.path.join(wd, "ref.ovl")
     t0 = time.perf_counter()
-    subprocess.run([exe, "--step", "1", "-t", str(cores), "-x", preset, p, p, "-o", out], check=True,
+    subprocess.run([exe, "--step", "1", "-I", "3G", "-t", str(cores), "-x", preset, p, p, "-o", out], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     dt = time.perf_counter() - t0
     nbytes = os.path.getsize(out)
     bases = int(rs_dev.lens.sum())
+    res = {"value": bases / dt, "unit": "query bases/s", "cores": cores, "kind": "reference", "wall_s": dt, "ovl_bytes": nbytes,
+           "sample": "whole read set (%d reads, %d bases) all-vs-all, compiled reference minimap2-nd --step 1 -I 3G -t %d -x %s"
+                     % (len(rs_dev), bases, cores, preset)}
+    if device_records is not None:
+        h = hashlib.md5()
+        with open(out, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        mine = overlap.encode(device_records, np.zeros(2, dtype=np.uint32))
+        res["device_ovl_bytes"] = len(mine)
+        res["device_ovl_identical"] = len(mine) == nbytes and hashlib.md5(mine).hexdigest() == h.hexdigest()
     for f in (p, out):
         os.remove(f)
-    return {"value": bases / dt, "unit": "query bases/s", "cores": cores, "kind": "reference", "wall_s": dt, "ovl_bytes": nbytes,
-            "sample": "whole read set (%d reads, %d bases) all-vs-all, compiled reference minimap2-nd --step 1 -t %d -x %s"
-                      % (len(rs_dev), bases, cores, preset)}
+    return res
 
 
 def reduce_over_ranks(dist, torch, bases: int, dt: float, device, seeds: int = 0):
@@ -436,10 +447,13 @@ def main():
                 full = db.correct_piles(recs, off, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads)
                 out["parity"] = parity_block(ref, full, piles)
                 parity_fail = out["parity"]["mismatch"] != 0
-            if not args.no_overlap and n_files == 1 and args.config == 2:
+            if not args.no_overlap and n_files == 1 and args.config in (2, 3):
                 from nextdenovo_amd import overlap
+                files = sh.overlaps(my_file)   # (untimed) the records of the one raw_align job of this layout: seed file x itself
                 out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(
-                    overlap.ReadSet(np.arange(len(rs), dtype=np.uint32), lens, words, word_off), preset)
+                    overlap.ReadSet(np.arange(len(rs), dtype=np.uint32), lens, words, word_off), preset, files[0] if len(files) == 1 else None)
+                if out["overlap"]["cpu_baseline"] and out["overlap"]["cpu_baseline"].get("device_ovl_identical") is False:
+                    parity_fail = True
         print(json.dumps(out))
         if parity_fail:
             db.close()

@@ -968,7 +968,6 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.stats.tasks += nt;
     const uint64_t tc2 = wall_ns();
 
-    bool need_wide = false;
     for (size_t i = 0; i < nt; i++) {
         const AlnOut &o = S.h_outs.p[i];
         S.stats.cells += (uint64_t)o.cells;
@@ -979,14 +978,19 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
             S.stats.trace_bits += (uint64_t)o.cells;
             S.stats.columns += (uint64_t)o.n_cols;
         }
-        if (o.status == ST_NEED_WIDE) need_wide = true;
     }
-    // (an alignment whose live band left the register path: K12 saw it as unaligned, so its pile must go the host way, where
-    // run_chunk reruns it in the wide kernel; rare enough to send the whole call there)
     for (size_t r = 0; r < n; r++) {
         LqRound &R = *rounds[r];
         S.stats.lq_rounds++;
         const LqPileDev &P = piles[r];
+        // (an alignment whose live band left the register path: K12 saw it as unaligned, so its pile goes the host way, where
+        // run_chunk reruns it in the wide kernel)
+        bool need_wide = false;
+        if (usable[r])
+            for (uint32_t k = 0; k < 30u * P.n_regions && !need_wide; k++) {
+                const int32_t t = pieces[P.first_piece + k].task;
+                need_wide = t >= 0 && S.h_outs.p[t].status == ST_NEED_WIDE;
+            }
         if (!usable[r] || need_wide || P.err != 0) {
             S.stats.lq_declined++;
             static const bool trace = getenv("NDGPU_TRACE") != nullptr;
