@@ -182,6 +182,9 @@ void ndgpu_reset_stats(void);
  * (another thread inside nextCorrect / ndgpu_correct_*) keeps its buffers and is skipped.  Returns the bytes released; buffers
  * are re-created on demand. */
 uint64_t ndgpu_release_memory(void);
+/* Device bytes the consensus contexts must leave free when they size their buffers (the memory plan of every batch call subtracts
+ * them from what is free): what another stage on the same device -- the overlap stage of the next seed file -- will need again. */
+void ndgpu_reserve_device_memory(uint64_t bytes);
 /* Number of HIP devices visible (0 if none); does not create a context. */
 int ndgpu_device_count(void);
 

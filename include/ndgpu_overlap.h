@@ -115,6 +115,9 @@ int ndgpu_ovl_last_error(void);
  * NDGPU_OVL_POOL_GB if set); this releases them.
  * Returns the bytes released. */
 uint64_t ndgpu_ovl_trim(void);
+/* out[0] = device bytes the library has in use now, out[1] = cached for reuse, out[2] = the most it ever had in use at once -- what a
+ * caller that runs another memory-hungry stage on the same device between two calls should leave free (out[2] - out[1]). */
+void ndgpu_ovl_pool_bytes(uint64_t out[3]);
 
 /* ---- overlap sort / filter: the `ovl_sort` program between the two stages (util/ovl_sort.c, raw reads, no -H) ----
  *

@@ -216,6 +216,14 @@ def release_device_memory() -> int:
     return int(lib.ndgpu_release_memory())
 
 
+def reserve_device_memory(n_bytes: int):
+    """Device bytes every later consensus call leaves free (ndgpu_reserve_device_memory)."""
+    lib = load()
+    lib.ndgpu_reserve_device_memory.argtypes = [C.c_uint64]
+    lib.ndgpu_reserve_device_memory.restype = None
+    lib.ndgpu_reserve_device_memory(int(max(0, n_bytes)))
+
+
 def reset_stats():
     load().ndgpu_reset_stats()
 

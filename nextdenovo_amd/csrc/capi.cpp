@@ -651,6 +651,8 @@ uint64_t ndgpu_release_memory(void) {
     return f1 > f0 ? (uint64_t)(f1 - f0) : 0;
 }
 
+void ndgpu_reserve_device_memory(uint64_t bytes) { DeviceAligner::reserve_device_memory(bytes); }
+
 int ndgpu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -474,13 +474,17 @@ bool DeviceAligner::release_memory_if_idle() {
 // (the overlap library's cache, the read DB and everything else stay where they are) plus what the contexts already
 // hold: per context a trace budget (the forward / traceback chunk size) and a budget of alignment columns per sub-batch
 // (~40 bytes of tags, column indexes, link tables and cell tables per column, growth slack included).
+static std::atomic<unsigned long long> g_reserved_bytes{0};
+void DeviceAligner::reserve_device_memory(uint64_t bytes) { g_reserved_bytes = bytes; }
+
 void DeviceAligner::plan_memory(int drivers, uint64_t *tag_budget) {
     size_t free_b = 0, total_b = 0;
     const int dev = context(0).device();
     (void)hipSetDevice(dev);
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
     const long long held = g_dev_bytes.load();
-    long long avail = (long long)free_b + held - (long long)((size_t)10 << 30);  // headroom: runtime, pinned staging, the next overlap stage's growth
+    long long avail = (long long)free_b + held - (long long)((size_t)10 << 30)   // headroom: runtime, pinned staging
+                      - (long long)g_reserved_bytes.load();                      // what the caller's other stage will need again
     if (const char *e = getenv("NDGPU_DEVICE_BUDGET_GB")) avail = std::min<long long>(avail, (long long)(atof(e) * (double)(1ull << 30)));
     if (avail < ((long long)4 << 30)) avail = (long long)4 << 30;
     const long long per_ctx = avail / std::max(1, drivers);

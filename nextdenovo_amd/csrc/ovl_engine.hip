@@ -87,6 +87,7 @@ void *pool_alloc(size_t bytes)
 // bounded by the library's own working set: live + cached bytes stay below 1.25 x the most that was ever live at once
 // (and below NDGPU_OVL_POOL_GB if that is set); what comes back beyond it is freed at once.
 int last_error_take() { return g_last_error.exchange(0); }
+void note_oom() { g_last_error = 1; }
 
 static size_t pool_cap()
 {
@@ -119,8 +120,11 @@ void pool_trim()
 }
 
 size_t pool_cached_bytes() { std::lock_guard<std::mutex> g(g_pool_mu); return g_pool_cached; }
+void pool_bytes(uint64_t out[3]) { std::lock_guard<std::mutex> g(g_pool_mu); out[0] = g_pool_live, out[1] = g_pool_cached, out[2] = g_pool_peak; }
 
-#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[ndgpu_overlap] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); throw std::runtime_error("hip"); } } while (0)
+// (a device filled to the brim makes the runtime's own allocations fail too -- launch arguments, staging: "out of memory" may
+// surface at any call; it is reported as what it is, so that the caller can release memory and try again)
+#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[ndgpu_overlap] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); if (_e == hipErrorOutOfMemory) { ndovl::note_oom(); (void)hipGetLastError(); } throw std::runtime_error("hip"); } } while (0)
 
 template <class T> struct DevBuf {
 	T *p = nullptr;
@@ -957,6 +961,9 @@ void ndgpu_ovl_free(void *p) { free(p); }
 // 1 if an entry point has failed for lack of device memory since the last call of this function (the caller may free
 // memory and try again), 2 for another allocation error, 0 otherwise; reading it clears it
 int ndgpu_ovl_last_error(void) { return ndovl::last_error_take(); }
+
+// device bytes of the library's block pool: in use now, cached for reuse, the most that ever were in use at once
+void ndgpu_ovl_pool_bytes(uint64_t out[3]) { ndovl::pool_bytes(out); }
 
 // release the device blocks the library keeps cached between calls (returns the bytes released)
 uint64_t ndgpu_ovl_trim(void)

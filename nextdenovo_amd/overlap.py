@@ -253,6 +253,16 @@ class Index:
         self.lib.ndgpu_ovl_reset_stats(self.h)
 
 
+def pool_bytes():
+    """(in use, cached, peak in use) device bytes of the overlap library's block pool."""
+    lib = load()
+    out = (C.c_uint64 * 3)()
+    lib.ndgpu_ovl_pool_bytes.argtypes = [C.c_void_p]
+    lib.ndgpu_ovl_pool_bytes.restype = None
+    lib.ndgpu_ovl_pool_bytes(out)
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def trim() -> int:
     """Release the device blocks the overlap library keeps cached between calls (ndgpu_ovl_trim)."""
     lib = load()

@@ -152,4 +152,10 @@ class Shard:
         self.stats["sort_s"] += t1 - t0
         self.stats["assemble_s"] += time.perf_counter() - t1
         self.sort_stats = sst
+        if isinstance(self.backend, DeviceBackend):
+            # the consensus contexts size their (grow-only) buffers from what is free when they are called: leave the overlap stage
+            # of the next seed file what this one needed beyond what the library still has cached
+            from . import api
+            _live, cached, peak = overlap.pool_bytes()
+            api.reserve_device_memory(max(0, peak - cached))
         return sub, off, seeds, len(bl)
