@@ -226,6 +226,7 @@ struct Regs {
 	const uint32_t *want;
 	bool nameless;                  // mm_map(..., qname = 0)
 	std::vector<uint32_t> *counts;  // hits of every query read
+	uint64_t *max_anchors;          // (may be null) the most anchors any one read had
 };
 
 struct Engine {
@@ -445,7 +446,7 @@ static const char *check_opt(const ndgpu_ovl_opt &o)
 	if (o.min_cnt < 2) return "min_cnt must be >= 2";
 	if (o.max_chain_iter < 1 || o.max_chain_iter >= 8192) return "max_chain_iter must be in 1..8191";
 	if (o.max_gap < 0 || o.bw < 0) return "negative max_gap / bw";
-	if (o.step == 2 && o.mode != 0 && o.mode != 2) return "--step 2 is built for --mode 0 (no re-alignment) and --mode 2 (the default)";
+	if (o.step == 2 && (o.mode < 0 || o.mode > 2)) return "--step 2 is built for --mode 0 (no re-alignment), 1 and 2 (the default)";
 	return nullptr;
 }
 
@@ -509,6 +510,12 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	r_aoff_all.download(h_raoff.data(), n_q + 1, stream);
 	S.off.download(h_moff.data(), n_q + 1, stream);
 	HIP_OK(hipGetLastError());
+	if (regs && regs->max_anchors) {
+		HIP_OK(hipStreamSynchronize(stream));
+		uint64_t m = 0;
+		for (uint32_t i = 0; i < n_q; ++i) m = std::max<uint64_t>(m, h_raoff[i + 1] - h_raoff[i]);
+		*regs->max_anchors = m;
+	}
 	st.seed_ms += tm.stop();
 	st.anchors += total_a;
 
@@ -851,15 +858,16 @@ int64_t ndgpu_ovl_map(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_
 // --step 2's marking and re-alignment (minimap2/map.c:997-1126), which run on the host (csrc/ovl_step2.cpp).
 int64_t ndgpu_ovl_map_regs(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
                            uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, const uint64_t *want_off,
-                           const uint32_t *want, int nameless, ndgpu_ovl_rec **recs, uint32_t **counts)
+                           const uint32_t *want, int nameless, ndgpu_ovl_rec **recs, uint32_t **counts, uint64_t *max_anchors)
 {
 	*recs = nullptr, *counts = nullptr;
+	if (max_anchors) *max_anchors = 0;
 	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return -1; }
 	try {
 		HIP_OK(hipSetDevice(h->e.device));
 		std::vector<OvlRec> out;
 		std::vector<uint32_t> cnt;
-		const Regs rg{want_off, want, nameless != 0, &cnt};
+		const Regs rg{want_off, want, nameless != 0, &cnt, max_anchors};
 		int64_t n = h->e.map(*opt, mid_occ, n_reads, words, n_words, word_off, lens, ids, out, nullptr, &rg);
 		if (n < 0) return n;
 		if (cnt.size() != n_reads) cnt.resize(n_reads, 0u);

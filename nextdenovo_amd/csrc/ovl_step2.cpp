@@ -354,10 +354,11 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
                                const uint32_t *q_ids, ndgpu_ovl_rec10 **recs)
 {
 	*recs = nullptr;
-	if (opt->step != 2 || opt->mode != 2 || cn < 1) return -1;
+	if (opt->step != 2 || (opt->mode != 2 && opt->mode != 1) || cn < 1) return -1;
+	const int one_read_below = opt->mode == 2 ? 200 : 20;  // map.c:1032
 	ndgpu_ovl_rec *raw = nullptr;
 	uint32_t *cnt = nullptr;
-	const int64_t n_raw = ndgpu_ovl_map_regs(idx, opt, mid_occ, n_q, q_words, q_n_words, q_word_off, q_lens, q_ids, nullptr, nullptr, 0, &raw, &cnt);
+	const int64_t n_raw = ndgpu_ovl_map_regs(idx, opt, mid_occ, n_q, q_words, q_n_words, q_word_off, q_lens, q_ids, nullptr, nullptr, 0, &raw, &cnt, nullptr);
 	if (n_raw < 0) return n_raw;
 	try {
 		std::vector<Reg> R((size_t)n_raw);
@@ -402,7 +403,7 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 			for (int k = 0; k < n; ++k) first[r0[k].rid] = -1;
 			plan[i].c = c, plan[i].seq_index = seq_index;
 			if (c >= (int)kMaxCon) continue;
-			if (seq_index < 200) {
+			if (seq_index < one_read_below) {
 				for (int k = 0; k < n; ++k)
 					if (r0[k].mlen == 2) ua.push_back(UnitA{i, off[i] + (uint64_t)k});
 			} else {
@@ -425,6 +426,7 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 		const uint64_t kBases = 1500000000ull;
 		ndgpu_ovl_opt ro = *opt;
 		std::vector<std::vector<Reg>> res_a(ua.size()), res_b(ub.size());
+		uint64_t most_anchors = 0;
 		auto run_units = [&](ndgpu_ovl_index *ix, size_t n_units, auto seq_of, auto want_of, auto store) -> int {
 			size_t u0 = 0;
 			while (u0 < n_units) {
@@ -442,9 +444,11 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 				}
 				ndgpu_ovl_rec *rr = nullptr;
 				uint32_t *rc = nullptr;
+				uint64_t ma = 0;
 				const int64_t nn = ndgpu_ovl_map_regs(ix, &ro, mid_occ, m, seq_of.words, seq_of.n_words, woff.data(), lens.data(), ids.data(), want_off.data(),
-				                                      want.data(), 1, &rr, &rc);
+				                                      want.data(), 1, &rr, &rc, &ma);
 				if (nn < 0) return (int)nn;
+				most_anchors = std::max(most_anchors, ma);
 				uint64_t at = 0;
 				for (uint32_t j = 0; j < m; ++j) {
 					std::vector<Reg> v(rc[j]);
@@ -468,6 +472,12 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 		int rc0 = run_units(q_mini, ua.size(), seq_t, [&](size_t u, std::vector<uint32_t> &w) { w.push_back(ua[u].q); },
 		                    [&](size_t u, std::vector<Reg> &&v) { res_a[u] = std::move(v); });
 		if (rc0 < 0) return rc0;
+		if (opt->mode == 1 && most_anchors > 100000) {
+			fprintf(stderr, "[ndgpu_overlap] --step 2 --mode 1: a candidate has %llu anchors against its query's one-read index; beyond 100,000 the "
+			                "reference thins the anchors first (mm_chain_dp_nextdenovo, minimap2/chain.c:185-226), which is not built\n",
+			        (unsigned long long)most_anchors);
+			return -3;
+		}
 		rc0 = run_units(t_mini, ub.size(), seq_q, [&](size_t u, std::vector<uint32_t> &w) { w.insert(w.end(), want_b.begin() + ub[u].w0, want_b.begin() + ub[u].w1); },
 		                [&](size_t u, std::vector<Reg> &&v) { res_b[u] = std::move(v); });
 		if (rc0 < 0) return rc0;
@@ -480,7 +490,7 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 			const int n = (int)(off[i + 1] - off[i]);
 			const uint32_t ql = q_lens[i];
 			int c = plan[i].c;
-			if (c < (int)kMaxCon && plan[i].seq_index < 200) {
+			if (c < (int)kMaxCon && plan[i].seq_index < one_read_below) {
 				bool stop = false;
 				for (; ia < ua.size() && ua[ia].q == i; ++ia) {
 					if (stop) continue;

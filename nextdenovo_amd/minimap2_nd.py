@@ -14,8 +14,9 @@ mm_idx_gen does with -I (index.c:284-287,351-360), the occurrence threshold come
 with `--mode 0`.  `--mode 3` (HiFi: chain ends trimmed, every hit extended into the unaligned read ends, minimap2/map.c:340-482) is built in.
 `--step 2` is the `cns_align` command of nextDenovo:356-366 on corrected reads: FASTA input with numeric names; the hits of every
 read on the device, the per-target marking, the re-alignment's bookkeeping (its mapping passes run on the device again), the record
-filters, the dovetail / contained filter, the 10-field encoder and the `.bl` table on the host (csrc/ovl_step2.cpp).  --mode 1
-(mm_map_nextdenovo1, a chaining variant of its own) is not built.
+filters, the dovetail / contained filter, the 10-field encoder and the `.bl` table on the host (csrc/ovl_step2.cpp).  `--mode 1` too
+(the two forms of the re-alignment switch at 20 candidates instead of 200, --cn 50), short of the anchor thinning its chaining
+applies to mappings with more than 100,000 anchors (refused when one occurs).
 Options of other paths (-a, -c, --step 3) are rejected, not approximated.
 """
 from __future__ import annotations
@@ -169,9 +170,13 @@ def build_opt(a: Args) -> overlap.Opt:
             raise SystemExit("[ERROR] option %s is outside the --step 1 overlap path of this engine" % name)
     if a.step not in (1, 2):
         raise SystemExit("[ERROR] --step 1 or --step 2 is required")
-    if a.step == 2 and opt.mode not in (0, 2):
-        raise SystemExit("[ERROR] --step 2 is built for --mode 2 (the default: every marked candidate mapped again) and --mode 0 (no "
-                         "re-alignment); --mode %d is not" % opt.mode)
+    if a.step == 2 and opt.mode not in (0, 1, 2):
+        raise SystemExit("[ERROR] --step 2 runs with --mode 2 (the default: every marked candidate mapped again), 1 or 0 (no re-alignment); "
+                         "--mode 3 belongs to --step 1")
+    if a.step == 2 and opt.mode == 1:   # main.c:455-457
+        opt.minide = max(opt.minide, 0.01)
+        if a.cn == 20:
+            a.cn = 50
     if a.step == 2 and not a.out:
         raise SystemExit("[ERROR] --step 2 needs -o FILE (the .bl table is written next to it, main.c:262-272)")
     return opt
@@ -227,7 +232,7 @@ def run(argv) -> int:
     try:
         if flt:
             out.write(b"\x00\xff")  # init_ovl_mode(stdout, 10), lib/ovl.c:70-75
-        realign = a.step == 2 and opt.mode == 2
+        realign = a.step == 2 and opt.mode in (1, 2)
         mini_opt, q_minis = None, {}
         if realign:  # the re-alignment's indexes use the short k-mer sketch (--kn 17 --wn 10, main.c:197), hpc as the preset's
             mini_opt = overlap.Opt.from_buffer_copy(opt)

@@ -75,7 +75,7 @@ def _bind(lib):
     lib.ndgpu_ovl_reset_stats.argtypes = [P]
     lib.ndgpu_ovl_map2.argtypes = lib.ndgpu_ovl_map.argtypes
     lib.ndgpu_ovl_map2.restype = C.c_int64
-    lib.ndgpu_ovl_map_regs.argtypes = [P, C.POINTER(Opt), C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, P, P, C.c_int, C.POINTER(P), C.POINTER(P)]
+    lib.ndgpu_ovl_map_regs.argtypes = [P, C.POINTER(Opt), C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, P, P, C.c_int, C.POINTER(P), C.POINTER(P), P]
     lib.ndgpu_ovl_map_regs.restype = C.c_int64
     lib.ndgpu_ovl_map2_realign.argtypes = [P, P, P, C.POINTER(Opt), C.c_int32, C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, C.c_uint32, P, C.c_uint64,
                                            P, P, P, C.POINTER(P)]
@@ -219,7 +219,7 @@ class Index:
         wa = None if want is None else np.ascontiguousarray(want, dtype=np.uint32)
         n = self.lib.ndgpu_ovl_map_regs(self.h, C.byref(opt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off), _ptr(rs.lens),
                                         _ptr(rs.ids), None if wo is None else _ptr(wo), None if wa is None else _ptr(wa), 1 if nameless else 0,
-                                        C.byref(recs), C.byref(cnt))
+                                        C.byref(recs), C.byref(cnt), None)
         if n < 0:
             raise _fail(self.lib, "ndgpu_ovl_map_regs failed (%d)" % n)
         return _take(self.lib, recs, n, REC), _take(self.lib, cnt, len(rs), np.uint32)

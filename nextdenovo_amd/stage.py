@@ -156,6 +156,7 @@ class Shard:
             # the consensus contexts size their (grow-only) buffers from what is free when they are called: leave the overlap stage
             # of the next seed file what this one needed beyond what the library still has cached
             from . import api
+            # (+ a margin for what the overlap stage takes outside its block pool: scratch of spilling kernels, rocPRIM, the runtime)
             _live, cached, peak = overlap.pool_bytes()
-            api.reserve_device_memory(max(0, peak - cached))
+            api.reserve_device_memory(max(0, peak - cached) + max(32 << 30, peak // 4))
         return sub, off, seeds, len(bl)

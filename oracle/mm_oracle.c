@@ -592,6 +592,8 @@ int nd_mm_map_read(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uin
 
 static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, const char *qname, const uint8_t *qcodes, int qlen,
                           nd_mm_reg *regs, int reg_cap, int mode3);
+static int64_t g_s2_unrestated; /* (defined with the --step 2 re-alignment below) */
+static int g_count_big_maps;
 
 static int map_read_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
                          nd_mm_reg *regs, int reg_cap, int mode3)
@@ -620,6 +622,7 @@ static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_o
 	}
 	a = (nd_mm128*)malloc(sizeof(nd_mm128) * (n_a > 0 ? n_a : 1));
 	n_a = nd_mm_seeds(ix, opt, qname, qlen, mid_occ, mv, n_mv, a, 1);
+	if (g_count_big_maps && n_a > 100000) g_s2_unrestated++;
 	u = (uint64_t*)malloc(8 * (n_a > 0 ? n_a : 1));
 	n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
 	n = n_u <= reg_cap ? n_u : -n_u;
@@ -877,7 +880,11 @@ static int update_regs(nd_mm_reg *reg_new, int n_reg_new, nd_mm_reg *reg, int s,
 	return c;
 }
 
-/* The re-alignment of `--step 2` (worker_for, map.c:1031-1126; --mode 2 is what the pipeline runs: options.c:56, nextDenovo:361-364).
+/* The re-alignment of `--step 2` (worker_for, map.c:1031-1126; --mode 2 is what the pipeline runs: options.c:56, nextDenovo:361-364;
+ * --mode 1 differs in the threshold between the two forms -- 20 candidates instead of 200 -- in its defaults (--cn 50, --minide >=
+ * 0.01, main.c:455-457) and in that the one-read-index form chains with mm_chain_dp_nextdenovo (chain.c:164-), which is mm_chain_dp
+ * unless a mapping has more than 100,000 anchors: then it first drops anchors of over-represented positions.  That branch is NOT
+ * restated: nd_mm_step2_unrestated() counts the mappings it would have applied to, and a test that sees one must not trust the result).
  * Every hit the marking left with mlen == 2 is mapped again with the short k-mer sketch (kn, wn: main.c:197):
  *   fewer than 200 candidates: the QUERY read becomes a one-read index (mm_idx_str_nextdenovo3) and every candidate target is
  *     mapped against it (mm_map, no name); of its first ten hits the first one nearly as long as the best that passes
@@ -886,17 +893,22 @@ static int update_regs(nd_mm_reg *reg_new, int n_reg_new, nd_mm_reg *reg, int s,
  *     against each batch, the hits are sorted by their target's number in the batch and update_reg_nextdenovo picks per target.
  * Two hits that say "the query is contained" (MAX_CON) end it.  `c` comes in from the marking. */
 static int64_t g_s2_one_read_index, g_s2_batched; /* queries re-aligned either way (test instrumentation) */
+static int64_t g_s2_unrestated;                   /* --mode 1 mappings with more than 100,000 anchors (see realign) */
 void nd_mm_step2_counters(int64_t out[2]) { out[0] = g_s2_one_read_index, out[1] = g_s2_batched; g_s2_one_read_index = g_s2_batched = 0; }
+int64_t nd_mm_step2_unrestated(void) { int64_t n = g_s2_unrestated; g_s2_unrestated = 0; return n; }
+static int g_count_big_maps; /* set while --mode 1 maps a candidate against the query's one-read index */
 
-static void realign_mode2(const nd_mm_index *ix, const nd_mm_opt *opt, int kn, int wn, int cn, int mid_occ, const uint8_t *tcodes,
+static void realign_mode2(const nd_mm_index *ix, const nd_mm_opt *opt, int mode, int kn, int wn, int cn, int mid_occ, const uint8_t *tcodes,
                           const uint64_t *toff, const uint8_t *q, int ql, nd_mm_reg *regs, int n_regs, int seq_index, int c)
 {
+	const int one_read_below = mode == 2 ? 200 : 20; /* map.c:1032 */
 	nd_mm_opt mo = *opt;
 	int k, reg_cap = 1 << 14;
 	nd_mm_reg *rn = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * reg_cap);
 	mo.k = kn, mo.w = wn;
-	if (seq_index < 200) g_s2_one_read_index++; else g_s2_batched++;
-	if (seq_index < 200) {
+	if (seq_index < one_read_below) g_s2_one_read_index++; else g_s2_batched++;
+	if (seq_index < one_read_below) {
+		g_count_big_maps = mode == 1;
 		const uint64_t off0 = 0;
 		const uint32_t len0 = (uint32_t)ql, id0 = 0;
 		nd_mm_index *mi = nd_mm_index_build(1, q, &off0, &len0, &id0, wn, kn, opt->hpc);
@@ -926,6 +938,7 @@ static void realign_mode2(const nd_mm_index *ix, const nd_mm_opt *opt, int kn, i
 			if ((uint32_t)r->qs <= (uint32_t)opt->maxhan2 && (uint32_t)r->qe + (uint32_t)opt->maxhan2 >= (uint32_t)ql)
 				if (++c >= 2) break;
 		}
+		g_count_big_maps = 0;
 		nd_mm_index_free(mi);
 	} else {
 		const int per = (int)((float)seq_index / ((seq_index + cn - 1) / cn) + 0.999);
@@ -1018,7 +1031,7 @@ int64_t nd_mm_step2(const nd_mm_opt *opt, int mode, int kn, int wn, int cn, floa
 			}
 		}
 		for (k = 0; k < n_regs; ++k) if (first[regs[k].rid] >= 0) first[regs[k].rid] = -1;
-		if (mode == 2 && c < 2) realign_mode2(ix, opt, kn, wn, cn, mid_occ, tcodes, toff, qcodes + qoff[i], (int)ql, regs, n_regs, seq_index, c);
+		if (mode && c < 2) realign_mode2(ix, opt, mode, kn, wn, cn, mid_occ, tcodes, toff, qcodes + qoff[i], (int)ql, regs, n_regs, seq_index, c);
 		for (k = 0; k < n_regs; ++k) { /* writer, map.c:1296-1330 (outctn off) */
 			const nd_mm_reg *r = &regs[k];
 			const uint32_t tl = ix->len[r->rid];

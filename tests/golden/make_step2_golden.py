@@ -34,6 +34,10 @@ CASES_M2 = [(tag + ".m2", argv) for tag, argv in CASES] + [
 ]
 
 
+# --mode 1: the re-alignment with its own thresholds (20 candidates instead of 200 between its two forms, --cn 50; main.c:455-457)
+CASES_M1 = [("ont.m1", dict(CASES)["ont"]), ("deep.m1", dict(CASES_M2)["deep.m2"])]
+
+
 def files_of(tag):
     if tag.startswith("deep"):
         return ["c.fa.gz", "c.fa.gz"]
@@ -61,7 +65,7 @@ def main():
     with gzip.GzipFile(os.path.join(OUT, "c.fa.gz"), "wb", mtime=0) as f:
         for i, sq in enumerate(rd.seqs):
             f.write(b">%d %d 0.99\n%s\n" % (i + 1, sq.size, synth.codes_to_ascii(sq)))
-    for cases, mode in ((CASES, ("--mode", "0")), (CASES_M2, ())):
+    for cases, mode in ((CASES, ("--mode", "0")), (CASES_M2, ()), (CASES_M1, ("--mode", "1"))):
         for tag, argv in cases:
             out = os.path.join(OUT, tag + ".ovl")
             refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *mode, "-t", "3", *argv,

@@ -107,7 +107,7 @@ def test_oracle_mode3_end_extension_matches_live_reference(lib, sets, extra):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(M.REFDIR, "minimap2-nd")), reason="oracle/_ref not built")
-@pytest.mark.parametrize("mode,genome,depth", [(0, 60000, 28), (2, 60000, 28), (2, 30000, 150)], ids=["mode0", "mode2", "mode2-deep"])
+@pytest.mark.parametrize("mode,genome,depth", [(0, 60000, 28), (2, 60000, 28), (2, 30000, 150), (1, 60000, 28)], ids=["mode0", "mode2", "mode2-deep", "mode1"])
 @pytest.mark.parametrize("preset,extra", [("ava-ont", ("-k", "17", "-w", "17", "--minlen", "1000", "--maxhan1", "2000")),
                                           ("ava-pb", ("-k", "17", "-w", "10", "--minlen", "700", "--maxhan1", "1500", "--maxhan2", "300"))])
 def test_oracle_step2_matches_live_reference(lib, preset, extra, mode, genome, depth):
@@ -143,7 +143,7 @@ def test_oracle_step2_matches_live_reference(lib, preset, extra, mode, genome, d
         off[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
         sets.append((ids, lens, np.concatenate([seqs[i] for i in range(lo, hi)]).astype(np.uint8), off))
     out = os.path.join(wd, "o.ovl")
-    cmd = [os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *(("--mode", "0") if mode == 0 else ()), "--dual=yes", "-t", "3", "-x", preset,
+    cmd = [os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *(("--mode", str(mode)) if mode != 2 else ()), "--dual=yes", "-t", "3", "-x", preset,
            *extra, files[0], files[1], files[0], "-o", out]
     refpipe.run(cmd)
     want, want_bl = open(out, "rb").read(), open(out + ".bl").read()
@@ -151,13 +151,13 @@ def test_oracle_step2_matches_live_reference(lib, preset, extra, mode, genome, d
     for k_, name in (("-k", "k"), ("-w", "w"), ("--minlen", "minlen"), ("--maxhan1", "maxhan1"), ("--maxhan2", "maxhan2")):
         if k_ in extra:
             kw[name] = int(extra[extra.index(k_) + 1])
-    got, got_bl = M.step2(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]], mode)
+    got, got_bl = M.step2(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]], mode, cn=50 if mode == 1 else 20)
     assert len(want) > (3000 if depth < 100 else 1000) and got == want
     assert got_bl == want_bl and want_bl.count("\n") > 20
     if mode:
         cnt = (C.c_int64 * 2)()
         lib.nd_mm_step2_counters(cnt)
-        assert cnt[0] > 20 and (cnt[1] > 20 if depth > 100 else True), list(cnt)   # both forms of the re-alignment ran
+        assert cnt[0] + cnt[1] > 20 and (cnt[1] > 20 if depth > 100 else True), list(cnt)   # both forms of the re-alignment ran
         plain, _ = M.step2(lib, M.preset(preset, True, **kw), sets[0], [sets[1], sets[0]], 0)
         assert plain != got   # the re-alignment really changes records on this set
 
@@ -183,13 +183,13 @@ def _fasta_set(path):
     return (np.asarray(ids, dtype=np.uint32), lens, np.concatenate(arrs).astype(np.uint8), off)
 
 
-@pytest.mark.parametrize("tag", ["ont", "pb", "ont.m2", "pb.m2", "deep.m2"])
+@pytest.mark.parametrize("tag", ["ont", "pb", "ont.m2", "pb.m2", "deep.m2", "ont.m1", "deep.m1"])
 def test_oracle_step2_matches_golden(lib, tag):
     """The step-2 oracle on the committed fixtures of the compiled reference (tests/golden/step2; `.m2`: the command without --mode,
     i.e. with the re-alignment): what the GPU tests of the device path compare with on a box that has no reference."""
     sys.path.insert(0, os.path.join(HERE, "golden"))
-    from make_step2_golden import CASES as S0, CASES_M2, OUT
-    argv = dict(S0 + CASES_M2)[tag]
+    from make_step2_golden import CASES as S0, CASES_M1, CASES_M2, OUT
+    argv = dict(S0 + CASES_M2 + CASES_M1)[tag]
     kw = {}
     for k_, name in (("-k", "k"), ("-w", "w"), ("--minlen", "minlen"), ("--maxhan1", "maxhan1"), ("--maxhan2", "maxhan2")):
         if k_ in argv:
@@ -200,6 +200,9 @@ def test_oracle_step2_matches_golden(lib, tag):
     else:
         a, b = _fasta_set(os.path.join(OUT, "a.fa.gz")), _fasta_set(os.path.join(OUT, "b.fa.gz"))
         qs = [b, a]
-    got, got_bl = M.step2(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, qs, 2 if tag.endswith(".m2") else 0)
+    mode = 2 if tag.endswith(".m2") else 1 if tag.endswith(".m1") else 0
+    got, got_bl = M.step2(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, qs, mode, cn=50 if mode == 1 else 20)
+    lib.nd_mm_step2_unrestated.restype = C.c_int64
+    assert lib.nd_mm_step2_unrestated() == 0   # (no mapping of the fixture takes the branch of mm_chain_dp_nextdenovo that is not restated)
     assert got == open(os.path.join(OUT, tag + ".ovl"), "rb").read()
     assert got_bl == open(os.path.join(OUT, tag + ".ovl.bl")).read()

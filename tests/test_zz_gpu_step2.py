@@ -11,7 +11,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
-from make_step2_golden import CASES, CASES_M2, OUT as GOLD, files_of  # noqa: E402
+from make_step2_golden import CASES, CASES_M1, CASES_M2, OUT as GOLD, files_of  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 def run_case(tag, argv, tmp_path):
     from nextdenovo_amd import minimap2_nd
     out = str(tmp_path / "o.ovl")
-    mode = () if tag.endswith(".m2") else ("--mode", "0")   # `.m2`: the command as nextDenovo writes it (no --mode: the re-alignment)
+    # `.m2`: the command as nextDenovo writes it (no --mode: the re-alignment); `.m1`: --mode 1
+    mode = () if tag.endswith(".m2") else ("--mode", "1") if tag.endswith(".m1") else ("--mode", "0")
     assert minimap2_nd.run(["--step", "2", *mode, "-t", "3", *argv, *[os.path.join(GOLD, f) for f in files_of(tag)], "-o", out]) == 0
     with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
         want = f.read()
@@ -31,7 +32,7 @@ def run_case(tag, argv, tmp_path):
         assert g.read() == f.read()
 
 
-@pytest.mark.parametrize("tag,argv", CASES + CASES_M2, ids=[c[0] for c in CASES + CASES_M2])
+@pytest.mark.parametrize("tag,argv", CASES + CASES_M2 + CASES_M1, ids=[c[0] for c in CASES + CASES_M2 + CASES_M1])
 def test_step2_cli_writes_reference_bytes(tag, argv, tmp_path):
     run_case(tag, argv, tmp_path)
 
