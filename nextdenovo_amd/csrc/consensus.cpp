@@ -281,8 +281,19 @@ int update_lqreg(LqReg *lq, const std::string &seq, unsigned p, int i, unsigned 
 constexpr int kKmerLen = 8, kKmerRange = 40, kKmerBins = 65536, kKmerMaxSeq = 10;
 constexpr int kLqCanMax = 40, kLqSeqMax = 30, kLqRevLen = 2000;
 
-void count_kmers(const LqRegion &lq, uint16_t *bins, int c, int from_tail) {
-    memset(bins, 0, sizeof(uint16_t) * kKmerBins);
+// The 8-mer histogram of the reference lives on the stack and is cleared per call (lib/nextcorrect.c:281-300: 128 KB); a call touches
+// at most 40 x 32 of its 65,536 bins, so the clearing -- three to four times per region, tens of thousands of regions per step -- was
+// gigabytes of memset.  The bins a call touched are remembered and only those are cleared by the next one.
+struct KmerBins {
+    std::vector<uint16_t> v = std::vector<uint16_t>(kKmerBins, 0);
+    std::vector<uint16_t> touched;
+    uint16_t *data() { return v.data(); }
+};
+
+void count_kmers(const LqRegion &lq, KmerBins &kb, int c, int from_tail) {
+    uint16_t *bins = kb.v.data();
+    for (uint16_t t : kb.touched) bins[t] = 0;
+    kb.touched.clear();
     const int lim = std::min(lq.len, c);
     for (int j = 0; j < lim; j++) {
         const LqSeq &s = lq.seqs[j];
@@ -294,7 +305,7 @@ void count_kmers(const LqRegion &lq, uint16_t *bins, int c, int from_tail) {
             if (k) km = (uint16_t)(km << 2 | base_code(s.seq[off + k + kKmerLen - 1]));
             else
                 for (int x = 0; x < kKmerLen; x++) km = (uint16_t)(km << 2 | base_code(s.seq[off + x]));
-            bins[km]++;
+            if (bins[km]++ == 0) kb.touched.push_back(km);
         }
     }
 }
@@ -933,7 +944,7 @@ class PileImpl {
                 if (phase[lq.seqs[j].order].del) dif[j] = 1;
             compact_flagged(lq, dif);
         }
-        std::vector<uint16_t> bins(kKmerBins);
+        KmerBins bins;
         for (LqRegion &lq : regions) {  // :874-984
             if (!lq.len) continue;
             select_most2(lq, lq.len, &s, &k);
@@ -979,7 +990,7 @@ class PileImpl {
                         if (k == lq.len) { lq.len = 0; continue; }
                     }
                 }
-                count_kmers(lq, bins.data(), kLqCanMax, 0);
+                count_kmers(lq, bins, kLqCanMax, 0);
                 count_kscore(lq, bins.data(), 0);
                 unsigned klastscore, kmaxscore;
                 unsigned kmaxlen = lq.seqs[0].len;
@@ -989,7 +1000,7 @@ class PileImpl {
                     uint16_t *sv = saved;
                     if (n_aligned > sizeof(saved) / sizeof(saved[0])) { big.resize(n_aligned); sv = big.data(); }
                     for (j = 0; j < lq.len; j++) sv[lq.seqs[j].order] = lq.seqs[j].kscore;
-                    count_kmers(lq, bins.data(), kLqCanMax, 1);
+                    count_kmers(lq, bins, kLqCanMax, 1);
                     count_kscore(lq, bins.data(), 1);
                     for (j = 0; j < lq.len; j++) lq.seqs[j].kscore = (uint16_t)(lq.seqs[j].kscore + sv[lq.seqs[j].order]);
                 }
@@ -1031,7 +1042,7 @@ class PileImpl {
     // gathered by the backend
     int lqseqs_from_candidates() {
         int max_aln_length = 0;
-        std::vector<uint16_t> bins(kKmerBins);
+        KmerBins bins;
         for (size_t ri = 0; ri < regions.size(); ri++) {
             LqRegion &lq = regions[ri];
             RegionReq &rq = extract.regions[ri];
@@ -1053,10 +1064,10 @@ class PileImpl {
                 lq.len = 0;
                 continue;
             }
-            count_kmers(lq, bins.data(), 1, 0);
+            count_kmers(lq, bins, 1, 0);
             count_kscore(lq, bins.data(), 0);
             sort_by_kscore_desc(lq);
-            count_kmers(lq, bins.data(), kKmerMaxSeq, 0);
+            count_kmers(lq, bins, kKmerMaxSeq, 0);
             count_kscore(lq, bins.data(), 0);
             unsigned klastscore, kmaxscore = lq.seqs[0].kscore;
             unsigned kmaxlen = lq.seqs[0].len, kminlen;
@@ -1070,10 +1081,10 @@ class PileImpl {
                         }
                 }
                 for (int j = 0; j < lq.len; j++) saved[lq.seqs[j].order] = lq.seqs[j].kscore;
-                count_kmers(lq, bins.data(), 1, 1);
+                count_kmers(lq, bins, 1, 1);
                 count_kscore(lq, bins.data(), 1);
                 sort_by_kscore_desc(lq);
-                count_kmers(lq, bins.data(), kKmerMaxSeq, 1);
+                count_kmers(lq, bins, kKmerMaxSeq, 1);
                 count_kscore(lq, bins.data(), 1);
                 for (int j = 0; j < lq.len; j++)
                     lq.seqs[j].kscore = (uint16_t)(lq.seqs[j].kscore + saved[lq.seqs[j].order]);

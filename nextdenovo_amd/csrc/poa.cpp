@@ -42,9 +42,9 @@ struct PEdge {
     uint64_t labels = 0;                    // bit i: sequence i walks this edge
 };
 
-struct Cell {
-    uint16_t px = 0, py = 0;
-    long s = 0;
+struct Cell {   // 8 bytes: the matrix of a 300-node graph and a 300-base sequence is what this function spends its time moving
+    int32_t s;
+    uint16_t px, py;
 };
 
 struct Route {
@@ -162,12 +162,15 @@ void Graph::add_sequence(int seq, const char *s, int len) {
     const int X = (int)nodes.size();
     const int Y = len;
     const size_t W = (size_t)Y + 1;
-    std::vector<Cell> dp((size_t)(X + 1) * W);
+    // (one buffer per thread, not cleared: row 0, column 0 and every interior cell are written before they are read)
+    static thread_local std::vector<Cell> dp_buf;
+    if (dp_buf.size() < (size_t)(X + 1) * W) dp_buf.resize((size_t)(X + 1) * W);
+    Cell *const dp = dp_buf.data();
     auto at = [&](int r, int c) -> Cell & { return dp[(size_t)r * W + c]; };
     std::vector<uint16_t> rank(X);
 
     // dag.c:88-134 boundary scores
-    for (int c = 0; c <= Y; c++) at(0, c).s = c * kGap;
+    for (int c = 0; c <= Y; c++) at(0, c).s = (int32_t)(c * kGap), at(0, c).px = at(0, c).py = 0;
     for (int i = 0; i < X; i++) {
         int v = order[i];
         rank[v] = (uint16_t)i;
@@ -180,25 +183,32 @@ void Graph::add_sequence(int seq, const char *s, int len) {
                 if (t > b) b = t;
             }
         }
-        at(i + 1, 0).s = b + kGap;
+        at(i + 1, 0).s = (int32_t)(b + kGap), at(i + 1, 0).px = at(i + 1, 0).py = 0;
     }
 
     // dag.c:261-300 fill
+    std::vector<int> preds;
     for (int i = 0; i < X; i++) {
         const PNode &nd = nodes[order[i]];
+        preds.clear();
+        for (uint32_t id : nd.in_e) preds.push_back(rank[edges[id].from] + 1);
+        if (preds.empty()) preds.push_back(0);
+        Cell *const row = dp + (size_t)(i + 1) * W;
+        const size_t np = preds.size();
         for (int j = 0; j < Y; j++) {
-            long best = at(i + 1, j).s + kGap;
+            long best = row[j].s + kGap;
             int bx = i + 1, by = j;
-            auto consider = [&](int pr) {
-                long del = at(pr, j + 1).s + kGap;
-                long mat = at(pr, j).s + sub_score(s[j], nd.base);
+            const long sub = sub_score(s[j], nd.base);
+            for (size_t k = 0; k < np; k++) {   // per in-edge in insertion order (score ties: dag.c:284-285)
+                const int pr = preds[k];
+                const Cell *const pw = dp + (size_t)pr * W + j;
+                const long del = pw[1].s + kGap;
+                const long mat = pw[0].s + sub;
                 if (del > best && del >= mat) { best = del; bx = pr; by = j + 1; }
                 else if (mat > best && mat >= del) { best = mat; bx = pr; by = j; }
-            };
-            for (uint32_t id : nd.in_e) consider(rank[edges[id].from] + 1);
-            if (nd.in_e.empty()) consider(0);
-            Cell &c = at(i + 1, j + 1);
-            c.s = best;
+            }
+            Cell &c = row[j + 1];
+            c.s = (int32_t)best;
             c.px = (uint16_t)bx;
             c.py = (uint16_t)by;
         }

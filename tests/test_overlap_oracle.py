@@ -119,6 +119,8 @@ def test_oracle_step2_matches_live_reference(lib, preset, extra, mode, genome, d
     compiled reference."""
     from nextdenovo_amd import synth
     import refpipe
+    if preset == "ava-pb" and (depth > 100 or mode == 1):
+        pytest.skip("the batched form and --mode 1 are pinned live with the ava-ont options (and on the committed golden runs)")
     g = synth.make_genome(genome, seed=61, n_repeats=3 if genome > 20000 else 0, repeat_len=1500)
     rs = synth.simulate_reads(g, depth, "hifi", seed=62, mu=8.6, sigma=0.35, min_len=2500)
     seqs = list(rs.seqs)
