@@ -175,6 +175,7 @@ def cpu_baseline_overlap(rs_dev, preset, device_records=None):
     import hashlib
     import subprocess
     import tempfile
+    import numpy as np
     from nextdenovo_amd import ovl, overlap
     exe = os.path.join(ROOT, "oracle", "_ref", "minimap2-nd")
     if not os.path.exists(exe):
