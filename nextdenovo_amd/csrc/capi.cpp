@@ -446,6 +446,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     for (int c = 1; c < drivers; c++) th.emplace_back(drive, c);
     drive(0);
     for (auto &t : th) t.join();
+    DeviceAligner::level_buffers(drivers);  // (nothing in flight now) no context will have to grow a buffer in the middle of the next call
     if (getenv("NDGPU_TRACE"))
         fprintf(stderr, "[ndgpu trace] correct_piles %d piles in %zu sub-batches: %.1f ms wall | engine build %.1f ms, result take %.1f ms (summed over contexts)\n",
                 n_piles, n_sub, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_call0).count() * 1e-3,

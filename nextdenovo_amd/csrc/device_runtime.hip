@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <string>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -59,6 +60,7 @@ static inline bool oom_injected(size_t bytes) {
     return lim && bytes > lim;
 }
 
+static std::atomic<unsigned long long> g_reserved_bytes{0};  // kept free for the caller's other stage (ndgpu_reserve_device_memory)
 static std::atomic<long long> g_dev_bytes{0};  // device memory held by the grow-only buffers of all contexts
 // The runtime itself allocates on the device (kernel arguments, staging, scratch): a device filled to the last byte makes
 // launches and copies fail where nothing can be done about it.  Allocations that would leave less than this are refused
@@ -72,6 +74,20 @@ static inline hipError_t guarded_malloc(void **p, size_t bytes) {
     return hipMalloc(p, bytes);
 }
 
+// The contexts pull their sub-batches from one queue, so a context may meet a larger sub-batch than it has seen while another
+// context has met it before.  A buffer that has to grow therefore grows to the most ANY context has asked of the buffer of that
+// name: after the first step or two every context holds the sizes of the largest sub-batch and nothing is (re)allocated in steady
+// state -- a hipFree / hipHostMalloc in the middle of a step stalls every queue of the device (seconds, measured).
+static size_t high_water(const char *name, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<std::string, size_t> hw;
+    if (!name || !*name) return bytes;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &v = hw[name];
+    if (bytes > v) v = bytes;
+    return v;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -79,6 +95,7 @@ struct DevBuf {
     const char *name = "";
     void reserve(size_t n) {
         if (n <= cap) return;
+        n = std::max(n, high_water(name, n * sizeof(T)) / sizeof(T));
         if (p) {
             if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] free %s %p\n", name, (void *)p);
             if (!g_debug_nofree) HIP_CHECK(hipFree(p));
@@ -112,6 +129,10 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
     }
+    void level() {  // (while the device is idle) up to what any context has asked of the buffer of this name
+        const size_t want = high_water(name, 0) / sizeof(T);
+        if (want > cap) reserve(want);
+    }
     ~DevBuf() {
         if (p) {
             (void)hipFree(p);
@@ -124,8 +145,10 @@ template <typename T>
 struct PinBuf {
     T *p = nullptr;
     size_t cap = 0;
+    const char *name = "";
     void reserve(size_t n) {
         if (n <= cap) return;
+        n = std::max(n, high_water(name, n * sizeof(T)) / sizeof(T));
         if (p && !g_debug_nofree) HIP_CHECK(hipHostFree(p));
         p = nullptr;
         cap = 0;
@@ -144,6 +167,10 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
+    }
+    void level() {
+        const size_t want = high_water(name, 0) / sizeof(T);
+        if (want > cap) reserve(want);
     }
     ~PinBuf() {
         if (p) (void)hipHostFree(p);
@@ -348,6 +375,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
         }
     }
 #define NDGPU_NAME(x) s_->x.name = #x;
+    NDGPU_NAME(h_ops) NDGPU_NAME(h_outs) NDGPU_NAME(up) NDGPU_NAME(down)
     NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec)
     NDGPU_NAME(d_lq_out)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v)
@@ -463,6 +491,48 @@ void DeviceAligner::release_memory() {
 #undef NDGPU_REL
 }
 
+// After a batch call, with no kernel in flight: every context brings its buffers up to the sizes the largest sub-batch any context
+// met has asked for, so that the next call -- whichever context then meets that sub-batch -- allocates nothing in the middle of
+// a step.  (A context that is out of device memory keeps what it has.)
+void DeviceAligner::level_buffers(int drivers) {
+    for (int c = 0; c < drivers && c < kMaxContexts; c++) {
+        DeviceAligner *d = peek(c);
+        if (!d) continue;
+        State &S = *d->s_;
+        std::lock_guard<std::mutex> lock(S.mu);
+        (void)hipSetDevice(S.device);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+        // (what the memory plan keeps free stays free: headroom + the caller's reservation for its other stage)
+        long long budget = (long long)free_b - (long long)((size_t)10 << 30) - (long long)g_reserved_bytes.load();
+        auto lvl = [&](auto &buf, bool device) {
+            const size_t esz = sizeof(*buf.p);
+            const size_t want = high_water(buf.name, 0) / esz;
+            if (want <= buf.cap) return;
+            const long long growth = (long long)((want + want / 4 + 1024 - buf.cap) * esz);
+            if (device) {
+                if (growth > budget) return;
+                budget -= growth;
+            }
+            buf.level();
+        };
+        try {
+#define NDGPU_LVL(x) lvl(S.x, #x[0] == 'd');
+            NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_out)
+            NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v)
+            NDGPU_LVL(d_ids) NDGPU_LVL(d_reads) NDGPU_LVL(d_piles) NDGPU_LVL(d_read_pile) NDGPU_LVL(d_acc) NDGPU_LVL(d_tags)
+            NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_inscnt) NDGPU_LVL(d_insmax) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
+            NDGPU_LVL(d_cell_start) NDGPU_LVL(d_cell_len) NDGPU_LVL(d_cell_bpp) NDGPU_LVL(d_cell_blink) NDGPU_LVL(d_ent_pp)
+            NDGPU_LVL(d_ent_ppp) NDGPU_LVL(d_ent_cnt) NDGPU_LVL(d_err) NDGPU_LVL(d_cell_best) NDGPU_LVL(d_spec)
+            NDGPU_LVL(d_fin) NDGPU_LVL(d_sums) NDGPU_LVL(d_items) NDGPU_LVL(d_bt_exit) NDGPU_LVL(d_bt_steps) NDGPU_LVL(d_bt_entry)
+            NDGPU_LVL(d_bt_off) NDGPU_LVL(d_path) NDGPU_LVL(d_blocks) NDGPU_LVL(d_regions) NDGPU_LVL(d_strpool) NDGPU_LVL(d_cursor)
+            NDGPU_LVL(h_ops) NDGPU_LVL(h_outs) NDGPU_LVL(up) NDGPU_LVL(down)
+#undef NDGPU_LVL
+        } catch (const DeviceOom &) {
+        }
+    }
+}
+
 bool DeviceAligner::release_memory_if_idle() {
     if (!s_->batch_mu.try_lock()) return false;
     release_memory();
@@ -474,7 +544,6 @@ bool DeviceAligner::release_memory_if_idle() {
 // (the overlap library's cache, the read DB and everything else stay where they are) plus what the contexts already
 // hold: per context a trace budget (the forward / traceback chunk size) and a budget of alignment columns per sub-batch
 // (~40 bytes of tags, column indexes, link tables and cell tables per column, growth slack included).
-static std::atomic<unsigned long long> g_reserved_bytes{0};
 void DeviceAligner::reserve_device_memory(uint64_t bytes) { g_reserved_bytes = bytes; }
 
 void DeviceAligner::plan_memory(int drivers, uint64_t *tag_budget) {

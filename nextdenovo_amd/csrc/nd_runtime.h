@@ -61,6 +61,7 @@ class DeviceAligner {
     static RuntimeStats total_stats();
     // device memory plan of one batch call over `drivers` contexts: sets their trace budgets, returns the column budget of a sub-batch
     static void plan_memory(int drivers, uint64_t *tag_budget);
+    static void level_buffers(int drivers);             // after a batch call: every context up to the largest sizes any context met
     static void reserve_device_memory(uint64_t bytes);  // left free by every later plan (another stage's working set)
     static void reset_all_stats();
     void align_batch(AlnJob **jobs, size_t n);
