@@ -90,6 +90,55 @@ def iter_chunks(path: str, chunk_bases: int = CHUNK_BASES, chunk_recs: int = CHU
         lib.ndgpu_fastx_close(h)
 
 
+def iter_chunks_files(paths, threads: int = 0, depth: int = 4, **kw):
+    """iter_chunks over several files IN ORDER, the files being read (inflated, parsed) by up to `threads` reader threads at the same
+    time -- one gzip stream cannot be split, but input.fofn usually lists many files and the reference reads them one after the
+    other (util/seq_dump.c:60-72).  The native reader releases the interpreter lock, so the threads really run side by side; every
+    file's chunks pass through a bounded queue (`depth` chunks), the consumer sees exactly what the sequential loop would yield."""
+    import queue
+    import threading
+    paths = list(paths)
+    threads = threads or min(len(paths), os.cpu_count() or 1, 8)
+    if threads <= 1 or len(paths) <= 1:
+        for p in paths:
+            yield from iter_chunks(p, **kw)
+        return
+    queues = [queue.Queue(maxsize=depth) for _ in paths]
+    gate = threading.Semaphore(threads)   # files open at the same time
+    stop = threading.Event()
+
+    def reader(i):
+        try:
+            with gate:
+                for chunk in iter_chunks(paths[i], **kw):
+                    while not stop.is_set():
+                        try:
+                            queues[i].put(chunk, timeout=0.2)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+            queues[i].put(None)
+        except BaseException as e:   # handed to the consumer
+            queues[i].put(e)
+
+    workers = [threading.Thread(target=reader, args=(i,), daemon=True) for i in range(len(paths))]
+    for w in workers:
+        w.start()
+    try:
+        for i in range(len(paths)):
+            while True:
+                item = queues[i].get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+    finally:
+        stop.set()
+
+
 def read_records(path: str):
     """The whole file at once: (buffer uint8, [(offset, length)])."""
     bufs, recs, base = [], [], 0
@@ -216,13 +265,10 @@ def run(argv) -> int:
     base = os.path.dirname(fofn) or "."
     with open(fofn) as f:
         lines = f.read().split("\n")
-    for line in lines:
-        if len(line) == 0 or line.startswith("#"):
-            continue
-        path = line if line.startswith("/") else os.path.join(base, line)
-        for chunk in iter_chunks(path):
-            next_id, seed_cnt, part, part_cnt = _put_chunk(chunk, flt, seed_flt, block, seeds, seed_n, part, part_cnt, part_pre, part_idx,
-                                                           next_id, seed_cnt)
+    paths = [line if line.startswith("/") else os.path.join(base, line) for line in lines if len(line) and not line.startswith("#")]
+    for chunk in iter_chunks_files(paths, chunk_bases=CHUNK_BASES, chunk_recs=CHUNK_RECS):
+        next_id, seed_cnt, part, part_cnt = _put_chunk(chunk, flt, seed_flt, block, seeds, seed_n, part, part_cnt, part_pre, part_idx,
+                                                       next_id, seed_cnt)
     for s in seeds:
         s.close()
     part.close()

@@ -224,19 +224,23 @@ def test_native_reader_equals_python_parser_and_streams(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "seq_dump")), reason="oracle/_ref not built")
 @pytest.mark.parametrize("argv", [("-f", "1k", "-s", "3k", "-b", "6k", "-n", "2"), ("-f", "500", "-s", "1001", "-b", "0", "-n", "3")])
-def test_command_file_layout_with_a_stand_in_packer(tmp_path, argv, monkeypatch):
+@pytest.mark.parametrize("n_files", [1, 5])
+def test_command_file_layout_with_a_stand_in_packer(tmp_path, argv, monkeypatch, n_files):
     """The command's file logic -- ids, .idx offsets, seed dealing, part splitting, chunked reading -- without a GPU: the device
     packer is replaced by a numpy one (test-only; exact for ACGT reads) and the files are compared with the compiled reference's."""
     from nextdenovo_amd import overlap, seq_dump, synth
     rng = np.random.default_rng(21)
-    fa = tmp_path / "r.fa"
-    with open(fa, "w") as f:
-        for i in range(40):
-            n = int(rng.integers(200, 9000))
-            s = "".join(rng.choice(list("ACGT"), n))
-            f.write(">r%d\n" % i + "\n".join(s[k:k + 70] for k in range(0, n, 70)) + "\n")
+    paths = []
+    for k_file in range(n_files):   # several files (some gzipped): read side by side by the reader threads, consumed in order
+        fa = tmp_path / ("r%d.fa%s" % (k_file, ".gz" if k_file % 2 else ""))
+        with (gzip.open(fa, "wt") if k_file % 2 else open(fa, "w")) as f:
+            for i in range(40 if n_files == 1 else 12):
+                n = int(rng.integers(200, 9000))
+                s = "".join(rng.choice(list("ACGT"), n))
+                f.write(">r%d_%d\n" % (k_file, i) + "\n".join(s[k:k + 70] for k in range(0, n, 70)) + "\n")
+        paths.append(str(fa))
     fofn = tmp_path / "in.fofn"
-    fofn.write_text(str(fa) + "\n")
+    fofn.write_text("\n".join(paths) + "\n")
 
     def fake_pack(buf, a_off, lens):
         code = np.zeros(256, dtype=np.uint8)
