@@ -863,6 +863,8 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
 // Low-quality-region rounds of a batch of piles on the device: K7 / K8a over every (row, region) alignment, then K12 (lq_msa:
 // linked pseudo-seed, second MSA, DP, walk) -- the column streams stay in HBM, what comes back is each pile's walk string.
 // A round the kernel declines (r->ok stays false) is left to the caller's host path.
+constexpr uint64_t kLqMaxColumns = 12000;  // linked pseudo-seed columns K12 takes per pile (see run_lq)
+
 void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     if (n == 0) return;
     State &S = *s_;
@@ -902,13 +904,21 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
             usable[r] = 0;
             continue;
         }
+        uint64_t link_len = 1, ins_cap = 0;
+        for (uint32_t g = 0; g < nr; g++) link_len += (uint64_t)R.pieces[g].sl + 1;
+        // K12 is one wavefront per pile, ~2 us per cell row, and its launch lasts as long as its longest pile: a pile whose
+        // low-quality regions add up to tens of thousands of columns (repeat-rich genomes: config 3 had K12 launches of 250 ms)
+        // is faster on a host core, next to the others -- it is left to the host path before anything is laid out for it
+        static const uint64_t max_cols = getenv("NDGPU_K12_MAX_COLUMNS") ? strtoull(getenv("NDGPU_K12_MAX_COLUMNS"), nullptr, 10) : kLqMaxColumns;  // (test hook)
+        if (link_len > max_cols) {
+            usable[r] = 0;
+            continue;
+        }
         P.first_piece = (uint32_t)pieces.size();
         P.n_regions = nr;
         P.factor = R.factor;
         P.qv_factor = R.qv_factor;
-        uint64_t link_len = 1, ins_cap = 0;
         std::vector<uint64_t> t_off(nr, ~0ull);  // word offset of every region's pseudo-seed, packed on first use
-        for (uint32_t g = 0; g < nr; g++) link_len += (uint64_t)R.pieces[g].sl + 1;
         for (size_t k = 0; k < R.pieces.size(); k++) {
             const LqRound::Piece &pc = R.pieces[k];
             LqPieceDev d;
@@ -961,7 +971,10 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         out_bytes += P.out_cap;
     }
     const size_t nt = tasks.size();
-    if (nt == 0) return;
+    if (nt == 0) {  // nothing K12 takes in this call: every pile goes the host way
+        S.stats.lq_rounds += n, S.stats.lq_declined += n;
+        return;
+    }
 
     // ---- sequence words (parallel): memcpy of what is packed already, packing of the rest
     std::vector<uint32_t> &pool = S.pool;

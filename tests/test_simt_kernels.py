@@ -148,6 +148,9 @@ def test_lq_rounds_on_the_device_and_on_the_host(simt_lib):
     assert dev["bad"] == [] and dev["lq_rounds"] >= 10 and dev["lq_declined"] == 0, dev
     host = _forced({"NDGPU_LQ_HOST": "1", "SIMT_SCHEDULE": "1"}, stride=1)
     assert host["bad"] == [] and host["lq_rounds"] == 0, host
+    # piles whose low-quality regions add up to more columns than K12 takes go the host way, the others stay on the device
+    mixed = _forced({"NDGPU_K12_MAX_COLUMNS": "150"}, stride=1)
+    assert mixed["bad"] == [] and 0 < mixed["lq_declined"] < mixed["lq_rounds"], mixed
 
 
 def _synth_set(gsize, mu, sigma, seed, depth=30, profile="ont"):
