@@ -236,6 +236,7 @@ struct DeviceAligner::State {
     DevBuf<uint64_t> d_trace;
     DevBuf<int32_t> d_v, d_ids;
     std::vector<int32_t> order;
+    std::vector<uint32_t> order_cls;
     // main-phase state (alive from run_main to end_batch)
     std::mutex batch_mu;
     DevBuf<ReadDev> d_reads;
@@ -863,6 +864,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
 // Low-quality-region rounds of a batch of piles on the device: K7 / K8a over every (row, region) alignment, then K12 (lq_msa:
 // linked pseudo-seed, second MSA, DP, walk) -- the column streams stay in HBM, what comes back is each pile's walk string.
 // A round the kernel declines (r->ok stays false) is left to the caller's host path.
+constexpr uint32_t kLenClasses = 16384;  // 64-base length classes of the longest-first launch order (run_main); the last one holds >= 1 Mb
 constexpr uint64_t kLqMaxColumns = 12000;  // linked pseudo-seed columns K12 takes per pile (see run_lq)
 
 void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
@@ -1251,21 +1253,29 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         size_t a = 0;
         for (size_t b : chunk_end) {
             if (b > a) {
-                HIP_CHECK(hipEventRecord(S.evs[0], st));
                 NDGPU_DBG(st, "main: forward %zu..%zu of %zu tasks, %zu piles", a, b, nt, np);
                 const int32_t *order = nullptr;
                 static const bool lpt = !getenv("NDGPU_K7_NO_ORDER");
-                if (lpt && b - a > 64) {  // longest alignments first (their chains bound the launch)
+                if (lpt && b - a > 64) {
+                    // longest alignments first (their chains bound the launch): a counting sort over 64-base length classes
+                    // -- a sub-batch holds up to a million tasks and this runs on the context's critical path
                     std::vector<int32_t> &ord = S.order;
-                    ord.resize(b - a);
-                    for (size_t i = 0; i < ord.size(); i++) ord[i] = (int32_t)i;
-                    std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
-                        return tasks[a + x].q_len + tasks[a + x].t_len > tasks[a + y].q_len + tasks[a + y].t_len;
-                    });
-                    S.d_ids.reserve(ord.size());
-                    S.h2d(S.d_ids.p, ord.data(), ord.size() * sizeof(int32_t), st);
+                    std::vector<uint32_t> &cls = S.order_cls;
+                    const size_t m = b - a;
+                    ord.resize(m);
+                    cls.assign(kLenClasses + 1, 0);
+                    auto cls_of = [&](size_t i) {
+                        const uint32_t c = ((uint32_t)tasks[a + i].q_len + (uint32_t)tasks[a + i].t_len) >> 6;
+                        return (kLenClasses - 1) - std::min<uint32_t>(c, kLenClasses - 1);  // class 0 = the longest
+                    };
+                    for (size_t i = 0; i < m; i++) cls[cls_of(i) + 1]++;
+                    for (uint32_t c = 0; c < kLenClasses; c++) cls[c + 1] += cls[c];
+                    for (size_t i = 0; i < m; i++) ord[cls[cls_of(i)]++] = (int32_t)i;
+                    S.d_ids.reserve(m);
+                    S.h2d(S.d_ids.p, ord.data(), m * sizeof(int32_t), st);
                     order = S.d_ids.p;
                 }
+                HIP_CHECK(hipEventRecord(S.evs[0], st));
                 launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st, order);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
                 NDGPU_DBG(st, "main: traceback");
