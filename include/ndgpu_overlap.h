@@ -257,6 +257,43 @@ typedef struct ndgpu_ksw_result {
 } ndgpu_ksw_result;
 int ndgpu_ksw_extd2_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res);
 
+/* ---- `minimap2-nd --step 1 -c`: base-level alignment through the chains (off the default correction path: nextDenovo runs
+ *      --step 1 without -c) ----
+ * the scoring side of mm_mapopt_t (minimap.h; defaults mm_mapopt_init, minimap2/options.c:36-43; -A -B -O -E -z -s of main.c) */
+typedef struct ndgpu_ovl_aln_opt {
+	int32_t a, b, q, e, q2, e2, sc_ambi;  /* match, mismatch, gap open / extend of the two pieces, score of a base against N */
+	int32_t zdrop, zdrop_inv, end_bonus;
+	int32_t min_dp_max;                   /* -s: 80 (min_chain_score * a when mm_mapopt_init runs; the ava presets do not touch it) */
+	int32_t min_ksw_len;                  /* 200: anchors closer than this on either read are bridged by the next gap's alignment */
+	int64_t max_sw_mat;                   /* 100000000: a larger problem counts as z-dropped (mm_align_pair, minimap2/align.c:323) */
+	int32_t host_threads;                 /* threads of the bookkeeping between the batches; 0 = all */
+} ndgpu_ovl_aln_opt;
+void ndgpu_ovl_aln_opt_default(ndgpu_ovl_aln_opt *o, int32_t min_chain_score);
+typedef struct ndgpu_ovl_cigar_stats {
+	uint64_t chains, first_pass, second_pass, inversion_tests, inversions, cells, overlaps;
+	/* chains aligned (pieces of split chains included); extension / gap problems of the first pass; gaps aligned again after a
+	 * z-drop; local alignments of the inversion test; inversions looked at; DP cells (query x target) of all problems; records out */
+} ndgpu_ovl_cigar_stats;
+/* array-level view (and the first half of ndgpu_ovl_map_cigar): the chains of every query read as mm_align_skeleton takes them
+ * (minimap2/hit.c:52-85): chains[] in hit order, self hits included, = (strand, index-local target, offset of the first anchor in
+ * the read's anchors, anchor count, chain score, hash, 0, 0); counts[i] = chains of read i; the chained anchors of read i =
+ * ax / ay[a_off[i] .. a_off[i + 1]) in the order of the reference's a[].  Everything malloc'd (ndgpu_ovl_free). */
+int64_t ndgpu_ovl_map_chains(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                             uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, ndgpu_ovl_rec **chains,
+                             uint32_t **counts, uint64_t **ax, uint64_t **ay, uint64_t **a_off);
+/* replaces: mm_map_file() + the step-1 writer WITH MM_F_CIGAR: mm_align_skeleton (minimap2/align.c:857-913: mm_align1 per chain --
+ * left extension, gap filling with the approximate-then-exact z-drop passes, right extension --, z-drop splits, mm_align1_inv,
+ * mm_filter_regs, mm_hit_sort) between chaining and the writer's filter (minimap2/map.c:484-503, 1297-1304).  The records carry the
+ * alignments' coordinates and exact match counts.  t_words / t_word_off / t_lens / t_ids = the reads the index was built from (the
+ * caller's arrays of ndgpu_ovl_index_create).  opt->step must be 1, opt->mode not 3, k <= 28 (the compiled reference aborts on
+ * ava-hifi -c), two different gap pieces (ksw_extd2_sse; with q == q2 and e == e2 the reference takes ksw_extz2_sse, not built).
+ * Every alignment runs on the device (one wavefront per problem, csrc/ksw2_kernels.hip); the joining of CIGARs, the z-drop
+ * bookkeeping and the seed filters are host logic.  *recs is malloc'd (ndgpu_ovl_free).  Returns the record count, < 0 on error. */
+int64_t ndgpu_ovl_map_cigar(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, const ndgpu_ovl_aln_opt *aopt, int32_t mid_occ,
+                            uint32_t n_reads, const uint32_t *words, uint64_t n_words, const uint64_t *word_off, const uint32_t *lens,
+                            const uint32_t *ids, const uint32_t *t_words, const uint64_t *t_word_off, const uint32_t *t_lens,
+                            const uint32_t *t_ids, ndgpu_ovl_rec **recs, ndgpu_ovl_cigar_stats *stats);
+
 void ndgpu_ovl_get_stats(const ndgpu_ovl_index *idx, ndgpu_ovl_stats *st);
 void ndgpu_ovl_reset_stats(ndgpu_ovl_index *idx);
 

@@ -502,3 +502,162 @@ extern "C" void ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen
         free(r.cigar);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ksw_ll_i16 (minimap2/ksw2_ll_sse.c:85-156 with the query profile of ksw_ll_qinit, :32-83, size 2): the local-alignment SCORE
+// behind the inversion test of a z-dropped gap (mm_test_zdrop, minimap2/align.c:71-87) and behind mm_align1_inv (:790-845).
+// It is Farrar's striped Smith-Waterman on eight 16-bit lanes, and its values are those of the striped schedule, not of the
+// textbook recurrence: a vertical gap (E) is opened from H as it stands BEFORE the lazy-F pass, so a cell whose value arrived
+// through an F that crossed a stripe boundary opens no E; the query is padded to a multiple of 8 with zero-score columns that
+// take part in the maximum; of equal maxima the last target row and the last cell in stripe order win.  The kernel therefore runs
+// the schedule itself: one problem per wavefront, lanes 0..7 = the eight stripes (the other lanes idle along so that the
+// wavefront's control flow stays uniform), the H / E / Hmax rows in an HBM scratch slice [segment][stripe].
+namespace {
+
+struct LlJobDev {
+    uint64_t q_off, t_off, h_off;  // codes in the byte pool; 4 x slen x 8 int16 of scratch
+    int32_t qlen, tlen, gapo, gape;
+    int8_t mat[25 + 3];
+};
+struct LlRes { int32_t score, qe, te; };
+
+__device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
+__device__ __forceinline__ int subs_u16(int a, int b) { return a > b ? a - b : 0; }  // _mm_subs_epu16 on values that are never negative
+
+__global__ __launch_bounds__(64) void ksw_ll_kernel(const LlJobDev *__restrict__ jobs, const uint8_t *__restrict__ pool,
+                                                    int16_t *__restrict__ scratch, LlRes *__restrict__ res) {
+    const LlJobDev J = jobs[blockIdx.x];
+    const int lane = (int)threadIdx.x;
+    const bool live = lane < 8;
+    const int slen = (J.qlen + 7) / 8;
+    const uint8_t *query = pool + J.q_off, *target = pool + J.t_off;
+    int16_t *H0 = scratch + J.h_off, *H1 = H0 + (size_t)slen * 8, *E = H1 + (size_t)slen * 8, *Hmax = E + (size_t)slen * 8;
+    const int gapoe = J.gapo + J.gape, gape = J.gape;
+    if (live)
+        for (int j = 0; j < slen; ++j) H0[j * 8 + lane] = 0, E[j * 8 + lane] = 0, Hmax[j * 8 + lane] = 0;
+    __syncthreads();
+    int gmax = 0, te = -1;
+    for (int i = 0; i < J.tlen; ++i) {
+        const int8_t *ma = J.mat + (int)target[i] * 5;
+        int f = 0, mx = 0;
+        int h = live && slen > 0 ? (int)H0[(slen - 1) * 8 + lane] : 0;
+        h = __shfl_up(h, 1, 64);  // _mm_slli_si128(h, 2): stripe k starts from the end of stripe k - 1
+        if (lane == 0) h = 0;
+        for (int j = 0; j < slen; ++j) {
+            const int pos = j + lane * slen;
+            const int sc = live && pos < J.qlen ? (int)ma[query[pos]] : 0;
+            h = sat16(h + sc);
+            int e = live ? (int)E[j * 8 + lane] : 0;
+            h = h > e ? h : e;
+            h = h > f ? h : f;
+            mx = mx > h ? mx : h;
+            if (live) H1[j * 8 + lane] = (int16_t)h;
+            h = subs_u16(h, gapoe);
+            e = subs_u16(e, gape);
+            e = e > h ? e : h;
+            if (live) E[j * 8 + lane] = (int16_t)e;
+            f = subs_u16(f, gape);
+            f = f > h ? f : h;
+            h = live ? (int)H0[j * 8 + lane] : 0;
+        }
+        bool done = false;
+        for (int k = 0; k < 8 && !done; ++k) {  // the lazy-F pass
+            f = __shfl_up(f, 1, 64);
+            if (lane == 0) f = 0;
+            for (int j = 0; j < slen; ++j) {
+                int hh = live ? (int)H1[j * 8 + lane] : 0;
+                hh = hh > f ? hh : f;
+                if (live) H1[j * 8 + lane] = (int16_t)hh;
+                hh = subs_u16(hh, gapoe);
+                f = subs_u16(f, gape);
+                if (!(__ballot(live && f > hh) & 0xffull)) {
+                    done = true;
+                    break;
+                }
+            }
+        }
+        for (int o = 4; o; o >>= 1) {
+            const int v = __shfl_xor(mx, o, 64);
+            mx = mx > v ? mx : v;
+        }
+        const int imax = __shfl(mx, 0, 64);
+        if (imax >= gmax) {
+            gmax = imax, te = i;
+            if (live)
+                for (int j = 0; j < slen; ++j) Hmax[j * 8 + lane] = H1[j * 8 + lane];
+        }
+        int16_t *t = H1;
+        H1 = H0, H0 = t;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int qe = -1;
+        for (int i = 0; i < slen * 8; ++i)
+            if ((int)(uint16_t)Hmax[i] == gmax) qe = i / 8 + i % 8 * slen;
+        LlRes r;
+        r.score = gmax, r.qe = qe, r.te = te;
+        res[blockIdx.x] = r;
+    }
+}
+
+}  // namespace
+
+// a batch of ksw_ll_i16 problems (see above); jobs[i].mat is the 5 x 5 matrix; res[i] = score, query end, target end.  Internal to
+// the library (csrc/ovl_cigar.cpp).  Returns 0, < 0 on error.
+struct ndgpu_ll_job { const uint8_t *query, *target; const int8_t *mat; int32_t qlen, tlen, gapo, gape; };
+struct ndgpu_ll_result { int32_t score, qe, te; };
+int ndgpu_ksw_ll_batch(const ndgpu_ll_job *jobs, int n, ndgpu_ll_result *out) {
+    if (n <= 0) return 0;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        fprintf(stderr, "[ndgpu_overlap] FATAL: no HIP device visible: ksw_ll has no CPU fallback\n");
+        return -1;
+    }
+    int dev = 0;
+    if (const char *e = getenv("NDGPU_DEVICE")) dev = atoi(e) % n_dev;
+    if (!hip_ok(hipSetDevice(dev), "hipSetDevice")) return -1;
+    std::vector<LlJobDev> h((size_t)n);
+    std::vector<uint8_t> pool;
+    uint64_t h_total = 0;
+    for (int i = 0; i < n; i++) {
+        const ndgpu_ll_job &J = jobs[i];
+        if (J.qlen < 0 || J.tlen < 0 || (J.qlen > 0 && !J.query) || (J.tlen > 0 && !J.target) || !J.mat) return -2;
+        LlJobDev &D = h[(size_t)i];
+        memset(&D, 0, sizeof(D));
+        D.qlen = J.qlen, D.tlen = J.tlen, D.gapo = J.gapo, D.gape = J.gape;
+        for (int k = 0; k < 25; k++) D.mat[k] = J.mat[k];
+        for (int k = 0; k < J.qlen; k++)
+            if (J.query[k] > 4) return -2;
+        for (int k = 0; k < J.tlen; k++)
+            if (J.target[k] > 4) return -2;
+        D.q_off = pool.size();
+        pool.insert(pool.end(), J.query, J.query + J.qlen);
+        D.t_off = pool.size();
+        pool.insert(pool.end(), J.target, J.target + J.tlen);
+        D.h_off = h_total;
+        h_total += 4ull * 8ull * (uint64_t)((J.qlen + 7) / 8);
+    }
+    pool.push_back(0);
+    Dev<LlJobDev> d_jobs;
+    Dev<uint8_t> d_pool;
+    Dev<int16_t> d_h;
+    Dev<LlRes> d_res;
+    hipStream_t st = nullptr;
+    bool ok = hip_ok(hipStreamCreate(&st), "hipStreamCreate") && d_jobs.alloc((size_t)n) && d_pool.alloc(pool.size()) && d_h.alloc(h_total + 1) &&
+              d_res.alloc((size_t)n);
+    std::vector<LlRes> r((size_t)n);
+    if (ok) {
+        ok = hip_ok(hipMemcpyAsync(d_pool.p, pool.data(), pool.size(), hipMemcpyHostToDevice, st), "upload") &&
+             hip_ok(hipMemcpyAsync(d_jobs.p, h.data(), sizeof(LlJobDev) * (size_t)n, hipMemcpyHostToDevice, st), "upload");
+        if (ok) {
+            hipLaunchKernelGGL(ksw_ll_kernel, dim3((unsigned)n), dim3(64), 0, st, d_jobs.p, d_pool.p, d_h.p, d_res.p);
+            ok = hip_ok(hipGetLastError(), "launch") &&
+                 hip_ok(hipMemcpyAsync(r.data(), d_res.p, sizeof(LlRes) * (size_t)n, hipMemcpyDeviceToHost, st), "download") &&
+                 hip_ok(hipStreamSynchronize(st), "sync");
+        }
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (!ok) return -1;
+    for (int i = 0; i < n; i++) out[i].score = r[(size_t)i].score, out[i].qe = r[(size_t)i].qe, out[i].te = r[(size_t)i].te;
+    return 0;
+}

@@ -28,6 +28,9 @@ struct OvlParams {
 	int32_t provisional; // K5 stops at the hits themselves (target number, block length and match count in the name / match
 	                     // fields, hit order): the passes of --step 2's re-alignment, whose marking and filters follow on the host
 	int32_t nameless;    // the query has no name (mm_map(..., qname = 0), minimap2/map.c:1052,1088): no self test in K5
+	int32_t chains;      // -c: K5 hands out the chains themselves -- every hit (self hits too, mm_align_skeleton aligns them) as
+	                     // (strand, target, a[] offset, anchor count, chain score, hash) in hit order, and the chained anchors in the
+	                     // order of the reference's a[] (chains by the x of their first anchor, minimap2/chain.c:150-160)
 };
 
 // minimizer index of the target reads, resident in HBM
@@ -124,7 +127,10 @@ void launch_chain_ends(const uint64_t *r_aoff, uint32_t n_reads, const OvlParams
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
                  const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
                  uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
-                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, hipStream_t s);
+                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, uint64_t *cx, uint64_t *cy, uint32_t *n_ca, hipStream_t s);
+// -c: the chained anchors of every read (K5 left n_ca[read] of them at the front of the read's slice of cx / cy), back to back
+void launch_compact_anchors(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *cx, const uint64_t *cy, const uint32_t *n_ca,
+                            const uint64_t *ca_off, uint64_t *dx, uint64_t *dy, hipStream_t s);
 void launch_compact_recs10(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec10 *recs, const uint32_t *n_rec,
                            const uint64_t *rec_off, OvlRec10 *dense, hipStream_t s);
 void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,

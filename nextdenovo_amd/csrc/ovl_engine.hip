@@ -230,6 +230,9 @@ struct Regs {
 	bool nameless;                  // mm_map(..., qname = 0)
 	std::vector<uint32_t> *counts;  // hits of every query read
 	uint64_t *max_anchors;          // (may be null) the most anchors any one read had
+	// -c (ndgpu_ovl_map_chains): the hits are chains -- OvlRec = (strand, target, offset into the read's anchors, anchor count, chain
+	// score, hash, 0, 0) -- and the chained anchors of every read come with them, in the reference's a[] order; null otherwise
+	std::vector<uint64_t> *ca_x = nullptr, *ca_y = nullptr, *ca_off = nullptr;
 };
 
 struct Engine {
@@ -459,7 +462,8 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	OvlParams Pm = to_params(o);
 	Pm.k = P.k, Pm.w = P.w, Pm.hpc = P.hpc; // the sketch parameters belong to the index
 	if (regs) {
-		Pm.provisional = 1, Pm.step2 = 0, Pm.mode3 = 0, Pm.dvt = 0, Pm.nameless = regs->nameless;
+		Pm.provisional = 1, Pm.step2 = 0, Pm.mode3 = 0, Pm.dvt = 0, Pm.nameless = regs->nameless, Pm.chains = regs->ca_x != nullptr;
+		if (regs->ca_x) regs->ca_x->clear(), regs->ca_y->clear(), regs->ca_off->assign(1, 0);
 		if (regs->nameless) Pm.no_diag = Pm.no_dual = 0; // skip_seed looks at names only when there is one (minimap2/map.c:129)
 		regs->counts->clear();
 	}
@@ -540,6 +544,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		++st.batches;
 		if (na == 0) {
 			if (regs) regs->counts->insert(regs->counts->end(), nb, 0u);
+			if (regs && regs->ca_off) regs->ca_off->insert(regs->ca_off->end(), nb, regs->ca_off->back());
 			r0 = r1;
 			continue;
 		}
@@ -640,10 +645,13 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		DevBuf<uint32_t> tables((size_t)nb * 512), n_rec(nb + 1), n_chain(nb);
 		DevBuf<OvlRec> recs(rec_cap);
 		DevBuf<OvlRec10> recs10(P.step2 ? rec_cap : 0);
+		DevBuf<uint64_t> cx(P.chains ? na : 0), cy(P.chains ? na : 0);
+		DevBuf<uint32_t> n_ca(P.chains ? nb + 1 : 0);
 		n_rec.zero(stream);
+		if (P.chains) n_ca.zero(stream);
 		tm.start();
 		launch_hits(r_aoff.p, nb, r0, ax.p, ay.p, ix, qd, P, f.p, p.p, v.p, t.p, u.p, bx.p, by.p, wx.p, wy.p, tables.p, stacks.p, n_end.p,
-		            recs.p, n_rec.p, n_chain.p, recs10.p, stream);
+		            recs.p, n_rec.p, n_chain.p, recs10.p, cx.p, cy.p, n_ca.p, stream);
 		DevBuf<uint64_t> rec_off(nb + 1);
 		tb = 0;
 		exscan_u32_to_u64(nullptr, tb, n_rec.p, rec_off.p, nb + 1, stream);
@@ -658,6 +666,27 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 			n_rec.download(regs->counts->data() + at, nb, stream);
 		}
 		HIP_OK(hipStreamSynchronize(stream));
+		if (P.chains) {
+			DevBuf<uint64_t> ca_off(nb + 1);
+			tb = 0;
+			exscan_u32_to_u64(nullptr, tb, n_ca.p, ca_off.p, nb + 1, stream);
+			exscan_u32_to_u64(temp(tb), tb, n_ca.p, ca_off.p, nb + 1, stream);
+			std::vector<uint64_t> h_off(nb + 1);
+			ca_off.download(h_off.data(), nb + 1, stream);
+			HIP_OK(hipStreamSynchronize(stream));
+			const uint64_t n_c = h_off[nb], base = regs->ca_off->back();
+			DevBuf<uint64_t> dx(n_c + 1), dy(n_c + 1);
+			launch_compact_anchors(r_aoff.p, nb, cx.p, cy.p, n_ca.p, ca_off.p, dx.p, dy.p, stream);
+			HIP_OK(hipGetLastError());
+			const size_t at = regs->ca_x->size();
+			regs->ca_x->resize(at + n_c), regs->ca_y->resize(at + n_c);
+			if (n_c) {
+				HIP_OK(hipMemcpyAsync(regs->ca_x->data() + at, dx.p, n_c * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+				HIP_OK(hipMemcpyAsync(regs->ca_y->data() + at, dy.p, n_c * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+			}
+			HIP_OK(hipStreamSynchronize(stream));
+			for (uint32_t i = 1; i <= nb; ++i) regs->ca_off->push_back(base + h_off[i]);
+		}
 		if (P.step2) {
 			DevBuf<OvlRec10> dense10(n_out + 1);
 			launch_compact_recs10(r_aoff.p, nb, P.min_cnt, recs10.p, n_rec.p, rec_off.p, dense10.p, stream);
@@ -878,6 +907,44 @@ int64_t ndgpu_ovl_map_regs(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t
 		*counts = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n_reads ? n_reads : 1));
 		if (n) memcpy(*recs, out.data(), sizeof(ndgpu_ovl_rec) * (size_t)n);
 		if (n_reads) memcpy(*counts, cnt.data(), sizeof(uint32_t) * n_reads);
+		return n;
+	} catch (...) {
+		return -2;
+	}
+}
+
+// The chains of every query read as the base-level alignment of -c takes them (minimap2/align.c:857-905 after mm_gen_regs,
+// minimap2/hit.c:52-85): hits in hit order, self hits included, chains[i] = (strand, index-local target, first anchor's offset in
+// the read's slice of ax / ay, anchor count, chain score, hash, 0, 0); the chained anchors of read i = ax / ay[a_off[i] .. a_off[i + 1])
+// in the order of the reference's a[] (chains by the x of their first anchor).
+int64_t ndgpu_ovl_map_chains(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
+                             uint64_t n_words, const uint64_t *word_off, const uint32_t *lens, const uint32_t *ids, ndgpu_ovl_rec **chains,
+                             uint32_t **counts, uint64_t **ax, uint64_t **ay, uint64_t **a_off)
+{
+	*chains = nullptr, *counts = nullptr, *ax = *ay = *a_off = nullptr;
+	if (const char *msg = check_opt(*opt)) { fprintf(stderr, "[ndgpu_overlap] %s\n", msg); return -1; }
+	if (opt->step != 1 || opt->mode == 3) { fprintf(stderr, "[ndgpu_overlap] chains are handed out for --step 1 without --mode 3 only\n"); return -1; }
+	try {
+		HIP_OK(hipSetDevice(h->e.device));
+		std::vector<OvlRec> out;
+		std::vector<uint32_t> cnt;
+		std::vector<uint64_t> x, y, off;
+		Regs rg{nullptr, nullptr, false, &cnt, nullptr};
+		rg.ca_x = &x, rg.ca_y = &y, rg.ca_off = &off;
+		int64_t n = h->e.map(*opt, mid_occ, n_reads, words, n_words, word_off, lens, ids, out, nullptr, &rg);
+		if (n < 0) return n;
+		if (cnt.size() != n_reads) cnt.resize(n_reads, 0u);
+		if (off.size() != (size_t)n_reads + 1) off.resize((size_t)n_reads + 1, off.empty() ? 0 : off.back());
+		*chains = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec) * (size_t)(n ? n : 1));
+		*counts = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n_reads ? n_reads : 1));
+		*ax = (uint64_t*)malloc(sizeof(uint64_t) * (x.size() ? x.size() : 1));
+		*ay = (uint64_t*)malloc(sizeof(uint64_t) * (y.size() ? y.size() : 1));
+		*a_off = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)n_reads + 1));
+		if (!*chains || !*counts || !*ax || !*ay || !*a_off) return -2;
+		if (n) memcpy(*chains, out.data(), sizeof(ndgpu_ovl_rec) * (size_t)n);
+		if (n_reads) memcpy(*counts, cnt.data(), sizeof(uint32_t) * n_reads);
+		if (!x.empty()) memcpy(*ax, x.data(), sizeof(uint64_t) * x.size()), memcpy(*ay, y.data(), sizeof(uint64_t) * y.size());
+		memcpy(*a_off, off.data(), sizeof(uint64_t) * ((size_t)n_reads + 1));
 		return n;
 	} catch (...) {
 		return -2;

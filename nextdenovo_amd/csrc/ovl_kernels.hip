@@ -1317,7 +1317,7 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
                             uint64_t *__restrict__ bx, uint64_t *__restrict__ by, uint64_t *__restrict__ wx, uint64_t *__restrict__ wy,
                             uint32_t *__restrict__ tables, SortJob *__restrict__ stacks, const uint32_t *__restrict__ n_end,
                             OvlRec *__restrict__ recs, uint32_t *__restrict__ n_rec, uint32_t *__restrict__ n_chain,
-                            OvlRec10 *__restrict__ recs10)
+                            OvlRec10 *__restrict__ recs10, uint64_t *__restrict__ cx, uint64_t *__restrict__ cy, uint32_t *__restrict__ n_ca)
 {
 	const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rl >= n_reads) return;
@@ -1325,6 +1325,7 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 	const uint64_t a0 = r_aoff[rl];
 	const int32_t n = (int32_t)(r_aoff[rl + 1] - a0);
 	n_rec[rl] = 0, n_chain[rl] = 0;
+	if (P.chains) n_ca[rl] = 0;
 	if (n == 0) return;
 	const uint64_t *X = ax + a0, *Y = ay + a0;
 	const int32_t *F = f + a0, *Pp = p + a0;
@@ -1363,6 +1364,20 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 	k = 0;
 	for (int32_t i = 0; i < n_u; ++i) { WX[i] = BX[k], WY[i] = (uint64_t)(uint32_t)k << 32 | (uint32_t)i; k += (int32_t)U[i]; }
 	reference_sort_xy(WX, WY, (uint32_t)n_u, head, tail, stack);
+	if (P.chains) {
+		// -c: the base-level alignment walks a[] itself (the chain before / after a hit's own: minimap2/align.c:629-664), so the
+		// chains are copied out in that order and addressed there from here on
+		uint64_t *CX = cx + a0, *CY = cy + a0;
+		int32_t kk = 0;
+		for (int32_t i = 0; i < n_u; ++i) {
+			const int32_t src = (int32_t)WY[i], first = (int32_t)(WY[i] >> 32), cnt = (int32_t)U[src];
+			for (int32_t j = 0; j < cnt; ++j) CX[kk + j] = BX[first + j], CY[kk + j] = BY[first + j];
+			WY[i] = (uint64_t)(uint32_t)kk << 32 | (uint32_t)src;
+			kk += cnt;
+		}
+		BX = CX, BY = CY;
+		n_ca[rl] = (uint32_t)kk;
+	}
 	// hash-ordered hits: z.x = score<<32 | (cnt ^ h), z.y = first<<32 | cnt, over the re-ordered chains
 	const uint32_t qhash = q.hash[rd];
 	// (the host rejects min_cnt < 2, so n_u <= n / 2 and the upper halves of WX/WY are free)
@@ -1390,6 +1405,13 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 		int32_t qs, qe;
 		if (!rev) qs = (int32_t)BY[first] + 1 - span0, qe = (int32_t)BY[last] + 1;
 		else qs = (int32_t)qlen - ((int32_t)BY[last] + 1), qe = (int32_t)qlen - ((int32_t)BY[first] + 1 - span0);
+		if (P.chains) {
+			OvlRec c;
+			c.rev = rev, c.qname = rid, c.qs = (uint32_t)first, c.qe = (uint32_t)cnt, c.tname = (uint32_t)(ZX[i] >> 32), c.ts = (uint32_t)ZX[i];
+			c.te = 0, c.match = 0;
+			out[n_out++] = c;
+			continue;
+		}
 		const uint32_t tid = P.nameless ? 0u : ix.id[rid]; // (re-alignment: `rid` numbers the wanted list, nobody has a name)
 		if (!P.nameless && tid == qid) continue;
 		int32_t mlen = span0, blen = span0; // mm_cal_fuzzy_len (minimap2/hit.c): matching bases, block length
@@ -1505,10 +1527,26 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
                  const QueryDev &q, const OvlParams &P, const int32_t *f, const int32_t *p, int32_t *v, int32_t *t, uint64_t *u,
                  uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
-                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, hipStream_t s)
+                 OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, uint64_t *cx, uint64_t *cy, uint32_t *n_ca, hipStream_t s)
 {
 	if (n_reads) hipLaunchKernelGGL(hits_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
-	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain, recs10);
+	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain, recs10, cx, cy, n_ca);
+}
+
+__global__ void compact_anchors_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, const uint64_t *__restrict__ cx,
+                                       const uint64_t *__restrict__ cy, const uint32_t *__restrict__ n_ca, const uint64_t *__restrict__ ca_off,
+                                       uint64_t *__restrict__ dx, uint64_t *__restrict__ dy)
+{
+	const uint32_t rl = blockIdx.x;
+	if (rl >= n_reads) return;
+	const uint64_t src = r_aoff[rl], dst = ca_off[rl];
+	for (uint32_t i = threadIdx.x; i < n_ca[rl]; i += blockDim.x) dx[dst + i] = cx[src + i], dy[dst + i] = cy[src + i];
+}
+
+void launch_compact_anchors(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *cx, const uint64_t *cy, const uint32_t *n_ca,
+                            const uint64_t *ca_off, uint64_t *dx, uint64_t *dy, hipStream_t s)
+{
+	if (n_reads) hipLaunchKernelGGL(compact_anchors_kernel, dim3(n_reads), dim3(256), 0, s, r_aoff, n_reads, cx, cy, n_ca, ca_off, dx, dy);
 }
 
 // gather per-read record runs into one dense array

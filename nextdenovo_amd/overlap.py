@@ -38,6 +38,24 @@ REC10 = np.dtype([(n, np.uint32) for n in ("rev", "qname", "qs", "qe", "qlen", "
 _lib = None
 
 
+class AlnOpt(C.Structure):
+    """ndgpu_ovl_aln_opt: the scoring side of mm_mapopt_t that -c uses (minimap2/options.c:36-43)."""
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "q", "e", "q2", "e2", "sc_ambi", "zdrop", "zdrop_inv", "end_bonus", "min_dp_max", "min_ksw_len")] \
+        + [("max_sw_mat", C.c_int64), ("host_threads", C.c_int32)]
+
+
+class CigarStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("chains", "first_pass", "second_pass", "inversion_tests", "inversions", "cells", "overlaps")]
+
+
+def aln_opt(**kw) -> AlnOpt:
+    o = AlnOpt()
+    load().ndgpu_ovl_aln_opt_default(C.byref(o), 40)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -80,6 +98,13 @@ def _bind(lib):
     lib.ndgpu_ovl_map2_realign.argtypes = [P, P, P, C.POINTER(Opt), C.c_int32, C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, C.c_uint32, P, C.c_uint64,
                                            P, P, P, C.POINTER(P)]
     lib.ndgpu_ovl_map2_realign.restype = C.c_int64
+    lib.ndgpu_ovl_aln_opt_default.argtypes = [C.POINTER(AlnOpt), C.c_int32]
+    lib.ndgpu_ovl_map_chains.argtypes = [P, C.POINTER(Opt), C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, C.POINTER(P), C.POINTER(P), C.POINTER(P),
+                                         C.POINTER(P), C.POINTER(P)]
+    lib.ndgpu_ovl_map_chains.restype = C.c_int64
+    lib.ndgpu_ovl_map_cigar.argtypes = [P, C.POINTER(Opt), C.POINTER(AlnOpt), C.c_int32, C.c_uint32, P, C.c_uint64, P, P, P, P, P, P, P, C.POINTER(P),
+                                        C.POINTER(CigarStats)]
+    lib.ndgpu_ovl_map_cigar.restype = C.c_int64
     lib.ndgpu_s2_new.restype = P
     lib.ndgpu_s2_free.argtypes = [P]
     lib.ndgpu_s2_filter_encode.argtypes = [P, P, C.c_int64, C.c_int32, C.c_int32, P, C.POINTER(P), P]
@@ -235,6 +260,33 @@ class Index:
         if n < 0:
             raise _fail(self.lib, "ndgpu_ovl_map2_realign failed (%d)" % n)
         return _take(self.lib, recs, n, REC10)
+
+    def map_chains(self, rs: ReadSet, mid_occ: int, opt: Opt | None = None):
+        """The chains of every read as -c's base-level alignment takes them (ndgpu_ovl_map_chains) ->
+        (chains, chains per read, anchor x, anchor y, anchor offsets per read)."""
+        opt = opt or self.opt
+        ch, cnt, ax, ay, off = (C.c_void_p() for _ in range(5))
+        n = self.lib.ndgpu_ovl_map_chains(self.h, C.byref(opt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off), _ptr(rs.lens),
+                                          _ptr(rs.ids), C.byref(ch), C.byref(cnt), C.byref(ax), C.byref(ay), C.byref(off))
+        if n < 0:
+            raise _fail(self.lib, "ndgpu_ovl_map_chains failed (%d)" % n)
+        a_off = _take(self.lib, off, len(rs) + 1, np.uint64)
+        na = int(a_off[-1])
+        return _take(self.lib, ch, n, REC), _take(self.lib, cnt, len(rs), np.uint32), _take(self.lib, ax, na, np.uint64), _take(self.lib, ay, na, np.uint64), a_off
+
+    def map_cigar(self, target: ReadSet, rs: ReadSet, mid_occ: int, aopt: AlnOpt | None = None, opt: Opt | None = None, want_stats: bool = False):
+        """`--step 1 -c` (ndgpu_ovl_map_cigar): the step-1 records after base-level alignment through the chains; `target` = the
+        reads this index was built from."""
+        opt = opt or self.opt
+        aopt = aopt or aln_opt()
+        recs, st = C.c_void_p(), CigarStats()
+        n = self.lib.ndgpu_ovl_map_cigar(self.h, C.byref(opt), C.byref(aopt), mid_occ, len(rs), _ptr(rs.words), rs.words.size, _ptr(rs.word_off),
+                                         _ptr(rs.lens), _ptr(rs.ids), _ptr(target.words), _ptr(target.word_off), _ptr(target.lens), _ptr(target.ids),
+                                         C.byref(recs), C.byref(st))
+        if n < 0:
+            raise _fail(self.lib, "ndgpu_ovl_map_cigar failed (%d)" % n)
+        out = _take(self.lib, recs, n, REC)
+        return (out, {k: int(getattr(st, k)) for k, _ in CigarStats._fields_}) if want_stats else out
 
     def debug_anchors(self, q: int):
         ax, ay, f, p = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
