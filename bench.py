@@ -40,8 +40,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# before anything touches HIP (see nextdenovo_amd/__init__.py): 16 hardware queues for the contexts' streams instead of HIP's 4
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def parse(argv=None):

@@ -270,9 +270,10 @@ typedef struct ndgpu_ovl_aln_opt {
 } ndgpu_ovl_aln_opt;
 void ndgpu_ovl_aln_opt_default(ndgpu_ovl_aln_opt *o, int32_t min_chain_score);
 typedef struct ndgpu_ovl_cigar_stats {
-	uint64_t chains, first_pass, second_pass, inversion_tests, inversions, cells, overlaps;
+	uint64_t chains, first_pass, second_pass, inversion_tests, inversions, cells, overlaps, inversions_aligned, splits;
 	/* chains aligned (pieces of split chains included); extension / gap problems of the first pass; gaps aligned again after a
-	 * z-drop; local alignments of the inversion test; inversions looked at; DP cells (query x target) of all problems; records out */
+	 * z-drop; local alignments of the inversion test; inversions looked at (mm_align1_inv calls); DP cells (query x target) of all
+	 * problems; records out; inversions that were aligned; chains a z-drop split */
 } ndgpu_ovl_cigar_stats;
 /* array-level view (and the first half of ndgpu_ovl_map_cigar): the chains of every query read as mm_align_skeleton takes them
  * (minimap2/hit.c:52-85): chains[] in hit order, self hits included, = (strand, index-local target, offset of the first anchor in

@@ -17,14 +17,6 @@
 #include "nd_host.h"
 #include "nd_runtime.h"
 
-// HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
-// run one after the other.  The contexts of this library keep 16+ streams busy and some of their kernels are long and narrow by
-// nature (one wavefront per pile in K12, one alignment chain per wavefront in K8a): on 4 queues they hold up every stream
-// behind them (measured, profiles/r03_hw_queues_ab.json: 14,083 config-3-like piles, 12.1 s -> 5.7 s with 16 queues).  The HIP
-// runtime reads the variable on its first call, so setting a default here -- when the library is loaded -- is early enough unless
-// the process has used HIP before; a value the user has exported is kept.
-__attribute__((constructor)) static void ndgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-
 using namespace ndgpu;
 
 namespace {

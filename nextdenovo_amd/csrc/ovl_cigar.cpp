@@ -876,6 +876,7 @@ int run_tasks(std::vector<Task> &tasks, const Opt &o, const Targets &tg, int thr
         st->chains += tasks.size(), st->first_pass += J1.jobs.size(), st->second_pass += J2.jobs.size(), st->inversion_tests += L.size();
         for (const auto &j : J1.jobs) st->cells += (uint64_t)j.qlen * (uint64_t)j.tlen;
         for (const auto &j : J2.jobs) st->cells += (uint64_t)j.qlen * (uint64_t)j.tlen;
+        for (const Task &T : tasks) st->splits += T.reg->r2 != nullptr;
     }
     free_results(res1);
     free_results(res2);
@@ -932,7 +933,7 @@ int run_inversions(std::vector<InvTask> &inv, const Opt &o, const Targets &tg, n
         R.inv_ok = true;
         R.inv_reg = std::move(v);
     }
-    if (st) st->inversions += inv.size(), st->first_pass += J.jobs.size(), st->inversion_tests += L.size();
+    if (st) st->inversions += inv.size(), st->first_pass += J.jobs.size(), st->inversion_tests += L.size(), st->inversions_aligned += J.jobs.size();
     free_results(res);
     return 0;
 }

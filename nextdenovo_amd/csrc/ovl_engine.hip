@@ -20,9 +20,6 @@
 
 #include <atomic>
 
-// (see capi.cpp: streams that share one of HIP's 4 default hardware queues serialize; read by the runtime on its first call)
-__attribute__((constructor)) static void ndgpu_ovl_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-
 #include "../../include/ndgpu_overlap.h"
 #include "ovl_device.h"
 #include "ovl_pool.h"

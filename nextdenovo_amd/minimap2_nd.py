@@ -17,7 +17,9 @@ read on the device, the per-target marking, the re-alignment's bookkeeping (its 
 filters, the dovetail / contained filter, the 10-field encoder and the `.bl` table on the host (csrc/ovl_step2.cpp).  `--mode 1` too
 (the two forms of the re-alignment switch at 20 candidates instead of 200, --cn 50), short of the anchor thinning its chaining
 applies to mappings with more than 100,000 anchors (refused when one occurs).
-Options of other paths (-a, -c, --step 3) are rejected, not approximated.
+`-c` (with --step 1, not --mode 3, not ava-hifi -- the compiled reference aborts there): base-level alignment through every chain
+(mm_align_skeleton, minimap2/align.c:857-913) before the writer's filter; -A -B -O -E -z -s as in minimap2/main.c:250-252,353-361.
+Options of other paths (-a, --step 3) are rejected, not approximated.
 """
 from __future__ import annotations
 
@@ -54,12 +56,14 @@ class Args:
         self.out = None
         self.batch_size = IDX_BATCH
         self.kn, self.wn, self.cn = 17, 10, 20   # --step 2 (main.c:197)
+        self.cigar = False        # -c
+        self.aopt = None          # the scoring options of -c (overlap.AlnOpt)
         self.files = []
         self.ops = []  # (name, value) in command-line order, applied after the preset
 
 
 LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df", "--minide", "--minmatch", "--kn", "--wn", "--cn"}
-SHORT_WITH_ARG = set("xtfIKkwornmgsNpM")
+SHORT_WITH_ARG = set("xtfIKkwornmgsNpMABOEz")
 
 
 def parse_argv(argv) -> Args:
@@ -97,6 +101,7 @@ def build_opt(a: Args) -> overlap.Opt:
         if name == "-x":
             a.preset = val
     opt = overlap.preset(a.preset)  # raises for unsupported presets
+    a.aopt = overlap.aln_opt()
     for name, val in a.ops:
         if name == "--step":
             a.step = int(val)
@@ -166,6 +171,23 @@ def build_opt(a: Args) -> overlap.Opt:
             a.cn = int(val)
         elif name == "-o":
             a.out = val
+        elif name == "-c":
+            a.cigar = True
+        elif name == "-A":
+            a.aopt.a = int(val)
+        elif name == "-B":
+            a.aopt.b = int(val)
+        elif name == "-s":
+            a.aopt.min_dp_max = int(val)
+        elif name in ("-O", "-E", "-z"):  # one value sets both (main.c:353-361)
+            head, _, tail = val.partition(",")
+            first, second = int(head), int(tail) if tail else int(head)
+            if name == "-O":
+                a.aopt.q, a.aopt.q2 = first, second
+            elif name == "-E":
+                a.aopt.e, a.aopt.e2 = first, second
+            else:
+                a.aopt.zdrop, a.aopt.zdrop_inv = first, second
         else:
             raise SystemExit("[ERROR] option %s is outside the --step 1 overlap path of this engine" % name)
     if a.step not in (1, 2):
@@ -177,6 +199,8 @@ def build_opt(a: Args) -> overlap.Opt:
         opt.minide = max(opt.minide, 0.01)
         if a.cn == 20:
             a.cn = 50
+    if a.cigar and (a.step != 1 or opt.mode == 3):
+        raise SystemExit("[ERROR] -c is built for --step 1 without --mode 3")
     if a.step == 2 and not a.out:
         raise SystemExit("[ERROR] --step 2 needs -o FILE (the .bl table is written next to it, main.c:262-272)")
     return opt
@@ -254,6 +278,8 @@ def run(argv) -> int:
                                 del q_minis[qi]   # (it is closed with the part)
                         elif flt:
                             out.write(flt.feed(ix.map2(q, mid_occ), opt.maxhan1, opt.maxhan2))
+                        elif a.cigar:
+                            out.write(overlap.encode(ix.map_cigar(part, q, mid_occ, a.aopt), prev))
                         else:
                             out.write(overlap.encode(ix.map(q, mid_occ), prev))
                 finally:

@@ -45,7 +45,8 @@ class AlnOpt(C.Structure):
 
 
 class CigarStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("chains", "first_pass", "second_pass", "inversion_tests", "inversions", "cells", "overlaps")]
+    _fields_ = [(n, C.c_uint64) for n in ("chains", "first_pass", "second_pass", "inversion_tests", "inversions", "cells", "overlaps", "inversions_aligned",
+                                         "splits")]
 
 
 def aln_opt(**kw) -> AlnOpt:

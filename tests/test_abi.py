@@ -158,7 +158,14 @@ def test_minimap2_nd_cli_host_logic():
     o = m.build_opt(a)
     assert (o.k, o.w, o.hpc, o.mid_occ, o.bw, o.min_chain_score) == (51, 51, 1, 800, 500, 100)
     assert abs(m.build_opt(m.parse_argv("--step 1 -x ava-hifi a b".split())).mid_occ_frac - 1e-4) < 1e-9
-    for bad in ("--step 2 -x ava-ont a b", "--step 1 -x map-ont a b", "--step 1 -x ava-ont -c a b"):
+    a = m.parse_argv("--step 1 -x ava-ont -c -z 300,150 -s 90 -O 5,20 -E 3 -A 3 -B 5 a b".split())   # -c and its scoring options
+    o = m.build_opt(a)
+    assert a.cigar and (a.aopt.zdrop, a.aopt.zdrop_inv, a.aopt.min_dp_max, a.aopt.q, a.aopt.q2, a.aopt.e, a.aopt.e2, a.aopt.a, a.aopt.b) == \
+        (300, 150, 90, 5, 20, 3, 3, 3, 5)
+    d = m.build_opt(m.parse_argv("--step 1 -x ava-pb -c a b".split()))
+    assert (d.k, d.hpc) == (19, 1)
+    for bad in ("--step 2 -x ava-ont a b", "--step 1 -x map-ont a b", "--step 1 -x ava-ont -a a b", "--step 2 -x ava-ont -c a b -o x",
+                "--step 1 --mode 3 -x ava-ont -c a b"):
         with pytest.raises((SystemExit, ValueError)):
             m.build_opt(m.parse_argv(bad.split()))
 

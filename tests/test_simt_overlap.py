@@ -142,3 +142,21 @@ def test_step2_with_the_realignment(interpreted, tmp_path, tag):
     host): the compiled reference's `.ovl` / `.bl` bytes through the command line."""
     import test_zz_gpu_step2 as S2
     S2.run_case(tag, dict(S2.CASES_M2 + S2.CASES_M1)[tag], tmp_path)
+
+
+_C_FAST = ("ont.sv.c", "pb.sv.dvt.c")
+
+
+@pytest.mark.parametrize("tag", _C_FAST)
+def test_step1_with_base_level_alignment(interpreted, tag):
+    """`--step 1 -c` (mm_align_skeleton as batches of device problems: the ksw2 extension kernel in all its roles, the ksw_ll
+    kernel of the inversion test, K5 handing out chains): the compiled reference's bytes on the rearranged reads -- z-drops,
+    second passes, chain splits, inversion tests and aligned inversions all occur (the other six golden cases run on the GPU)."""
+    import test_zz_gpu_cigar as GC
+    case = [c for c in GC.G.CASES_C if c[0] == tag][0]
+    GC.test_cigar_bytes_match_reference_golden(case)
+
+
+def test_chains_of_the_base_level_alignment_match_oracle(interpreted, olib):
+    import test_zz_gpu_cigar as GC
+    GC.check_chains_against_oracle(olib, "ava-ont", True, "seed", "part")

@@ -77,6 +77,25 @@ def main():
         res[name] = entry
         print(name, json.dumps(entry), flush=True)
 
+    # --step 1 -c on raw reads (ONT error profile): base-level alignment through every chain (csrc/ovl_cigar.cpp)
+    g2 = synth.make_genome(1000000, seed=93, n_repeats=5)
+    rs2 = synth.simulate_reads(g2, 20, "ont", seed=94, mu=9.3, sigma=0.5, min_len=2000)
+    fa2 = os.path.join(wd, "raw.fasta")
+    write_fasta(fa2, rs2.seqs)
+    bases2 = int(sum(s.size for s in rs2.seqs))
+    argv = ["--step", "1", "-c", "--dual=yes", "-x", "ava-ont"]
+    out = os.path.join(wd, "step1_c.ovl")
+    minimap2_nd.run([*argv, "-t", "8", fa2, fa2, "-o", out])
+    dev_s, _ = timed(lambda: minimap2_nd.run([*argv, "-t", "8", fa2, fa2, "-o", out]))
+    entry = {"reads": {"n": len(rs2.seqs), "bases": bases2, "what": "1 Mb genome, 20x ONT-profile raw reads"}, "device_s": dev_s,
+             "device_query_bases_per_s": bases2 / dev_s, "ovl_bytes": os.path.getsize(out)}
+    if have_ref:
+        ref_out = os.path.join(wd, "step1_c.ref.ovl")
+        ref_s = run_ref([*argv, "-t", str(CORES), fa2, fa2, "-o", ref_out])
+        entry.update(reference_s=ref_s, reference_threads=CORES, identical=open(out, "rb").read() == open(ref_out, "rb").read(), speedup=ref_s / dev_s)
+    res["step1_c_ava_ont"] = entry
+    print("step1_c_ava_ont", json.dumps(entry), flush=True)
+
     # ksw2-extd2: a batch of gap-filling / extension problems as mm_align1 would hand them over
     import ksw_util as K
     rng = np.random.default_rng(5)
