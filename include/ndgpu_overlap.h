@@ -257,6 +257,14 @@ typedef struct ndgpu_ksw_result {
 } ndgpu_ksw_result;
 int ndgpu_ksw_extd2_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res);
 
+/* replaces: ksw_ll_qinit(km, 2, qlen, query, 5, mat) + ksw_ll_i16 (minimap2/ksw2_ll_sse.c:32-156; callers mm_test_zdrop and
+ * mm_align1_inv, minimap2/align.c:80-82,813-815): the striped local-alignment SCORE of a batch of problems, one wavefront each, with
+ * the values of the SSE schedule (score, query end, target end -- also for equal maxima and the padding columns).  mat is 5 x 5,
+ * codes <= 4.  Returns 0, < 0 on error. */
+typedef struct ndgpu_ll_job { const uint8_t *query, *target; const int8_t *mat; int32_t qlen, tlen, gapo, gape; } ndgpu_ll_job;
+typedef struct ndgpu_ll_result { int32_t score, qe, te; } ndgpu_ll_result;
+int ndgpu_ksw_ll_batch(const ndgpu_ll_job *jobs, int n, ndgpu_ll_result *res);
+
 /* ---- `minimap2-nd --step 1 -c`: base-level alignment through the chains (off the default correction path: nextDenovo runs
  *      --step 1 without -c) ----
  * the scoring side of mm_mapopt_t (minimap.h; defaults mm_mapopt_init, minimap2/options.c:36-43; -A -B -O -E -z -s of main.c) */

@@ -602,11 +602,8 @@ __global__ __launch_bounds__(64) void ksw_ll_kernel(const LlJobDev *__restrict__
 
 }  // namespace
 
-// a batch of ksw_ll_i16 problems (see above); jobs[i].mat is the 5 x 5 matrix; res[i] = score, query end, target end.  Internal to
-// the library (csrc/ovl_cigar.cpp).  Returns 0, < 0 on error.
-struct ndgpu_ll_job { const uint8_t *query, *target; const int8_t *mat; int32_t qlen, tlen, gapo, gape; };
-struct ndgpu_ll_result { int32_t score, qe, te; };
-int ndgpu_ksw_ll_batch(const ndgpu_ll_job *jobs, int n, ndgpu_ll_result *out) {
+// a batch of ksw_ll_i16 problems (see above; include/ndgpu_overlap.h); used by csrc/ovl_cigar.cpp
+extern "C" int ndgpu_ksw_ll_batch(const ndgpu_ll_job *jobs, int n, ndgpu_ll_result *out) {
     if (n <= 0) return 0;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {

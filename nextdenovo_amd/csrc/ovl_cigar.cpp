@@ -32,10 +32,6 @@
 
 #include "../../include/ndgpu_overlap.h"
 
-struct ndgpu_ll_job { const uint8_t *query, *target; const int8_t *mat; int32_t qlen, tlen, gapo, gape; };
-struct ndgpu_ll_result { int32_t score, qe, te; };
-int ndgpu_ksw_ll_batch(const ndgpu_ll_job *jobs, int n, ndgpu_ll_result *out);  // csrc/ksw2_kernels.hip
-
 namespace {
 
 constexpr uint64_t kSeedLongJoin = 1ULL << 40, kSeedIgnore = 1ULL << 41, kSeedTandem = 1ULL << 42, kSeedSelf = 1ULL << 43;  // mmpriv.h:18-21

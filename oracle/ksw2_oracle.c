@@ -261,3 +261,72 @@ int nd_oracle_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t 
 	free(u); free(sf); free(qr); free(H); free(p); free(off);
 	return 0;
 }
+
+/* ksw_ll_i16 with the query profile of ksw_ll_qinit (minimap2/ksw2_ll_sse.c:32-83 with size 2, :85-156): the local-alignment score
+ * behind the inversion test of minimap2's -c path (mm_test_zdrop, minimap2/align.c:71-87) and behind mm_align1_inv (:790-845).
+ * Farrar's striped Smith-Waterman on eight 16-bit lanes, restated lane by lane in scalar C: stripe k holds the query positions
+ * j + k * slen; the values are those of the striped schedule (E is opened from H as it stands before the lazy-F pass; the zero-score
+ * padding columns behind the query take part in the maximum; of equal maxima the last row and the last cell in memory order win).
+ * Pinned against the compiled reference function (oracle/_ref/libksw2llref.so) by tests/test_oracle_ksw2.py. */
+static int ll_sat16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
+static int ll_subs(int a, int b) { return a > b ? a - b : 0; } /* _mm_subs_epu16 on non-negative values */
+int nd_oracle_ksw_ll_i16(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat /* 5 x 5 */, int gapo,
+                         int gape, int *qe, int *te)
+{
+	const int slen = (qlen + 7) / 8, gapoe = gapo + gape;
+	int i, j, k, gmax = 0;
+	int16_t *H0, *H1, *E, *Hmax, *tmp;
+	*qe = *te = -1;
+	H0 = (int16_t*)calloc((size_t)slen * 8 * 4 + 8, 2);
+	H1 = H0 + (size_t)slen * 8, E = H1 + (size_t)slen * 8, Hmax = E + (size_t)slen * 8;
+	for (i = 0; i < tlen; ++i) {
+		const int8_t *ma = mat + target[i] * 5;
+		int h[8], f[8], mx[8], done = 0, imax = 0;
+		for (k = 0; k < 8; ++k) f[k] = 0, mx[k] = 0;
+		for (k = 7; k >= 1; --k) h[k] = slen > 0 ? H0[(slen - 1) * 8 + k - 1] : 0; /* _mm_slli_si128(h, 2) */
+		h[0] = 0;
+		for (j = 0; j < slen; ++j)
+			for (k = 0; k < 8; ++k) {
+				const int pos = j + k * slen, sc = pos < qlen ? ma[query[pos]] : 0;
+				int hh = ll_sat16(h[k] + sc), e = E[j * 8 + k];
+				hh = hh > e ? hh : e;
+				hh = hh > f[k] ? hh : f[k];
+				mx[k] = mx[k] > hh ? mx[k] : hh;
+				H1[j * 8 + k] = (int16_t)hh;
+				hh = ll_subs(hh, gapoe);
+				e = ll_subs(e, gape);
+				e = e > hh ? e : hh;
+				E[j * 8 + k] = (int16_t)e;
+				f[k] = ll_subs(f[k], gape);
+				f[k] = f[k] > hh ? f[k] : hh;
+				h[k] = H0[j * 8 + k];
+			}
+		for (k = 0; k < 8 && !done; ++k) { /* the lazy-F pass */
+			int l, any;
+			for (l = 7; l >= 1; --l) f[l] = f[l - 1];
+			f[0] = 0;
+			for (j = 0; j < slen; ++j) {
+				any = 0;
+				for (l = 0; l < 8; ++l) {
+					int hh = H1[j * 8 + l];
+					hh = hh > f[l] ? hh : f[l];
+					H1[j * 8 + l] = (int16_t)hh;
+					hh = ll_subs(hh, gapoe);
+					f[l] = ll_subs(f[l], gape);
+					if (f[l] > hh) any = 1;
+				}
+				if (!any) { done = 1; break; }
+			}
+		}
+		for (k = 0; k < 8; ++k) imax = imax > mx[k] ? imax : mx[k];
+		if (imax >= gmax) {
+			gmax = imax, *te = i;
+			memcpy(Hmax, H1, (size_t)slen * 8 * 2);
+		}
+		tmp = H1, H1 = H0, H0 = tmp;
+	}
+	for (i = 0; i < slen * 8; ++i)
+		if ((int)(uint16_t)Hmax[i] == gmax) *qe = i / 8 + i % 8 * slen;
+	free(H0 < H1 ? (H0 < Hmax ? H0 : Hmax) : (H1 < Hmax ? H1 : Hmax));
+	return gmax;
+}

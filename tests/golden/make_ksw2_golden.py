@@ -32,6 +32,11 @@ def main():
     ref = C.CDLL(K.REF)
     write(ref, K.problems(SEED, COUNT, MAX_LEN), "ksw2.npz")
     write(ref, K.mid_problems(), "ksw2_mid.npz")   # targets of 1,025 .. 4,096 bases (the kernel's large LDS tier)
+    # ksw_ll_i16 (oracle/_ref/libksw2llref.so, built from minimap2/ksw2_ll_sse.c): score, query end, target end
+    ll = C.CDLL(K.REF_LL)
+    res = np.asarray([K.call_ll_ref(ll, p) for p in K.ll_problems()], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "ksw_ll.npz"), res=res)
+    print("ksw_ll.npz", res.shape[0], "problems")
 
 
 if __name__ == "__main__":

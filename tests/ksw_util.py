@@ -206,3 +206,89 @@ def mid_problems():
         out.append(dict(q=q.astype(np.uint8), t=t, mat=matrix(*[(2, 4, 1), (1, 4, 1)][n % 2]), gaps=gaps, w=w, zdrop=zdrop,
                         end_bonus=[-1, 0, 5, 50][n % 4], flag=flags[(n // 2) % len(flags)]))
     return out
+
+
+# ---- ksw_ll_i16: the striped local-alignment score of the -c path's inversion test (minimap2/ksw2_ll_sse.c) ----
+REF_LL = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libksw2llref.so")
+
+
+class LlJob(C.Structure):  # ndgpu_ll_job (include/ndgpu_overlap.h)
+    _fields_ = [("query", C.c_void_p), ("target", C.c_void_p), ("mat", C.c_void_p)] + [(n, C.c_int32) for n in ("qlen", "tlen", "gapo", "gape")]
+
+
+class LlResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("score", "qe", "te")]
+
+
+def ll_problems(seed=20260926, n=400):
+    """Problems in the shapes the inversion test / mm_align1_inv pose: a stretch of one read against the reverse complement of a
+    stretch of the other (related or not), lengths 1 .. 3000 around the multiples of 8 (the stripe width), N bases, several scorings."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(n):
+        L = int(rng.choice([1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 200, int(rng.integers(1, 700)), int(rng.integers(700, 3000)) if it % 10 == 0 else 100]))
+        base = rng.integers(0, 4, L).astype(np.uint8)
+        kind = it % 4
+        if kind == 0:    # unrelated
+            q, t = base, rng.integers(0, 4, int(rng.integers(1, 2 * L + 2))).astype(np.uint8)
+        else:            # related: substitutions and indels, a flank of unrelated sequence on either side
+            y, i, rate = [], 0, float(rng.choice([0.0, 0.05, 0.15, 0.3]))
+            while i < base.size:
+                r = rng.random()
+                if r < rate / 3:
+                    y.append(int(rng.integers(0, 4))), 
+                    i += 1
+                elif r < 2 * rate / 3:
+                    i += int(rng.choice([1, 1, 2, 6]))
+                elif r < rate:
+                    y.extend(rng.integers(0, 4, int(rng.choice([1, 1, 2, 6]))).tolist())
+                else:
+                    y.append(int(base[i]))
+                    i += 1
+            t = np.asarray(y if y else [0], dtype=np.uint8)
+            if kind == 2:
+                t = np.concatenate([rng.integers(0, 4, int(rng.integers(0, 40))).astype(np.uint8), t, rng.integers(0, 4, int(rng.integers(0, 40))).astype(np.uint8)])
+            q = base
+            if kind == 3 and q.size > 4:
+                q = q.copy()
+                q[rng.integers(0, q.size, max(1, q.size // 25))] = 4
+        a, b, amb = [(2, 4, 1), (1, 4, 1), (1, 19, 0), (2, 8, 2)][int(rng.integers(0, 4))]
+        gapo, gape = [(4, 2), (6, 2), (24, 1), (2, 1)][int(rng.integers(0, 4))]
+        out.append(dict(q=np.ascontiguousarray(q), t=np.ascontiguousarray(t), mat=matrix(a, b, amb), gapo=gapo, gape=gape))
+    return out
+
+
+def call_ll_ref(lib, p):
+    """ksw_ll_qinit(0, 2, qlen, query, 5, mat) + ksw_ll_i16 of the compiled reference -> (score, qe, te)."""
+    lib.ksw_ll_qinit.restype = C.c_void_p
+    lib.ksw_ll_qinit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.ksw_ll_i16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ksw_ll_i16.restype = C.c_int
+    qp = lib.ksw_ll_qinit(None, 2, p["q"].size, p["q"].ctypes.data, 5, p["mat"].ctypes.data)
+    qe, te = C.c_int(0), C.c_int(0)
+    sc = lib.ksw_ll_i16(qp, p["t"].size, p["t"].ctypes.data, p["gapo"], p["gape"], C.byref(qe), C.byref(te))
+    C.CDLL(None).free(C.c_void_p(qp))
+    return int(sc), int(qe.value), int(te.value)
+
+
+def call_ll_oracle(lib, p):
+    f = lib.nd_oracle_ksw_ll_i16
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    f.restype = C.c_int
+    qe, te = C.c_int(0), C.c_int(0)
+    sc = f(p["q"].size, p["q"].ctypes.data, p["t"].size, p["t"].ctypes.data, p["mat"].ctypes.data, p["gapo"], p["gape"], C.byref(qe), C.byref(te))
+    return int(sc), int(qe.value), int(te.value)
+
+
+def call_ll_batch(lib, ps):
+    """ndgpu_ksw_ll_batch over a list of problems -> list of (score, qe, te)."""
+    n = len(ps)
+    jobs, res = (LlJob * n)(), (LlResult * n)()
+    for j, p in zip(jobs, ps):
+        j.query, j.target, j.mat = p["q"].ctypes.data, p["t"].ctypes.data, p["mat"].ctypes.data
+        j.qlen, j.tlen, j.gapo, j.gape = p["q"].size, p["t"].size, p["gapo"], p["gape"]
+    lib.ndgpu_ksw_ll_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.ndgpu_ksw_ll_batch.restype = C.c_int
+    rc = lib.ndgpu_ksw_ll_batch(jobs, n, res)
+    assert rc == 0, rc
+    return [(int(r.score), int(r.qe), int(r.te)) for r in res]

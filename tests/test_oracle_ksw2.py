@@ -63,3 +63,23 @@ def test_oracle_matches_live_reference(oracle_lib, seed, count, max_len):
         a = K.call_sse(ref, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
         b = K.call_oracle(oracle_lib, p["q"], p["t"], p["mat"], *p["gaps"], p["w"], p["zdrop"], p["end_bonus"], p["flag"])
         assert a == b, i
+
+
+def test_ll_oracle_matches_golden_vectors(oracle_lib):
+    """nd_oracle_ksw_ll_i16 (the striped local-alignment score of the -c path's inversion test) against the vectors of the compiled
+    ksw_ll_qinit + ksw_ll_i16 (tests/golden/ksw_ll.npz)."""
+    want = np.load(os.path.join(HERE, "golden", "ksw_ll.npz"))["res"]
+    ps = K.ll_problems()
+    assert len(ps) == want.shape[0]
+    for i, p in enumerate(ps):
+        assert K.call_ll_oracle(oracle_lib, p) == tuple(int(x) for x in want[i]), i
+    assert (want[:, 0] > 100).sum() > 30 and (want[:, 0] == 0).sum() >= 1
+    # the padding columns behind the query take part: ends beyond the query's last base occur
+    assert sum(1 for p, w in zip(ps, want) if w[1] >= p["q"].size) >= 1
+
+
+@pytest.mark.skipif(not os.path.exists(K.REF_LL), reason="oracle/_ref not built")
+def test_ll_oracle_matches_live_reference(oracle_lib):
+    ref = C.CDLL(K.REF_LL)
+    for i, p in enumerate(K.ll_problems(seed=11, n=1200)):
+        assert K.call_ll_oracle(oracle_lib, p) == K.call_ll_ref(ref, p), i

@@ -36,3 +36,8 @@ def test_long_targets(simt_ovl, oracle_lib):
 def test_large_lds_tier(simt_ovl):
     """A sample of the 1,025 .. 4,096-base targets (the kernel's large LDS tier) through the interpreter."""
     G.check_mid(simt_ovl, stride=17)
+
+
+def test_local_alignment_score_of_the_inversion_test(simt_ovl, oracle_lib):
+    """ksw_ll_kernel through the interpreter: a sample of the compiled reference's ksw_ll_i16 vectors and of oracle-checked problems."""
+    G.check_ll(simt_ovl, oracle_lib, stride=4)

@@ -152,11 +152,11 @@ def test_step1_with_base_level_alignment(interpreted, tag):
     """`--step 1 -c` (mm_align_skeleton as batches of device problems: the ksw2 extension kernel in all its roles, the ksw_ll
     kernel of the inversion test, K5 handing out chains): the compiled reference's bytes on the rearranged reads -- z-drops,
     second passes, chain splits, inversion tests and aligned inversions all occur (the other six golden cases run on the GPU)."""
-    import test_zz_gpu_cigar as GC
+    import test_zzz_gpu_cigar as GC
     case = [c for c in GC.G.CASES_C if c[0] == tag][0]
     GC.test_cigar_bytes_match_reference_golden(case)
 
 
 def test_chains_of_the_base_level_alignment_match_oracle(interpreted, olib):
-    import test_zz_gpu_cigar as GC
+    import test_zzz_gpu_cigar as GC
     GC.check_chains_against_oracle(olib, "ava-ont", True, "seed", "part")

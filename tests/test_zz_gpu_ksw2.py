@@ -4,6 +4,7 @@ oracle on targets longer than the kernel's LDS budget.  (Named to run after the 
 import os
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -72,3 +73,22 @@ def check_mid(lib, stride=1):
 def test_ksw_large_lds_tier_matches_reference_vectors(ovl_lib):
     """Targets of 1,025 .. 4,096 bases run in the kernel's large LDS tier (44 KB of dynamic LDS per wavefront)."""
     check_mid(ovl_lib)
+
+
+def check_ll(lib, oracle_lib=None, stride=1):
+    """ndgpu_ksw_ll_batch (ksw_ll_kernel: the SSE schedule of ksw_ll_i16, lanes 0..7 = the stripes) against the compiled reference's
+    vectors, in one batch; with an oracle also on problems the vectors do not hold."""
+    want = np.load(os.path.join(HERE, "golden", "ksw_ll.npz"))["res"]
+    ps = K.ll_problems()
+    idx = list(range(0, len(ps), stride))
+    got = K.call_ll_batch(lib, [ps[i] for i in idx])
+    for i, g in zip(idx, got):
+        assert g == tuple(int(x) for x in want[i]), i
+    if oracle_lib is not None:
+        more = K.ll_problems(seed=23, n=300)[::stride]
+        for p, g in zip(more, K.call_ll_batch(lib, more)):
+            assert g == K.call_ll_oracle(oracle_lib, p)
+
+
+def test_ksw_ll_matches_reference_vectors(ovl_lib, oracle_lib):
+    check_ll(ovl_lib, oracle_lib)
