@@ -32,6 +32,7 @@ CASES_C = [  # (file tag, preset, target, query, dual, extra argv); sets "seed"/
     ("ont.svself.c", "ava-ont", "sv", "sv", False, ("-c",)),
     ("pb.sv.dvt.c", "ava-pb", "sv", "svq", True, ("-c", "--dvt")),
     ("ont.sv.z200.c", "ava-ont", "sv", "svq", True, ("-c", "-z", "200,100", "-s", "120")),
+    ("ont.sv.I150k.c", "ava-ont", "sv", "svq", True, ("-c", "-I", "150k")),   # a multi-part index: through the command line only
 ]
 
 
