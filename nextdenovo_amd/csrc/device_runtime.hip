@@ -241,7 +241,7 @@ struct DeviceAligner::State {
     std::mutex batch_mu;
     DevBuf<ReadDev> d_reads;
     DevBuf<PileDev> d_piles;
-    DevBuf<uint32_t> d_read_pile, d_acc, d_tags, d_colidx, d_cov, d_inscnt, d_insmax, d_cellbase, d_entbase;
+    DevBuf<uint32_t> d_read_pile, d_acc, d_tags, d_colidx, d_cov /* coverage | insertion counts | longest insertion: one block, one fill */, d_cellbase, d_entbase;
     DevBuf<uint32_t> d_cell_start, d_cell_len, d_cell_bpp, d_cell_blink, d_ent_pp, d_ent_ppp, d_ent_cnt, d_err;
     DevBuf<long long> d_ent_score;
     DevBuf<int32_t> d_cell_best, d_spec, d_fin;  // K10 segments: cell bests, boundary scores (kSegEnts per segment)
@@ -381,7 +381,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     NDGPU_NAME(d_lq_out)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
-    NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_inscnt) NDGPU_NAME(d_insmax) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
+    NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
     NDGPU_NAME(d_cell_start) NDGPU_NAME(d_cell_len) NDGPU_NAME(d_cell_bpp) NDGPU_NAME(d_cell_blink) NDGPU_NAME(d_ent_pp)
     NDGPU_NAME(d_ent_ppp) NDGPU_NAME(d_ent_cnt) NDGPU_NAME(d_err) NDGPU_NAME(d_ent_score) NDGPU_NAME(d_cell_best) NDGPU_NAME(d_spec)
     NDGPU_NAME(d_fin) NDGPU_NAME(d_sums) NDGPU_NAME(d_items) NDGPU_NAME(d_bt_exit) NDGPU_NAME(d_bt_steps) NDGPU_NAME(d_bt_entry)
@@ -483,7 +483,7 @@ void DeviceAligner::release_memory() {
     NDGPU_REL(d_lq_out)
     NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
-    NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_inscnt) NDGPU_REL(d_insmax) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
+    NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
     NDGPU_REL(d_cell_start) NDGPU_REL(d_cell_len) NDGPU_REL(d_cell_bpp) NDGPU_REL(d_cell_blink) NDGPU_REL(d_ent_pp)
     NDGPU_REL(d_ent_ppp) NDGPU_REL(d_ent_cnt) NDGPU_REL(d_err) NDGPU_REL(d_ent_score) NDGPU_REL(d_cell_best) NDGPU_REL(d_spec)
     NDGPU_REL(d_fin) NDGPU_REL(d_sums) NDGPU_REL(d_items) NDGPU_REL(d_bt_exit) NDGPU_REL(d_bt_steps) NDGPU_REL(d_bt_entry)
@@ -522,7 +522,7 @@ void DeviceAligner::level_buffers(int drivers) {
             NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_out)
             NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v)
             NDGPU_LVL(d_ids) NDGPU_LVL(d_reads) NDGPU_LVL(d_piles) NDGPU_LVL(d_read_pile) NDGPU_LVL(d_acc) NDGPU_LVL(d_tags)
-            NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_inscnt) NDGPU_LVL(d_insmax) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
+            NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
             NDGPU_LVL(d_cell_start) NDGPU_LVL(d_cell_len) NDGPU_LVL(d_cell_bpp) NDGPU_LVL(d_cell_blink) NDGPU_LVL(d_ent_pp)
             NDGPU_LVL(d_ent_ppp) NDGPU_LVL(d_ent_cnt) NDGPU_LVL(d_err) NDGPU_LVL(d_cell_best) NDGPU_LVL(d_spec)
             NDGPU_LVL(d_fin) NDGPU_LVL(d_sums) NDGPU_LVL(d_items) NDGPU_LVL(d_bt_exit) NDGPU_LVL(d_bt_steps) NDGPU_LVL(d_bt_entry)
@@ -1230,9 +1230,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_acc.reserve(acc_slots + 1);
     S.d_tags.reserve(tag_slots + 9);  // (K9 reads 32-byte windows: up to 7 tags past a read's last one)
     S.d_colidx.reserve(colidx_slots + 1);
-    S.d_cov.reserve(col_slots + 1);
-    S.d_inscnt.reserve(col_slots + 1);
-    S.d_insmax.reserve(col_slots + 1);
+    S.d_cov.reserve(3 * (col_slots + 1));  // per column: coverage, insertion count, longest insertion -- three arrays in one block
     S.d_cellbase.reserve(col_slots + 1);
     S.d_entbase.reserve(col_slots + 1);
     S.d_err.reserve(4);
@@ -1244,9 +1242,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.h2d(S.d_reads.p, reads.data(), nr * sizeof(ReadDev), st);
     S.h2d(S.d_piles.p, piles.data(), np * sizeof(PileDev), st);
     S.h2d(S.d_read_pile.p, read_pile.data(), nr * sizeof(uint32_t), st);
-    HIP_CHECK(hipMemsetAsync(S.d_cov.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
-    HIP_CHECK(hipMemsetAsync(S.d_inscnt.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
-    HIP_CHECK(hipMemsetAsync(S.d_insmax.p, 0, (col_slots + 1) * sizeof(uint32_t), st));
+    uint32_t *const d_cov = S.d_cov.p, *const d_inscnt = d_cov + (col_slots + 1), *const d_insmax = d_inscnt + (col_slots + 1);
+    HIP_CHECK(hipMemsetAsync(d_cov, 0, 3 * (col_slots + 1) * sizeof(uint32_t), st));  // (one fill for the three)
     HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
 
     {
@@ -1316,12 +1313,12 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     NDGPU_DBG(st, "main: shift_scan");
     launch_shift_scan(S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_reads.p, (int)nr, st);
     NDGPU_DBG(st, "main: pile_accept");
-    launch_pile_accept(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_cov.p, (int)np, st);
+    launch_pile_accept(S.d_piles.p, S.d_reads.p, S.d_acc.p, d_cov, (int)np, st);
     NDGPU_DBG(st, "main: make_tags");
     launch_make_tags(S.d_piles.p, S.d_reads.p, S.d_tasks.p, S.d_ops.p, S.d_pool.p, S.db_pool, S.d_read_pile.p,
-                     S.d_tags.p, S.d_colidx.p, S.d_inscnt.p, S.d_insmax.p, (int)nr, st);
+                     S.d_tags.p, S.d_colidx.p, d_inscnt, d_insmax, (int)nr, st);
     NDGPU_DBG(st, "main: col_scan");
-    launch_col_scan(S.d_piles.p, S.d_cov.p, S.d_inscnt.p, S.d_insmax.p, S.d_cellbase.p, S.d_entbase.p, (int)np, st);
+    launch_col_scan(S.d_piles.p, d_cov, d_inscnt, d_insmax, S.d_cellbase.p, S.d_entbase.p, (int)np, st);
     NDGPU_DBG(st, "main: col_scan done");
     HIP_CHECK(hipEventRecord(S.evs[1], st));
     S.d2h(piles.data(), S.d_piles.p, np * sizeof(PileDev), st);
@@ -1411,7 +1408,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     // sub-batch is counted and scored again with the full capacity (everything the kernels write is rewritten)
     K10Args ka;
     ka.piles = S.d_piles.p;
-    ka.coverage = S.d_cov.p, ka.max_size = S.d_insmax.p, ka.cell_base = S.d_cellbase.p, ka.ent_base = S.d_entbase.p;
+    ka.coverage = d_cov, ka.max_size = d_insmax, ka.cell_base = S.d_cellbase.p, ka.ent_base = S.d_entbase.p;
     ka.cell_start = S.d_cell_start.p, ka.cell_len = S.d_cell_len.p;
     ka.ent_pp = S.d_ent_pp.p, ka.ent_ppp = S.d_ent_ppp.p, ka.ent_cnt = S.d_ent_cnt.p;
     ka.cell_best_pp = S.d_cell_bpp.p, ka.cell_best_link = S.d_cell_blink.p, ka.cell_best = S.d_cell_best.p;
@@ -1424,7 +1421,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
         HIP_CHECK(hipEventRecord(S.evs[2], st));
         NDGPU_DBG(st, "main: count_links %zu blocks, cells %llu ents %llu segs %u", blocks.size(), (unsigned long long)cells,
                   (unsigned long long)ents, n_segs);
-        launch_count_links(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_blocks.p, S.d_tags.p, S.d_colidx.p, S.d_insmax.p,
+        launch_count_links(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_blocks.p, S.d_tags.p, S.d_colidx.p, d_insmax,
                            S.d_cellbase.p, S.d_entbase.p, S.d_cell_start.p, S.d_cell_len.p, S.d_ent_pp.p, S.d_ent_ppp.p,
                            S.d_ent_cnt.p, S.d_err.p, (int)blocks.size(), attempt != 0 || S.k9_full_capacity, st);
         HIP_CHECK(hipEventRecord(S.evs[3], st));
