@@ -128,9 +128,12 @@ void ndgpu_ovl_pool_bytes(uint64_t out[3]);
  *
  * Returns the records of `sorted.ovl` in file order (per seed: the self record, then the admitted overlaps, inclusive
  * ends; util/ovl_sort.c:675-741, 433-571, 876-925) and the `.bl` verdicts ('c' contained, 'k' chimeric) in seed order.
- * Covers the in-memory case of the reference (no temporary files); equal (seed, match, span) keys keep input order.
+ * Equal (seed, match, span) keys keep input order.  When the candidates do not fit the device at once (~360 bytes per raw record all
+ * told) the raw records -- which stay in the caller's arrays -- pass the device twice in pieces and the seeds are sorted and filtered
+ * in consecutive id ranges (the counterpart of the reference's temporary files and merge under a small -m, util/ovl_sort.c:1079-1110:
+ * like there, the result is the same); NDGPU_OVLSORT_PIECE_RECORDS / NDGPU_OVLSORT_RANGE_CANDIDATES force that form.
  * All three outputs are malloc'd (ndgpu_ovl_free). */
-typedef struct ndgpu_ovl_sort_stats { double gpu_ms; uint64_t raw_records, candidates, seeds, kept; } ndgpu_ovl_sort_stats;
+typedef struct ndgpu_ovl_sort_stats { double gpu_ms; uint64_t raw_records, candidates, seeds, kept, ranges; } ndgpu_ovl_sort_stats;  /* ranges: seed-id ranges the candidates were sorted in (1 = all at once) */
 int64_t ndgpu_ovl_sort(const ndgpu_ovl_rec *const *files, const int64_t *n_per_file, int32_t n_files, const uint32_t *seed_len,
                        uint32_t n_ids, int32_t min_seed_len, int32_t max_bin_cov, int32_t max_flank_len, ndgpu_ovl_rec **out,
                        uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl, ndgpu_ovl_sort_stats *stats);

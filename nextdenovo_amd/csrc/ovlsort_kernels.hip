@@ -105,6 +105,46 @@ __global__ void seed_start_kernel(const uint32_t *__restrict__ flag, const uint6
 }
 
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+// ---- the out-of-core form (csrc/ovlsort_engine.hip: sort_out_of_core): the records of ONE file arrive in pieces ----
+// like expand_count_kernel for a piece of one file: carry_* = records of this file before the piece that missed the seed table
+__global__ void expand_count_piece_kernel(uint64_t n, const uint32_t *__restrict__ hit_q, const uint32_t *__restrict__ hit_t,
+                                          const uint64_t *__restrict__ miss_q_scan, const uint64_t *__restrict__ miss_t_scan, uint64_t carry_q,
+                                          uint64_t carry_t, uint32_t *__restrict__ sel)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const bool q = hit_q[i] && carry_q + miss_q_scan[i] < 5;
+	const bool t = hit_t[i] && carry_t + miss_t_scan[i] < 5;
+	sel[i] = (uint32_t)q | (uint32_t)t << 1;
+}
+
+// candidates per seed (which seed ranges fit the device at a time)
+__global__ void cand_hist_kernel(const OvlRec *__restrict__ raw, const uint32_t *__restrict__ sel, uint64_t n, uint32_t *__restrict__ hist)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t s = sel[i];
+	if (s & 1) atomicAdd(hist + raw[i].qname, 1u);
+	if (s & 2) atomicAdd(hist + raw[i].tname, 1u);
+}
+
+// the sides of a record whose seed lies in [lo, hi)
+__global__ void range_sel_kernel(const OvlRec *__restrict__ raw, const uint8_t *__restrict__ sel, uint64_t n, uint32_t lo, uint32_t hi,
+                                 uint32_t *__restrict__ out)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t s = sel[i];
+	const OvlRec r = raw[i];
+	out[i] = (uint32_t)((s & 1) && r.qname >= lo && r.qname < hi) | (uint32_t)((s & 2) && r.tname >= lo && r.tname < hi) << 1;
+}
+
+__global__ void narrow_u32_u8_kernel(const uint32_t *__restrict__ in, uint64_t n, uint8_t *__restrict__ out)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (uint8_t)in[i];
+}
+
 
 void launch_expand_flags(const OvlRec *raw, uint64_t n, const uint32_t *seed_len, uint32_t n_ids, uint32_t *hq, uint32_t *ht, uint32_t *mq,
                          uint32_t *mt, hipStream_t s)
@@ -115,6 +155,23 @@ void launch_expand_count(uint64_t n, const uint32_t *file_of, const uint64_t *fi
                          const uint64_t *mqs, const uint64_t *mts, uint32_t *sel, hipStream_t s)
 {
 	if (n) hipLaunchKernelGGL(expand_count_kernel, GRID1(n), 0, s, n, file_of, file_start, hq, ht, mqs, mts, sel);
+}
+void launch_expand_count_piece(uint64_t n, const uint32_t *hq, const uint32_t *ht, const uint64_t *mqs, const uint64_t *mts, uint64_t carry_q,
+                               uint64_t carry_t, uint32_t *sel, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(expand_count_piece_kernel, GRID1(n), 0, s, n, hq, ht, mqs, mts, carry_q, carry_t, sel);
+}
+void launch_cand_hist(const OvlRec *raw, const uint32_t *sel, uint64_t n, uint32_t *hist, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(cand_hist_kernel, GRID1(n), 0, s, raw, sel, n, hist);
+}
+void launch_range_sel(const OvlRec *raw, const uint8_t *sel, uint64_t n, uint32_t lo, uint32_t hi, uint32_t *out, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(range_sel_kernel, GRID1(n), 0, s, raw, sel, n, lo, hi, out);
+}
+void launch_narrow_u32_u8(const uint32_t *in, uint64_t n, uint8_t *out, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(narrow_u32_u8_kernel, GRID1(n), 0, s, in, n, out);
 }
 void launch_sel_count(const uint32_t *sel, uint64_t n, uint32_t *cnt, hipStream_t s)
 {

@@ -412,7 +412,7 @@ def encode(recs: np.ndarray, prev: np.ndarray) -> bytes:
 
 
 class SortStats(C.Structure):
-    _fields_ = [("gpu_ms", C.c_double)] + [(n, C.c_uint64) for n in ("raw_records", "candidates", "seeds", "kept")]
+    _fields_ = [("gpu_ms", C.c_double)] + [(n, C.c_uint64) for n in ("raw_records", "candidates", "seeds", "kept", "ranges")]
 
 
 def from_decoded(a: np.ndarray) -> np.ndarray:

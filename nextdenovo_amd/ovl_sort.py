@@ -6,12 +6,15 @@ util/ovl_sort.c:1040-1078):
 
     python -m nextdenovo_amd.ovl_sort -m 40g -t 8 -k 40 -i .input.seed.001.idx -o input.seed.001.sorted.ovl input.fofn
 
-`-m`, `-t`, `-d` only shape the reference's external merge sort and are accepted and ignored: the device sort is in-memory
-(about 150 bytes of HBM per candidate overlap: 1.9 G overlaps per call on a 288 GB MI355X, 2^31 at most) and says so plainly when
-a seed file exceeds that -- the remedy is the reference's own knob, more seed files (`seed_cutfiles`).  Cutting one seed file
-into seed-id ranges is NOT equivalent (measured: the filter's verdicts for a seed depend on overlaps filed under other seeds), so
-no such fallback is offered.  Equal (seed, match, span) keys keep input order, which is what the reference produces when its
-buffers are not spilled.  `-H` selects the high-quality-read variant of the filter (`ndgpu_ovl_sort_hq`); `-l 0` is refused.
+`-m`, `-t`, `-d` shape the reference's external merge sort (sorted runs in temporary files when the buffers of `-m` are smaller
+than the data, merged at the end: util/ovl_sort.c:1079-1110; the result does not depend on them) and are accepted and ignored: the
+records of the input files are decoded into host memory and the device decides by itself.  When raw records, flags and candidates
+fit the device (about 360 bytes per raw record: 0.7 G records on a 288 GB MI355X) the sort is one pass; otherwise the raw records
+pass the device twice in pieces and the seeds are sorted and filtered in consecutive seed-id ranges (`ndgpu_ovl_sort`,
+csrc/ovlsort_engine.hip: sort_out_of_core) -- same records, same order, same `.bl`.  (Cutting the SEED FILE into id ranges by hand is
+not equivalent: whether a record is looked at depends on how many earlier records of its file missed the seed table, so the table
+must stay whole; the out-of-core form keeps it whole.)  Equal (seed, match, span) keys keep input order, which is what the
+reference produces when its buffers are not spilled.  `-H` selects the high-quality-read variant of the filter (`ndgpu_ovl_sort_hq`); `-l 0` is refused.
 """
 from __future__ import annotations
 

@@ -333,3 +333,51 @@ def test_sort_hq_variant_matches_reference(tmp_path, profile, preset, k, flank):
     assert ovl_sort.run(argv) == 0
     assert len(want) > 10000 and open(so, "rb").read() == want
     assert open(so + ".bl").read() == want_bl
+
+
+def _random_step1_files(seed=3, n_files=5, per_file=2500, n_ids=400):
+    """Step-1 records nobody mapped: random but well-formed (spans inside the reads, both directions), 45 % of the ids are not
+    seeds -- so the "5 misses then stop" rule of a file (util/ovl_sort.c:975-1003) cuts in at different records for the two sides."""
+    from nextdenovo_amd import overlap
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(3000, 30000, n_ids).astype(np.uint32)
+    seed_len = np.where(rng.random(n_ids) < 0.55, lens, 0).astype(np.uint32)
+    files = []
+    for f in range(n_files):
+        r = np.zeros(per_file, dtype=overlap.REC)
+        # early records of a file hit seeds more often, so that the fifth miss falls somewhere in the middle of it
+        pool_hit, pool_any = np.flatnonzero(seed_len), np.arange(n_ids)
+        for k in range(per_file):
+            q = int(rng.choice(pool_hit if rng.random() < (0.97 if k < per_file // 2 else 0.6) else pool_any))
+            t = int(rng.choice(pool_hit if rng.random() < (0.97 if k < per_file // 3 else 0.6) else pool_any))
+            ql, tl = int(lens[q]), int(lens[t])
+            span = int(rng.integers(300, min(ql, tl) - 10))
+            qs, ts = int(rng.integers(0, ql - span)), int(rng.integers(0, tl - span))
+            r[k] = (int(rng.integers(0, 2)), q, qs, qs + span, t, ts, ts + span + int(rng.integers(-20, 20)) if ts + span + 20 < tl else ts + span,
+                    int(span * rng.uniform(0.2, 0.9)))
+        files.append(r)
+    return files, seed_len, int(lens[seed_len > 0].min())
+
+
+@pytest.mark.parametrize("hq", [False, True])
+def test_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, hq):
+    """The out-of-core form of the sort (raw records through the device in pieces, seeds in id ranges: what `ovl_sort -m` smaller than
+    the data does with temporary files) == the sort at once: records, order and `.bl`, with pieces that cut files where the miss
+    counters stand between 0 and 5, and on the stage fixture's own overlaps."""
+    from nextdenovo_amd import overlap, ovl_sort
+    cases = [_random_step1_files() + (40,)]
+    if not hq:
+        sl, mn = ovl_sort.read_idx(os.path.join(STAGE, ".input.seed.001.idx"))
+        cases.append((_device_raw([("seed", "part", True), ("seed", "seed", False)]), sl, mn, 40))
+    for files, seed_len, mn, k in cases:
+        monkeypatch.delenv("NDGPU_OVLSORT_PIECE_RECORDS", raising=False)
+        monkeypatch.delenv("NDGPU_OVLSORT_RANGE_CANDIDATES", raising=False)
+        recs, bl, st = overlap.sort_overlaps(files, seed_len, mn, k, 300, hq=hq)
+        assert st["ranges"] == 1 and st["kept"] == recs.size and recs.size > 100
+        for piece, rng_cap in ((257, 900), (1000000, 2000), (61, 10 ** 9)):
+            monkeypatch.setenv("NDGPU_OVLSORT_PIECE_RECORDS", str(piece))
+            monkeypatch.setenv("NDGPU_OVLSORT_RANGE_CANDIDATES", str(rng_cap))
+            r2, bl2, st2 = overlap.sort_overlaps(files, seed_len, mn, k, 300, hq=hq)
+            assert np.array_equal(r2, recs) and bl2 == bl
+            assert (st2["candidates"], st2["seeds"], st2["kept"]) == (st["candidates"], st["seeds"], st["kept"])
+            assert st2["ranges"] > (1 if rng_cap < 10 ** 9 else 0)

@@ -160,3 +160,8 @@ def test_step1_with_base_level_alignment(interpreted, tag):
 def test_chains_of_the_base_level_alignment_match_oracle(interpreted, olib):
     import test_zzz_gpu_cigar as GC
     GC.check_chains_against_oracle(olib, "ava-ont", True, "seed", "part")
+
+
+def test_sort_in_seed_ranges_equals_the_sort_at_once(interpreted, monkeypatch):
+    """The out-of-core form of the overlap sort (tests/test_gpu_ovlsort.py) under the interpreter."""
+    GS.test_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, False)
