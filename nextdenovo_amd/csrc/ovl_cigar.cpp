@@ -826,7 +826,6 @@ int run_tasks(std::vector<Task> &tasks, const Opt &o, const Targets &tg, int thr
     JobList J1;
     for (Task &T : tasks) pose_first(T, o, J1);
     std::vector<ndgpu_ksw_result> res1(J1.jobs.size());
-    memset(res1.data(), 0, sizeof(ndgpu_ksw_result) * res1.size());
     if (!J1.jobs.empty() && ndgpu_ksw_extd2_batch(J1.jobs.data(), (int)J1.jobs.size(), res1.data()) != 0) return -1;
     par_for(tasks.size(), threads, [&](size_t i) { judge(tasks[i], o, res1); });
     std::vector<ndgpu_ll_job> L;
@@ -862,7 +861,6 @@ int run_tasks(std::vector<Task> &tasks, const Opt &o, const Targets &tg, int thr
         }
     }
     std::vector<ndgpu_ksw_result> res2(J2.jobs.size());
-    memset(res2.data(), 0, sizeof(ndgpu_ksw_result) * res2.size());
     if (!J2.jobs.empty() && ndgpu_ksw_extd2_batch(J2.jobs.data(), (int)J2.jobs.size(), res2.data()) != 0) {
         free_results(res1);
         return -1;
@@ -909,7 +907,6 @@ int run_inversions(std::vector<InvTask> &inv, const Opt &o, const Targets &tg, n
         I.job = J.add(o, I.qseq + I.q_off, I.ql - I.q_off, I.tseq.data() + I.t_off, I.tl - I.t_off, (int)(o.bw * 1.5), o.zdrop, -1, EZ_EXTZ_ONLY);
     }
     std::vector<ndgpu_ksw_result> res(J.jobs.size());
-    memset(res.data(), 0, sizeof(ndgpu_ksw_result) * res.size());
     if (!J.jobs.empty() && ndgpu_ksw_extd2_batch(J.jobs.data(), (int)J.jobs.size(), res.data()) != 0) return -1;
     for (InvTask &I : inv) {
         ReadCtx &R = *I.R;
