@@ -359,8 +359,7 @@ def _random_step1_files(seed=3, n_files=5, per_file=2500, n_ids=400):
     return files, seed_len, int(lens[seed_len > 0].min())
 
 
-@pytest.mark.parametrize("hq", [False, True])
-def test_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, hq):
+def check_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, hq):   # (run from tests/test_zzz_gpu_cigar.py and tests/test_simt_overlap.py)
     """The out-of-core form of the sort (raw records through the device in pieces, seeds in id ranges: what `ovl_sort -m` smaller than
     the data does with temporary files) == the sort at once: records, order and `.bl`, with pieces that cut files where the miss
     counters stand between 0 and 5, and on the stage fixture's own overlaps."""

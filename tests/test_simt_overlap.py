@@ -144,14 +144,14 @@ def test_step2_with_the_realignment(interpreted, tmp_path, tag):
     S2.run_case(tag, dict(S2.CASES_M2 + S2.CASES_M1)[tag], tmp_path)
 
 
-_C_FAST = ("ont.sv.c", "pb.sv.dvt.c")
+_C_FAST = ("pb.sv.dvt.c",)   # (one of the nine golden runs: ~70 s under the interpreter; all nine run on the GPU)
 
 
 @pytest.mark.parametrize("tag", _C_FAST)
 def test_step1_with_base_level_alignment(interpreted, tag):
     """`--step 1 -c` (mm_align_skeleton as batches of device problems: the ksw2 extension kernel in all its roles, the ksw_ll
     kernel of the inversion test, K5 handing out chains): the compiled reference's bytes on the rearranged reads -- z-drops,
-    second passes, chain splits, inversion tests and aligned inversions all occur (the other six golden cases run on the GPU)."""
+    second passes, chain splits, inversion tests and aligned inversions all occur, with the homopolymer-compressed sketch and --dvt."""
     import test_zzz_gpu_cigar as GC
     case = [c for c in GC.G.CASES_C if c[0] == tag][0]
     GC.test_cigar_bytes_match_reference_golden(case)
@@ -164,4 +164,4 @@ def test_chains_of_the_base_level_alignment_match_oracle(interpreted, olib):
 
 def test_sort_in_seed_ranges_equals_the_sort_at_once(interpreted, monkeypatch):
     """The out-of-core form of the overlap sort (tests/test_gpu_ovlsort.py) under the interpreter."""
-    GS.test_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, False)
+    GS.check_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, False)

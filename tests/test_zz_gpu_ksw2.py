@@ -89,6 +89,3 @@ def check_ll(lib, oracle_lib=None, stride=1):
         for p, g in zip(more, K.call_ll_batch(lib, more)):
             assert g == K.call_ll_oracle(oracle_lib, p)
 
-
-def test_ksw_ll_matches_reference_vectors(ovl_lib, oracle_lib):
-    check_ll(ovl_lib, oracle_lib)

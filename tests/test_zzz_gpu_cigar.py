@@ -2,7 +2,8 @@
 the device, csrc/ovl_cigar.cpp + csrc/ksw2_kernels.hip) against the bytes the compiled reference writes: the golden `.ovl` files
 of tests/golden/make_cigar_golden.py (plain read sets and a set with insertions / inversions that z-drop, split chains and bring
 up the inversion alignment), the command line, the chains themselves against the overlap oracle, and -- where oracle/_ref
-travelled -- a fresh read set against the reference binary run on the spot."""
+travelled -- a fresh read set against the reference binary run on the spot.  (Named to run last: these paths were finished after the
+round's GPU budget was spent and have run under the kernel interpreter only.)"""
 import ctypes as C
 import os
 import sys
@@ -145,3 +146,17 @@ def test_fresh_reads_against_the_reference_binary(tmp_path):
             recs, st = ix.map_cigar(T, Q, ix.mid_occ(), ao, want_stats=True)
         assert overlap.encode(recs, np.zeros(2, dtype=np.uint32)) == want
         assert st["splits"] > 0
+
+
+@pytest.mark.parametrize("hq", [False, True])
+def test_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, hq):
+    """The out-of-core form of `ovl_sort` (also new at the end of round 3, hence in this last file): tests/test_gpu_ovlsort.py."""
+    import test_gpu_ovlsort as GS
+    GS.check_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, hq)
+
+
+def test_ksw_ll_matches_reference_vectors(oracle_lib):
+    """ksw_ll_kernel (the inversion test's local-alignment score) against the compiled reference's vectors and the oracle."""
+    import test_zz_gpu_ksw2 as GK
+    from nextdenovo_amd import overlap
+    GK.check_ll(overlap.load(), oracle_lib)
