@@ -323,6 +323,9 @@ def main():
         step()
     cns_wall[0] = 0.0
     api.reset_stats()
+    if not args.no_overlap:
+        from nextdenovo_amd import overlap as _ovl
+        _ovl.pool_calls(reset=True)
     for k in sh.stats:
         sh.stats[k] = 0
     sync()
@@ -335,6 +338,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     st = api.stats()
+    pool_timed = None
+    if not args.no_overlap:
+        pool_timed = _ovl.pool_calls()
 
     total_bases, max_dt, total_seeds = bases, dt, n_ok
     per_rank = None
@@ -423,6 +429,9 @@ def main():
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms", "lq_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
+            # buffers (re)allocated inside the timed steps: while batches ran (these stall every context) / between batches
+            "allocations": {"in_step": int(st["allocs"]), "in_step_ms": round(st["alloc_ms"], 1), "between_batches": int(st["level_allocs"]),
+                            "between_batches_ms": round(st["level_ms"], 1)},
         }
         if per_rank is not None:
             out["per_rank"] = per_rank   # over the K timed steps; rank r = seed file r
@@ -434,7 +443,9 @@ def main():
                               "value": q_bases / (o_ms * 1e-3) if o_ms > 0 else 0.0,
                               "unit": "query bases/s (this rank's raw_align jobs, index builds included)",
                               "sort": {"ms_per_step": sh.stats["sort_s"] / args.steps * 1e3, "blacklisted": int(last.get("n_bl", 0)), "k": sort_k},
-                              "pile_assembly_ms_per_step": sh.stats["assemble_s"] / args.steps * 1e3}
+                              "pile_assembly_ms_per_step": sh.stats["assemble_s"] / args.steps * 1e3,
+                              # hipMalloc / hipFree calls of the overlap library's block pool inside the timed steps (each stalls every stream)
+                              "pool_calls": {"n": pool_timed[0], "ms": round(pool_timed[1] * 1e3, 1)}}
             ost = sh.ovl_stats
             if ost:
                 out["overlap"]["kernel_ms_last_index"] = {k: round(ost[k], 3) for k in ("sketch_ms", "index_sort_ms", "seed_ms", "sort_ms",

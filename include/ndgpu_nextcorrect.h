@@ -173,6 +173,11 @@ typedef struct {
     uint64_t lq_rounds;        /* low-quality-region rounds (pile x round) handed to K12 */
     uint64_t lq_declined;      /* of which the kernel declined: the host path took them */
     double lq_ms;              /* HIP-event time of K12 */
+    uint64_t allocs;           /* device / pinned buffers (re)allocated while batches were running, since the last reset ... */
+    double alloc_ms;           /* ... and the wall time those calls took: an allocation in the middle of a step stalls every context,
+                                  so steady-state steps should show none */
+    uint64_t level_allocs;     /* the same between batches (buffers brought up to the largest sub-batch seen, nothing in flight) */
+    double level_ms;
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

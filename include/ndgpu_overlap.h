@@ -118,6 +118,9 @@ uint64_t ndgpu_ovl_trim(void);
 /* out[0] = device bytes the library has in use now, out[1] = cached for reuse, out[2] = the most it ever had in use at once -- what a
  * caller that runs another memory-hungry stage on the same device between two calls should leave free (out[2] - out[1]). */
 void ndgpu_ovl_pool_bytes(uint64_t out[3]);
+/* out[0] = hipMalloc / hipFree calls the library's block pool has made, out[1] = nanoseconds they took (such a call stalls every stream
+ * of the process, the consensus contexts' included); reset != 0 clears the counters */
+void ndgpu_ovl_pool_calls(uint64_t out[2], int reset);
 
 /* ---- overlap sort / filter: the `ovl_sort` program between the two stages (util/ovl_sort.c, raw reads, no -H) ----
  *

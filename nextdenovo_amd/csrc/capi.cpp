@@ -638,6 +638,7 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->lq_rounds = s.lq_rounds;
     o->lq_declined = s.lq_declined;
     o->lq_ms = s.lq_ms;
+    o->allocs = s.allocs, o->alloc_ms = s.alloc_ms, o->level_allocs = s.level_allocs, o->level_ms = s.level_ms;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

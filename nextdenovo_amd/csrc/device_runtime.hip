@@ -61,7 +61,11 @@ static inline bool oom_injected(size_t bytes) {
 }
 
 static std::atomic<unsigned long long> g_reserved_bytes{0};  // kept free for the caller's other stage (ndgpu_reserve_device_memory)
-static std::atomic<long long> g_dev_bytes{0};  // device memory held by the grow-only buffers of all contexts
+static std::atomic<long long> g_dev_bytes{0};
+// (re)allocations of device / pinned buffers since the last ndgpu_reset_stats and the wall time the calls took: an allocation in
+// the middle of a step stalls every context (section 6 of DESIGN.md), so a steady-state step should show none
+static std::atomic<unsigned long long> g_alloc_calls{0}, g_alloc_ns{0}, g_level_calls{0}, g_level_ns{0};
+static std::atomic<int> g_leveling{0};  // level_buffers is at work (no kernel in flight): counted apart  // device memory held by the grow-only buffers of all contexts
 // The runtime itself allocates on the device (kernel arguments, staging, scratch): a device filled to the last byte makes
 // launches and copies fail where nothing can be done about it.  Allocations that would leave less than this are refused
 // like an exhausted device (-> DeviceOom -> the sub-batch is halved).
@@ -88,6 +92,15 @@ static size_t high_water(const char *name, size_t bytes) {
     return v;
 }
 
+struct AllocTimer {  // counts one (re)allocation and its wall time
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocTimer() {
+        const unsigned long long ns = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (g_leveling.load()) g_level_calls++, g_level_ns += ns;
+        else g_alloc_calls++, g_alloc_ns += ns;
+    }
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -96,6 +109,7 @@ struct DevBuf {
     void reserve(size_t n) {
         if (n <= cap) return;
         n = std::max(n, high_water(name, n * sizeof(T)) / sizeof(T));
+        const AllocTimer alloc_timer;
         if (p) {
             if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] free %s %p\n", name, (void *)p);
             if (!g_debug_nofree) HIP_CHECK(hipFree(p));
@@ -149,6 +163,7 @@ struct PinBuf {
     void reserve(size_t n) {
         if (n <= cap) return;
         n = std::max(n, high_water(name, n * sizeof(T)) / sizeof(T));
+        const AllocTimer alloc_timer;
         if (p && !g_debug_nofree) HIP_CHECK(hipHostFree(p));
         p = nullptr;
         cap = 0;
@@ -437,10 +452,13 @@ RuntimeStats DeviceAligner::total_stats() {
         t.links += s.links; t.score_launches += s.score_launches; t.backtrack_ms += s.backtrack_ms;
         t.score_segments += s.score_segments; t.score_repairs += s.score_repairs; t.score_slow_piles += s.score_slow_piles;
     }
+    t.allocs = g_alloc_calls.load(), t.alloc_ms = (double)g_alloc_ns.load() * 1e-6;
+    t.level_allocs = g_level_calls.load(), t.level_ms = (double)g_level_ns.load() * 1e-6;
     return t;
 }
 
 void DeviceAligner::reset_all_stats() {
+    g_alloc_calls = 0, g_alloc_ns = 0, g_level_calls = 0, g_level_ns = 0;
     for (int i = 0; i < kMaxContexts; i++)
         if (DeviceAligner *c = peek(i)) c->reset_stats();
 }
@@ -496,6 +514,7 @@ void DeviceAligner::release_memory() {
 // met has asked for, so that the next call -- whichever context then meets that sub-batch -- allocates nothing in the middle of
 // a step.  (A context that is out of device memory keeps what it has.)
 void DeviceAligner::level_buffers(int drivers) {
+    struct Mark { Mark() { g_leveling++; } ~Mark() { g_leveling--; } } mark;
     for (int c = 0; c < drivers && c < kMaxContexts; c++) {
         DeviceAligner *d = peek(c);
         if (!d) continue;

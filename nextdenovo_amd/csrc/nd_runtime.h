@@ -43,6 +43,10 @@ struct RuntimeStats {
     uint64_t lq_rounds = 0;        // low-quality-region rounds (pile x round) handed to K12
     uint64_t lq_declined = 0;      // of which the kernel declined (host path took them)
     double lq_ms = 0;              // K12
+    uint64_t allocs = 0;           // device / pinned buffers (re)allocated while batches were running, since the last reset
+    double alloc_ms = 0;           // wall time of those calls (an allocation in the middle of a step stalls every context)
+    uint64_t level_allocs = 0;     // the same between batches (level_buffers: nothing in flight)
+    double level_ms = 0;
 };
 
 // Thrown when a device (or pinned host) allocation fails for lack of memory.  The C ABI catches it, releases the

@@ -25,6 +25,7 @@
 #include "ovl_pool.h"
 
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <unordered_map>
 
@@ -38,6 +39,11 @@ std::multimap<size_t, void*> g_pool_free;        // size class -> block
 std::unordered_map<void*, size_t> g_pool_size;   // live + cached blocks -> size class
 size_t g_pool_cached = 0;
 size_t g_pool_live = 0, g_pool_peak = 0;         // bytes handed out now / the most that ever were
+std::atomic<unsigned long long> g_pool_calls{0}, g_pool_ns{0};  // hipMalloc / hipFree calls the pool made and their wall time
+struct PoolTimer {
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	~PoolTimer() { g_pool_calls++; g_pool_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 size_t size_class(size_t b)
 {
 	if (b < 4096) return 4096;
@@ -64,6 +70,7 @@ void *pool_alloc(size_t bytes)
 		}
 	}
 	void *p = nullptr;
+	const PoolTimer timer;
 	hipError_t e = hipMalloc(&p, c);
 	if (e != hipSuccess) { // give the cache back and retry once
 		pool_trim();
@@ -103,6 +110,7 @@ void pool_free(void *p)
 	if (it == g_pool_size.end()) { (void)hipFree(p); return; }
 	g_pool_live -= it->second;
 	if (g_pool_live + g_pool_cached + it->second > g_pool_peak + g_pool_peak / 4 || g_pool_cached + it->second > pool_cap()) {
+		const PoolTimer timer;
 		(void)hipFree(p);
 		g_pool_size.erase(it);
 		return;
@@ -121,6 +129,7 @@ void pool_trim()
 
 size_t pool_cached_bytes() { std::lock_guard<std::mutex> g(g_pool_mu); return g_pool_cached; }
 void pool_bytes(uint64_t out[3]) { std::lock_guard<std::mutex> g(g_pool_mu); out[0] = g_pool_live, out[1] = g_pool_cached, out[2] = g_pool_peak; }
+void pool_calls(uint64_t out[2], int reset) { out[0] = g_pool_calls.load(), out[1] = g_pool_ns.load(); if (reset) g_pool_calls = 0, g_pool_ns = 0; }
 
 // (a device filled to the brim makes the runtime's own allocations fail too -- launch arguments, staging: "out of memory" may
 // surface at any call; it is reported as what it is, so that the caller can release memory and try again)
@@ -1039,6 +1048,7 @@ int ndgpu_ovl_last_error(void) { return ndovl::last_error_take(); }
 
 // device bytes of the library's block pool: in use now, cached for reuse, the most that ever were in use at once
 void ndgpu_ovl_pool_bytes(uint64_t out[3]) { ndovl::pool_bytes(out); }
+void ndgpu_ovl_pool_calls(uint64_t out[2], int reset) { ndovl::pool_calls(out, reset); }
 
 // release the device blocks the library keeps cached between calls (returns the bytes released)
 uint64_t ndgpu_ovl_trim(void)

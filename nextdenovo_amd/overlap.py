@@ -316,6 +316,16 @@ def pool_bytes():
     return int(out[0]), int(out[1]), int(out[2])
 
 
+def pool_calls(reset: bool = False):
+    """(hipMalloc / hipFree calls the overlap library's block pool made, seconds they took) since the last reset."""
+    lib = load()
+    out = (C.c_uint64 * 2)()
+    lib.ndgpu_ovl_pool_calls.argtypes = [C.c_void_p, C.c_int]
+    lib.ndgpu_ovl_pool_calls.restype = None
+    lib.ndgpu_ovl_pool_calls(out, 1 if reset else 0)
+    return int(out[0]), out[1] * 1e-9
+
+
 def trim() -> int:
     """Release the device blocks the overlap library keeps cached between calls (ndgpu_ovl_trim)."""
     lib = load()
