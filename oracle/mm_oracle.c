@@ -1060,3 +1060,6 @@ int64_t nd_mm_step2_mode0(const nd_mm_opt *opt, float minide, int32_t minmatch, 
 	return nd_mm_step2(opt, 0, 17, 10, 20, minide, minmatch, mid_occ_frac, mid_occ_fixed, n_t, tcodes, toff, tlen, tids, n_q, qcodes, qoff, qlen, qids,
 	                   out, out_cap, mid_occ_out, prev_io, s2_state);
 }
+
+/* ---------------------------------------------------------------- --step 1 -c: base-level alignment through the chains */
+#include "cigar_oracle.c"

@@ -118,6 +118,49 @@ def step1(lib, opt: MMOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0, batch_size=
     return blob, mid_occ
 
 
+class AlnOpt(C.Structure):  # nd_aln_opt (oracle/cigar_oracle.c): the scoring side of -c, defaults of mm_mapopt_init (options.c:36-43)
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "q", "e", "q2", "e2", "sc_ambi", "zdrop", "zdrop_inv", "end_bonus", "min_dp_max", "min_ksw_len")] \
+        + [("max_sw_mat", C.c_int64)]
+
+
+def aln_opt(**kw) -> AlnOpt:
+    o = AlnOpt(a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, zdrop_inv=200, end_bonus=-1, min_dp_max=80, min_ksw_len=200,
+               max_sw_mat=100000000)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def step1_cigar(lib, opt: MMOpt, ao: AlnOpt, tset, qset, mid_occ_frac=2e-4, mid_occ=0, batch_size=None):
+    """`--step 1 -c` of the oracle (nd_mm_step1_cigar): .ovl bytes; arguments as step1()."""
+    tid, tl, tc, to = tset
+    qid, ql, qc, qo = qset
+    parts = [(0, tid.size)]
+    if batch_size is not None:
+        from nextdenovo_amd.minimap2_nd import index_parts
+        parts = index_parts(tl, batch_size)
+    lib.nd_mm_step1_cigar.restype = C.c_int64
+    lib.nd_mm_step1_cigar.argtypes = [C.POINTER(MMOpt), C.POINTER(AlnOpt), C.c_float, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_void_p]
+    prev = np.zeros(2, dtype=np.uint32)
+    blob = b""
+    for lo, hi in parts:
+        cap = 1 << 22
+        while True:
+            out = np.zeros(cap, dtype=np.uint8)
+            mo = C.c_int32(0)
+            pv = prev.copy()
+            n = lib.nd_mm_step1_cigar(C.byref(opt), C.byref(ao), np.float32(mid_occ_frac), mid_occ, hi - lo, ptr(tc), ptr(to[lo:hi]), ptr(tl[lo:hi]),
+                                      ptr(tid[lo:hi]), qid.size, ptr(qc), ptr(qo), ptr(ql), ptr(qid), ptr(out), cap, C.byref(mo), ptr(pv))
+            if n >= 0:
+                break
+            cap = max(cap * 4, -n * 2)
+        prev = pv
+        mid_occ = mo.value
+        blob += out[:n].tobytes()
+    return blob, mid_occ
+
+
 def step2_mode0(lib, opt: MMOpt, tset, qsets, minide=0.05, minmatch=100, mid_occ_frac=2e-4):
     return step2(lib, opt, tset, qsets, 0, minide, minmatch, mid_occ_frac)
 

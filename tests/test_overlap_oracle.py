@@ -208,3 +208,15 @@ def test_oracle_step2_matches_golden(lib, tag):
     assert lib.nd_mm_step2_unrestated() == 0   # (no mapping of the fixture takes the branch of mm_chain_dp_nextdenovo that is not restated)
     assert got == open(os.path.join(OUT, tag + ".ovl"), "rb").read()
     assert got_bl == open(os.path.join(OUT, tag + ".ovl.bl")).read()
+
+
+def test_cigar_oracle_matches_golden_ovl(lib):
+    """`--step 1 -c`: the oracle's restatement of mm_align_skeleton (oracle/cigar_oracle.c, scalar ksw2 / ksw_ll kernels) against the
+    compiled reference's bytes on the rearranged reads -- z-drops, second passes, chain splits, inversion tests, aligned inversions,
+    the homopolymer-compressed sketch, --dvt.  (All nine golden runs match; one is in the CPU suite, ~30 s.)"""
+    import make_cigar_golden as G
+    tag, preset, t, q, dual, extra = [c for c in G.CASES_C if c[0] == "pb.sv.dvt.c"][0]
+    with open(os.path.join(G.OUT, tag + ".ovl"), "rb") as f:
+        want = f.read()
+    got, _ = M.step1_cigar(lib, M.preset(preset, dual, dvt=1), M.aln_opt(), M.load_set(G.set_path(t)), M.load_set(G.set_path(q)))
+    assert got == want

@@ -160,3 +160,42 @@ def test_ksw_ll_matches_reference_vectors(oracle_lib):
     import test_zz_gpu_ksw2 as GK
     from nextdenovo_amd import overlap
     GK.check_ll(overlap.load(), oracle_lib)
+
+
+def test_device_equals_oracle_on_unseen_reads(oracle_lib):
+    """The device path against the oracle's restatement of the -c path (oracle/cigar_oracle.c) on reads neither has a golden file
+    for -- needs no compiled reference on the box."""
+    from nextdenovo_amd import overlap, synth
+    olib = M.bind(oracle_lib)
+    rng = np.random.default_rng(9)
+    g = synth.make_genome(30000, seed=41, n_repeats=3, repeat_len=1500)
+    rs = synth.simulate_reads(g, 18, "ont", seed=42, mu=8.8, sigma=0.4, min_len=2500)
+    seqs = []
+    for n, s in enumerate(rs.seqs):
+        s = s.copy()
+        if n % 3 == 1 and s.size > 5000:
+            p = int(s.size * 0.45)
+            s = np.concatenate([s[:p], rng.integers(0, 4, int(rng.integers(500, 1000))).astype(np.uint8), s[p:]])
+        if n % 3 == 2 and s.size > 5000:
+            p, ln = int(s.size * 0.5), int(rng.integers(700, 1200))
+            s[p:p + ln] = synth.revcomp_codes(s[p:p + ln])
+        seqs.append(s)
+    n = len(seqs)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    lens = np.asarray([s.size for s in seqs], dtype=np.uint32)
+    words = [synth.pack_2bit_msb(s) for s in seqs]
+    woff = np.zeros(n, dtype=np.uint64)
+    woff[1:] = np.cumsum([w.size for w in words])[:-1]
+    R = overlap.ReadSet(ids, lens, np.concatenate(words), woff)
+    codes = np.concatenate(seqs).astype(np.uint8)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+    oset = (ids, lens, codes, off)
+    for preset in ("ava-ont", "ava-pb"):
+        o, ao = dev_opts(preset, False, ())
+        with overlap.Index(o, R) as ix:
+            mid = ix.mid_occ()
+            recs, st = ix.map_cigar(R, R, mid, ao, want_stats=True)
+        want, _ = M.step1_cigar(olib, M.preset(preset, False), M.aln_opt(), oset, oset, mid_occ=mid)
+        assert overlap.encode(recs, np.zeros(2, dtype=np.uint32)) == want
+        assert st["splits"] > 0 and len(want) > 1000
