@@ -47,9 +47,11 @@ def run_ref(argv):
 
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else "measure_modes.json"
+    only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"modes", "c", "ksw"}   # which blocks to run
+    small = bool(os.environ.get("ND_MEASURE_SMALL"))   # (a dry run of the script itself on tiny inputs)
     wd = tempfile.mkdtemp(prefix="ndmodes")
     res = {"host_cores": CORES}
-    g = synth.make_genome(3000000, seed=91, n_repeats=5)
+    g = synth.make_genome(40000 if small else 3000000, seed=91, n_repeats=5)
     rs = synth.simulate_reads(g, 30, "hifi", seed=92, mu=9.3, sigma=0.35, min_len=3000)
     fa = os.path.join(wd, "cns.fasta")
     write_fasta(fa, rs.seqs)
@@ -61,7 +63,7 @@ def main():
         ("step2_mode0", ["--step", "2", "--mode", "0", "--dual=yes", "-x", "ava-ont", "-k", "17", "-w", "17", "--minlen", "2000"]),
         ("step2_default_mode2", ["--step", "2", "--dual=yes", "-x", "ava-ont", "-k", "17", "-w", "17", "--minlen", "2000"]),
     ]
-    for name, argv in cases:
+    for name, argv in (cases if "modes" in only else []):
         out = os.path.join(wd, name + ".ovl")
         minimap2_nd.run([*argv, "-t", "8", fa, fa, "-o", out])   # warm-up (HIP initialisation, allocator)
         dev_s, _ = timed(lambda: minimap2_nd.run([*argv, "-t", "8", fa, fa, "-o", out]))
@@ -78,7 +80,17 @@ def main():
         print(name, json.dumps(entry), flush=True)
 
     # --step 1 -c on raw reads (ONT error profile): base-level alignment through every chain (csrc/ovl_cigar.cpp)
-    g2 = synth.make_genome(1000000, seed=93, n_repeats=5)
+    if "c" in only:
+        measure_c(res, wd, have_ref, small)
+    if "ksw" in only:
+        measure_ksw(res, small)
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def measure_c(res, wd, have_ref, small):
+    g2 = synth.make_genome(30000 if small else 1000000, seed=93, n_repeats=5)
     rs2 = synth.simulate_reads(g2, 20, "ont", seed=94, mu=9.3, sigma=0.5, min_len=2000)
     fa2 = os.path.join(wd, "raw.fasta")
     write_fasta(fa2, rs2.seqs)
@@ -96,12 +108,14 @@ def main():
     res["step1_c_ava_ont"] = entry
     print("step1_c_ava_ont", json.dumps(entry), flush=True)
 
+
+def measure_ksw(res, small):
     # ksw2-extd2: a batch of gap-filling / extension problems as mm_align1 would hand them over
     import ksw_util as K
     rng = np.random.default_rng(5)
     lib = overlap.load()
     probs = []
-    for n in range(6000):
+    for n in range(60 if small else 6000):
         L = int(rng.choice([200, 500, 1000, 2000, 4000]))
         t = rng.integers(0, 4, L).astype(np.uint8)
         q = t.copy()
@@ -133,9 +147,6 @@ def main():
         entry["reference_sample"] = "%d of the problems, ksw_extd2_sse (SSE4.1) through ctypes, one thread" % len(sample)
     res["ksw2_extd2_batch"] = entry
     print("ksw2", json.dumps(entry), flush=True)
-    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
-    with open(out_path, "w") as f:
-        json.dump(res, f, indent=1)
 
 
 if __name__ == "__main__":
