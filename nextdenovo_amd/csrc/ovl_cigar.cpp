@@ -26,7 +26,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -48,15 +50,24 @@ template <class F> void par_for(size_t n, int threads, F f) {
     }
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;
+    std::exception_ptr failed;  // the first exception of a worker, rethrown in the caller
+    std::mutex mu;
     for (int t = 0; t < nt; t++)
         th.emplace_back([&] {
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= n) break;
-                f(i);
+            try {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= n) break;
+                    f(i);
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu);
+                if (!failed) failed = std::current_exception();
+                next = n;
             }
         });
     for (auto &t : th) t.join();
+    if (failed) std::rethrow_exception(failed);
 }
 
 struct Anchor { uint64_t x, y; };
@@ -1008,6 +1019,7 @@ extern "C" int64_t ndgpu_ovl_map_cigar(ndgpu_ovl_index *idx, const ndgpu_ovl_opt
     }
     int threads = aopt->host_threads > 0 ? aopt->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     const Targets tg{t_words, t_word_off, t_lens, t_ids};
+    try {
 
     ndgpu_ovl_rec *chains = nullptr;
     uint32_t *counts = nullptr;
@@ -1134,4 +1146,8 @@ extern "C" int64_t ndgpu_ovl_map_cigar(ndgpu_ovl_index *idx, const ndgpu_ovl_opt
     if (!out.empty()) memcpy(*recs, out.data(), sizeof(ndgpu_ovl_rec) * out.size());
     if (stats) stats->overlaps = out.size();
     return (int64_t)out.size();
+    } catch (const std::exception &e) {  // (host memory: nothing of this may cross the C boundary)
+        fprintf(stderr, "[ndgpu_overlap] ndgpu_ovl_map_cigar: %s\n", e.what());
+        return -2;
+    }
 }
