@@ -279,7 +279,9 @@ typedef struct ndgpu_ovl_aln_opt {
 	int32_t zdrop, zdrop_inv, end_bonus;
 	int32_t min_dp_max;                   /* -s: 80 (min_chain_score * a when mm_mapopt_init runs; the ava presets do not touch it) */
 	int32_t min_ksw_len;                  /* 200: anchors closer than this on either read are bridged by the next gap's alignment */
-	int64_t max_sw_mat;                   /* 100000000: a larger problem counts as z-dropped (mm_align_pair, minimap2/align.c:323) */
+	int64_t max_sw_mat;                   /* --cap-sw-mem; 0 = none (the default: mm_mapopt_init leaves it 0): a problem of more cells counts as
+	                                         z-dropped without being aligned (mm_align_pair, minimap2/align.c:323; the compiled reference segfaults on the first such gap of a
+	                                         chain that has no CIGAR yet, so there is nothing to compare a cap with) */
 	int32_t host_threads;                 /* threads of the bookkeeping between the batches; 0 = all */
 } ndgpu_ovl_aln_opt;
 void ndgpu_ovl_aln_opt_default(ndgpu_ovl_aln_opt *o, int32_t min_chain_score);

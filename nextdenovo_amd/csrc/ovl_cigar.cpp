@@ -980,7 +980,7 @@ extern "C" void ndgpu_ovl_aln_opt_default(ndgpu_ovl_aln_opt *o, int32_t min_chai
     o->a = 2, o->b = 4, o->q = 4, o->e = 2, o->q2 = 24, o->e2 = 1, o->sc_ambi = 1, o->zdrop = 400, o->zdrop_inv = 200, o->end_bonus = -1;
     o->min_dp_max = 40 * 2;  // min_chain_score * a at the time mm_mapopt_init runs (40, before the preset raises it)
     (void)min_chain_score;
-    o->min_ksw_len = 200, o->max_sw_mat = 100000000;
+    o->min_ksw_len = 200, o->max_sw_mat = 0;  // (this minimap2 never sets a cap: mm_mapopt_init leaves it 0, --cap-sw-mem sets it, main.c:305)
     o->host_threads = 0;
 }
 

@@ -62,7 +62,7 @@ class Args:
         self.ops = []  # (name, value) in command-line order, applied after the preset
 
 
-LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df", "--minide", "--minmatch", "--kn", "--wn", "--cn"}
+LONG_WITH_ARG = {"--step", "--minlen", "--maxhan1", "--maxhan2", "--seed", "--dual", "--mode", "--df", "--minide", "--minmatch", "--kn", "--wn", "--cn", "--cap-sw-mem"}
 SHORT_WITH_ARG = set("xtfIKkwornmgsNpMABOEz")
 
 
@@ -179,6 +179,8 @@ def build_opt(a: Args) -> overlap.Opt:
             a.aopt.b = int(val)
         elif name == "-s":
             a.aopt.min_dp_max = int(val)
+        elif name == "--cap-sw-mem":
+            a.aopt.max_sw_mat = parse_num(val)   # main.c:305
         elif name in ("-O", "-E", "-z"):  # one value sets both (main.c:353-361)
             head, _, tail = val.partition(",")
             first, second = int(head), int(tail) if tail else int(head)

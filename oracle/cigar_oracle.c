@@ -323,6 +323,17 @@ static void c_align_pair(c_ctx *C, int qlen, const uint8_t *qseq, int tlen, cons
 		return;
 	}
 	nd_oracle_ksw_extd2(qlen, qseq, tlen, tseq, 5, C->mat, (int8_t)o->q, (int8_t)o->e, (int8_t)o->q2, (int8_t)o->e2, w, zdrop, end_bonus, flag, ez, C->cg, C->cg_cap);
+	if (getenv("ND_ORACLE_DBG")) { /* the format of minimap2's --print-aln-seq (align.c:315-322,333-339), for a diff against it */
+		int i;
+		fprintf(stderr, "===> q=(%d,%d), e=(%d,%d), bw=%d, flag=%d, zdrop=%d <===\n", o->q, o->q2, o->e, o->e2, w, flag, o->zdrop);
+		for (i = 0; i < tlen; ++i) fputc("ACGTN"[tseq[i]], stderr);
+		fputc('\n', stderr);
+		for (i = 0; i < qlen; ++i) fputc("ACGTN"[qseq[i]], stderr);
+		fputc('\n', stderr);
+		fprintf(stderr, "score=%d, cigar=", ez->score);
+		for (i = 0; i < ez->n_cigar; ++i) fprintf(stderr, "%d%c", C->cg[i] >> 4, "MIDN"[C->cg[i] & 0xf]);
+		fprintf(stderr, "\n");
+	}
 }
 
 static int c_test_zdrop(c_ctx *C, const uint8_t *qseq, const uint8_t *tseq, int n_cigar, const uint32_t *cigar) /* mm_test_zdrop */

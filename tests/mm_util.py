@@ -125,7 +125,7 @@ class AlnOpt(C.Structure):  # nd_aln_opt (oracle/cigar_oracle.c): the scoring si
 
 def aln_opt(**kw) -> AlnOpt:
     o = AlnOpt(a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, zdrop_inv=200, end_bonus=-1, min_dp_max=80, min_ksw_len=200,
-               max_sw_mat=100000000)
+               max_sw_mat=0)   # (never set by mm_mapopt_init: no cap unless --cap-sw-mem)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

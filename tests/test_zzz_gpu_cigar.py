@@ -33,6 +33,8 @@ def dev_opts(preset, dual, extra):
         ao.zdrop, ao.zdrop_inv = int(z[0]), int(z[-1])
     if "-s" in extra:
         ao.min_dp_max = int(extra[extra.index("-s") + 1])
+    if "--cap-sw-mem" in extra:
+        ao.max_sw_mat = int(extra[extra.index("--cap-sw-mem") + 1])
     return o, ao
 
 
