@@ -4,7 +4,9 @@
     python tools/fuzz_overlap.py step2 SEED N    oracle `--step 2` (--mode 0 / 1 / 2, --minlen --maxhan --minide --minmatch --kn --wn --cn)
     python tools/fuzz_overlap.py cli SEED N      the DEVICE command line (python -m nextdenovo_amd.minimap2_nd: --step 1 with the options above, -c,
                                                  --mode 3) -- on a GPU box, or with NDGPU_SIMT=1 under the kernel interpreter
-Round 3: 75 + 30 + 32 cases, all byte-identical.  (`-c` has a fuzzer of its own: tools/fuzz_cigar.py.)"""
+    python tools/fuzz_overlap.py sort SEED N     the sort oracle (and, on a GPU box with NDGPU_FUZZ_DEVICE=1 or under NDGPU_SIMT=1, the device sort)
+                                                 against the compiled `ovl_sort` (-k -l -H)
+Round 3: 75 + 30 + 32 + 38 cases, all byte-identical.  (`-c` has a fuzzer of its own: tools/fuzz_cigar.py.)"""
 import ctypes as C
 import os
 import subprocess
@@ -162,17 +164,64 @@ def fuzz_cli(seed, n_cases, lib):
 
 
 
+def fuzz_sort(seed, n_cases, lib):
+    """`ovl_sort` (-k -l -H on ONT / HiFi read sets with glued chimeric reads): the sort oracle -- and with DEV the device sort -- against the
+    compiled reference program."""
+    import os_util as O
+    from nextdenovo_amd import ovl
+    olib = O.bind(lib)
+    DEV = bool(os.environ.get("NDGPU_SIMT") or os.environ.get("NDGPU_FUZZ_DEVICE"))
+    if DEV:
+        from nextdenovo_amd import overlap
+    rng = np.random.default_rng(seed)
+    n = n_cases
+    bad = 0
+    for it in range(n):
+        G=int(rng.integers(30000,90000)); depth=float(rng.uniform(15,70)); prof=str(rng.choice(["ont","ont","hifi"]))
+        g=synth.make_genome(G, seed=int(rng.integers(1,10**6)), n_repeats=int(rng.integers(0,6)), repeat_len=int(rng.integers(800,3000)))
+        kw=dict(mu=9.0,sigma=0.3,min_len=3000) if prof=="hifi" else dict(mu=float(rng.uniform(8.6,9.4)),sigma=0.5,min_len=1000)
+        rs=synth.simulate_reads(g, depth, prof, seed=int(rng.integers(1,10**6)), **kw)
+        seqs=list(rs.seqs)
+        for t in range(int(rng.integers(0,25))):
+            a,b=rng.integers(0,len(seqs),2); y=synth.revcomp_codes(seqs[b]) if t%2 else seqs[b]
+            seqs.append(np.concatenate([seqs[a][:max(1500,seqs[a].size//2)], y[:max(1500,y.size//2)]]))
+        wd=tempfile.mkdtemp(prefix="fs")
+        seed,part=M.dump_reads(wd,[synth.codes_to_ascii(s) for s in seqs],seed_cutoff=int(rng.choice([4000,7000,10000])))
+        preset="ava-hifi" if prof=="hifi" else "ava-ont"
+        files=[]
+        try:
+            if part:
+                M.ref_step1(seed,part,os.path.join(wd,"a.ovl"),preset,True); files.append(os.path.join(wd,"a.ovl"))
+            M.ref_step1(seed,seed,os.path.join(wd,"b.ovl"),preset,False); files.append(os.path.join(wd,"b.ovl"))
+        except subprocess.CalledProcessError: print(it,"step1 failed",flush=True); continue
+        idx=os.path.join(wd,"db",".input.seed.001.idx")
+        k=int(rng.choice([6,12,20,30,40,60])); flank=int(rng.choice([100,300,300,1000])); hq=bool(prof=="hifi" and rng.random()<0.7) or bool(rng.random()<0.15)
+        try: want,want_bl=O.ref_sort(wd,idx,files,k=k,flank=flank if flank!=300 else None,hq=hq)
+        except Exception as e: print(it,"ref sort failed",e,flush=True); continue
+        sl,mn=O.read_idx(idx)
+        blob,bl,_=O.oracle_sort(olib,[ovl.decode_ovl(f) for f in files],sl,mn,max_bin_cov=k,flank=flank,hq=hq)
+        ok=blob==want and bl==want_bl
+        if DEV:
+            recs,dbl,_=overlap.sort_overlaps([overlap.from_decoded(ovl.decode_ovl(f)) for f in files], sl, mn, k, flank, hq=hq)
+            ok = ok and overlap.encode(recs,np.zeros(2,dtype=np.uint32))==want and ''.join('%d %s\n'%x for x in dbl)==want_bl
+        bad+=(not ok)
+        print(it,"equal" if ok else "DIFFER",prof,"k",k,"l",flank,"H",hq,len(blob),len(want),"" if ok else wd,flush=True)
+    print("mismatches", bad)
+    return bad
+
+
+
 def main():
     mode, seed, n_cases = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     lib = M.bind(C.CDLL(os.path.join(ROOT, "oracle", "libndoracle.so")))
     lib.nd_mm_step2_unrestated.restype = C.c_int64
-    if mode == "cli" and os.environ.get("NDGPU_SIMT"):
+    if mode in ("cli", "sort") and os.environ.get("NDGPU_SIMT"):
         sys.path.insert(0, os.path.join(ROOT, "tests", "simt"))
         import build_simt
         from nextdenovo_amd import overlap
         os.environ.setdefault("NDGPU_CONTEXTS", "1")
         overlap._lib = overlap._bind(C.CDLL(build_simt.build_overlap()))
-    return 1 if {"plain": fuzz_plain, "step2": fuzz_step2, "cli": fuzz_cli}[mode](seed, n_cases, lib) else 0
+    return 1 if {"plain": fuzz_plain, "step2": fuzz_step2, "cli": fuzz_cli, "sort": fuzz_sort}[mode](seed, n_cases, lib) else 0
 
 
 if __name__ == "__main__":
