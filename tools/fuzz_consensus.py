@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Random piles and random parameters against the compiled reference's nextCorrect() (oracle/_ref/nextcorrect.so):
+    python tools/fuzz_consensus.py SEED N_SETS
+Every set: a random genome / depth / error profile (ONT, CLR, HiFi), its piles (analytic overlaps), random `read_type`, `-fast`, `-split`,
+`max_lq_length`, `min_len_aln`, `max_cov_aln`, `min_cov_base`, `min_error_corrected_ratio`; the resident-DB batch entry (ndgpu_correct_piles:
+all kernels incl. K12) against the reference pile by pile: length, float32 identity bits, sequence.  On a GPU box, or with NDGPU_SIMT=1 under
+the kernel interpreter (a minute or two per set)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refpipe  # noqa: E402
+from nextdenovo_amd import api, synth  # noqa: E402
+
+
+def main():
+    seed, n_sets = int(sys.argv[1]), int(sys.argv[2])
+    if os.environ.get("NDGPU_SIMT"):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "simt"))
+        import build_simt
+        os.environ.setdefault("NDGPU_CONTEXTS", "2")
+        api._LIB = api._bind(C.CDLL(build_simt.build()))
+    ref = refpipe.ref_cns()
+    rng = np.random.default_rng(seed)
+    bad = total = 0
+    for it in range(n_sets):
+        prof = str(rng.choice(["ont", "ont", "clr", "hifi"]))
+        read_type = {"ont": 1, "clr": int(rng.choice([1, 2])), "hifi": 3}[prof]
+        g = synth.make_genome(int(rng.integers(15000, 40000)), seed=int(rng.integers(1, 10 ** 6)), n_repeats=int(rng.integers(0, 3)), repeat_len=1200)
+        depth = float(rng.uniform(14, 45))
+        kw = dict(mu=9.0, sigma=0.3, min_len=2500) if prof == "hifi" else dict(mu=float(rng.uniform(8.2, 9.0)), sigma=float(rng.uniform(0.3, 0.6)))
+        rs = synth.simulate_reads(g, depth, prof, seed=int(rng.integers(1, 10 ** 6)), **kw)
+        P = dict(min_len_aln=int(rng.choice([300, 500, 1000])), max_cov_aln=int(rng.choice([20, 45, 130])), min_cov_base=int(rng.choice([2, 4, 6])),
+                 min_error_corrected_ratio=float(rng.choice([0.6, 0.8, 0.95])), split=int(rng.random() < 0.3), fast=int(rng.random() < 0.25),
+                 read_type=read_type)
+        max_lq = int(rng.choice([500, 1000, 10000]))
+        piles = synth.build_piles(rs, seed_cutoff=1000, max_cov_aln=P["max_cov_aln"], min_len_aln=P["min_len_aln"])
+        if not piles:
+            continue
+        if len(piles) > 14:
+            piles = [piles[i] for i in sorted(rng.choice(len(piles), 14, replace=False))]
+        words, off, lens = synth.pack_db(rs)
+        db = api.ReadDB(words, off, lens)
+        recs, poff = synth.flatten_piles(piles)
+        t0 = time.time()
+        got = db.correct_piles(recs, poff, max_lq_length=max_lq, host_threads=4, **P)
+        db.close()
+        n_bad = 0
+        for p, gt in zip(piles, got):
+            seqs, st, en, mal = synth.pile_sequences(rs, p)
+            mlq = min(en[0] // 2, max_lq)   # lib/nextcorrect.py:137: max_lq_length is capped by half the seed
+            want = refpipe.call_nextcorrect(ref, seqs, st, en, mal, P["min_len_aln"], P["max_cov_aln"], P["min_cov_base"], mlq,
+                                            P["min_error_corrected_ratio"], P["split"], P["fast"], P["read_type"])
+            same = gt[0] == want[0] and (want[0] <= 4 or (gt[2] == want[2] and np.float32(gt[1]) == np.float32(want[1])))
+            n_bad += not same
+        total += len(piles)
+        bad += n_bad
+        print(it, "equal" if n_bad == 0 else "DIFFER(%d)" % n_bad, prof, "piles", len(piles), P, "max_lq", max_lq, "%.0fs" % (time.time() - t0), flush=True)
+    print("piles", total, "mismatches", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
