@@ -6,7 +6,8 @@
                                                  --mode 3) -- on a GPU box, or with NDGPU_SIMT=1 under the kernel interpreter
     python tools/fuzz_overlap.py sort SEED N     the sort oracle (and, on a GPU box with NDGPU_FUZZ_DEVICE=1 or under NDGPU_SIMT=1, the device sort)
                                                  against the compiled `ovl_sort` (-k -l -H)
-Round 3: 75 + 30 + 32 + 38 cases, all byte-identical.  (`-c` has a fuzzer of its own: tools/fuzz_cigar.py.)"""
+    python tools/fuzz_overlap.py dump SEED N     the device `seq_dump` command against the compiled one (GPU box or NDGPU_SIMT=1)
+Round 3: 75 + 30 + 32 + 38 + 52 cases, all byte-identical.  (`-c` has a fuzzer of its own: tools/fuzz_cigar.py.)"""
 import ctypes as C
 import os
 import subprocess
@@ -211,17 +212,68 @@ def fuzz_sort(seed, n_cases, lib):
 
 
 
+def fuzz_dump(seed, n_cases, lib):
+    """`seq_dump` (messy FASTA / FASTQ[.gz]: lower case, N and IUPAC codes, CRLF, empty records, multi-file fofn; -f -s -b -n): the device
+    command (the 2-bit packer kernel) against the compiled reference program, every output file."""
+    REF = os.path.join(ROOT, 'oracle', '_ref', 'seq_dump')
+    rng = np.random.default_rng(seed)
+    n = n_cases
+    bad = 0
+    import gzip
+    from nextdenovo_amd import seq_dump
+
+    def seq(k):
+        alpha=list("ACGT") if rng.random()<0.6 else list("ACGTacgtNnRYKMU-")
+        p=np.ones(len(alpha)); p[:4]=20; p/=p.sum()
+        return "".join(rng.choice(alpha,k,p=p))
+    for it in range(n):
+        d=tempfile.mkdtemp(prefix="fd"); paths=[]
+        for fi in range(int(rng.integers(1,5))):
+            fq=rng.random()<0.4; gz=rng.random()<0.4
+            path=os.path.join(d,"f%d.%s%s"%(fi,"fq" if fq else "fa",".gz" if gz else ""))
+            with (gzip.open(path,"wt",newline="") if gz else open(path,"w",newline="")) as f:
+                if rng.random()<0.3 and not fq: f.write("leading junk\n")
+                for r in range(int(rng.integers(1,40))):
+                    L=int(rng.choice([0,1,15,16,17,31,32,33,int(rng.integers(1,400)),int(rng.integers(400,6000)),int(rng.integers(400,6000))]))
+                    s=seq(L); nl="\r\n" if rng.random()<0.2 else "\n"
+                    if fq:
+                        q="".join(rng.choice(list("@+>IJK#5!~"),L))
+                        f.write("@q%d_%d comment%s%s%s+%s%s%s"%(fi,r,nl,s,nl,"" if rng.random()<0.5 else "q%d"%r,nl,q+nl))
+                    else:
+                        w=int(rng.choice([50,60,70,80,10**7])); f.write(">r%d_%d%s"%(fi,r," c" if rng.random()<0.5 else "")+nl)
+                        for k in range(0,max(L,1),w): f.write(s[k:k+w]+nl)
+                        if rng.random()<0.1: f.write(nl)
+            paths.append(path)
+        fofn=os.path.join(d,"in.fofn"); open(fofn,"w").write("\n".join(paths)+"\n")
+        argv=["-f",str(int(rng.choice([1,16,100,500,1000]))),"-s",str(int(rng.choice([500,1001,2500,4000]))),"-b",str(rng.choice(["0","3k","20k","1g"])),"-n",str(int(rng.integers(1,4)))]
+        ref,mine=os.path.join(d,"ref"),os.path.join(d,"mine")
+        r=subprocess.run([REF,*argv,"-d",ref,fofn],stdout=subprocess.DEVNULL,stderr=subprocess.DEVNULL)
+        if r.returncode!=0: print(it,"reference failed",argv,flush=True); continue
+        try: rc=seq_dump.run([*argv,"-d",mine,fofn])
+        except SystemExit as e: print(it,"device refused",argv,e,flush=True); continue
+        names=sorted(os.listdir(ref)); ok=names==sorted(os.listdir(mine))
+        diff=[]
+        if ok:
+            for nme in names:
+                if open(os.path.join(ref,nme),"rb").read()!=open(os.path.join(mine,nme),"rb").read(): ok=False; diff.append(nme)
+        bad+=(not ok)
+        print(it,"equal" if ok else "DIFFER",argv,len(names),"files",diff,"" if ok else d,flush=True)
+    print("mismatches", bad)
+    return bad
+
+
+
 def main():
     mode, seed, n_cases = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     lib = M.bind(C.CDLL(os.path.join(ROOT, "oracle", "libndoracle.so")))
     lib.nd_mm_step2_unrestated.restype = C.c_int64
-    if mode in ("cli", "sort") and os.environ.get("NDGPU_SIMT"):
+    if mode in ("cli", "sort", "dump") and os.environ.get("NDGPU_SIMT"):
         sys.path.insert(0, os.path.join(ROOT, "tests", "simt"))
         import build_simt
         from nextdenovo_amd import overlap
         os.environ.setdefault("NDGPU_CONTEXTS", "1")
         overlap._lib = overlap._bind(C.CDLL(build_simt.build_overlap()))
-    return 1 if {"plain": fuzz_plain, "step2": fuzz_step2, "cli": fuzz_cli, "sort": fuzz_sort}[mode](seed, n_cases, lib) else 0
+    return 1 if {"plain": fuzz_plain, "step2": fuzz_step2, "cli": fuzz_cli, "sort": fuzz_sort, "dump": fuzz_dump}[mode](seed, n_cases, lib) else 0
 
 
 if __name__ == "__main__":
