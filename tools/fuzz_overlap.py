@@ -7,7 +7,8 @@
     python tools/fuzz_overlap.py sort SEED N     the sort oracle (and, on a GPU box with NDGPU_FUZZ_DEVICE=1 or under NDGPU_SIMT=1, the device sort)
                                                  against the compiled `ovl_sort` (-k -l -H)
     python tools/fuzz_overlap.py dump SEED N     the device `seq_dump` command against the compiled one (GPU box or NDGPU_SIMT=1)
-Round 3: 75 + 30 + 32 + 38 + 52 cases, all byte-identical.  (`-c` has a fuzzer of its own: tools/fuzz_cigar.py.)"""
+    python tools/fuzz_overlap.py mode3 SEED N    the device command line with --mode 3;   cli2: with --step 2 (GPU box or NDGPU_SIMT=1)
+Round 3: 75 + 30 + 32 + 38 + 52 + 24 + 20 cases, all byte-identical.  (`-c` has a fuzzer of its own: tools/fuzz_cigar.py.)"""
 import ctypes as C
 import os
 import subprocess
@@ -263,17 +264,115 @@ def fuzz_dump(seed, n_cases, lib):
 
 
 
+def fuzz_mode3(seed, n_cases, lib):
+    """`--step 1 --mode 3` (HiFi / ONT / CLR reads; --dvt --df -f --maxhan --minlen): the device command line against the reference binary."""
+    from nextdenovo_amd import minimap2_nd
+    rng = np.random.default_rng(seed)
+    n = n_cases
+    bad = 0
+    for it in range(n):
+        prof=str(rng.choice(["hifi","hifi","ont"]))
+        g=synth.make_genome(int(rng.integers(30000,80000)), seed=int(rng.integers(1,10**6)), n_repeats=int(rng.integers(0,5)), repeat_len=int(rng.integers(800,3000)))
+        kw=dict(mu=float(rng.uniform(8.7,9.2)),sigma=0.3,min_len=3000) if prof=="hifi" else dict(mu=8.8,sigma=0.5,min_len=1500)
+        rs=synth.simulate_reads(g, float(rng.uniform(12,35)), prof, seed=int(rng.integers(1,10**6)), **kw)
+        wd=tempfile.mkdtemp(prefix="f3")
+        seed,part=M.dump_reads(wd,[synth.codes_to_ascii(s) for s in rs.seqs],seed_cutoff=int(rng.choice([5000,8000])))
+        preset="ava-hifi" if prof=="hifi" else str(rng.choice(["ava-ont","ava-pb"])); dual=bool(rng.random()<0.5)
+        extra=["--mode","3"]
+        if rng.random()<0.4: extra+=["--dvt"]
+        if rng.random()<0.3: extra+=["--df",str(rng.choice(["0.05","0.2","0.4"]))]
+        if rng.random()<0.3 and prof=="hifi": extra+=["-f",str(rng.choice(["40","200","0.001"]))]
+        if rng.random()<0.3: extra+=["--maxhan1",str(int(rng.choice([1000,3000]))),"--maxhan2",str(int(rng.choice([100,500])))]
+        if rng.random()<0.3: extra+=["--minlen",str(int(rng.choice([300,2000])))]
+        t,q=seed,(part if dual and part else seed)
+        try: want=M.ref_step1(t,q,os.path.join(wd,"ref.ovl"),preset,dual,tuple(extra),threads=4)
+        except subprocess.CalledProcessError: print(it,"reference failed",preset,extra,flush=True); continue
+        argv=["--step","1"]+(["--dual=yes"] if dual else [])+["-t","4","-x",preset,*extra,t,q,"-o",os.path.join(wd,"dev.ovl")]
+        t0=time.time()
+        try: minimap2_nd.run(argv); got=open(os.path.join(wd,"dev.ovl"),"rb").read()
+        except SystemExit as e: print(it,"device refused",extra,e,flush=True); continue
+        ok=got==want; bad+=(not ok)
+        print(it,"equal" if ok else "DIFFER",preset,dual,extra,len(got),len(want),"%.0fs"%(time.time()-t0),"" if ok else wd,flush=True)
+    print("mismatches", bad)
+    return bad
+
+
+
+def fuzz_cli2(seed, n_cases, lib):
+    """`--step 2` (modes 0 / 1 / 2 and their options): the device command line against the reference binary (`.ovl` and `.bl`)."""
+    from nextdenovo_amd import minimap2_nd
+    rng = np.random.default_rng(seed)
+    n = n_cases
+    bad = 0
+    for it in range(n):
+        G=int(rng.integers(15000,35000)); depth=float(rng.uniform(10,40))
+        g=synth.make_genome(G, seed=int(rng.integers(1,10**6)), n_repeats=int(rng.integers(0,4)), repeat_len=int(rng.integers(500,2000)))
+        rs=synth.simulate_reads(g, depth, "hifi", seed=int(rng.integers(1,10**6)), mu=float(rng.uniform(8.3,8.9)), sigma=0.35, min_len=2000)
+        seqs=list(rs.seqs)
+        for t in range(int(rng.integers(0,30))):
+            a=int(rng.integers(0,len(seqs)))
+            if seqs[a].size>3000:
+                L=int(rng.integers(2100,2900)); s0=int(rng.integers(0,seqs[a].size-L)); seqs.append(seqs[a][s0:s0+L].copy())
+        wd=tempfile.mkdtemp(prefix="f2"); half=len(seqs)//2; files=[]; sets=[]
+        for tag,lo,hi in (("a",0,half),("b",half,len(seqs))):
+            p=os.path.join(wd,tag+".fasta")
+            with open(p,"w") as f:
+                for i in range(lo,hi): f.write(">%d %d 0.99\n%s\n"%(i+1,seqs[i].size,synth.codes_to_ascii(seqs[i]).decode()))
+            files.append(p)
+            ids=np.arange(lo+1,hi+1,dtype=np.uint32); lens=np.asarray([seqs[i].size for i in range(lo,hi)],dtype=np.uint32)
+            off=np.zeros(hi-lo,dtype=np.uint64); off[1:]=np.cumsum(lens.astype(np.uint64))[:-1]
+            sets.append((ids,lens,np.concatenate([seqs[i] for i in range(lo,hi)]).astype(np.uint8),off))
+        preset=str(rng.choice(["ava-ont","ava-pb"])); mode=int(rng.choice([0,1,2,2]))
+        extra=["-k","17","-w",str(int(rng.choice([10,17])))]; kw={"k":17,"w":int(extra[3])}
+        s2=dict(minide=0.05,minmatch=100,kn=17,wn=10,cn=50 if mode==1 else 20)
+        if rng.random()<0.5:
+            ml=int(rng.choice([700,1000,2000,3000])); extra+=["--minlen",str(ml)]; kw["minlen"]=ml
+        else: kw["minlen"]=2000
+        if rng.random()<0.4:
+            h1=int(rng.choice([1500,2000,8000])); extra+=["--maxhan1",str(h1)]; kw["maxhan1"]=h1
+        if rng.random()<0.3:
+            h2=int(rng.choice([100,300,900])); extra+=["--maxhan2",str(h2)]; kw["maxhan2"]=h2
+        if rng.random()<0.3:
+            mi=float(rng.choice([0.02,0.1,0.3])); extra+=["--minide",str(mi)]; s2["minide"]=mi
+        if rng.random()<0.3:
+            mm=int(rng.choice([50,200,500])); extra+=["--minmatch",str(mm)]; s2["minmatch"]=mm
+        if mode and rng.random()<0.3:
+            kn=int(rng.choice([15,17,19])); extra+=["--kn",str(kn)]; s2["kn"]=kn
+        if mode and rng.random()<0.3:
+            wn=int(rng.choice([5,10,15])); extra+=["--wn",str(wn)]; s2["wn"]=wn
+        if mode and rng.random()<0.3:
+            cn=int(rng.choice([5,20,40])); extra+=["--cn",str(cn)]; s2["cn"]=cn
+        if mode==1: s2["minide"]=max(s2["minide"],0.01)
+        out=os.path.join(wd,"o.ovl")
+        cmd=[os.path.join(M.REFDIR,"minimap2-nd"),"--step","2",*(("--mode",str(mode)) if mode!=2 else ()),"--dual=yes","-t","3","-x",preset,*extra,files[0],files[1],files[0],"-o",out]
+        try: subprocess.run(cmd,check=True,stdout=subprocess.DEVNULL,stderr=subprocess.DEVNULL)
+        except subprocess.CalledProcessError: print(it,"reference failed",mode,preset,extra,flush=True); continue
+        want,want_bl=open(out,"rb").read(),open(out+".bl").read()
+        t0=time.time()
+        dout=os.path.join(wd,"dev.ovl")
+        dargv=["--step","2",*(("--mode",str(mode)) if mode!=2 else ()),"--dual=yes","-t","3","-x",preset,*extra,files[0],files[1],files[0],"-o",dout]
+        try: minimap2_nd.run(dargv)
+        except SystemExit as e: print(it,"device refused",extra,e,flush=True); continue
+        got,got_bl=open(dout,"rb").read(),open(dout+".bl").read()
+        un=0
+        ok=got==want and got_bl==want_bl; bad+=(not ok)
+        print(it,"equal" if ok else "DIFFER","mode",mode,preset,extra,len(got),len(want),"unrestated",un,"%.0fs"%(time.time()-t0),"" if ok else wd,flush=True)
+    print("mismatches", bad)
+    return bad
+
+
+
 def main():
     mode, seed, n_cases = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     lib = M.bind(C.CDLL(os.path.join(ROOT, "oracle", "libndoracle.so")))
     lib.nd_mm_step2_unrestated.restype = C.c_int64
-    if mode in ("cli", "sort", "dump") and os.environ.get("NDGPU_SIMT"):
+    if mode in ("cli", "sort", "dump", "mode3", "cli2") and os.environ.get("NDGPU_SIMT"):
         sys.path.insert(0, os.path.join(ROOT, "tests", "simt"))
         import build_simt
         from nextdenovo_amd import overlap
         os.environ.setdefault("NDGPU_CONTEXTS", "1")
         overlap._lib = overlap._bind(C.CDLL(build_simt.build_overlap()))
-    return 1 if {"plain": fuzz_plain, "step2": fuzz_step2, "cli": fuzz_cli, "sort": fuzz_sort, "dump": fuzz_dump}[mode](seed, n_cases, lib) else 0
+    return 1 if {"plain": fuzz_plain, "step2": fuzz_step2, "cli": fuzz_cli, "sort": fuzz_sort, "dump": fuzz_dump, "mode3": fuzz_mode3, "cli2": fuzz_cli2}[mode](seed, n_cases, lib) else 0
 
 
 if __name__ == "__main__":
