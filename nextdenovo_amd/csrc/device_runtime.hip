@@ -466,15 +466,15 @@ void DeviceAligner::reset_all_stats() {
 uint32_t *DeviceAligner::upload_db(const uint32_t *pool_words, size_t n_words, int device) {
     HIP_CHECK(hipSetDevice(device));
     uint32_t *d = nullptr;
-    const hipError_t e = hipMalloc((void **)&d, (n_words + 2) * sizeof(uint32_t));
+    const hipError_t e = hipMalloc((void **)&d, (n_words + kPoolPadWords) * sizeof(uint32_t));
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         return nullptr;
     }
     HIP_CHECK(e);
-    if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] db_pool %p .. %p\n", (void *)d, (void *)(d + n_words + 2));
+    if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] db_pool %p .. %p\n", (void *)d, (void *)(d + n_words + kPoolPadWords));
     HIP_CHECK(hipMemcpy(d, pool_words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemset(d + n_words, 0, 2 * sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(d + n_words, 0, kPoolPadWords * sizeof(uint32_t)));
     return d;
 }
 
@@ -731,8 +731,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
             if (bad[i]) t.max_d = 0;
         }
     });
-    pool.push_back(0);
-    pool.push_back(0);  // fetch16 reads one word past the last base
+    pool.insert(pool.end(), kPoolPadWords, 0u);  // the kernels fetch up to five words from a sequence's last base on
 
     S.d_pool.reserve(pool.size());
     S.d_tasks.reserve(n);
@@ -999,7 +998,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
 
     // ---- sequence words (parallel): memcpy of what is packed already, packing of the rest
     std::vector<uint32_t> &pool = S.pool;
-    pool.assign(pool_words + 2, 0);  // (+ 2: fetch16 reads one word past the last base)
+    pool.assign(pool_words + kPoolPadWords, 0);  // (the kernels fetch up to five words from a sequence's last base on)
     std::atomic<int> bad_any{0};
     par_ranges(srcs.size(), S.host_threads, [&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
@@ -1206,8 +1205,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             P.min_len_aln = 0xffffffffu;
         }
     }
-    pool.push_back(0);
-    pool.push_back(0);
+    pool.insert(pool.end(), kPoolPadWords, 0u);
     const size_t nt = tasks.size(), nr = reads.size();
 
     // forward/traceback chunks bounded by the trace budget

@@ -81,22 +81,47 @@ __device__ __forceinline__ int wave_shr1(int first, int v) {  // lane l gets v o
     return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ int snake16(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint32_t q_sh, uint32_t t_sh,
+// 64 bases starting at base `pos` of a sequence (pos counts from the sequence's first word), as four words of 16: five words are
+// read (the pools are padded for it: kPoolPadWords) and shifted into place
+struct Bases64 { uint32_t w[4]; };
+__device__ __forceinline__ Bases64 fetch64(const uint32_t *__restrict__ p, uint32_t sub);
+__device__ __forceinline__ Bases64 fetch64_rel(const uint32_t *__restrict__ seq, uint32_t pos) { return fetch64(seq + (pos >> 4), pos & 15u); }
+__device__ __forceinline__ Bases64 fetch64_abs(const uint32_t *__restrict__ pool, uint64_t off) {  // off: base offset into the pool (64 bits: a
+    return fetch64(pool + (off >> 4), (uint32_t)(off & 15u));                                       // resident read DB exceeds 2^32 bases)
+}
+__device__ __forceinline__ Bases64 fetch64(const uint32_t *__restrict__ p, uint32_t sub) {
+    struct W4 { uint32_t x, y, z, w; } v;   // (five adjacent words, 4-byte aligned: the compiler merges them into wide loads)
+    v.x = p[0], v.y = p[1], v.z = p[2], v.w = p[3];
+    const uint32_t v4 = p[4];
+    const uint32_t s = sub * 2u;
+    Bases64 r;
+    r.w[0] = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> s);
+    r.w[1] = (uint32_t)((((uint64_t)v.z << 32) | v.y) >> s);
+    r.w[2] = (uint32_t)((((uint64_t)v.w << 32) | v.z) >> s);
+    r.w[3] = (uint32_t)((((uint64_t)v4 << 32) | v.w) >> s);
+    return r;
+}
+
+// The snake of one cell (lib/align.c:452-455): how far the diagonal runs on equal bases from (x, x - k).  An edit step lasts as long as
+// its slowest lane, and a lane that compares 16 bases per round trip to the cache needs another round for every 16 equal bases -- with
+// 30-odd live diagonals nearly every step has a lane that needs three; 64 bases per round make the second round rare (a run of 64 equal
+// bases between two reads with 10 % differences).  Same loads in bytes, a third of the dependent rounds.
+__device__ __forceinline__ int snake64(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint32_t q_sh, uint32_t t_sh,
                                        int q_len, int t_len, int x, int k) {
     int y = x - k;
-    for (;;) {  // 16 bases per XOR, first mismatch = ctz / 2 (lib/align.c:452-455)
+    for (;;) {
         int rem = q_len - x;
         const int rt = t_len - y;
         rem = rt < rem ? rt : rem;
         if (rem <= 0) break;
-        const uint32_t a = fetch16_rel(qp, q_sh + (uint32_t)x);
-        const uint32_t b = fetch16_rel(tp, t_sh + (uint32_t)y);
-        const uint32_t diff = a ^ b;
-        int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
+        const Bases64 a = fetch64_rel(qp, q_sh + (uint32_t)x);
+        const Bases64 b = fetch64_rel(tp, t_sh + (uint32_t)y);
+        const uint32_t d0 = a.w[0] ^ b.w[0], d1 = a.w[1] ^ b.w[1], d2 = a.w[2] ^ b.w[2], d3 = a.w[3] ^ b.w[3];
+        int m = d0 ? (__builtin_ctz(d0) >> 1) : d1 ? 16 + (__builtin_ctz(d1) >> 1) : d2 ? 32 + (__builtin_ctz(d2) >> 1) : d3 ? 48 + (__builtin_ctz(d3) >> 1) : 64;
         m = m < rem ? m : rem;
         x += m;
         y += m;
-        if (m < 16) break;
+        if (m < 64) break;
     }
     return x;
 }
@@ -165,7 +190,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         if (act0) {
             const bool down = (k0 == min_k) || (k0 != max_k && vm < vp);  // lib/align.c:443
             left0 = !down;
-            x0 = snake16(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp : vm + 1, k0);
+            x0 = snake64(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp : vm + 1, k0);
         }
         const unsigned long long lb0 = __ballot(act0 && left0);
         const unsigned long long fb0 = __ballot(act0 && x0 >= q_len && x0 - k0 >= t_len);
@@ -183,7 +208,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
             if (act1) {
                 const bool down = k1 != max_k && vm1 < vp1;
                 left1 = !down;
-                x1 = snake16(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp1 : vm1 + 1, k1);
+                x1 = snake64(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp1 : vm1 + 1, k1);
                 const int m1 = 2 * x1 - k1;
                 row_best = m1 > row_best ? m1 : row_best;
             }
@@ -441,17 +466,28 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     uint64_t hdr = (STREAM && pos) ? S[pos - 1] : 0ull;
 
     for (;;) {
-        // match run, back to front (lib/align.c:502-507), 16 bases per compare
+        // match run, back to front (lib/align.c:502-507), 64 bases per compare: every lane walks an alignment of its own and the
+        // wavefront repeats this loop until its slowest lane is through -- with 16 bases a round, some lane of 64 nearly always
+        // needs a third round (a run of 32 equal bases); with 64 a second round is rare
         for (;;) {
             const int yy = x - k;
             const int avail = (x < yy ? x : yy) + 1;
             if (avail <= 0) break;
-            const int n = avail < 16 ? avail : 16;
-            const uint32_t a = fetch16(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
-            const uint32_t b = fetch16(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
-            uint32_t diff = a ^ b;
-            if (n < 16) diff &= (1u << (2 * n)) - 1u;
-            const int m = diff ? n - 1 - ((31 - __builtin_clz(diff)) >> 1) : n;
+            const int n = avail < 64 ? avail : 64;
+            const Bases64 a = fetch64_abs(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
+            const Bases64 b = fetch64_abs(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
+            int m = n;  // bases [0, n) of the fetch are the run's candidates, the last one first
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                const int nb = n - 16 * i;  // candidates in word i
+                if (nb <= 0) continue;
+                uint32_t diff = a.w[i] ^ b.w[i];
+                if (nb < 16) diff &= (1u << (2 * nb)) - 1u;
+                if (diff) {
+                    m = n - 1 - (16 * i + ((31 - __builtin_clz(diff)) >> 1));
+                    break;
+                }
+            }
             if (m) {
                 int left_to_emit = m;  // match columns are code 0: only the cursor moves
                 while (left_to_emit > 0) {
