@@ -464,6 +464,9 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     uint32_t pos = STREAM ? (uint32_t)outs[gid].trace_end : 0u;  // one past the record of step d
     int idx = outs[gid].fin_idx;                                  // cell index of diagonal k in step d
     uint64_t hdr = (STREAM && pos) ? S[pos - 1] : 0ull;
+    // the two words before the header: the second word of this record if it has one, and -- whichever length it has -- the header of the
+    // record before it.  Loaded a step ahead of their use, so that the walk never waits for the record it steps into.
+    uint64_t c1 = (STREAM && pos >= 2) ? S[pos - 2] : 0ull, c2 = (STREAM && pos >= 3) ? S[pos - 3] : 0ull;
 
     for (;;) {
         // match run, back to front (lib/align.c:502-507), 64 bases per compare: every lane walks an alignment of its own and the
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
         else if (x >= 0) {
             if (STREAM) {
                 const bool second = idx >= kStreamBits && pos >= 2;
-                const uint64_t w = second ? S[pos - 2] : hdr;
+                const uint64_t w = second ? c1 : hdr;
                 left = (w >> ((second ? idx - kStreamBits : idx) & 63)) & 1ull;
             } else {
                 const int ix = (k - trace_mink[T.mink_off + (uint64_t)(uint32_t)d]) >> 1;
@@ -540,8 +543,10 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
         if (STREAM) {  // step d - 1: its record ends where this one began; idx(d - 1) = idx(d) + j(d - 1) - left
             const uint32_t len = 1u + (uint32_t)((hdr >> kStreamBits) & 1ull);
             pos = pos > len ? pos - len : 0u;
-            hdr = pos ? S[pos - 1] : 0ull;
+            hdr = pos ? (len == 1u ? c1 : c2) : 0ull;   // = S[pos - 1]
             idx += (int)(hdr >> (kStreamBits + 1)) - (left ? 1 : 0);
+            c1 = pos >= 2 ? S[pos - 2] : 0ull;
+            c2 = pos >= 3 ? S[pos - 3] : 0ull;
         }
     }
     if ((col & 15u) != 0) W[col >> 4] = acc;
