@@ -31,19 +31,6 @@ namespace ndgpu {
 
 namespace {
 
-typedef uint64_t __attribute__((aligned(4))) u64_a4;  // dwordx2 loads need 4-byte alignment only
-
-__device__ __forceinline__ uint32_t fetch16(const uint32_t *__restrict__ pool, uint64_t off) {
-    const uint32_t s = (uint32_t)(off & 15u) * 2u;
-    const uint64_t v = *(const u64_a4 *)(pool + (off >> 4));
-    return (uint32_t)(v >> s);
-}
-
-__device__ __forceinline__ uint32_t fetch16_rel(const uint32_t *__restrict__ seq, uint32_t pos) {  // pos: base index from seq's first word
-    const uint64_t v = *(const u64_a4 *)(seq + (pos >> 4));
-    return (uint32_t)(v >> ((pos & 15u) * 2u));
-}
-
 // maximum over the 64 lanes (all of them active) with data-parallel-primitive moves instead of six LDS permutes: the
 // forward kernel is bound by instruction issue, and this reduction sits on every edit step
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -340,22 +327,7 @@ __global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__r
                 const bool down = (k == min_k) || (k != max_k && vm < vp);
                 x = down ? vp : vm + 1;
                 left = !down;
-                int y = x - k;
-                // snake: 16 bases per XOR, first mismatch = ctz/2 (lib/align.c:452-455)
-                for (;;) {
-                    int rem = q_len - x;
-                    const int rt = t_len - y;
-                    rem = rt < rem ? rt : rem;
-                    if (rem <= 0) break;
-                    const uint32_t a = fetch16_rel(qp, q_sh + (uint32_t)x);
-                    const uint32_t b = fetch16_rel(tp, t_sh + (uint32_t)y);
-                    const uint32_t diff = a ^ b;
-                    int m = diff ? (__builtin_ctz(diff) >> 1) : 16;
-                    m = m < rem ? m : rem;
-                    x += m;
-                    y += m;
-                    if (m < 16) break;
-                }
+                x = snake64(qp, tp, q_sh, t_sh, q_len, t_len, x, k);  // (lib/align.c:452-455)
             }
             const unsigned long long lb = __ballot(act && left);
             if (lane == 0) trace[row0 + (uint64_t)d * row_words + (uint32_t)ps] = lb;
