@@ -5,7 +5,7 @@
 #      lane-accurate interpreter (tests/simt);
 #   3. optional (slower): the interpreter tests once more with the lanes of a wavefront run highest first and a random wavefront
 #      schedule, and sanitizer sweeps (UBSan, ASan) of both interpreted libraries.
-# usage: tools/check.sh [quick|full]
+# usage: tools/check.sh [quick|full [fuzz]]
 set -e
 cd "$(dirname "$0")/.."
 python -c "import __graft_entry__ as g; g.build(); print('build ok')"
@@ -18,3 +18,9 @@ for san in undefined address; do
     python -m pytest tests/test_simt_kernels.py tests/test_simt_overlap.py tests/test_simt_ksw2.py -x -q \
       -k "not forced and not out_of and not step2_mode0"   # (child processes and exception paths do not mix with a preloaded sanitizer)
 done
+# 4. optional (`tools/check.sh fuzz`, after `full`): short campaigns of the fuzzers against the compiled reference programs (oracle/_ref) --
+#    the oracles, then the device paths under the interpreter
+[ "${2:-}" = fuzz ] || exit 0
+python tools/fuzz_overlap.py plain 1 10 && python tools/fuzz_overlap.py step2 1 6 && python tools/fuzz_overlap.py sort 1 6 && python tools/fuzz_cigar.py oracle 1 6
+NDGPU_SIMT=1 python tools/fuzz_overlap.py cli 1 6 && NDGPU_SIMT=1 python tools/fuzz_overlap.py dump 1 10 && NDGPU_SIMT=1 python tools/fuzz_cigar.py device 1 3
+NDGPU_SIMT=1 python tools/fuzz_consensus.py 1 8 && NDGPU_SIMT=1 python tools/fuzz_stage.py 1 2
