@@ -127,6 +127,7 @@ consensus_trimed *nextCorrect(char **seqs, unsigned int *aln_start, unsigned int
         run_engines(&ep, 1, be, 1);
     } catch (const DeviceOom &) {  // lib/nextcorrect.c:2254-2261: a seed whose working memory cannot be had is reported, not fatal
         DeviceAligner::context(0).release_memory();
+        DeviceAligner::forget_sizes();
         return (consensus_trimed *)make_error_seed(3);
     }
     return (consensus_trimed *)eng.take_result();
@@ -162,6 +163,7 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
             for (size_t i = a; i < b; i++) out[i] = (consensus_trimed *)eng[i]->take_result();
         } catch (const DeviceOom &) {
             DeviceAligner::context(0).release_memory();
+            DeviceAligner::forget_sizes();
             for (size_t i = a; i < b; i++) {  // engines restart from scratch
                 delete eng[i];
                 eng[i] = new PileEngine(seqs[i], aln_start[i], aln_end[i], seq_count[i],
@@ -411,6 +413,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
         }
         if (oom) {
             DeviceAligner::context(ctx).release_memory();
+            DeviceAligner::forget_sizes();
             for (PileEngine *e : eng) delete e;
             if (cnt == 1) {
                 out[order[base]] = (consensus_trimed *)make_error_seed(3);

@@ -59,6 +59,11 @@ static inline bool oom_injected(size_t bytes) {
     static const size_t lim = getenv("NDGPU_OOM_ABOVE") ? (size_t)strtoull(getenv("NDGPU_OOM_ABOVE"), nullptr, 10) : 0;
     return lim && bytes > lim;
 }
+// The same for the pinned host arenas: NDGPU_PINNED_OOM_ABOVE=bytes.
+static inline bool oom_injected_pinned(size_t bytes) {
+    static const size_t lim = getenv("NDGPU_PINNED_OOM_ABOVE") ? (size_t)strtoull(getenv("NDGPU_PINNED_OOM_ABOVE"), nullptr, 10) : 0;
+    return lim && bytes > lim;
+}
 
 static std::atomic<unsigned long long> g_reserved_bytes{0};  // kept free for the caller's other stage (ndgpu_reserve_device_memory)
 static std::atomic<long long> g_dev_bytes{0};
@@ -82,14 +87,26 @@ static inline hipError_t guarded_malloc(void **p, size_t bytes) {
 // context has met it before.  A buffer that has to grow therefore grows to the most ANY context has asked of the buffer of that
 // name: after the first step or two every context holds the sizes of the largest sub-batch and nothing is (re)allocated in steady
 // state -- a hipFree / hipHostMalloc in the middle of a step stalls every queue of the device (seconds, measured).
-static size_t high_water(const char *name, size_t bytes) {
-    static std::mutex mu;
-    static std::unordered_map<std::string, size_t> hw;
-    if (!name || !*name) return bytes;
-    std::lock_guard<std::mutex> lock(mu);
-    size_t &v = hw[name];
+// A mark is recorded only AFTER an allocation of that size succeeded, and every mark is dropped when a context runs out of device
+// memory (clear_high_water, from release_memory): a size that could not be had must not be asked for again by the halves of the
+// sub-batch that failed (lib/nextcorrect.c:2254-2261: only a single pile that does not fit is an out-of-memory seed).
+static std::mutex g_hw_mu;
+static std::unordered_map<std::string, size_t> g_hw;
+static size_t high_water(const char *name) {
+    if (!name || !*name) return 0;
+    std::lock_guard<std::mutex> lock(g_hw_mu);
+    auto it = g_hw.find(name);
+    return it == g_hw.end() ? 0 : it->second;
+}
+static void record_high_water(const char *name, size_t bytes) {
+    if (!name || !*name) return;
+    std::lock_guard<std::mutex> lock(g_hw_mu);
+    size_t &v = g_hw[name];
     if (bytes > v) v = bytes;
-    return v;
+}
+static void clear_high_water() {
+    std::lock_guard<std::mutex> lock(g_hw_mu);
+    g_hw.clear();
 }
 
 struct AllocTimer {  // counts one (re)allocation and its wall time
@@ -108,7 +125,8 @@ struct DevBuf {
     const char *name = "";
     void reserve(size_t n) {
         if (n <= cap) return;
-        n = std::max(n, high_water(name, n * sizeof(T)) / sizeof(T));
+        const size_t asked = n;
+        n = std::max(n, high_water(name) / sizeof(T));  // (what any context has HELD of this buffer; never a size that failed)
         const AllocTimer alloc_timer;
         if (p) {
             if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] free %s %p\n", name, (void *)p);
@@ -117,10 +135,13 @@ struct DevBuf {
         }
         p = nullptr;
         cap = 0;
-        size_t want = n + n / 4 + 1024;
-        hipError_t rc = guarded_malloc((void **)&p, want * sizeof(T));
-        if (rc == hipErrorOutOfMemory && want > n + 1024) {  // without the growth slack
-            want = n + 1024;
+        // most wanted first: the mark with growth slack, the mark, what this call needs with slack, what this call needs
+        size_t want = 0;
+        hipError_t rc = hipErrorOutOfMemory;
+        const size_t tries[4] = {n + n / 4 + 1024, n + 1024, asked + asked / 4 + 1024, asked + 1024};
+        for (int t = 0; t < 4 && rc == hipErrorOutOfMemory; t++) {
+            if (t && tries[t] >= want) continue;
+            want = tries[t];
             rc = guarded_malloc((void **)&p, want * sizeof(T));
         }
         if (rc == hipErrorOutOfMemory) {
@@ -130,10 +151,11 @@ struct DevBuf {
         }
         HIP_CHECK(rc);
         cap = want;
+        record_high_water(name, std::min(want - 1024, n) * sizeof(T));
         g_dev_bytes += (long long)(cap * sizeof(T));
         if (g_debug_alloc)
             fprintf(stderr, "[ndgpu alloc] %s %p .. %p (%zu bytes, asked %zu)\n", name, (void *)p, (void *)((char *)p + want * sizeof(T)),
-                    want * sizeof(T), n * sizeof(T));
+                    want * sizeof(T), asked * sizeof(T));
     }
     void release() {
         if (p) {
@@ -144,7 +166,7 @@ struct DevBuf {
         cap = 0;
     }
     void level() {  // (while the device is idle) up to what any context has asked of the buffer of this name
-        const size_t want = high_water(name, 0) / sizeof(T);
+        const size_t want = high_water(name) / sizeof(T);
         if (want > cap) reserve(want);
     }
     ~DevBuf() {
@@ -162,13 +184,19 @@ struct PinBuf {
     const char *name = "";
     void reserve(size_t n) {
         if (n <= cap) return;
-        n = std::max(n, high_water(name, n * sizeof(T)) / sizeof(T));
+        const size_t asked = n;
+        n = std::max(n, high_water(name) / sizeof(T));
         const AllocTimer alloc_timer;
         if (p && !g_debug_nofree) HIP_CHECK(hipHostFree(p));
         p = nullptr;
         cap = 0;
         size_t want = n + n / 4 + 1024;
-        const hipError_t rc = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        hipError_t rc = oom_injected_pinned(want * sizeof(T)) ? hipErrorOutOfMemory : hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (rc == hipErrorOutOfMemory && asked + 1024 < want) {  // what this call needs, no more
+            (void)hipGetLastError();
+            want = asked + 1024;
+            rc = oom_injected_pinned(want * sizeof(T)) ? hipErrorOutOfMemory : hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        }
         if (rc == hipErrorOutOfMemory) {
             (void)hipGetLastError();
             p = nullptr;
@@ -176,6 +204,7 @@ struct PinBuf {
         }
         HIP_CHECK(rc);
         cap = want;
+        record_high_water(name, std::min(want - 1024, n) * sizeof(T));
         if (g_debug_alloc) fprintf(stderr, "[ndgpu alloc] pinned %p .. %p\n", (void *)p, (void *)((char *)p + want * sizeof(T)));
     }
     void release() {
@@ -184,7 +213,7 @@ struct PinBuf {
         cap = 0;
     }
     void level() {
-        const size_t want = high_water(name, 0) / sizeof(T);
+        const size_t want = high_water(name) / sizeof(T);
         if (want > cap) reserve(want);
     }
     ~PinBuf() {
@@ -519,6 +548,10 @@ void DeviceAligner::level_buffers(int drivers) {
         DeviceAligner *d = peek(c);
         if (!d) continue;
         State &S = *d->s_;
+        // a context with a batch open (another caller's thread) keeps its main-phase buffers alive between run_main and end_batch:
+        // growing them here would free live device state.  It is skipped, like release_memory_if_idle skips it.
+        std::unique_lock<std::mutex> batch(S.batch_mu, std::try_to_lock);
+        if (!batch.owns_lock()) continue;
         std::lock_guard<std::mutex> lock(S.mu);
         (void)hipSetDevice(S.device);
         size_t free_b = 0, total_b = 0;
@@ -527,7 +560,7 @@ void DeviceAligner::level_buffers(int drivers) {
         long long budget = (long long)free_b - (long long)((size_t)10 << 30) - (long long)g_reserved_bytes.load();
         auto lvl = [&](auto &buf, bool device) {
             const size_t esz = sizeof(*buf.p);
-            const size_t want = high_water(buf.name, 0) / esz;
+            const size_t want = high_water(buf.name) / esz;
             if (want <= buf.cap) return;
             const long long growth = (long long)((want + want / 4 + 1024 - buf.cap) * esz);
             if (device) {
@@ -552,6 +585,8 @@ void DeviceAligner::level_buffers(int drivers) {
         }
     }
 }
+
+void DeviceAligner::forget_sizes() { clear_high_water(); }
 
 bool DeviceAligner::release_memory_if_idle() {
     if (!s_->batch_mu.try_lock()) return false;
@@ -1592,7 +1627,11 @@ void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
     if (regs.empty()) return;
     S.d_regions.reserve(regs.size());
     S.d_cursor.reserve(2);
-    size_t cap = std::max<size_t>(S.d_strpool.cap, (size_t)64 << 20);
+    // first guess of the string pool: 64 MB, or less when the regions cannot produce that much (<= 40 candidates of <= max_len
+    // characters each); the kernel reports what it needed and a pool that was too small is retaken at the exact size
+    size_t bound = (size_t)1 << 20;
+    for (const RegionDev &g : regs) bound += (size_t)40 * ((size_t)g.max_len + 64);
+    size_t cap = std::max<size_t>(S.d_strpool.cap, std::min<size_t>((size_t)64 << 20, bound));
     std::vector<char> hstr;
     for (;;) {
         S.d_strpool.reserve(cap);

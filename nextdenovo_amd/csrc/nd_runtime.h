@@ -85,6 +85,9 @@ class DeviceAligner {
     void set_host_threads(int n);   // threads used for packing / decoding inside a batch
     // after a DeviceOom: wait for the stream, drop every grow-only buffer of this context (they are re-created on demand)
     void release_memory();
+    // after a DeviceOom: drop the process-wide "largest size any context held of a buffer" marks, so that the retry of a smaller
+    // range asks for what IT needs and not for what just failed
+    static void forget_sizes();
     // the public entry's form: only when no batch is open on this context (a batch keeps its main-phase buffers alive from
     // run_main to end_batch, between the calls that hold the context's lock); false = the context is busy, nothing released
     bool release_memory_if_idle();

@@ -6,8 +6,8 @@
 //                     of an edit step in registers (lane l = diagonal min_k + 2l, a second
 //                     cell per lane on the steps wider than 64 cells); a step is one wave
 //                     permute + one DPP shift (the reference's V[k-1], V[k+1]), a snake
-//                     (XOR + ctz over 16-base 2-bit words fetched from the HBM-resident
-//                     pool), two ballots (move bits -> trace record, finish test), one wave
+//                     (XOR + ctz over 64 bases a round: five adjacent 16-base words per operand
+//                     from the HBM-resident pool), two ballots (move bits -> trace record, finish test), one wave
 //                     max (best anti-diagonal) and two ballots for the band re-centring.
 //                     Traceback memory is 1 bit per evaluated cell + 8 bits of offset per
 //                     step in a record stream, instead of the reference's one byte per cell
@@ -16,7 +16,7 @@
 //                     rare alignments whose live band exceeds the register path (exactness
 //                     of the band-cap / edit-budget failure semantics).
 // K8a ond_traceback : one lane per alignment walks d -> 0 reading the move bits,
-//                     re-deriving match runs with clz over 16-base words, and emits
+//                     re-deriving match runs with clz over 64 bases a round, and emits
 //                     2-bit column kinds back to front.
 #include <hip/hip_runtime.h>
 
@@ -71,6 +71,7 @@ __device__ __forceinline__ int wave_shr1(int first, int v) {  // lane l gets v o
 // 64 bases starting at base `pos` of a sequence (pos counts from the sequence's first word), as four words of 16: five words are
 // read (the pools are padded for it: kPoolPadWords) and shifted into place
 struct Bases64 { uint32_t w[4]; };
+static_assert(kPoolPadWords >= 5, "fetch64 reads five words from the word that holds a sequence's last base");
 __device__ __forceinline__ Bases64 fetch64(const uint32_t *__restrict__ p, uint32_t sub);
 __device__ __forceinline__ Bases64 fetch64_rel(const uint32_t *__restrict__ seq, uint32_t pos) { return fetch64(seq + (pos >> 4), pos & 15u); }
 __device__ __forceinline__ Bases64 fetch64_abs(const uint32_t *__restrict__ pool, uint64_t off) {  // off: base offset into the pool (64 bits: a

@@ -10,6 +10,22 @@
 
 namespace ndovl {
 
+// Every device operation of the overlap library reports its failure by throwing (defined in ovl_engine.hip): a rocPRIM primitive
+// that returns an error, a kernel launch the runtime refuses.  Until round 4 the primitives' return values were dropped -- and a
+// primitive that fails also clears the runtime's sticky error, so the stage-end hipGetLastError() saw nothing: on a device short
+// of memory a sort or a scan that never ran left its output buffer as it was and the call returned fewer records, silently.
+// Out of memory is noted for ndgpu_ovl_last_error() (1), so that the caller can release memory and try again.
+void device_check(int hip_error, const char *what);
+// Test hook: NDGPU_OVL_FAIL_AT=k makes the k-th checked device operation of the process (block-pool allocation, rocPRIM primitive,
+// kernel launch) fail as if the device were out of memory; read at every operation, so a test can move it between calls.
+bool fault_injected();
+#define ND_LAUNCH(...)                                                                     \
+	do {                                                                                   \
+		if (ndovl::fault_injected()) ndovl::device_check((int)hipErrorOutOfMemory, __func__); \
+		hipLaunchKernelGGL(__VA_ARGS__);                                                   \
+		ndovl::device_check((int)hipGetLastError(), __func__);                             \
+	} while (0)
+
 constexpr uint64_t kSeedTandem = 1ULL << 42; // MM_SEED_TANDEM (minimap2/mmpriv.h:20)
 constexpr uint64_t kSeedSelf = 1ULL << 43;   // MM_SEED_SELF   (minimap2/mmpriv.h:21)
 constexpr uint64_t kSeedLongJoin = 1ULL << 40; // MM_SEED_LONG_JOIN (minimap2/mmpriv.h:18)

@@ -57,6 +57,7 @@ size_t size_class(size_t b)
 void *pool_alloc(size_t bytes)
 {
 	const size_t c = size_class(bytes);
+	if (fault_injected()) device_check((int)hipErrorOutOfMemory, "pool_alloc (injected)");
 	{
 		std::lock_guard<std::mutex> g(g_pool_mu);
 		auto it = g_pool_free.find(c);
@@ -95,6 +96,27 @@ void *pool_alloc(size_t bytes)
 // (and below NDGPU_OVL_POOL_GB if that is set); what comes back beyond it is freed at once.
 int last_error_take() { return g_last_error.exchange(0); }
 void note_oom() { g_last_error = 1; }
+
+void device_check(int hip_error, const char *what)
+{
+	if (hip_error == (int)hipSuccess) return;
+	fprintf(stderr, "[ndgpu_overlap] %s failed: %s\n", what, hipGetErrorString((hipError_t)hip_error));
+	g_last_error = hip_error == (int)hipErrorOutOfMemory ? 1 : 2;
+	(void)hipGetLastError();
+	throw std::runtime_error(what);
+}
+
+bool fault_injected()
+{
+	static std::mutex mu;
+	static unsigned long long n_ops = 0, target = 0;
+	const char *e = getenv("NDGPU_OVL_FAIL_AT");
+	if (!e) { if (target) { std::lock_guard<std::mutex> g(mu); target = 0; } return false; }
+	const unsigned long long t = strtoull(e, nullptr, 10);
+	std::lock_guard<std::mutex> g(mu);
+	if (t != target) target = t, n_ops = 0;  // a new value: the count starts again
+	return ++n_ops == target;
+}
 
 static size_t pool_cap()
 {

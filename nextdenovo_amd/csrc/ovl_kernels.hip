@@ -160,10 +160,10 @@ void launch_sketch(bool fill, const uint32_t *words, const uint64_t *woff, const
 	dim3 grid((n_reads + 63) / 64), block(64);
 	size_t sm = sketch_smem(P.w);
 	if (fill)
-		hipLaunchKernelGGL(sketch_kernel<true>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
+		ND_LAUNCH(sketch_kernel<true>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
 		                   out_off, out_x, out_y, out_read, out_cnt);
 	else
-		hipLaunchKernelGGL(sketch_kernel<false>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
+		ND_LAUNCH(sketch_kernel<false>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
 		                   out_off, out_x, out_y, out_read, out_cnt);
 }
 
@@ -257,9 +257,9 @@ void launch_run_compact(bool fill, const uint32_t *words, const uint64_t *woff, 
                         uint8_t *sym, uint32_t *rstart, uint32_t *n_sym, hipStream_t s)
 {
 	if (!n_tiles) return;
-	if (fill) hipLaunchKernelGGL(run_compact_kernel<true>, dim3(n_tiles), dim3(kSkThreads), 0, s, words, woff, len, tiles, n_tiles, tile_prefix,
+	if (fill) ND_LAUNCH(run_compact_kernel<true>, dim3(n_tiles), dim3(kSkThreads), 0, s, words, woff, len, tiles, n_tiles, tile_prefix,
 	                             first_tile, roff, tile_cnt, sym, rstart, n_sym);
-	else hipLaunchKernelGGL(run_compact_kernel<false>, dim3(n_tiles), dim3(kSkThreads), 0, s, words, woff, len, tiles, n_tiles, tile_prefix,
+	else ND_LAUNCH(run_compact_kernel<false>, dim3(n_tiles), dim3(kSkThreads), 0, s, words, woff, len, tiles, n_tiles, tile_prefix,
 	                        first_tile, roff, tile_cnt, sym, rstart, n_sym);
 }
 
@@ -424,14 +424,14 @@ void launch_sketch_tiles(bool fill, bool hpc, const uint32_t *words, const uint6
 	dim3 g(n_tiles), b(kSkThreads);
 #define SK_ARGS words, woff, len, sym, rstart, roff, n_sym, tiles, n_tiles, P.w, P.k, rid_is_index, tile_off, tile_cnt, out_x, out_y, out_read
 	if (P.k > 32) {
-		if (fill && hpc) hipLaunchKernelGGL((sketch_tile_kernel<true, true, true>), g, b, 0, s, SK_ARGS);
-		else if (fill) hipLaunchKernelGGL((sketch_tile_kernel<true, false, true>), g, b, 0, s, SK_ARGS);
-		else if (hpc) hipLaunchKernelGGL((sketch_tile_kernel<false, true, true>), g, b, 0, s, SK_ARGS);
-		else hipLaunchKernelGGL((sketch_tile_kernel<false, false, true>), g, b, 0, s, SK_ARGS);
-	} else if (fill && hpc) hipLaunchKernelGGL((sketch_tile_kernel<true, true, false>), g, b, 0, s, SK_ARGS);
-	else if (fill) hipLaunchKernelGGL((sketch_tile_kernel<true, false, false>), g, b, 0, s, SK_ARGS);
-	else if (hpc) hipLaunchKernelGGL((sketch_tile_kernel<false, true, false>), g, b, 0, s, SK_ARGS);
-	else hipLaunchKernelGGL((sketch_tile_kernel<false, false, false>), g, b, 0, s, SK_ARGS);
+		if (fill && hpc) ND_LAUNCH((sketch_tile_kernel<true, true, true>), g, b, 0, s, SK_ARGS);
+		else if (fill) ND_LAUNCH((sketch_tile_kernel<true, false, true>), g, b, 0, s, SK_ARGS);
+		else if (hpc) ND_LAUNCH((sketch_tile_kernel<false, true, true>), g, b, 0, s, SK_ARGS);
+		else ND_LAUNCH((sketch_tile_kernel<false, false, true>), g, b, 0, s, SK_ARGS);
+	} else if (fill && hpc) ND_LAUNCH((sketch_tile_kernel<true, true, false>), g, b, 0, s, SK_ARGS);
+	else if (fill) ND_LAUNCH((sketch_tile_kernel<true, false, false>), g, b, 0, s, SK_ARGS);
+	else if (hpc) ND_LAUNCH((sketch_tile_kernel<false, true, false>), g, b, 0, s, SK_ARGS);
+	else ND_LAUNCH((sketch_tile_kernel<false, false, false>), g, b, 0, s, SK_ARGS);
 #undef SK_ARGS
 }
 
@@ -479,13 +479,13 @@ void launch_pack_2bit(const uint8_t *ascii, const uint64_t *a_off, const uint32_
                       uint32_t *words, hipStream_t s)
 {
 	if (!n_words) return;
-	hipLaunchKernelGGL(pack_2bit_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, ascii, a_off, len, w_off, n_reads, n_words,
+	ND_LAUNCH(pack_2bit_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, ascii, a_off, len, w_off, n_reads, n_words,
 	                   words);
 }
 
 void launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint32_t n, uint64_t *dst, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(gather_u64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, n, dst);
+	if (n) ND_LAUNCH(gather_u64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, n, dst);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,13 +499,14 @@ __global__ void shift_keys_kernel(const uint64_t *__restrict__ x, uint64_t *__re
 
 void launch_shift_keys(const uint64_t *x, uint64_t *key, uint64_t n, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(shift_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, key, n);
+	if (n) ND_LAUNCH(shift_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, key, n);
 }
 
 // ------------------------------------------------------------------------------------------------
 // rocPRIM wrappers (plain library primitives: LSD radix sort, run-length encode, scans)
 
-#define RP_CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) return (int)_e; } while (0)
+// (the size query -- tmp == nullptr -- touches nothing; the call that works is a checked device operation)
+#define RP_CHECK(e) do { if (tmp && ndovl::fault_injected()) ndovl::device_check((int)hipErrorOutOfMemory, __func__); ndovl::device_check((int)(e), __func__); } while (0)
 
 int sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout,
                    size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s)
@@ -553,7 +554,7 @@ __global__ void build_buckets_kernel(const uint64_t *__restrict__ ukey, uint64_t
 
 void launch_build_buckets(const uint64_t *ukey, uint64_t n_keys, uint32_t shift, uint32_t *bucket, hipStream_t s)
 {
-	hipLaunchKernelGGL(build_buckets_kernel, dim3(((1u << kBucketBits) + 256) / 256), dim3(256), 0, s, ukey, n_keys, shift, bucket);
+	ND_LAUNCH(build_buckets_kernel, dim3(((1u << kBucketBits) + 256) / 256), dim3(256), 0, s, ukey, n_keys, shift, bucket);
 }
 
 __device__ __forceinline__ bool index_lookup(const IndexDev &ix, uint64_t minier, uint32_t &start, uint32_t &cnt)
@@ -701,7 +702,7 @@ void launch_seed_count(const uint64_t *mx, const uint64_t *my, const uint32_t *m
                        const QueryDev &q, const OvlParams &P, int mid_occ, uint32_t *m_start, uint32_t *m_cnt, uint32_t *m_surv,
                        hipStream_t s)
 {
-	if (n_m) hipLaunchKernelGGL(seed_count_kernel, dim3((unsigned)((n_m + 255) / 256)), dim3(256), 0, s, mx, my, m_read, n_m, ix, q, P,
+	if (n_m) ND_LAUNCH(seed_count_kernel, dim3((unsigned)((n_m + 255) / 256)), dim3(256), 0, s, mx, my, m_read, n_m, ix, q, P,
 	                            mid_occ, m_start, m_cnt, m_surv);
 }
 
@@ -709,7 +710,7 @@ void launch_seed_fill(const uint64_t *mx, const uint64_t *my, const uint32_t *m_
                       const QueryDev &q, const OvlParams &P, const uint32_t *m_start, const uint32_t *m_cnt, const uint64_t *a_off,
                       uint64_t a_base, const KeyLayout &L, uint64_t *ckey, uint64_t *ay, hipStream_t s)
 {
-	if (m1 > m0) hipLaunchKernelGGL(seed_fill_kernel, dim3((unsigned)((m1 - m0 + 255) / 256)), dim3(256), 0, s, mx, my, m_read, m0, m1, ix, q,
+	if (m1 > m0) ND_LAUNCH(seed_fill_kernel, dim3((unsigned)((m1 - m0 + 255) / 256)), dim3(256), 0, s, mx, my, m_read, m0, m1, ix, q,
 	                                P, m_start, m_cnt, a_off, a_base, L, ckey, ay);
 }
 
@@ -726,7 +727,7 @@ __global__ void gather_read_off_kernel(const uint64_t *__restrict__ a_off, const
 void launch_gather_read_off(const uint64_t *a_off, const uint64_t *m_off, uint32_t n_reads, uint64_t n_m, uint64_t total,
                             uint64_t *r_aoff, hipStream_t s)
 {
-	hipLaunchKernelGGL(gather_read_off_kernel, dim3((n_reads + 256) / 256), dim3(256), 0, s, a_off, m_off, n_reads, n_m, total, r_aoff);
+	ND_LAUNCH(gather_read_off_kernel, dim3((n_reads + 256) / 256), dim3(256), 0, s, a_off, m_off, n_reads, n_m, total, r_aoff);
 }
 
 __global__ void local_off_kernel(const uint64_t *__restrict__ all, uint32_t r0, uint32_t n, uint64_t *__restrict__ out)
@@ -737,7 +738,7 @@ __global__ void local_off_kernel(const uint64_t *__restrict__ all, uint32_t r0, 
 
 void launch_local_off(const uint64_t *r_aoff_all, uint32_t r0, uint32_t n, uint64_t *r_aoff, hipStream_t s)
 {
-	hipLaunchKernelGGL(local_off_kernel, dim3((n + 256) / 256), dim3(256), 0, s, r_aoff_all, r0, n, r_aoff);
+	ND_LAUNCH(local_off_kernel, dim3((n + 256) / 256), dim3(256), 0, s, r_aoff_all, r0, n, r_aoff);
 }
 
 // sorted keys -> anchor x; a read is flagged when two neighbouring anchors of it carry the same key
@@ -766,7 +767,7 @@ __global__ void anchor_decode_kernel(const uint64_t *__restrict__ skey, uint64_t
 void launch_anchor_decode(const uint64_t *skey, uint64_t n, const KeyLayout &L, uint64_t *ax, uint32_t *tie_flag, uint64_t *segval,
                           hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(anchor_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, n, L, ax, tie_flag, segval);
+	if (n) ND_LAUNCH(anchor_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, n, L, ax, tie_flag, segval);
 }
 
 int incl_max_scan_u64(void *tmp, size_t &tmp_bytes, const uint64_t *in, uint64_t *out, size_t n, hipStream_t s)
@@ -807,13 +808,13 @@ __global__ void slab_write_kernel(const uint64_t *__restrict__ skey, const uint3
 void launch_slab_flag(const uint64_t *skey, const uint64_t *segstart1, uint64_t n, const KeyLayout &L, const uint64_t *r_aoff,
                       uint32_t *flag, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(slab_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, segstart1, n, L, r_aoff, flag);
+	if (n) ND_LAUNCH(slab_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, segstart1, n, L, r_aoff, flag);
 }
 
 void launch_slab_write(const uint64_t *skey, const uint32_t *flag, const uint64_t *rank, uint64_t n, const KeyLayout &L,
                        uint64_t *slab_i0, uint32_t *slab_read, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(slab_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, flag, rank, n, L, slab_i0,
+	if (n) ND_LAUNCH(slab_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, skey, flag, rank, n, L, slab_i0,
 	                          slab_read);
 }
 
@@ -833,7 +834,7 @@ __global__ void __launch_bounds__(64) read_span_kernel(const uint64_t *__restric
 
 void launch_read_span(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *ay, float *avg_span, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(read_span_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, ay, avg_span);
+	if (n_reads) ND_LAUNCH(read_span_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, ay, avg_span);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1037,14 +1038,14 @@ __global__ void __launch_bounds__(64) sort_pass_kernel(const SortJob *__restrict
 void launch_sort_init(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t *r_aoff, const uint64_t *ukey, const uint64_t *uy,
                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *jobs, uint32_t *n_jobs, hipStream_t s)
 {
-	if (n_tie) hipLaunchKernelGGL(sort_init_kernel, dim3(n_tie), dim3(64), 0, s, tie_reads, n_tie, r_aoff, ukey, uy, L, ax, ay, (SortJob*)jobs,
+	if (n_tie) ND_LAUNCH(sort_init_kernel, dim3(n_tie), dim3(64), 0, s, tie_reads, n_tie, r_aoff, ukey, uy, L, ax, ay, (SortJob*)jobs,
 	                              n_jobs);
 }
 
 void launch_sort_pass(const void *jobs, uint32_t n_jobs, uint64_t *x, uint64_t *y, uint64_t *tx, uint64_t *ty, uint32_t *gs, void *next,
                       uint32_t *n_next, hipStream_t s)
 {
-	if (n_jobs) hipLaunchKernelGGL(sort_pass_kernel, dim3(n_jobs), dim3(64), 0, s, (const SortJob*)jobs, n_jobs, x, y, tx, ty, gs,
+	if (n_jobs) ND_LAUNCH(sort_pass_kernel, dim3(n_jobs), dim3(64), 0, s, (const SortJob*)jobs, n_jobs, x, y, tx, ty, gs,
 	                               (SortJob*)next, n_next);
 }
 
@@ -1251,14 +1252,14 @@ void launch_chain(const uint64_t *slab_i0, const uint32_t *slab_read, uint32_t n
                   const float *read_avg_span, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f, int32_t *p, int32_t *v,
                   unsigned long long *cells, hipStream_t s)
 {
-	if (n_slabs) hipLaunchKernelGGL(chain_kernel, dim3(n_slabs), dim3(64), 0, s, slab_i0, slab_read, n_slabs, n_anchors, r_aoff, read_avg_span,
+	if (n_slabs) ND_LAUNCH(chain_kernel, dim3(n_slabs), dim3(64), 0, s, slab_i0, slab_read, n_slabs, n_anchors, r_aoff, read_avg_span,
 	                                ax, ay, P, f, p, v, cells);
 }
 
 void launch_chain_ends(const uint64_t *r_aoff, uint32_t n_reads, const OvlParams &P, const int32_t *f, const int32_t *p, const int32_t *v,
                        int32_t *t, uint64_t *u, uint32_t *n_end, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(chain_ends_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, P, f, p, v, t, u, n_end);
+	if (n_reads) ND_LAUNCH(chain_ends_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, P, f, p, v, t, u, n_end);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1529,7 +1530,7 @@ void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, c
                  uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
                  OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, uint64_t *cx, uint64_t *cy, uint32_t *n_ca, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(hits_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
+	if (n_reads) ND_LAUNCH(hits_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
 	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain, recs10, cx, cy, n_ca);
 }
 
@@ -1546,7 +1547,7 @@ __global__ void compact_anchors_kernel(const uint64_t *__restrict__ r_aoff, uint
 void launch_compact_anchors(const uint64_t *r_aoff, uint32_t n_reads, const uint64_t *cx, const uint64_t *cy, const uint32_t *n_ca,
                             const uint64_t *ca_off, uint64_t *dx, uint64_t *dy, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(compact_anchors_kernel, dim3(n_reads), dim3(256), 0, s, r_aoff, n_reads, cx, cy, n_ca, ca_off, dx, dy);
+	if (n_reads) ND_LAUNCH(compact_anchors_kernel, dim3(n_reads), dim3(256), 0, s, r_aoff, n_reads, cx, cy, n_ca, ca_off, dx, dy);
 }
 
 // gather per-read record runs into one dense array
@@ -1573,13 +1574,13 @@ __global__ void compact_recs10_kernel(const uint64_t *__restrict__ r_aoff, uint3
 void launch_compact_recs10(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec10 *recs, const uint32_t *n_rec,
                            const uint64_t *rec_off, OvlRec10 *dense, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(compact_recs10_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, min_cnt, recs, n_rec, rec_off, dense);
+	if (n_reads) ND_LAUNCH(compact_recs10_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, min_cnt, recs, n_rec, rec_off, dense);
 }
 
 void launch_compact_recs(const uint64_t *r_aoff, uint32_t n_reads, int min_cnt, const OvlRec *recs, const uint32_t *n_rec,
                          const uint64_t *rec_off, OvlRec *dense, hipStream_t s)
 {
-	if (n_reads) hipLaunchKernelGGL(compact_recs_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, min_cnt, recs, n_rec, rec_off, dense);
+	if (n_reads) ND_LAUNCH(compact_recs_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, min_cnt, recs, n_rec, rec_off, dense);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1732,27 +1733,27 @@ __global__ void scatter_recs_kernel(const OvlRec *__restrict__ recs, uint64_t n,
 void launch_ext_size(const OvlRec *recs, uint64_t n, const uint32_t *qlen, const uint32_t *tlen, const OvlParams &P, uint32_t *need,
                      hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(ext_size_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, recs, n, qlen, tlen, P, need);
+	if (n) ND_LAUNCH(ext_size_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, recs, n, qlen, tlen, P, need);
 }
 
 void launch_ext_ends(const OvlRec *recs, uint64_t t0, uint64_t t1, const uint32_t *qwords, const uint64_t *qwoff, const uint32_t *qlen,
                      const uint32_t *twords, const uint64_t *twoff, const uint32_t *tlen, const OvlParams &P, const uint64_t *fr_off,
                      uint64_t fr_base, int32_t *fr_pool, int32_t *ext_x, int32_t *ext_y, hipStream_t s)
 {
-	if (t1 > t0) hipLaunchKernelGGL(ext_ends_kernel, dim3((unsigned)((t1 - t0 + 63) / 64)), dim3(64), 0, s, recs, t0, t1, qwords, qwoff, qlen,
+	if (t1 > t0) ND_LAUNCH(ext_ends_kernel, dim3((unsigned)((t1 - t0 + 63) / 64)), dim3(64), 0, s, recs, t0, t1, qwords, qwoff, qlen,
 	                                twords, twoff, tlen, P, fr_off, fr_base, fr_pool, ext_x, ext_y);
 }
 
 void launch_ext_apply(OvlRec *recs, uint64_t n, const int32_t *ext_x, const int32_t *ext_y, const uint32_t *qid, const uint32_t *qlen,
                       const uint32_t *tid, const uint32_t *tlen, const OvlParams &P, uint32_t *keep, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(ext_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, ext_x, ext_y, qid, qlen, tid, tlen,
+	if (n) ND_LAUNCH(ext_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, ext_x, ext_y, qid, qlen, tid, tlen,
 	                          P, keep);
 }
 
 void launch_scatter_recs(const OvlRec *recs, uint64_t n, const uint32_t *keep, const uint64_t *pos, OvlRec *out, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(scatter_recs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, keep, pos, out);
+	if (n) ND_LAUNCH(scatter_recs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, recs, n, keep, pos, out);
 }
 
 

@@ -14,7 +14,7 @@
 
 namespace ndovl {
 
-#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[ndgpu_overlap] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); throw std::runtime_error("hip"); } } while (0)
+#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[ndgpu_overlap] HIP error at %s:%d\n", __FILE__, __LINE__); ndovl::device_check((int)_e, "hip call"); } } while (0)
 
 namespace {
 template <class T> struct Buf {

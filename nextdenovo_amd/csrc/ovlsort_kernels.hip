@@ -149,58 +149,59 @@ __global__ void narrow_u32_u8_kernel(const uint32_t *__restrict__ in, uint64_t n
 void launch_expand_flags(const OvlRec *raw, uint64_t n, const uint32_t *seed_len, uint32_t n_ids, uint32_t *hq, uint32_t *ht, uint32_t *mq,
                          uint32_t *mt, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(expand_flags_kernel, GRID1(n), 0, s, raw, n, seed_len, n_ids, hq, ht, mq, mt);
+	if (n) ND_LAUNCH(expand_flags_kernel, GRID1(n), 0, s, raw, n, seed_len, n_ids, hq, ht, mq, mt);
 }
 void launch_expand_count(uint64_t n, const uint32_t *file_of, const uint64_t *file_start, const uint32_t *hq, const uint32_t *ht,
                          const uint64_t *mqs, const uint64_t *mts, uint32_t *sel, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(expand_count_kernel, GRID1(n), 0, s, n, file_of, file_start, hq, ht, mqs, mts, sel);
+	if (n) ND_LAUNCH(expand_count_kernel, GRID1(n), 0, s, n, file_of, file_start, hq, ht, mqs, mts, sel);
 }
 void launch_expand_count_piece(uint64_t n, const uint32_t *hq, const uint32_t *ht, const uint64_t *mqs, const uint64_t *mts, uint64_t carry_q,
                                uint64_t carry_t, uint32_t *sel, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(expand_count_piece_kernel, GRID1(n), 0, s, n, hq, ht, mqs, mts, carry_q, carry_t, sel);
+	if (n) ND_LAUNCH(expand_count_piece_kernel, GRID1(n), 0, s, n, hq, ht, mqs, mts, carry_q, carry_t, sel);
 }
 void launch_cand_hist(const OvlRec *raw, const uint32_t *sel, uint64_t n, uint32_t *hist, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(cand_hist_kernel, GRID1(n), 0, s, raw, sel, n, hist);
+	if (n) ND_LAUNCH(cand_hist_kernel, GRID1(n), 0, s, raw, sel, n, hist);
 }
 void launch_range_sel(const OvlRec *raw, const uint8_t *sel, uint64_t n, uint32_t lo, uint32_t hi, uint32_t *out, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(range_sel_kernel, GRID1(n), 0, s, raw, sel, n, lo, hi, out);
+	if (n) ND_LAUNCH(range_sel_kernel, GRID1(n), 0, s, raw, sel, n, lo, hi, out);
 }
 void launch_narrow_u32_u8(const uint32_t *in, uint64_t n, uint8_t *out, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(narrow_u32_u8_kernel, GRID1(n), 0, s, in, n, out);
+	if (n) ND_LAUNCH(narrow_u32_u8_kernel, GRID1(n), 0, s, in, n, out);
 }
 void launch_sel_count(const uint32_t *sel, uint64_t n, uint32_t *cnt, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(sel_count_kernel, GRID1(n), 0, s, sel, n, cnt);
+	if (n) ND_LAUNCH(sel_count_kernel, GRID1(n), 0, s, sel, n, cnt);
 }
 void launch_expand_write(const OvlRec *raw, uint64_t n, const uint32_t *sel, const uint64_t *pos, OvlRec *cand, uint32_t *k_span,
                          uint32_t *k_match, uint32_t *k_seed, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(expand_write_kernel, GRID1(n), 0, s, raw, n, sel, pos, cand, k_span, k_match, k_seed);
+	if (n) ND_LAUNCH(expand_write_kernel, GRID1(n), 0, s, raw, n, sel, pos, cand, k_span, k_match, k_seed);
 }
-void launch_iota(uint32_t *a, uint64_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(iota_kernel, GRID1(n), 0, s, a, n); }
+void launch_iota(uint32_t *a, uint64_t n, hipStream_t s) { if (n) ND_LAUNCH(iota_kernel, GRID1(n), 0, s, a, n); }
 void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint64_t n, uint32_t *dst, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(gather_u32_kernel, GRID1(n), 0, s, src, idx, n, dst);
+	if (n) ND_LAUNCH(gather_u32_kernel, GRID1(n), 0, s, src, idx, n, dst);
 }
 void launch_seed_flag(const OvlRec *cand, const uint32_t *perm, uint64_t n, uint32_t *flag, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(seed_flag_kernel, GRID1(n), 0, s, cand, perm, n, flag);
+	if (n) ND_LAUNCH(seed_flag_kernel, GRID1(n), 0, s, cand, perm, n, flag);
 }
 void launch_seed_start(const uint32_t *flag, const uint64_t *rank, uint64_t n, uint64_t *start, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(seed_start_kernel, GRID1(n), 0, s, flag, rank, n, start);
+	if (n) ND_LAUNCH(seed_start_kernel, GRID1(n), 0, s, flag, rank, n, start);
 }
 
 int sort_pairs_u32(void *tmp, size_t &tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n,
                    hipStream_t s)
 {
-	hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, 32, s);
-	return e == hipSuccess ? 0 : (int)e;
+	if (tmp && fault_injected()) device_check((int)hipErrorOutOfMemory, __func__);
+	device_check((int)rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, 32, s), __func__);
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -566,9 +567,9 @@ void launch_seed_filter(const OvlRec *cand, const uint32_t *perm, const uint64_t
                         const uint32_t *seed_len, int max_bin_cov, int flank, int min_seed_len, uint32_t max_bins, uint32_t *kept, OvlRec *out,
                         uint32_t *n_out, uint32_t *bl_id, uint8_t *bl_kind, bool hq, hipStream_t s)
 {
-	if (n_seeds && hq) hipLaunchKernelGGL(seed_filter_hq_kernel, dim3(n_seeds), dim3(64), (size_t)max_bins * 2, s, cand, perm, seed_start, n_seeds,
+	if (n_seeds && hq) ND_LAUNCH(seed_filter_hq_kernel, dim3(n_seeds), dim3(64), (size_t)max_bins * 2, s, cand, perm, seed_start, n_seeds,
 	                                      n_cand, seed_len, max_bin_cov, flank, min_seed_len, max_bins, kept, out, n_out, bl_id, bl_kind);
-	else if (n_seeds) hipLaunchKernelGGL(seed_filter_kernel, dim3(n_seeds), dim3(64), (size_t)max_bins * 2, s, cand, perm, seed_start, n_seeds, n_cand,
+	else if (n_seeds) ND_LAUNCH(seed_filter_kernel, dim3(n_seeds), dim3(64), (size_t)max_bins * 2, s, cand, perm, seed_start, n_seeds, n_cand,
 	                                seed_len, max_bin_cov, flank, min_seed_len, max_bins, kept, out, n_out, bl_id, bl_kind);
 }
 
@@ -586,7 +587,7 @@ __global__ void compact_seed_recs_kernel(const uint64_t *__restrict__ seed_start
 void launch_compact_seed_recs(const uint64_t *seed_start, uint32_t n_seeds, const OvlRec *out, const uint32_t *n_out, const uint64_t *off,
                               OvlRec *dense, hipStream_t s)
 {
-	if (n_seeds) hipLaunchKernelGGL(compact_seed_recs_kernel, dim3(n_seeds), dim3(64), 0, s, seed_start, n_seeds, out, n_out, off, dense);
+	if (n_seeds) ND_LAUNCH(compact_seed_recs_kernel, dim3(n_seeds), dim3(64), 0, s, seed_start, n_seeds, out, n_out, off, dense);
 }
 
 } // namespace ndovl

@@ -454,6 +454,9 @@ def sort_overlaps(files, seed_len: np.ndarray, min_seed_len: int, max_bin_cov: i
     st = SortStats()
     n = (lib.ndgpu_ovl_sort_hq if hq else lib.ndgpu_ovl_sort)(ptrs, cnts, nf, _ptr(seed_len), seed_len.size, int(min_seed_len), int(max_bin_cov), int(max_flank_len),
                            C.byref(out), C.byref(bid), C.byref(bkind), C.byref(nbl), C.byref(st))
+    if n == -2:   # a device operation failed: MemoryError if it was memory (like every other entry point), RuntimeError otherwise
+        raise _fail(lib, "ndgpu_ovl_sort failed (about 150 bytes of device memory per candidate overlap are needed; use more seed files: "
+                         "seed_cutfiles)")
     if n < 0:
         raise RuntimeError({-1: "ndgpu_ovl_sort: no usable HIP device", -2: "ndgpu_ovl_sort: out of device memory (about 150 bytes per candidate "
                             "overlap are needed; use more seed files: seed_cutfiles)", -3: "ndgpu_ovl_sort: more than 2^31 candidate overlaps in "

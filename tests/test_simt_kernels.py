@@ -8,6 +8,7 @@ The scoring kernel's forced paths read their switches once per process, so they 
 import ctypes as C
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -182,3 +183,52 @@ def test_db_path_equals_ascii_path_and_host_oracle(simt_api, host_harness, profi
         assert g[0] == c[0] and g[0] > 1000
         assert g[2] == c[2]
         assert np.float32(g[1]) == np.float32(c[1])
+
+
+_OOM_CHILD = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, build_simt, chain_util
+from nextdenovo_amd import api, synth
+api._LIB = api._bind(C.CDLL(build_simt.build()))
+g = synth.make_genome(20000, seed=31, n_repeats=0)
+rs = synth.simulate_reads(g, 30, "ont", seed=32, mu=7.9, sigma=0.3)
+piles = synth.build_piles(rs, seed_cutoff=1000)[:8]
+words, off, lens = synth.pack_db(rs)
+recs, poff = synth.flatten_piles(piles)
+db = api.ReadDB(words, off, lens)
+res = db.correct_piles(recs, poff, host_threads=4)
+again = db.correct_piles(recs, poff, host_threads=4) if %d else res   # a second call after the failures: nothing is poisoned
+db.close()
+print(json.dumps(dict(a=[chain_util.digest(r) for r in res], b=[chain_util.digest(r) for r in again])))
+"""
+
+
+def _oom_child(env, twice=0):
+    e = dict(os.environ, NDGPU_TRACE="1", NDGPU_CONTEXTS="1", NDGPU_SUBBATCHES_PER_CONTEXT="1", **env)
+    out = subprocess.run([sys.executable, "-c", _OOM_CHILD % (os.path.dirname(HERE), HERE, os.path.join(HERE, "simt"), twice)], env=e,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+
+
+def test_out_of_device_memory_halves_the_sub_batch(simt_lib):
+    """lib/nextcorrect.c:2254-2261, lib/nextcorrect.py:255-257: a seed whose working memory cannot be had is a `len == 3` seed and
+    nothing else is lost.  Here: a sub-batch that does not fit is halved until its pieces fit -- the records of the pieces are the
+    records of the undisturbed run -- and only a single pile that does not fit alone is reported.  (Round 3 shipped a size mark that
+    made every retry ask for the failed size again: every pile of the sub-batch came back as len 3.)"""
+    want, _ = _oom_child({})
+    assert len(want["a"]) == 8 and all(d[0] > 1000 for d in want["a"])
+    # find a limit the whole sub-batch does not fit under but single piles do: the largest allocation of the undisturbed run / 3
+    _, err = _oom_child({"NDGPU_DEBUG_ALLOC": "1"})
+    big = max(int(m) for m in re.findall(r"\((\d+) bytes, asked", err))
+    got, err = _oom_child({"NDGPU_OOM_ABOVE": str(big // 3)}, twice=1)
+    assert "out of device memory" in err and "halved" in err
+    assert got["a"] == want["a"], "halved sub-batches must give the undisturbed records"
+    assert got["b"] == want["a"], "a later call must not inherit sizes that failed"
+    # pinned host arenas fail the same way
+    got, err = _oom_child({"NDGPU_PINNED_OOM_ABOVE": str(200 << 10)})
+    assert "halved" in err and all(a == b or a[0] == 3 for a, b in zip(got["a"], want["a"]))
+    # nothing fits: every seed is an out-of-memory seed, nothing aborts
+    got, err = _oom_child({"NDGPU_OOM_ABOVE": str(64 << 10)})
+    assert all(d[0] == 3 for d in got["a"]) and "out-of-memory seed" in err

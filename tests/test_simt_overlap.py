@@ -165,3 +165,41 @@ def test_chains_of_the_base_level_alignment_match_oracle(interpreted, olib):
 def test_sort_in_seed_ranges_equals_the_sort_at_once(interpreted, monkeypatch):
     """The out-of-core form of the overlap sort (tests/test_gpu_ovlsort.py) under the interpreter."""
     GS.check_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, False)
+
+
+def test_every_failed_device_operation_surfaces(interpreted, monkeypatch):
+    """DESIGN section 7b (round 3): on a device short of memory an all-vs-all job once returned records built from half the anchors
+    and no error.  The primitives' return values were dropped, and a failing primitive clears the runtime's sticky error.  Here
+    every checked device operation of an index build + map + sort (block-pool allocation, rocPRIM primitive, kernel launch) is
+    made to fail in turn (NDGPU_OVL_FAIL_AT): the call must raise MemoryError -- never return a different number of records --
+    and the next, undisturbed call must give the undisturbed result."""
+    from nextdenovo_amd import overlap
+    dset, _ = None, None
+    p = os.path.join(GO.GOLD, GO.SETS[0] + ".2bit")
+    dset = overlap.ReadSet.from_2bit(p)
+    lens = np.asarray(dset.lens, dtype=np.uint32)
+
+    def job():
+        with overlap.Index(overlap.preset("ava-ont"), dset) as ix:
+            raw = ix.map(dset, ix.mid_occ())
+        srt, bl, _ = overlap.sort_overlaps([raw], lens, int(lens.min()), 40, 300)
+        return raw, srt, bl
+
+    monkeypatch.delenv("NDGPU_OVL_FAIL_AT", raising=False)
+    want = job()
+    assert want[0].shape[0] > 100
+    # fail the 1st, 2nd, ... checked operation of a job until a job gets through (the k-th operation does not exist)
+    k = 1
+    while True:
+        monkeypatch.setenv("NDGPU_OVL_FAIL_AT", str(k))   # (a new value restarts the library's count)
+        try:
+            got = job()
+        except MemoryError:
+            k += 1
+            continue
+        assert all(np.array_equal(a, b) for a, b in zip(got[:2], want[:2])) and got[2] == want[2]
+        break
+    assert k > 60, k
+    monkeypatch.delenv("NDGPU_OVL_FAIL_AT")
+    again = job()
+    assert all(np.array_equal(a, b) for a, b in zip(again[:2], want[:2])) and again[2] == want[2]
