@@ -77,24 +77,29 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
     uint32_t col = 0, col_end = 0;
     uint64_t qo = 0;
     uint32_t p1 = kTagHead, p2 = kTagHead;  // the row's two previous tags
-    // the word of 16 column kinds / 16 bases the row is reading: a step of the column loop then costs a load only every 16th time
-    // (its latency is the wavefront's: every column waits for the slowest lane)
-    uint32_t ops_wi = 0xffffffffu, ops_w = 0;
-    uint64_t q_wi = ~0ull;
-    uint32_t q_w = 0;
+    // the word of 16 column kinds / 16 bases the row is reading, and the word after it, fetched when the row steps into the current
+    // one: a step of the column loop never waits for memory (its latency is the wavefront's -- every column waits for the slowest
+    // lane, and with 30 rows at 30 different phases some lane crossed a word boundary in nearly every column; a trip to L2 / HBM
+    // costs more than the rest of a column).  The streams are sequential, so the word after is always the one needed next; the
+    // ops of a task carry a pad word and the pools kPoolPadWords, so the look-ahead never leaves its buffer.
+    uint32_t ops_wi = 0x7fffffffu, ops_w = 0, ops_nx = 0;
+    uint64_t q_wi = ~0ull >> 1;
+    uint32_t q_w = 0, q_nx = 0;
     auto op_peek = [&]() -> uint32_t {
         const uint32_t wi = col >> 4;
         if (wi != ops_wi) {
-            ops_w = W[wi];
+            ops_w = wi == ops_wi + 1u ? ops_nx : W[wi];
             ops_wi = wi;
+            ops_nx = W[wi + 1u];
         }
         return (ops_w >> ((col & 15u) * 2u)) & 3u;
     };
     auto q_take = [&]() -> uint32_t {
         const uint64_t wi = qo >> 4;
         if (wi != q_wi) {
-            q_w = pool[wi];
+            q_w = wi == q_wi + 1ull ? q_nx : pool[wi];
             q_wi = wi;
+            q_nx = pool[wi + 1ull];
         }
         const uint32_t c = (q_w >> ((uint32_t)(qo & 15u) * 2u)) & 3u;
         qo++;
@@ -118,8 +123,13 @@ __global__ __launch_bounds__(64) void lq_msa_kernel(LqPileDev *__restrict__ pile
         col = T.ops_cap - (uint32_t)O.n_cols;
         col_end = T.ops_cap;
         qo = T.q_off & kOffMask;
-        ops_wi = 0xffffffffu;
-        q_wi = ~0ull;
+        // (both streams start here: their first words are on their way while the 'N' column is scored)
+        ops_wi = col >> 4;
+        ops_w = W[ops_wi];
+        ops_nx = W[ops_wi + 1u];
+        q_wi = qo >> 4;
+        q_w = pool[q_wi];
+        q_nx = pool[q_wi + 1ull];
     };
 
     for (int i = lane; i < kLqDeltaCap * 6; i += 64) cell_n[0][i] = cell_n[1][i] = 0;
