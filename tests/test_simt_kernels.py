@@ -76,6 +76,38 @@ def test_align_fuzz_vs_oracle(simt_lib, oracle_lib):
     assert ok > 20
 
 
+def test_align_beyond_the_sequence_window(simt_lib, oracle_lib):
+    """K7 reads its sequences through a 2,048-base ring in LDS that follows the front (chunks of 1,024 bases, the next one in
+    flight), and falls back to global memory for a cell outside it: alignments several windows long, with exact runs longer than a
+    compare round (64) and than a chunk, a query that starts far into the target's word grid, very unequal error rates (fronts that
+    lean to one side) and lengths around the chunk boundaries -- all against the oracle."""
+    from nextdenovo_amd import synth
+    rng = np.random.default_rng(5)
+    cases = []
+    for L in (2040, 2049, 3071, 3073, 4100, 9000):
+        base = rng.integers(0, 4, L, dtype=np.uint8)
+        cases.append((synth.mutate(base, np.random.default_rng(L), "ont")[0], synth.mutate(base, np.random.default_rng(L + 1), "ont")[0], 0))
+    base = rng.integers(0, 4, 7000, dtype=np.uint8)
+    clean = base.copy()
+    noisy = synth.mutate(base, np.random.default_rng(9), "ont")[0]
+    cases.append((clean, noisy, 0))                       # one side exact: long diagonal runs on the other side's errors only
+    cases.append((noisy, clean, 0))
+    exact = np.concatenate([synth.mutate(base[:2500], np.random.default_rng(10), "clr")[0], base[2500:4700], synth.mutate(base[4700:], np.random.default_rng(11), "clr")[0]])
+    cases.append((exact, base, 0))                        # a 2,200-base exact run: the front jumps past a whole chunk in one step
+    cases.append((base, exact, 0))
+    hq = synth.mutate(base, np.random.default_rng(12), "hifi")[0]
+    cases.append((hq, base, 1))                           # align_hq: narrow band, long runs
+    cases.append((base[37:], synth.mutate(base, np.random.default_rng(13), "ont")[0][:6900], 0))
+    for i, (q, t, is_hq) in enumerate(cases):
+        qa, ta = util.ASC[q].tobytes(), util.ASC[t].tobytes()
+        o, ots, oqs, _ = util.oracle_align(oracle_lib, qa, ta, is_hq)
+        n, tu, qu, ts, qs = util.gpu_align(simt_lib, qa, ta, is_hq)
+        assert n == o.aln_len, i
+        if o.status == 1:
+            assert ts == ots and qs == oqs and (tu, qu) == (o.t_used, o.q_used), i
+    assert sum(1 for q, t, h in cases if len(q) > 2048) >= 10
+
+
 @pytest.mark.parametrize("schedule", [0, 1, 2, 7])
 def test_golden_piles_nextcorrect(simt_lib, schedule):
     """nextCorrect() end to end (K7 ... K11, the three-wave scoring pipeline with its default segments, the segmented walk)
