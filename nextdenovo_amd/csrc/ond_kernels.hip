@@ -114,86 +114,6 @@ __device__ __forceinline__ int snake64(const uint32_t *__restrict__ qp, const ui
     return x;
 }
 
-// K7 reads its two sequences through a WINDOW IN LDS.  An edit step is a dependent chain -- permute, snake, ballots, wave maximum --
-// and until round 4 the snake's ten words came from global memory: a round trip to L2 / HBM of several hundred cycles in the middle
-// of every step, most of the 0.65 us a step took on an idle device (profiles/r04_chain_latency_64base_snake.json; comparing 64 bases
-// instead of 16 per round trip had changed nothing: the trip itself was the cost).  The front of an alignment moves ~3 bases per
-// step and its cells stay within ~200 bases of one another (band <= 238 diagonals, anti-diagonals within 150 of the best), so the
-// wavefront keeps the last kWinWords words (2,048 bases) of either sequence in a ring in LDS, filled a chunk of 64 words at a time --
-// one word per lane -- and the chunk after the newest one is already on its way in a register when the front is still a thousand
-// bases short of it: no step waits for memory.  A cell whose five words are not (or no longer) in the ring reads global memory as
-// before, so the ring's policy is a matter of speed only; what lies beyond a sequence's end is never compared (the run is cut at
-// the shorter remainder), so stale ring content there is harmless.
-constexpr uint32_t kWinWords = 128;
-struct SeqWindow {
-    const uint32_t *__restrict__ g;  // the sequence's first word in global memory
-    uint32_t *ring;                  // kWinWords words of LDS
-    uint32_t sh;                     // the first base's offset inside g[0]
-    uint32_t hi;                     // words [hi - kWinWords, hi) are in the ring (hi: a multiple of 64)
-    uint32_t n_words;                // words worth fetching: the sequence's own + the four a 64-base fetch may touch beyond
-    uint32_t pend;                   // word hi + lane, on its way (or arrived)
-    bool all;                        // everything worth fetching is in the ring or pending-free: no commit is left to do
-    __device__ __forceinline__ uint32_t guarded(uint32_t w) const { return w < n_words ? g[w] : 0u; }
-    __device__ __forceinline__ void init(const uint32_t *gp, uint32_t *lds, uint32_t shift, int len, int lane) {
-        g = gp, ring = lds, sh = shift;
-        n_words = ((shift + (uint32_t)len + 15u) >> 4) + 4u;
-        const uint32_t a = guarded((uint32_t)lane), b = guarded(64u + (uint32_t)lane);
-        ring[lane] = a;
-        ring[64 + lane] = b;
-        hi = kWinWords;
-        all = hi >= n_words;
-        pend = all ? 0u : guarded(hi + (uint32_t)lane);
-    }
-    // before a step whose cells start no further than base `x_max`: bring the next chunk in if the front is about to need it
-    __device__ __forceinline__ void advance(int x_max, int lane) {
-        if (all) return;
-        const uint32_t need = ((sh + (uint32_t)x_max + 64u) >> 4) + 5u;  // one past the last word a first round may touch
-        if (need + 8u < hi) return;
-        ND_LOCKSTEP();  // (every lane has read what it wanted of the slots that are overwritten now)
-        ring[(hi + (uint32_t)lane) & (kWinWords - 1u)] = pend;
-        hi += 64u;
-        all = hi >= n_words;
-        pend = all ? 0u : guarded(hi + (uint32_t)lane);
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ Bases64 fetch(uint32_t pos_rel) const {  // 64 bases from base pos_rel of the sequence
-        const uint32_t p = sh + pos_rel, w0 = p >> 4;
-        if (w0 + kWinWords >= hi && (w0 + 4u < hi || all)) {
-            struct W4 { uint32_t x, y, z, w; } v;
-            v.x = ring[w0 & (kWinWords - 1u)], v.y = ring[(w0 + 1u) & (kWinWords - 1u)], v.z = ring[(w0 + 2u) & (kWinWords - 1u)];
-            v.w = ring[(w0 + 3u) & (kWinWords - 1u)];
-            const uint32_t v4 = ring[(w0 + 4u) & (kWinWords - 1u)];
-            const uint32_t s = (p & 15u) * 2u;
-            Bases64 r;
-            r.w[0] = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> s);
-            r.w[1] = (uint32_t)((((uint64_t)v.z << 32) | v.y) >> s);
-            r.w[2] = (uint32_t)((((uint64_t)v.w << 32) | v.z) >> s);
-            r.w[3] = (uint32_t)((((uint64_t)v4 << 32) | v.w) >> s);
-            return r;
-        }
-        return fetch64(g + w0, p & 15u);
-    }
-};
-
-__device__ __forceinline__ int snake64_win(const SeqWindow &Q, const SeqWindow &T, int q_len, int t_len, int x, int k) {
-    int y = x - k;
-    for (;;) {
-        int rem = q_len - x;
-        const int rt = t_len - y;
-        rem = rt < rem ? rt : rem;
-        if (rem <= 0) break;
-        const Bases64 a = Q.fetch((uint32_t)x);
-        const Bases64 b = T.fetch((uint32_t)y);
-        const uint32_t d0 = a.w[0] ^ b.w[0], d1 = a.w[1] ^ b.w[1], d2 = a.w[2] ^ b.w[2], d3 = a.w[3] ^ b.w[3];
-        int m = d0 ? (__builtin_ctz(d0) >> 1) : d1 ? 16 + (__builtin_ctz(d1) >> 1) : d2 ? 32 + (__builtin_ctz(d2) >> 1) : d3 ? 48 + (__builtin_ctz(d3) >> 1) : 64;
-        m = m < rem ? m : rem;
-        x += m;
-        y += m;
-        if (m < 64) break;
-    }
-    return x;
-}
-
 __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
                                                           const uint32_t *__restrict__ pool,
                                                           const uint32_t *__restrict__ db_pool,
@@ -226,11 +146,6 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
     const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
     uint64_t *__restrict__ S = trace + T.trace_off;
     uint32_t pos = 0;
-    __shared__ uint32_t ring_q[kWinWords], ring_t[kWinWords];
-    SeqWindow WQ, WT;
-    WQ.init(qp, ring_q, q_sh, q_len, lane);
-    WT.init(tp, ring_t, t_sh, t_len, lane);
-    __builtin_amdgcn_wave_barrier();
 
     int px0 = 0, px1 = 0;  // the step before: x of cell `lane` / of cell 64 + `lane` (the reference memsets V: all zero)
     int pj = 0;            // its j
@@ -248,10 +163,6 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         cells += ncell;
         max_band = band > max_band ? band : max_band;
 
-        // no cell of this step starts beyond x = (best_m + k) / 2 + 1 (its neighbours' 2x - k were <= best_m), y = x - k
-        WQ.advance(((best_m + max_k) >> 1) + 2, lane);
-        WT.advance(((best_m - min_k) >> 1) + 2, lane);
-
         // ---- cells 0..63
         const int src = pj + lane;
         int vp = __shfl(px0, src & 63, 64);
@@ -267,7 +178,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         if (act0) {
             const bool down = (k0 == min_k) || (k0 != max_k && vm < vp);  // lib/align.c:443
             left0 = !down;
-            x0 = snake64_win(WQ, WT, q_len, t_len, down ? vp : vm + 1, k0);
+            x0 = snake64(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp : vm + 1, k0);
         }
         const unsigned long long lb0 = __ballot(act0 && left0);
         const unsigned long long fb0 = __ballot(act0 && x0 >= q_len && x0 - k0 >= t_len);
@@ -285,7 +196,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
             if (act1) {
                 const bool down = k1 != max_k && vm1 < vp1;
                 left1 = !down;
-                x1 = snake64_win(WQ, WT, q_len, t_len, down ? vp1 : vm1 + 1, k1);
+                x1 = snake64(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp1 : vm1 + 1, k1);
                 const int m1 = 2 * x1 - k1;
                 row_best = m1 > row_best ? m1 : row_best;
             }
@@ -490,58 +401,6 @@ __global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__r
     }
 }
 
-// K8a walks BACKWARDS through both sequences, a few bases per edit step, and every step used to wait for the ten words of its compare
-// to come from global memory (0.72 us a step on an idle device, all of it that trip).  The walk only ever needs the 64 bases that end
-// at its cursor, and the cursor only moves down: a lane keeps the two aligned 64-base blocks around its cursor in LDS -- eight words
-// per sequence, word w of the pool in slot w & 7; the wavefront's slots interleaved by lane ([slot][lane]), so that 64 lanes at 64
-// different slots never meet in a bank -- and holds the block below them in registers, requested when the cursor entered its
-// current block, i.e. at least 64 bases before the block becomes the lower half of a compare.  A step then costs ten LDS reads.
-struct BackWindow {
-    const uint32_t *__restrict__ pool;
-    uint32_t *ring;   // this lane's column of the wavefront's [8][64] table
-    int64_t cur;      // block (64 bases = 4 words) that holds the cursor; the ring holds cur and cur - 1, `nxt` holds cur - 2
-    uint32_t n0, n1, n2, n3;
-    __device__ __forceinline__ void load_block(int64_t b, uint32_t &a, uint32_t &c, uint32_t &e, uint32_t &f) const {
-        if (b >= 0) {  // (a block below the pool's first word: the cursor never reaches it, only the look-ahead asks)
-            struct alignas(16) W4 { uint32_t x, y, z, w; };
-            const W4 v = *reinterpret_cast<const W4 *>(pool + b * 4);
-            a = v.x, c = v.y, e = v.z, f = v.w;
-        } else a = c = e = f = 0u;
-    }
-    __device__ __forceinline__ void put(int64_t b, uint32_t a, uint32_t c, uint32_t e, uint32_t f) {
-        uint32_t *r = ring + ((uint32_t)(b & 1) * 4u) * 64u;
-        r[0] = a, r[64] = c, r[128] = e, r[192] = f;
-    }
-    __device__ __forceinline__ void init(const uint32_t *pl, uint32_t *lane_ring, uint64_t base) {
-        pool = pl, ring = lane_ring;
-        cur = (int64_t)(base >> 6);
-        uint32_t a, c, e, f;
-        load_block(cur, a, c, e, f);
-        put(cur, a, c, e, f);
-        load_block(cur - 1, a, c, e, f);
-        put(cur - 1, a, c, e, f);
-        load_block(cur - 2, n0, n1, n2, n3);
-    }
-    // the 64 bases that END at base `base` of the pool (base >= 63), base - 63 + i at bits [2i, 2i + 1] of the 128
-    __device__ __forceinline__ Bases64 fetch_back(uint64_t base) {
-        while ((int64_t)(base >> 6) < cur) {  // the cursor stepped down a block: the block in the registers takes the retired one's slots
-            cur--;
-            put(cur - 1, n0, n1, n2, n3);
-            load_block(cur - 2, n0, n1, n2, n3);
-        }
-        const uint64_t s0 = base - 63u;
-        const uint32_t ws = (uint32_t)(s0 >> 4), sh = (uint32_t)(s0 & 15u) * 2u;
-        const uint32_t v0 = ring[((ws) & 7u) * 64u], v1 = ring[((ws + 1u) & 7u) * 64u], v2 = ring[((ws + 2u) & 7u) * 64u];
-        const uint32_t v3 = ring[((ws + 3u) & 7u) * 64u], v4 = ring[((ws + 4u) & 7u) * 64u];
-        Bases64 r;
-        r.w[0] = (uint32_t)((((uint64_t)v1 << 32) | v0) >> sh);
-        r.w[1] = (uint32_t)((((uint64_t)v2 << 32) | v1) >> sh);
-        r.w[2] = (uint32_t)((((uint64_t)v3 << 32) | v2) >> sh);
-        r.w[3] = (uint32_t)((((uint64_t)v4 << 32) | v3) >> sh);
-        return r;
-    }
-};
-
 // K8a: one lane per alignment walks d -> 0.  STREAM: the register path's record stream (see K7), read back to front -- the
 // header of the current step's record is kept in a register, its cell index follows the walk; otherwise the wide kernel's rows.
 template <bool STREAM>
@@ -581,10 +440,6 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     // the two words before the header: the second word of this record if it has one, and -- whichever length it has -- the header of the
     // record before it.  Loaded a step ahead of their use, so that the walk never waits for the record it steps into.
     uint64_t c1 = (STREAM && pos >= 2) ? S[pos - 2] : 0ull, c2 = (STREAM && pos >= 3) ? S[pos - 3] : 0ull;
-    __shared__ uint32_t ring_q[8 * 64], ring_t[8 * 64];
-    BackWindow BQ, BT;
-    BQ.init(qp, ring_q + threadIdx.x, q_off + (uint64_t)(uint32_t)(x < 0 ? 0 : x));
-    BT.init(tp, ring_t + threadIdx.x, t_off + (uint64_t)(uint32_t)(x - k < 0 ? 0 : x - k));
 
     for (;;) {
         // match run, back to front (lib/align.c:502-507), 64 bases per compare: every lane walks an alignment of its own and the
@@ -595,9 +450,8 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
             const int avail = (x < yy ? x : yy) + 1;
             if (avail <= 0) break;
             const int n = avail < 64 ? avail : 64;
-            // (fewer than 64 bases left on either side: the last steps of a walk read global memory -- the 64 bases FROM x - n + 1)
-            const Bases64 a = n == 64 ? BQ.fetch_back(q_off + (uint64_t)(uint32_t)x) : fetch64_abs(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
-            const Bases64 b = n == 64 ? BT.fetch_back(t_off + (uint64_t)(uint32_t)yy) : fetch64_abs(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
+            const Bases64 a = fetch64_abs(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
+            const Bases64 b = fetch64_abs(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
             int m = n;  // bases [0, n) of the fetch are the run's candidates, the last one first
 #pragma unroll
             for (int i = 3; i >= 0; --i) {

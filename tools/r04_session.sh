@@ -47,6 +47,7 @@ print(" ms_per_step %.0f consensus %.0f overlap %.0f allocations %s pool_calls %
       d["overlap"]["ms_per_step"], d["allocations"], d["overlap"]["pool_calls"], d["kernel_ms"]))
 P
             ;;
+    parity) timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_k10.py tests/test_gpu_configs.py -m gpu -q -x --timeout=600 > "$out/pytest_parity.log" 2>&1; echo "parity exit $?"; tail -3 "$out/pytest_parity.log" ;;
     *) echo "unknown stage $s" ;;
   esac
   echo "   ($s: $(( $(date +%s) - t0 )) s)"
