@@ -62,6 +62,84 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+# ---- roofline bookkeeping -----------------------------------------------------------------------
+# Algorithmic bytes of the consensus kernels, from the run's own counters (operands once as 2-bit words,
+# one trace bit per evaluated (d, k) cell, outputs once).  Names are the kernels' names in a rocprofv3 kernel trace.
+def kernel_models(st):
+    m = {}
+    m["ond_forward_kernel"] = {
+        "label": "K7 ond_forward (banded O(ND) forward sweep, one wavefront per alignment)",
+        "alg_bytes": st["seq_bases"] / 4.0 + st["cells"] / 8.0,
+        "formula": "seq_bases / 4 (2-bit operands, read once) + cells / 8 (one trace bit per evaluated cell, written once)",
+        "ms": st["forward_ms"], "launches": st["forward_launches"]}
+    m["ond_traceback_kernel"] = {
+        "label": "K8a ond_traceback (one lane per alignment)",
+        "alg_bytes": st["seq_bases"] / 4.0 + st["d_steps"] / 8.0 + st["columns"] / 4.0,
+        "formula": "seq_bases / 4 (operands) + d_steps / 8 (the path's move bit of every edit step) + columns / 4 (2-bit column kinds out)",
+        "ms": st["traceback_ms"], "launches": st["traceback_launches"]}
+    m["lq_msa_kernel"] = {
+        "label": "K12 lq_msa (low-quality-region rounds: second MSA, DP and walk, one wavefront per pile)",
+        "alg_bytes": st["lq_aln_columns"] / 4.0 + st["lq_bases"] / 4.0 + float(st["lq_out"]),
+        "formula": "lq_aln_columns / 4 (2-bit column kinds in) + lq_bases / 4 (2-bit candidate bases in) + lq_out (characters out)",
+        "ms": st["lq_ms"], "launches": st["lq_launches"]}
+    m["count_links_kernel"] = {
+        "label": "K9 count_links (MSA link counting, wave per 32 columns)",
+        "alg_bytes": 4.0 * st["tags"] + 12.0 * st["links"] + 8.0 * st["cells_msa"],
+        "formula": "4 B per alignment tag in + 12 B per distinct link out + 8 B per MSA cell out",
+        "ms": st["links_ms"], "launches": st["score_launches"]}
+    m["score_seg_kernel"] = {
+        "label": "K10 score_seg (segment-parallel scoring DP)",
+        "alg_bytes": 20.0 * st["cells_msa"] + 12.0 * st["links"] + 20.0 * st["path_items"],
+        "formula": "20 B per MSA cell (8 in, 12 out) + 12 B per link in + 20 B of column metadata",
+        "ms": st["score_ms"], "launches": st["score_launches"]}
+    return m
+
+
+def committed_kernel_stats():
+    """The newest profiles/rNN_bench_kernel_stats.txt (tools/rocprof_summary.py of `rocprofv3 --kernel-trace --stats -- python
+    bench.py`): [(kernel name, calls, avg_us)] in the file's order (most GPU time first), and the file's name."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats.txt")))
+    if not files:
+        return [], None
+    rows = []
+    for ln in open(files[-1]):
+        mt = re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+        if mt:
+            rows.append((mt.group(1).strip(), int(mt.group(2)), float(mt.group(4))))
+    return rows, os.path.relpath(files[-1], ROOT)
+
+
+def kernel_source_sha16():
+    """What a committed counter measurement is tied to: the consensus kernels' sources."""
+    h = hashlib.sha256()
+    for f in ("ond_kernels.hip", "lq_kernels.hip", "msa_kernels.hip", "nd_device.h"):
+        with open(os.path.join(ROOT, "nextdenovo_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel, launches_per_step, config):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written by tools/make_pmc_json.py
+    from two separate rocprofv3 --pmc runs) -- only if it was measured on these kernel sources and this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pm = json.load(f)
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_traffic.json"
+    if pm.get("kernel_source_sha16") != kernel_source_sha16():
+        return None, "profiles/pmc_traffic.json was measured on other kernel sources (%s): not reported" % pm.get("kernel_source_sha16")
+    k = pm.get("kernels", {}).get(kernel)
+    if not k or pm.get("config") != config or abs(k["launches_per_step"] - launches_per_step) > 0.5:
+        return None, "profiles/pmc_traffic.json holds no matching entry for this kernel / workload"
+    # MI355X_MICROARCH.md (HBM / rocprofv3): KB units; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes for wide reads -> x2
+    return {"bytes": (2.0 * k["fetch_kb_per_launch"] + k["write_kb_per_launch"]) * 1024.0,
+            "fetch_kb_raw": k["fetch_kb_per_launch"], "write_kb_raw": k["write_kb_per_launch"],
+            "correction": "FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes; MI355X_MICROARCH.md, HBM section), KB units",
+            "source": pm.get("source")}, None
+
+
 # ---- CPU baseline leg (the ONLY place bench.py touches oracle/) ---------------------------------
 _REF = None
 
@@ -357,32 +435,50 @@ def main():
         else:
             recs, off = last["sub"], last["off"]
             piles = [{"seed": int(last["seeds"][i]), "recs": recs[int(off[i]):int(off[i + 1])]} for i in range(last["seeds"].size)]
-        # Roofline of the dominant kernel by GPU time: K7 ond_forward (banded O(ND) forward sweep).  Algorithmic bytes per
-        # launch = 2-bit operands read once + 1 trace bit per evaluated cell + 4 B min_k per edit step.
-        # K10 (scoring DP, segment-parallel since round 2) is reported alongside with its own algorithmic bytes: every MSA
-        # cell table entry read once (start, len: 8 B), its best_pp / best_link / best score written once (12 B), every
-        # link read once (pp, ppp, count: 12 B), 20 B of column metadata.
-        launches = max(1, st["forward_launches"])
-        alg_bytes = (st["seq_bases"] / 4.0 + st["cells"] / 8.0 + 4.0 * st["d_steps"]) / launches
-        # what the kernel is built to move, from this run's own counters: operands once, the trace records it wrote (8 bytes per
-        # edit step up to 56 cells, 16 beyond: `trace_words`), one 48-byte result per task -- to hold against the PMC figure
-        k7_model = (st["seq_bases"] / 4.0 + 8.0 * st["trace_words"] + 48.0 * st["tasks"]) / launches
-        avg_ms = st["forward_ms"] / launches
-        k7_achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        k10_launches = max(1, st["score_launches"])
-        k10_bytes = (20.0 * st["cells_msa"] + 12.0 * st["links"] + 20.0 * st["path_items"]) / k10_launches
-        k10_ms = st["score_ms"] / k10_launches
-        k10_achieved = k10_bytes / (k10_ms * 1e-3) / 1e9 if k10_ms > 0 else 0.0
-        traffic, traffic_note = None, None
-        try:  # HBM bytes per K7 launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself)
-            with open(os.path.join(ROOT, "profiles", "pmc_k7_traffic.json")) as f:
-                pm = json.load(f)
-            if not analytic and args.config == pm["workload"]["config"] and world == 1 and n_files == 1 and \
-                    abs(launches / args.steps - pm["launches_per_step"]) < 0.5:
-                traffic = (pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024.0
-                traffic_note = pm["source"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # Roofline: the kernel that leads the GPU time of the committed rocprofv3 kernel trace of this command (profiles/), priced
+        # with the algorithmic bytes of SURVEY.md section 8d from this run's counters over its HIP-event launch time; the other
+        # modelled kernels beside it.
+        models = kernel_models(st)
+        stat_rows, stat_file = committed_kernel_stats()
+        dom = None
+        for name, calls, avg_us in stat_rows:
+            for key in models:
+                if name.startswith(key):
+                    dom = (key, name, calls, avg_us)
+                    break
+            if dom:
+                break
+        if dom is None:  # no committed profile: the modelled kernel with the most event time in this run
+            key = max(models, key=lambda k_: models[k_]["ms"])
+            dom = (key, key, 0, 0.0)
+
+        def entry(key, rocprof_avg_us=None):
+            md = models[key]
+            launches = max(1, int(md["launches"]))
+            per_launch = md["alg_bytes"] / launches
+            avg_ms = md["ms"] / launches
+            ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            e = {"kernel": key, "what": md["label"], "achieved": ach, "frac": ach / 8000.0, "alg_bytes_per_launch": per_launch,
+                 "alg_bytes_formula": md["formula"], "avg_launch_ms": avg_ms, "launches": launches,
+                 "launches_per_step": launches / args.steps}
+            if rocprof_avg_us:
+                e["rocprof_avg_launch_ms"] = rocprof_avg_us / 1e3
+                e["frac_at_rocprof_avg"] = per_launch / (rocprof_avg_us * 1e-6) / 1e9 / 8000.0
+            return e
+        same_workload = args.config == 2 and not args.genome_size and world == 1 and n_files == 1 and not analytic  # what the committed trace ran
+        dom_entry = entry(dom[0], (dom[3] or None) if same_workload else None)
+        traffic, traffic_note = None, "analytic / sharded runs carry no committed counter figure"
+        if not analytic and world == 1 and n_files == 1:
+            traffic, traffic_note = committed_traffic(dom[0], dom_entry["launches_per_step"], args.config)
+        others = {}
+        rp = {}
+        for name, calls, avg_us in stat_rows:
+            for key in models:
+                if name.startswith(key) and key not in rp:
+                    rp[key] = avg_us
+        for key in models:
+            if key != dom[0]:
+                others[key] = entry(key, rp.get(key) if same_workload else None)
         peak = 8000.0
         n_cols = max(1, st["path_items"])
         out = {
@@ -408,22 +504,21 @@ def main():
                        "longest_chain_bound": "none since round 2: the scoring DP and the best_pp walk are cut into 1024-column segments "
                                               "scored at the same time (DESIGN section 5); a seed's length no longer bounds a step",
                        "datagen_s": round(t_gen, 1)},
-            "roofline": {"bound": "hbm", "kernel": "ond_forward_kernel (K7, banded O(ND) forward sweep)", "achieved": k7_achieved,
-                         "peak": peak, "unit": "GB/s", "frac": k7_achieved / peak, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_note,
-                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic and alg_bytes else None,
-                         "modelled_bytes_per_launch": k7_model, "modelled_trace_write_bytes_per_launch": 8.0 * st["trace_words"] / launches,
-                         "modelled_over_algorithmic": k7_model / alg_bytes if alg_bytes else None,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": int(launches),
-                         "cells_per_s": st["cells"] / (st["forward_ms"] * 1e-3) if st["forward_ms"] > 0 else 0.0,
-                         "note": "latency-bound (dependent edit steps, 33 of 64 lanes live on average), not bandwidth-bound; launch "
-                                 "times are HIP-event times with up to 8 contexts' launches in flight at once",
-                         "k10_scoring_dp": {"achieved": k10_achieved, "frac": k10_achieved / peak, "alg_bytes_per_launch": k10_bytes,
-                                            "avg_launch_ms": k10_ms, "launches": int(k10_launches),
-                                            "segments": int(st["score_segments"]), "repaired_segments": int(st["score_repairs"]),
-                                            "piles_through_int64_kernel": int(st["score_slow_piles"]),
-                                            "us_per_column_contended": st["score_ms"] * 1e3 / n_cols,
-                                            "note": "segment-parallel: a column's cost is throughput (GPU time / columns), no longer a chain"}},
+            "roofline": dict(dom_entry, **{
+                "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                "dominant_by": ("%s: `%s` leads the GPU time of the committed kernel trace" % (stat_file, dom[1])) if stat_file else
+                               "no committed kernel trace: the modelled kernel with the most HIP-event time in this run",
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+                "traffic_detail": traffic if traffic else traffic_note,
+                "traffic_over_algorithmic": (traffic["bytes"] / dom_entry["alg_bytes_per_launch"]) if traffic and dom_entry["alg_bytes_per_launch"] else None,
+                "cells_per_s_k7": st["cells"] / (st["forward_ms"] * 1e-3) if st["forward_ms"] > 0 else 0.0,
+                "note": "every consensus kernel is a chain of dependent steps per alignment / pile / column, bound by instruction issue and "
+                        "latency, not by bytes (SURVEY.md section 8d expects << 1 % of the HBM roofline); launch times are HIP-event "
+                        "brackets on the kernel's own stream with up to 8 contexts' launches in flight at once, `rocprof_avg_launch_ms` "
+                        "is the same kernel's average in the committed trace",
+                "timed_step_note": "lengths_only=True: the library computes every corrected sequence, the Python copy of the bytes is skipped",
+                "other_kernels": others}),
             "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "trace_words", "lq_rounds", "lq_declined", "max_band", "piles", "tags",
                                             "cells_msa", "links", "path_items", "score_segments", "score_repairs", "score_slow_piles")},
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",

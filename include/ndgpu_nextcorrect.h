@@ -178,6 +178,12 @@ typedef struct {
                                   so steady-state steps should show none */
     uint64_t level_allocs;     /* the same between batches (buffers brought up to the largest sub-batch seen, nothing in flight) */
     double level_ms;
+    uint64_t traceback_launches; /* K8a launches */
+    uint64_t lq_launches;      /* K12 launches, and what they moved algorithmically: */
+    uint64_t lq_columns;       /* columns of the linked pseudo-seeds walked */
+    uint64_t lq_aln_columns;   /* alignment columns (2-bit kinds) read */
+    uint64_t lq_bases;         /* candidate bases (2-bit) read */
+    uint64_t lq_out;           /* consensus characters written */
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

@@ -642,6 +642,8 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->lq_declined = s.lq_declined;
     o->lq_ms = s.lq_ms;
     o->allocs = s.allocs, o->alloc_ms = s.alloc_ms, o->level_allocs = s.level_allocs, o->level_ms = s.level_ms;
+    o->traceback_launches = s.traceback_launches, o->lq_launches = s.lq_launches, o->lq_columns = s.lq_columns;
+    o->lq_aln_columns = s.lq_aln_columns, o->lq_bases = s.lq_bases, o->lq_out = s.lq_out;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

@@ -305,6 +305,7 @@ struct DeviceAligner::State {
     std::vector<ReadDev> reads;
     std::vector<PileDev> piles;
     hipEvent_t evs[8] = {nullptr};
+    std::vector<hipEvent_t> lq_evs;  // run_lq: K7 / K8a brackets per chunk
     PinBuf<uint32_t> h_ops;
     PinBuf<AlnOut> h_outs;
     std::vector<uint32_t> pool;
@@ -480,6 +481,8 @@ RuntimeStats DeviceAligner::total_stats() {
         t.piles += s.piles; t.tags += s.tags; t.cells_msa += s.cells_msa; t.path_items += s.path_items;
         t.links += s.links; t.score_launches += s.score_launches; t.backtrack_ms += s.backtrack_ms;
         t.score_segments += s.score_segments; t.score_repairs += s.score_repairs; t.score_slow_piles += s.score_slow_piles;
+        t.traceback_launches += s.traceback_launches; t.lq_launches += s.lq_launches; t.lq_columns += s.lq_columns;
+        t.lq_aln_columns += s.lq_aln_columns; t.lq_bases += s.lq_bases; t.lq_out += s.lq_out;
     }
     t.allocs = g_alloc_calls.load(), t.alloc_ms = (double)g_alloc_ns.load() * 1e-6;
     t.level_allocs = g_level_calls.load(), t.level_ms = (double)g_level_ns.load() * 1e-6;
@@ -1078,15 +1081,24 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.h2d(S.d_tasks.p, tasks.data(), nt * sizeof(AlnTask), st);
     S.h2d(S.d_lq_piles.p, piles.data(), n * sizeof(LqPileDev), st);
     S.h2d(S.d_lq_pieces.p, pieces.data(), pieces.size() * sizeof(LqPieceDev), st);
-    HIP_CHECK(hipEventRecord(S.evs[0], st));
+    // (HIP-event brackets per kernel: K7, K8a per chunk -- read after the round's one synchronisation)
+    while (S.lq_evs.size() < 2 * chunk_end.size() + 1) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        S.lq_evs.push_back(e);
+    }
+    HIP_CHECK(hipEventRecord(S.lq_evs[0], st));
     {
-        size_t a = 0;
+        size_t a = 0, c = 0;
         for (size_t b : chunk_end) {
             NDGPU_DBG(st, "lq: forward / traceback %zu..%zu of %zu tasks", a, b, nt);
             launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st);
+            HIP_CHECK(hipEventRecord(S.lq_evs[2 * c + 1], st));
             launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr, S.d_ops.p, nullptr,
                                  (int)(b - a), st);
+            HIP_CHECK(hipEventRecord(S.lq_evs[2 * c + 2], st));
             a = b;
+            c++;
         }
     }
     HIP_CHECK(hipEventRecord(S.evs[1], st));
@@ -1101,11 +1113,17 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.sync_drain(st);
     HIP_CHECK(hipGetLastError());
     float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, S.evs[0], S.evs[1]));
-    S.stats.forward_ms += ms;  // (K7 + K8a of the rounds, not split)
+    for (size_t c = 0; c < chunk_end.size(); c++) {
+        HIP_CHECK(hipEventElapsedTime(&ms, S.lq_evs[2 * c], S.lq_evs[2 * c + 1]));
+        S.stats.forward_ms += ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, S.lq_evs[2 * c + 1], S.lq_evs[2 * c + 2]));
+        S.stats.traceback_ms += ms;
+    }
     S.stats.forward_launches += chunk_end.size();
+    S.stats.traceback_launches += chunk_end.size();
     HIP_CHECK(hipEventElapsedTime(&ms, S.evs[1], S.evs[2]));
     S.stats.lq_ms += ms;
+    S.stats.lq_launches++;
     S.stats.tasks += nt;
     const uint64_t tc2 = wall_ns();
 
@@ -1140,6 +1158,14 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         }
         R.lqc.assign(out.data() + P.out_off, P.out_len);
         R.ok = true;
+        S.stats.lq_columns += P.link_len;
+        S.stats.lq_out += P.out_len;
+        for (uint32_t k = 0; k < 30u * P.n_regions; k++) {
+            const int32_t t = pieces[P.first_piece + k].task;
+            if (t < 0) continue;
+            S.stats.lq_bases += (uint64_t)tasks[(size_t)t].q_len;
+            if (S.h_outs.p[t].status == ST_ALIGNED) S.stats.lq_aln_columns += (uint64_t)S.h_outs.p[t].n_cols;
+        }
     }
     g_prof.c_pack += tc1 - tc0, g_prof.c_dev += tc2 - tc1, g_prof.c_decode += wall_ns() - tc2, g_prof.c_jobs += nt;
 }
@@ -1339,6 +1365,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                 S.stats.forward_launches++;
                 HIP_CHECK(hipEventElapsedTime(&ms, S.evs[1], S.evs[2]));
                 S.stats.traceback_ms += ms;
+                S.stats.traceback_launches++;
             }
             a = b;
         }

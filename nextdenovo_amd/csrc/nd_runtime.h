@@ -47,6 +47,13 @@ struct RuntimeStats {
     double alloc_ms = 0;           // wall time of those calls (an allocation in the middle of a step stalls every context)
     uint64_t level_allocs = 0;     // the same between batches (level_buffers: nothing in flight)
     double level_ms = 0;
+    // per-kernel launch counts and the algorithmic units of K8a / K12, for the roofline entries of bench.py
+    uint64_t traceback_launches = 0;  // K8a launches (main phase + low-quality-region rounds)
+    uint64_t lq_launches = 0;         // K12 launches
+    uint64_t lq_columns = 0;          // columns of the linked pseudo-seeds K12 walked
+    uint64_t lq_aln_columns = 0;      // alignment columns (2-bit kinds) K12 read
+    uint64_t lq_bases = 0;            // candidate bases (2-bit) K12 read
+    uint64_t lq_out = 0;              // consensus characters K12 wrote
 };
 
 // Thrown when a device (or pinned host) allocation fails for lack of memory.  The C ABI catches it, releases the

@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""profiles/pmc_traffic.json from a tools/rocprof_pmc_summary.py table: per modelled kernel the FETCH_SIZE / WRITE_SIZE KB per
+launch, tied to the kernel sources they were measured on (bench.py refuses the figure once the sources change).
+usage: make_pmc_json.py <pmc_summary.txt> <bench steps the passes ran, warm-up included> <config> [source note]"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    table, steps, config = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
+    note = sys.argv[4] if len(sys.argv) > 4 else os.path.relpath(table, ROOT)
+    keys = ("ond_forward_kernel", "ond_traceback_kernel", "lq_msa_kernel", "count_links_kernel", "score_seg_kernel<96")
+    kernels = {}
+    for ln in open(table):
+        mt = re.match(r"^(\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+([\d.]+)\s*$", ln)
+        if not mt:
+            continue
+        for k in keys:
+            if mt.group(1).startswith(k):
+                kernels[k.split("<")[0]] = {"launches_per_step": int(mt.group(2)) / steps, "fetch_kb_per_launch": float(mt.group(3)),
+                                            "write_kb_per_launch": float(mt.group(4))}
+    out = {"config": config, "kernel_source_sha16": bench.kernel_source_sha16(), "source": note, "kernels": kernels}
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,11 @@ print(" ms_per_step %.0f consensus %.0f overlap %.0f allocations %s pool_calls %
 P
             ;;
     parity) timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_k10.py tests/test_gpu_configs.py -m gpu -q -x --timeout=600 > "$out/pytest_parity.log" 2>&1; echo "parity exit $?"; tail -3 "$out/pytest_parity.log" ;;
+    trace)  NDGPU_TRACE=1 NDGPU_PROF=1 timeout 400 python bench.py --steps 3 --warmup 2 --no-cpu-baseline > "$out/bench_trace.json" 2> "$out/bench_trace.err"; echo "trace exit $?"; tail -c 300 "$out/bench_trace.json" ;;
+    timeline) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/stats" -o s -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/$out/prof.log" 2>&1)
+            db="$(ls "$out"/stats/*results.db | head -1)"
+            python tools/rocprof_summary.py "$db" > "$out/kernel_stats.txt" 2>> "$out/prof.log"; head -30 "$out/kernel_stats.txt"
+            python tools/rocprof_timeline.py "$db" > "$out/timeline.txt" 2>> "$out/prof.log"; rm -rf "$out/stats" ;;
     *) echo "unknown stage $s" ;;
   esac
   echo "   ($s: $(( $(date +%s) - t0 )) s)"
