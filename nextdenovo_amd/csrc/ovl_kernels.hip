@@ -12,6 +12,9 @@
 //                            (minimap2/chain.c:87-162, hit.c:8-95, map.c:1296-1304)
 //
 // Integer / byte work, HBM- and latency-bound: nothing here is shaped like a GEMM.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -1312,25 +1315,41 @@ __device__ __forceinline__ int dovetail_class(int rev, uint32_t qs, uint32_t qe,
 	return 0;
 }
 
-__global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *__restrict__ ax,
+__global__ void __launch_bounds__(64) hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *__restrict__ ax,
                             const uint64_t *__restrict__ ay, IndexDev ix, QueryDev q, OvlParams P, const int32_t *__restrict__ f,
                             const int32_t *__restrict__ p, int32_t *__restrict__ v, int32_t *__restrict__ t, uint64_t *__restrict__ u,
                             uint64_t *__restrict__ bx, uint64_t *__restrict__ by, uint64_t *__restrict__ wx, uint64_t *__restrict__ wy,
                             uint32_t *__restrict__ tables, SortJob *__restrict__ stacks, const uint32_t *__restrict__ n_end,
                             OvlRec *__restrict__ recs, uint32_t *__restrict__ n_rec, uint32_t *__restrict__ n_chain,
-                            OvlRec10 *__restrict__ recs10, uint64_t *__restrict__ cx, uint64_t *__restrict__ cy, uint32_t *__restrict__ n_ca)
+                            OvlRec10 *__restrict__ recs10, uint64_t *__restrict__ cx, uint64_t *__restrict__ cy, uint32_t *__restrict__ n_ca,
+                            unsigned long long *__restrict__ prof)
 {
-	const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;
+	// (NDGPU_K5_PROF: per phase the sum over reads and the longest single read, in 10 ns ticks of the constant clock)
+#ifdef SIMT_EMULATION
+#define K5_TICK(ph) ((void)0)
+#else
+	unsigned long long tk = prof ? wall_clock64() : 0ull;
+#define K5_TICK(ph) do { if (prof && lane == 0) { const unsigned long long now = wall_clock64(); atomicAdd(&prof[2 * (ph)], now - tk); atomicMax(&prof[2 * (ph) + 1], now - tk); tk = now; } } while (0)
+#endif
+	// One WAVEFRONT per read.  Until round 4 a lane took a read and walked it alone: ~1.4 us per anchor of dependent global loads,
+	// 5 ms for an average read and 40 ms for the heaviest one -- the length of the launch (the per-phase clock of NDGPU_K5_PROF:
+	// backtrack 19 ms, chain copy 9 ms, records 5 ms on that read).  The walks of a read's chains are independent but for one
+	// rule -- a chain stops at the first anchor a better chain has taken -- and that rule is order-free once stated as "an anchor
+	// belongs to the best chain end of its subtree": every lane walks one chain, best ranks first, and claims with atomicMax.
+	const int lane = (int)threadIdx.x;
+	const uint32_t rl = blockIdx.x;
 	if (rl >= n_reads) return;
 	const uint32_t rd = read_base + rl;
 	const uint64_t a0 = r_aoff[rl];
 	const int32_t n = (int32_t)(r_aoff[rl + 1] - a0);
-	n_rec[rl] = 0, n_chain[rl] = 0;
-	if (P.chains) n_ca[rl] = 0;
+	if (lane == 0) {
+		n_rec[rl] = 0, n_chain[rl] = 0;
+		if (P.chains) n_ca[rl] = 0;
+	}
 	if (n == 0) return;
 	const uint64_t *X = ax + a0, *Y = ay + a0;
 	const int32_t *F = f + a0, *Pp = p + a0;
-	int32_t *V = v + a0, *T = t + a0;
+	int32_t *T = t + a0;  // (v[] is K4's; the walks are not listed any more)
 	uint64_t *U = u + a0, *BX = bx + a0, *BY = by + a0, *WX = wx + a0, *WY = wy + a0;
 	uint32_t *head = tables + (size_t)rl * 512, *tail = head + 256;
 	SortJob *stack = stacks + a0 / 64 + 2 * (size_t)rl;
@@ -1338,46 +1357,110 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 	// chain ends were collected by K4 (u[], n_end[]); t[] is zero
 	int32_t n_u = (int32_t)n_end[rl];
 	if (n_u == 0) return;
-	heap_sort_desc(U, n_u); // distinct keys
-
-	// backtrack, best chain first
-	int32_t n_v = 0, k = 0;
-	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t v0 = n_v, k0 = k;
-		int32_t j = (int32_t)U[i];
-		do { V[n_v++] = j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0);
-		if (j < 0) {
-			if (n_v - v0 >= P.min_cnt) U[k++] = U[i] >> 32 << 32 | (uint64_t)(uint32_t)(n_v - v0);
-		} else if ((int32_t)(U[i] >> 32) - F[j] >= P.min_sc) {
-			if (n_v - v0 >= P.min_cnt) U[k++] = ((U[i] >> 32) - (uint64_t)F[j]) << 32 | (uint64_t)(uint32_t)(n_v - v0);
+	auto sync_wave = [] {  // what lanes wrote to global memory before is visible to the lanes after
+		__threadfence_block();
+		__builtin_amdgcn_wave_barrier();
+	};
+	auto excl_sum = [&](int32_t val, int32_t &total) {  // exclusive prefix sum over the 64 lanes
+		int32_t inc = val;
+		for (int dd = 1; dd < 64; dd <<= 1) {
+			const int32_t o = __shfl_up(inc, dd, 64);
+			if (lane >= dd) inc += o;
 		}
-		if (k0 == k) n_v = v0;
+		total = __shfl(inc, 63, 64);
+		return inc - val;
+	};
+	if (lane == 0) heap_sort_desc(U, n_u);
+	sync_wave();
+	K5_TICK(0);
+
+	// backtrack, best chain first (chain.c:106-125).  Sequentially: chain i takes its end anchor, then follows p[] while the
+	// anchors are free.  An anchor is taken by the best-ranked chain end among those whose walk leads through it, and nothing below
+	// it on that chain's walk can belong to a better one (it would lead through the anchor too): so the claims are the maximum of
+	// (n_u - i) over the chains that walk through, whatever the order of the walks -- a lane stops where it meets a better claim,
+	// and a better chain that arrives later walks on over the worse claims above.
+	for (int32_t base = 0; base < n_u; base += 64) {
+		const int32_t i = base + lane;
+		if (i < n_u) {
+			const int32_t mine = n_u - i;
+			int32_t j = (int32_t)U[i];
+			do {
+				if (atomicMax(&T[j], mine) > mine) break;
+				j = Pp[j];
+			} while (j >= 0);
+		}
+	}
+	sync_wave();
+	// every chain's length and verdict; the chains that pass, in rank order: U[k] = score << 32 | count, WX[k] = end anchor << 32 | k0
+	int32_t k = 0, n_v = 0;
+	for (int32_t base = 0; base < n_u; base += 64) {
+		const int32_t i = base + lane;
+		bool keep = false;
+		int32_t cnt = 0, end = 0;
+		uint64_t nu = 0;
+		if (i < n_u) {
+			const int32_t mine = n_u - i;
+			const uint64_t ui = U[i];
+			end = (int32_t)ui;
+			cnt = 1;  // (the end anchor is taken whoever holds it: do { ... } while)
+			int32_t j = Pp[end];
+			while (j >= 0 && T[j] == mine) cnt++, j = Pp[j];
+			if (j < 0) keep = cnt >= P.min_cnt, nu = ui >> 32 << 32 | (uint64_t)(uint32_t)cnt;
+			else if ((int32_t)(ui >> 32) - F[j] >= P.min_sc) keep = cnt >= P.min_cnt, nu = ((ui >> 32) - (uint64_t)F[j]) << 32 | (uint64_t)(uint32_t)cnt;
+		}
+		ND_LOCKSTEP();  // (every lane has read its U[i]: slots up to base + lane are overwritten now)
+		const unsigned long long km = __ballot(keep);
+		int32_t tot = 0;
+		const int32_t off = excl_sum(keep ? cnt : 0, tot);
+		if (keep) {
+			const int32_t kk = k + __popcll(km & ((1ULL << lane) - 1));
+			U[kk] = nu;
+			WX[kk] = (uint64_t)(uint32_t)end << 32 | (uint32_t)(n_v + off);
+		}
+		k += __popcll(km);
+		n_v += tot;
 	}
 	n_u = k;
+	sync_wave();
+	K5_TICK(1);
 	if (n_u == 0) return;
-	// chained anchors, each chain in increasing order
-	k = 0;
-	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t k0 = k, cnt = (int32_t)U[i];
-		for (int32_t j = 0; j < cnt; ++j) { const int32_t src = V[k0 + (cnt - 1 - j)]; BX[k] = X[src], BY[k] = Y[src]; ++k; }
+	// chained anchors, each chain in increasing order; then the chains' first anchors for the ordering below
+	for (int32_t base = 0; base < n_u; base += 64) {
+		const int32_t i = base + lane;
+		if (i < n_u) {
+			const int32_t cnt = (int32_t)U[i], k0 = (int32_t)(uint32_t)WX[i];
+			int32_t j = (int32_t)(WX[i] >> 32);
+			for (int32_t m = cnt - 1; m >= 0; --m) { BX[k0 + m] = X[j], BY[k0 + m] = Y[j]; j = Pp[j]; }
+			WY[i] = (uint64_t)(uint32_t)k0 << 32 | (uint32_t)i;
+			WX[i] = BX[k0];
+		}
 	}
-	// order chains by the x of their first anchor (the reference sort, ties included)
-	k = 0;
-	for (int32_t i = 0; i < n_u; ++i) { WX[i] = BX[k], WY[i] = (uint64_t)(uint32_t)k << 32 | (uint32_t)i; k += (int32_t)U[i]; }
-	reference_sort_xy(WX, WY, (uint32_t)n_u, head, tail, stack);
+	sync_wave();
+	K5_TICK(2);
+	// order chains by the x of their first anchor (the reference sort, ties included: a sequential replay, lane 0)
+	if (lane == 0) reference_sort_xy(WX, WY, (uint32_t)n_u, head, tail, stack);
+	sync_wave();
+	K5_TICK(3);
 	if (P.chains) {
 		// -c: the base-level alignment walks a[] itself (the chain before / after a hit's own: minimap2/align.c:629-664), so the
 		// chains are copied out in that order and addressed there from here on
 		uint64_t *CX = cx + a0, *CY = cy + a0;
 		int32_t kk = 0;
-		for (int32_t i = 0; i < n_u; ++i) {
-			const int32_t src = (int32_t)WY[i], first = (int32_t)(WY[i] >> 32), cnt = (int32_t)U[src];
-			for (int32_t j = 0; j < cnt; ++j) CX[kk + j] = BX[first + j], CY[kk + j] = BY[first + j];
-			WY[i] = (uint64_t)(uint32_t)kk << 32 | (uint32_t)src;
-			kk += cnt;
+		for (int32_t base = 0; base < n_u; base += 64) {
+			const int32_t i = base + lane;
+			int32_t src = 0, first = 0, cnt = 0;
+			if (i < n_u) src = (int32_t)WY[i], first = (int32_t)(WY[i] >> 32), cnt = (int32_t)U[src];
+			int32_t tot = 0;
+			const int32_t at = kk + excl_sum(cnt, tot);
+			if (i < n_u) {
+				for (int32_t j = 0; j < cnt; ++j) CX[at + j] = BX[first + j], CY[at + j] = BY[first + j];
+				WY[i] = (uint64_t)(uint32_t)at << 32 | (uint32_t)src;
+			}
+			kk += tot;
 		}
 		BX = CX, BY = CY;
-		n_ca[rl] = (uint32_t)kk;
+		if (lane == 0) n_ca[rl] = (uint32_t)kk;
+		sync_wave();
 	}
 	// hash-ordered hits: z.x = score<<32 | (cnt ^ h), z.y = first<<32 | cnt, over the re-ordered chains
 	const uint32_t qhash = q.hash[rd];
@@ -1385,19 +1468,24 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 	uint64_t *ZX = WX + n_u, *ZY = WY + n_u;
 	// The reference now copies the chains back in this order; the anchors are the same, so they are addressed
 	// in place through `first` (their offset in B).
-	for (int32_t i = 0; i < n_u; ++i) {
+	for (int32_t i = lane; i < n_u; i += 64) {
 		const int32_t src = (int32_t)WY[i];
 		const int32_t first = (int32_t)(WY[i] >> 32), cnt = (int32_t)U[src];
 		const uint32_t h = (uint32_t)hash_full((hash_full(BX[first]) + hash_full(BY[first])) ^ (uint64_t)qhash);
 		ZX[i] = U[src] ^ (uint64_t)h;
 		ZY[i] = (uint64_t)(uint32_t)first << 32 | (uint32_t)cnt;
 	}
-	reference_sort_xy(ZX, ZY, (uint32_t)n_u, head, tail, stack);
+	sync_wave();
+	K5_TICK(4);
+	if (lane == 0) reference_sort_xy(ZX, ZY, (uint32_t)n_u, head, tail, stack);
+	sync_wave();
+	K5_TICK(5);
 	// reversed: larger first
 	const uint32_t qid = q.id[rd], qlen = q.len[rd];
 	OvlRec *out = recs + a0 / (uint64_t)(P.min_cnt > 1 ? P.min_cnt : 1) + rl;
 	uint32_t n_out = 0;
-	for (int32_t i = n_u - 1; i >= 0; --i) {
+	// one lane per hit, in rounds of 64 from the last sorted hit down; the hits that pass keep their order
+	auto hit = [&](int32_t i, OvlRec &r) -> bool {
 		const int32_t first = (int32_t)(ZY[i] >> 32), cnt = (int32_t)ZY[i], last = first + cnt - 1;
 		const int32_t span0 = (int32_t)(BY[first] >> 32 & 0xff);
 		const uint32_t rev = (uint32_t)(BX[first] >> 63), rid = (uint32_t)(BX[first] << 1 >> 33);
@@ -1410,11 +1498,11 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 			OvlRec c;
 			c.rev = rev, c.qname = rid, c.qs = (uint32_t)first, c.qe = (uint32_t)cnt, c.tname = (uint32_t)(ZX[i] >> 32), c.ts = (uint32_t)ZX[i];
 			c.te = 0, c.match = 0;
-			out[n_out++] = c;
-			continue;
+			r = c;
+			return true;
 		}
 		const uint32_t tid = P.nameless ? 0u : ix.id[rid]; // (re-alignment: `rid` numbers the wanted list, nobody has a name)
-		if (!P.nameless && tid == qid) continue;
+		if (!P.nameless && tid == qid) return false;
 		int32_t mlen = span0, blen = span0; // mm_cal_fuzzy_len (minimap2/hit.c): matching bases, block length
 		for (int32_t m = first + 1; m <= last; ++m) {
 			const int sp = (int)(BY[m] >> 32 & 0xff);
@@ -1423,12 +1511,10 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 			blen += tl > ql ? tl : ql;
 			mlen += tl > sp && ql > sp ? sp : tl < ql ? tl : ql;
 		}
-		OvlRec r;
 		if (P.step2 || P.provisional) { // provisional: local target index and block length in the name fields, judged below / on the host
 			r.rev = rev, r.qname = rid, r.qs = (uint32_t)qs, r.qe = (uint32_t)qe, r.tname = (uint32_t)blen, r.ts = (uint32_t)rs, r.te = (uint32_t)re,
 			r.match = (uint32_t)mlen;
-			out[n_out++] = r;
-			continue;
+			return true;
 		}
 		if (P.mode3) {
 			// nd_fix_bad_ends + nd_update_coors (minimap2/map.c:313-373): anchors at either end of the chain that sit off its
@@ -1471,17 +1557,26 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 			}
 			r.rev = rev, r.qname = rd, r.qs = (uint32_t)q0, r.qe = (uint32_t)q1, r.tname = rid, r.ts = (uint32_t)ts, r.te = (uint32_t)te,
 			r.match = (uint32_t)mlen;
-			out[n_out++] = r;
-			continue;
+			return true;
 		}
-		if (qe - qs < P.minlen) continue;
+		if (qe - qs < P.minlen) return false;
 		if (P.dvt && !dovetail_class((int)rev, (uint32_t)qs, (uint32_t)qe, qlen, (uint32_t)rs, (uint32_t)re, ix.len[rid], P.maxhan1,
-		                             P.maxhan2)) continue;
+		                             P.maxhan2)) return false;
 		r.rev = rev, r.qname = qid, r.qs = (uint32_t)qs, r.qe = (uint32_t)qe, r.tname = tid, r.ts = (uint32_t)rs, r.te = (uint32_t)re,
 		r.match = (uint32_t)mlen;
-		out[n_out++] = r;
+		return true;
+	};
+	for (int32_t base = 0; base < n_u; base += 64) {
+		const int32_t i = n_u - 1 - (base + lane);
+		OvlRec r;
+		const bool keep = i >= 0 && hit(i, r);
+		const unsigned long long km = __ballot(keep);
+		if (keep) out[n_out + (uint32_t)__popcll(km & ((1ULL << lane) - 1))] = r;
+		n_out += (uint32_t)__popcll(km);
 	}
-	if (P.step2 && !P.provisional) {
+	sync_wave();
+	K5_TICK(6);
+	if (P.step2 && !P.provisional && lane == 0) {
 		// worker_for with the re-alignment switched off (--mode 0, minimap2/map.c:988-1031): the first hit of a target carries
 		// the verdict of that target -- the match count of a dovetail hit, 3 = the query looks contained -- later hits of the
 		// same target are marked 1 and count only when they are nearly as long; two contained verdicts end the marking.
@@ -1522,7 +1617,7 @@ __global__ void hits_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_read
 		}
 		n_out = n10;
 	}
-	n_rec[rl] = n_out, n_chain[rl] = (uint32_t)n_u;
+	if (lane == 0) n_rec[rl] = n_out, n_chain[rl] = (uint32_t)n_u;
 }
 
 void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, const uint64_t *ax, const uint64_t *ay, const IndexDev &ix,
@@ -1530,8 +1625,19 @@ void launch_hits(const uint64_t *r_aoff, uint32_t n_reads, uint32_t read_base, c
                  uint64_t *bx, uint64_t *by, uint64_t *wx, uint64_t *wy, uint32_t *tables, void *stacks, const uint32_t *n_end,
                  OvlRec *recs, uint32_t *n_rec, uint32_t *n_chain, OvlRec10 *recs10, uint64_t *cx, uint64_t *cy, uint32_t *n_ca, hipStream_t s)
 {
-	if (n_reads) ND_LAUNCH(hits_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
-	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain, recs10, cx, cy, n_ca);
+	static const bool want_prof = getenv("NDGPU_K5_PROF") != nullptr;
+	unsigned long long *prof = nullptr;
+	if (want_prof && n_reads && hipMalloc((void**)&prof, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(prof, 0, 16 * sizeof(unsigned long long), s);
+	if (n_reads) ND_LAUNCH(hits_kernel, dim3(n_reads), dim3(64), 0, s, r_aoff, n_reads, read_base, ax, ay, ix, q, P, f, p,
+	                                v, t, u, bx, by, wx, wy, tables, (SortJob*)stacks, n_end, recs, n_rec, n_chain, recs10, cx, cy, n_ca, prof);
+	if (prof) {
+		unsigned long long h[16];
+		(void)hipStreamSynchronize(s);
+		(void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+		(void)hipFree(prof);
+		static const char *name[7] = {"heap sort of chain ends", "backtrack", "copy chains", "sort chains by x", "hash keys", "sort by hash", "records"};
+		for (int i = 0; i < 7; ++i) fprintf(stderr, "[k5 prof] %-26s sum %9.3f ms  longest read %8.3f ms\n", name[i], h[2 * i] * 1e-5, h[2 * i + 1] * 1e-5);
+	}
 }
 
 __global__ void compact_anchors_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, const uint64_t *__restrict__ cx,
