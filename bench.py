@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="consensus stage only, on analytically derived piles")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N > 1: every rank computes the mirror jobs it needs itself instead of taking them from the rank that owns them "
+                         "(nextdenovo_amd/stage.py: Exchange)")
     ap.add_argument("--analytic-piles", action="store_true",
                     help="run the overlap stage but feed the consensus stage with piles derived from the true read positions")
     return ap.parse_args(argv)
@@ -358,9 +361,16 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # ("nccl" IS RCCL on ROCm.  NDGPU_BENCH_DIST_BACKEND=gloo is the test hook of tests/test_bench_cpu.py: main() itself, N = 2, on
+        # a machine without a GPU)
+        dist_backend = os.environ.get("NDGPU_BENCH_DIST_BACKEND", "nccl")
+        if dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(dist_backend)
 
+    dist_dev = "cuda" if (dist is None or os.environ.get("NDGPU_BENCH_DIST_BACKEND", "nccl") == "nccl") else "cpu"
     analytic = args.analytic_piles or args.no_overlap
     if args.host_threads <= 0:  # the ranks of one node share its cores
         args.host_threads = max(8, (os.cpu_count() or 8) // max(1, world))
@@ -370,7 +380,14 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     db = api.ReadDB(words, word_off, lens)  # every read, both strands, resident in HBM from here on
-    sh = stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k)
+    exchange = None
+    if world > 1 and not args.no_exchange:
+        # the ranks of this node hand seed x seed job records to one another through a node-local directory, as the reference hands
+        # the .ovl file of a pair to its second reader with `ln -sf` (nextDenovo:455-459): a pair is mapped once per node
+        xdir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "ndgpu_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+        exchange = stage.Exchange(xdir, rank)
+    sh = stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k,
+                     exchange=exchange)
     a_piles = a_recs = a_off = None
     if analytic:  # piles from the true read positions, for the seeds of this rank's seed file
         a_piles = synth.build_piles(rs, seed_cutoff=1000, seed_ids=[int(i) for i in sh.seed_ids[my_file]])
@@ -381,7 +398,8 @@ def main():
     def sync():
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if dist_dev == "cuda":
+                torch.cuda.synchronize()
 
     def step():
         if args.no_overlap:
@@ -423,9 +441,9 @@ def main():
     total_bases, max_dt, total_seeds = bases, dt, n_ok
     per_rank = None
     if dist is not None:
-        total_bases, max_dt = reduce_over_ranks(dist, torch, bases, dt, "cuda", n_ok)
+        total_bases, max_dt = reduce_over_ranks(dist, torch, bases, dt, dist_dev, n_ok)
         total_seeds = reduce_over_ranks.seeds
-        per_rank = gather_rank_stats(dist, torch, "cuda", [dt, sh.stats.get("overlap_s", 0.0) if not args.no_overlap else 0.0,
+        per_rank = gather_rank_stats(dist, torch, dist_dev, [dt, sh.stats.get("overlap_s", 0.0) if not args.no_overlap else 0.0,
                                                            (sh.stats.get("sort_s", 0.0) + sh.stats.get("assemble_s", 0.0)) if not args.no_overlap else 0.0,
                                                            cns_wall[0], float(st["piles"]), float(st["path_items"])])
 
@@ -530,6 +548,15 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = per_rank   # over the K timed steps; rank r = seed file r
+        if world > 1:
+            pl = stage.plan(n_files, len(sh.part_ids))
+            out["config"]["raw_align_jobs"] = {
+                "exchange": exchange is not None,
+                "per_rank_jobs_computed": [r_["jobs_computed_with_exchange" if exchange is not None else "jobs_computed_alone"] for r_ in pl],
+                "per_rank_index_builds": [r_["index_builds_with_exchange" if exchange is not None else "index_builds_alone"] for r_ in pl],
+                "rank0_exchange": dict(exchange.stats) if exchange is not None else None,
+                "note": "a seed x seed pair is mapped once per node and handed over through /dev/shm (nextDenovo:455-459 does it with "
+                        "`ln -sf`); --no-exchange: every rank maps the mirrors it needs itself"}
         if not args.no_overlap:
             q_bases = int(lens.sum())
             o_ms = sh.stats["overlap_s"] / args.steps * 1e3
@@ -568,6 +595,9 @@ def main():
     db.close()
     if dist is not None:
         dist.barrier()
+        if exchange is not None and rank == 0:   # (every rank is past its last read)
+            import shutil
+            shutil.rmtree(exchange.dir, ignore_errors=True)
         dist.destroy_process_group()
 
 

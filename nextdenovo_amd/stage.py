@@ -8,8 +8,19 @@ read.  `Shard.piles(i)` computes exactly the jobs whose `.ovl` files the sort of
 (i, part j), (i, seed t >= i), and the mirrors (t < i, seed i) that the reference reaches through `ln -sf`
 (nextDenovo:459) -- hands them to `ndgpu_ovl_sort` in job order and applies the pile admission of lib/nextcorrect.py:92-143.
 No rank needs anything another rank computed: bench.py --gpus N and the multi-GPU tests give seed file r to rank r.
+
+Computing every mirror on the rank that needs it maps each seed x seed pair twice across the node (N jobs and N index builds per
+rank instead of the (N + 1) / 2 jobs the job matrix holds per seed file).  The reference maps a pair once and hands the file over
+with `ln -sf` (nextDenovo:455-459); `Shard(exchange=Exchange(dir, rank))` is that hand-over for ranks of one node: every
+seed x seed job has ONE owner (`owner_of`: the job (i, t) belongs to rank i when i + t is odd or i == t, to rank t otherwise, so
+every rank owns about (N + 1) / 2 jobs), the owner writes the job's records into a node-local directory (/dev/shm), the other
+rank that needs them reads them there.  Orientation is the reference's (target = seed file i, query = seed file t) whoever
+computes the job, so the records are the same bytes either way; a file that does not arrive in time is computed locally.
 """
 from __future__ import annotations
+
+import os
+import time
 
 import numpy as np
 
@@ -66,13 +77,73 @@ def deal(lens: np.ndarray, read_cutoff: int, seed_cutoff: int, n_seed_files: int
     return kept, seed_files, parts
 
 
+def owner_of(i: int, t: int) -> int:
+    """The rank that computes the seed x seed job (target seed file i, query seed file t), i <= t."""
+    return i if (i == t or (i + t) % 2 == 1) else t
+
+
+def plan(n_seed_files: int, n_part_files: int = 0):
+    """Per rank (= seed file): the raw_align jobs it computes and the index builds they need, without and with the hand-over --
+    what bounds the overlap stage's share of a multi-GPU step.  Jobs cost about the same (1 / N^2 of the pair space each)."""
+    rows = []
+    for r in range(n_seed_files):
+        needs = [j for j in job_matrix(n_seed_files, n_part_files) if j[1] == r or (j[2] == "seed" and j[3] == r)]
+        own = [j for j in needs if j[2] == "part" or owner_of(j[1], j[3]) == r]
+        rows.append({"rank": r, "jobs_needed": len(needs), "jobs_computed_alone": len(needs), "index_builds_alone": len({j[1] for j in needs}),
+                     "jobs_computed_with_exchange": len(own), "index_builds_with_exchange": len({j[1] for j in own}),
+                     "jobs_received": len(needs) - len(own)})
+    return rows
+
+
+class Exchange:
+    """Node-local hand-over of seed x seed job records between the ranks of one node (one directory, one file per job and step)."""
+
+    def __init__(self, directory: str, rank: int, timeout_s: float = 120.0):
+        self.dir, self.rank, self.timeout_s, self.step = directory, rank, timeout_s, 0
+        os.makedirs(directory, exist_ok=True)
+        self.stats = {"sent": 0, "received": 0, "recomputed": 0, "wait_s": 0.0}
+
+    def _path(self, step, k):
+        return os.path.join(self.dir, "step%06d.job%05d.npy" % (step, k))
+
+    def begin_step(self):
+        self.step += 1
+        for f in os.listdir(self.dir):   # this rank's files of two steps ago: every reader is past them
+            if f.endswith(".r%d.npy" % self.rank) and int(f[4:10]) + 2 <= self.step:
+                try:
+                    os.unlink(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+
+    def put(self, k, recs):
+        final = self._path(self.step, k)[:-4] + ".r%d.npy" % self.rank
+        tmp = final + ".tmp"
+        with open(tmp, "wb") as f:
+            np.save(f, recs)
+        os.rename(tmp, final)   # (atomic: a reader sees the whole file or none)
+        self.stats["sent"] += 1
+
+    def get(self, k, owner):
+        """The records of job k as rank `owner` wrote them, or None after the timeout."""
+        path = self._path(self.step, k)[:-4] + ".r%d.npy" % owner
+        t0 = time.perf_counter()
+        while not os.path.exists(path):
+            if time.perf_counter() - t0 > self.timeout_s:
+                self.stats["wait_s"] += time.perf_counter() - t0
+                return None
+            time.sleep(0.0005)
+        self.stats["wait_s"] += time.perf_counter() - t0
+        self.stats["received"] += 1
+        return np.load(path)
+
+
 class Shard:
     """One read set (2-bit words as in a .2bit file, read i at words[word_off[i]], lens[i] bases; read id = index) and
     the parameters of the stage."""
 
     def __init__(self, words, word_off, lens, preset="ava-ont", seed_cutoff=1000, read_cutoff=500, n_seed_files=1, sort_k=40,
                  flank=300, min_len_seed=None, min_len_aln=500, max_cov_aln=130, min_cov_seed=10, blacklist=True, occ=None,
-                 backend=None):
+                 backend=None, exchange=None):
         self.words = np.ascontiguousarray(words, dtype=np.uint32)
         self.word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
         self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
@@ -89,6 +160,7 @@ class Shard:
         self.ovl_stats = None
         # tests plug a CPU backend built from oracle/ here (same two calls); the product has the device backend only
         self.backend = backend if backend is not None else DeviceBackend(self.opt)
+        self.exchange = exchange   # None: every job this seed file needs is computed here
 
     def _set(self, ids):
         return overlap.ReadSet(ids, self.lens[ids], self.words, self.word_off[ids])
@@ -104,12 +176,33 @@ class Shard:
         t0 = time.perf_counter()
         out = []
         be = self.backend
+        ex = self.exchange
+        if ex is not None:
+            ex.begin_step()
         try:
-            for k, tgt, kind, j, dual in self.jobs_of(i):
+            jobs = self.jobs_of(i)
+
+            def compute(k, tgt, kind, j, dual):
                 query = self._set(self.part_ids[j] if kind == "part" else self.seed_ids[j])
-                out.append(be.map(tgt, self._set(self.seed_ids[tgt]), query, minimap2_nd.IDX_BATCH if kind == "part" else self.seed_batch, dual))
-                if tgt != i:  # a mirror job: that index is not needed again by this shard
+                r = be.map(tgt, self._set(self.seed_ids[tgt]), query, minimap2_nd.IDX_BATCH if kind == "part" else self.seed_batch, dual)
+                if tgt != i:  # that index is not needed again by this shard
                     be.release(tgt)
+                return r
+            got = {}
+            # the jobs this rank owns first (the others wait for them), then what the others hand over
+            for k, tgt, kind, j, dual in jobs:
+                if ex is None or kind == "part" or owner_of(tgt, j) == i:
+                    got[k] = compute(k, tgt, kind, j, dual)
+                    if ex is not None and kind == "seed" and tgt != j:
+                        ex.put(k, got[k])
+            for k, tgt, kind, j, dual in jobs:
+                if k not in got:
+                    r = ex.get(k, owner_of(tgt, j))
+                    if r is None:   # the owner is late or gone: the job is computed here, the step goes on
+                        ex.stats["recomputed"] += 1
+                        r = compute(k, tgt, kind, j, dual)
+                    got[k] = r
+            out = [got[k] for k, *_ in jobs]
         finally:
             be.release(i, keep_stats=True)
             self.ovl_stats = getattr(be, "last_stats", None)

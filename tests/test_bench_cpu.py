@@ -45,3 +45,53 @@ def test_bench_line_on_a_tiny_genome(monkeypatch):
     # the timed step followed a warm-up step: nothing was (re)allocated in it
     assert d["allocations"]["in_step"] == 0 and d["overlap"]["pool_calls"]["n"] == 0
     assert d["counters"]["piles"] == d["config"]["piles_rank0"] and d["counters"]["lq_declined"] == 0
+
+
+def _rank_main(rank, port, q):
+    """bench.main() of one rank of two, libraries = the interpreted builds, collectives over gloo."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      NDGPU_BENCH_DIST_BACKEND="gloo", NDGPU_DEVICE="0", NDGPU_CONTEXTS="1")
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "simt"))
+    sys.path.insert(0, ROOT)
+    import build_simt
+    from nextdenovo_amd import api, overlap
+    overlap._lib = overlap._bind(C.CDLL(build_simt.build_overlap()))
+    api._LIB = api._bind(C.CDLL(build_simt.build()))
+    sys.argv = ["bench.py", "--gpus", "2", "--genome-size", "30000", "--depth", "14", "--steps", "1", "--warmup", "1"]
+    import bench
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    q.put((rank, [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]))
+
+
+def test_bench_line_of_two_ranks(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), on
+    the CPU: rank 0 prints the ONE line, whole-job value, strong scaling, per-rank stage times; the seed x seed pair of the two seed
+    files is mapped by its owner only and handed over."""
+    import socket
+
+    import torch.multiprocessing as mp
+    import build_simt
+    build_simt.build(), build_simt.build_overlap()   # (not twice at the same time in the children)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=1200) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[1] == [] and len(res[0]) == 1
+    d = json.loads(res[0][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["seed_files"] == 2
+    assert len(d["per_rank"]) == 2 and all(r["piles"] > 0 for r in d["per_rank"])
+    ra = d["config"]["raw_align_jobs"]
+    assert ra["exchange"] is True and ra["per_rank_jobs_computed"] == [2, 1] and ra["rank0_exchange"]["sent"] == 2   # (warm-up + 1 step)
+    assert ra["rank0_exchange"]["recomputed"] == 0

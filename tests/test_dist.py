@@ -22,8 +22,9 @@ def _free_port():
     return p
 
 
-def _correct_file(i, n_files):
-    """{seed id: (len, md5)} of seed file i of n_files of the shared read set, CPU backends."""
+def _correct_file(i, n_files, exchange_dir=None):
+    """{seed id: (len, md5)} of seed file i of n_files of the shared read set, CPU backends.  With `exchange_dir` the ranks hand
+    the seed x seed jobs over (stage.Exchange): every pair is mapped by one rank only."""
     import ctypes as C
 
     import numpy as np
@@ -38,7 +39,8 @@ def _correct_file(i, n_files):
     rs = synth.simulate_reads(g, 22, "ont", seed=43, mu=8.0, sigma=0.35)
     words, word_off, lens = synth.pack_db(rs)
     sh = stage.Shard(words, word_off, lens, preset="ava-ont", seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=17,
-                     blacklist=False, backend=stage_util.OracleBackend(olib, "ava-ont"))
+                     blacklist=False, backend=stage_util.OracleBackend(olib, "ava-ont"),
+                     exchange=stage.Exchange(exchange_dir, i, timeout_s=300.0) if exchange_dir else None)
     sub, off, seeds, _n_bl = sh.piles(i)
     out = {}
     for p in range(seeds.size):
@@ -47,10 +49,12 @@ def _correct_file(i, n_files):
         ln, ide, seq = util.call_correct(fn, fr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal, max_lq=min(en[0] // 2, 10000),
                                                      read_type=1, fast=0, split=0))
         out[int(seeds[p])] = (int(ln), hashlib.md5(seq).hexdigest())
+    if exchange_dir:
+        _correct_file.exchange_stats = dict(sh.exchange.stats)
     return out, [int(x) for x in sh.seed_ids[i]], sh.jobs_of(i)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange_dir=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -61,12 +65,12 @@ def _worker(rank, world, port, q):
     import bench
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_files, mine = bench.shard_of_rank(world, rank, 0, 0)
-    recs, seed_ids, jobs = _correct_file(mine, n_files)
+    recs, seed_ids, jobs = _correct_file(mine, n_files, exchange_dir)
     bases = sum(ln for ln, _ in recs.values() if ln > 4)
     total, tmax = bench.reduce_over_ranks(dist, torch, bases, 1.0 + rank, "cpu", len(recs))
     per = bench.gather_rank_stats(dist, torch, "cpu", [1.0 + rank, 0.5, 0.25, 0.125, float(len(recs)), float(bases)])
     assert len(per) == world and per[rank]["piles"] == len(recs) and per[1 - rank]["wall_s"] == 2.0 - rank
-    q.put((rank, recs, seed_ids, jobs, bases, total, tmax, bench.reduce_over_ranks.seeds))
+    q.put((rank, recs, seed_ids, jobs, bases, total, tmax, bench.reduce_over_ranks.seeds) + ((_correct_file.exchange_stats,) if exchange_dir else ()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,3 +103,36 @@ def test_two_ranks_share_one_read_set(host_harness, oracle_lib):
     both = dict(rec0)
     both.update(rec1)
     assert both == single and len(single) >= 6 and sum(1 for ln, _ in single.values() if ln > 1000) >= 6
+
+
+def test_two_ranks_hand_the_mirror_job_over(host_harness, oracle_lib, tmp_path):
+    """nextDenovo:455-459: the reference maps a seed x seed pair once and links the file for its second reader.  With
+    stage.Exchange rank 0 owns (0, seed 0) and (0, seed 1), writes the latter into the node-local directory, rank 1 computes only
+    (1, seed 1) and reads the mirror: the records of both ranks are those of the run in which every rank maps everything it needs."""
+    import torch.multiprocessing as mp
+
+    from nextdenovo_amd import stage
+    sys.path.insert(0, HERE)
+    assert [stage.owner_of(0, 0), stage.owner_of(0, 1), stage.owner_of(1, 1)] == [0, 0, 1]
+    pl = stage.plan(8)
+    assert max(r["jobs_computed_with_exchange"] for r in pl) == 5 and sum(r["jobs_computed_with_exchange"] for r in pl) == 36
+    assert all(r["jobs_computed_alone"] == 8 for r in pl)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    xdir = str(tmp_path / "xchg")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, xdir)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, rec0, *_r0, x0), (_, rec1, *_r1, x1) = res
+    assert x0["sent"] == 1 and x0["received"] == 0 and x1["received"] == 1 and x1["sent"] == 0 and x0["recomputed"] == x1["recomputed"] == 0
+    single = {}
+    for i in range(2):
+        single.update(_correct_file(i, 2)[0])
+    both = dict(rec0)
+    both.update(rec1)
+    assert both == single and len(single) >= 6
