@@ -278,6 +278,8 @@ struct DeviceAligner::State {
     DevBuf<AlnTask> d_tasks;
     DevBuf<AlnOut> d_outs;
     DevBuf<uint64_t> d_trace;
+    DevBuf<uint64_t> d_wtrace;  // wide-band alignments (K7w): trace rows and their min_k -- members, not locals of run_wide: a local
+    DevBuf<int32_t> d_wmink;    // buffer was a hipMalloc + hipFree per call, and hipFree waits for every stream of the device
     DevBuf<int32_t> d_v, d_ids;
     std::vector<int32_t> order;
     std::vector<uint32_t> order_cls;
@@ -424,7 +426,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     NDGPU_NAME(h_ops) NDGPU_NAME(h_outs) NDGPU_NAME(up) NDGPU_NAME(down)
     NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec)
     NDGPU_NAME(d_lq_out)
-    NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v)
+    NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v) NDGPU_NAME(d_wtrace) NDGPU_NAME(d_wmink)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
     NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
     NDGPU_NAME(d_cell_start) NDGPU_NAME(d_cell_len) NDGPU_NAME(d_cell_bpp) NDGPU_NAME(d_cell_blink) NDGPU_NAME(d_ent_pp)
@@ -531,7 +533,7 @@ void DeviceAligner::release_memory() {
 #define NDGPU_REL(x) S.x.release();
     NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec)
     NDGPU_REL(d_lq_out)
-    NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v)
+    NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v) NDGPU_REL(d_wtrace) NDGPU_REL(d_wmink)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
     NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
     NDGPU_REL(d_cell_start) NDGPU_REL(d_cell_len) NDGPU_REL(d_cell_bpp) NDGPU_REL(d_cell_blink) NDGPU_REL(d_ent_pp)
@@ -575,7 +577,7 @@ void DeviceAligner::level_buffers(int drivers) {
         try {
 #define NDGPU_LVL(x) lvl(S.x, #x[0] == 'd');
             NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_out)
-            NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v)
+            NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v) NDGPU_LVL(d_wtrace) NDGPU_LVL(d_wmink)
             NDGPU_LVL(d_ids) NDGPU_LVL(d_reads) NDGPU_LVL(d_piles) NDGPU_LVL(d_read_pile) NDGPU_LVL(d_acc) NDGPU_LVL(d_tags)
             NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
             NDGPU_LVL(d_cell_start) NDGPU_LVL(d_cell_len) NDGPU_LVL(d_cell_bpp) NDGPU_LVL(d_cell_blink) NDGPU_LVL(d_ent_pp)
@@ -866,8 +868,8 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
     const bool ops_to_host = jobs != nullptr;  // the device main phase keeps ops in HBM
     // process in groups bounded by the trace budget; wide rows are band-cap sized
     size_t at = 0;
-    DevBuf<uint64_t> trace;
-    DevBuf<int32_t> mink;
+    DevBuf<uint64_t> &trace = S.d_wtrace;
+    DevBuf<int32_t> &mink = S.d_wmink;
     while (at < ids.size()) {
         size_t take = 0;
         uint64_t tw = 0, mr = 0, vw = 0;
@@ -902,11 +904,11 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
         S.h2d(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), st);
         launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
         launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
+        for (size_t i = 0; i < take; i++) S.d2h(&S.h_outs.p[ids[at + i]], S.d_outs.p + ids[at + i], sizeof(AlnOut), st);
         S.sync_drain(st);
         for (size_t i = 0; i < take; i++) {
             const int32_t id = ids[at + i];
             const AlnTask &t = S.tasks[id];
-            HIP_CHECK(hipMemcpy(&S.h_outs.p[id], S.d_outs.p + id, sizeof(AlnOut), hipMemcpyDeviceToHost));
             if (ops_to_host)
                 HIP_CHECK(hipMemcpy(S.h_ops.p + t.ops_off, S.d_ops.p + t.ops_off,
                                     ((uint64_t)(t.ops_cap + 15) / 16 + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -31,69 +31,135 @@
 
 namespace ndovl {
 
-// ---- caching allocator (ovl_pool.h) ----
+// ---- device block pool (ovl_pool.h) ----
+// Slabs taken from the driver (hipMalloc) and carved up here: best-fit free ranges, split on allocation, merged with their
+// neighbours on release.  Until round 4 the pool cached whole blocks by size class and gave back to the driver what exceeded 1.25 x
+// its working set: every query batch asks for slightly different sizes, so a genome-scale job went to the driver 2,205 times a
+// step -- 20 s of a 27 s overlap stage on a device whose memory the consensus contexts mostly hold (config 3, profiles/r04), and
+// each hipFree waits for every stream of the device.  A range allocator serves any size from what it holds: in steady state no
+// step goes to the driver at all.
 namespace {
 std::atomic<int> g_last_error{0};  // why the last failed entry point failed: 1 = out of device memory, 2 = anything else
 std::mutex g_pool_mu;
-std::multimap<size_t, void*> g_pool_free;        // size class -> block
-std::unordered_map<void*, size_t> g_pool_size;   // live + cached blocks -> size class
-size_t g_pool_cached = 0;
-size_t g_pool_live = 0, g_pool_peak = 0;         // bytes handed out now / the most that ever were
+struct Range { size_t size; int slab; };
+std::map<uintptr_t, Range> g_free_at;                  // free ranges by address
+std::multimap<size_t, uintptr_t> g_free_by_size;       // and by size (best fit)
+std::unordered_map<uintptr_t, Range> g_live_at;        // handed-out ranges
+struct Slab { void *base; size_t size; size_t live; };
+std::vector<Slab> g_slabs;                             // (released slabs keep their index: base == nullptr)
+size_t g_pool_slab_bytes = 0, g_pool_live = 0, g_pool_peak = 0;
 std::atomic<unsigned long long> g_pool_calls{0}, g_pool_ns{0};  // hipMalloc / hipFree calls the pool made and their wall time
 struct PoolTimer {
 	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
 	~PoolTimer() { g_pool_calls++; g_pool_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
 };
-size_t size_class(size_t b)
+constexpr size_t kPoolAlign = 512;
+void erase_by_size(size_t size, uintptr_t at)
 {
-	if (b < 4096) return 4096;
-	size_t p = 4096;
-	while (p * 2 <= b) p *= 2;              // p <= b < 2p
-	const size_t step = p / 8;
-	return p + (b - p + step - 1) / step * step;
+	auto r = g_free_by_size.equal_range(size);
+	for (auto it = r.first; it != r.second; ++it)
+		if (it->second == at) { g_free_by_size.erase(it); return; }
+}
+void add_free(uintptr_t at, size_t size, int slab) // merges with the free neighbours of the same slab
+{
+	auto nx = g_free_at.lower_bound(at);
+	if (nx != g_free_at.end() && nx->second.slab == slab && at + size == nx->first) {
+		size += nx->second.size;
+		erase_by_size(nx->second.size, nx->first);
+		nx = g_free_at.erase(nx);
+	}
+	if (nx != g_free_at.begin()) {
+		auto pv = std::prev(nx);
+		if (pv->second.slab == slab && pv->first + pv->second.size == at) {
+			at = pv->first;
+			size += pv->second.size;
+			erase_by_size(pv->second.size, pv->first);
+			g_free_at.erase(pv);
+		}
+	}
+	g_free_at[at] = Range{size, slab};
+	g_free_by_size.emplace(size, at);
+}
+size_t release_idle_slabs() // hipFree of every slab nothing lives in; returns the bytes released
+{
+	size_t freed = 0;
+	for (size_t k = 0; k < g_slabs.size(); ++k) {
+		Slab &sl = g_slabs[k];
+		if (!sl.base || sl.live) continue;
+		const uintptr_t at = (uintptr_t)sl.base;
+		auto it = g_free_at.find(at);
+		if (it == g_free_at.end() || it->second.size != sl.size) continue; // (cannot happen: an idle slab is one free range)
+		erase_by_size(it->second.size, at);
+		g_free_at.erase(it);
+		const PoolTimer timer;
+		(void)hipFree(sl.base);
+		g_pool_slab_bytes -= sl.size;
+		freed += sl.size;
+		sl.base = nullptr;
+	}
+	return freed;
 }
 }
 
 void *pool_alloc(size_t bytes)
 {
-	const size_t c = size_class(bytes);
+	const size_t c = (std::max<size_t>(bytes, 1) + kPoolAlign - 1) / kPoolAlign * kPoolAlign;
 	if (fault_injected()) device_check((int)hipErrorOutOfMemory, "pool_alloc (injected)");
-	{
-		std::lock_guard<std::mutex> g(g_pool_mu);
-		auto it = g_pool_free.find(c);
-		if (it != g_pool_free.end()) {
-			void *p = it->second;
-			g_pool_free.erase(it);
-			g_pool_cached -= c;
-			g_pool_live += c;
-			if (g_pool_live > g_pool_peak) g_pool_peak = g_pool_live;
-			return p;
-		}
-	}
-	void *p = nullptr;
-	const PoolTimer timer;
-	hipError_t e = hipMalloc(&p, c);
-	if (e != hipSuccess) { // give the cache back and retry once
-		pool_trim();
-		e = hipMalloc(&p, c);
-	}
-	if (e != hipSuccess) {
-		fprintf(stderr, "[ndgpu_overlap] hipMalloc of %zu bytes failed: %s\n", c, hipGetErrorString(e));
-		g_last_error = e == hipErrorOutOfMemory ? 1 : 2;
-		(void)hipGetLastError();
-		throw std::runtime_error("hipMalloc");
-	}
 	std::lock_guard<std::mutex> g(g_pool_mu);
-	g_pool_size[p] = c;
+	auto it = g_free_by_size.lower_bound(c);
+	if (it == g_free_by_size.end()) {
+		// a new slab: large enough that the requests to come are carved out of it, not bigger than the device can give
+		// (under the kernel interpreter of tests/simt a slab is the request itself unless a slab size is given: the interpreter's
+		// allocations are exact-size host blocks, which is what lets AddressSanitizer see a kernel read past a buffer's end)
+#ifdef SIMT_EMULATION
+		const size_t unit = getenv("NDGPU_OVL_SLAB_MB") ? (size_t)atol(getenv("NDGPU_OVL_SLAB_MB")) << 20 : 0;
+#else
+		const size_t unit = getenv("NDGPU_OVL_SLAB_MB") ? (size_t)atol(getenv("NDGPU_OVL_SLAB_MB")) << 20 : (size_t)8 << 30;
+#endif
+		size_t want = std::max(c, unit);
+		void *p = nullptr;
+		hipError_t e;
+		{
+			const PoolTimer timer;
+			e = hipMalloc(&p, want);
+		}
+		if (e != hipSuccess && want > c) { // the device is short: what this request needs and no more
+			(void)hipGetLastError();
+			want = c;
+			const PoolTimer timer;
+			e = hipMalloc(&p, want);
+		}
+		if (e != hipSuccess) { // give idle slabs back and try once more
+			(void)hipGetLastError();
+			if (release_idle_slabs()) {
+				const PoolTimer timer;
+				e = hipMalloc(&p, want);
+			}
+		}
+		if (e != hipSuccess) {
+			fprintf(stderr, "[ndgpu_overlap] hipMalloc of %zu bytes failed: %s (pool: %zu bytes in slabs, %zu live)\n", want, hipGetErrorString(e),
+			        g_pool_slab_bytes, g_pool_live);
+			g_last_error = e == hipErrorOutOfMemory ? 1 : 2;
+			(void)hipGetLastError();
+			throw std::runtime_error("hipMalloc");
+		}
+		g_slabs.push_back(Slab{p, want, 0});
+		g_pool_slab_bytes += want;
+		add_free((uintptr_t)p, want, (int)g_slabs.size() - 1);
+		it = g_free_by_size.lower_bound(c);
+	}
+	const uintptr_t at = it->second;
+	const Range r = g_free_at[at];
+	g_free_by_size.erase(it);
+	g_free_at.erase(at);
+	if (r.size > c) add_free(at + c, r.size - c, r.slab);
+	g_live_at[at] = Range{c, r.slab};
+	g_slabs[(size_t)r.slab].live += c;
 	g_pool_live += c;
 	if (g_pool_live > g_pool_peak) g_pool_peak = g_pool_live;
-	return p;
+	return (void*)at;
 }
 
-// What the cache may hold: blocks come back in many size classes (every query batch asks for slightly different sizes),
-// and a cache that keeps them all ends up owning the whole HBM while the consensus contexts starve.  The cache is therefore
-// bounded by the library's own working set: live + cached bytes stay below 1.25 x the most that was ever live at once
-// (and below NDGPU_OVL_POOL_GB if that is set); what comes back beyond it is freed at once.
 int last_error_take() { return g_last_error.exchange(0); }
 void note_oom() { g_last_error = 1; }
 
@@ -118,39 +184,34 @@ bool fault_injected()
 	return ++n_ops == target;
 }
 
-static size_t pool_cap()
-{
-	static const size_t cap = getenv("NDGPU_OVL_POOL_GB") ? (size_t)(atof(getenv("NDGPU_OVL_POOL_GB")) * (double)(1ull << 30)) : ~(size_t)0;
-	return cap;
-}
-
 void pool_free(void *p)
 {
 	if (!p) return;
 	std::lock_guard<std::mutex> g(g_pool_mu);
-	auto it = g_pool_size.find(p);
-	if (it == g_pool_size.end()) { (void)hipFree(p); return; }
-	g_pool_live -= it->second;
-	if (g_pool_live + g_pool_cached + it->second > g_pool_peak + g_pool_peak / 4 || g_pool_cached + it->second > pool_cap()) {
-		const PoolTimer timer;
-		(void)hipFree(p);
-		g_pool_size.erase(it);
-		return;
-	}
-	g_pool_free.emplace(it->second, p);
-	g_pool_cached += it->second;
+	auto it = g_live_at.find((uintptr_t)p);
+	if (it == g_live_at.end()) { (void)hipFree(p); return; }
+	const Range r = it->second;
+	g_live_at.erase(it);
+	g_pool_live -= r.size;
+	g_slabs[(size_t)r.slab].live -= r.size;
+	add_free((uintptr_t)p, r.size, r.slab);
+	// (NDGPU_OVL_POOL_GB: a bound on what the pool keeps from the driver -- idle slabs beyond it go back)
+	static const size_t cap = getenv("NDGPU_OVL_POOL_GB") ? (size_t)(atof(getenv("NDGPU_OVL_POOL_GB")) * (double)(1ull << 30)) : ~(size_t)0;
+	if (g_pool_slab_bytes > cap) (void)release_idle_slabs();
+#ifdef SIMT_EMULATION
+	if (!getenv("NDGPU_OVL_SLAB_MB")) (void)release_idle_slabs();  // (exact-size blocks go back when they are free: use-after-free is seen)
+#endif
 }
 
 void pool_trim()
 {
 	std::lock_guard<std::mutex> g(g_pool_mu);
-	for (auto &kv : g_pool_free) { (void)hipFree(kv.second); g_pool_size.erase(kv.second); }
-	g_pool_free.clear();
-	g_pool_cached = 0;
+	(void)release_idle_slabs();
 }
 
-size_t pool_cached_bytes() { std::lock_guard<std::mutex> g(g_pool_mu); return g_pool_cached; }
-void pool_bytes(uint64_t out[3]) { std::lock_guard<std::mutex> g(g_pool_mu); out[0] = g_pool_live, out[1] = g_pool_cached, out[2] = g_pool_peak; }
+// what the pool holds beyond what is in use (an upper bound of what pool_trim() can give back: idle slabs only)
+size_t pool_cached_bytes() { std::lock_guard<std::mutex> g(g_pool_mu); return g_pool_slab_bytes - g_pool_live; }
+void pool_bytes(uint64_t out[3]) { std::lock_guard<std::mutex> g(g_pool_mu); out[0] = g_pool_live, out[1] = g_pool_slab_bytes - g_pool_live, out[2] = g_pool_peak; }
 void pool_calls(uint64_t out[2], int reset) { out[0] = g_pool_calls.load(), out[1] = g_pool_ns.load(); if (reset) g_pool_calls = 0, g_pool_ns = 0; }
 
 // (a device filled to the brim makes the runtime's own allocations fail too -- launch arguments, staging: "out of memory" may

@@ -22,6 +22,7 @@ def test_bench_line_on_a_tiny_genome(monkeypatch):
     import build_simt
     from nextdenovo_amd import api, overlap
     monkeypatch.setenv("NDGPU_CONTEXTS", "2")
+    monkeypatch.setenv("NDGPU_OVL_SLAB_MB", "64")   # the overlap library's block pool as on the device: slabs, carved up by the library
     monkeypatch.setattr(overlap, "_lib", overlap._bind(C.CDLL(build_simt.build_overlap())))
     monkeypatch.setattr(api, "_LIB", api._bind(C.CDLL(build_simt.build())))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--genome-size", "30000", "--depth", "14", "--steps", "1", "--warmup", "1"])
