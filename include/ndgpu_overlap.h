@@ -287,6 +287,9 @@ typedef struct ndgpu_ovl_aln_opt {
 void ndgpu_ovl_aln_opt_default(ndgpu_ovl_aln_opt *o, int32_t min_chain_score);
 typedef struct ndgpu_ovl_cigar_stats {
 	uint64_t chains, first_pass, second_pass, inversion_tests, inversions, cells, overlaps, inversions_aligned, splits;
+	uint64_t chains_ns, ksw_ns, ksw_ll_ns, total_ns;
+	/* wall time of the call: sketch / seeds / chaining on the device (ndgpu_ovl_map_chains); the ksw_extd2 batches (upload, kernel,
+	 * backtrack, download); the ksw_ll batches; everything (the rest is the host's chain walking, CIGAR joining and filters) */
 	/* chains aligned (pieces of split chains included); extension / gap problems of the first pass; gaps aligned again after a
 	 * z-drop; local alignments of the inversion test; inversions looked at (mm_align1_inv calls); DP cells (query x target) of all
 	 * problems; records out; inversions that were aligned; chains a z-drop split */

@@ -20,6 +20,7 @@
 // Built for the presets nextDenovo uses with raw reads (ava-ont, ava-pb: every chain is kept, MM_F_ALL_CHAINS, no long joins, no
 // splicing, no short-read mode).  The compiled reference aborts on `-x ava-hifi -c` (k = 51), so there is nothing to match there.
 // There is no CPU path: the alignments themselves run on the device or the call fails.
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -33,6 +34,10 @@
 #include <vector>
 
 #include "../../include/ndgpu_overlap.h"
+
+// wall time of the device batches of one ndgpu_ovl_map_cigar call (ndgpu_ovl_cigar_stats: the split the -c timing reports)
+static std::atomic<uint64_t> g_t_ksw_ns{0}, g_t_ll_ns{0};
+
 
 namespace {
 
@@ -837,7 +842,7 @@ int run_tasks(std::vector<Task> &tasks, const Opt &o, const Targets &tg, int thr
     JobList J1;
     for (Task &T : tasks) pose_first(T, o, J1);
     std::vector<ndgpu_ksw_result> res1(J1.jobs.size());
-    if (!J1.jobs.empty() && ndgpu_ksw_extd2_batch(J1.jobs.data(), (int)J1.jobs.size(), res1.data()) != 0) return -1;
+    if (!J1.jobs.empty() && ([&] { const auto t0_ = std::chrono::steady_clock::now(); const int rc_ = ndgpu_ksw_extd2_batch(J1.jobs.data(), (int)J1.jobs.size(), res1.data()); g_t_ksw_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count(); return rc_; }()) != 0) return -1;
     par_for(tasks.size(), threads, [&](size_t i) { judge(tasks[i], o, res1); });
     std::vector<ndgpu_ll_job> L;
     std::vector<Seg *> l_seg;
@@ -853,7 +858,7 @@ int run_tasks(std::vector<Task> &tasks, const Opt &o, const Targets &tg, int thr
                 l_seg.push_back(&s);
             }
     std::vector<ndgpu_ll_result> lres(L.size());
-    if (!L.empty() && ndgpu_ksw_ll_batch(L.data(), (int)L.size(), lres.data()) != 0) {
+    if (!L.empty() && ([&] { const auto t0_ = std::chrono::steady_clock::now(); const int rc_ = ndgpu_ksw_ll_batch(L.data(), (int)L.size(), lres.data()); g_t_ll_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count(); return rc_; }()) != 0) {
         free_results(res1);
         return -1;
     }
@@ -872,7 +877,7 @@ int run_tasks(std::vector<Task> &tasks, const Opt &o, const Targets &tg, int thr
         }
     }
     std::vector<ndgpu_ksw_result> res2(J2.jobs.size());
-    if (!J2.jobs.empty() && ndgpu_ksw_extd2_batch(J2.jobs.data(), (int)J2.jobs.size(), res2.data()) != 0) {
+    if (!J2.jobs.empty() && ([&] { const auto t0_ = std::chrono::steady_clock::now(); const int rc_ = ndgpu_ksw_extd2_batch(J2.jobs.data(), (int)J2.jobs.size(), res2.data()); g_t_ksw_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count(); return rc_; }()) != 0) {
         free_results(res1);
         return -1;
     }
@@ -900,7 +905,7 @@ int run_inversions(std::vector<InvTask> &inv, const Opt &o, const Targets &tg, n
             L.push_back(j);
         }
     std::vector<ndgpu_ll_result> lres(L.size());
-    if (!L.empty() && ndgpu_ksw_ll_batch(L.data(), (int)L.size(), lres.data()) != 0) return -1;
+    if (!L.empty() && ([&] { const auto t0_ = std::chrono::steady_clock::now(); const int rc_ = ndgpu_ksw_ll_batch(L.data(), (int)L.size(), lres.data()); g_t_ll_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count(); return rc_; }()) != 0) return -1;
     JobList J;
     for (InvTask &I : inv) {
         if (!I.go) continue;
@@ -918,7 +923,7 @@ int run_inversions(std::vector<InvTask> &inv, const Opt &o, const Targets &tg, n
         I.job = J.add(o, I.qseq + I.q_off, I.ql - I.q_off, I.tseq.data() + I.t_off, I.tl - I.t_off, (int)(o.bw * 1.5), o.zdrop, -1, EZ_EXTZ_ONLY);
     }
     std::vector<ndgpu_ksw_result> res(J.jobs.size());
-    if (!J.jobs.empty() && ndgpu_ksw_extd2_batch(J.jobs.data(), (int)J.jobs.size(), res.data()) != 0) return -1;
+    if (!J.jobs.empty() && ([&] { const auto t0_ = std::chrono::steady_clock::now(); const int rc_ = ndgpu_ksw_extd2_batch(J.jobs.data(), (int)J.jobs.size(), res.data()); g_t_ksw_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count(); return rc_; }()) != 0) return -1;
     for (InvTask &I : inv) {
         ReadCtx &R = *I.R;
         R.inv_done = true, R.inv_ok = false;
@@ -1024,7 +1029,10 @@ extern "C" int64_t ndgpu_ovl_map_cigar(ndgpu_ovl_index *idx, const ndgpu_ovl_opt
     ndgpu_ovl_rec *chains = nullptr;
     uint32_t *counts = nullptr;
     uint64_t *ax = nullptr, *ay = nullptr, *a_off = nullptr;
+    const auto t_call0 = std::chrono::steady_clock::now();
+    g_t_ksw_ns = 0, g_t_ll_ns = 0;
     const int64_t n_ch = ndgpu_ovl_map_chains(idx, opt, mid_occ, n_reads, words, n_words, word_off, lens, ids, &chains, &counts, &ax, &ay, &a_off);
+    const uint64_t chains_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_call0).count();
     struct Free { void *p[5]; ~Free() { for (void *q : p) free(q); } };
     Free fr{{chains, counts, ax, ay, a_off}};
     if (n_ch < 0) return n_ch;
@@ -1144,7 +1152,11 @@ extern "C" int64_t ndgpu_ovl_map_cigar(ndgpu_ovl_index *idx, const ndgpu_ovl_opt
     *recs = (ndgpu_ovl_rec *)malloc(sizeof(ndgpu_ovl_rec) * (out.size() ? out.size() : 1));
     if (!*recs) return -2;
     if (!out.empty()) memcpy(*recs, out.data(), sizeof(ndgpu_ovl_rec) * out.size());
-    if (stats) stats->overlaps = out.size();
+    if (stats) {
+        stats->overlaps = out.size();
+        stats->chains_ns = chains_ns, stats->ksw_ns = g_t_ksw_ns.load(), stats->ksw_ll_ns = g_t_ll_ns.load();
+        stats->total_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_call0).count();
+    }
     return (int64_t)out.size();
     } catch (const std::exception &e) {  // (host memory: nothing of this may cross the C boundary)
         fprintf(stderr, "[ndgpu_overlap] ndgpu_ovl_map_cigar: %s\n", e.what());

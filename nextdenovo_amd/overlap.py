@@ -46,7 +46,7 @@ class AlnOpt(C.Structure):
 
 class CigarStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("chains", "first_pass", "second_pass", "inversion_tests", "inversions", "cells", "overlaps", "inversions_aligned",
-                                         "splits")]
+                                         "splits", "chains_ns", "ksw_ns", "ksw_ll_ns", "total_ns")]
 
 
 def aln_opt(**kw) -> AlnOpt:

@@ -105,6 +105,24 @@ def measure_c(res, wd, have_ref, small):
         ref_out = os.path.join(wd, "step1_c.ref.ovl")
         ref_s = run_ref([*argv, "-t", str(CORES), fa2, fa2, "-o", ref_out])
         entry.update(reference_s=ref_s, reference_threads=CORES, identical=open(out, "rb").read() == open(ref_out, "rb").read(), speedup=ref_s / dev_s)
+    # where the time goes: the same job through the library's entry point (index + ndgpu_ovl_map_cigar), with the call's own clock
+    words, word_off, lens = synth.pack_db(rs2)
+    dset = overlap.ReadSet(np.arange(1, len(rs2.seqs) + 1, dtype=np.uint32), lens, words, word_off)
+    opt = minimap2_nd.build_opt(minimap2_nd.parse_argv([*argv, "a", "b"]))
+    with overlap.Index(opt, dset) as ix:
+        mid = ix.mid_occ()
+        ix.map_cigar(dset, dset, mid, want_stats=True)   # (warm)
+        t0 = time.perf_counter()
+        recs, st = ix.map_cigar(dset, dset, mid, want_stats=True)
+        call_s = time.perf_counter() - t0
+    host_ns = st["total_ns"] - st["chains_ns"] - st["ksw_ns"] - st["ksw_ll_ns"]
+    entry["split"] = {"map_cigar_call_s": call_s, "records": int(recs.shape[0]),
+                      "chains_on_device_s": st["chains_ns"] * 1e-9, "ksw_extd2_batches_s": st["ksw_ns"] * 1e-9, "ksw_ll_batches_s": st["ksw_ll_ns"] * 1e-9,
+                      "host_chain_walk_cigar_join_filters_s": host_ns * 1e-9, "dp_cells": st["cells"], "first_pass": st["first_pass"],
+                      "second_pass": st["second_pass"], "inversion_tests": st["inversion_tests"], "chains": st["chains"],
+                      "dp_gcells_per_s_in_batches": st["cells"] / max(1, st["ksw_ns"]),
+                      "note": "ksw batches = upload + kernel + backtrack + download of ndgpu_ksw_extd2_batch; host = chain walking, "
+                              "CIGAR joining, z-drop bookkeeping, filters, sort (host threads)"}
     res["step1_c_ava_ont"] = entry
     print("step1_c_ava_ont", json.dumps(entry), flush=True)
 
