@@ -23,9 +23,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/ndgpu_overlap.h"
+#include "ovl_pool.h"
 
 namespace {
 
@@ -336,11 +339,19 @@ bool hip_ok(hipError_t e, const char *what) {
     return false;
 }
 
-template <class T> struct Dev {
+template <class T> struct Dev {  // a block of the overlap library's pool (csrc/ovl_pool.h): no driver call per batch in steady state
     T *p = nullptr;
-    bool alloc(size_t n) { return hip_ok(hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)), "hipMalloc"); }
+    bool alloc(size_t n) {
+        try {
+            p = (T *)ndovl::pool_alloc(sizeof(T) * (n ? n : 1));
+        } catch (const std::exception &) {
+            p = nullptr;
+            return false;
+        }
+        return true;
+    }
     ~Dev() {
-        if (p) (void)hipFree(p);
+        if (p) ndovl::pool_free(p);
     }
 };
 
@@ -358,8 +369,16 @@ static uint64_t scratch_of(const ndgpu_ksw_job &J) {
 }
 
 extern "C" int ndgpu_ksw_extd2_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res) {
-    // sub-batches bounded by device scratch (NDGPU_KSW_SCRATCH_GB, default 8): a caller may hand over every gap of a read set
+    // sub-batches bounded by device scratch: a caller may hand over every gap of a read set, and the backtrack matrix of a 1 kb x 1 kb
+    // problem is 2 MB.  A launch should hold tens of thousands of problems -- one wavefront each, 8,192 resident at a time, and a
+    // launch lasts at least as long as its longest problem: with the 8 GB of round 3 a 20 Mb read set went through 190 launches
+    // of ~4,000 wavefronts, each with its own allocations (79 s; profiles/r04_overlap_c_timing.json) -- so the budget is a third of
+    // what the device has free (what the pool holds idle counts as free), NDGPU_KSW_SCRATCH_GB overrides.
     uint64_t budget = 8ull << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max<uint64_t>(budget, ((uint64_t)free_b + ndovl::pool_cached_bytes()) / 3);
+    }
     if (const char *e = getenv("NDGPU_KSW_SCRATCH_GB")) budget = (uint64_t)(atof(e) * (double)(1ull << 30));
     int a = 0;
     while (a < n) {
@@ -423,7 +442,10 @@ static int run_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res) {
     Dev<Ez> d_res;
     Dev<int32_t> d_ids;
     std::vector<int32_t> ids;
-    for (auto &t : tier) ids.insert(ids.end(), t.begin(), t.end());
+    for (auto &t : tier) {  // the longest problems of a tier first: a launch lasts as long as its last wavefront
+        std::stable_sort(t.begin(), t.end(), [&](int32_t a_, int32_t b_) { return jobs[a_].qlen + jobs[a_].tlen > jobs[b_].qlen + jobs[b_].tlen; });
+        ids.insert(ids.end(), t.begin(), t.end());
+    }
     hipStream_t st = nullptr;
     bool ok = hip_ok(hipStreamCreate(&st), "hipStreamCreate") && d_jobs.alloc((size_t)n) && d_pool.alloc(pool.size()) && d_p.alloc(p_total) &&
               d_diff.alloc(diff_total) && d_h.alloc(h_total) && d_off.alloc(off_total) && d_cigar.alloc(cigar_total) && d_res.alloc((size_t)n) && d_ids.alloc((size_t)n);
