@@ -303,6 +303,9 @@ struct DeviceAligner::State {
     DevBuf<LqPileDev> d_lq_piles;
     DevBuf<LqPieceDev> d_lq_pieces;
     DevBuf<uint32_t> d_lq_rec;
+    DevBuf<LqJobDev> d_lq_jobs;   // K12a's jobs and their streams: a header per cell row, a word per link
+    DevBuf<uint64_t> d_lq_hdr;
+    DevBuf<uint32_t> d_lq_lnk;
     DevBuf<char> d_lq_out;
     std::vector<ReadDev> reads;
     std::vector<PileDev> piles;
@@ -424,7 +427,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     }
 #define NDGPU_NAME(x) s_->x.name = #x;
     NDGPU_NAME(h_ops) NDGPU_NAME(h_outs) NDGPU_NAME(up) NDGPU_NAME(down)
-    NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec)
+    NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec) NDGPU_NAME(d_lq_jobs) NDGPU_NAME(d_lq_hdr) NDGPU_NAME(d_lq_lnk)
     NDGPU_NAME(d_lq_out)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v) NDGPU_NAME(d_wtrace) NDGPU_NAME(d_wmink)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
@@ -531,7 +534,7 @@ void DeviceAligner::release_memory() {
     S.pending.clear();
     S.up_used = S.down_used = 0;
 #define NDGPU_REL(x) S.x.release();
-    NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec)
+    NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec) NDGPU_REL(d_lq_jobs) NDGPU_REL(d_lq_hdr) NDGPU_REL(d_lq_lnk)
     NDGPU_REL(d_lq_out)
     NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v) NDGPU_REL(d_wtrace) NDGPU_REL(d_wmink)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
@@ -576,7 +579,7 @@ void DeviceAligner::level_buffers(int drivers) {
         };
         try {
 #define NDGPU_LVL(x) lvl(S.x, #x[0] == 'd');
-            NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_out)
+            NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_jobs) NDGPU_LVL(d_lq_hdr) NDGPU_LVL(d_lq_lnk) NDGPU_LVL(d_lq_out)
             NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v) NDGPU_LVL(d_wtrace) NDGPU_LVL(d_wmink)
             NDGPU_LVL(d_ids) NDGPU_LVL(d_reads) NDGPU_LVL(d_piles) NDGPU_LVL(d_read_pile) NDGPU_LVL(d_acc) NDGPU_LVL(d_tags)
             NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
@@ -923,6 +926,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
 // linked pseudo-seed, second MSA, DP, walk) -- the column streams stay in HBM, what comes back is each pile's walk string.
 // A round the kernel declines (r->ok stays false) is left to the caller's host path.
 constexpr uint32_t kLenClasses = 16384;  // 64-base length classes of the longest-first launch order (run_main); the last one holds >= 1 Mb
+constexpr uint64_t kLqJobColumns = 192;     // columns of a K12a job (a pile of 3,000 columns is ~15 wavefronts' worth of link building)
 constexpr uint64_t kLqMaxColumns = 12000;  // linked pseudo-seed columns K12 takes per pile (see run_lq)
 
 void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
@@ -949,7 +953,8 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     };
     std::vector<Src> srcs;
     std::vector<uint8_t> usable(n, 1);
-    uint64_t pool_words = 0, ops_words = 0, cell_rows = 0, out_bytes = 0;
+    uint64_t pool_words = 0, ops_words = 0, cell_rows = 0, out_bytes = 0, hdr_words = 0, lnk_words = 0;
+    std::vector<LqJobDev> jobs;
     size_t n_piece_total = 0;
     for (size_t r = 0; r < n; r++) n_piece_total += rounds[r]->pieces.size();
     pieces.reserve(n_piece_total);
@@ -1021,14 +1026,54 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
             continue;
         }
         P.link_len = (uint32_t)link_len;
-        // cell rows = columns + the longest insertion run after every column; bounded by all the candidates' bases, in practice
-        // a fraction of the columns: three times the columns are laid out, a pile that needs more is declined (host path)
-        P.row_cap = (uint32_t)std::min<uint64_t>(link_len + ins_cap, 3 * link_len + 1024);
         P.out_cap = (uint32_t)(2 * link_len + 64);
         P.cell_off = cell_rows * 6;
         P.out_off = out_bytes;
-        cell_rows += P.row_cap;
         out_bytes += P.out_cap;
+        // K12a's jobs: runs of regions of about kLqJobColumns columns (each region with the 'N' column in front of it); a job
+        // starts only behind a region that has columns (its rows' first tags come from the tail of that region's alignments).
+        // Capacities: cell rows = columns + the longest insertion run after every column -- bounded by the candidates' bases, in
+        // practice a fraction of the columns: three times the columns are laid out, a job that needs more declines the pile (host
+        // path); links <= tags = the alignments' columns (<= q_len + t_len each) + a tag per row of an unaligned region's columns
+        // + 30 per 'N'.
+        static const uint64_t job_cols = getenv("NDGPU_K12_JOB_COLUMNS") ? strtoull(getenv("NDGPU_K12_JOB_COLUMNS"), nullptr, 10) : kLqJobColumns;  // (test hook: 1 = every region a job)
+        P.first_job = (uint32_t)jobs.size();
+        {
+            uint32_t g = 0, t = 0;
+            while (g < nr) {
+                LqJobDev jb;
+                memset(&jb, 0, sizeof(jb));
+                jb.pile = (uint32_t)r, jb.g_a = g, jb.t0 = t;
+                uint64_t cols = 0, ins = 0, tags = 0;
+                do {
+                    const uint32_t sl = R.pieces[g].sl;
+                    cols += (uint64_t)sl + 1;
+                    tags += 30;
+                    for (uint32_t row = 0; row < 30u; row++) {
+                        const LqRound::Piece &pc = R.pieces[(size_t)row * nr + g];
+                        if (pc.job >= 0) {
+                            const AlnJob &j = (*R.jobs)[(size_t)pc.job];
+                            ins += (uint64_t)j.q_len;
+                            tags += (uint64_t)j.q_len + (uint64_t)j.t_len;
+                        } else tags += sl;
+                    }
+                    t += sl + 1;
+                    g++;
+                } while (g < nr && (cols < job_cols || R.pieces[g - 1].sl == 0));
+                jb.g_b = g;
+                if (g == nr) cols += 1, tags += 30, t += 1;  // the closing 'N'
+                jb.t1 = t;
+                jb.row_cap = (uint32_t)std::min<uint64_t>(cols + ins, 3 * cols + 256);
+                jb.lnk_cap = (uint32_t)std::min<uint64_t>(tags, (uint64_t)jb.row_cap * 30u);
+                jb.hdr_off = hdr_words, jb.lnk_off = lnk_words;
+                hdr_words += jb.row_cap;
+                lnk_words += jb.lnk_cap;
+                P.row_cap += jb.row_cap;
+                jobs.push_back(jb);
+            }
+        }
+        P.n_jobs = (uint32_t)jobs.size() - P.first_job;
+        cell_rows += P.row_cap;
     }
     const size_t nt = tasks.size();
     if (nt == 0) {  // nothing K12 takes in this call: every pile goes the host way
@@ -1056,6 +1101,9 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.d_lq_piles.reserve(n);
     S.d_lq_pieces.reserve(pieces.size());
     S.d_lq_rec.reserve(cell_rows * 6 + 6);
+    S.d_lq_jobs.reserve(jobs.size() + 1);
+    S.d_lq_hdr.reserve(hdr_words + 1);
+    S.d_lq_lnk.reserve(lnk_words + 64);   // (K12b fetches a row's 64 link slots ahead)
     S.d_lq_out.reserve(out_bytes + 1);
 
     // forward / traceback chunks bounded by the trace budget (the column streams of every chunk stay resident)
@@ -1083,6 +1131,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.h2d(S.d_tasks.p, tasks.data(), nt * sizeof(AlnTask), st);
     S.h2d(S.d_lq_piles.p, piles.data(), n * sizeof(LqPileDev), st);
     S.h2d(S.d_lq_pieces.p, pieces.data(), pieces.size() * sizeof(LqPieceDev), st);
+    if (!jobs.empty()) S.h2d(S.d_lq_jobs.p, jobs.data(), jobs.size() * sizeof(LqJobDev), st);
     // (HIP-event brackets per kernel: K7, K8a per chunk -- read after the round's one synchronisation)
     while (S.lq_evs.size() < 2 * chunk_end.size() + 1) {
         hipEvent_t e;
@@ -1105,7 +1154,8 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     }
     HIP_CHECK(hipEventRecord(S.evs[1], st));
     NDGPU_DBG(st, "lq: msa of %zu piles", n);
-    launch_lq_msa(S.d_lq_piles.p, S.d_lq_pieces.p, S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_pool.p, S.d_lq_rec.p, S.d_lq_out.p, (int)n, st);
+    launch_lq_msa(S.d_lq_piles.p, S.d_lq_jobs.p, S.d_lq_pieces.p, S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_pool.p, S.d_lq_hdr.p, S.d_lq_lnk.p,
+                  S.d_lq_rec.p, S.d_lq_out.p, (int)n, (int)jobs.size(), st);
     HIP_CHECK(hipEventRecord(S.evs[2], st));
     S.h_outs.reserve(nt + 1);
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, nt * sizeof(AlnOut), hipMemcpyDeviceToHost, st));

@@ -119,8 +119,9 @@ struct LqPileDev {
     uint32_t link_len;       // columns of the linked pseudo-seed: 1 + sum(sl + 1)
     int32_t factor;          // 2 (HiFi 4)     lib/nextcorrect.c:1262
     int32_t qv_factor;       // 5 (HiFi 2)     lib/nextcorrect.c:1303
-    uint32_t row_cap;        // capacity in cell rows ((column, delta) pairs) of the pile's cell tables
+    uint32_t row_cap;        // capacity in cell rows ((column, delta) pairs) of the pile's cell records
     uint32_t out_cap;        // capacity of the pile's output characters
+    uint32_t first_job, n_jobs;  // the pile's jobs (K12a), in column order
     uint32_t pad_;
     uint64_t cell_off;       // first cell record (6 per cell row)
     uint64_t out_off;        // first output character
@@ -128,8 +129,19 @@ struct LqPileDev {
     uint32_t out_len;
     uint32_t err;            // nonzero: declined (capacity, or an alignment that does not end at both sequence ends)
 };
-void launch_lq_msa(LqPileDev *piles, const LqPieceDev *pieces, const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops,
-                   const uint32_t *pool, uint32_t *cell_rec, char *out_chars, int n_piles, void *stream);
+struct LqJobDev {            // K12a's unit of work: regions [g_a, g_b) of a pile, each with the 'N' column in front of it
+    uint32_t pile;
+    uint32_t g_a, g_b;
+    uint32_t t0, t1;         // columns [t0, t1) of the linked pseudo-seed (t0 = the 'N' in front of region g_a; the last job ends behind the closing 'N')
+    uint32_t row_cap, lnk_cap;   // capacity of the job's streams: cell-row headers, link words
+    uint32_t pad_;
+    uint64_t hdr_off, lnk_off;
+    // written by the kernel
+    uint32_t n_rows, n_links, err, pad2_;
+};
+void launch_lq_msa(LqPileDev *piles, LqJobDev *jobs, const LqPieceDev *pieces, const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops,
+                   const uint32_t *pool, uint64_t *hdr, uint32_t *lnk, uint32_t *cell_rec, char *out_chars, int n_piles, int n_jobs,
+                   void *stream);
 
 // ---- scoring DP (K10), segment-parallel: see the head comment of the K10 section in msa_kernels.hip ----
 struct SegItem {            // work item of the segment kernel

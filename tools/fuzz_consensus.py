@@ -95,7 +95,8 @@ def main():
         total += len(piles)
         bad += n_bad
         print(it, "equal" if n_bad == 0 else "DIFFER(%d)" % n_bad, prof, "piles", len(piles), P, "max_lq", max_lq, "%.0fs" % (time.time() - t0), flush=True)
-    print("piles", total, "mismatches", bad)
+    st = api.stats()
+    print("piles", total, "mismatches", bad, "| K12 rounds", st["lq_rounds"], "declined", st["lq_declined"], "columns", st["lq_columns"])
     return 1 if bad else 0
 
 
