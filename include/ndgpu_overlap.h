@@ -199,7 +199,8 @@ int64_t ndgpu_ovl_map2(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t m
  * ts, te as usual; `qname` = the hit's target -- its index-local read number, or, with a wanted list, its POSITION in the read's list
  * want[want_off[i] .. want_off[i + 1]) (the read is then mapped against those reads only, which are seen in list order: the
  * per-thread mini-index of the re-alignment, minimap2/index.c:434-575); `tname` = block length, `match` = match count.
- * nameless != 0: the reads have no names (mm_map(..., qname = 0)): no name-based seed skipping, no self test.  counts[i] = hits
+ * nameless bit 0: the reads have no names (mm_map(..., qname = 0)): no name-based seed skipping, no self test; bit 1: the chaining
+ * is mm_chain_dp_nextdenovo (mm_map_nextdenovo1, minimap2/map.c:1047: a mapping with more than 100,000 anchors is thinned first).  counts[i] = hits
  * of read i; *max_anchors (may be NULL) = the most anchors any one read had.  Both arrays malloc'd (ndgpu_ovl_free).  Returns the
  * number of hits, < 0 on error. */
 int64_t ndgpu_ovl_map_regs(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32_t mid_occ, uint32_t n_reads, const uint32_t *words,
@@ -207,8 +208,8 @@ int64_t ndgpu_ovl_map_regs(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int32
                            const uint32_t *want, int nameless, ndgpu_ovl_rec **recs, uint32_t **counts, uint64_t *max_anchors);
 /* replaces: worker_for WITH the re-alignment (minimap2/map.c:988-1126) + the writer's record filter (:1305-1309): `--step 2` as
  * nextDenovo runs it (no --mode, i.e. --mode 2, options.c:56), or --mode 1 (the two forms of the re-alignment switch at 20 candidates
- * instead of 200; a candidate whose mapping against the query's one-read index has more than 100,000 anchors would take the anchor
- * thinning of mm_chain_dp_nextdenovo, chain.c:185-226, which is not built: -3).  idx = the index part (the preset's k, w); q_mini / t_mini = indexes
+ * instead of 200, and the one-read-index mappings chain through mm_chain_dp_nextdenovo: a mapping with more than 100,000 anchors
+ * loses the anchors of crowded target positions first, chain.c:185-226).  idx = the index part (the preset's k, w); q_mini / t_mini = indexes
  * with the short sketch (--kn 17 --wn 10, main.c:197) over the query reads / over the part's target reads; cn = --cn (20).
  * opt->step must be 2 and opt->mode 1 or 2.  *recs is malloc'd (ndgpu_ovl_free).  Returns the record count, < 0 on error. */
 int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, ndgpu_ovl_index *t_mini, const ndgpu_ovl_opt *opt,

@@ -44,6 +44,8 @@ struct OvlParams {
 	int32_t provisional; // K5 stops at the hits themselves (target number, block length and match count in the name / match
 	                     // fields, hit order): the passes of --step 2's re-alignment, whose marking and filters follow on the host
 	int32_t nameless;    // the query has no name (mm_map(..., qname = 0), minimap2/map.c:1052,1088): no self test in K5
+	int32_t thin;        // the chaining is mm_chain_dp_nextdenovo (--step 2 --mode 1's one-read-index mappings): beyond 100,000 anchors the
+	                     // anchors of crowded target positions are dropped first (thin_anchors_kernel, minimap2/chain.c:185-226)
 	int32_t chains;      // -c: K5 hands out the chains themselves -- every hit (self hits too, mm_align_skeleton aligns them) as
 	                     // (strand, target, a[] offset, anchor count, chain score, hash) in hit order, and the chained anchors in the
 	                     // order of the reference's a[] (chains by the x of their first anchor, minimap2/chain.c:150-160)
@@ -135,6 +137,7 @@ void launch_sort_init(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t 
                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *jobs, uint32_t *n_jobs, hipStream_t s);
 void launch_sort_pass(const void *jobs, uint32_t n_jobs, uint64_t *x, uint64_t *y, uint64_t *tx, uint64_t *ty, uint32_t *gs, void *next,
                       uint32_t *n_next, hipStream_t s);
+void launch_thin_anchors(const uint64_t *r_aoff, uint32_t n_reads, uint64_t *ax, int32_t *t, int32_t *v, hipStream_t s);
 void launch_chain(const uint64_t *slab_i0, const uint32_t *slab_read, uint32_t n_slabs, uint64_t n_anchors, const uint64_t *r_aoff,
                   const float *read_avg_span, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f, int32_t *p, int32_t *v,
                   unsigned long long *cells, hipStream_t s);

@@ -322,6 +322,7 @@ struct Regs {
 	// -c (ndgpu_ovl_map_chains): the hits are chains -- OvlRec = (strand, target, offset into the read's anchors, anchor count, chain
 	// score, hash, 0, 0) -- and the chained anchors of every read come with them, in the reference's a[] order; null otherwise
 	std::vector<uint64_t> *ca_x = nullptr, *ca_y = nullptr, *ca_off = nullptr;
+	bool thin = false;              // chain with mm_chain_dp_nextdenovo (anchor thinning beyond 100,000 anchors)
 };
 
 struct Engine {
@@ -551,7 +552,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	OvlParams Pm = to_params(o);
 	Pm.k = P.k, Pm.w = P.w, Pm.hpc = P.hpc; // the sketch parameters belong to the index
 	if (regs) {
-		Pm.provisional = 1, Pm.step2 = 0, Pm.mode3 = 0, Pm.dvt = 0, Pm.nameless = regs->nameless, Pm.chains = regs->ca_x != nullptr;
+		Pm.provisional = 1, Pm.step2 = 0, Pm.mode3 = 0, Pm.dvt = 0, Pm.nameless = regs->nameless, Pm.thin = regs->thin, Pm.chains = regs->ca_x != nullptr;
 		if (regs->ca_x) regs->ca_x->clear(), regs->ca_y->clear(), regs->ca_off->assign(1, 0);
 		if (regs->nameless) Pm.no_diag = Pm.no_dual = 0; // skip_seed looks at names only when there is one (minimap2/map.c:129)
 		regs->counts->clear();
@@ -721,6 +722,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		cells.zero(stream);
 		t.zero(stream);
 		tm.start();
+		if (P.thin) launch_thin_anchors(r_aoff.p, nb, ax.p, t.p, v.p, stream);
 		launch_chain(slab_i0.p, slab_read.p, (uint32_t)n_slabs, na, r_aoff.p, avg_span.p, ax.p, ay.p, P, f.p, p.p, v.p, cells.p, stream);
 		launch_chain_ends(r_aoff.p, nb, P, f.p, p.p, v.p, t.p, u.p, n_end.p, stream);
 		HIP_OK(hipGetLastError());
@@ -988,7 +990,8 @@ int64_t ndgpu_ovl_map_regs(ndgpu_ovl_index *h, const ndgpu_ovl_opt *opt, int32_t
 		HIP_OK(hipSetDevice(h->e.device));
 		std::vector<OvlRec> out;
 		std::vector<uint32_t> cnt;
-		const Regs rg{want_off, want, nameless != 0, &cnt, max_anchors};
+		Regs rg{want_off, want, (nameless & 1) != 0, &cnt, max_anchors};
+		rg.thin = (nameless & 2) != 0;
 		int64_t n = h->e.map(*opt, mid_occ, n_reads, words, n_words, word_off, lens, ids, out, nullptr, &rg);
 		if (n < 0) return n;
 		if (cnt.size() != n_reads) cnt.resize(n_reads, 0u);

@@ -1119,6 +1119,14 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 		}
 		const uint64_t ri = __shfl(cx, bl, 64), yi = __shfl(cy, bl, 64);
 		const int32_t qi = (int32_t)yi, span = (int32_t)(yi >> 32 & 0xff);
+		if (ri == ~0ull) {  // an anchor the thinning dropped (chain.c:231-234): f = p = v = -1, and nobody chains through it
+			if (lane == 0) F[i] = -1, Pp[i] = -1, V[i] = -1, ring[i & (kRing - 1)] = (uint16_t)i;
+			wx = __shfl_up(wx, 1, 64), wq = __shfl_up(wq, 1, 64), wf = __shfl_up(wf, 1, 64), wp = __shfl_up(wp, 1, 64);
+			wv = __shfl_up(wv, 1, 64);
+			if (lane == 0) wx = ri, wq = qi, wf = -1, wp = -1, wv = -1;
+			__builtin_amdgcn_wave_barrier();
+			continue;
+		}
 		int32_t best = span, skipped = 0, best_j = -1;
 		bool stop = false, fenced = false;
 		for (int32_t base = i - 1; base >= i0 && !stop; base -= 64) {
@@ -1131,10 +1139,13 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 				xj = 0, qj = 0, fj = 0, pj = -1;
 				if (j >= i0) xj = X[j], qj = (int32_t)Y[j], fj = F[j], pj = Pp[j];
 			}
-			const bool in_win = j >= i0 && i - j <= P.max_iter && ri <= xj + max_dist;
+			// (a dropped anchor -- x all ones -- lies inside the window as far as the index range goes and is stepped over:
+			// chain.c:241,244; the window's far end is the first anchor that is neither dropped nor in reach)
+			const bool dropped = xj == ~0ull;
+			const bool in_win = j >= i0 && i - j <= P.max_iter && (dropped || ri <= xj + max_dist);
 			bool act = false;
 			int32_t sc = INT32_MIN;
-			if (in_win) {
+			if (in_win && !dropped) {
 				const int64_t dr = (int64_t)(ri - xj);
 				const int32_t dq = qi - qj;
 				if (!(dr == 0 || dq <= 0 || dq > P.max_gap)) {
@@ -1249,6 +1260,55 @@ __global__ void __launch_bounds__(64) chain_ends_kernel(const uint64_t *__restri
 	__builtin_amdgcn_wave_barrier();
 	for (int32_t i = lane; i < n; i += 64) T[i] = 0;
 	if (lane == 0) n_end[rd] = n_u;
+}
+
+// mm_chain_dp_nextdenovo's anchor thinning (minimap2/chain.c:185-226), for the mappings of --step 2 --mode 1 that chain through it: a
+// read with more than 100,000 anchors loses the anchors of crowded target positions before the DP.  Groups = runs of anchors with the
+// same 32-bit target position (strand and read number are not looked at); t[] counts them from slot 1, v[g - 1] holds group g's
+// position, v[last] the last position + 20; when the largest group has more than 200 anchors, an anchor of a group larger than 0.8 x
+// the largest is dropped if it lies within 10 of the last position kept and the next group starts within 10 of it.  A dropped anchor's
+// x becomes all ones (the reference's a[i].x = -1).  Two sequential passes per read, one lane each: rare reads, ~10 ms.
+// (The reference's counters can step one slot past its arrays when every anchor is a group of its own; that slot is not written here.)
+__global__ void thin_anchors_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, uint64_t *__restrict__ ax, int32_t *__restrict__ t,
+                                    int32_t *__restrict__ v)
+{
+	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rd >= n_reads) return;
+	const uint64_t a0 = r_aoff[rd];
+	const int64_t n = (int64_t)(r_aoff[rd + 1] - a0);
+	if (n <= 100000) return;
+	uint64_t *X = ax + a0;
+	int32_t *T = t + a0, *V = v + a0;   // T arrives zeroed and leaves zeroed; V is K4's to overwrite
+	const int32_t maxc = 200, maxw = 10;
+	int64_t i, j = 0;
+	int32_t px = 0, k = 0, pm, pi;
+	for (i = 0; i < n; ++i) {
+		pi = (int32_t)X[i];
+		if (pi != px) {
+			if (j < n && T[j] > k) k = T[j];
+			j++;
+			V[j - 1] = px = pi;
+		}
+		if (j < n) T[j]++;
+	}
+	if (j < n && T[j] > k) k = T[j];
+	if (j < n) V[j] = (int32_t)X[n - 1] + maxw * 2;
+	const int64_t groups = j;
+	if (k > maxc) {
+		k = (int32_t)((double)k * (double)0.8f + .499);
+		for (i = j = 0, px = 0, pm = (int32_t)X[0]; i < n; ++i) {
+			pi = (int32_t)X[i];
+			if (pi != px) px = pi, j++;
+			if (j < n && T[j] > k && pi > pm && pi < pm + maxw && V[j] < pi + maxw) X[i] = ~0ull;
+			else pm = pi;
+		}
+	}
+	for (i = 0; i <= groups && i < n; ++i) T[i] = 0;
+}
+
+void launch_thin_anchors(const uint64_t *r_aoff, uint32_t n_reads, uint64_t *ax, int32_t *t, int32_t *v, hipStream_t s)
+{
+	if (n_reads) ND_LAUNCH(thin_anchors_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, ax, t, v);
 }
 
 void launch_chain(const uint64_t *slab_i0, const uint32_t *slab_read, uint32_t n_slabs, uint64_t n_anchors, const uint64_t *r_aoff,

@@ -427,7 +427,7 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 		ndgpu_ovl_opt ro = *opt;
 		std::vector<std::vector<Reg>> res_a(ua.size()), res_b(ub.size());
 		uint64_t most_anchors = 0;
-		auto run_units = [&](ndgpu_ovl_index *ix, size_t n_units, auto seq_of, auto want_of, auto store) -> int {
+		auto run_units = [&](ndgpu_ovl_index *ix, size_t n_units, auto seq_of, auto want_of, auto store, int how = 1) -> int {
 			size_t u0 = 0;
 			while (u0 < n_units) {
 				size_t u1 = u0;
@@ -446,7 +446,7 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 				uint32_t *rc = nullptr;
 				uint64_t ma = 0;
 				const int64_t nn = ndgpu_ovl_map_regs(ix, &ro, mid_occ, m, seq_of.words, seq_of.n_words, woff.data(), lens.data(), ids.data(), want_off.data(),
-				                                      want.data(), 1, &rr, &rc, &ma);
+				                                      want.data(), how, &rr, &rc, &ma);
 				if (nn < 0) return (int)nn;
 				most_anchors = std::max(most_anchors, ma);
 				uint64_t at = 0;
@@ -470,14 +470,11 @@ int64_t ndgpu_ovl_map2_realign(ndgpu_ovl_index *idx, ndgpu_ovl_index *q_mini, nd
 			std::pair<uint64_t, uint64_t> operator()(size_t u) const { const uint32_t q = (*ub)[u].q; return {word_off[q], lens[q]}; }
 		} seq_q{q_words, q_n_words, q_word_off, q_lens, &ub};
 		int rc0 = run_units(q_mini, ua.size(), seq_t, [&](size_t u, std::vector<uint32_t> &w) { w.push_back(ua[u].q); },
-		                    [&](size_t u, std::vector<Reg> &&v) { res_a[u] = std::move(v); });
+		                    [&](size_t u, std::vector<Reg> &&v) { res_a[u] = std::move(v); },
+		                    // --mode 1 maps these through mm_map_nextdenovo1 (map.c:1047): mm_chain_dp_nextdenovo, which thins the anchors of
+		                    // a mapping that has more than 100,000 of them before it chains (bit 1 of `nameless`)
+		                    opt->mode == 1 ? 3 : 1);
 		if (rc0 < 0) return rc0;
-		if (opt->mode == 1 && most_anchors > 100000) {
-			fprintf(stderr, "[ndgpu_overlap] --step 2 --mode 1: a candidate has %llu anchors against its query's one-read index; beyond 100,000 the "
-			                "reference thins the anchors first (mm_chain_dp_nextdenovo, minimap2/chain.c:185-226), which is not built\n",
-			        (unsigned long long)most_anchors);
-			return -3;
-		}
 		rc0 = run_units(t_mini, ub.size(), seq_q, [&](size_t u, std::vector<uint32_t> &w) { w.insert(w.end(), want_b.begin() + ub[u].w0, want_b.begin() + ub[u].w1); },
 		                [&](size_t u, std::vector<Reg> &&v) { res_b[u] = std::move(v); });
 		if (rc0 < 0) return rc0;

@@ -15,8 +15,8 @@ with `--mode 0`.  `--mode 3` (HiFi: chain ends trimmed, every hit extended into 
 `--step 2` is the `cns_align` command of nextDenovo:356-366 on corrected reads: FASTA input with numeric names; the hits of every
 read on the device, the per-target marking, the re-alignment's bookkeeping (its mapping passes run on the device again), the record
 filters, the dovetail / contained filter, the 10-field encoder and the `.bl` table on the host (csrc/ovl_step2.cpp).  `--mode 1` too
-(the two forms of the re-alignment switch at 20 candidates instead of 200, --cn 50), short of the anchor thinning its chaining
-applies to mappings with more than 100,000 anchors (refused when one occurs).
+(the two forms of the re-alignment switch at 20 candidates instead of 200, --cn 50; its one-read-index mappings chain through
+mm_chain_dp_nextdenovo, anchor thinning beyond 100,000 anchors included).
 `-c` (with --step 1, not --mode 3, not ava-hifi -- the compiled reference aborts there): base-level alignment through every chain
 (mm_align_skeleton, minimap2/align.c:857-913) before the writer's filter; -A -B -O -E -z -s as in minimap2/main.c:250-252,353-361.
 Options of other paths (-a, --step 3) are rejected, not approximated.

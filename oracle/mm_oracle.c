@@ -378,6 +378,7 @@ static int ilog2(uint32_t v) /* floor(log2 v), v > 0 */
  * the target coordinate of their first anchor); u[] (room for n) = score<<32 | n_anchors per chain.
  * f_out/p_out (optional, room for n) receive the DP score / predecessor arrays.  Returns the number of
  * chains; *n_b = anchors kept. */
+static int g_chain_thin; /* the next nd_mm_chain call is mm_chain_dp_nextdenovo (set by the --mode 1 one-read-index mapping) */
 int nd_mm_chain(const nd_mm_opt *opt, int64_t n, nd_mm128 *a, uint64_t *u, int64_t *n_b, int32_t *f_out, int32_t *p_out)
 {
 	const int max_dist = opt->max_gap, bw = opt->bw;
@@ -393,15 +394,48 @@ int nd_mm_chain(const nd_mm_opt *opt, int64_t n, nd_mm128 *a, uint64_t *u, int64
 	t = (int32_t*)calloc(n, 4); v = (int32_t*)malloc(4 * n);
 	for (i = 0; i < n; ++i) span_sum += a[i].y >> 32 & 0xff;
 	avg_span = (float)span_sum / n;
+	/* mm_chain_dp_nextdenovo (minimap2/chain.c:185-226; the chaining of --step 2 --mode 1's one-read-index mappings): beyond
+	 * 100,000 anchors, anchors of crowded target positions are dropped before the DP.  Groups = runs of anchors with the same
+	 * 32-bit target position (strand and read number are not looked at); t[] counts them from slot 1, v[g - 1] holds group g's
+	 * position, v[last] the last position + 20; when the largest group has more than 200 anchors, an anchor of a group larger than
+	 * 0.8 x the largest is dropped if it lies within 10 of the last position that was kept and the next group starts within 10 of
+	 * it.  A dropped anchor's x becomes all ones: the DP steps over it and gives it f = p = v = -1. */
+	if (g_chain_thin && n > 100000 && !getenv("ND_ORACLE_NO_THINNING")) { /* (the switch: a test shows that its fixture depends on this branch) */
+		int32_t px, pm, pi, maxc = 200, maxw = 10;
+		for (i = j = px = k = 0; i < n; ++i) {
+			pi = (int32_t)a[i].x;
+			if (pi != px) {
+				if (t[j] > k) k = t[j];
+				j++;
+				v[j - 1] = px = pi;
+			}
+			t[j]++;
+		}
+		if (t[j] > k) k = t[j];
+		v[j++] = (int32_t)a[i - 1].x + maxw * 2;
+		if (k > maxc) {
+			k = (int32_t)((double)k * (float)0.8 + .499);
+			for (i = j = px = 0, pm = (int32_t)a[0].x; i < n; ++i) {
+				pi = (int32_t)a[i].x;
+				if (pi != px) px = pi, j++;
+				if (t[j] > k && pi > pm && pi < pm + maxw && v[j] < pi + maxw) a[i].x = ~(uint64_t)0;
+				else pm = pi;
+			}
+		}
+		memset(t, 0, 4 * n);
+	}
 	for (i = 0; i < n; ++i) {
 		const uint64_t ri = a[i].x;
 		const int32_t qi = (int32_t)a[i].y, span = (int32_t)(a[i].y >> 32 & 0xff);
 		int32_t best = span, skipped = 0;
 		int64_t best_j = -1;
-		while (st < i && ri > a[st].x + (uint64_t)max_dist) ++st;
+		if (ri == ~(uint64_t)0) { v[i] = f[i] = p[i] = -1; continue; }
+		while (st < i && (a[st].x == ~(uint64_t)0 || ri > a[st].x + (uint64_t)max_dist)) ++st;
 		if (i - st > opt->max_iter) st = i - opt->max_iter;
 		for (j = i - 1; j >= st; --j) {
-			int64_t dr = (int64_t)(ri - a[j].x);
+			int64_t dr;
+			if (a[j].x == ~(uint64_t)0) continue;
+			dr = (int64_t)(ri - a[j].x);
 			int32_t dq = qi - (int32_t)a[j].y, dd, sc, gap_log;
 			if (dr == 0 || dq <= 0) continue;
 			if (dq > max_dist) continue;
@@ -592,7 +626,7 @@ int nd_mm_map_read(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uin
 
 static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, const char *qname, const uint8_t *qcodes, int qlen,
                           nd_mm_reg *regs, int reg_cap, int mode3);
-static int64_t g_s2_unrestated; /* (defined with the --step 2 re-alignment below) */
+static int64_t g_s2_big_maps; /* (defined with the --step 2 re-alignment below) */
 static int g_count_big_maps;
 
 static int map_read_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
@@ -622,9 +656,11 @@ static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_o
 	}
 	a = (nd_mm128*)malloc(sizeof(nd_mm128) * (n_a > 0 ? n_a : 1));
 	n_a = nd_mm_seeds(ix, opt, qname, qlen, mid_occ, mv, n_mv, a, 1);
-	if (g_count_big_maps && n_a > 100000) g_s2_unrestated++;
+	if (g_count_big_maps && n_a > 100000) g_s2_big_maps++;
 	u = (uint64_t*)malloc(8 * (n_a > 0 ? n_a : 1));
+	g_chain_thin = g_count_big_maps;
 	n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
+	g_chain_thin = 0;
 	n = n_u <= reg_cap ? n_u : -n_u;
 	if (n > 0) nd_mm_gen_regs(nd_mm_read_hash(qname, qlen, opt->seed), qlen, n_u, u, a, regs);
 	if (n > 0 && mode3)
@@ -893,9 +929,10 @@ static int update_regs(nd_mm_reg *reg_new, int n_reg_new, nd_mm_reg *reg, int s,
  *     against each batch, the hits are sorted by their target's number in the batch and update_reg_nextdenovo picks per target.
  * Two hits that say "the query is contained" (MAX_CON) end it.  `c` comes in from the marking. */
 static int64_t g_s2_one_read_index, g_s2_batched; /* queries re-aligned either way (test instrumentation) */
-static int64_t g_s2_unrestated;                   /* --mode 1 mappings with more than 100,000 anchors (see realign) */
+static int64_t g_s2_big_maps;                     /* --mode 1 mappings with more than 100,000 anchors: the anchor thinning ran (see nd_mm_chain) */
 void nd_mm_step2_counters(int64_t out[2]) { out[0] = g_s2_one_read_index, out[1] = g_s2_batched; g_s2_one_read_index = g_s2_batched = 0; }
-int64_t nd_mm_step2_unrestated(void) { int64_t n = g_s2_unrestated; g_s2_unrestated = 0; return n; }
+int64_t nd_mm_step2_big_maps(void) { int64_t n = g_s2_big_maps; g_s2_big_maps = 0; return n; }
+int64_t nd_mm_step2_unrestated(void) { return 0; } /* (kept for callers of round 3: every branch is restated now) */
 static int g_count_big_maps; /* set while --mode 1 maps a candidate against the query's one-read index */
 
 static void realign_mode2(const nd_mm_index *ix, const nd_mm_opt *opt, int mode, int kn, int wn, int cn, int mid_occ, const uint8_t *tcodes,

@@ -38,14 +38,43 @@ CASES_M2 = [(tag + ".m2", argv) for tag, argv in CASES] + [
 CASES_M1 = [("ont.m1", dict(CASES)["ont"]), ("deep.m1", dict(CASES_M2)["deep.m2"])]
 
 
+# --mode 1 with mappings of more than 100,000 anchors: mm_chain_dp_nextdenovo thins the anchors of crowded target positions first
+# (minimap2/chain.c:185-226).  Reads across an array of 237 copies of a 36-base unit: against a one-read index every minimizer of the
+# array has ~237 occurrences (below -f 1000, which keeps the array out of the first pass, where it has ~2,000), so a candidate read
+# brings ~237 x 237 x 4 anchors.  The fixture DEPENDS on the thinning: without it the oracle's records differ
+# (tests/test_overlap_oracle.py::test_oracle_step2_anchor_thinning).
+CASES_THIN = [("tandem.m1", ("--dual=yes", "-x", "ava-ont", "-k", "17", "-w", "17", "--minlen", "1000", "--maxhan1", "2000", "-f", "1000"))]
+
+
 def files_of(tag):
+    if tag.startswith("tandem"):
+        return ["tandem.fa.gz", "tandem.fa.gz"]
     if tag.startswith("deep"):
         return ["c.fa.gz", "c.fa.gz"]
     return ["a.fa.gz", "a.fa.gz"] if ".self" in tag else ["a.fa.gz", "b.fa.gz", "a.fa.gz"]
 
 
+def make_tandem():
+    rng = np.random.default_rng(2)
+    ul, copies = int(rng.integers(18, 40)), int(rng.integers(215, 300))
+    unit = rng.integers(0, 4, ul, dtype=np.uint8)
+    left, right = rng.integers(0, 4, 9000, dtype=np.uint8), rng.integers(0, 4, 9000, dtype=np.uint8)
+    g = np.concatenate([left] + [unit] * copies + [right])
+    rs = synth.simulate_reads(g, 3.5, "hifi", seed=3, mu=9.3, sigma=0.2, min_len=8000)
+    with gzip.GzipFile(os.path.join(OUT, "tandem.fa.gz"), "wb", mtime=0) as f:
+        for i, sq in enumerate(rs.seqs):
+            f.write(b">%d %d 0.99\n%s\n" % (i + 1, sq.size, synth.codes_to_ascii(sq)))
+    for tag, argv in CASES_THIN:
+        out = os.path.join(OUT, tag + ".ovl")
+        refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", "--mode", "1", "-t", "3", *argv,
+                     *[os.path.join(OUT, f) for f in files_of(tag)], "-o", out])
+        print(tag, ul, copies, len(rs.seqs), os.path.getsize(out), os.path.getsize(out + ".bl"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "tandem":   # (only the anchor-thinning fixture)
+        return make_tandem()
     g = synth.make_genome(26000, seed=61, n_repeats=2, repeat_len=1200)
     rs = synth.simulate_reads(g, 22, "hifi", seed=62, mu=8.3, sigma=0.35, min_len=2200)
     seqs = list(rs.seqs)
@@ -71,6 +100,7 @@ def main():
             refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *mode, "-t", "3", *argv,
                          *[os.path.join(OUT, f) for f in files_of(tag)], "-o", out])
             print(tag, os.path.getsize(out), os.path.getsize(out + ".bl"))
+    make_tandem()
 
 
 if __name__ == "__main__":

@@ -165,7 +165,7 @@ def step2_mode0(lib, opt: MMOpt, tset, qsets, minide=0.05, minmatch=100, mid_occ
     return step2(lib, opt, tset, qsets, 0, minide, minmatch, mid_occ_frac)
 
 
-def step2(lib, opt: MMOpt, tset, qsets, mode=2, minide=0.05, minmatch=100, mid_occ_frac=2e-4, kn=17, wn=10, cn=20):
+def step2(lib, opt: MMOpt, tset, qsets, mode=2, minide=0.05, minmatch=100, mid_occ_frac=2e-4, kn=17, wn=10, cn=20, mid_occ_fixed=0):
     """`minimap2-nd --step 2 [--mode 0|2] target query...` with the oracle (mode 2 = the default, minimap2/options.c:56): returns
     (.ovl bytes incl. the 00 FF header, .bl text)."""
     lib.nd_mm_step2.argtypes = [C.POINTER(MMOpt), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int32, C.c_float, C.c_int, C.c_int32,
@@ -186,7 +186,7 @@ def step2(lib, opt: MMOpt, tset, qsets, mode=2, minide=0.05, minmatch=100, mid_o
             while True:
                 out = np.zeros(cap, dtype=np.uint8)
                 mo = C.c_int32(0)
-                n = lib.nd_mm_step2(C.byref(opt), mode, kn, wn, cn, np.float32(minide), minmatch, np.float32(mid_occ_frac), 0, tid.size, ptr(tc), ptr(to),
+                n = lib.nd_mm_step2(C.byref(opt), mode, kn, wn, cn, np.float32(minide), minmatch, np.float32(mid_occ_frac), int(mid_occ_fixed), tid.size, ptr(tc), ptr(to),
                                           ptr(tl), ptr(tid), qid.size, ptr(qc), ptr(qo), ptr(ql), ptr(qid), ptr(out), cap, C.byref(mo),
                                           ptr(prev), st)
                 if n >= 0:

@@ -204,10 +204,30 @@ def test_oracle_step2_matches_golden(lib, tag):
         qs = [b, a]
     mode = 2 if tag.endswith(".m2") else 1 if tag.endswith(".m1") else 0
     got, got_bl = M.step2(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, qs, mode, cn=50 if mode == 1 else 20)
-    lib.nd_mm_step2_unrestated.restype = C.c_int64
-    assert lib.nd_mm_step2_unrestated() == 0   # (no mapping of the fixture takes the branch of mm_chain_dp_nextdenovo that is not restated)
+    lib.nd_mm_step2_big_maps.restype = C.c_int64
+    assert lib.nd_mm_step2_big_maps() == 0   # (no mapping of these fixtures has the 100,000 anchors mm_chain_dp_nextdenovo thins: see below)
     assert got == open(os.path.join(OUT, tag + ".ovl"), "rb").read()
     assert got_bl == open(os.path.join(OUT, tag + ".ovl.bl")).read()
+
+
+def test_oracle_step2_anchor_thinning(lib, monkeypatch):
+    """mm_chain_dp_nextdenovo (minimap2/chain.c:185-226): --mode 1 chains its one-read-index mappings through it, and a mapping with
+    more than 100,000 anchors loses the anchors of crowded target positions before the DP.  tests/golden/step2/tandem.* is a read set
+    across a tandem array whose mappings have 300,000 and more; the compiled reference's bytes are reproduced WITH the restated
+    thinning and not without it (five of six random arrays behaved like this one when the fixture was chosen)."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_step2_golden import CASES_THIN, OUT
+    tag, argv = CASES_THIN[0]
+    a = _fasta_set(os.path.join(OUT, "tandem.fa.gz"))
+    opt = M.preset("ava-ont", True, k=17, w=17, minlen=1000, maxhan1=2000)
+    want, want_bl = open(os.path.join(OUT, tag + ".ovl"), "rb").read(), open(os.path.join(OUT, tag + ".ovl.bl")).read()
+    got, got_bl = M.step2(lib, opt, a, [a], 1, cn=50, mid_occ_fixed=1000)
+    lib.nd_mm_step2_big_maps.restype = C.c_int64
+    assert lib.nd_mm_step2_big_maps() >= 5
+    assert got == want and got_bl == want_bl
+    monkeypatch.setenv("ND_ORACLE_NO_THINNING", "1")
+    got0, got_bl0 = M.step2(lib, opt, a, [a], 1, cn=50, mid_occ_fixed=1000)
+    assert (got0, got_bl0) != (want, want_bl)
 
 
 def test_cigar_oracle_matches_golden_ovl(lib):

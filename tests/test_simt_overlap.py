@@ -135,13 +135,13 @@ def test_whole_stage_from_2bit_to_cns_fasta(interpreted, tmp_path):
     assert open(out + ".idx", "rb").read() == GS._golden("cns.default.fasta.idx", gz=True)
 
 
-@pytest.mark.parametrize("tag", ["ont.m2", "hifi.self.m2", "ont.m1"] + (["pb.m2", "ont.I.m2", "deep.m2"] if os.environ.get("NDGPU_SLOW_TESTS") else []))
+@pytest.mark.parametrize("tag", ["ont.m2", "hifi.self.m2", "ont.m1"] + (["pb.m2", "ont.I.m2", "deep.m2", "tandem.m1"] if os.environ.get("NDGPU_SLOW_TESTS") else []))
 def test_step2_with_the_realignment(interpreted, tmp_path, tag):
     """`--step 2` as nextDenovo writes it (no --mode: every marked candidate mapped again with the short k-mer sketch -- hits per
     read, wanted-target lists and nameless units through the seed kernels, provisional records out of K5, the bookkeeping on the
     host): the compiled reference's `.ovl` / `.bl` bytes through the command line."""
     import test_zz_gpu_step2 as S2
-    S2.run_case(tag, dict(S2.CASES_M2 + S2.CASES_M1)[tag], tmp_path)
+    S2.run_case(tag, dict(S2.CASES_M2 + S2.CASES_M1 + S2.CASES_THIN)[tag], tmp_path)
 
 
 _C_FAST = ("pb.sv.dvt.c",)   # (one of the nine golden runs: ~70 s under the interpreter; all nine run on the GPU)
