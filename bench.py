@@ -80,8 +80,9 @@ def kernel_models(st):
         "alg_bytes": st["seq_bases"] / 4.0 + st["d_steps"] / 8.0 + st["columns"] / 4.0,
         "formula": "seq_bases / 4 (operands) + d_steps / 8 (the path's move bit of every edit step) + columns / 4 (2-bit column kinds out)",
         "ms": st["traceback_ms"], "launches": st["traceback_launches"]}
-    m["lq_msa_kernel"] = {
-        "label": "K12 lq_msa (low-quality-region rounds: second MSA, DP and walk, one wavefront per pile)",
+    m["lq_score_kernel"] = {
+        "label": "K12 lq_links + lq_score (low-quality-region rounds: links per run of regions, then scores / best links / walk per pile; "
+                 "one HIP-event bracket over both, lq_score is ~85 % of it)",
         "alg_bytes": st["lq_aln_columns"] / 4.0 + st["lq_bases"] / 4.0 + float(st["lq_out"]),
         "formula": "lq_aln_columns / 4 (2-bit column kinds in) + lq_bases / 4 (2-bit candidate bases in) + lq_out (characters out)",
         "ms": st["lq_ms"], "launches": st["lq_launches"]}

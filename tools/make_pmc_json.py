@@ -15,7 +15,7 @@ import bench  # noqa: E402
 def main():
     table, steps, config = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
     note = sys.argv[4] if len(sys.argv) > 4 else os.path.relpath(table, ROOT)
-    keys = ("ond_forward_kernel", "ond_traceback_kernel", "lq_msa_kernel", "count_links_kernel", "score_seg_kernel<96")
+    keys = ("ond_forward_kernel", "ond_traceback_kernel", "count_links_kernel", "score_seg_kernel<96")
     kernels = {}
     for ln in open(table):
         mt = re.match(r"^(\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+([\d.]+)\s*$", ln)
