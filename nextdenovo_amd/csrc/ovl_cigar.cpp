@@ -1004,10 +1004,11 @@ extern "C" int64_t ndgpu_ovl_map_cigar(ndgpu_ovl_index *idx, const ndgpu_ovl_opt
         fprintf(stderr, "[ndgpu_overlap] -c with k > 28 (ava-hifi): the compiled reference aborts there; not built\n");
         return -1;
     }
-    if (aopt->q == aopt->q2 && aopt->e == aopt->e2) {
-        fprintf(stderr, "[ndgpu_overlap] -c with one gap piece (-O a,a -E b,b) takes ksw_extz2_sse in the reference; only the two-piece kernel is built\n");
-        return -1;
-    }
+    // One gap piece (-O a -E b: q == q2, e == e2): the reference takes ksw_extz2_sse there (minimap2/align.c:313-331).  With the four
+    // flag sets this path passes (EXTZ_ONLY | RIGHT | REV_CIGAR, APPROX_MAX, none, EXTZ_ONLY: align.c:697,733,745,764,821) that kernel
+    // and ksw_extd2_sse with two equal pieces return the same scores, end points and CIGARs -- the second piece never beats the first,
+    // so the two extra backtrack states never occur -- which tests/test_oracle_ksw2.py holds against the compiled ksw2_extz2_sse.c on
+    // 12,000 fuzzed problems (they differ under APPROX_DROP, which this path does not use).  The two-piece kernel serves both.
     Opt o;
     o.a = aopt->a, o.b = aopt->b, o.q = aopt->q, o.e = aopt->e, o.q2 = aopt->q2, o.e2 = aopt->e2, o.sc_ambi = aopt->sc_ambi, o.zdrop = aopt->zdrop;
     o.zdrop_inv = aopt->zdrop_inv, o.end_bonus = aopt->end_bonus, o.min_dp_max = aopt->min_dp_max, o.min_ksw_len = aopt->min_ksw_len;

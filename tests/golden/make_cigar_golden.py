@@ -33,6 +33,8 @@ CASES_C = [  # (file tag, preset, target, query, dual, extra argv); sets "seed"/
     ("pb.sv.dvt.c", "ava-pb", "sv", "svq", True, ("-c", "--dvt")),
     ("ont.sv.z200.c", "ava-ont", "sv", "svq", True, ("-c", "-z", "200,100", "-s", "120")),
     ("ont.sv.I150k.c", "ava-ont", "sv", "svq", True, ("-c", "-I", "150k")),   # a multi-part index: through the command line only
+    # one gap piece: the reference aligns with ksw_extz2_sse (minimap2/align.c:313-331)
+    ("ont.sv.O4E2.c", "ava-ont", "sv", "svq", True, ("-c", "-O", "4", "-E", "2")),
 ]
 
 

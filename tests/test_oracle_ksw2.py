@@ -83,3 +83,39 @@ def test_ll_oracle_matches_live_reference(oracle_lib):
     ref = C.CDLL(K.REF_LL)
     for i, p in enumerate(K.ll_problems(seed=11, n=1200)):
         assert K.call_ll_oracle(oracle_lib, p) == K.call_ll_ref(ref, p), i
+
+
+REF_Z = os.path.join(os.path.dirname(K.REF), "libksw2zref.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_Z), reason="oracle/_ref not built")
+def test_one_gap_piece_is_the_two_piece_kernel_with_equal_pieces(oracle_lib):
+    """`-c -O a -E b` (q == q2, e == e2): the reference aligns with ksw_extz2_sse (minimap2/align.c:313-331), the product with its
+    two-piece kernel.  Under the four flag sets the -c path passes (align.c:697,733,745,764,821) the compiled ksw2_extz2_sse.c and the
+    two-piece restatement with equal pieces return the same scores, end points and CIGARs on fuzzed problems.  (They differ under
+    KSW_EZ_APPROX_DROP -- the first anti-diagonal's z-drop update -- which that path never sets.)"""
+    refz = C.CDLL(REF_Z)
+    fz = refz.ksw_extz2_sse
+    fz.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int8, C.c_void_p, C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int, C.c_int,
+                   C.POINTER(K.Extz)]
+    fz.restype = None
+    free = C.CDLL(None).free
+
+    def call_z(p, go, ge, flag):
+        ez = K.Extz()
+        q, t = np.ascontiguousarray(p["q"], dtype=np.uint8), np.ascontiguousarray(p["t"], dtype=np.uint8)
+        fz(None, q.size, q.ctypes.data, t.size, t.ctypes.data, 5, p["mat"].ctypes.data, go, ge, p["w"], p["zdrop"], p["end_bonus"], flag, C.byref(ez))
+        d = dict(max=ez.max_zd & 0x7fffffff, zdropped=ez.max_zd >> 31, max_q=ez.max_q, max_t=ez.max_t, mqe=ez.mqe, mqe_t=ez.mqe_t, mte=ez.mte,
+                 mte_q=ez.mte_q, score=ez.score, n_cigar=ez.n_cigar, reach_end=ez.reach_end)
+        cig = [ez.cigar[i] for i in range(ez.n_cigar)] if ez.n_cigar else []
+        if ez.cigar:
+            free(ez.cigar)
+        return K._as_tuple(d, cig)
+    flags = [K.F_EXTZ_ONLY | K.F_RIGHT | K.F_REV_CIGAR, K.F_APPROX_MAX, 0, K.F_EXTZ_ONLY]
+    n = 0
+    for i, p in enumerate(K.problems(41, 3000, max_len=500)):
+        go, ge = p["gaps"][0], p["gaps"][1]
+        fl = flags[i % 4]
+        assert call_z(p, go, ge, fl) == K.call_oracle(oracle_lib, p["q"], p["t"], p["mat"], go, ge, go, ge, p["w"], p["zdrop"], p["end_bonus"], fl), i
+        n += 1
+    assert n == 3000

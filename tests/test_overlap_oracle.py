@@ -240,3 +240,15 @@ def test_cigar_oracle_matches_golden_ovl(lib):
         want = f.read()
     got, _ = M.step1_cigar(lib, M.preset(preset, dual, dvt=1), M.aln_opt(), M.load_set(G.set_path(t)), M.load_set(G.set_path(q)))
     assert got == want
+
+
+@pytest.mark.skipif(not os.environ.get("NDGPU_SLOW_TESTS"), reason="~40 s; the kernel-level equivalence is in test_oracle_ksw2.py")
+def test_cigar_oracle_one_gap_piece(lib):
+    """`-c -O 4 -E 2`: the reference binary aligned this golden run with ksw_extz2_sse; the oracle's two-piece kernel with equal
+    pieces reproduces its bytes."""
+    import make_cigar_golden as G
+    tag, preset, t, q, dual, extra = [c for c in G.CASES_C if c[0] == "ont.sv.O4E2.c"][0]
+    with open(os.path.join(G.OUT, tag + ".ovl"), "rb") as f:
+        want = f.read()
+    got, _ = M.step1_cigar(lib, M.preset(preset, dual), M.aln_opt(q=4, e=2, q2=4, e2=2), M.load_set(G.set_path(t)), M.load_set(G.set_path(q)))
+    assert got == want

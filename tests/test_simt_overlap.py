@@ -144,7 +144,7 @@ def test_step2_with_the_realignment(interpreted, tmp_path, tag):
     S2.run_case(tag, dict(S2.CASES_M2 + S2.CASES_M1 + S2.CASES_THIN)[tag], tmp_path)
 
 
-_C_FAST = ("pb.sv.dvt.c",)   # (one of the nine golden runs: ~70 s under the interpreter; all nine run on the GPU)
+_C_FAST = ("pb.sv.dvt.c",) + (("ont.sv.O4E2.c",) if os.environ.get("NDGPU_SLOW_TESTS") else ())   # (~70 s each under the interpreter; all ten golden runs run on the GPU; O4E2 = one gap piece)
 
 
 @pytest.mark.parametrize("tag", _C_FAST)

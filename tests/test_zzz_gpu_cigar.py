@@ -33,6 +33,12 @@ def dev_opts(preset, dual, extra):
         ao.zdrop, ao.zdrop_inv = int(z[0]), int(z[-1])
     if "-s" in extra:
         ao.min_dp_max = int(extra[extra.index("-s") + 1])
+    if "-O" in extra:   # minimap2/main.c:356-358: one value sets both gap pieces
+        v = extra[extra.index("-O") + 1].split(",")
+        ao.q, ao.q2 = int(v[0]), int(v[-1])
+    if "-E" in extra:
+        v = extra[extra.index("-E") + 1].split(",")
+        ao.e, ao.e2 = int(v[0]), int(v[-1])
     if "--cap-sw-mem" in extra:
         ao.max_sw_mat = int(extra[extra.index("--cap-sw-mem") + 1])
     return o, ao
