@@ -307,7 +307,8 @@ int64_t ndgpu_ovl_map_chains(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, int
  * mm_filter_regs, mm_hit_sort) between chaining and the writer's filter (minimap2/map.c:484-503, 1297-1304).  The records carry the
  * alignments' coordinates and exact match counts.  t_words / t_word_off / t_lens / t_ids = the reads the index was built from (the
  * caller's arrays of ndgpu_ovl_index_create).  opt->step must be 1, opt->mode not 3, k <= 28 (the compiled reference aborts on
- * ava-hifi -c), two different gap pieces (ksw_extd2_sse; with q == q2 and e == e2 the reference takes ksw_extz2_sse, not built).
+ * ava-hifi -c);
+ * with q == q2 and e == e2 the reference takes ksw_extz2_sse, which equals the two-piece kernel with equal pieces under the flags this path passes).
  * Every alignment runs on the device (one wavefront per problem, csrc/ksw2_kernels.hip); the joining of CIGARs, the z-drop
  * bookkeeping and the seed filters are host logic.  *recs is malloc'd (ndgpu_ovl_free).  Returns the record count, < 0 on error. */
 int64_t ndgpu_ovl_map_cigar(ndgpu_ovl_index *idx, const ndgpu_ovl_opt *opt, const ndgpu_ovl_aln_opt *aopt, int32_t mid_occ,

@@ -104,27 +104,27 @@ def iter_chunks_files(paths, threads: int = 0, depth: int = 4, **kw):
             yield from iter_chunks(p, **kw)
         return
     queues = [queue.Queue(maxsize=depth) for _ in paths]
-    gate = threading.Semaphore(threads)   # files open at the same time
     stop = threading.Event()
 
     def reader(i):
         try:
-            with gate:
-                for chunk in iter_chunks(paths[i], **kw):
-                    while not stop.is_set():
-                        try:
-                            queues[i].put(chunk, timeout=0.2)
-                            break
-                        except queue.Full:
-                            pass
-                    if stop.is_set():
-                        return
+            for chunk in iter_chunks(paths[i], **kw):
+                while not stop.is_set():
+                    try:
+                        queues[i].put(chunk, timeout=0.2)
+                        break
+                    except queue.Full:
+                        pass
+                if stop.is_set():
+                    return
             queues[i].put(None)
         except BaseException as e:   # handed to the consumer
             queues[i].put(e)
-
+    # `threads` files are open at a time, and always the lowest unfinished ones: the reader of file i + threads starts when file i has
+    # been consumed.  (A semaphore any reader may take let readers of later files hold every permit while they waited on their full
+    # queues, and the reader of the file the consumer was waiting for never got one.)
     workers = [threading.Thread(target=reader, args=(i,), daemon=True) for i in range(len(paths))]
-    for w in workers:
+    for w in workers[:threads]:
         w.start()
     try:
         for i in range(len(paths)):
@@ -135,6 +135,8 @@ def iter_chunks_files(paths, threads: int = 0, depth: int = 4, **kw):
                 if isinstance(item, BaseException):
                     raise item
                 yield item
+            if i + threads < len(paths):
+                workers[i + threads].start()
     finally:
         stop.set()
 

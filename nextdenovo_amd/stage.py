@@ -251,5 +251,12 @@ class Shard:
             from . import api
             # (+ a margin for what the overlap stage takes outside its block pool: scratch of spilling kernels, rocPRIM, the runtime)
             _live, cached, peak = overlap.pool_bytes()
-            api.reserve_device_memory(max(0, peak - cached) + max(32 << 30, peak // 4))
+            # (the margin scales with the device: 32 GB on a 288 GB MI355X, an eighth of the memory on a smaller part -- a fixed 32 GB
+            # left the consensus stage its 4 GB floor on anything below ~50 GB)
+            try:
+                import torch
+                total = torch.cuda.mem_get_info()[1] if torch.cuda.is_available() else 288 << 30
+            except Exception:
+                total = 288 << 30
+            api.reserve_device_memory(max(0, peak - cached) + max(min(32 << 30, total // 8), peak // 4))
         return sub, off, seeds, len(bl)
