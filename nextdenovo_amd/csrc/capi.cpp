@@ -349,7 +349,11 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
             est[k] = e + e / 6;
             total += est[k];
         }
-        int per_ctx = 2;  // (measured on config 2: 1, 2, 3, 4, 6 per context = 1147, 1095, 1181, 1269, 1376 ms per step)
+        // (measured on config 2, 1,666 piles: 1, 2, 3, 4, 6 per context = 1147, 1095, 1181, 1269, 1376 ms per step in round 2; 1 and 2
+        // within noise since.  A small call -- the share of one rank of 4 or 8 -- is a matter of latency, not of filling the device:
+        // every sub-batch of a context is another pass through the same dependent phases, and with one per context the 210 piles of a
+        // rank of 8 take 170 ms instead of 262, the 407 of a rank of 4 255 instead of 320: profiles/r04_rank_share_config2.txt)
+        int per_ctx = n_piles >= 1024 ? 2 : 1;
         if (const char *e = getenv("NDGPU_SUBBATCHES_PER_CONTEXT")) per_ctx = std::max(1, atoi(e));
         const uint64_t piece = std::min<uint64_t>(tag_budget, std::max<uint64_t>(total / (uint64_t)(drivers * per_ctx) + 1, 2000000ull));
         uint64_t acc = 0;
