@@ -107,13 +107,7 @@ class Exchange:
         return os.path.join(self.dir, "step%06d.job%05d.npy" % (step, k))
 
     def begin_step(self):
-        self.step += 1
-        for f in os.listdir(self.dir):   # this rank's files of two steps ago: every reader is past them
-            if f.endswith(".r%d.npy" % self.rank) and int(f[4:10]) + 2 <= self.step:
-                try:
-                    os.unlink(os.path.join(self.dir, f))
-                except OSError:
-                    pass
+        self.step += 1   # (a file is removed by its one reader once it has been read: the writer may be steps ahead of the reader)
 
     def put(self, k, recs):
         final = self._path(self.step, k)[:-4] + ".r%d.npy" % self.rank
@@ -134,7 +128,12 @@ class Exchange:
             time.sleep(0.0005)
         self.stats["wait_s"] += time.perf_counter() - t0
         self.stats["received"] += 1
-        return np.load(path)
+        recs = np.load(path)
+        try:
+            os.unlink(path)   # (a seed x seed job has exactly one other reader)
+        except OSError:
+            pass
+        return recs
 
 
 class Shard:
