@@ -195,11 +195,11 @@ def test_every_failed_device_operation_surfaces(interpreted, monkeypatch):
         try:
             got = job()
         except MemoryError:
-            k += 1
+            k += 1 if k < 12 else 3   # (every operation of the first dozen, every third after: the job has ~110)
             continue
         assert all(np.array_equal(a, b) for a, b in zip(got[:2], want[:2])) and got[2] == want[2]
         break
-    assert k > 60, k
+    assert k > 60, k   # (the first operation that does not exist lies beyond the job's ~110)
     monkeypatch.delenv("NDGPU_OVL_FAIL_AT")
     again = job()
     assert all(np.array_equal(a, b) for a, b in zip(again[:2], want[:2])) and again[2] == want[2]
