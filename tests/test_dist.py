@@ -136,3 +136,27 @@ def test_two_ranks_hand_the_mirror_job_over(host_harness, oracle_lib, tmp_path):
     both = dict(rec0)
     both.update(rec1)
     assert both == single and len(single) >= 6
+
+
+def test_a_late_owner_does_not_stop_the_step(host_harness, oracle_lib, tmp_path):
+    """The hand-over never blocks a step for good: a job whose owner does not deliver within the timeout is computed by the rank that
+    needs it (same orientation, same records), and the count says so."""
+    import ctypes as C
+
+    import numpy as np
+
+    import stage_util
+    from nextdenovo_amd import stage, synth
+    olib = C.CDLL(os.path.join(ROOT, "oracle", "libndoracle.so"))
+    g = synth.make_genome(30000, seed=42, n_repeats=0)
+    rs = synth.simulate_reads(g, 22, "ont", seed=43, mu=8.0, sigma=0.35)
+    words, word_off, lens = synth.pack_db(rs)
+
+    def shard(ex):
+        return stage.Shard(words, word_off, lens, preset="ava-ont", seed_cutoff=1000, read_cutoff=500, n_seed_files=2, sort_k=17,
+                           blacklist=False, backend=stage_util.OracleBackend(olib, "ava-ont"), exchange=ex)
+    want = shard(None).piles(1)
+    ex = stage.Exchange(str(tmp_path / "nobody_writes_here"), 1, timeout_s=0.3)   # rank 1 of 2: the mirror (0, seed 1) belongs to rank 0
+    got = shard(ex).piles(1)
+    assert ex.stats["recomputed"] == 1 and ex.stats["received"] == 0 and ex.stats["sent"] == 0
+    assert all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3])) and got[3] == want[3]

@@ -53,6 +53,7 @@ P
             db="$(ls "$out"/stats/*results.db | head -1)"
             python tools/rocprof_summary.py "$db" > "$out/kernel_stats.txt" 2>> "$out/prof.log"; head -30 "$out/kernel_stats.txt"
             python tools/rocprof_timeline.py "$db" > "$out/timeline.txt" 2>> "$out/prof.log"; rm -rf "$out/stats" ;;
+    smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | tail -3 ;;
     *) echo "unknown stage $s" ;;
   esac
   echo "   ($s: $(( $(date +%s) - t0 )) s)"
