@@ -1066,16 +1066,59 @@ size_t sort_job_bytes() { return sizeof(SortJob); }
 
 constexpr int kRing = 8192; // > max_chain_iter (5000)
 
+// Wave-wide scans with data-parallel-primitive moves (row_shr 1 / 2 / 3 of the input, row_shr 4 and 8 of the partial results, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): seven dependent steps of a few cycles each.  K4's inner loop ran
+// them as 19 ds_bpermute shuffles until round 4 -- ~100 cycles apiece on a chain that is walked once per anchor: more than half of the
+// ~1.5 us an anchor of the longest slab cost.  A lane whose source lies outside its row (or is masked off) receives the identity.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_move(int identity, int src)
+{
+	return __builtin_amdgcn_update_dpp(identity, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+__device__ __forceinline__ int wave_shr1_i32(int first, int v) // lane l gets v of lane l - 1, lane 0 gets `first`
+{
+	return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) // (lane 0's result is the caller's to set)
+{
+	const uint32_t lo = (uint32_t)wave_shr1_i32(0, (int)(uint32_t)v), hi = (uint32_t)wave_shr1_i32(0, (int)(uint32_t)(v >> 32));
+	return (uint64_t)hi << 32 | lo;
+}
+
 __device__ __forceinline__ int wave_excl_max(int v, int lane)
 {
 	// inclusive max-scan, then shift by one lane
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		int o = __shfl_up(v, d, 64);
-		if (lane >= d) v = v > o ? v : o;
-	}
-	int e = __shfl_up(v, 1, 64);
-	return lane == 0 ? INT32_MIN : e;
+	const int id = INT32_MIN;
+	int r = v, t;
+	t = dpp_move<0x111, 0xf, 0xf>(id, v); r = r > t ? r : t;
+	t = dpp_move<0x112, 0xf, 0xf>(id, v); r = r > t ? r : t;
+	t = dpp_move<0x113, 0xf, 0xf>(id, v); r = r > t ? r : t;
+	t = dpp_move<0x114, 0xf, 0xe>(id, r); r = r > t ? r : t;
+	t = dpp_move<0x118, 0xf, 0xc>(id, r); r = r > t ? r : t;
+	t = dpp_move<0x142, 0xa, 0xf>(id, r); r = r > t ? r : t;
+	t = dpp_move<0x143, 0xc, 0xf>(id, r); r = r > t ? r : t;
+	(void)lane;
+	return wave_shr1_i32(INT32_MIN, r);
+}
+
+// inclusive scan of the maps x -> max(x + a, b) under composition (lane l's result = the maps of lanes 0..l applied in lane order)
+__device__ __forceinline__ void wave_incl_compose(int &a, int &b)
+{
+	const int ida = 0, idb = INT32_MIN / 2;
+	const int a0 = a, b0 = b;
+	auto after = [&](int oa, int ob) { // (a, b) after (oa, ob)
+		const int nb = ob + a > b ? ob + a : b;
+		a = oa + a, b = nb;
+	};
+	after(dpp_move<0x111, 0xf, 0xf>(ida, a0), dpp_move<0x111, 0xf, 0xf>(idb, b0));
+	after(dpp_move<0x112, 0xf, 0xf>(ida, a0), dpp_move<0x112, 0xf, 0xf>(idb, b0));
+	after(dpp_move<0x113, 0xf, 0xf>(ida, a0), dpp_move<0x113, 0xf, 0xf>(idb, b0));
+	{ const int oa = dpp_move<0x114, 0xf, 0xe>(ida, a), ob = dpp_move<0x114, 0xf, 0xe>(idb, b); after(oa, ob); }
+	{ const int oa = dpp_move<0x118, 0xf, 0xc>(ida, a), ob = dpp_move<0x118, 0xf, 0xc>(idb, b); after(oa, ob); }
+	{ const int oa = dpp_move<0x142, 0xa, 0xf>(ida, a), ob = dpp_move<0x142, 0xa, 0xf>(idb, b); after(oa, ob); }
+	{ const int oa = dpp_move<0x143, 0xc, 0xf>(ida, a), ob = dpp_move<0x143, 0xc, 0xf>(idb, b); after(oa, ob); }
 }
 
 // The 64 most recent anchors (x, query position, f, p, v) ride in registers, lane l = anchor i-1-l, and are
@@ -1121,8 +1164,8 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 		const int32_t qi = (int32_t)yi, span = (int32_t)(yi >> 32 & 0xff);
 		if (ri == ~0ull) {  // an anchor the thinning dropped (chain.c:231-234): f = p = v = -1, and nobody chains through it
 			if (lane == 0) F[i] = -1, Pp[i] = -1, V[i] = -1, ring[i & (kRing - 1)] = (uint16_t)i;
-			wx = __shfl_up(wx, 1, 64), wq = __shfl_up(wq, 1, 64), wf = __shfl_up(wf, 1, 64), wp = __shfl_up(wp, 1, 64);
-			wv = __shfl_up(wv, 1, 64);
+			wx = wave_shr1_u64(wx), wq = wave_shr1_i32(0, wq), wf = wave_shr1_i32(0, wf), wp = wave_shr1_i32(0, wp);
+			wv = wave_shr1_i32(0, wv);
 			if (lane == 0) wx = ri, wq = qi, wf = -1, wp = -1, wv = -1;
 			__builtin_amdgcn_wave_barrier();
 			continue;
@@ -1175,14 +1218,7 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 			int a = 0, b = INT32_MIN / 2;
 			if (newmax) a = -1, b = 0;
 			else if (marked) a = 1;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const int oa = __shfl_up(a, d, 64), ob = __shfl_up(b, d, 64);
-				if (lane >= d) { // (a,b) after (oa,ob)
-					const int nb = ob + a > b ? ob + a : b;
-					a = oa + a, b = nb;
-				}
-			}
+			wave_incl_compose(a, b);
 			const int after = skipped + a > b ? skipped + a : b;
 			const bool exits = marked && !newmax && after > P.max_skip;
 			const unsigned long long exit_mask = __ballot(exits);
@@ -1212,8 +1248,8 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 		}
 		if (lane == 0) F[i] = best, Pp[i] = best_j, V[i] = peak, ring[i & (kRing - 1)] = (uint16_t)i;
 		// shift the register window by one anchor
-		wx = __shfl_up(wx, 1, 64), wq = __shfl_up(wq, 1, 64), wf = __shfl_up(wf, 1, 64), wp = __shfl_up(wp, 1, 64);
-		wv = __shfl_up(wv, 1, 64);
+		wx = wave_shr1_u64(wx), wq = wave_shr1_i32(0, wq), wf = wave_shr1_i32(0, wf), wp = wave_shr1_i32(0, wp);
+		wv = wave_shr1_i32(0, wv);
 		if (lane == 0) wx = ri, wq = qi, wf = best, wp = best_j, wv = peak;
 		__builtin_amdgcn_wave_barrier();
 	}
