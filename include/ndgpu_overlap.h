@@ -115,6 +115,12 @@ int ndgpu_ovl_last_error(void);
  * NDGPU_OVL_POOL_GB if set); this releases them.
  * Returns the bytes released. */
 uint64_t ndgpu_ovl_trim(void);
+/* Declare a host buffer of 2-bit read words (the `words` array of the calls below, as stored in a .2bit file) resident: it is uploaded once,
+ * and every later call whose `words` lie inside it works on the device copy instead of uploading them again (index build and query side of
+ * every raw_align job name the same reads).  The buffer must stay valid and unchanged until ndgpu_ovl_words_release().  Additive: the
+ * reference has no counterpart (its reads live in host memory, lib/bseq.c).  Returns 0, -1 on failure (out of device memory). */
+int ndgpu_ovl_words_resident(const uint32_t *words, uint64_t n_words);
+void ndgpu_ovl_words_release(const uint32_t *words);
 /* out[0] = device bytes the library has in use now, out[1] = cached for reuse, out[2] = the most it ever had in use at once -- what a
  * caller that runs another memory-hungry stage on the same device between two calls should leave free (out[2] - out[1]). */
 void ndgpu_ovl_pool_bytes(uint64_t out[3]);

@@ -279,11 +279,27 @@ struct EvTimer {
 	double stop() { HIP_OK(hipEventRecord(b, s)); HIP_OK(hipEventSynchronize(b)); float ms = 0; HIP_OK(hipEventElapsedTime(&ms, a, b)); return ms; }
 };
 
+// Resident read words (ndgpu_ovl_words_resident): a host buffer of 2-bit words the caller has declared resident is uploaded once;
+// every read set that names words inside it afterwards works on the device copy.  The stage maps the same reads step after step and job
+// after job -- index build and query side of every job upload their words, 2 x 57.5 MB per config-2 step from pageable memory -- and
+// the metric is defined with the inputs resident in HBM.
+struct ResidentWords { const uint32_t *host; uint64_t n_words; uint32_t *dev; };
+static std::mutex g_res_mu;
+static std::vector<ResidentWords> g_resident;
+static const uint32_t *resident_view(const uint32_t *w, uint64_t n_words)
+{
+	std::lock_guard<std::mutex> g(g_res_mu);
+	for (const ResidentWords &r : g_resident)
+		if (w >= r.host && w + n_words <= r.host + r.n_words) return r.dev + (w - r.host);
+	return nullptr;
+}
+
 struct ReadSetDev {
 	uint32_t n = 0;
 	uint64_t bases = 0;
 	uint32_t max_len = 0;
 	DevBuf<uint32_t> words, len, id, order;
+	const uint32_t *wp = nullptr;   // the read words on the device: `words`, or a view into a resident copy
 	DevBuf<uint64_t> woff, namekey;
 	std::vector<uint32_t> h_len;
 	void upload(uint32_t n_reads, const uint32_t *w, uint64_t n_words, const uint64_t *off, const uint32_t *lens, const uint32_t *ids,
@@ -291,7 +307,8 @@ struct ReadSetDev {
 	{
 		n = n_reads;
 		h_len.assign(lens, lens + n_reads);
-		words.alloc(n_words + 4); words.upload(w, n_words, s);
+		wp = resident_view(w, n_words);
+		if (!wp) { words.alloc(n_words + 4); words.upload(w, n_words, s); wp = words.p; }
 		woff.alloc(n); woff.upload(off, n, s);
 		len.alloc(n); len.upload(lens, n, s);
 		id.alloc(n); id.upload(ids, n, s);
@@ -393,11 +410,11 @@ struct Engine {
 			roff.alloc(R.n + 1); roff.upload(h_roff.data(), R.n + 1, stream);
 			sym.alloc(acc + R.n + 1); rstart.alloc(acc + R.n + 1); n_sym_d.alloc(R.n + 1);
 			n_sym_d.zero(stream);
-			launch_run_compact(false, R.words.p, R.woff.p, R.len.p, d_tiles.p, nt, nullptr, d_first.p, roff.p, cnt.p, sym.p, rstart.p,
+			launch_run_compact(false, R.wp, R.woff.p, R.len.p, d_tiles.p, nt, nullptr, d_first.p, roff.p, cnt.p, sym.p, rstart.p,
 			                   n_sym_d.p, stream);
 			DevBuf<uint64_t> prefix(nt + 1);
 			exscan(cnt.p, prefix.p, nt + 1);
-			launch_run_compact(true, R.words.p, R.woff.p, R.len.p, d_tiles.p, nt, prefix.p, d_first.p, roff.p, cnt.p, sym.p, rstart.p,
+			launch_run_compact(true, R.wp, R.woff.p, R.len.p, d_tiles.p, nt, prefix.p, d_first.p, roff.p, cnt.p, sym.p, rstart.p,
 			                   n_sym_d.p, stream);
 			h_nsym.resize(R.n);
 			n_sym_d.download(h_nsym.data(), R.n, stream);
@@ -411,7 +428,7 @@ struct Engine {
 		DevBuf<uint32_t> d_first(R.n + 1), cnt(nt + 1);
 		d_first.upload(first.data(), R.n + 1, stream);
 		cnt.zero(stream);
-		launch_sketch_tiles(false, P.hpc != 0, R.words.p, R.woff.p, R.len.p, sym.p, rstart.p, roff.p, n_sym_d.p, d_tiles.p, nt, P, rid_is_index,
+		launch_sketch_tiles(false, P.hpc != 0, R.wp, R.woff.p, R.len.p, sym.p, rstart.p, roff.p, n_sym_d.p, d_tiles.p, nt, P, rid_is_index,
 		                    nullptr, cnt.p, nullptr, nullptr, nullptr, stream);
 		DevBuf<uint64_t> tile_off(nt + 1);
 		exscan(cnt.p, tile_off.p, nt + 1);
@@ -421,7 +438,7 @@ struct Engine {
 		out.n = total;
 		out.x.alloc(total + 1); out.y.alloc(total + 1);
 		if (want_read) out.read.alloc(total + 1);
-		launch_sketch_tiles(true, P.hpc != 0, R.words.p, R.woff.p, R.len.p, sym.p, rstart.p, roff.p, n_sym_d.p, d_tiles.p, nt, P, rid_is_index,
+		launch_sketch_tiles(true, P.hpc != 0, R.wp, R.woff.p, R.len.p, sym.p, rstart.p, roff.p, n_sym_d.p, d_tiles.p, nt, P, rid_is_index,
 		                    tile_off.p, cnt.p, out.x.p, out.y.p, want_read ? out.read.p : nullptr, stream);
 		out.off.alloc(R.n + 1);
 		launch_gather_u64(tile_off.p, d_first.p, R.n + 1, out.off.p, stream);
@@ -438,7 +455,7 @@ struct Engine {
 		cnt.zero(stream);
 		EvTimer tm(stream);
 		tm.start();
-		launch_sketch(false, R.words.p, R.woff.p, R.len.p, R.order.p, R.n, P, rid_is_index, nullptr, nullptr, nullptr, nullptr, cnt.p, stream);
+		launch_sketch(false, R.wp, R.woff.p, R.len.p, R.order.p, R.n, P, rid_is_index, nullptr, nullptr, nullptr, nullptr, cnt.p, stream);
 		out.off.alloc(R.n + 1);
 		size_t tb = 0;
 		exscan_u32_to_u64(nullptr, tb, cnt.p, out.off.p, R.n + 1, stream);
@@ -449,7 +466,7 @@ struct Engine {
 		out.n = total;
 		out.x.alloc(total + 1); out.y.alloc(total + 1);
 		if (want_read) out.read.alloc(total + 1);
-		launch_sketch(true, R.words.p, R.woff.p, R.len.p, R.order.p, R.n, P, rid_is_index, out.off.p, out.x.p, out.y.p,
+		launch_sketch(true, R.wp, R.woff.p, R.len.p, R.order.p, R.n, P, rid_is_index, out.off.p, out.x.p, out.y.p,
 		              want_read ? out.read.p : nullptr, nullptr, stream);
 		HIP_OK(hipGetLastError());
 		st.sketch_ms += tm.stop();
@@ -818,7 +835,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 				const uint64_t ints = h_off[t1] - h_off[t0];
 				if (fr.n < ints + 1) fr.alloc(ints + 1);
 				if (ints) HIP_OK(hipMemsetAsync(fr.p, 0, ints * sizeof(int32_t), stream));
-				launch_ext_ends(dense.p, t0, t1, Q.words.p, Q.woff.p, Q.len.p, T.words.p, T.woff.p, T.len.p, P, fr_off.p, h_off[t0], fr.p,
+				launch_ext_ends(dense.p, t0, t1, Q.wp, Q.woff.p, Q.len.p, T.wp, T.woff.p, T.len.p, P, fr_off.p, h_off[t0], fr.p,
 				                ext_x.p, ext_y.p, stream);
 				++st.ext_launches;
 				t0 = t1;
@@ -1137,6 +1154,41 @@ void ndgpu_ovl_pool_bytes(uint64_t out[3]) { ndovl::pool_bytes(out); }
 void ndgpu_ovl_pool_calls(uint64_t out[2], int reset) { ndovl::pool_calls(out, reset); }
 
 // release the device blocks the library keeps cached between calls (returns the bytes released)
+int ndgpu_ovl_words_resident(const uint32_t *words, uint64_t n_words)
+{
+	if (!words || !n_words) return -1;
+	try {
+		int device = 0;
+		if (const char *d = getenv("NDGPU_DEVICE")) device = atoi(d);
+		HIP_OK(hipSetDevice(device));
+		{
+			std::lock_guard<std::mutex> g(ndovl::g_res_mu);
+			for (const ndovl::ResidentWords &r : ndovl::g_resident)
+				if (r.host == words && r.n_words == n_words) return 0;
+		}
+		uint32_t *dev = (uint32_t*)ndovl::pool_alloc((n_words + 8) * sizeof(uint32_t));
+		HIP_OK(hipMemcpy(dev, words, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+		HIP_OK(hipMemset(dev + n_words, 0, 8 * sizeof(uint32_t)));
+		std::lock_guard<std::mutex> g(ndovl::g_res_mu);
+		ndovl::g_resident.push_back(ndovl::ResidentWords{words, n_words, dev});
+		return 0;
+	} catch (...) {
+		return -1;
+	}
+}
+
+void ndgpu_ovl_words_release(const uint32_t *words)
+{
+	std::lock_guard<std::mutex> g(ndovl::g_res_mu);
+	for (size_t i = 0; i < ndovl::g_resident.size(); ++i)
+		if (ndovl::g_resident[i].host == words) {
+			(void)hipDeviceSynchronize();
+			ndovl::pool_free(ndovl::g_resident[i].dev);
+			ndovl::g_resident.erase(ndovl::g_resident.begin() + (long)i);
+			return;
+		}
+}
+
 uint64_t ndgpu_ovl_trim(void)
 {
 	const uint64_t b = ndovl::pool_cached_bytes();

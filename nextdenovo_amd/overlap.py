@@ -326,6 +326,23 @@ def pool_calls(reset: bool = False):
     return int(out[0]), out[1] * 1e-9
 
 
+def words_resident(words: np.ndarray) -> None:
+    """Upload a read set's 2-bit words once (ndgpu_ovl_words_resident): later calls that name words inside this array use the device
+    copy.  The array must stay alive and unchanged until words_release(words)."""
+    lib = load()
+    lib.ndgpu_ovl_words_resident.argtypes = [C.c_void_p, C.c_uint64]
+    lib.ndgpu_ovl_words_resident.restype = C.c_int
+    if lib.ndgpu_ovl_words_resident(_ptr(words), words.size) != 0:
+        raise _fail(lib, "ndgpu_ovl_words_resident failed")
+
+
+def words_release(words: np.ndarray) -> None:
+    lib = load()
+    lib.ndgpu_ovl_words_release.argtypes = [C.c_void_p]
+    lib.ndgpu_ovl_words_release.restype = None
+    lib.ndgpu_ovl_words_release(_ptr(words))
+
+
 def trim() -> int:
     """Release the device blocks the overlap library keeps cached between calls (ndgpu_ovl_trim)."""
     lib = load()

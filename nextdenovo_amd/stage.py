@@ -160,6 +160,23 @@ class Shard:
         # tests plug a CPU backend built from oracle/ here (same two calls); the product has the device backend only
         self.backend = backend if backend is not None else DeviceBackend(self.opt)
         self.exchange = exchange   # None: every job this seed file needs is computed here
+        # the reads are mapped step after step and job after job: their words go to the device once (like the consensus read DB),
+        # not with every index build and every query batch
+        self._resident = False
+        if isinstance(self.backend, DeviceBackend):
+            overlap.words_resident(self.words)
+            self._resident = True
+
+    def close(self):
+        if self._resident:
+            overlap.words_release(self.words)
+            self._resident = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _set(self, ids):
         return overlap.ReadSet(ids, self.lens[ids], self.words, self.word_off[ids])
