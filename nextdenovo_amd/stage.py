@@ -163,7 +163,7 @@ class Shard:
         # the reads are mapped step after step and job after job: their words go to the device once (like the consensus read DB),
         # not with every index build and every query batch
         self._resident = False
-        if isinstance(self.backend, DeviceBackend):
+        if isinstance(self.backend, DeviceBackend) and not os.environ.get("NDGPU_OVL_NO_RESIDENT"):   # (the switch: an A/B knob)
             overlap.words_resident(self.words)
             self._resident = True
 
