@@ -923,7 +923,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
     (void)n;
 }
 
-// Low-quality-region rounds of a batch of piles on the device: K7 / K8a over every (row, region) alignment, then K12 (lq_msa:
+// Low-quality-region rounds of a batch of piles on the device: K7 / K8a over every (row, region) alignment, then K12 (lq_links + lq_score:
 // linked pseudo-seed, second MSA, DP, walk) -- the column streams stay in HBM, what comes back is each pile's walk string.
 // A round the kernel declines (r->ok stays false) is left to the caller's host path.
 constexpr uint32_t kLenClasses = 16384;  // 64-base length classes of the longest-first launch order (run_main); the last one holds >= 1 Mb
@@ -972,7 +972,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         }
         uint64_t link_len = 1, ins_cap = 0;
         for (uint32_t g = 0; g < nr; g++) link_len += (uint64_t)R.pieces[g].sl + 1;
-        // K12 is one wavefront per pile, ~2 us per cell row, and its launch lasts as long as its longest pile: a pile whose
+        // K12b is one wavefront per pile, ~1 us per cell row, and its launch lasts as long as its longest pile: a pile whose
         // low-quality regions add up to tens of thousands of columns (repeat-rich genomes: config 3 had K12 launches of 250 ms)
         // is faster on a host core, next to the others -- it is left to the host path before anything is laid out for it
         static const uint64_t max_cols = getenv("NDGPU_K12_MAX_COLUMNS") ? strtoull(getenv("NDGPU_K12_MAX_COLUMNS"), nullptr, 10) : kLqMaxColumns;  // (test hook)
