@@ -1,40 +1,60 @@
 #!/bin/bash
-# One GPU-box session, in stages, so that a round's metered GPU minutes go to measurements in a fixed order and every stage leaves
-# its evidence under gpurun_out/ even if a later one is cut off.  Run through gpurun from the repo root:
-#     gpurun --timeout 2400 -- 'bash tools/gpu_session.sh r03 tests bench prof pmc'
-# stages:  tests  pytest -m gpu (the new files test_zz_gpu_* included)           -> gpurun_out/<tag>/pytest.log
-#          bench  python bench.py (default config), then --config 3 if asked     -> gpurun_out/<tag>/bench*.json
-#          prof   rocprofv3 --kernel-trace --stats of the default bench          -> gpurun_out/<tag>/stats/ + kernel_stats.txt
-#          pmc    FETCH_SIZE / WRITE_SIZE passes (no trace flags with --pmc)     -> gpurun_out/<tag>/pmc_*/
-# Copy what is to be judged into profiles/ afterwards (gpurun_out/ is scratch).
+# GPU-box sessions, in stages; every stage leaves its evidence under gpurun_out/<tag>/ even if a later one is cut off.
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh <tag> <stages...>'
+# stages: tests (full pytest -m gpu, no -x) | testsx (-x) | chain | pressure | bench | bench20 | prof | pmc | modes | c3 | c3shard
 set -u
-tag=${1:-session}; shift || true
+tag=${1:-r4}; shift || true
 stages=${*:-tests bench}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 for s in $stages; do
   echo "== stage $s =="
+  t0=$(date +%s)
   case $s in
-    tests)
-      timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > "$out/pytest.log" 2>&1
-      echo "pytest exit $?" | tee -a "$out/pytest.log"; tail -5 "$out/pytest.log" ;;
-    bench)
-      timeout 900 python bench.py --steps 3 --warmup 1 > "$out/bench_default.json" 2> "$out/bench_default.err"
-      echo "bench exit $?"; tail -c 1500 "$out/bench_default.json" ;;
-    bench3)
-      timeout 1800 python bench.py --config 3 --steps 1 --warmup 1 > "$out/bench_config3.json" 2> "$out/bench_config3.err"
-      echo "bench3 exit $?"; tail -c 1500 "$out/bench_config3.json" ;;
-    prof)
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/stats" -o s -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 > "$OLDPWD/$out/prof.log" 2>&1)
-      python tools/rocprof_summary.py "$(ls "$out"/stats/*results.db | head -1)" > "$out/kernel_stats.txt" 2>> "$out/prof.log"; head -25 "$out/kernel_stats.txt" ;;
-    pmc)
-      for c in FETCH_SIZE WRITE_SIZE; do
-        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/$out/pmc_$c" -o p -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 > "$OLDPWD/$out/pmc_$c.log" 2>&1)
-      done
-      python tools/rocprof_pmc_summary.py "$(ls "$out"/pmc_FETCH_SIZE/*results.db | head -1)" "$(ls "$out"/pmc_WRITE_SIZE/*results.db | head -1)" > "$out/pmc_summary.txt" 2>&1; head -30 "$out/pmc_summary.txt" ;;
-    smoke)
-      timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ;;
+    tests)  timeout 1700 python -m pytest tests -m gpu -q --durations=20 --timeout=900 > "$out/pytest.log" 2>&1; echo "pytest exit $?" | tee -a "$out/pytest.log"; tail -15 "$out/pytest.log" ;;
+    testsx) timeout 1700 python -m pytest tests -m gpu -q -x --timeout=900 > "$out/pytest_x.log" 2>&1; echo "pytest -x exit $?" | tee -a "$out/pytest_x.log"; tail -5 "$out/pytest_x.log" ;;
+    chain)  timeout 300 python tools/chain_latency.py "$out/chain_latency.json" > "$out/chain.log" 2>&1; tail -4 "$out/chain.log" ;;
+    pressure) timeout 600 python tools/pressure_overlap.py 4.6e6 "$out/pressure_overlap.json" > "$out/pressure.log" 2>&1; echo "pressure exit $?"; grep -v "^\[ndgpu_overlap\]" "$out/pressure.log" | tail -20 ;;
+    bench)  timeout 900 python bench.py --steps 10 --warmup 3 > "$out/bench_config2.json" 2> "$out/bench_config2.err"; echo "bench exit $?"
+            python - "$out/bench_config2.json" <<'P'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(" ms_per_step %.1f value %.1f M cns %.1f ovl %.1f | kernel_ms %s | parity %s" % (d["ms_per_step"], d["value"] / 1e6, d["consensus_ms_per_step"], d["overlap"]["ms_per_step"], d["kernel_ms"], d.get("parity", {}).get("mismatch")))
+print(" roofline", json.dumps(d["roofline"])[:1500])
+P
+            ;;
+    bench20) timeout 900 python bench.py --steps 20 --warmup 5 > "$out/bench_config2_20.json" 2> "$out/bench_config2_20.err"; echo "bench20 exit $?"; tail -c 600 "$out/bench_config2_20.json" ;;
+    quick)  timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$out/bench_quick.json" 2> "$out/bench_quick.err"; echo "quick exit $?"
+            python - "$out/bench_quick.json" <<'P'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(" ms_per_step %.1f value %.1f M cns %.1f ovl %.1f | kernel_ms %s" % (d["ms_per_step"], d["value"] / 1e6, d["consensus_ms_per_step"], d["overlap"]["ms_per_step"], d["kernel_ms"]))
+P
+            ;;
+    prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/stats" -o s -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/$out/prof.log" 2>&1)
+            python tools/rocprof_summary.py "$(ls "$out"/stats/*results.db | head -1)" > "$out/kernel_stats.txt" 2>> "$out/prof.log"; head -30 "$out/kernel_stats.txt"; rm -rf "$out/stats" ;;
+    pmc)    for c in FETCH_SIZE WRITE_SIZE; do
+              (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/$out/pmc_$c" -o p -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/$out/pmc_$c.log" 2>&1)
+            done
+            python tools/rocprof_pmc_summary.py "$(ls "$out"/pmc_FETCH_SIZE/*results.db | head -1)" "$(ls "$out"/pmc_WRITE_SIZE/*results.db | head -1)" > "$out/pmc_summary.txt" 2>&1; head -40 "$out/pmc_summary.txt"; rm -rf "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE ;;
+    modes)  timeout 1500 python tools/measure_modes.py "$out/overlap_modes.json" > "$out/modes.log" 2>&1; echo "modes exit $?"; tail -12 "$out/modes.log" ;;
+    c3)     timeout 1700 python bench.py --config 3 --steps 1 --warmup 1 --no-cpu-baseline > "$out/bench_config3.json" 2> "$out/bench_config3.err"; echo "c3 exit $?"
+            python - "$out/bench_config3.json" <<'P'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(" ms_per_step %.0f consensus %.0f overlap %.0f allocations %s pool_calls %s kernel_ms %s" % (d["ms_per_step"], d["consensus_ms_per_step"],
+      d["overlap"]["ms_per_step"], d["allocations"], d["overlap"]["pool_calls"], d["kernel_ms"]))
+P
+            ;;
+    parity) timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_k10.py tests/test_gpu_configs.py -m gpu -q -x --timeout=600 > "$out/pytest_parity.log" 2>&1; echo "parity exit $?"; tail -3 "$out/pytest_parity.log" ;;
+    trace)  NDGPU_TRACE=1 NDGPU_PROF=1 timeout 400 python bench.py --steps 3 --warmup 2 --no-cpu-baseline > "$out/bench_trace.json" 2> "$out/bench_trace.err"; echo "trace exit $?"; tail -c 300 "$out/bench_trace.json" ;;
+    timeline) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/stats" -o s -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/$out/prof.log" 2>&1)
+            db="$(ls "$out"/stats/*results.db | head -1)"
+            python tools/rocprof_summary.py "$db" > "$out/kernel_stats.txt" 2>> "$out/prof.log"; head -30 "$out/kernel_stats.txt"
+            python tools/rocprof_timeline.py "$db" > "$out/timeline.txt" 2>> "$out/prof.log"; rm -rf "$out/stats" ;;
+    smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | tail -3 ;;
     *) echo "unknown stage $s" ;;
   esac
+  echo "   ($s: $(( $(date +%s) - t0 )) s)"
 done
