@@ -693,24 +693,6 @@ void par_ranges(size_t n, int base_threads, F f) {  // f(begin, end) over contig
     for (auto &x : th) x.join();
 }
 
-template <typename F>
-void par_each(size_t n, int base_threads, F f) {  // f(i) for every i, items handed out one by one (uneven items: rounds, piles)
-    if (base_threads <= 1 || n < 16) {
-        for (size_t i = 0; i < n; i++) f(i);
-        return;
-    }
-    CoreLease lease(base_threads);
-    const size_t nt = std::min<size_t>((size_t)lease.n, n / 4);
-    std::atomic<size_t> next{0};
-    auto work = [&] {
-        for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &x : th) x.join();
-}
-
 // ASCII -> 2-bit into a preallocated word range (same coding as pack_append)
 bool pack_into(uint32_t *out, const char *s, size_t n) {
     unsigned bad = 0;
@@ -974,78 +956,54 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     std::vector<uint8_t> usable(n, 1);
     uint64_t pool_words = 0, ops_words = 0, cell_rows = 0, out_bytes = 0, hdr_words = 0, lnk_words = 0;
     std::vector<LqJobDev> jobs;
-    // Two passes over the rounds, both on the context's host threads: what a round needs (counts), then -- offsets being prefix sums of
-    // the counts -- its pieces, tasks, sources and jobs written in place.  (One serial loop over ~110,000 pieces of a sub-batch with
-    // its push_backs was 9 ms of a round's critical path: ~36 ms per context and config-2 step.)
-    struct Lay {  // per round: counts in pass 1, starting offsets in pass 2
-        uint64_t pieces = 0, tasks = 0, srcs = 0, jobs = 0, pool_words = 0, ops_words = 0, hdr_words = 0, lnk_words = 0, cell_rows = 0, out_bytes = 0;
-        uint64_t seq_bases = 0, pool_bases = 0;
-    };
-    static const uint64_t max_cols = getenv("NDGPU_K12_MAX_COLUMNS") ? strtoull(getenv("NDGPU_K12_MAX_COLUMNS"), nullptr, 10) : kLqMaxColumns;  // (test hook)
-    static const uint64_t job_cols = getenv("NDGPU_K12_JOB_COLUMNS") ? strtoull(getenv("NDGPU_K12_JOB_COLUMNS"), nullptr, 10) : kLqJobColumns;  // (test hook: 1 = every region a job)
-    std::vector<Lay> cnt(n), at(n);
-    // One round: with `write` its pieces / tasks / sources / jobs go to the arrays at the offsets of `B`; either way `L` receives what
-    // the round takes.  A round K12 does not take (no regions, too many columns, beyond the packed fields) takes nothing.
-    auto lay_round = [&](size_t r, bool write, const Lay &B, Lay &L) {
+    size_t n_piece_total = 0;
+    for (size_t r = 0; r < n; r++) n_piece_total += rounds[r]->pieces.size();
+    pieces.reserve(n_piece_total);
+    for (size_t r = 0; r < n; r++) {
         LqRound &R = *rounds[r];
-        LqPileDev P;
+        R.ok = false;
+        R.lqc.clear();
+        LqPileDev &P = piles[r];
         memset(&P, 0, sizeof(P));
-        L = Lay();
-        if (write) {
-            R.ok = false;
-            R.lqc.clear();
-            piles[r] = P;
-        }
         const uint32_t nr = R.n_regions;
         if (nr == 0 || R.pieces.size() != (size_t)nr * 30u) {
             usable[r] = 0;
-            return;
+            continue;
         }
         uint64_t link_len = 1, ins_cap = 0;
         for (uint32_t g = 0; g < nr; g++) link_len += (uint64_t)R.pieces[g].sl + 1;
         // K12b is one wavefront per pile, ~1 us per cell row, and its launch lasts as long as its longest pile: a pile whose
         // low-quality regions add up to tens of thousands of columns (repeat-rich genomes: config 3 had K12 launches of 250 ms)
         // is faster on a host core, next to the others -- it is left to the host path before anything is laid out for it
-        if (link_len > max_cols || link_len >= (1ull << 20)) {  // (the second: beyond the record's row field)
+        static const uint64_t max_cols = getenv("NDGPU_K12_MAX_COLUMNS") ? strtoull(getenv("NDGPU_K12_MAX_COLUMNS"), nullptr, 10) : kLqMaxColumns;  // (test hook)
+        if (link_len > max_cols) {
             usable[r] = 0;
-            return;
+            continue;
         }
-        for (size_t k = 0; k < R.pieces.size(); k++)
-            if (R.pieces[k].job >= 0) ins_cap += (uint64_t)(*R.jobs)[(size_t)R.pieces[k].job].q_len;
-        if (link_len + ins_cap >= (1ull << 27)) {  // beyond the packed tag's column field
-            usable[r] = 0;
-            return;
-        }
-        P.first_piece = (uint32_t)B.pieces;
+        P.first_piece = (uint32_t)pieces.size();
         P.n_regions = nr;
         P.factor = R.factor;
         P.qv_factor = R.qv_factor;
         std::vector<uint64_t> t_off(nr, ~0ull);  // word offset of every region's pseudo-seed, packed on first use
-        std::vector<uint64_t> ins_of(nr, 0), tags_of(nr, 0);  // per region: candidate bases / tag bound of its 30 rows (K12a's job capacities)
         for (size_t k = 0; k < R.pieces.size(); k++) {
             const LqRound::Piece &pc = R.pieces[k];
             LqPieceDev d;
             d.task = -1;
             d.sl = pc.sl;
-            if (pc.job < 0) tags_of[k % nr] += pc.sl;
             if (pc.job >= 0) {
                 const AlnJob &j = (*R.jobs)[(size_t)pc.job];
                 const uint32_t g = (uint32_t)(k % nr);
-                ins_of[g] += (uint64_t)j.q_len;
-                tags_of[g] += (uint64_t)j.q_len + (uint64_t)j.t_len;
                 AlnTask t;
                 memset(&t, 0, sizeof(t));
                 t.q_len = j.q_len;
                 t.t_len = j.t_len;
-                if (write) srcs[B.srcs + L.srcs] = Src{j.q_words, j.q, (uint32_t)j.q_len, B.pool_words + L.pool_words};
-                L.srcs++;
-                t.q_off = (B.pool_words + L.pool_words) * 16;
-                L.pool_words += ((uint64_t)j.q_len + 15) / 16;
+                srcs.push_back(Src{j.q_words, j.q, (uint32_t)j.q_len, pool_words});
+                t.q_off = pool_words * 16;
+                pool_words += ((uint64_t)j.q_len + 15) / 16;
                 if (t_off[g] == ~0ull) {
-                    t_off[g] = B.pool_words + L.pool_words;
-                    if (write) srcs[B.srcs + L.srcs] = Src{nullptr, j.t, (uint32_t)j.t_len, B.pool_words + L.pool_words};
-                    L.srcs++;
-                    L.pool_words += ((uint64_t)j.t_len + 15) / 16;
+                    t_off[g] = pool_words;
+                    srcs.push_back(Src{nullptr, j.t, (uint32_t)j.t_len, pool_words});
+                    pool_words += ((uint64_t)j.t_len + 15) / 16;
                 }
                 t.t_off = t_off[g] * 16;
                 int md, bd;
@@ -1053,30 +1011,34 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
                 t.max_d = md;
                 t.band = bd;
                 t.row_words = kFastRowWords;
-                t.ops_off = B.ops_words + L.ops_words;
+                t.ops_off = ops_words;
                 t.ops_cap = (uint32_t)(j.q_len + j.t_len);
-                L.ops_words += (uint64_t)(t.ops_cap + 15) / 16 + 1;
-                d.task = (int32_t)(B.tasks + L.tasks);
-                if (write) tasks[B.tasks + L.tasks] = t;
-                L.tasks++;
-                L.seq_bases += (uint64_t)j.q_len + (uint64_t)j.t_len;
-                L.pool_bases += (uint64_t)j.q_len;
+                ops_words += (uint64_t)(t.ops_cap + 15) / 16 + 1;
+                ins_cap += (uint64_t)j.q_len;
+                d.task = (int32_t)tasks.size();
+                tasks.push_back(t);
+                S.stats.seq_bases += (uint64_t)j.q_len + (uint64_t)j.t_len;
+                S.stats.pool_bases += (uint64_t)j.q_len;
             }
-            if (write) pieces[B.pieces + L.pieces] = d;
-            L.pieces++;
+            pieces.push_back(d);
+        }
+        if (link_len + ins_cap >= (1ull << 27) || link_len >= (1ull << 20)) {  // beyond the packed tag's column field / the record's row field
+            usable[r] = 0;
+            continue;
         }
         P.link_len = (uint32_t)link_len;
         P.out_cap = (uint32_t)(2 * link_len + 64);
-        P.cell_off = B.cell_rows * 6;
-        P.out_off = B.out_bytes;
-        L.out_bytes = P.out_cap;
+        P.cell_off = cell_rows * 6;
+        P.out_off = out_bytes;
+        out_bytes += P.out_cap;
         // K12a's jobs: runs of regions of about kLqJobColumns columns (each region with the 'N' column in front of it); a job
         // starts only behind a region that has columns (its rows' first tags come from the tail of that region's alignments).
         // Capacities: cell rows = columns + the longest insertion run after every column -- bounded by the candidates' bases, in
         // practice a fraction of the columns: three times the columns are laid out, a job that needs more declines the pile (host
         // path); links <= tags = the alignments' columns (<= q_len + t_len each) + a tag per row of an unaligned region's columns
         // + 30 per 'N'.
-        P.first_job = (uint32_t)B.jobs;
+        static const uint64_t job_cols = getenv("NDGPU_K12_JOB_COLUMNS") ? strtoull(getenv("NDGPU_K12_JOB_COLUMNS"), nullptr, 10) : kLqJobColumns;  // (test hook: 1 = every region a job)
+        P.first_job = (uint32_t)jobs.size();
         {
             uint32_t g = 0, t = 0;
             while (g < nr) {
@@ -1087,8 +1049,15 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
                 do {
                     const uint32_t sl = R.pieces[g].sl;
                     cols += (uint64_t)sl + 1;
-                    tags += 30 + tags_of[g];
-                    ins += ins_of[g];
+                    tags += 30;
+                    for (uint32_t row = 0; row < 30u; row++) {
+                        const LqRound::Piece &pc = R.pieces[(size_t)row * nr + g];
+                        if (pc.job >= 0) {
+                            const AlnJob &j = (*R.jobs)[(size_t)pc.job];
+                            ins += (uint64_t)j.q_len;
+                            tags += (uint64_t)j.q_len + (uint64_t)j.t_len;
+                        } else tags += sl;
+                    }
                     t += sl + 1;
                     g++;
                 } while (g < nr && (cols < job_cols || R.pieces[g - 1].sl == 0));
@@ -1097,38 +1066,16 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
                 jb.t1 = t;
                 jb.row_cap = (uint32_t)std::min<uint64_t>(cols + ins, 3 * cols + 256);
                 jb.lnk_cap = (uint32_t)std::min<uint64_t>(tags, (uint64_t)jb.row_cap * 30u);
-                jb.hdr_off = B.hdr_words + L.hdr_words, jb.lnk_off = B.lnk_words + L.lnk_words;
-                L.hdr_words += jb.row_cap;
-                L.lnk_words += jb.lnk_cap;
+                jb.hdr_off = hdr_words, jb.lnk_off = lnk_words;
+                hdr_words += jb.row_cap;
+                lnk_words += jb.lnk_cap;
                 P.row_cap += jb.row_cap;
-                if (write) jobs[B.jobs + L.jobs] = jb;
-                L.jobs++;
+                jobs.push_back(jb);
             }
         }
-        P.n_jobs = (uint32_t)L.jobs;
-        L.cell_rows = P.row_cap;
-        if (write) piles[r] = P;
-    };
-    par_each(n, S.host_threads, [&](size_t r) { lay_round(r, false, Lay(), cnt[r]); });
-    {
-        Lay run;
-        for (size_t r = 0; r < n; r++) {
-            at[r] = run;
-            const Lay &c = cnt[r];
-            run.pieces += c.pieces, run.tasks += c.tasks, run.srcs += c.srcs, run.jobs += c.jobs, run.pool_words += c.pool_words;
-            run.ops_words += c.ops_words, run.hdr_words += c.hdr_words, run.lnk_words += c.lnk_words, run.cell_rows += c.cell_rows;
-            run.out_bytes += c.out_bytes;
-            S.stats.seq_bases += c.seq_bases;
-            S.stats.pool_bases += c.pool_bases;
-        }
-        pieces.resize(run.pieces), tasks.resize(run.tasks), srcs.resize(run.srcs), jobs.resize(run.jobs);
-        pool_words = run.pool_words, ops_words = run.ops_words, hdr_words = run.hdr_words, lnk_words = run.lnk_words;
-        cell_rows = run.cell_rows, out_bytes = run.out_bytes;
+        P.n_jobs = (uint32_t)jobs.size() - P.first_job;
+        cell_rows += P.row_cap;
     }
-    par_each(n, S.host_threads, [&](size_t r) {
-        Lay got;
-        lay_round(r, true, at[r], got);
-    });
     const size_t nt = tasks.size();
     if (nt == 0) {  // nothing K12 takes in this call: every pile goes the host way
         S.stats.lq_rounds += n, S.stats.lq_declined += n;
