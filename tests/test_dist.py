@@ -160,3 +160,31 @@ def test_a_late_owner_does_not_stop_the_step(host_harness, oracle_lib, tmp_path)
     got = shard(ex).piles(1)
     assert ex.stats["recomputed"] == 1 and ex.stats["received"] == 0 and ex.stats["sent"] == 0
     assert all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3])) and got[3] == want[3]
+
+
+def test_the_owner_may_run_steps_ahead_of_the_reader(host_harness, oracle_lib, tmp_path):
+    """Ranks are not synchronised between steps: the owner of a mirror job may be several steps ahead of the rank that reads it.  Files
+    are kept until their one reader has read them (the reader removes them), so nothing is lost and nothing is recomputed."""
+    import ctypes as C
+
+    import numpy as np
+
+    import stage_util
+    from nextdenovo_amd import stage, synth
+    olib = C.CDLL(os.path.join(ROOT, "oracle", "libndoracle.so"))
+    g = synth.make_genome(24000, seed=42, n_repeats=0)
+    rs = synth.simulate_reads(g, 20, "ont", seed=43, mu=8.0, sigma=0.35)
+    words, word_off, lens = synth.pack_db(rs)
+    xdir = str(tmp_path / "x")
+
+    def shard(rank):
+        return stage.Shard(words, word_off, lens, preset="ava-ont", seed_cutoff=1000, read_cutoff=500, n_seed_files=2, sort_k=17,
+                           blacklist=False, backend=stage_util.OracleBackend(olib, "ava-ont"), exchange=stage.Exchange(xdir, rank, timeout_s=5.0))
+    s0, s1 = shard(0), shard(1)
+    first = [s0.overlaps(0) for _ in range(3)]          # rank 0 runs three steps: three files of the job (0, seed 1) wait
+    assert s0.exchange.stats["sent"] == 3 and len(os.listdir(xdir)) == 3
+    got = [s1.overlaps(1) for _ in range(3)]            # rank 1 catches up, step by step
+    assert s1.exchange.stats == {"sent": 0, "received": 3, "recomputed": 0, "wait_s": s1.exchange.stats["wait_s"]}
+    assert os.listdir(xdir) == []
+    for step in range(3):                               # the mirror rank 1 read is the job rank 0 computed in that step
+        assert np.array_equal(got[step][0], first[step][1])
