@@ -359,7 +359,9 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    # NDGPU_BENCH_FORCE_DIST=1: the process group, the barrier and the RCCL all-reduce / all-gather of an N > 1 run with ONE rank --
+    # the rehearsal of the collective leg that a one-GPU box allows (`torch.distributed.run --nproc-per-node 1`)
+    if world > 1 or os.environ.get("NDGPU_BENCH_FORCE_DIST"):
         import torch
         import torch.distributed as dist
         # ("nccl" IS RCCL on ROCm.  NDGPU_BENCH_DIST_BACKEND=gloo is the test hook of tests/test_bench_cpu.py: main() itself, N = 2, on
@@ -460,10 +462,10 @@ def main():
         models = kernel_models(st)
         stat_rows, stat_file = committed_kernel_stats()
         dom = None
-        for name, calls, avg_us in stat_rows:
+        for kname, calls, avg_us in stat_rows:   # (rows in order of GPU time)
             for key in models:
-                if name.startswith(key):
-                    dom = (key, name, calls, avg_us)
+                if kname.startswith(key):
+                    dom = (key, kname, calls, avg_us)
                     break
             if dom:
                 break
@@ -491,9 +493,9 @@ def main():
             traffic, traffic_note = committed_traffic(dom[0], dom_entry["launches_per_step"], args.config)
         others = {}
         rp = {}
-        for name, calls, avg_us in stat_rows:
+        for kname, calls, avg_us in stat_rows:
             for key in models:
-                if name.startswith(key) and key not in rp:
+                if kname.startswith(key) and key not in rp:
                     rp[key] = avg_us
         for key in models:
             if key != dom[0]:

@@ -38,6 +38,7 @@ def test_bench_line_on_a_tiny_genome(monkeypatch):
         assert k in d, k
     assert d["metric"] == "corrected bases/sec" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert "synthetic uniform 0.03 Mb" in d["config"]["workload"] and "kernel" not in d["config"]["workload"]   # the read set's name, nothing else
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1

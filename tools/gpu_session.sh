@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box sessions, in stages; every stage leaves its evidence under gpurun_out/<tag>/ even if a later one is cut off.
 #   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh <tag> <stages...>'
-# stages: tests (full pytest -m gpu, no -x) | testsx (-x) | chain | pressure | bench | bench20 | prof | pmc | modes | c3 | c3shard
+# stages: tests (full pytest -m gpu, no -x) | testsx (-x) | chain | pressure | bench | bench20 | prof | pmc | modes | c3 | c3shard | rccl
 set -u
 tag=${1:-r4}; shift || true
 stages=${*:-tests bench}
@@ -53,6 +53,10 @@ P
             db="$(ls "$out"/stats/*results.db | head -1)"
             python tools/rocprof_summary.py "$db" > "$out/kernel_stats.txt" 2>> "$out/prof.log"; head -30 "$out/kernel_stats.txt"
             python tools/rocprof_timeline.py "$db" > "$out/timeline.txt" 2>> "$out/prof.log"; rm -rf "$out/stats" ;;
+    rccl)   # the collective leg of an N > 1 run with the one rank a one-GPU box allows: torch + RCCL + the product libraries in one process
+            NDGPU_BENCH_FORCE_DIST=1 timeout ${RCCL_TIMEOUT:-200} python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
+              bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_rccl_one_rank.json" 2> "$out/bench_rccl_one_rank.err"; echo "rccl exit $?"
+            tail -c 400 "$out/bench_rccl_one_rank.err"; grep -o '"per_rank": [^]]*]' "$out/bench_rccl_one_rank.json" ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | tail -3 ;;
     *) echo "unknown stage $s" ;;
   esac
