@@ -388,6 +388,11 @@ def main():
         # the ranks of this node hand seed x seed job records to one another through a node-local directory, as the reference hands
         # the .ovl file of a pair to its second reader with `ln -sf` (nextDenovo:455-459): a pair is mapped once per node
         xdir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "ndgpu_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+        if rank == 0:   # a run that died may have left files of ITS job layout here: start from an empty directory
+            import shutil
+            shutil.rmtree(xdir, ignore_errors=True)
+            os.makedirs(xdir, exist_ok=True)
+        dist.barrier()      # (nobody writes before the directory is clean)
         exchange = stage.Exchange(xdir, rank)
     sh = stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k,
                      exchange=exchange)

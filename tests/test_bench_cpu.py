@@ -81,6 +81,12 @@ def test_bench_line_of_two_ranks(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # what a run that died on this port would have left behind: job files of another layout (bench.py starts from an empty directory)
+    xdir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "ndgpu_bench_%d" % port)
+    os.makedirs(xdir, exist_ok=True)
+    for k in range(6):
+        with open(os.path.join(xdir, "step000001.job%05d.r0.npy" % k), "wb") as f:
+            f.write(b"not the records of this job")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_rank_main, args=(r, port, q)) for r in range(2)]
@@ -97,3 +103,4 @@ def test_bench_line_of_two_ranks(tmp_path):
     ra = d["config"]["raw_align_jobs"]
     assert ra["exchange"] is True and ra["per_rank_jobs_computed"] == [2, 1] and ra["rank0_exchange"]["sent"] == 2   # (warm-up + 1 step)
     assert ra["rank0_exchange"]["recomputed"] == 0
+    assert not os.path.exists(xdir)   # (removed by rank 0 once every rank is past its last read)
