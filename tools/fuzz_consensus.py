@@ -42,7 +42,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests", "simt"))
         import build_simt
         os.environ.setdefault("NDGPU_CONTEXTS", "2")
-        api._LIB = api._bind(C.CDLL(build_simt.build()))
+        api._LIB = api._bind(C.CDLL(os.environ.get("NDGPU_SIMT_LIB") or build_simt.build()))   # (NDGPU_SIMT_LIB: tools/kernel_candidate.py)
     rng = np.random.default_rng(seed)
     bad = total = 0
     for it in range(n_sets):

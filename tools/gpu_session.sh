@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box sessions, in stages; every stage leaves its evidence under gpurun_out/<tag>/ even if a later one is cut off.
 #   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh <tag> <stages...>'
-# stages: tests (full pytest -m gpu, no -x) | testsx (-x) | chain | pressure | bench | bench20 | prof | pmc | modes | c3 | c3shard | rccl
+# stages: tests (full pytest -m gpu, no -x) | testsx (-x) | chain | pressure | bench | bench20 | prof | pmc | modes | c3 | c3shard | rccl | cand
 set -u
 tag=${1:-r4}; shift || true
 stages=${*:-tests bench}
@@ -57,6 +57,19 @@ P
             NDGPU_BENCH_FORCE_DIST=1 timeout ${RCCL_TIMEOUT:-200} python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
               bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_rccl_one_rank.json" 2> "$out/bench_rccl_one_rank.err"; echo "rccl exit $?"
             tail -c 400 "$out/bench_rccl_one_rank.err"; grep -o '"per_rank": [^]]*]' "$out/bench_rccl_one_rank.json" ;;
+    cand)   # A/B of a kernel candidate (tools/kernel_candidate.py; CAND=<name>): the product library, then the candidate in its place with the parity leg
+            timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_product.json" 2> "$out/bench_product.err"; echo "product exit $?"
+            timeout 200 python tools/kernel_candidate.py bench ${CAND:-snake32} --steps 10 --warmup 3 > "$out/bench_${CAND:-snake32}.json" 2> "$out/bench_${CAND:-snake32}.err"; echo "candidate exit $?"
+            python - "$out/bench_product.json" "$out/bench_${CAND:-snake32}.json" <<'P'
+import json, sys
+for p in sys.argv[1:]:
+    try:
+        d = json.loads(open(p).read().strip().splitlines()[-1])
+        print(" %s: ms_per_step %.1f cns %.1f ovl %.1f | kernel_ms %s | parity %s" % (p.split("/")[-1], d["ms_per_step"], d["consensus_ms_per_step"], d["overlap"]["ms_per_step"], {k: round(v) for k, v in d["kernel_ms"].items()}, d.get("parity")))
+    except Exception as e:
+        print(" %s: %r" % (p, e))
+P
+            ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | tail -3 ;;
     *) echo "unknown stage $s" ;;
   esac
