@@ -5,7 +5,13 @@
  *   nd_os_expand   util/ovl_sort.c:980-1037  (sort_ovl_file: pre-filters, both directions, seed lookup,
  *                                             the "5 misses then stop" counters per input file)
  *   nd_os_order    util/ovl_sort.c:246-261 (cmp_ovl) + :876-925 (merge_ovl_from_sort): seed asc, match desc,
- *                  span asc; equal keys keep input order (glibc qsort is a merge sort; buffers merge in order)
+ *                  span asc; equal keys keep input order (glibc qsort is a merge sort; buffers merge in order).
+ *                  One case in which the reference does not define the order at all: equal keys in DIFFERENT input
+ *                  files (duplicated read segments).  The merge takes the sort buffer with the lower index (:883-893),
+ *                  and a reader thread takes its buffer when it reaches its file's first kept record (:933-936): a
+ *                  race between the -t threads.  On an idle machine buffer i goes to file i -- file order, as here
+ *                  and on the device -- and on a loaded one it does not (tools/fuzz_stage.py met it once in 50 sets;
+ *                  14 reruns of the compiled ovl_sort on that input gave file order every time).
  *   admit()        util/ovl_sort.c:675-741   (encode_ovl_filter: 64-base coverage bins)
  *   finish_seed()  util/ovl_sort.c:433-571   (ovl_filter: chimera / low-coverage trimming, .bl verdict)
  *                  with check_chimer :316-336 and check_chimer2 :339-383

@@ -79,9 +79,28 @@ def main():
                                 "-o", out] + extra)
         got, want = records(out + ".001.fasta"), records(ref_out)
         ok = rc == 0 and got == want
+        note = ""
+        if rc == 0 and not ok:
+            # Equal sort keys in DIFFERENT raw files (duplicated read segments): the reference's merge takes the block with the lower
+            # index (util/ovl_sort.c:883-893) and its reader threads take their blocks in the order they get to their first record
+            # (:933-936) -- a race.  The device keeps file order, which is what the reference does on an idle machine.  Sort again;
+            # if the reference does not reproduce its own file, compare against the chain rerun from the new one.
+            ra = os.path.dirname(sorted_ovl)
+            for attempt in range(3):
+                again = os.path.join(ra, "again%d.sorted.ovl" % attempt)
+                subprocess.run([os.path.join(refpipe.REFDIR, "ovl_sort"), "-m", "2g", "-t", "4", "-k", str(k), "-i", os.path.join(wd, "db", ".input.seed.001.idx"),
+                                "-o", os.path.basename(again), "input.fofn"], cwd=ra, check=True, capture_output=True)
+                if open(again, "rb").read() == open(sorted_ovl, "rb").read():
+                    continue
+                ref2 = os.path.join(wd, "ref2.cns.fasta")
+                subprocess.run([sys.executable, driver, "-f", idxs, "-i", again, "-r", rtype, "-p", "4", "-min_len_seed", str(min_len_seed),
+                                "-o", ref2] + extra, capture_output=True, text=True, timeout=1800, check=True)
+                if records(ref2) == got:
+                    ok, note = True, "(the reference's sort does not reproduce itself on this set: cross-file tie race; equal to its rerun)"
+                break
         bad += not ok
         print(it, "equal" if ok else "DIFFER", prof, "seed_cutoff", seed_cutoff, "k", k, extra, "records", len(got), len(want), "%.0fs" % (time.time() - t0),
-              "" if ok else wd, flush=True)
+              note if ok else wd, flush=True)
     print("mismatches", bad)
     return 1 if bad else 0
 
