@@ -8,6 +8,7 @@ build_variants/<name>/ (git-ignored; travels to the GPU box), compiled for gfx95
                                                             against the compiled reference (CPU; needs oracle/_ref)
     python tools/kernel_candidate.py isa <name>            VALU / SALU / memory instruction counts of K7 and K8a, product vs candidate
     python tools/kernel_candidate.py bench <name> [args]   bench.py with the candidate library in the product library's place (GPU box)
+    python tools/kernel_candidate.py chain <name> [out]    tools/chain_latency.py (the isolated edit step) with the candidate library (GPU box)
 
 Candidates:
   snake32   the match run of a cell compared 32 bases per round (three + three words, two funnel shifts each, one 64-bit count) in
@@ -194,6 +195,15 @@ def bench(name, argv):
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 
 
+def chain(name, argv):
+    """tools/chain_latency.py (one long alignment on an idle device: the isolated edit step) with the candidate library."""
+    from nextdenovo_amd import build as B
+    B.LIB = os.path.join(variant_dir(name), "libndgpu_nextcorrect.so")
+    import runpy
+    sys.argv = ["chain_latency.py"] + argv
+    runpy.run_path(os.path.join(ROOT, "tools", "chain_latency.py"), run_name="__main__")
+
+
 if __name__ == "__main__":
     what, name = sys.argv[1], sys.argv[2]
     if what == "build":
@@ -204,3 +214,5 @@ if __name__ == "__main__":
         sys.exit(simt(name))
     elif what == "bench":
         bench(name, sys.argv[3:])
+    elif what == "chain":
+        chain(name, sys.argv[3:])
