@@ -55,6 +55,9 @@ def parse(argv=None):
     ap.add_argument("--profile", default="")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lengths-only", action="store_true",
+                    help="the timed steps skip the hand-over of the corrected sequences and the cns.fasta / .idx write (A/B runs only: "
+                         "the output is part of the stage)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="consensus stage only, on analytically derived piles")
     ap.add_argument("--no-exchange", action="store_true",
@@ -146,14 +149,20 @@ def committed_traffic(kernel, launches_per_step, config):
 
 # ---- CPU baseline leg (the ONLY place bench.py touches oracle/) ---------------------------------
 _REF = None
+_CPU_CTX = None   # (read set, piles, max_lq_length, read type): inherited by the fork()ed workers
 
 
-def _ref_worker(item):
+def _ref_worker(i):
     """One fork()ed worker = one `nextcorrect.py -p` worker (lib/nextcorrect.py:183-199):
-    calls the compiled reference's nextCorrect() on one pile."""
+    calls the compiled reference's nextCorrect() on one pile; returns the record's fingerprint and the CPU time the call took
+    in this worker (process_time: the worker's own user + system time, not the wall of a pool that waits for its slowest pile)."""
     global _REF
     import ctypes as C
-    seqs, st, en, mal, mlq, rt = item
+    from nextdenovo_amd import synth
+    rs, piles, max_lq, rt = _CPU_CTX
+    key = i
+    seqs, st, en, mal = synth.pile_sequences(rs, piles[i])   # (the worker fetches its own sequences: lib/nextcorrect.py:189-193)
+    mlq = min(en[0] // 2, max_lq)                            # lib/nextcorrect.py:188
     if _REF is None:
         class CT(C.Structure):
             _fields_ = [("len", C.c_uint), ("identity", C.c_float), ("seq", C.c_void_p)]
@@ -168,22 +177,27 @@ def _ref_worker(item):
     n = len(seqs)
     cs = (C.c_char_p * n)()
     cs[:] = seqs
+    c0 = time.process_time()
     r = lib.nextCorrect(cs, (C.c_uint * n)(*st), (C.c_uint * n)(*en), n, mal, 500, 130, 4, mlq, 0.8, 0, 0, rt)
+    cpu_s = time.process_time() - c0
     ln, ide = r.contents.len, r.contents.identity
     # what the parity block compares: length, the float32 identity bit for bit, md5 of the corrected bases
     # (error seeds -- len 2 / 3 / 4 -- carry no sequence: lib/nextcorrect.c:261-266, 2126)
     digest = hashlib.md5(C.string_at(r.contents.seq, ln)).hexdigest() if ln > 4 else ""
     bits = struct.unpack("<I", struct.pack("<f", ide))[0] if ln > 4 else 0
     lib.free_consensus_trimed(r)
-    return ln, bits, digest, ide
+    return key, ln, bits, digest, ide, cpu_s
 
 
-def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16, repeats=True):
-    """Reference CPU path on a bounded sample of the same workload, all sample piles in
-    flight over a fork pool of `cores` workers (the reference's own parallelism model).
-    The sample = every k-th pile + the `n_longest` longest seeds (where the device's wide tables, its int32
-    guard and its segment stitching matter); the rate is taken over the every-k-th part only, so that it
-    stays a representative sample of the workload.  Returns (record, {pile index: (len, identity bits, md5)})."""
+def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16):
+    """Reference CPU path on a bounded sample of the same workload: the compiled reference's nextCorrect() over a fork pool of
+    `cores` workers that STREAMS the piles (imap_unordered, one pile per task, longest seeds first), as lib/nextcorrect.py:232-235
+    streams all of them -- with >= 16 piles per worker the pool's tail (its longest pile) amortises.  Every pile's CPU time is
+    measured inside its worker, so the record carries both the makespan rate (`value` = bases / wall on `cores` workers) and the
+    per-core rate (`per_core_measured` = bases / CPU-seconds; x cores = what a perfectly packed pool would do).
+    The sample = every k-th pile + the `n_longest` longest seeds (where the device's wide tables, its int32 guard and its segment
+    stitching matter); both parts count for the rates and for the parity block.
+    Returns (record, {pile index: (len, identity bits, md5)})."""
     from multiprocessing import get_context
     from nextdenovo_amd import synth
     ref_so = os.path.join(ROOT, "oracle", "_ref", "nextcorrect.so")
@@ -191,36 +205,37 @@ def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16, repeats=T
         return None, {}
     cores = max(1, min(os.cpu_count() or 1, 64))
     if n_sample <= 0:
-        n_sample = min(len(piles), 4 * cores)
+        n_sample = min(len(piles), 16 * cores)
     step = max(1, len(piles) // n_sample)
     idx = list(range(0, len(piles), step))[:n_sample]
     by_len = sorted(range(len(piles)), key=lambda i: -int(piles[i]["recs"][0][3]))
-    extra = [i for i in by_len[:n_longest] if i not in set(idx)]
+    have = set(idx)
+    idx += [i for i in by_len[:n_longest] if i not in have]
+    idx.sort(key=lambda i: -int(piles[i]["recs"][0][3]))  # longest first: the pool's last tasks are its shortest
 
-    def item(i):
-        seqs, st, en, mal = synth.pile_sequences(rs, piles[i])
-        return (seqs, st, en, mal, min(en[0] // 2, max_lq), read_type)
-
-    items = [item(i) for i in idx]
+    global _CPU_CTX
+    _CPU_CTX = (rs, piles, max_lq, read_type)
     ctx = get_context("fork")
+    got = {}
     with ctx.Pool(cores) as pool:
-        pool.map(_ref_worker, items[:cores])  # warm: dlopen + page in
-        runs = []
-        for _ in range(3 if repeats else 1):  # three runs, the median counts
-            t0 = time.perf_counter()
-            got = pool.map(_ref_worker, items, chunksize=1)
-            runs.append(time.perf_counter() - t0)
-            if runs[-1] > 12.0:               # (a bounded leg: a sample that takes longer than this is timed once)
-                break
-        dt = sorted(runs)[len(runs) // 2]
-        got_extra = pool.map(_ref_worker, [item(i) for i in extra], chunksize=1) if extra else []
-    bases = int(sum(ln for ln, _b, _d, ide in got if ln > 4 and ide >= 0.8))
-    ref = {i: g[:3] for i, g in zip(idx + extra, got + got_extra)}
+        pool.map(_ref_worker, idx[-cores:], chunksize=1)  # warm: dlopen + page in, on the shortest piles
+        t0 = time.perf_counter()
+        for key, ln, bits, digest, ide, cpu_s in pool.imap_unordered(_ref_worker, idx, chunksize=1):
+            got[key] = (ln, bits, digest, ide, cpu_s)
+        dt = time.perf_counter() - t0
+    bases = int(sum(ln for ln, _b, _d, ide, _c in got.values() if ln > 4 and ide >= 0.8))
+    cpu_s = float(sum(g[4] for g in got.values()))
+    slowest = max(g[4] for g in got.values())
+    ref = {i: got[i][:3] for i in idx}
+    _CPU_CTX = None
+    per_core = bases / cpu_s if cpu_s > 0 else 0.0
     return {"value": bases / dt, "unit": "corrected bases/s", "cores": cores, "kind": "reference",
-            "sample": "%d of %d piles (every %d-th), %d corrected bases in %.2f s wall (median of %d run%s: %s); compiled reference "
-                      "nextcorrect.so via fork pool" % (len(idx), len(piles), step, bases, dt, len(runs), "" if len(runs) == 1 else "s",
-                                                        ", ".join("%.2f" % x for x in runs)),
-            "per_core": bases / dt / cores}, ref
+            "wall_s": dt, "cpu_seconds": cpu_s, "per_core_measured": per_core, "per_core_measured_x_cores": per_core * cores,
+            "slowest_pile_cpu_s": slowest, "piles_per_worker": len(idx) / cores,
+            "sample": "%d of %d piles (every %d-th + the %d longest seeds), %d corrected bases; compiled reference nextcorrect.so, fork pool "
+                      "of %d workers streaming one pile per task, longest first (lib/nextcorrect.py:232-235): %.2f s wall, %.1f CPU-seconds "
+                      "summed over the piles (process_time inside the workers), slowest pile %.2f CPU-s; `value` = bases / wall, "
+                      "`per_core_measured` = bases / CPU-seconds" % (len(idx), len(piles), step, n_longest, bases, cores, dt, cpu_s, slowest)}, ref
 
 
 def parity_block(ref, gpu_full, piles):
@@ -287,6 +302,47 @@ def cpu_baseline_overlap(rs_dev, preset, device_records=None):
     for f in (p, out):
         os.remove(f)
     return res
+
+
+def host_description():
+    """What the step's host phases ran on: the figure moves with the box, so the line says which box."""
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = None
+    return {"cpu_model": model, "cpu_count": os.cpu_count(), "cpus_allowed": aff}
+
+
+def host_snapshot():
+    """Load average and the GPU's clocks / busy figure as sysfs shows them (no tool is run): taken before and after the timed steps."""
+    import glob
+    snap = {}
+    try:
+        snap["loadavg"] = [round(x, 1) for x in os.getloadavg()]
+    except OSError:
+        pass
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))[:1]:
+        for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("gpu_busy_percent", "gpu_busy_percent")):
+            try:
+                with open(os.path.join(card, fn)) as f:
+                    txt = f.read().strip()
+            except OSError:
+                continue
+            if key == "gpu_busy_percent":
+                snap[key] = txt
+            else:  # the active level carries a '*'
+                act = [ln.split(":", 1)[1].strip().rstrip("*").strip() for ln in txt.splitlines() if ln.strip().endswith("*")]
+                snap[key] = act[0] if act else txt.splitlines()[-1].strip() if txt else ""
+    return snap
 
 
 def reduce_over_ranks(dist, torch, bases: int, dt: float, device, seeds: int = 0):
@@ -396,10 +452,11 @@ def main():
         exchange = stage.Exchange(xdir, rank)
     sh = stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k,
                      exchange=exchange)
-    a_piles = a_recs = a_off = None
+    a_piles = a_recs = a_off = a_names = None
     if analytic:  # piles from the true read positions, for the seeds of this rank's seed file
         a_piles = synth.build_piles(rs, seed_cutoff=1000, seed_ids=[int(i) for i in sh.seed_ids[my_file]])
         a_recs, a_off = synth.flatten_piles(a_piles)
+        a_names = [int(p_["seed"]) for p_ in a_piles]
     last = {}
     cns_wall = [0.0]
 
@@ -409,38 +466,76 @@ def main():
             if dist_dev == "cuda":
                 torch.cuda.synchronize()
 
+    # The stage's output is part of the stage (lib/nextcorrect.py:236-260): every step writes its cns.fasta + cns.fasta.idx, record
+    # for record as the reference's loop prints them, into a scratch directory (removed at the end).
+    import tempfile
+    out_dir = tempfile.mkdtemp(prefix="ndgpu_bench_cns_")
+    fa_path = os.path.join(out_dir, "cns.%d.fasta" % rank)
+    write_wall = [0.0]
+    fasta_bytes = [0]
+
     def step():
         if args.no_overlap:
-            r_, o_ = a_recs, a_off
+            r_, o_, names = a_recs, a_off, a_names
         else:
             sub, off, seeds, n_bl = sh.piles(my_file)
             last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
-            r_, o_ = (a_recs, a_off) if analytic else (sub, off)
+            r_, o_, names = (a_recs, a_off, a_names) if analytic else (sub, off, seeds)
         t_c = time.perf_counter()
-        res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads, lengths_only=True)
-        cns_wall[0] += time.perf_counter() - t_c
+        res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads,
+                               lengths_only=args.lengths_only)
+        t_w = time.perf_counter()
+        cns_wall[0] += t_w - t_c
         # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
-        ok = [ln for ln, ide in res if ln >= 500 and ln > 4 and ide >= 0.8]
-        return sum(ok), len(ok)
+        n_ok = b_ok = 0
+        if args.lengths_only:
+            for ln, ide in res:
+                if ln >= 500 and ln > 4 and ide >= 0.8:
+                    n_ok += 1
+                    b_ok += ln
+        else:
+            with open(fa_path, "wb") as OUT, open(fa_path + ".idx", "wb") as IDX:
+                pos = 0
+                for name, (ln, ide, seq) in zip(names, res):
+                    if ln >= 500 and ln > 4 and ide >= 0.8:
+                        head = b">%d %d %f\n" % (name, ln, ide)
+                        OUT.write(head)
+                        OUT.write(seq)
+                        OUT.write(b"\n")
+                        pos += len(head) + ln + 1
+                        IDX.write(b"%d\t%d\t%d\n" % (name, pos - ln - 1, ln))
+                        n_ok += 1
+                        b_ok += ln
+                    elif ln != 3:
+                        IDX.write(b"%d\t0\t0\n" % name)
+                fasta_bytes[0] = pos
+        write_wall[0] += time.perf_counter() - t_w
+        return b_ok, n_ok
 
     for _ in range(args.warmup):
         step()
     cns_wall[0] = 0.0
+    write_wall[0] = 0.0
     api.reset_stats()
     if not args.no_overlap:
         from nextdenovo_amd import overlap as _ovl
         _ovl.pool_calls(reset=True)
     for k in sh.stats:
         sh.stats[k] = 0
+    host0 = host_snapshot()
     sync()
     t0 = time.perf_counter()
     bases = n_ok = 0
+    step_s = []
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         b, n = step()
+        step_s.append(time.perf_counter() - t_s)
         bases += b
         n_ok += n
     sync()
     dt = time.perf_counter() - t0
+    host1 = host_snapshot()
     st = api.stats()
     pool_timed = None
     if not args.no_overlap:
@@ -543,13 +638,27 @@ def main():
                         "latency, not by bytes (SURVEY.md section 8d expects << 1 % of the HBM roofline); launch times are HIP-event "
                         "brackets on the kernel's own stream with up to 8 contexts' launches in flight at once, `rocprof_avg_launch_ms` "
                         "is the same kernel's average in the committed trace",
-                "timed_step_note": "lengths_only=True: the library computes every corrected sequence, the Python copy of the bytes is skipped",
+                "timed_step_note": ("--lengths-only: the library computes every corrected sequence, the hand-over of the bytes and the "
+                                    "cns.fasta write are skipped" if args.lengths_only else
+                                    "every step takes the corrected sequences from the library and writes cns.fasta + cns.fasta.idx "
+                                    "(lib/nextcorrect.py:236-260) inside the timed region"),
                 "other_kernels": others}),
             "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "trace_words", "lq_rounds", "lq_declined", "max_band", "piles", "tags",
                                             "cells_msa", "links", "path_items", "score_segments", "score_repairs", "score_slow_piles")},
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms", "lq_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
+            "fasta_write": {"ms_per_step": write_wall[0] / args.steps * 1e3, "bytes_per_step": fasta_bytes[0],
+                            "included_in_value": not args.lengths_only},
+            # every timed step by itself (rank 0), so that a slow box, a cold start and noise can be told apart; `value` stays
+            # total bases / total wall of the K steps (the launch contract), the median is beside it
+            "step_ms": {"list": [round(x * 1e3, 1) for x in step_s], "min": round(min(step_s) * 1e3, 1),
+                        "median": round(sorted(step_s)[len(step_s) // 2] * 1e3, 1),
+                        "p90": round(sorted(step_s)[min(len(step_s) - 1, int(0.9 * len(step_s)))] * 1e3, 1),
+                        "max": round(max(step_s) * 1e3, 1),
+                        "value_at_median_step": (bases / args.steps) / sorted(step_s)[len(step_s) // 2]},
+            "host": dict(host_description(), host_threads=args.host_threads, contexts=int(os.environ.get("NDGPU_CONTEXTS", "0")) or "default",
+                         before=host0, after=host1),
             # buffers (re)allocated inside the timed steps: while batches ran (these stall every context) / between batches
             "allocations": {"in_step": int(st["allocs"]), "in_step_ms": round(st["alloc_ms"], 1), "between_batches": int(st["level_allocs"]),
                             "between_batches_ms": round(st["level_ms"], 1)},
@@ -601,6 +710,8 @@ def main():
             db.close()
             sys.exit("bench.py: the device's records differ from the reference's (see \"parity\")")
     db.close()
+    import shutil as _sh
+    _sh.rmtree(out_dir, ignore_errors=True)
     if dist is not None:
         dist.barrier()
         if exchange is not None and rank == 0:   # (every rank is past its last read)

@@ -184,6 +184,8 @@ typedef struct {
     uint64_t lq_aln_columns;   /* alignment columns (2-bit kinds) read */
     uint64_t lq_bases;         /* candidate bases (2-bit) read */
     uint64_t lq_out;           /* consensus characters written */
+    uint64_t lq_jobs;          /* K12 jobs (runs of regions scored from a speculative start) */
+    uint64_t lq_repairs;       /* of which scored again after a failed boundary check */
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

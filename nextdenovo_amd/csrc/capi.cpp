@@ -648,6 +648,7 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->allocs = s.allocs, o->alloc_ms = s.alloc_ms, o->level_allocs = s.level_allocs, o->level_ms = s.level_ms;
     o->traceback_launches = s.traceback_launches, o->lq_launches = s.lq_launches, o->lq_columns = s.lq_columns;
     o->lq_aln_columns = s.lq_aln_columns, o->lq_bases = s.lq_bases, o->lq_out = s.lq_out;
+    o->lq_jobs = s.lq_jobs, o->lq_repairs = s.lq_repairs;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

@@ -307,7 +307,8 @@ struct DeviceAligner::State {
     DevBuf<LqJobDev> d_lq_jobs;   // K12a's jobs and their streams: a header per cell row, a word per link
     DevBuf<uint64_t> d_lq_hdr;
     DevBuf<uint32_t> d_lq_lnk;
-    DevBuf<char> d_lq_out;
+    DevBuf<char> d_lq_out, d_lq_tmp;   // the piles' characters / the jobs' stretches of the walk (one slot per cell row)
+    DevBuf<int32_t> d_lq_bnd;          // K12b's boundary planes: 4 x kLqLinkCap words per job
     std::vector<ReadDev> reads;
     std::vector<PileDev> piles;
     hipEvent_t evs[8] = {nullptr};
@@ -429,7 +430,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
 #define NDGPU_NAME(x) s_->x.name = #x;
     NDGPU_NAME(h_ops) NDGPU_NAME(h_outs) NDGPU_NAME(up) NDGPU_NAME(down)
     NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec) NDGPU_NAME(d_lq_jobs) NDGPU_NAME(d_lq_hdr) NDGPU_NAME(d_lq_lnk)
-    NDGPU_NAME(d_lq_out)
+    NDGPU_NAME(d_lq_out) NDGPU_NAME(d_lq_tmp) NDGPU_NAME(d_lq_bnd)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v) NDGPU_NAME(d_wtrace) NDGPU_NAME(d_wmink)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
     NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
@@ -488,7 +489,7 @@ RuntimeStats DeviceAligner::total_stats() {
         t.links += s.links; t.score_launches += s.score_launches; t.backtrack_ms += s.backtrack_ms;
         t.score_segments += s.score_segments; t.score_repairs += s.score_repairs; t.score_slow_piles += s.score_slow_piles;
         t.traceback_launches += s.traceback_launches; t.lq_launches += s.lq_launches; t.lq_columns += s.lq_columns;
-        t.lq_aln_columns += s.lq_aln_columns; t.lq_bases += s.lq_bases; t.lq_out += s.lq_out;
+        t.lq_aln_columns += s.lq_aln_columns; t.lq_bases += s.lq_bases; t.lq_out += s.lq_out; t.lq_jobs += s.lq_jobs; t.lq_repairs += s.lq_repairs;
     }
     t.allocs = g_alloc_calls.load(), t.alloc_ms = (double)g_alloc_ns.load() * 1e-6;
     t.level_allocs = g_level_calls.load(), t.level_ms = (double)g_level_ns.load() * 1e-6;
@@ -536,7 +537,7 @@ void DeviceAligner::release_memory() {
     S.up_used = S.down_used = 0;
 #define NDGPU_REL(x) S.x.release();
     NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec) NDGPU_REL(d_lq_jobs) NDGPU_REL(d_lq_hdr) NDGPU_REL(d_lq_lnk)
-    NDGPU_REL(d_lq_out)
+    NDGPU_REL(d_lq_out) NDGPU_REL(d_lq_tmp) NDGPU_REL(d_lq_bnd)
     NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v) NDGPU_REL(d_wtrace) NDGPU_REL(d_wmink)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
     NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
@@ -580,7 +581,7 @@ void DeviceAligner::level_buffers(int drivers) {
         };
         try {
 #define NDGPU_LVL(x) lvl(S.x, #x[0] == 'd');
-            NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_jobs) NDGPU_LVL(d_lq_hdr) NDGPU_LVL(d_lq_lnk) NDGPU_LVL(d_lq_out)
+            NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_jobs) NDGPU_LVL(d_lq_hdr) NDGPU_LVL(d_lq_lnk) NDGPU_LVL(d_lq_out) NDGPU_LVL(d_lq_tmp) NDGPU_LVL(d_lq_bnd)
             NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v) NDGPU_LVL(d_wtrace) NDGPU_LVL(d_wmink)
             NDGPU_LVL(d_ids) NDGPU_LVL(d_reads) NDGPU_LVL(d_piles) NDGPU_LVL(d_read_pile) NDGPU_LVL(d_acc) NDGPU_LVL(d_tags)
             NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
@@ -929,6 +930,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
 constexpr uint32_t kLenClasses = 16384;  // 64-base length classes of the longest-first launch order (run_main); the last one holds >= 1 Mb
 constexpr uint64_t kLqJobColumns = 192;     // columns of a K12a job (a pile of 3,000 columns is ~15 wavefronts' worth of link building)
 constexpr uint64_t kLqMaxColumns = 12000;  // linked pseudo-seed columns K12 takes per pile (see run_lq)
+constexpr uint32_t kLqWarmColumns = 64;    // columns a K12b job starts before its own first one (speculative start, checked by the stitch)
 
 void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     if (n == 0) return;
@@ -1106,6 +1108,8 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.d_lq_hdr.reserve(hdr_words + 1);
     S.d_lq_lnk.reserve(lnk_words + 64);   // (K12b fetches a row's 64 link slots ahead)
     S.d_lq_out.reserve(out_bytes + 1);
+    S.d_lq_tmp.reserve(cell_rows + 1);
+    S.d_lq_bnd.reserve((jobs.size() + 1) * 4 * (size_t)kLqLinkCap);
 
     // forward / traceback chunks bounded by the trace budget (the column streams of every chunk stay resident)
     std::vector<size_t> chunk_end;
@@ -1155,8 +1159,12 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     }
     HIP_CHECK(hipEventRecord(S.evs[1], st));
     NDGPU_DBG(st, "lq: msa of %zu piles", n);
+    // test hooks: NDGPU_K12_WARM = warm-up columns of a job's speculative start; NDGPU_K12_FORCE=repair: every second job is scored again
+    // by the stitch kernel as if its boundary check had failed
+    static const uint32_t k12_warm = getenv("NDGPU_K12_WARM") ? (uint32_t)std::max(1, atoi(getenv("NDGPU_K12_WARM"))) : kLqWarmColumns;
+    static const uint32_t k12_force = (getenv("NDGPU_K12_FORCE") && !strcmp(getenv("NDGPU_K12_FORCE"), "repair")) ? 2u : 0u;
     launch_lq_msa(S.d_lq_piles.p, S.d_lq_jobs.p, S.d_lq_pieces.p, S.d_tasks.p, S.d_outs.p, S.d_ops.p, S.d_pool.p, S.d_lq_hdr.p, S.d_lq_lnk.p,
-                  S.d_lq_rec.p, S.d_lq_out.p, (int)n, (int)jobs.size(), st);
+                  S.d_lq_rec.p, S.d_lq_bnd.p, S.d_lq_tmp.p, S.d_lq_out.p, (int)n, (int)jobs.size(), k12_warm, k12_force, st);
     HIP_CHECK(hipEventRecord(S.evs[2], st));
     S.h_outs.reserve(nt + 1);
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, nt * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
@@ -1211,6 +1219,8 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         }
         R.lqc.assign(out.data() + P.out_off, P.out_len);
         R.ok = true;
+        S.stats.lq_repairs += P.n_repair;
+        S.stats.lq_jobs += P.n_jobs;
         S.stats.lq_columns += P.link_len;
         S.stats.lq_out += P.out_len;
         for (uint32_t k = 0; k < 30u * P.n_regions; k++) {
@@ -1407,8 +1417,11 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                 launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st, order);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
                 NDGPU_DBG(st, "main: traceback");
+                // (the same order: a wavefront of K8a is 64 walks, as long as its longest one -- in table order a 500-base walk
+                // shares a wavefront with a 200 kb one; NDGPU_K8_NO_ORDER: table order, for A/B runs)
+                static const bool k8_order = !getenv("NDGPU_K8_NO_ORDER");
                 launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr,
-                                     S.d_ops.p, nullptr, (int)(b - a), st);
+                                     S.d_ops.p, nullptr, (int)(b - a), st, k8_order ? order : nullptr);
                 NDGPU_DBG(st, "main: traceback done");
                 HIP_CHECK(hipEventRecord(S.evs[2], st));
                 HIP_CHECK(hipEventSynchronize(S.evs[2]));
@@ -1434,6 +1447,10 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             S.stats.trace_words += (uint64_t)o.trace_end;
             if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
             if (o.status == ST_NEED_WIDE) wide.push_back((int32_t)i);
+            if (o.status == ST_ALIGNED) {   // (K8a's output: 2-bit column kinds -- the term bench.py's roofline prices it with)
+                S.stats.trace_bits += (uint64_t)o.cells;
+                S.stats.columns += (uint64_t)o.n_cols;
+            }
         }
         if (!wide.empty()) run_wide(nullptr, nt, wide);
         S.stats.tasks += nt;

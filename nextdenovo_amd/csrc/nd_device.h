@@ -122,26 +122,38 @@ struct LqPileDev {
     uint32_t row_cap;        // capacity in cell rows ((column, delta) pairs) of the pile's cell records
     uint32_t out_cap;        // capacity of the pile's output characters
     uint32_t first_job, n_jobs;  // the pile's jobs (K12a), in column order
-    uint32_t pad_;
-    uint64_t cell_off;       // first cell record (6 per cell row)
+    uint32_t n_repair;       // (written by the stitch) jobs it scored again from their predecessor's true scores
+    uint64_t cell_off;       // first cell record (6 per cell row); cell_off / 6 = the pile's first scratch character
     uint64_t out_off;        // first output character
-    // written by the kernel
+    // written by the kernels
     uint32_t out_len;
     uint32_t err;            // nonzero: declined (capacity, or an alignment that does not end at both sequence ends)
+    uint32_t n_rows;         // cell rows of the pile
+    uint32_t pad_;
 };
 struct LqJobDev {            // K12a's unit of work: regions [g_a, g_b) of a pile, each with the 'N' column in front of it
     uint32_t pile;
     uint32_t g_a, g_b;
     uint32_t t0, t1;         // columns [t0, t1) of the linked pseudo-seed (t0 = the 'N' in front of region g_a; the last job ends behind the closing 'N')
     uint32_t row_cap, lnk_cap;   // capacity of the job's streams: cell-row headers, link words
-    uint32_t pad_;
+    uint32_t row0;           // (stitch) the job's first cell row within the pile
     uint64_t hdr_off, lnk_off;
-    // written by the kernel
-    uint32_t n_rows, n_links, err, pad2_;
+    // written by K12a
+    uint32_t n_rows, n_links, err;
+    // written by K12b (scores): links of the boundary column it started from / of its last column, the smallest offset-carrying
+    // candidate and the largest absolute value it compared (raw), a capacity error
+    uint32_t score_err;
+    uint32_t n_spec, n_fin;
+    int32_t mn, mx;
+    // written by K12d (walk)
+    uint32_t out_len, walk_err, walk_end, pad_;
 };
+constexpr int kLqLinkCap = 384;      // links per column the scoring tables (and a job's boundary planes) hold
+// K12: links per job (lq_links), scores + best links per job from a speculative start (lq_score), boundary checks / repairs per pile
+// (lq_stitch), walk per job (lq_walk), the pile's characters (lq_gather).  bnd: 4 x kLqLinkCap words per job; tmp_chars: one per cell row.
 void launch_lq_msa(LqPileDev *piles, LqJobDev *jobs, const LqPieceDev *pieces, const AlnTask *tasks, const AlnOut *outs, const uint32_t *ops,
-                   const uint32_t *pool, uint64_t *hdr, uint32_t *lnk, uint32_t *cell_rec, char *out_chars, int n_piles, int n_jobs,
-                   void *stream);
+                   const uint32_t *pool, uint64_t *hdr, uint32_t *lnk, uint32_t *cell_rec, int32_t *bnd, char *tmp_chars, char *out_chars,
+                   int n_piles, int n_jobs, uint32_t warm, uint32_t force_repair, void *stream);
 
 // ---- scoring DP (K10), segment-parallel: see the head comment of the K10 section in msa_kernels.hip ----
 struct SegItem {            // work item of the segment kernel
@@ -245,10 +257,11 @@ void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool
                         uint64_t *trace, int n_tasks, void *stream, const int32_t *order = nullptr);  // order: device, n_tasks ids, longest first
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace, int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream);
-// task_ids == nullptr: tasks [0, n), traces in the register path's stream format; otherwise the listed (wide-band) tasks,
-// traces in the wide kernel's row format
+// task_ids == nullptr: tasks [0, n), traces in the register path's stream format, walked in the order `order` lists them
+// (device, n ids; nullptr = table order); otherwise the listed (wide-band) tasks, traces in the wide kernel's row format
 void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                           const uint64_t *trace,
-                          const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n, void *stream);
+                          const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n, void *stream,
+                          const int32_t *order = nullptr);
 
 }  // namespace ndgpu

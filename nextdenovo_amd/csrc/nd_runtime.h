@@ -54,6 +54,8 @@ struct RuntimeStats {
     uint64_t lq_aln_columns = 0;      // alignment columns (2-bit kinds) K12 read
     uint64_t lq_bases = 0;            // candidate bases (2-bit) K12 read
     uint64_t lq_out = 0;              // consensus characters K12 wrote
+    uint64_t lq_jobs = 0;             // K12 jobs (runs of regions scored from a speculative start)
+    uint64_t lq_repairs = 0;          // of which the stitch kernel scored again (failed boundary check)
 };
 
 // Thrown when a device (or pinned host) allocation fails for lack of memory.  The C ABI catches it, releases the

@@ -545,18 +545,20 @@ void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t 
                        pool, db_pool, trace, trace_mink, vscratch, task_ids);
 }
 
-// task_ids == nullptr: every task of the table, traces in the register path's stream format; otherwise the listed (wide-band)
-// tasks, traces in the wide kernel's row format
+// task_ids == nullptr: every task of the table, traces in the register path's stream format -- in the order `order` lists them
+// (longest first: the 64 walks of a wavefront then are of one length class and end together, and the long ones start first), or
+// in table order; otherwise the listed (wide-band) tasks, traces in the wide kernel's row format
 void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                           const uint64_t *trace,
-                          const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream) {
+                          const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream,
+                          const int32_t *order) {
     if (n_tasks <= 0) return;
     if (task_ids)
         hipLaunchKernelGGL(ond_traceback_kernel<false>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                            tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
     else
         hipLaunchKernelGGL(ond_traceback_kernel<true>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                           tasks, outs, pool, db_pool, trace, (const int32_t *)nullptr, ops, task_ids, n_tasks);
+                           tasks, outs, pool, db_pool, trace, (const int32_t *)nullptr, ops, order, n_tasks);
 }
 
 }  // namespace ndgpu

@@ -42,8 +42,16 @@ def test_bench_line_on_a_tiny_genome(monkeypatch):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    cb = d["cpu_baseline"]   # both rates: the pool's makespan and the per-core figure measured inside the workers
+    assert cb["cpu_seconds"] > 0 and abs(cb["per_core_measured_x_cores"] - cb["per_core_measured"] * cb["cores"]) < 1e-6 * cb["per_core_measured_x_cores"]
+    assert cb["wall_s"] > 0 and cb["slowest_pile_cpu_s"] <= cb["cpu_seconds"]
     assert d["parity"]["piles"] > 5 and d["parity"]["mismatch"] == 0
     assert d["overlap"]["cpu_baseline"]["device_ovl_identical"] is True
+    # every timed step by itself, the box the host phases ran on, and the stage's output inside the timed region
+    assert len(d["step_ms"]["list"]) == d["steps"] and d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
+    assert d["host"]["cpu_count"] >= 1 and d["host"]["host_threads"] >= 1
+    assert d["fasta_write"]["included_in_value"] is True and d["fasta_write"]["bytes_per_step"] > 0
+    assert "cns.fasta" in r["timed_step_note"]
     # the timed step followed a warm-up step: nothing was (re)allocated in it
     assert d["allocations"]["in_step"] == 0 and d["overlap"]["pool_calls"]["n"] == 0
     assert d["counters"]["piles"] == d["config"]["piles_rank0"] and d["counters"]["lq_declined"] == 0

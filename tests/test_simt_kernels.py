@@ -147,7 +147,8 @@ for i, p in enumerate(util.load_piles()):
 st = api.Stats()
 lib.ndgpu_get_stats(C.byref(st))
 print(json.dumps(dict(bad=bad, segments=int(st.score_segments), repairs=int(st.score_repairs), slow=int(st.score_slow_piles),
-                      lq_rounds=int(st.lq_rounds), lq_declined=int(st.lq_declined))))
+                      lq_rounds=int(st.lq_rounds), lq_declined=int(st.lq_declined), lq_jobs=int(st.lq_jobs),
+                      lq_repairs=int(st.lq_repairs))))
 """
 
 
@@ -184,6 +185,26 @@ def test_lq_rounds_on_the_device_and_on_the_host(simt_lib):
     # piles whose low-quality regions add up to more columns than K12 takes go the host way, the others stay on the device
     mixed = _forced({"NDGPU_K12_MAX_COLUMNS": "150"}, stride=1)
     assert mixed["bad"] == [] and 0 < mixed["lq_declined"] < mixed["lq_rounds"], mixed
+
+
+@pytest.mark.parametrize("env,repairs", [
+    ({"NDGPU_K12_JOB_COLUMNS": "1"}, False),                                  # every region a job: a speculative start per region
+    ({"NDGPU_K12_JOB_COLUMNS": "1", "NDGPU_K12_WARM": "1"}, None),            # one warm-up column: boundary checks fail and are repaired
+    ({"NDGPU_K12_JOB_COLUMNS": "1", "NDGPU_K12_WARM": "3", "SIMT_LANES_DESCENDING": "1"}, None),
+    ({"NDGPU_K12_JOB_COLUMNS": "1", "NDGPU_K12_FORCE": "repair"}, True),      # every second job scored again by the stitch kernel
+    ({"NDGPU_K12_JOB_COLUMNS": "40", "NDGPU_K12_FORCE": "repair", "NDGPU_K12_WARM": "16"}, True),
+])
+def test_lq_rounds_cut_into_speculative_jobs(simt_lib, env, repairs):
+    """K12b scores a pile's low-quality-region MSA job by job from speculative starts (a warm-up on the tail of the job before, every
+    unknown score one constant), the stitch kernel checks every boundary and scores a job that fails again from the true scores, the
+    walk is cut at the 'N' cells: whatever the cut and the warm-up, the records are the reference's."""
+    r = _forced(env, stride=1)
+    assert r["bad"] == [] and r["lq_declined"] == 0, r
+    assert r["lq_jobs"] > r["lq_rounds"], r          # piles were cut into several jobs
+    if repairs is True:
+        assert r["lq_repairs"] > 0, r
+    elif repairs is False:
+        assert r["lq_repairs"] == 0, r
 
 
 def _synth_set(gsize, mu, sigma, seed, depth=30, profile="ont"):
