@@ -32,6 +32,10 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(" ms_per_step %.1f value %.1f M cns %.1f ovl %.1f | kernel_ms %s" % (d["ms_per_step"], d["value"] / 1e6, d["consensus_ms_per_step"], d["overlap"]["ms_per_step"], d["kernel_ms"]))
 P
             ;;
+    q:*)    # quick bench under an environment: stage name "q:TAG:VAR=val,VAR2=val2"
+            qtag=$(echo "$s" | cut -d: -f2); qenv=$(echo "$s" | cut -d: -f3- | tr ',' ' ')
+            env $qenv timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > "$out/bench_q_$qtag.json" 2> "$out/bench_q_$qtag.err"; echo "q $qtag exit $?"
+            python tools/bench_brief.py "$out/bench_q_$qtag.json" ;;
     prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/stats" -o s -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/$out/prof.log" 2>&1)
             python tools/rocprof_summary.py "$(ls "$out"/stats/*results.db | head -1)" > "$out/kernel_stats.txt" 2>> "$out/prof.log"; head -30 "$out/kernel_stats.txt"; rm -rf "$out/stats" ;;
     pmc)    for c in FETCH_SIZE WRITE_SIZE; do
