@@ -203,7 +203,8 @@ def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16):
     ref_so = os.path.join(ROOT, "oracle", "_ref", "nextcorrect.so")
     if not os.path.exists(ref_so) or not piles:
         return None, {}
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    from nextdenovo_amd import hostinfo
+    cores = max(1, min(hostinfo.effective_cpus(), 64))   # (the CPUs this process can have: a cgroup quota counts, see hostinfo.py)
     if n_sample <= 0:
         n_sample = min(len(piles), 16 * cores)
     step = max(1, len(piles) // n_sample)
@@ -230,6 +231,7 @@ def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16):
     _CPU_CTX = None
     per_core = bases / cpu_s if cpu_s > 0 else 0.0
     return {"value": bases / dt, "unit": "corrected bases/s", "cores": cores, "kind": "reference",
+            "cores_note": "min(64, the CPUs this process can have: hardware threads %s, cgroup quota %s)" % (os.cpu_count(), hostinfo.cgroup_cpu_quota()),
             "wall_s": dt, "cpu_seconds": cpu_s, "per_core_measured": per_core, "per_core_measured_x_cores": per_core * cores,
             "slowest_pile_cpu_s": slowest, "piles_per_worker": len(idx) / cores,
             "sample": "%d of %d piles (every %d-th + the %d longest seeds), %d corrected bases; compiled reference nextcorrect.so, fork pool "
@@ -242,7 +244,7 @@ def parity_block(ref, gpu_full, piles):
     """Compare the device's records of the CPU-sample piles (taken from a whole-batch call, the very call shape
     the timed steps make) with the compiled reference's: length, float32 identity bits, md5 of the bases.  Seeds the
     reference itself could not hold in memory (its len 3, lib/nextcorrect.c:2254-2261) are counted, not compared."""
-    bad, ref_oom = [], 0
+    bad, ref_oom, from_file = [], 0, 0
     for i, (ln, bits, digest) in sorted(ref.items()):
         g_ln, g_ide, g_seq = gpu_full[i]
         if ln == 3:
@@ -250,8 +252,12 @@ def parity_block(ref, gpu_full, piles):
             continue
         if ln > 4 or g_ln > 4:
             g_bits = struct.unpack("<I", struct.pack("<f", g_ide))[0] if g_ln > 4 else 0
-            g_dig = hashlib.md5(g_seq).hexdigest() if g_ln > 4 else ""
-            same = (ln, bits, digest) == (g_ln, g_bits, g_dig)
+            if g_seq is None:   # (a record the stage's output filter dropped -- lib/nextcorrect.py:236 -- is not in cns.fasta)
+                same = (ln, bits) == (g_ln, g_bits)
+            else:
+                g_dig = hashlib.md5(g_seq).hexdigest() if g_ln > 4 else ""
+                same = (ln, bits, digest) == (g_ln, g_bits, g_dig) and len(g_seq) == g_ln
+                from_file += 1
         else:
             same = ln == g_ln  # error seeds: the convention code only (2 uncorrectable, 3 memory, 4 all clipped)
         if not same:
@@ -259,7 +265,9 @@ def parity_block(ref, gpu_full, piles):
     lens = [int(piles[i]["recs"][0][3]) + 1 for i in ref]
     depth = [int(piles[i]["recs"].shape[0]) for i in ref]
     return {"piles": len(ref), "mismatch": len(bad), "against": "oracle/_ref/nextcorrect.so (compiled reference)",
-            "compared": "len, float32 identity bits, md5(seq)", "longest_seed": max(lens) if lens else 0,
+            "compared": "len, float32 identity bits, md5(seq); the sequences are the bytes the last timed step wrote into its cns.fasta "
+                        "(%d records read back from the file)" % from_file if from_file else "len, float32 identity bits, md5(seq)",
+            "longest_seed": max(lens) if lens else 0,
             "seeds_ge_100kb": sum(1 for x in lens if x >= 100000), "deepest_pile": max(depth) if depth else 0,
             "error_seeds": sum(1 for v in ref.values() if v[0] <= 4), "reference_out_of_memory_seeds": ref_oom,
             "device_out_of_memory_seeds": sum(1 for i in ref if gpu_full[i][0] == 3), "mismatches": bad[:8]}
@@ -277,7 +285,8 @@ def cpu_baseline_overlap(rs_dev, preset, device_records=None):
     exe = os.path.join(ROOT, "oracle", "_ref", "minimap2-nd")
     if not os.path.exists(exe):
         return None
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    from nextdenovo_amd import hostinfo
+    cores = max(1, min(hostinfo.effective_cpus(), 64))
     wd = tempfile.mkdtemp(prefix="ndbench")
     p = os.path.join(wd, "reads.2bit")
     ovl.write_2bit(p, rs_dev.ids, rs_dev.lens, rs_dev.words, rs_dev.word_off)
@@ -319,7 +328,9 @@ def host_description():
         aff = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         aff = None
-    return {"cpu_model": model, "cpu_count": os.cpu_count(), "cpus_allowed": aff}
+    from nextdenovo_amd import hostinfo
+    return {"cpu_model": model, "cpu_count": os.cpu_count(), "cpus_allowed": aff, "cgroup_cpu_quota": hostinfo.cgroup_cpu_quota(),
+            "effective_cpus": hostinfo.effective_cpus()}
 
 
 def host_snapshot():
@@ -330,6 +341,10 @@ def host_snapshot():
         snap["loadavg"] = [round(x, 1) for x in os.getloadavg()]
     except OSError:
         pass
+    from nextdenovo_amd import hostinfo
+    th = hostinfo.throttle_stat()
+    if th:
+        snap["cgroup_periods_throttled_usec"] = list(th)
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))[:1]:
         for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("gpu_busy_percent", "gpu_busy_percent")):
             try:
@@ -432,7 +447,8 @@ def main():
     dist_dev = "cuda" if (dist is None or os.environ.get("NDGPU_BENCH_DIST_BACKEND", "nccl") == "nccl") else "cpu"
     analytic = args.analytic_piles or args.no_overlap
     if args.host_threads <= 0:  # the ranks of one node share its cores
-        args.host_threads = max(8, (os.cpu_count() or 8) // max(1, world))
+        from nextdenovo_amd import hostinfo
+        args.host_threads = max(4, hostinfo.effective_cpus() // max(1, world))
     t_gen = time.perf_counter()
     name, rs, words, word_off, lens, preset, read_type, max_lq, sort_k, genome_size, depth, profile = make_workload(args)
     n_files, my_file = shard_of_rank(world, rank, args.seed_files or world, args.shard)
@@ -473,6 +489,7 @@ def main():
     fa_path = os.path.join(out_dir, "cns.%d.fasta" % rank)
     write_wall = [0.0]
     fasta_bytes = [0]
+    last_res = []
 
     def step():
         if args.no_overlap:
@@ -482,33 +499,25 @@ def main():
             last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
             r_, o_, names = (a_recs, a_off, a_names) if analytic else (sub, off, seeds)
         t_c = time.perf_counter()
-        res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads,
-                               lengths_only=args.lengths_only)
-        t_w = time.perf_counter()
-        cns_wall[0] += t_w - t_c
-        # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
         n_ok = b_ok = 0
         if args.lengths_only:
-            for ln, ide in res:
-                if ln >= 500 and ln > 4 and ide >= 0.8:
-                    n_ok += 1
-                    b_ok += ln
+            res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads, lengths_only=True)
+            t_w = time.perf_counter()
+            cns_wall[0] += t_w - t_c
         else:
             with open(fa_path, "wb") as OUT, open(fa_path + ".idx", "wb") as IDX:
-                pos = 0
-                for name, (ln, ide, seq) in zip(names, res):
-                    if ln >= 500 and ln > 4 and ide >= 0.8:
-                        head = b">%d %d %f\n" % (name, ln, ide)
-                        OUT.write(head)
-                        OUT.write(seq)
-                        OUT.write(b"\n")
-                        pos += len(head) + ln + 1
-                        IDX.write(b"%d\t%d\t%d\n" % (name, pos - ln - 1, ln))
-                        n_ok += 1
-                        b_ok += ln
-                    elif ln != 3:
-                        IDX.write(b"%d\t0\t0\n" % name)
-                fasta_bytes[0] = pos
+                t_lib = [0.0]
+                res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads,
+                                       fasta=(OUT, IDX, names, 500, 0.8), lib_wall=t_lib)
+                t_w = t_c + t_lib[0]
+                cns_wall[0] += t_lib[0]
+                fasta_bytes[0] = OUT.tell()
+        last_res[:] = [res]
+        # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
+        for ln, ide in res:
+            if ln >= 500 and ln > 4 and ide >= 0.8:
+                n_ok += 1
+                b_ok += ln
         write_wall[0] += time.perf_counter() - t_w
         return b_ok, n_ok
 
@@ -695,7 +704,23 @@ def main():
         parity_fail = False
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             out["cpu_baseline"], ref = cpu_baseline(rs, piles, read_type, args.cpu_sample, max_lq)
-            if ref:  # one more (untimed) whole-batch call that keeps the sequences: what the timed steps computed
+            if ref and not args.lengths_only and last_res and os.path.exists(fa_path):
+                # what the LAST TIMED STEP wrote: (len, identity) of every pile from the library's records, the bases from the
+                # step's cns.fasta (a record the output filter dropped has no bases there: length and identity only)
+                by_name = {}
+                with open(fa_path, "rb") as f:
+                    blob = f.read()
+                at = 0
+                while at < len(blob):
+                    e1 = blob.index(b"\n", at)
+                    e2 = blob.index(b"\n", e1 + 1)
+                    by_name[int(blob[at + 1:e1].split()[0])] = blob[e1 + 1:e2]
+                    at = e2 + 1
+                full = [(ln, ide, by_name.get(int(piles[i]["seed"]))) for i, (ln, ide) in enumerate(last_res[0])]
+                out["parity"] = parity_block(ref, full, piles)
+                out["parity"]["fasta_records"] = len(by_name)
+                parity_fail = out["parity"]["mismatch"] != 0
+            elif ref:  # one more (untimed) whole-batch call that keeps the sequences: what the timed steps computed
                 full = db.correct_piles(recs, off, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads)
                 out["parity"] = parity_block(ref, full, piles)
                 parity_fail = out["parity"]["mismatch"] != 0

@@ -11,6 +11,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per devic
 from . import build as _build
 
 _LIB = None
+_BIG = C.c_char * (1 << 30)   # (one array type for every record's view; never instantiated over memory it does not own)
 
 
 class ConsensusTrimed(C.Structure):
@@ -153,15 +154,21 @@ class ReadDB:
             self._h = None
 
     def correct_piles(self, recs, pile_off, min_len_aln=500, max_cov_aln=130, min_cov_base=4, max_lq_length=10000,
-                      min_error_corrected_ratio=0.8, split=0, fast=0, read_type=1, host_threads=0, lengths_only=False):
+                      min_error_corrected_ratio=0.8, split=0, fast=0, read_type=1, host_threads=0, lengths_only=False, fasta=None, lib_wall=None):
+        """fasta = (OUT, IDX, seed names, min_len_seed, min_error_corrected_ratio): the accepted records are written as
+        lib/nextcorrect.py:236-260 writes them and [(len, identity)] comes back instead of the sequences."""
         import numpy as np
         recs = np.ascontiguousarray(recs, dtype=np.uint32)
         pile_off = np.ascontiguousarray(pile_off, dtype=np.uint64)
         n = int(pile_off.size) - 1
         out = (C.POINTER(ConsensusTrimed) * n)()
+        import time
+        t0 = time.perf_counter()
         rc = self._lib.ndgpu_correct_piles(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
                                            min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
                                            host_threads, out)
+        if lib_wall is not None:   # (the library call by itself: what is left of the caller's wall is the hand-over of the records)
+            lib_wall[0] = time.perf_counter() - t0
         if rc == -2:
             raise ValueError("ndgpu_correct_piles: an overlap record names a read or a window that is not in this read DB "
                              "(sorted.ovl and the .idx / .2bit files do not belong together?)")
@@ -173,7 +180,33 @@ class ReadDB:
                 res.append((out[i].contents.len, out[i].contents.identity))
                 self._lib.free_consensus_trimed(out[i])
             return res
+        if fasta is not None:
+            return self._write_fasta(out, n, *fasta)
         return [_take(self._lib, out[i]) for i in range(n)]
+
+    def _write_fasta(self, out, n, OUT, IDX, names, min_len_seed, min_ratio):
+        """The output loop of lib/nextcorrect.py:236-260 (no -s) straight from the library's records: header, the bases as the
+        library holds them (one copy, into the file), the .idx line.  OUT / IDX are binary files; returns [(len, identity)]."""
+        res = []
+        pos = OUT.tell()
+        free = self._lib.free_consensus_trimed
+        for i in range(n):
+            c = out[i].contents
+            ln, ide = c.len, c.identity
+            name = int(names[i])
+            if ln >= min_len_seed and ln > 4 and ide >= min_ratio:
+                head = b">%d %d %f\n" % (name, ln, ide)
+                OUT.write(head)
+                OUT.write(memoryview(_BIG.from_address(c.seq))[:ln])   # (a view of the library's bytes: no copy before the file's)
+                OUT.write(b"\n")
+                pos += len(head) + ln + 1
+                if IDX is not None:
+                    IDX.write(b"%d\t%d\t%d\n" % (name, pos - ln - 1, ln))
+            elif ln != 3 and IDX is not None:
+                IDX.write(b"%d\t0\t0\n" % name)
+            res.append((ln, ide))
+            free(out[i])
+        return res
 
 
 class ExtJob(C.Structure):

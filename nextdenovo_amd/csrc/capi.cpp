@@ -145,7 +145,9 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
                         unsigned int min_cov, float min_error_corrected_ratio, unsigned int split, unsigned int fast,
                         int read_type, int host_threads, consensus_trimed **out) {
     if (n_piles <= 0) return 0;
-    if (host_threads <= 0) host_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    // (what the process can have, not what the machine has: a cgroup quota of 16 CPUs on a 256-thread host; asking for more only
+    // gets the whole process throttled)
+    if (host_threads <= 0 || (host_threads > effective_cpus() && !getenv("NDGPU_NO_CPU_CAP"))) host_threads = effective_cpus();
     std::vector<PileEngine *> eng((size_t)n_piles, nullptr);
     parallel_for((size_t)n_piles, host_threads, [&](size_t i) {
         eng[i] = new PileEngine(seqs[i], aln_start[i], aln_end[i], seq_count[i],
@@ -295,7 +297,9 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                         unsigned int fast, int read_type, int host_threads, consensus_trimed **out) {
     if (n_piles <= 0) return 0;
     if (!h || !h->db || !h->dev_pool) return -1;
-    if (host_threads <= 0) host_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    // (what the process can have, not what the machine has: a cgroup quota of 16 CPUs on a 256-thread host; asking for more only
+    // gets the whole process throttled)
+    if (host_threads <= 0 || (host_threads > effective_cpus() && !getenv("NDGPU_NO_CPU_CAP"))) host_threads = effective_cpus();
     const ReadDb &db = *h->db;
     // every record must name reads of this DB and windows inside them (a sorted.ovl written against other .idx files
     // would otherwise index the host tables and the device pool out of bounds): -2, nothing is computed
@@ -355,15 +359,26 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
         // rank of 8 take 170 ms instead of 262, the 407 of a rank of 4 255 instead of 320: profiles/r04_rank_share_config2.txt)
         int per_ctx = n_piles >= 1024 ? 2 : 1;
         if (const char *e = getenv("NDGPU_SUBBATCHES_PER_CONTEXT")) per_ctx = std::max(1, atoi(e));
-        const uint64_t piece = std::min<uint64_t>(tag_budget, std::max<uint64_t>(total / (uint64_t)(drivers * per_ctx) + 1, 2000000ull));
-        uint64_t acc = 0;
+        // exactly drivers x per_ctx pieces of equal cost where the caps allow it (a cut where the running cost passes the next multiple of
+        // total / pieces): with "cut before the piece would overflow" the pieces came out slightly small and a 17th, alone in a third round
+        // of the contexts, ended every config-2 call ~60 ms late.  The caps (piles per sub-batch, the memory plan's columns) still cut.
+        const uint64_t n_target = (uint64_t)std::max(1, drivers * per_ctx);
+        const uint64_t piece = std::min<uint64_t>(tag_budget, std::max<uint64_t>(total / n_target + 1, 2000000ull));
+        const bool by_target = piece > total / n_target && total / n_target + 1 >= 2000000ull;  // (neither cap nor floor bites)
+        uint64_t acc = 0, run = 0, next_cut = 1;
         size_t cnt = 0;
         for (size_t k = 0; k < (size_t)n_piles; k++) {
-            if (cnt && (cnt >= sub || acc + est[k] > piece)) {
+            bool cut = cnt && (cnt >= sub || acc + est[k] > tag_budget);
+            if (!cut && cnt) {
+                if (by_target) cut = next_cut < n_target && run + est[k] / 2 >= next_cut * total / n_target;
+                else cut = acc + est[k] > piece;
+            }
+            if (cut) {
                 sub_start.push_back(k);
                 acc = 0, cnt = 0;
+                while (by_target && next_cut < n_target && run + est[k] / 2 >= next_cut * total / n_target) next_cut++;
             }
-            acc += est[k], cnt++;
+            acc += est[k], run += est[k], cnt++;
         }
         sub_start.push_back((size_t)n_piles);
     }
@@ -468,6 +483,9 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                 g_prof.m_post * 1e-9);
         fprintf(stderr, "[ndgpu prof] advance, CPU seconds by phase: after main %.3f  after extract %.3f  after LQ round 1 %.3f  after round 2 + splice %.3f\n",
                 g_prof.adv_ns[0] * 1e-9, g_prof.adv_ns[1] * 1e-9, g_prof.adv_ns[2] * 1e-9, g_prof.adv_ns[3] * 1e-9);
+        fprintf(stderr, "[ndgpu prof] after extract: 8-mer ranking %.3f  POA %.3f  LQ round 1 layout %.3f s (CPU seconds)\n", g_prof.rank_ns * 1e-9,
+                g_prof.poa_ns * 1e-9, g_prof.lqstart_ns * 1e-9);
+        g_prof.rank_ns = g_prof.poa_ns = g_prof.lqstart_ns = 0;
         fprintf(stderr, "[ndgpu prof] LQ-stage alignment batches (%llu jobs): host packing %.3f s, device round trip %.3f s, host decoding %.3f s "
                         "(wall sums over contexts)\n", (unsigned long long)g_prof.c_jobs.load(), g_prof.c_pack * 1e-9, g_prof.c_dev * 1e-9,
                 g_prof.c_decode * 1e-9);

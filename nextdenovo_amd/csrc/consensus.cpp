@@ -24,6 +24,8 @@
 #include <chrono>
 #include <cstring>
 #include <thread>
+#include <cmath>
+#include <sched.h>
 
 namespace ndgpu {
 static inline uint64_t now_ns();
@@ -568,10 +570,17 @@ class PileImpl {
         phase = PileEngine::EXTRACT;
     }
 
+    uint64_t poa_ns_local = 0;
     void after_extract() {
+        const uint64_t t0 = now_ns();
+        poa_ns_local = 0;
         lq_max_aln_length = prm.read_type == 3 ? lqseqs_from_candidates_kmer() : lqseqs_from_candidates();
         extract.regions.clear();
+        const uint64_t t1 = now_ns();
         start_lq_round();
+        g_prof.poa_ns += poa_ns_local;
+        g_prof.rank_ns += t1 - t0 - poa_ns_local;
+        g_prof.lqstart_ns += now_ns() - t1;
     }
 
     // lib/nextcorrect.c:1717-1784
@@ -1028,7 +1037,7 @@ class PileImpl {
                 if (lq.seqs[0].len < 20000) {
                     std::vector<std::string> in;
                     for (int x = 0; x < k; x++) in.push_back(lq.seqs[j + x].seq);
-                    lq.sudoseed = poa_consensus(in);
+                    { const uint64_t tp = now_ns(); lq.sudoseed = poa_consensus(in); poa_ns_local += now_ns() - tp; }
                 } else lq.sudoseed = lq.seqs[0].seq;
                 lq.has_seed = true;
                 lq.sudoseed_len = (unsigned)lq.sudoseed.size();
@@ -1116,7 +1125,7 @@ class PileImpl {
             {
                 std::vector<std::string> in;
                 for (int x = 0; x < k; x++) in.push_back(lq.seqs[j + x].seq);
-                lq.sudoseed = poa_consensus(in);
+                { const uint64_t tp = now_ns(); lq.sudoseed = poa_consensus(in); poa_ns_local += now_ns() - tp; }
             }
             lq.has_seed = true;
             lq.sudoseed_len = (unsigned)lq.sudoseed.size();
@@ -1487,6 +1496,43 @@ bool pack_2bit_lsb(uint32_t *out, const char *s, size_t n) {
     return (bad & 0x80u) == 0;
 }
 
+int effective_cpus() {
+    static const int n = [] {
+        int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+            const int a = CPU_COUNT(&set);
+            if (a > 0 && a < hw) hw = a;
+        }
+        auto from_quota = [&](double quota, double period) {
+            if (quota > 0 && period > 0) {
+                const int q = (int)std::ceil(quota / period - 1e-9);
+                if (q >= 1 && q < hw) hw = q;
+            }
+        };
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "max 100000" or "1600000 100000"
+            char a[64] = {0};
+            double period = 0;
+            if (fscanf(f, "%63s %lf", a, &period) == 2 && strcmp(a, "max") != 0) from_quota(atof(a), period);
+            fclose(f);
+        } else {
+            double quota = -1, period = 0;
+            if (FILE *q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (fscanf(q, "%lf", &quota) != 1) quota = -1;
+                fclose(q);
+            }
+            if (FILE *q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(q, "%lf", &period) != 1) period = 0;
+                fclose(q);
+            }
+            from_quota(quota, period);
+        }
+        if (const char *e = getenv("NDGPU_HOST_CPUS")) hw = std::max(1, atoi(e));  // (override)
+        return hw;
+    }();
+    return n;
+}
+
 static std::atomic<int> g_cores_total(0), g_cores_used(0);
 void CoreGovernor::set_total(int total) { g_cores_total.store(total < 0 ? 0 : total); }
 int CoreGovernor::acquire(int base) {
@@ -1496,7 +1542,8 @@ int CoreGovernor::acquire(int base) {
     for (;;) {
         int grant = total - used;
         if (grant < base) grant = base;
-        if (grant > 4 * base) grant = 4 * base;  // thread start-up and allocator contention eat the gain beyond this
+        static const int cap_mul = getenv("NDGPU_GOV_CAP") ? std::max(1, atoi(getenv("NDGPU_GOV_CAP"))) : 4;
+        if (grant > cap_mul * base) grant = cap_mul * base;  // thread start-up and allocator contention eat the gain beyond this
         if (g_cores_used.compare_exchange_weak(used, used + grant)) return grant;
     }
 }

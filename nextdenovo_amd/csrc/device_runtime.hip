@@ -395,6 +395,9 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     s_->device = env ? atoi(env) : 0;
     if (s_->device >= n) s_->device = s_->device % n;
     HIP_CHECK(hipSetDevice(s_->device));
+    // A host thread that waits for its stream sleeps instead of spinning: eight driver threads spinning in hipStreamSynchronize are
+    // eight cores the host phases of the other contexts do not get -- half of a 16-CPU container (NDGPU_SPIN_SYNC=1: the runtime's default)
+    if (!getenv("NDGPU_SPIN_SYNC")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     // Optional CU partition (NDGPU_RESERVED_CUS=n, default off): the first n compute units are kept for the scoring
     // launches of the small sub-batches that hold the longest seeds (lat_stream), every other kernel of every context
     // runs on the rest.  Measured on config 2: the long chains gain nothing (their 3.5 us per column is the chain
@@ -439,9 +442,10 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     NDGPU_NAME(d_fin) NDGPU_NAME(d_sums) NDGPU_NAME(d_items) NDGPU_NAME(d_bt_exit) NDGPU_NAME(d_bt_steps) NDGPU_NAME(d_bt_entry)
     NDGPU_NAME(d_bt_off) NDGPU_NAME(d_path) NDGPU_NAME(d_blocks) NDGPU_NAME(d_regions) NDGPU_NAME(d_strpool) NDGPU_NAME(d_cursor)
 #undef NDGPU_NAME
-    HIP_CHECK(hipEventCreate(&s_->ev0));
-    HIP_CHECK(hipEventCreate(&s_->ev1));
-    for (auto &e : s_->evs) HIP_CHECK(hipEventCreate(&e));
+    const unsigned ev_flags = getenv("NDGPU_SPIN_SYNC") ? hipEventDefault : hipEventBlockingSync;  // (hipEventSynchronize sleeps, see above)
+    HIP_CHECK(hipEventCreateWithFlags(&s_->ev0, ev_flags));
+    HIP_CHECK(hipEventCreateWithFlags(&s_->ev1, ev_flags));
+    for (auto &e : s_->evs) HIP_CHECK(hipEventCreateWithFlags(&e, ev_flags));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)8 << 30))
         s_->trace_budget_bytes = std::min<size_t>(free_b / 24, (size_t)8 << 30);
@@ -1417,9 +1421,10 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                 launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st, order);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
                 NDGPU_DBG(st, "main: traceback");
-                // (the same order: a wavefront of K8a is 64 walks, as long as its longest one -- in table order a 500-base walk
-                // shares a wavefront with a 200 kb one; NDGPU_K8_NO_ORDER: table order, for A/B runs)
-                static const bool k8_order = !getenv("NDGPU_K8_NO_ORDER");
+                // (K8a stays in table order: measured in round 5, the 64 walks of a wavefront ordered longest first like K7's --
+                // equal lengths, long walks first -- cost 605 ms of traceback per step against 496: the lanes of a wavefront in pile
+                // order walk neighbouring windows of one seed and share its cache lines; NDGPU_K8_ORDER=1 switches the order on)
+                static const bool k8_order = getenv("NDGPU_K8_ORDER") != nullptr;
                 launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr,
                                      S.d_ops.p, nullptr, (int)(b - a), st, k8_order ? order : nullptr);
                 NDGPU_DBG(st, "main: traceback done");

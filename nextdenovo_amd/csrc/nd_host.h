@@ -178,9 +178,15 @@ struct HostProf {
     std::atomic<uint64_t> main_ns{0}, extract_ns{0}, align_ns{0}, advance_ns{0}, build_ns{0}, jobs{0};
     std::atomic<uint64_t> m_prep{0}, m_aln{0}, m_tags{0}, m_msa{0}, m_post{0};  // inside run_main
     std::atomic<uint64_t> adv_ns[4] = {{0}, {0}, {0}, {0}};  // CPU time inside PileEngine::advance by phase (summed over threads)
+    std::atomic<uint64_t> rank_ns{0}, poa_ns{0}, lqstart_ns{0};  // inside "after extract": 8-mer ranking, POA, laying out LQ round 1
     std::atomic<uint64_t> c_pack{0}, c_dev{0}, c_decode{0}, c_jobs{0};  // LQ-stage alignment batches: host packing / device round trip / host decoding
 };
 extern HostProf g_prof;
+
+// The CPUs this process can actually have: the smaller of the hardware threads, the scheduling affinity and the cgroup CPU quota
+// (cpu.max / cpu.cfs_quota_us).  A container on a 256-thread host with a quota of 16 CPUs that starts 256 busy threads spends its
+// quota in the first quarter of every 100 ms period and is then throttled as a whole -- the threads that launch kernels included.
+int effective_cpus();
 
 // Host cores are shared by the driver threads of all device contexts: each host section is guaranteed its base share and
 // borrows the cores that no other section is using at that moment (the tail of a call, when few contexts are still

@@ -923,6 +923,7 @@ ndgpu_ovl_index *ndgpu_ovl_index_create(const ndgpu_ovl_opt *opt, uint32_t n_rea
 		int dev = 0;
 		if (const char *e = getenv("NDGPU_DEVICE")) dev = atoi(e);
 		HIP_OK(hipSetDevice(dev));
+		if (!getenv("NDGPU_SPIN_SYNC")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);  // (a waiting host thread sleeps: see device_runtime.hip)
 		h = new ndgpu_ovl_index();
 		h->e.device = dev;
 		HIP_OK(hipStreamCreate(&h->e.stream));

@@ -177,3 +177,8 @@ extern "C" void ndtest_advance_profile(double out[4]) {
         g_prof.adv_ns[i] = 0;
     }
 }
+// ... and inside "after extract": 8-mer ranking, POA, laying out LQ round 1
+extern "C" void ndtest_extract_profile(double out[3]) {
+    out[0] = g_prof.rank_ns.load() * 1e-9, out[1] = g_prof.poa_ns.load() * 1e-9, out[2] = g_prof.lqstart_ns.load() * 1e-9;
+    g_prof.rank_ns = 0, g_prof.poa_ns = 0, g_prof.lqstart_ns = 0;
+}

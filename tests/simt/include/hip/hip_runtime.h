@@ -213,7 +213,8 @@ typedef simtStream *hipStream_t;
 typedef simtEvent *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
-enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
+enum { hipEventDefault = 0, hipEventBlockingSync = 1, hipEventDisableTiming = 2 };
+enum { hipDeviceScheduleAuto = 0, hipDeviceScheduleSpin = 1, hipDeviceScheduleYield = 2, hipDeviceScheduleBlockingSync = 4 };
 enum { hipHostMallocDefault = 0 };
 struct hipDeviceProp_t {
     char name[256];
@@ -248,6 +249,7 @@ hipError_t hipStreamSynchronize(hipStream_t);
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned);
 hipError_t hipEventCreate(hipEvent_t *);
 hipError_t hipEventCreateWithFlags(hipEvent_t *, unsigned);
+hipError_t hipSetDeviceFlags(unsigned);
 hipError_t hipEventDestroy(hipEvent_t);
 hipError_t hipEventRecord(hipEvent_t, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t);

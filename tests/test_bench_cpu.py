@@ -46,6 +46,7 @@ def test_bench_line_on_a_tiny_genome(monkeypatch):
     assert cb["cpu_seconds"] > 0 and abs(cb["per_core_measured_x_cores"] - cb["per_core_measured"] * cb["cores"]) < 1e-6 * cb["per_core_measured_x_cores"]
     assert cb["wall_s"] > 0 and cb["slowest_pile_cpu_s"] <= cb["cpu_seconds"]
     assert d["parity"]["piles"] > 5 and d["parity"]["mismatch"] == 0
+    assert d["parity"]["fasta_records"] > 5 and "cns.fasta" in d["parity"]["compared"]   # the bytes compared are the ones the step wrote
     assert d["overlap"]["cpu_baseline"]["device_ovl_identical"] is True
     # every timed step by itself, the box the host phases ran on, and the stage's output inside the timed region
     assert len(d["step_ms"]["list"]) == d["steps"] and d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]

@@ -24,6 +24,8 @@ g = synth.make_genome(int(float(sys.argv[1]) if len(sys.argv) > 1 else 200000), 
 rs = synth.simulate_reads(g, 50, "ont", seed=43)
 piles = sorted(synth.build_piles(rs, seed_cutoff=1000), key=lambda p: -int(p["recs"][0][3]))[:int(sys.argv[2]) if len(sys.argv) > 2 else 6]
 prof = (C.c_double * 4)()
+ex = (C.c_double * 3)()
+ext = [0.0] * 3
 tot = [0.0] * 4
 bases = 0
 t0 = time.perf_counter()
@@ -34,8 +36,12 @@ for p in piles:
     h.ndtest_advance_profile(prof)
     print("seed %6d bases, %3d reads -> %6d corrected | advance: main %.3f extract %.3f lq1 %.3f lq2+splice %.3f s"
           % (en[0] + 1, len(seqs), ln, prof[0], prof[1], prof[2], prof[3]))
+    h.ndtest_extract_profile(ex)
+    for i in range(3):
+        ext[i] += ex[i]
     for i in range(4):
         tot[i] += prof[i]
     bases += ln
+print("after extract: ranking %.3f  POA %.3f  LQ round 1 layout %.3f s" % tuple(ext))
 print("total %.1f s wall (oracle alignments included); advance by phase: %s; %.2f us of advance per corrected base"
       % (time.perf_counter() - t0, " ".join("%.3f" % x for x in tot), sum(tot) / max(1, bases) * 1e6))
