@@ -158,6 +158,18 @@ int ndgpu_correct_piles(ndgpu_db *db, int n_piles, const uint32_t *recs, const u
                         unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
                         unsigned int fast, int read_type, int host_threads, consensus_trimed **out);
 
+/* The same call, handing the records over as they become ready: `done(user, pile_ids, n)` is called once per finished sub-batch
+ * (n piles whose out[pile_ids[k]] are final), from the host thread that drove that sub-batch, one call at a time (the library
+ * serialises them).  The reference streams its records the same way -- the parent of lib/nextcorrect.py:232-260 prints each seed
+ * as its worker returns it, in no particular order -- so a caller can write cns.fasta while the later sub-batches are still on the
+ * device.  Every pile is reported exactly once before the call returns; done == NULL makes this ndgpu_correct_piles. */
+typedef void (*ndgpu_piles_done_fn)(void *user, const uint32_t *pile_ids, int n);
+int ndgpu_correct_piles_stream(ndgpu_db *db, int n_piles, const uint32_t *recs, const uint64_t *pile_off,
+                               unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
+                               unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
+                               unsigned int fast, int read_type, int host_threads, consensus_trimed **out,
+                               ndgpu_piles_done_fn done, void *user);
+
 /* Counters accumulated by this process's device runtime since the last reset. */
 typedef struct {
     uint64_t tasks, wide_tasks, cells, d_steps, trace_bits, columns, pool_bases, seq_bases;

@@ -19,6 +19,9 @@ class ConsensusTrimed(C.Structure):
     _fields_ = [("len", C.c_uint), ("identity", C.c_float), ("seq", C.c_void_p)]
 
 
+PILES_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint32), C.c_int)   # ndgpu_piles_done_fn
+
+
 class Stats(C.Structure):
     _fields_ = [("tasks", C.c_uint64), ("wide_tasks", C.c_uint64), ("cells", C.c_uint64), ("d_steps", C.c_uint64),
                 ("trace_bits", C.c_uint64), ("columns", C.c_uint64), ("pool_bases", C.c_uint64), ("seq_bases", C.c_uint64),
@@ -69,6 +72,8 @@ def _bind(lib):
                                         C.c_uint, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_int,
                                         C.POINTER(C.POINTER(ConsensusTrimed))]
     lib.ndgpu_correct_piles.restype = C.c_int
+    lib.ndgpu_correct_piles_stream.argtypes = lib.ndgpu_correct_piles.argtypes + [PILES_DONE_FN, C.c_void_p]
+    lib.ndgpu_correct_piles_stream.restype = C.c_int
     lib.ndgpu_get_stats.argtypes = [C.POINTER(Stats)]
     lib.ndgpu_reset_stats.argtypes = []
     lib.ndgpu_device_count.restype = C.c_int
@@ -164,33 +169,56 @@ class ReadDB:
         out = (C.POINTER(ConsensusTrimed) * n)()
         import time
         t0 = time.perf_counter()
-        rc = self._lib.ndgpu_correct_piles(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
-                                           min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
-                                           host_threads, out)
-        if lib_wall is not None:   # (the library call by itself: what is left of the caller's wall is the hand-over of the records)
+        if fasta is not None:
+            # the records are handed over sub-batch by sub-batch, while the later ones are still on the device: the parent of
+            # lib/nextcorrect.py:232-260 prints each seed as its worker returns it, in no particular order
+            OUT, IDX, names, min_len_seed, min_ratio = fasta
+            res = [None] * n
+            state = {"pos": OUT.tell(), "err": None, "t": 0.0}
+
+            def done(_user, ids, cnt):
+                tw = time.perf_counter()
+                try:
+                    self._write_records(out, [ids[k] for k in range(cnt)], res, state, OUT, IDX, names, min_len_seed, min_ratio)
+                except BaseException as e:  # noqa: BLE001  (an exception must not unwind through the C caller)
+                    state["err"] = e
+                state["t"] += time.perf_counter() - tw
+
+            cb = PILES_DONE_FN(done)
+            rc = self._lib.ndgpu_correct_piles_stream(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
+                                                      min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
+                                                      host_threads, out, cb, None)
+            if state["err"] is not None:
+                raise state["err"]
+        else:
+            rc = self._lib.ndgpu_correct_piles(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
+                                               min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
+                                               host_threads, out)
+        if lib_wall is not None:   # (the library call, hand-over included when it streams; [1]: the time inside the hand-over)
             lib_wall[0] = time.perf_counter() - t0
+            if len(lib_wall) > 1:
+                lib_wall[1] = state["t"] if fasta is not None else 0.0
         if rc == -2:
             raise ValueError("ndgpu_correct_piles: an overlap record names a read or a window that is not in this read DB "
                              "(sorted.ovl and the .idx / .2bit files do not belong together?)")
         if rc != 0:
             raise RuntimeError("ndgpu_correct_piles failed (%d)" % rc)
+        if fasta is not None:
+            return res
         if lengths_only:
             res = []
             for i in range(n):
                 res.append((out[i].contents.len, out[i].contents.identity))
                 self._lib.free_consensus_trimed(out[i])
             return res
-        if fasta is not None:
-            return self._write_fasta(out, n, *fasta)
         return [_take(self._lib, out[i]) for i in range(n)]
 
-    def _write_fasta(self, out, n, OUT, IDX, names, min_len_seed, min_ratio):
+    def _write_records(self, out, ids, res, state, OUT, IDX, names, min_len_seed, min_ratio):
         """The output loop of lib/nextcorrect.py:236-260 (no -s) straight from the library's records: header, the bases as the
-        library holds them (one copy, into the file), the .idx line.  OUT / IDX are binary files; returns [(len, identity)]."""
-        res = []
-        pos = OUT.tell()
+        library holds them (one copy, into the file), the .idx line.  OUT / IDX are binary files; res[i] = (len, identity)."""
+        pos = state["pos"]
         free = self._lib.free_consensus_trimed
-        for i in range(n):
+        for i in ids:
             c = out[i].contents
             ln, ide = c.len, c.identity
             name = int(names[i])
@@ -204,9 +232,9 @@ class ReadDB:
                     IDX.write(b"%d\t%d\t%d\n" % (name, pos - ln - 1, ln))
             elif ln != 3 and IDX is not None:
                 IDX.write(b"%d\t0\t0\n" % name)
-            res.append((ln, ide))
+            res[i] = (ln, ide)
             free(out[i])
-        return res
+        state["pos"] = pos
 
 
 class ExtJob(C.Structure):

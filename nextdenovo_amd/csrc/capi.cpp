@@ -295,6 +295,15 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
                         unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
                         unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
                         unsigned int fast, int read_type, int host_threads, consensus_trimed **out) {
+    return ndgpu_correct_piles_stream(h, n_piles, recs, pile_off, min_len_aln, max_cov_aln, min_cov, max_lq_length, min_error_corrected_ratio,
+                                      split, fast, read_type, host_threads, out, nullptr, nullptr);
+}
+
+int ndgpu_correct_piles_stream(ndgpu_db *h, int n_piles, const uint32_t *recs, const uint64_t *pile_off,
+                               unsigned int min_len_aln, unsigned int max_cov_aln, unsigned int min_cov,
+                               unsigned int max_lq_length, float min_error_corrected_ratio, unsigned int split,
+                               unsigned int fast, int read_type, int host_threads, consensus_trimed **out,
+                               ndgpu_piles_done_fn done, void *user) {
     if (n_piles <= 0) return 0;
     if (!h || !h->db || !h->dev_pool) return -1;
     // (what the process can have, not what the machine has: a cgroup quota of 16 CPUs on a 256-thread host; asking for more only
@@ -362,21 +371,51 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
         // exactly drivers x per_ctx pieces of equal cost where the caps allow it (a cut where the running cost passes the next multiple of
         // total / pieces): with "cut before the piece would overflow" the pieces came out slightly small and a 17th, alone in a third round
         // of the contexts, ended every config-2 call ~60 ms late.  The caps (piles per sub-batch, the memory plan's columns) still cut.
-        const uint64_t n_target = (uint64_t)std::max(1, drivers * per_ctx);
+        // Rounds may taper (NDGPU_TAPER=w1,w2,...: the share of the call's cost each round of the contexts takes; default: equal
+        // rounds): what the LAST round leaves for the host -- its piles' candidate ranking, POA, two more rounds -- ends the call with
+        // the device idle, and it is that round's share of the call's host work divided by the CPUs the process has.
+        std::vector<double> weights((size_t)per_ctx, 1.0 / per_ctx);
+        if (const char *e = getenv("NDGPU_TAPER")) {
+            std::vector<double> w;
+            for (const char *p = e; *p;) {
+                char *end = nullptr;
+                const double v = strtod(p, &end);
+                if (end == p) break;
+                if (v > 0) w.push_back(v);
+                p = *end ? end + 1 : end;
+            }
+            double sum = 0;
+            for (double v : w) sum += v;
+            if (!w.empty() && sum > 0) {
+                for (double &v : w) v /= sum;
+                weights = w;
+            }
+        }
+        std::vector<uint64_t> targets;   // cumulative cost at which piece k ends
+        {
+            double at = 0;
+            for (double w : weights)
+                for (int c = 0; c < drivers; c++) {
+                    at += w / drivers;
+                    targets.push_back((uint64_t)(at * (double)total));
+                }
+            if (!targets.empty()) targets.pop_back();  // (the last piece ends with the piles)
+        }
+        const uint64_t n_target = (uint64_t)targets.size() + 1;
         const uint64_t piece = std::min<uint64_t>(tag_budget, std::max<uint64_t>(total / n_target + 1, 2000000ull));
-        const bool by_target = piece > total / n_target && total / n_target + 1 >= 2000000ull;  // (neither cap nor floor bites)
-        uint64_t acc = 0, run = 0, next_cut = 1;
-        size_t cnt = 0;
+        const bool by_target = total / n_target + 1 <= tag_budget && total / n_target + 1 >= 2000000ull;  // (neither cap nor floor bites)
+        uint64_t acc = 0, run = 0;
+        size_t cnt = 0, next_cut = 0;
         for (size_t k = 0; k < (size_t)n_piles; k++) {
             bool cut = cnt && (cnt >= sub || acc + est[k] > tag_budget);
             if (!cut && cnt) {
-                if (by_target) cut = next_cut < n_target && run + est[k] / 2 >= next_cut * total / n_target;
+                if (by_target) cut = next_cut < targets.size() && run + est[k] / 2 >= targets[next_cut];
                 else cut = acc + est[k] > piece;
             }
             if (cut) {
                 sub_start.push_back(k);
                 acc = 0, cnt = 0;
-                while (by_target && next_cut < n_target && run + est[k] / 2 >= next_cut * total / n_target) next_cut++;
+                while (by_target && next_cut < targets.size() && run + est[k] / 2 >= targets[next_cut]) next_cut++;
             }
             acc += est[k], run += est[k], cnt++;
         }
@@ -388,6 +427,7 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
     if (const char *e = getenv("NDGPU_THREADS_PER_CONTEXT")) threads_each = std::max(1, atoi(e));
     CoreGovernor::set_total(getenv("NDGPU_NO_BORROW") ? 0 : host_threads);
     std::atomic<uint64_t> oom_seeds{0};
+    std::mutex done_mu;
     // one range of the length-sorted piles through one context; out of device memory -> the context's buffers are
     // dropped and the range is halved, down to a single pile, which is then an out-of-memory seed (len 3)
     std::function<void(int, size_t, size_t)> run_range = [&](int ctx, size_t base, size_t cnt) {
@@ -437,6 +477,10 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
             if (cnt == 1) {
                 out[order[base]] = (consensus_trimed *)make_error_seed(3);
                 oom_seeds++;
+                if (done) {
+                    std::lock_guard<std::mutex> lock(done_mu);
+                    done(user, &order[base], 1);
+                }
             } else {
                 run_range(ctx, base, cnt / 2);
                 run_range(ctx, base + cnt / 2, cnt - cnt / 2);
@@ -445,6 +489,10 @@ int ndgpu_correct_piles(ndgpu_db *h, int n_piles, const uint32_t *recs, const ui
         }
         const auto t_t0 = std::chrono::steady_clock::now();
         for (size_t k = 0; k < cnt; k++) out[order[base + k]] = (consensus_trimed *)eng[k]->take_result();
+        if (done) {  // (the caller's hand-over of this sub-batch's records, while the other contexts work on)
+            std::lock_guard<std::mutex> lock(done_mu);
+            done(user, &order[base], (int)cnt);
+        }
         // tearing down the per-pile host state (thousands of small vectors per pile, ~0.3 ms each; parallel frees
         // only fight over the allocator) is not on anybody's critical path: a reaper thread does it while the caller
         // goes on, and the next call (or the library's unload) waits for it

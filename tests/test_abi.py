@@ -10,7 +10,7 @@ def _declared_functions(header):
     txt = open(header).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = set()
-    for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", txt, flags=re.M):
+    for m in re.finditer(r"^(?!typedef\b)[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", txt, flags=re.M):   # (function-pointer typedefs are not functions)
         names.add(m.group(1))
     return names
 
