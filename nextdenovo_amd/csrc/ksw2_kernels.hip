@@ -470,7 +470,12 @@ static int run_batch(const ndgpu_ksw_job *jobs, int n, ndgpu_ksw_result *res) {
                  hip_ok(hipStreamSynchronize(st), "sync");
         }
     }
-    if (st) (void)hipStreamDestroy(st);
+    if (st) {
+        // (a failure after the launches: the kernels may still be running on `st`, and the blocks below go back to a pool that hands
+        // them to the next caller at once -- hipStreamDestroy does not wait)
+        if (!ok) (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
     if (!ok) return -1;
     for (int i = 0; i < n; i++) {
         const Ez &z = h_res[(size_t)i];
@@ -675,7 +680,12 @@ extern "C" int ndgpu_ksw_ll_batch(const ndgpu_ll_job *jobs, int n, ndgpu_ll_resu
                  hip_ok(hipStreamSynchronize(st), "sync");
         }
     }
-    if (st) (void)hipStreamDestroy(st);
+    if (st) {
+        // (a failure after the launches: the kernels may still be running on `st`, and the blocks below go back to a pool that hands
+        // them to the next caller at once -- hipStreamDestroy does not wait)
+        if (!ok) (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
     if (!ok) return -1;
     for (int i = 0; i < n; i++) out[i].score = r[(size_t)i].score, out[i].qe = r[(size_t)i].qe, out[i].te = r[(size_t)i].te;
     return 0;

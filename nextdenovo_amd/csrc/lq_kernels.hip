@@ -156,6 +156,15 @@ __global__ __launch_bounds__(64) void lq_links_kernel(LqJobDev *__restrict__ job
                 else al = true;
             }
         }
+        if (al) {
+            // the job before checks "no columns of the finished piece left over" only where an 'N' column follows INSIDE it; for the
+            // region in front of this job that column is this job's first, so the count is taken here: the alignment must hold
+            // exactly one kind that is not a hanging base (kind 1) per column of the region
+            uint32_t cols_t = 0;
+            const uint32_t *Wc = ops + T.ops_off;
+            for (uint32_t c = T.ops_cap - (uint32_t)O.n_cols; c < T.ops_cap; c++) cols_t += lq_op_at(Wc, c) != 1u;
+            if (cols_t != pc.sl) err = 7;
+        }
         if (!al) {
             p1 = tag_pack((int32_t)t_end, 0u, 6u);
             p2 = pc.sl >= 2u ? tag_pack((int32_t)t_end - 1, 0u, 6u) : tag_pack((int32_t)t_end - 1, 0u, 5u);  // (the 'N' in front of a one-column region)

@@ -27,6 +27,8 @@
 #include <map>
 #include <chrono>
 #include <mutex>
+#include <thread>
+#include <exception>
 #include <unordered_map>
 
 namespace ndovl {
@@ -114,7 +116,14 @@ void *pool_alloc(size_t bytes)
 #ifdef SIMT_EMULATION
 		const size_t unit = getenv("NDGPU_OVL_SLAB_MB") ? (size_t)atol(getenv("NDGPU_OVL_SLAB_MB")) << 20 : 0;
 #else
-		const size_t unit = getenv("NDGPU_OVL_SLAB_MB") ? (size_t)atol(getenv("NDGPU_OVL_SLAB_MB")) << 20 : (size_t)8 << 30;
+		// (8 GB on a 288 GB MI355X; a sixteenth of the memory on a smaller part, so that one long-lived block -- the resident read
+		// words -- does not pin an eighth of the device in its slab)
+		static const size_t dev_unit = [] {
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) return (size_t)8 << 30;
+			return std::max<size_t>((size_t)256 << 20, std::min<size_t>((size_t)8 << 30, total_b / 16));
+		}();
+		const size_t unit = getenv("NDGPU_OVL_SLAB_MB") ? (size_t)atol(getenv("NDGPU_OVL_SLAB_MB")) << 20 : dev_unit;
 #endif
 		size_t want = std::max(c, unit);
 		void *p = nullptr;
@@ -203,10 +212,10 @@ void pool_free(void *p)
 #endif
 }
 
-void pool_trim()
+size_t pool_trim() // the bytes given back to the driver (idle slabs only: a slab that holds a live block stays)
 {
 	std::lock_guard<std::mutex> g(g_pool_mu);
-	(void)release_idle_slabs();
+	return release_idle_slabs();
 }
 
 // what the pool holds beyond what is in use (an upper bound of what pool_trim() can give back: idle slabs only)
@@ -359,6 +368,7 @@ struct Engine {
 	uint32_t dbg_r0 = 0, dbg_n = 0;
 
 	DevBuf<uint8_t> tmp;
+	std::vector<hipStream_t> lane_streams;   // the streams of map()'s concurrent batches (created on first use)
 	void *temp(size_t bytes) { if (tmp.n < bytes) tmp.alloc(bytes + bytes / 4); return tmp.p; }
 
 	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p, bucket.p, bucket_shift}; }
@@ -642,18 +652,60 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	uint64_t budget = 192ULL << 20; // anchors per batch (~100 B of HBM each)
 	if (const char *e = getenv("NDGPU_OVL_BATCH_ANCHORS")) budget = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
 
-	uint32_t r0 = 0;
-	while (r0 < n_q) {
+	// The batches run side by side (NDGPU_OVL_LANES of them at a time, a host thread and a stream each): every kernel of a batch is a
+	// chain of its own -- K4 lasts as long as its heaviest read pair, the replay passes of the exact sort are host round trips, K5 as
+	// long as its heaviest read -- and alone on the device each of them leaves it mostly idle (68 ms of kernels one after the other
+	// for a config-2 job).  The reads of a batch know nothing of the other batches: a set that fits one batch is cut into `lanes`.
+	int lanes = 3;
+	if (const char *e = getenv("NDGPU_OVL_LANES")) lanes = std::max(1, atoi(e));
+	if (lanes > 1 && total_a >= (uint64_t)lanes * (2ULL << 20)) budget = std::min<uint64_t>(budget, total_a / (uint64_t)lanes + 1);
+	std::vector<std::pair<uint32_t, uint32_t>> ranges;
+	for (uint32_t r0 = 0; r0 < n_q;) {
 		uint32_t r1 = r0;
 		while (r1 < n_q && (r1 - r0) < max_batch_reads && (r1 == r0 || h_raoff[r1 + 1] - h_raoff[r0] <= budget)) ++r1;
+		ranges.push_back({r0, r1});
+		r0 = r1;
+	}
+	struct BatchOut {
+		std::vector<OvlRec> recs;
+		std::vector<OvlRec10> recs10;
+		std::vector<uint32_t> counts;
+		std::vector<uint64_t> ca_x, ca_y, ca_off{0};   // (ca_off: relative to the batch)
+		ndgpu_ovl_stats st{};
+	};
+	std::vector<BatchOut> outs(ranges.size());
+	const Regs *const regs_all = regs;
+	const bool want10 = out10 != nullptr;
+	std::mutex dbg_mu;
+	auto run_batch = [&](size_t bi, hipStream_t stream, DevBuf<uint8_t> &lane_tmp) {
+		// (everything the batch touches by these names is its own: its stream, its scratch, its counters, its output)
+		BatchOut &BO = outs[bi];
+		ndgpu_ovl_stats &st = BO.st;
+		std::vector<OvlRec> &out = BO.recs;
+		std::vector<OvlRec10> *const out10 = want10 ? &BO.recs10 : nullptr;
+		Regs lregs{};
+		if (regs_all) {
+			lregs = *regs_all;
+			lregs.counts = &BO.counts, lregs.max_anchors = nullptr;
+			if (regs_all->ca_x) lregs.ca_x = &BO.ca_x, lregs.ca_y = &BO.ca_y, lregs.ca_off = &BO.ca_off;
+		}
+		const Regs *const regs = regs_all ? &lregs : nullptr;
+		auto temp = [&](size_t bytes) -> void * { if (lane_tmp.n < bytes) lane_tmp.alloc(bytes + bytes / 4); return lane_tmp.p; };
+		auto exscan = [&](const uint32_t *in, uint64_t *o, size_t n) {
+			size_t tb2 = 0;
+			exscan_u32_to_u64(nullptr, tb2, in, o, n, stream);
+			exscan_u32_to_u64(temp(tb2), tb2, in, o, n, stream);
+		};
+		EvTimer tm(stream);
+		size_t tb = 0;
+		const uint32_t r0 = ranges[bi].first, r1 = ranges[bi].second;
 		const uint32_t nb = r1 - r0;
 		const uint64_t a_base = h_raoff[r0], na = h_raoff[r1] - a_base;
 		++st.batches;
 		if (na == 0) {
 			if (regs) regs->counts->insert(regs->counts->end(), nb, 0u);
 			if (regs && regs->ca_off) regs->ca_off->insert(regs->ca_off->end(), nb, regs->ca_off->back());
-			r0 = r1;
-			continue;
+			return;
 		}
 		KeyLayout L;
 		L.pos_bits = pos_bits, L.rev_shift = pos_bits + rid_bits, L.read_shift = L.rev_shift + 1, L.read_base = r0;
@@ -807,8 +859,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 			st.chain_cells += h_cells;
 			for (uint32_t c : h_chain) st.chains += c;
 			st.overlaps += n_out;
-			r0 = r1;
-			continue;
+			return;
 		}
 		DevBuf<OvlRec> dense(n_out + 1);
 		launch_compact_recs(r_aoff.p, nb, P.min_cnt, recs.p, n_rec.p, rec_off.p, dense.p, stream);
@@ -865,11 +916,64 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		st.overlaps += n_out;
 
 		// debug view (last batch)
-		dbg_r0 = r0, dbg_n = nb;
-		dbg_aoff.assign(h_raoff.begin() + r0, h_raoff.begin() + r1 + 1);
-		for (auto &x : dbg_aoff) x -= a_base;
-		dbg_ax = std::move(ax); dbg_ay = std::move(ay); dbg_f = std::move(f); dbg_p = std::move(p);
-		r0 = r1;
+		if (bi + 1 == ranges.size()) {
+			std::lock_guard<std::mutex> g(dbg_mu);
+			dbg_r0 = r0, dbg_n = nb;
+			dbg_aoff.assign(h_raoff.begin() + r0, h_raoff.begin() + r1 + 1);
+			for (auto &x : dbg_aoff) x -= a_base;
+			dbg_ax = std::move(ax); dbg_ay = std::move(ay); dbg_f = std::move(f); dbg_p = std::move(p);
+		}
+	};
+	const size_t n_lanes = std::min<size_t>((size_t)lanes, ranges.size());
+	if (n_lanes <= 1) {
+		for (size_t bi = 0; bi < ranges.size(); ++bi) run_batch(bi, stream, tmp);
+	} else {
+		HIP_OK(hipStreamSynchronize(stream));   // (the minimizers, their seed counts and offsets are final)
+		while (lane_streams.size() < n_lanes) {
+			hipStream_t ls = nullptr;
+			HIP_OK(hipStreamCreate(&ls));
+			lane_streams.push_back(ls);
+		}
+		std::atomic<size_t> next{0};
+		std::vector<std::exception_ptr> errs(n_lanes);
+		std::vector<std::thread> th;
+		for (size_t w = 0; w < n_lanes; ++w)
+			th.emplace_back([&, w] {
+				try {
+					HIP_OK(hipSetDevice(device));
+					DevBuf<uint8_t> lane_tmp;
+					for (;;) {
+						const size_t bi = next.fetch_add(1);
+						if (bi >= ranges.size()) break;
+						run_batch(bi, lane_streams[w], lane_tmp);
+					}
+					HIP_OK(hipStreamSynchronize(lane_streams[w]));
+				} catch (...) {
+					errs[w] = std::current_exception();
+					next = ranges.size();   // (the other lanes stop at their next batch)
+					(void)hipStreamSynchronize(lane_streams[w]);   // nothing of this lane is in flight when its blocks go back to the pool
+				}
+			});
+		for (auto &t : th) t.join();
+		for (auto &e : errs) if (e) std::rethrow_exception(e);
+	}
+	// the batches' outputs, in read order
+	for (BatchOut &BO : outs) {
+		out.insert(out.end(), BO.recs.begin(), BO.recs.end());
+		if (out10) out10->insert(out10->end(), BO.recs10.begin(), BO.recs10.end());
+		if (regs) {
+			regs->counts->insert(regs->counts->end(), BO.counts.begin(), BO.counts.end());
+			if (regs->ca_x) {
+				const uint64_t base = regs->ca_off->back();
+				regs->ca_x->insert(regs->ca_x->end(), BO.ca_x.begin(), BO.ca_x.end());
+				regs->ca_y->insert(regs->ca_y->end(), BO.ca_y.begin(), BO.ca_y.end());
+				for (size_t i = 1; i < BO.ca_off.size(); ++i) regs->ca_off->push_back(base + BO.ca_off[i]);
+			}
+		}
+		const ndgpu_ovl_stats &b = BO.st;
+		st.seed_ms += b.seed_ms, st.sort_ms += b.sort_ms, st.exact_sort_ms += b.exact_sort_ms, st.chain_ms += b.chain_ms, st.hits_ms += b.hits_ms;
+		st.ext_ms += b.ext_ms, st.tie_reads += b.tie_reads, st.chain_cells += b.chain_cells, st.chains += b.chains, st.overlaps += b.overlaps;
+		st.batches += b.batches, st.ext_problems += b.ext_problems, st.ext_launches += b.ext_launches;
 	}
 	return out10 ? (int64_t)out10->size() : (int64_t)out.size();
 }
@@ -942,8 +1046,11 @@ void ndgpu_ovl_index_destroy(ndgpu_ovl_index *h)
 	if (!h) return;
 	hipStream_t s = h->e.stream;
 	if (s) (void)hipStreamSynchronize(s);
+	const std::vector<hipStream_t> lanes = h->e.lane_streams;
+	for (hipStream_t ls : lanes) (void)hipStreamSynchronize(ls);
 	delete h;
 	if (s) (void)hipStreamDestroy(s);
+	for (hipStream_t ls : lanes) (void)hipStreamDestroy(ls);
 }
 
 int32_t ndgpu_ovl_index_mid_occ(ndgpu_ovl_index *h, float frac)
@@ -1192,9 +1299,7 @@ void ndgpu_ovl_words_release(const uint32_t *words)
 
 uint64_t ndgpu_ovl_trim(void)
 {
-	const uint64_t b = ndovl::pool_cached_bytes();
-	ndovl::pool_trim();
-	return b;
+	return (uint64_t)ndovl::pool_trim();   // (what went back to the driver: idle slabs, not everything that was cached)
 }
 
 int64_t ndgpu_pack_2bit(uint32_t n_reads, const uint8_t *ascii, uint64_t n_bytes, const uint64_t *ascii_off, const uint32_t *lens,

@@ -8,6 +8,6 @@
 namespace ndovl {
 void *pool_alloc(size_t bytes);   // throws std::runtime_error on failure
 void pool_free(void *p);
-void pool_trim();                 // release every cached block
+size_t pool_trim();               // idle slabs back to the driver; returns the bytes released
 size_t pool_cached_bytes();
 }

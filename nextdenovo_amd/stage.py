@@ -102,29 +102,65 @@ class Exchange:
         self.dir, self.rank, self.timeout_s, self.step = directory, rank, timeout_s, 0
         os.makedirs(directory, exist_ok=True)
         self.stats = {"sent": 0, "received": 0, "recomputed": 0, "wait_s": 0.0}
+        self._mine = []   # (step, path) of the files this rank wrote and nobody is known to have read
 
-    def _path(self, step, k):
-        return os.path.join(self.dir, "step%06d.job%05d.npy" % (step, k))
+    KEEP_STEPS = 3   # an owner keeps the files of its last steps; older ones nobody has read are removed by it
 
-    def begin_step(self):
-        self.step += 1   # (a file is removed by its one reader once it has been read: the writer may be steps ahead of the reader)
+    def _path(self, step, k, owner):
+        return os.path.join(self.dir, "step%06d.job%05d.r%d.npy" % (step, k, owner))
 
-    def put(self, k, recs):
-        final = self._path(self.step, k)[:-4] + ".r%d.npy" % self.rank
+    def begin_step(self, step=None):
+        """One call per LOGICAL step (`Shard.piles` makes it once, before its attempts: a retry after an out-of-memory overlap
+        stage stays in the step its peers are in).  A file is removed by its one reader once it has been read -- the writer may be
+        steps ahead of the reader --, and what a reader never came for is removed by its owner KEEP_STEPS steps later."""
+        self.step = self.step + 1 if step is None else int(step)
+        keep = []
+        for st, path in self._mine:
+            if st <= self.step - self.KEEP_STEPS:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+            else:
+                keep.append((st, path))
+        self._mine = keep
+
+    def put(self, k, recs, owner=None):
+        """Job k of this step, written under the SEED FILE that owns it (`owner_of`; the rank by default: bench.py gives seed file r to
+        rank r)."""
+        final = self._path(self.step, k, self.rank if owner is None else owner)
         tmp = final + ".tmp"
         with open(tmp, "wb") as f:
             np.save(f, recs)
         os.rename(tmp, final)   # (atomic: a reader sees the whole file or none)
+        self._mine.append((self.step, final))
         self.stats["sent"] += 1
 
+    def _owner_moved_on(self, k, owner):
+        """The owner has written job k of a LATER step: the file of this step is not coming any more (it was read by nobody in time
+        and removed, or the owner never wrote it)."""
+        import glob
+        for path in glob.glob(os.path.join(self.dir, "step*.job%05d.r%d.npy" % (k, owner))):
+            try:
+                if int(os.path.basename(path)[4:10]) > self.step:
+                    return True
+            except ValueError:
+                pass
+        return False
+
     def get(self, k, owner):
-        """The records of job k as rank `owner` wrote them, or None after the timeout."""
-        path = self._path(self.step, k)[:-4] + ".r%d.npy" % owner
+        """The records of job k as the owner (a seed file index, `owner_of`) wrote them, or None after the timeout / once the owner
+        is seen to have moved on."""
+        path = self._path(self.step, k, owner)
         t0 = time.perf_counter()
+        t_look = t0
         while not os.path.exists(path):
-            if time.perf_counter() - t0 > self.timeout_s:
-                self.stats["wait_s"] += time.perf_counter() - t0
+            now = time.perf_counter()
+            if now - t0 > self.timeout_s or (now - t_look > 0.05 and self._owner_moved_on(k, owner) and not os.path.exists(path)):
+                self.stats["wait_s"] += now - t0
                 return None
+            if now - t_look > 0.05:
+                t_look = now
             time.sleep(0.0005)
         self.stats["wait_s"] += time.perf_counter() - t0
         self.stats["received"] += 1
@@ -162,10 +198,18 @@ class Shard:
         self.exchange = exchange   # None: every job this seed file needs is computed here
         # the reads are mapped step after step and job after job: their words go to the device once (like the consensus read DB),
         # not with every index build and every query batch
+        # (the device copy is keyed by this array's address range: the array must not be written to while the Shard lives -- it is
+        # made read-only here where that is this object's to decide)
         self._resident = False
         if isinstance(self.backend, DeviceBackend) and not os.environ.get("NDGPU_OVL_NO_RESIDENT"):   # (the switch: an A/B knob)
-            overlap.words_resident(self.words)
-            self._resident = True
+            try:
+                overlap.words_resident(self.words)
+                self._resident = True
+                if self.words.flags.owndata:
+                    self.words.flags.writeable = False
+            except (MemoryError, RuntimeError) as e:   # no room for the copy: every index build / query batch uploads its words
+                import sys
+                print("[ndgpu stage] read words not resident (%s): uploaded per call" % (e,), file=sys.stderr)
 
     def close(self):
         if self._resident:
@@ -186,14 +230,15 @@ class Shard:
         return [j for j in job_matrix(len(self.seed_ids), len(self.part_ids))
                 if j[1] == i or (j[2] == "seed" and j[3] == i)]
 
-    def overlaps(self, i):
-        """Step-1 records of every job of seed file i, job order."""
+    def overlaps(self, i, own_step=False):
+        """Step-1 records of every job of seed file i, job order.  own_step: the caller has begun the exchange's step itself (a retry
+        must not begin another)."""
         import time
         t0 = time.perf_counter()
         out = []
         be = self.backend
         ex = self.exchange
-        if ex is not None:
+        if ex is not None and not own_step:
             ex.begin_step()
         try:
             jobs = self.jobs_of(i)
@@ -210,7 +255,7 @@ class Shard:
                 if ex is None or kind == "part" or owner_of(tgt, j) == i:
                     got[k] = compute(k, tgt, kind, j, dual)
                     if ex is not None and kind == "seed" and tgt != j:
-                        ex.put(k, got[k])
+                        ex.put(k, got[k], i)
             for k, tgt, kind, j, dual in jobs:
                 if k not in got:
                     r = ex.get(k, owner_of(tgt, j))
@@ -236,8 +281,10 @@ class Shard:
             from . import api
             if getattr(self, "_release_first", False):
                 api.release_device_memory()   # learned below: on this device the two stages do not fit side by side
+            if self.exchange is not None:
+                self.exchange.begin_step()   # once per logical step, whatever happens below
             try:
-                files = self.overlaps(i)
+                files = self.overlaps(i, own_step=True)
             except MemoryError:
                 # the overlap stage ran out of device memory (any other failure -- a bad option, a failed occurrence-threshold
                 # query -- is raised as it is): the consensus contexts still hold the buffers of the last call
@@ -246,7 +293,7 @@ class Shard:
                 if isinstance(self.backend, DeviceBackend) and api.release_device_memory() > 0:
                     overlap.trim()
                     self._release_first = True
-                    files = self.overlaps(i)
+                    files = self.overlaps(i, own_step=True)
                 else:
                     raise
         t0 = time.perf_counter()

@@ -361,7 +361,8 @@ def simulate_reads_mp(genome: np.ndarray, depth: float, profile: str, seed: int,
     import os
     global _MP_GENOME
     _MP_GENOME = genome
-    procs = procs or min(chunks, os.cpu_count() or 1)
+    from . import hostinfo
+    procs = procs or min(chunks, hostinfo.effective_cpus())   # (the CPUs the process can have: a cgroup quota counts)
     jobs = [(depth / chunks, profile, seed * 1000 + c, mu, sigma, min_len, max_len) for c in range(chunks)]
     with mp.get_context("fork").Pool(procs) as pool:
         parts = pool.map(_mp_chunk, jobs, chunksize=1)
