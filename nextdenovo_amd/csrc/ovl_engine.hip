@@ -652,11 +652,12 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	uint64_t budget = 192ULL << 20; // anchors per batch (~100 B of HBM each)
 	if (const char *e = getenv("NDGPU_OVL_BATCH_ANCHORS")) budget = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
 
-	// The batches run side by side (NDGPU_OVL_LANES of them at a time, a host thread and a stream each): every kernel of a batch is a
-	// chain of its own -- K4 lasts as long as its heaviest read pair, the replay passes of the exact sort are host round trips, K5 as
-	// long as its heaviest read -- and alone on the device each of them leaves it mostly idle (68 ms of kernels one after the other
-	// for a config-2 job).  The reads of a batch know nothing of the other batches: a set that fits one batch is cut into `lanes`.
-	int lanes = 3;
+	// The batches can run side by side (NDGPU_OVL_LANES of them at a time, a host thread and a stream each; the reads of a batch know
+	// nothing of the other batches).  Measured in round 5 on the config-2 job (one batch cut into `lanes`): 1 lane 91.5 ms, 2 lanes
+	// 97.5, 3 lanes 96.8, 4 lanes 100.4, 6 lanes 133.9 -- the kernels of a batch are not the idle chains they look like in a trace
+	// (K4 and K5 fill the device while their heaviest read pair finishes), and every further stream costs what more device contexts
+	// cost the consensus stage.  So one lane is the default; the lanes stay for sets whose batches are many and small.
+	int lanes = 1;
 	if (const char *e = getenv("NDGPU_OVL_LANES")) lanes = std::max(1, atoi(e));
 	if (lanes > 1 && total_a >= (uint64_t)lanes * (2ULL << 20)) budget = std::min<uint64_t>(budget, total_a / (uint64_t)lanes + 1);
 	std::vector<std::pair<uint32_t, uint32_t>> ranges;

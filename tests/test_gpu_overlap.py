@@ -168,6 +168,7 @@ def test_live_set_many_batches(olib, profile, preset, monkeypatch, tmp_path):
     for dual in (False, True):
         want, mid = M.step1(olib, M.preset(preset, dual), oset, oset, **case_kwargs((), preset))
         o = dev_opt(preset, dual)
+        monkeypatch.setenv("NDGPU_OVL_LANES", "3" if dual else "1")   # the batches one after the other / three at a time (a stream each)
         with overlap.Index(o, dset) as ix:
             assert ix.mid_occ() == mid
             recs = ix.map(dset, mid)

@@ -38,7 +38,7 @@ CASES = {
     3: dict(size=12_000_000, seed=342, families=[((1000, 6000), (0.02, 0.08), 34)], frac=0.20, n_sample=40),
     4: dict(size=10_000_000, seed=442, families=[((1000, 8000), (0.03, 0.10), 25)], frac=0.12, n_sample=40),
     5: dict(size=16_000_000, seed=542, families=[((280, 320), (0.05, 0.15), 3), ((900, 6500), (0.02, 0.12), 13), ((2000, 9000), (0.01, 0.06), 4)],
-            frac=0.45, n_sample=24),
+            frac=0.45, n_sample=24, min_piles=100),   # (ultra-long reads: a seed file of 16 Mb at 30x holds ~150 seeds)
 }
 
 
@@ -63,7 +63,7 @@ def test_one_rank_of_eight_matches_compiled_reference(config):
     finally:
         sh.close()
     n = int(seeds.size)
-    assert n >= (200 if not small else 3), n
+    assert n >= (case.get("min_piles", 200) if not small else 3), n
     db = api.ReadDB(words, word_off, lens)
     try:
         api.reset_stats()

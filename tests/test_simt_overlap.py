@@ -60,6 +60,12 @@ def test_ovl_bytes_match_reference_golden(sets, case):
     GO.test_ovl_bytes_match_reference_golden(sets, case)
 
 
+def test_batches_side_by_side(interpreted, olib, monkeypatch, tmp_path):
+    """A read set mapped in many small batches, one after the other and three at a time (NDGPU_OVL_LANES: a host thread and a stream per
+    lane): the oracle's bytes either way."""
+    GO.test_live_set_many_batches(olib, "ont", "ava-ont", monkeypatch, tmp_path)
+
+
 _CLI_CASES = [c for c in GO.CASES + CASES_M3 if "-I" in c[5] or "--mode" in c[5]]
 
 
