@@ -933,7 +933,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
 // A round the kernel declines (r->ok stays false) is left to the caller's host path.
 constexpr uint32_t kLenClasses = 16384;  // 64-base length classes of the longest-first launch order (run_main); the last one holds >= 1 Mb
 constexpr uint64_t kLqJobColumns = 192;     // columns of a K12a job (a pile of 3,000 columns is ~15 wavefronts' worth of link building)
-constexpr uint64_t kLqMaxColumns = 12000;  // linked pseudo-seed columns K12 takes per pile (see run_lq)
+constexpr uint64_t kLqMaxColumns = 400000;  // linked pseudo-seed columns K12 takes per pile (see run_lq)
 constexpr uint32_t kLqWarmColumns = 64;    // columns a K12b job starts before its own first one (speculative start, checked by the stitch)
 
 void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
@@ -978,9 +978,9 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         }
         uint64_t link_len = 1, ins_cap = 0;
         for (uint32_t g = 0; g < nr; g++) link_len += (uint64_t)R.pieces[g].sl + 1;
-        // K12b is one wavefront per pile, ~1 us per cell row, and its launch lasts as long as its longest pile: a pile whose
-        // low-quality regions add up to tens of thousands of columns (repeat-rich genomes: config 3 had K12 launches of 250 ms)
-        // is faster on a host core, next to the others -- it is left to the host path before anything is laid out for it
+        // Until round 4 K12b was one wavefront per pile (~1 us per cell row; config 3 had K12 launches of 250 ms) and a pile whose
+        // low-quality regions added up to more than 12,000 columns was left to the host path.  Scored job by job (lq_kernels.hip) the
+        // chain is as long as a job, not as the pile: the bound is what the packed records can address (below), well above this.
         static const uint64_t max_cols = getenv("NDGPU_K12_MAX_COLUMNS") ? strtoull(getenv("NDGPU_K12_MAX_COLUMNS"), nullptr, 10) : kLqMaxColumns;  // (test hook)
         if (link_len > max_cols) {
             usable[r] = 0;
