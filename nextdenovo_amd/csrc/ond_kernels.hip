@@ -528,201 +528,6 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
 }
 
 
-
-// K8a, register-window form (round 5).  The walk of one lane is a chain of dependent steps, and in the form above every step waits for
-// two sequence fetches whose addresses the step before produced (0.9 us per edit step; a launch lasts as long as the longest walk of
-// its wavefronts, a sub-batch's main phase as long as K7 + K8a of its longest alignment).  Here a lane keeps the 128 bases that END at
-// its current position of either sequence in registers (the current base in the top two bits): a step compares the two windows' top
-// 64 bases (XOR + count-leading-zeros), shifts both by what it consumed -- the match run, plus the base the move takes from one of
-// them -- and touches memory only for its trace word.  The windows are loaded again every kWinRefill steps for all lanes of the
-// wavefront at once (the wavefront executes a refill whenever ANY of its lanes needs one, so the refills are made to coincide: with
-// ~12 bases consumed per step a 128-base window outlasts four steps almost always), and on demand when a lane's window runs dry.
-// Same comparisons, same moves, same columns as the form above (kept as ond_traceback_kernel; NDGPU_K8_OLD=1 selects it).
-struct Win128 { unsigned long long a, b, c, d; };   // d = the top 64 bits: the current base in bits [63:62] of d, the one before it below
-constexpr int kWinRefill = 4;
-
-// the 128 bases that end at base `ob` (a base offset into `pool`, inclusive), the last one on top.  Words before the pool's first are
-// not read (index clamped): what they would hold lies beyond the bases the caller counts as valid.
-__device__ __forceinline__ Win128 win_load(const uint32_t *__restrict__ pool, uint64_t ob) {
-    const long long wi = (long long)(ob >> 4);
-    const uint32_t sh = 2u * (15u - (uint32_t)(ob & 15u));   // bits to shift up so that base `ob` lands in the top two bits: 0..30
-    uint32_t v[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const long long idx = wi - 8 + i;
-        v[i] = pool[idx < 0 ? 0 : idx];
-    }
-    uint32_t o[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = (uint32_t)((((((unsigned long long)v[i + 1]) << 32) | v[i]) << sh) >> 32);
-    Win128 w;
-    w.a = ((unsigned long long)o[1] << 32) | o[0];
-    w.b = ((unsigned long long)o[3] << 32) | o[2];
-    w.c = ((unsigned long long)o[5] << 32) | o[4];
-    w.d = ((unsigned long long)o[7] << 32) | o[6];
-    return w;
-}
-// the window moved on by `nb` bases (0..128): what was `nb` below the top is the top now
-__device__ __forceinline__ Win128 win_shift(Win128 w, uint32_t nb) {
-    uint32_t sh = 2u * nb;
-    if (sh >= 128u) {
-        w.d = w.b, w.c = w.a, w.b = 0ull, w.a = 0ull;
-        sh -= 128u;
-        if (sh >= 128u) w.d = 0ull, w.c = 0ull, sh = 0u;   // (nb == 128)
-    }
-    if (sh >= 64u) {
-        w.d = w.c, w.c = w.b, w.b = w.a, w.a = 0ull;
-        sh -= 64u;
-    }
-    if (sh) {
-        const uint32_t r = 64u - sh;
-        w.d = (w.d << sh) | (w.c >> r);
-        w.c = (w.c << sh) | (w.b >> r);
-        w.b = (w.b << sh) | (w.a >> r);
-        w.a = w.a << sh;
-    }
-    return w;
-}
-
-template <bool STREAM>
-__global__ __launch_bounds__(64) void ond_traceback_win_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
-                                                                const uint32_t *__restrict__ pool,
-                                                                const uint32_t *__restrict__ db_pool,
-                                                                const uint64_t *__restrict__ trace,
-                                                                const int32_t *__restrict__ trace_mink,
-                                                                uint32_t *__restrict__ ops,
-                                                                const int32_t *__restrict__ ids, int n_tasks) {
-    const int slot = (int)(blockIdx.x * 64 + threadIdx.x);
-    const bool in_range = slot < n_tasks;
-    const int gid = in_range ? (ids ? ids[slot] : slot) : 0;
-    {  // a wavefront of long walks asks for priority over short ones (see K7); its lanes are neighbours of one pile
-        const int total = (int)__builtin_amdgcn_readfirstlane(tasks[gid].ops_cap);
-        if (total > 160000) __builtin_amdgcn_s_setprio(3);
-        else if (total > 80000) __builtin_amdgcn_s_setprio(2);
-        else if (total > 40000) __builtin_amdgcn_s_setprio(1);
-    }
-    // (every lane of the wavefront stays in the loop below until the last walk is through: the refills are wave-uniform)
-    bool live = in_range && outs[gid].status == ST_FINISHED;
-    const AlnTask T = tasks[gid];
-    const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
-    const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
-    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
-    int x = live ? outs[gid].x_final - 1 : -1;  // 0-based last query base (lib/align.c:492)
-    int k = live ? outs[gid].k_final : 0;
-    int d = live ? outs[gid].d_final : 0;
-    int gap = 0;
-    uint32_t col = T.ops_cap;  // columns [col, ops_cap) are written
-    uint32_t acc = 0;
-    uint32_t *W = ops + T.ops_off;
-    bool aborted = false;
-    const uint64_t *__restrict__ S = trace + T.trace_off;
-    uint32_t pos = (STREAM && live) ? (uint32_t)outs[gid].trace_end : 0u;  // one past the record of step d
-    int idx = live ? outs[gid].fin_idx : 0;                               // cell index of diagonal k in step d
-    uint64_t hdr = (STREAM && pos) ? S[pos - 1] : 0ull;
-    uint64_t c1 = (STREAM && pos >= 2) ? S[pos - 2] : 0ull, c2 = (STREAM && pos >= 3) ? S[pos - 3] : 0ull;
-
-    Win128 Q = {0ull, 0ull, 0ull, 0ull}, Tw = {0ull, 0ull, 0ull, 0ull};
-    int vq = 0, vt = 0;   // bases of the windows that are the sequences' (from the top)
-    auto refill = [&]() {
-        const int y = x - k;
-        vq = x >= 0 ? (x + 1 < 128 ? x + 1 : 128) : 0;
-        vt = y >= 0 ? (y + 1 < 128 ? y + 1 : 128) : 0;
-        if (vq) Q = win_load(qp, q_off + (uint64_t)(uint32_t)x);
-        if (vt) Tw = win_load(tp, t_off + (uint64_t)(uint32_t)y);
-    };
-
-    for (uint32_t it = 0; __ballot(live); it++) {
-        if ((it % (uint32_t)kWinRefill) == 0u && live) refill();
-        if (live) {
-            // match run, back to front (lib/align.c:502-507): the windows' top 64 bases at a time
-            for (;;) {
-                const int yy = x - k;
-                const int avail = (x < yy ? x : yy) + 1;
-                if (avail <= 0) break;
-                int cnt = vq < vt ? vq : vt;
-                if (cnt == 0) {   // a window ran dry in the middle of the sequences: load and go on
-                    refill();
-                    continue;
-                }
-                cnt = cnt < 64 ? cnt : 64;
-                const unsigned long long dd = Q.d ^ Tw.d, dc = Q.c ^ Tw.c;
-                int m = dd ? (__builtin_clzll(dd) >> 1) : dc ? 32 + (__builtin_clzll(dc) >> 1) : 64;
-                m = m < cnt ? m : cnt;
-                if (m) {
-                    int left_to_emit = m;  // match columns are code 0: only the cursor moves
-                    while (left_to_emit > 0) {
-                        const uint32_t room = ((col - 1u) & 15u) + 1u;
-                        const uint32_t take = (uint32_t)left_to_emit < room ? (uint32_t)left_to_emit : room;
-                        col -= take;
-                        left_to_emit -= (int)take;
-                        if ((col & 15u) == 0) {
-                            W[col >> 4] = acc;
-                            acc = 0;
-                        }
-                    }
-                    x -= m;
-                    gap = 0;
-                    Q = win_shift(Q, (uint32_t)m), Tw = win_shift(Tw, (uint32_t)m);
-                    vq -= m, vt -= m;
-                }
-                if (m < cnt) break;   // a difference inside what was compared; otherwise the run goes on (next 64 / after a refill)
-            }
-            if (x < 0 && x - k < 0) live = false;
-        }
-        if (live) {
-            bool left;
-            if (x < k) left = true;  // lib/align.c:512: forced query-consuming move
-            else if (x >= 0) {
-                if (STREAM) {
-                    const bool second = idx >= kStreamBits && pos >= 2;
-                    const uint64_t w = second ? c1 : hdr;
-                    left = (w >> ((second ? idx - kStreamBits : idx) & 63)) & 1ull;
-                } else {
-                    const int ix = (k - trace_mink[T.mink_off + (uint64_t)(uint32_t)d]) >> 1;
-                    left = (trace[T.trace_off + (uint64_t)(uint32_t)d * T.row_words + (uint32_t)(ix >> 6)] >> (ix & 63)) & 1ull;
-                }
-            } else left = false;
-            uint32_t code;
-            int nk, nx;
-            if (left) { nk = k - 1; nx = x - 1; code = 1u; if (x < 0) gap = 260; }
-            else { nk = k + 1; nx = x; code = 2u; if (x - k < 0) gap = 260; }
-            if (gap < 260) {
-                col--;
-                acc |= code << ((col & 15u) * 2u);
-                if ((col & 15u) == 0) {
-                    W[col >> 4] = acc;
-                    acc = 0;
-                }
-            }
-            if (gap++ > 250) {  // lib/align.c:542-545
-                aborted = true;
-                live = false;
-            } else {
-                // the move takes one base from the query (left) or from the target: that window moves on by one
-                if (left) {
-                    if (vq > 0) Q = win_shift(Q, 1u), vq--;
-                } else if (vt > 0) Tw = win_shift(Tw, 1u), vt--;
-                d--;
-                k = nk;
-                x = nx;
-                if (STREAM) {  // step d - 1: its record ends where this one began; idx(d - 1) = idx(d) + j(d - 1) - left
-                    const uint32_t len = 1u + (uint32_t)((hdr >> kStreamBits) & 1ull);
-                    pos = pos > len ? pos - len : 0u;
-                    hdr = pos ? (len == 1u ? c1 : c2) : 0ull;   // = S[pos - 1]
-                    idx += (int)(hdr >> (kStreamBits + 1)) - (left ? 1 : 0);
-                    c1 = pos >= 2 ? S[pos - 2] : 0ull;
-                    c2 = pos >= 3 ? S[pos - 3] : 0ull;
-                }
-            }
-        }
-    }
-    if (in_range && outs[gid].status == ST_FINISHED) {
-        if ((col & 15u) != 0) W[col >> 4] = acc;
-        outs[gid].n_cols = aborted ? 2 : (int32_t)(T.ops_cap - col);
-        outs[gid].status = aborted ? ST_GAP_ABORT : ST_ALIGNED;
-    }
-}
-
 }  // namespace
 
 void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, uint64_t *trace,
@@ -748,21 +553,11 @@ void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *po
                           const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream,
                           const int32_t *order) {
     if (n_tasks <= 0) return;
-    static const bool old_form = getenv("NDGPU_K8_OLD") != nullptr;   // (A/B: the fetch-per-step form)
-    if (old_form) {
-        if (task_ids)
-            hipLaunchKernelGGL(ond_traceback_kernel<false>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                               tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
-        else
-            hipLaunchKernelGGL(ond_traceback_kernel<true>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                               tasks, outs, pool, db_pool, trace, (const int32_t *)nullptr, ops, order, n_tasks);
-        return;
-    }
     if (task_ids)
-        hipLaunchKernelGGL(ond_traceback_win_kernel<false>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(ond_traceback_kernel<false>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                            tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
     else
-        hipLaunchKernelGGL(ond_traceback_win_kernel<true>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(ond_traceback_kernel<true>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                            tasks, outs, pool, db_pool, trace, (const int32_t *)nullptr, ops, order, n_tasks);
 }
 
