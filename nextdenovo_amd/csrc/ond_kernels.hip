@@ -81,12 +81,14 @@ __device__ __forceinline__ Bases64 fetch64(const uint32_t *__restrict__ p, uint3
     struct W4 { uint32_t x, y, z, w; } v;   // (five adjacent words, 4-byte aligned: the compiler merges them into wide loads)
     v.x = p[0], v.y = p[1], v.z = p[2], v.w = p[3];
     const uint32_t v4 = p[4];
+    // ({hi, lo} >> s)[31:0] with s = 0, 2, ..., 30 is ONE v_alignbit_b32 (full rate); written as a 64-bit shift it compiled to
+    // v_lshrrev_b64 -- eight of them per edit step in K7, eight in K8a, on kernels that are bound by instruction issue
     const uint32_t s = sub * 2u;
     Bases64 r;
-    r.w[0] = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> s);
-    r.w[1] = (uint32_t)((((uint64_t)v.z << 32) | v.y) >> s);
-    r.w[2] = (uint32_t)((((uint64_t)v.w << 32) | v.z) >> s);
-    r.w[3] = (uint32_t)((((uint64_t)v4 << 32) | v.w) >> s);
+    r.w[0] = __builtin_amdgcn_alignbit(v.y, v.x, s);
+    r.w[1] = __builtin_amdgcn_alignbit(v.z, v.y, s);
+    r.w[2] = __builtin_amdgcn_alignbit(v.w, v.z, s);
+    r.w[3] = __builtin_amdgcn_alignbit(v4, v.w, s);
     return r;
 }
 

@@ -360,6 +360,8 @@ struct Engine {
 	DevBuf<uint64_t> ukey, ustart, pos;
 	DevBuf<uint32_t> ucnt, bucket;
 	uint32_t bucket_shift = 0;
+	DevBuf<HashSlot> htab;   // the lookup table of build_index (absent when the device is short of memory for it)
+	uint64_t hmask = 0;
 	ndgpu_ovl_stats st{};
 	// debug view of the last map batch
 	std::vector<uint64_t> dbg_aoff;
@@ -371,7 +373,7 @@ struct Engine {
 	std::vector<hipStream_t> lane_streams;   // the streams of map()'s concurrent batches (created on first use)
 	void *temp(size_t bytes) { if (tmp.n < bytes) tmp.alloc(bytes + bytes / 4); return tmp.p; }
 
-	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p, bucket.p, bucket_shift}; }
+	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p, bucket.p, bucket_shift, htab.p, hmask}; }
 
 	// tiles of `tile` symbols over reads whose symbol counts are n_sym[]; first[r] = first tile of read r
 	// (of the next non-empty read for an empty one), first[n] = number of tiles
@@ -527,6 +529,23 @@ struct Engine {
 		bucket.alloc(((size_t)1 << kBucketBits) + 2);
 		launch_build_buckets(ukey.p, n_keys, bucket_shift, bucket.p, stream);
 		HIP_OK(hipGetLastError());
+		// the lookup table: at most half full, 16 bytes a slot; skipped (the bucket + binary search stay) when that is more than a
+		// sixteenth of the device (NDGPU_OVL_NO_HASH: the switch of the A/B)
+		htab.release();
+		hmask = 0;
+		if (n_keys && !getenv("NDGPU_OVL_NO_HASH")) {
+			uint64_t slots = 1024;
+			while (slots < 2 * n_keys) slots <<= 1;
+			size_t free_b = 0, total_b = 0;
+			const bool fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess || slots * sizeof(HashSlot) <= total_b / 16;
+			if (fits) {   // (an allocation that fails here is reported like any other of the build: the caller releases memory and retries)
+				htab.alloc(slots);
+				htab.zero(stream);
+				hmask = slots - 1;
+				launch_build_hash(ukey.p, ustart.p, n_keys, htab.p, hmask, stream);
+				HIP_OK(hipGetLastError());
+			}
+		}
 		st.index_sort_ms += tm.stop();
 	}
 

@@ -131,6 +131,10 @@ static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CS
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __builtin_amdgcn_wave_barrier() { (void)simt::wave_sync(0); }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+// v_alignbit_b32: the low 32 bits of {hi, lo} >> (shift & 31)
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned shift) {
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (shift & 31u));
+}
 
 static inline unsigned long long __ballot(int pred) {
     const simt::Snap s = simt::wave_sync(pred ? 1u : 0u);
@@ -190,6 +194,11 @@ template <class T, class U> static inline T atomicAdd(T *p, U v) { return __atom
 template <class T, class U> static inline T atomicOr(T *p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_SEQ_CST); }
 template <class T, class U> static inline T atomicAnd(T *p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_SEQ_CST); }
 template <class T, class U> static inline T atomicExch(T *p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_SEQ_CST); }
+template <class T, class U, class V> static inline T atomicCAS(T *p, U expected, V desired) {
+    T e = (T)expected;
+    __atomic_compare_exchange_n(p, &e, (T)desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return e;   // the value found (== expected when the exchange happened)
+}
 template <class T, class U> static inline T atomicMax(T *p, U v) {
     T cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
     while (cur < (T)v && !__atomic_compare_exchange_n(p, &cur, (T)v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
