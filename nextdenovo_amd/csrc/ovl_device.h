@@ -53,7 +53,8 @@ struct OvlParams {
 
 // minimizer index of the target reads, resident in HBM
 struct HashSlot { unsigned long long key1; uint32_t start, cnt; };
-__host__ __device__ inline uint64_t hash_slot_of(uint64_t key, uint64_t mask) { return (key * 0x9E3779B97F4A7C15ull >> 20) & mask; }
+// slot of a key in a table of `size` slots (any size: the mixed key's top 32 bits scaled into [0, size); size < 2^32)
+__host__ __device__ inline uint64_t hash_slot_of(uint64_t key, uint64_t size) { return ((key * 0x9E3779B97F4A7C15ull >> 32) * size) >> 32; }
 
 struct IndexDev {
 	uint64_t n_keys;
@@ -66,10 +67,10 @@ struct IndexDev {
 	const uint32_t *bucket;  // 2^kBucketBits + 1 entries: first key index of every top-bits bucket (narrows the binary search)
 	uint32_t bucket_shift;   // key >> bucket_shift = bucket
 	// open-addressing table over the distinct keys (nullptr: none -- the lookup is the bucket + binary search): one 16-byte slot
-	// {key + 1 (0 = empty), first occurrence, occurrences}, linear probing, at most half full -- ONE cache line per lookup where the
+	// {key + 1 (0 = empty), first occurrence, occurrences}, linear probing, two thirds full -- ONE cache line per lookup where the
 	// bucket table, the binary search's probes and the start offsets were five or six (minimap2/index.c:81-98 probes a hash table too)
 	const HashSlot *htab;
-	uint64_t hmask;          // slots - 1 (a power of two)
+	uint64_t hsize;          // slots (1.5 x the keys)
 };
 
 constexpr int kBucketBits = 22;
@@ -116,7 +117,7 @@ void launch_pack_2bit(const uint8_t *ascii, const uint64_t *a_off, const uint32_
 void launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint32_t n, uint64_t *dst, hipStream_t s);
 void launch_shift_keys(const uint64_t *x, uint64_t *key, uint64_t n, hipStream_t s);
 void launch_build_buckets(const uint64_t *ukey, uint64_t n_keys, uint32_t shift, uint32_t *bucket, hipStream_t s);
-void launch_build_hash(const uint64_t *ukey, const uint64_t *ustart, uint64_t n_keys, HashSlot *tab, uint64_t mask, hipStream_t s);  // tab zeroed by the caller
+void launch_build_hash(const uint64_t *ukey, const uint64_t *ustart, uint64_t n_keys, HashSlot *tab, uint64_t size, hipStream_t s);  // tab zeroed by the caller
 
 int sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout,
                    size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s);

@@ -360,8 +360,9 @@ struct Engine {
 	DevBuf<uint64_t> ukey, ustart, pos;
 	DevBuf<uint32_t> ucnt, bucket;
 	uint32_t bucket_shift = 0;
-	DevBuf<HashSlot> htab;   // the lookup table of build_index (absent when the device is short of memory for it)
-	uint64_t hmask = 0;
+	DevBuf<HashSlot> htab;   // the lookup table (build_hash: from the index's second map call on)
+	uint64_t hsize = 0;
+	uint32_t maps_served = 0;
 	ndgpu_ovl_stats st{};
 	// debug view of the last map batch
 	std::vector<uint64_t> dbg_aoff;
@@ -373,7 +374,7 @@ struct Engine {
 	std::vector<hipStream_t> lane_streams;   // the streams of map()'s concurrent batches (created on first use)
 	void *temp(size_t bytes) { if (tmp.n < bytes) tmp.alloc(bytes + bytes / 4); return tmp.p; }
 
-	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p, bucket.p, bucket_shift, htab.p, hmask}; }
+	IndexDev index_dev() const { return IndexDev{n_keys, ukey.p, ustart.p, pos.p, T.len.p, T.id.p, T.namekey.p, bucket.p, bucket_shift, htab.p, hsize}; }
 
 	// tiles of `tile` symbols over reads whose symbol counts are n_sym[]; first[r] = first tile of read r
 	// (of the next non-empty read for an empty one), first[n] = number of tiles
@@ -529,23 +530,30 @@ struct Engine {
 		bucket.alloc(((size_t)1 << kBucketBits) + 2);
 		launch_build_buckets(ukey.p, n_keys, bucket_shift, bucket.p, stream);
 		HIP_OK(hipGetLastError());
-		// the lookup table: at most half full, 16 bytes a slot; skipped (the bucket + binary search stay) when that is more than a
-		// sixteenth of the device (NDGPU_OVL_NO_HASH: the switch of the A/B)
 		htab.release();
-		hmask = 0;
-		if (n_keys && !getenv("NDGPU_OVL_NO_HASH")) {
-			uint64_t slots = 1024;
-			while (slots < 2 * n_keys) slots <<= 1;
-			size_t free_b = 0, total_b = 0;
-			const bool fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess || slots * sizeof(HashSlot) <= total_b / 16;
-			if (fits) {   // (an allocation that fails here is reported like any other of the build: the caller releases memory and retries)
-				htab.alloc(slots);
-				htab.zero(stream);
-				hmask = slots - 1;
-				launch_build_hash(ukey.p, ustart.p, n_keys, htab.p, hmask, stream);
-				HIP_OK(hipGetLastError());
-			}
-		}
+		hsize = 0, maps_served = 0;
+		st.index_sort_ms += tm.stop();
+	}
+
+	// The lookup table over the distinct keys: two thirds full, 16 bytes a slot.  Measured on config 2 (r5_10): the seed pass of a map
+	// call 13.5 -> 9.6 ms, the table's build 6.7 ms (a power-of-two table at most half full; smaller since) -- so an index builds
+	// it when its SECOND map call arrives (one index serves the 1-8 raw_align jobs of its seed file, nextDenovo:426-467; the index of
+	// a one-job layout never pays for it).  NDGPU_OVL_HASH=1: with the index; NDGPU_OVL_NO_HASH: never.  Skipped when it would take
+	// more than a sixteenth of the device; an allocation that fails is reported like any other.
+	void build_hash()
+	{
+		if (htab.p || !n_keys || getenv("NDGPU_OVL_NO_HASH")) return;
+		const uint64_t slots = n_keys + n_keys / 2 + 64;
+		if (slots >= (1ull << 32)) return;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && slots * sizeof(HashSlot) > total_b / 16) return;
+		EvTimer tm(stream);
+		tm.start();
+		htab.alloc(slots);
+		htab.zero(stream);
+		hsize = slots;
+		launch_build_hash(ukey.p, ustart.p, n_keys, htab.p, hsize, stream);
+		HIP_OK(hipGetLastError());
 		st.index_sort_ms += tm.stop();
 	}
 
@@ -607,6 +615,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	P = Pm;
 	struct Restore { Engine *e; OvlParams p; ~Restore() { e->P = p; } } restore{this, Pi};
 	++st.map_calls;
+	if (++maps_served >= (getenv("NDGPU_OVL_HASH") ? 1u : 2u)) build_hash();
 	out.clear();
 	if (out10) out10->clear();
 	if ((P.step2 != 0) != (out10 != nullptr)) return -1; // the two record types have an entry point each

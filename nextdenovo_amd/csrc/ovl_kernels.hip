@@ -562,32 +562,32 @@ void launch_build_buckets(const uint64_t *ukey, uint64_t n_keys, uint32_t shift,
 
 // the distinct keys into the open-addressing table (index build): a slot is claimed by compare-and-swap on its key word
 __global__ void build_hash_kernel(const uint64_t *__restrict__ ukey, const uint64_t *__restrict__ ustart, uint64_t n_keys, HashSlot *__restrict__ tab,
-                                  uint64_t mask)
+                                  uint64_t size)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_keys) return;
 	const unsigned long long k1 = ukey[i] + 1ull;
-	uint64_t s = hash_slot_of(ukey[i], mask);
+	uint64_t s = hash_slot_of(ukey[i], size);
 	for (;;) {
 		const unsigned long long found = atomicCAS(&tab[s].key1, 0ull, k1);
 		if (found == 0ull) break;
-		s = (s + 1) & mask;
+		s = s + 1 == size ? 0 : s + 1;
 	}
 	tab[s].start = (uint32_t)ustart[i];
 	tab[s].cnt = (uint32_t)(ustart[i + 1] - ustart[i]);
 }
 
-void launch_build_hash(const uint64_t *ukey, const uint64_t *ustart, uint64_t n_keys, HashSlot *tab, uint64_t mask, hipStream_t s)
+void launch_build_hash(const uint64_t *ukey, const uint64_t *ustart, uint64_t n_keys, HashSlot *tab, uint64_t size, hipStream_t s)
 {
 	if (!n_keys) return;
-	ND_LAUNCH(build_hash_kernel, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, s, ukey, ustart, n_keys, tab, mask);
+	ND_LAUNCH(build_hash_kernel, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, s, ukey, ustart, n_keys, tab, size);
 }
 
 __device__ __forceinline__ bool index_lookup(const IndexDev &ix, uint64_t minier, uint32_t &start, uint32_t &cnt)
 {
 	if (ix.htab) {
 		const unsigned long long want = minier + 1ull;
-		for (uint64_t s = hash_slot_of(minier, ix.hmask);; s = (s + 1) & ix.hmask) {
+		for (uint64_t s = hash_slot_of(minier, ix.hsize);; s = s + 1 == ix.hsize ? 0 : s + 1) {
 			const HashSlot e = ix.htab[s];
 			if (e.key1 == want) { start = e.start, cnt = e.cnt; return true; }
 			if (e.key1 == 0ull) { start = 0, cnt = 0; return false; }

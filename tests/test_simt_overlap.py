@@ -62,7 +62,9 @@ def test_ovl_bytes_match_reference_golden(sets, case):
 
 def test_batches_side_by_side(interpreted, olib, monkeypatch, tmp_path):
     """A read set mapped in many small batches, one after the other and three at a time (NDGPU_OVL_LANES: a host thread and a stream per
-    lane): the oracle's bytes either way."""
+    lane): the oracle's bytes either way.  The index's minimizer lookup goes through its open-addressing table from the first map call
+    on here (NDGPU_OVL_HASH; by default an index builds the table when its second map call arrives)."""
+    monkeypatch.setenv("NDGPU_OVL_HASH", "1")
     GO.test_live_set_many_batches(olib, "ont", "ava-ont", monkeypatch, tmp_path)
 
 
