@@ -272,11 +272,11 @@ bool pack_append(std::vector<uint32_t> &pool, const char *s, size_t n) {
 // hipMemcpyAsync / hipMemsetAsync each of them was a blit kernel of the runtime's own on the phase's stream -- ~190 copies and ~170
 // fills per config-2 step, ~1 ms each in the kernel trace (a few waves waiting for PCIe), one after the other in front of the phase's
 // first kernel, 11 % of the GPU time of a step.  The tables are staged in the context's pinned arena anyway; pinned host memory is
-// staged one behind the other, so ONE copy takes the stretch to a device-side staging block and ONE kernel takes the tables from there
-// to where they belong (and does the fills): blockIdx.y = the table, the blocks of a row stride over its 16-byte words.
+// mapped into the device's address space, so ONE kernel copies all of a phase's tables from the arena to where they belong (and does
+// the fills): blockIdx.y = the table, the blocks of a row stride over its 16-byte words.
 struct CopyDesc {
     void *dst;
-    const void *src;               // queued: in the pinned arena; at the launch: in the device's staging block; nullptr: fill with zeros
+    const void *src;               // in the pinned arena (device-visible); nullptr: fill with zeros
     unsigned long long bytes;
 };
 constexpr int kCopyPack = 12;
@@ -370,7 +370,6 @@ struct DeviceAligner::State {
     // using (GPU memory access faults on host heap addresses).  Everything a kernel or a copy engine touches is now
     // either device memory or these arenas.
     PinBuf<char> up, down;
-    DevBuf<char> d_stage;   // device-side image of the upload arena (flush(): one copy of the staged stretch, then a scatter kernel)
     size_t up_used = 0, down_used = 0;
     struct Pending {
         void *dst;
@@ -397,26 +396,9 @@ struct DeviceAligner::State {
                 else HIP_CHECK(hipMemsetAsync(D.dst, 0, D.bytes, st));
             }
         } else {
-            // the staged tables lie one behind the other in the pinned arena: ONE copy brings the whole stretch to the device-side
-            // staging block, one kernel takes the tables from there to where they belong and does the fills.  (A kernel that reads
-            // the pinned arena itself -- no staging copy -- was tried first: 2-19 s per step instead of 0.75, the device's
-            // fine-grained reads over the link starve everything else.)
-            const char *lo = nullptr, *hi = nullptr;
-            for (int i = 0; i < n_pack; i++)
-                if (pack.d[i].src) {
-                    const char *a = (const char *)pack.d[i].src, *b = a + pack.d[i].bytes;
-                    lo = !lo || a < lo ? a : lo;
-                    hi = !hi || b > hi ? b : hi;
-                }
-            if (lo) {
-                const size_t off = (size_t)(lo - up.p);
-                HIP_CHECK(hipMemcpyAsync(d_stage.p + off, lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
-                for (int i = 0; i < n_pack; i++)
-                    if (pack.d[i].src) pack.d[i].src = d_stage.p + ((const char *)pack.d[i].src - up.p);
-            }
-            // (fills keep src == nullptr)
+            // enough blocks to keep the link busy for the largest table, few enough that a 16-byte table is not a thousand idle wavefronts
             const unsigned long long per_row = pack_bytes / (unsigned long long)n_pack;
-            const unsigned bx = (unsigned)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, per_row / (256 * 16 * 2)));
+            const unsigned bx = (unsigned)std::min<unsigned long long>(512, std::max<unsigned long long>(1, per_row / (256 * 16 * 4)));
             hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, (unsigned)n_pack), dim3(256), 0, st, pack);
             HIP_CHECK(hipGetLastError());
         }
@@ -447,10 +429,6 @@ struct DeviceAligner::State {
         if (up_used + need > up.cap) {
             sync_drain(st);
             up.reserve(std::max(need, up.cap * 2));
-        }
-        if (d_stage.cap < up.cap) {   // (only when the arena has grown: nothing of this context is in flight then, or ever was)
-            if (d_stage.p) sync_drain(st);
-            d_stage.reserve(up.cap);
         }
         memcpy(up.p + up_used, src, bytes);
         queue(dst, up.p + up_used, bytes, st);   // (goes out with the phase's other tables: flush())
@@ -527,7 +505,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
         }
     }
 #define NDGPU_NAME(x) s_->x.name = #x;
-    NDGPU_NAME(h_ops) NDGPU_NAME(h_outs) NDGPU_NAME(up) NDGPU_NAME(down) NDGPU_NAME(d_stage)
+    NDGPU_NAME(h_ops) NDGPU_NAME(h_outs) NDGPU_NAME(up) NDGPU_NAME(down)
     NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec) NDGPU_NAME(d_lq_jobs) NDGPU_NAME(d_lq_hdr) NDGPU_NAME(d_lq_lnk)
     NDGPU_NAME(d_lq_out) NDGPU_NAME(d_lq_tmp) NDGPU_NAME(d_lq_bnd)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v) NDGPU_NAME(d_wtrace) NDGPU_NAME(d_wmink)
@@ -646,7 +624,7 @@ void DeviceAligner::release_memory() {
     NDGPU_REL(d_ent_ppp) NDGPU_REL(d_ent_cnt) NDGPU_REL(d_err) NDGPU_REL(d_ent_score) NDGPU_REL(d_cell_best) NDGPU_REL(d_spec)
     NDGPU_REL(d_fin) NDGPU_REL(d_sums) NDGPU_REL(d_items) NDGPU_REL(d_bt_exit) NDGPU_REL(d_bt_steps) NDGPU_REL(d_bt_entry)
     NDGPU_REL(d_bt_off) NDGPU_REL(d_path) NDGPU_REL(d_blocks) NDGPU_REL(d_regions) NDGPU_REL(d_strpool) NDGPU_REL(d_cursor)
-    NDGPU_REL(h_ops) NDGPU_REL(h_outs) NDGPU_REL(up) NDGPU_REL(down) NDGPU_REL(d_stage)
+    NDGPU_REL(h_ops) NDGPU_REL(h_outs) NDGPU_REL(up) NDGPU_REL(down)
 #undef NDGPU_REL
 }
 
@@ -690,7 +668,7 @@ void DeviceAligner::level_buffers(int drivers) {
             NDGPU_LVL(d_ent_ppp) NDGPU_LVL(d_ent_cnt) NDGPU_LVL(d_err) NDGPU_LVL(d_cell_best) NDGPU_LVL(d_spec)
             NDGPU_LVL(d_fin) NDGPU_LVL(d_sums) NDGPU_LVL(d_items) NDGPU_LVL(d_bt_exit) NDGPU_LVL(d_bt_steps) NDGPU_LVL(d_bt_entry)
             NDGPU_LVL(d_bt_off) NDGPU_LVL(d_path) NDGPU_LVL(d_blocks) NDGPU_LVL(d_regions) NDGPU_LVL(d_strpool) NDGPU_LVL(d_cursor)
-            NDGPU_LVL(h_ops) NDGPU_LVL(h_outs) NDGPU_LVL(up) NDGPU_LVL(down) NDGPU_LVL(d_stage)
+            NDGPU_LVL(h_ops) NDGPU_LVL(h_outs) NDGPU_LVL(up) NDGPU_LVL(down)
 #undef NDGPU_LVL
         } catch (const DeviceOom &) {
         }
