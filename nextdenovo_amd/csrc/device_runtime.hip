@@ -267,46 +267,6 @@ bool pack_append(std::vector<uint32_t> &pool, const char *s, size_t n) {
 }  // namespace
 
 
-// ---- uploads of a phase in ONE launch --------------------------------------------------------------------------------------
-// A phase hands the device half a dozen small tables (tasks, reads, piles, ids, ...) and zeroes a few accumulators.  As
-// hipMemcpyAsync / hipMemsetAsync each of them was a blit kernel of the runtime's own on the phase's stream -- ~190 copies and ~170
-// fills per config-2 step, ~1 ms each in the kernel trace (a few waves waiting for PCIe), one after the other in front of the phase's
-// first kernel, 11 % of the GPU time of a step.  The tables are staged in the context's pinned arena anyway; pinned host memory is
-// mapped into the device's address space, so ONE kernel copies all of a phase's tables from the arena to where they belong (and does
-// the fills): blockIdx.y = the table, the blocks of a row stride over its 16-byte words.
-struct CopyDesc {
-    void *dst;
-    const void *src;               // in the pinned arena (device-visible); nullptr: fill with zeros
-    unsigned long long bytes;
-};
-constexpr int kCopyPack = 12;
-struct CopyPack {
-    CopyDesc d[kCopyPack];
-};
-__global__ __launch_bounds__(256) void multi_copy_kernel(CopyPack P) {
-    const CopyDesc D = P.d[blockIdx.y];
-    const unsigned long long n = D.bytes;
-    char *__restrict__ dst = (char *)D.dst;
-    const char *__restrict__ src = (const char *)D.src;
-    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (unsigned long long)gridDim.x * blockDim.x;
-    const bool wide = (((uintptr_t)dst | (uintptr_t)src) & 15u) == 0;
-    if (wide) {
-        const unsigned long long nv = n >> 4;
-        uint4 *__restrict__ d4 = (uint4 *)dst;
-        const uint4 *__restrict__ s4 = (const uint4 *)src;
-        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-        for (unsigned long long i = tid; i < nv; i += nth) d4[i] = src ? s4[i] : zero;
-        for (unsigned long long i = (nv << 4) + tid; i < n; i += nth) dst[i] = src ? src[i] : (char)0;
-    } else if (((((uintptr_t)dst | (uintptr_t)src) & 3u) == 0)) {
-        const unsigned long long nv = n >> 2;
-        uint32_t *__restrict__ d1 = (uint32_t *)dst;
-        const uint32_t *__restrict__ s1 = (const uint32_t *)src;
-        for (unsigned long long i = tid; i < nv; i += nth) d1[i] = src ? s1[i] : 0u;
-        for (unsigned long long i = (nv << 2) + tid; i < n; i += nth) dst[i] = src ? src[i] : (char)0;
-    } else
-        for (unsigned long long i = tid; i < n; i += nth) dst[i] = src ? src[i] : (char)0;
-}
-
 struct DeviceAligner::State {
     int device = 0;
     const uint32_t *db_pool = nullptr;  // resident read DB of the batch in progress (owned by its ndgpu_db handle)
@@ -381,44 +341,11 @@ struct DeviceAligner::State {
         pending.clear();
         up_used = down_used = 0;
     }
-    // uploads / fills queued for the phase's one copy launch (flush(): before the first kernel that reads them, and before the stream
-    // is waited for)
-    CopyPack pack;
-    int n_pack = 0;
-    unsigned long long pack_bytes = 0;
-    void flush(hipStream_t st) {
-        if (!n_pack) return;
-        static const bool plain = getenv("NDGPU_PLAIN_COPIES") != nullptr;   // (A/B: the runtime's own copies and fills, one call each)
-        if (plain) {
-            for (int i = 0; i < n_pack; i++) {
-                const CopyDesc &D = pack.d[i];
-                if (D.src) HIP_CHECK(hipMemcpyAsync(D.dst, D.src, D.bytes, hipMemcpyHostToDevice, st));
-                else HIP_CHECK(hipMemsetAsync(D.dst, 0, D.bytes, st));
-            }
-        } else {
-            // enough blocks to keep the link busy for the largest table, few enough that a 16-byte table is not a thousand idle wavefronts
-            const unsigned long long per_row = pack_bytes / (unsigned long long)n_pack;
-            const unsigned bx = (unsigned)std::min<unsigned long long>(512, std::max<unsigned long long>(1, per_row / (256 * 16 * 4)));
-            hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, (unsigned)n_pack), dim3(256), 0, st, pack);
-            HIP_CHECK(hipGetLastError());
-        }
-        n_pack = 0;
-        pack_bytes = 0;
-    }
-    void queue(void *dst, const void *src, size_t bytes, hipStream_t st) {
-        if (!bytes) return;
-        if (n_pack == kCopyPack) flush(st);
-        pack.d[n_pack++] = CopyDesc{dst, src, (unsigned long long)bytes};
-        pack_bytes += bytes;
-    }
-    void fill0(void *dst, size_t bytes, hipStream_t st) { queue(dst, nullptr, bytes, st); }
     void sync_drain(hipStream_t st) {
-        flush(st);
         HIP_CHECK(hipStreamSynchronize(st));
         drain();
     }
     void reserve_down(size_t bytes, hipStream_t st) {  // room for `bytes` of downloads without moving the arena (views stay valid)
-        flush(st);
         if (down_used + bytes + 4096 <= down.cap) return;
         sync_drain(st);
         down.reserve(bytes + 4096);
@@ -431,14 +358,13 @@ struct DeviceAligner::State {
             up.reserve(std::max(need, up.cap * 2));
         }
         memcpy(up.p + up_used, src, bytes);
-        queue(dst, up.p + up_used, bytes, st);   // (goes out with the phase's other tables: flush())
+        HIP_CHECK(hipMemcpyAsync(dst, up.p + up_used, bytes, hipMemcpyHostToDevice, st));
         up_used += need;
     }
     // device -> host: the bytes land in the arena; dst_host (if given) receives them at the next drain; the returned
     // pointer is valid from the next stream synchronisation until the next drain / reserve
     void *d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st) {
         const size_t need = (bytes + 255) & ~(size_t)255;
-        flush(st);   // (what is fetched may depend on what was queued)
         if (down_used + need > down.cap) {
             sync_drain(st);
             down.reserve(std::max(need, down.cap * 2));
@@ -613,7 +539,6 @@ void DeviceAligner::release_memory() {
     (void)hipGetLastError();
     S.pending.clear();
     S.up_used = S.down_used = 0;
-    S.n_pack = 0, S.pack_bytes = 0;
 #define NDGPU_REL(x) S.x.release();
     NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec) NDGPU_REL(d_lq_jobs) NDGPU_REL(d_lq_hdr) NDGPU_REL(d_lq_lnk)
     NDGPU_REL(d_lq_out) NDGPU_REL(d_lq_tmp) NDGPU_REL(d_lq_bnd)
@@ -869,7 +794,6 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     const uint64_t tc1 = wall_ns();
     S.h2d(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), st);
     S.h2d(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), st);
-    S.flush(st);
     HIP_CHECK(hipEventRecord(S.ev0, st));
     NDGPU_DBG(st, "chunk: forward %zu tasks", n);
     launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, (int)n, st);
@@ -987,7 +911,6 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
             S.h2d(S.d_tasks.p + ids[at + i], &S.tasks[ids[at + i]], sizeof(AlnTask), st);
         }
         S.h2d(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), st);
-        S.flush(st);
         launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
         launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
         for (size_t i = 0; i < take; i++) S.d2h(&S.h_outs.p[ids[at + i]], S.d_outs.p + ids[at + i], sizeof(AlnOut), st);
@@ -1218,7 +1141,6 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     S.h2d(S.d_lq_piles.p, piles.data(), n * sizeof(LqPileDev), st);
     S.h2d(S.d_lq_pieces.p, pieces.data(), pieces.size() * sizeof(LqPieceDev), st);
     if (!jobs.empty()) S.h2d(S.d_lq_jobs.p, jobs.data(), jobs.size() * sizeof(LqJobDev), st);
-    S.flush(st);   // (the round's five tables in one launch)
     // (HIP-event brackets per kernel: K7, K8a per chunk -- read after the round's one synchronisation)
     while (S.lq_evs.size() < 2 * chunk_end.size() + 1) {
         hipEvent_t e;
@@ -1466,9 +1388,8 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.h2d(S.d_piles.p, piles.data(), np * sizeof(PileDev), st);
     S.h2d(S.d_read_pile.p, read_pile.data(), nr * sizeof(uint32_t), st);
     uint32_t *const d_cov = S.d_cov.p, *const d_inscnt = d_cov + (col_slots + 1), *const d_insmax = d_inscnt + (col_slots + 1);
-    S.fill0(d_cov, 3 * (col_slots + 1) * sizeof(uint32_t), st);  // (the three accumulators; with the tables above in the phase's one copy launch)
-    S.fill0(S.d_err.p, 4 * sizeof(uint32_t), st);
-    S.flush(st);
+    HIP_CHECK(hipMemsetAsync(d_cov, 0, 3 * (col_slots + 1) * sizeof(uint32_t), st));  // (one fill for the three)
+    HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
 
     {
         size_t a = 0;
@@ -1494,7 +1415,6 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                     for (size_t i = 0; i < m; i++) ord[cls[cls_of(i)]++] = (int32_t)i;
                     S.d_ids.reserve(m);
                     S.h2d(S.d_ids.p, ord.data(), m * sizeof(int32_t), st);
-                    S.flush(st);
                     order = S.d_ids.p;
                 }
                 HIP_CHECK(hipEventRecord(S.evs[0], st));
@@ -1651,8 +1571,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     for (int attempt = 0; attempt < 2; attempt++) {
         S.reserve_down(np * sizeof(PileDev) + paths * sizeof(PathItem) + 1024, st);
         S.h2d(S.d_piles.p, piles.data(), np * sizeof(PileDev), st);
-        if (attempt) S.fill0(S.d_err.p, 4 * sizeof(uint32_t), st);
-        S.flush(st);   // (with the column blocks and the work lists queued above)
+        if (attempt) HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
         HIP_CHECK(hipEventRecord(S.evs[2], st));
         NDGPU_DBG(st, "main: count_links %zu blocks, cells %llu ents %llu segs %u", blocks.size(), (unsigned long long)cells,
                   (unsigned long long)ents, n_segs);
@@ -1820,8 +1739,7 @@ void DeviceAligner::run_extract(ExtractPile **ep, size_t n) {
         S.d_strpool.reserve(cap);
         cap = S.d_strpool.cap;
         S.h2d(S.d_regions.p, regs.data(), regs.size() * sizeof(RegionDev), st);
-        S.fill0(S.d_cursor.p, sizeof(unsigned long long), st);
-        S.flush(st);
+        HIP_CHECK(hipMemsetAsync(S.d_cursor.p, 0, sizeof(unsigned long long), st));
         HIP_CHECK(hipEventRecord(S.evs[5], st));
         NDGPU_DBG(st, "extract: %zu regions", regs.size());
         launch_extract(S.d_piles.p, S.d_reads.p, S.d_acc.p, S.d_tags.p, S.d_colidx.p, S.d_regions.p, S.d_strpool.p,
