@@ -338,6 +338,9 @@ int ndgpu_correct_piles_stream(ndgpu_db *h, int n_piles, const uint32_t *recs, c
         return recs[pile_off[a] * 8 + 3] > recs[pile_off[b] * 8 + 3];
     });
     int drivers = 8;
+    // (a context is a host thread that launches and waits: with fewer CPUs than contexts -- a rank of 8 on a node whose container has 16
+    // -- the contexts only take the CPUs from one another's host phases)
+    drivers = std::min(drivers, std::max(2, host_threads));
     if (const char *e = getenv("NDGPU_CONTEXTS")) drivers = std::max(1, std::min(atoi(e), (int)DeviceAligner::kMaxContexts));
     // sub-batches: at most `sub` piles and at most `tag_budget` estimated alignment columns each, so that the
     // device buffers of a context (sized by the largest sub-batch it has seen) stay bounded whatever the seed lengths

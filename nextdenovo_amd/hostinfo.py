@@ -7,25 +7,25 @@ import math
 import os
 
 
-def cgroup_cpu_quota():
+def cgroup_cpu_quota(root: str = "/sys/fs/cgroup"):
     """CPUs the cgroup grants (float), or None when there is no quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cfs_period_us)."""
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open(os.path.join(root, "cpu.max")) as f:
             a, b = f.read().split()[:2]
         return None if a == "max" else float(a) / float(b)
     except (OSError, ValueError):
         pass
     try:
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+        with open(os.path.join(root, "cpu", "cpu.cfs_quota_us")) as f:
             q = float(f.read().strip())
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+        with open(os.path.join(root, "cpu", "cpu.cfs_period_us")) as f:
             p = float(f.read().strip())
         return q / p if q > 0 and p > 0 else None
     except (OSError, ValueError):
         return None
 
 
-def effective_cpus() -> int:
+def effective_cpus(root: str = "/sys/fs/cgroup") -> int:
     if os.environ.get("NDGPU_HOST_CPUS"):
         return max(1, int(os.environ["NDGPU_HOST_CPUS"]))
     n = os.cpu_count() or 1
@@ -33,7 +33,7 @@ def effective_cpus() -> int:
         n = min(n, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         pass
-    q = cgroup_cpu_quota()
+    q = cgroup_cpu_quota(root)
     if q:
         n = min(n, max(1, int(math.ceil(q - 1e-9))))
     return max(1, n)

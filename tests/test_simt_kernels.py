@@ -285,3 +285,40 @@ def test_out_of_device_memory_halves_the_sub_batch(simt_lib):
     # nothing fits: every seed is an out-of-memory seed, nothing aborts
     got, err = _oom_child({"NDGPU_OOM_ABOVE": str(64 << 10)})
     assert all(d[0] == 3 for d in got["a"]) and "out-of-memory seed" in err
+
+
+def test_records_are_handed_over_as_their_sub_batches_finish(simt_api, tmp_path, monkeypatch):
+    """ndgpu_correct_piles_stream: the completion callback reports every pile exactly once (a sub-batch at a time), and the cns.fasta /
+    .idx written from it hold the records of the plain call, line for line as lib/nextcorrect.py:236-260 prints them."""
+    from nextdenovo_amd import synth
+    monkeypatch.setenv("NDGPU_SUBBATCH", "2")   # several sub-batches, two contexts: callbacks from more than one thread
+    monkeypatch.setenv("NDGPU_CONTEXTS", "2")
+    rs, piles = _synth_set(20000, 7.9, 0.3, 31)
+    piles = piles[:7]
+    words, off, lens = synth.pack_db(rs)
+    db = simt_api.ReadDB(words, off, lens)
+    recs, poff = synth.flatten_piles(piles)
+    names = [int(p["seed"]) for p in piles]
+    plain = db.correct_piles(recs, poff, read_type=1, max_lq_length=10000, host_threads=4)
+    fa = tmp_path / "cns.fasta"
+    with open(fa, "wb") as OUT, open(str(fa) + ".idx", "wb") as IDX:
+        res = db.correct_piles(recs, poff, read_type=1, max_lq_length=10000, host_threads=4, fasta=(OUT, IDX, names, 500, 0.8))
+    db.close()
+    assert [(ln, np.float32(ide)) for ln, ide in res] == [(ln, np.float32(ide)) for ln, ide, _ in plain]
+    blob = open(fa, "rb").read()
+    got = {}
+    at = 0
+    while at < len(blob):
+        e1 = blob.index(b"\n", at)
+        e2 = blob.index(b"\n", e1 + 1)
+        name, ln, ide = blob[at + 1:e1].split()
+        got[int(name)] = (int(ln), ide.decode(), blob[e1 + 1:e2], e1 + 1)
+        at = e2 + 1
+    want = {n: (ln, "%f" % ide, seq) for n, (ln, ide, seq) in zip(names, plain) if ln >= 500 and ide >= 0.8}
+    assert len(want) >= 5 and {n: v[:3] for n, v in got.items()} == want
+    idx = dict((int(a), (int(b), int(c))) for a, b, c in (ln.split() for ln in open(str(fa) + ".idx")))
+    assert set(idx) == set(names)
+    for n, (ln, _ide, _seq, pos) in got.items():
+        assert idx[n] == (pos, ln)                 # offset of the record's first base, its length (lib/nextcorrect.py:249-251)
+    for n in set(names) - set(got):
+        assert idx[n] == (0, 0)
