@@ -42,6 +42,8 @@ P
               (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/$out/pmc_$c" -o p -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/$out/pmc_$c.log" 2>&1)
             done
             python tools/rocprof_pmc_summary.py "$(ls "$out"/pmc_FETCH_SIZE/*results.db | head -1)" "$(ls "$out"/pmc_WRITE_SIZE/*results.db | head -1)" > "$out/pmc_summary.txt" 2>&1; head -40 "$out/pmc_summary.txt"; rm -rf "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE ;;
+    sq)     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES -d "$OLDPWD/$out/pmc_sq" -o p -- python "$OLDPWD/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OLDPWD/$out/pmc_sq.log" 2>&1)
+            python tools/rocprof_sq_summary.py "$(ls "$out"/pmc_sq/*results.db | head -1)" > "$out/sq_summary.txt" 2>&1; head -30 "$out/sq_summary.txt"; rm -rf "$out"/pmc_sq ;;
     modes)  timeout 1500 python tools/measure_modes.py "$out/overlap_modes.json" > "$out/modes.log" 2>&1; echo "modes exit $?"; tail -12 "$out/modes.log" ;;
     c3)     timeout 1700 python bench.py --config 3 --steps 1 --warmup 1 --no-cpu-baseline > "$out/bench_config3.json" 2> "$out/bench_config3.err"; echo "c3 exit $?"
             python - "$out/bench_config3.json" <<'P'
