@@ -92,49 +92,26 @@ __device__ __forceinline__ Bases64 fetch64(const uint32_t *__restrict__ p, uint3
     return r;
 }
 
-// the first position (0..63) at which the 64 bases from `qpos` / `tpos` on differ; 64: none does.  No branch per word: find-first-bit
-// gives 0xffffffff for a word without a difference, so the minimum over (bit | 32 x word) is the first difference, or beyond 127.
-// (As a cascade of conditions the compiler made it four nested divergent branches -- ~25 scalar instructions of exec-mask bookkeeping
-// per cell round, on a kernel whose wavefronts spend twice as long issuing scalar instructions as vector ones: round 5's SQ counters,
-// profiles/r05_sq_wave_cycles_per_kernel.txt.)
-__device__ __forceinline__ int first_diff64(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint32_t qpos, uint32_t tpos) {
-    const Bases64 a = fetch64_rel(qp, qpos);
-    const Bases64 b = fetch64_rel(tp, tpos);
-    const uint32_t d0 = a.w[0] ^ b.w[0], d1 = a.w[1] ^ b.w[1], d2 = a.w[2] ^ b.w[2], d3 = a.w[3] ^ b.w[3];
-    const uint32_t c0 = (uint32_t)(__builtin_ffs((int)d0) - 1), c1 = (uint32_t)(__builtin_ffs((int)d1) - 1) | 32u;
-    const uint32_t c2 = (uint32_t)(__builtin_ffs((int)d2) - 1) | 64u, c3 = (uint32_t)(__builtin_ffs((int)d3) - 1) | 96u;
-    const uint32_t c01 = c0 < c1 ? c0 : c1, c23 = c2 < c3 ? c2 : c3;
-    uint32_t cm = c01 < c23 ? c01 : c23;
-    cm = cm < 128u ? cm : 128u;
-    return (int)(cm >> 1);
-}
-
 // The snake of one cell (lib/align.c:452-455): how far the diagonal runs on equal bases from (x, x - k).  An edit step lasts as long as
 // its slowest lane, and a lane that compares 16 bases per round trip to the cache needs another round for every 16 equal bases -- with
 // 30-odd live diagonals nearly every step has a lane that needs three; 64 bases per round make the second round rare (a run of 64 equal
-// bases between two reads with 10 % differences).  The first round is straight-line code -- a cell's x never exceeds q_len and its y
-// never t_len or falls below 0 (every cell starts from a furthest-reaching point of the step before), so the fetch is always inside the
-// pool and its padding (kPoolPadWords) and what remains of the sequences only caps the count; the loop is for the run of 64.
+// bases between two reads with 10 % differences).  Same loads in bytes, a third of the dependent rounds.
 __device__ __forceinline__ int snake64(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint32_t q_sh, uint32_t t_sh,
                                        int q_len, int t_len, int x, int k) {
     int y = x - k;
-    int rem = q_len - x;
-    const int rt = t_len - y;
-    rem = rt < rem ? rt : rem;
-    rem = rem > 0 ? rem : 0;
-    int m = first_diff64(qp, tp, q_sh + (uint32_t)x, t_sh + (uint32_t)y);
-    m = m < rem ? m : rem;
-    x += m;
-    y += m;
-    while (m == 64) {
-        rem = q_len - x;
-        const int r2 = t_len - y;
-        rem = r2 < rem ? r2 : rem;
+    for (;;) {
+        int rem = q_len - x;
+        const int rt = t_len - y;
+        rem = rt < rem ? rt : rem;
         if (rem <= 0) break;
-        m = first_diff64(qp, tp, q_sh + (uint32_t)x, t_sh + (uint32_t)y);
+        const Bases64 a = fetch64_rel(qp, q_sh + (uint32_t)x);
+        const Bases64 b = fetch64_rel(tp, t_sh + (uint32_t)y);
+        const uint32_t d0 = a.w[0] ^ b.w[0], d1 = a.w[1] ^ b.w[1], d2 = a.w[2] ^ b.w[2], d3 = a.w[3] ^ b.w[3];
+        int m = d0 ? (__builtin_ctz(d0) >> 1) : d1 ? 16 + (__builtin_ctz(d1) >> 1) : d2 ? 32 + (__builtin_ctz(d2) >> 1) : d3 ? 48 + (__builtin_ctz(d3) >> 1) : 64;
         m = m < rem ? m : rem;
         x += m;
         y += m;
+        if (m < 64) break;
     }
     return x;
 }
