@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
 // of 13.8 KB: the kernel is latency-bound and lives on resident wavefronts); a cell that overflows raises err[0] and the
 // host repeats the sub-batch with kLinkCap.
 template <int CAP>
-__global__ __launch_bounds__(64) void count_links_kernel(const PileDev *__restrict__ piles,
+__global__ __launch_bounds__(64, 7) void count_links_kernel(const PileDev *__restrict__ piles,
                                                           const ReadDev *__restrict__ reads,
                                                           const uint32_t *__restrict__ acc_list,
                                                           const ColBlock *__restrict__ blocks,
