@@ -49,6 +49,9 @@ typedef struct ndgpu_ovl_opt {
 	int32_t step;                       /* --step: 1 (raw reads, 8-field records) or 2 (corrected reads, `cns_align`, 10-field records) */
 	float   minide;                     /* --step 2: --minide (0.05) */
 	int32_t minmatch;                   /* --step 2: --minmatch (100) */
+	int32_t max_occ;                    /* -f FLOAT,INT (mm_mapopt_t::max_occ, main.c:343): when > the mid_occ of a map call, a query read
+	                                       that chained nothing is seeded again with this threshold and chained again (map.c:553-575,
+	                                       :678-700); 0 (every preset) = never */
 } ndgpu_ovl_opt;
 
 typedef struct ndgpu_ovl_index ndgpu_ovl_index;
@@ -60,7 +63,7 @@ typedef struct ndgpu_ovl_rec {
 
 /* mm_mapopt_init + mm_idxopt_init + mm_set_opt(preset) + `--step 1`; preset = "ava-ont" | "ava-pb" | "ava-hifi"
  * (options.c:84-111; ava-hifi = k 51, w 51, HPC: the two-word k-mer sketch mm_sketch_nextdenovo_longkmer, sketch.c:283-356).
- * Returns 0, or -1 for an unknown preset.  k may be 1..28, or odd in 33..63. */
+ * Returns 0, or -1 for an unknown preset.  k may be 1..127 except 32, 64 and 96 (mm_sketch's own range: sketch.c:84, :286-293). */
 int ndgpu_ovl_opt_preset(const char *preset, ndgpu_ovl_opt *opt);
 
 /* Sketch the target reads on the device and build the minimizer index in HBM. */
@@ -190,6 +193,7 @@ typedef struct ndgpu_ovl_stats {
 	uint64_t bases_sketched, minimizers, anchors, tie_reads, chain_cells, chains, overlaps, map_calls, batches;
 	uint64_t ext_problems, ext_launches; /* --mode 3: end extensions run (two candidates per hit), launches they took */
 	double ext_ms;
+	uint64_t rechained;                  /* -f FLOAT,INT: query reads seeded and chained a second time */
 } ndgpu_ovl_stats;
 /* ---- `minimap2-nd --step 2 --mode 0` (the cns_align command of nextDenovo:356-366 with the re-alignment switched off) ----
  * one --step 2 overlap before varint coding: the fields of `overlap_i` (lib/ovl.h); identity = matches * 10000 / block length */

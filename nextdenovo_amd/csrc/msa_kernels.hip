@@ -250,9 +250,10 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
 // ---- K9 --------------------------------------------------------------------------
 // CAP = links per cell the LDS lists hold.  The launch tries the small capacity first (4.6 KB of LDS per wavefront instead
 // of 13.8 KB: the kernel is latency-bound and lives on resident wavefronts); a cell that overflows raises err[0] and the
-// host repeats the sub-batch with kLinkCap.
+// host repeats the sub-batch with kLinkCap.  Seven wavefronts per SIMD for the small capacity (72 VGPRs, 36 B of scratch per lane):
+// 148 -> 127 ms per config-2 step with the kernel alone on the device; at 6 (80 VGPRs) 133 ms, at 8 (64 VGPRs, 76 B of scratch) 134 ms.
 template <int CAP>
-__global__ __launch_bounds__(64, 7) void count_links_kernel(const PileDev *__restrict__ piles,
+__global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(const PileDev *__restrict__ piles,
                                                           const ReadDev *__restrict__ reads,
                                                           const uint32_t *__restrict__ acc_list,
                                                           const ColBlock *__restrict__ blocks,

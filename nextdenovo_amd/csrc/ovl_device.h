@@ -85,6 +85,8 @@ struct QueryDev {
 	// target number is then the POSITION in that list.  nullptr: the whole index.
 	const uint64_t *want_off;
 	const uint32_t *want;
+	// -f FLOAT,INT (re-chaining, minimap2/map.c:553-575): the occurrence threshold of every query read; nullptr: the launch's one
+	const int32_t *read_mid;
 };
 
 // sort key of an anchor: | read (batch local) | strand | target read | target position |

@@ -463,7 +463,8 @@ struct Engine {
 
 	void sketch(const ReadSetDev &R, int rid_is_index, bool want_read, Sketch &out)
 	{
-		if ((P.k & 1) && !getenv("NDGPU_OVL_SEQ_SKETCH")) { sketch_tiled(R, rid_is_index, want_read, out); return; }
+		// (the position-parallel kernels take an odd k of one word up to 28, or of two words: 33..63)
+		if ((P.k & 1) && (P.k <= 28 || (P.k >= 33 && P.k <= 63)) && !getenv("NDGPU_OVL_SEQ_SKETCH")) { sketch_tiled(R, rid_is_index, want_read, out); return; }
 		DevBuf<uint32_t> cnt(R.n + 1);
 		cnt.zero(stream);
 		EvTimer tm(stream);
@@ -572,9 +573,39 @@ struct Engine {
 		return (int32_t)(v + 1);
 	}
 
+	// One pass over the query set.  read_mid (one occurrence threshold per query read) and chains_per_read (what the pass found)
+	// belong to map_rechain() below.
+	const int32_t *read_mid = nullptr;
+	std::vector<uint32_t> *chains_per_read = nullptr;
+	int64_t map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
+	                 const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10 = nullptr,
+	                 const Regs *regs = nullptr);
+	// -f FLOAT,INT (mm_mapopt_t::max_occ > mid_occ; minimap2/map.c:553-575 and :678-700): a query read that ends its chaining without a
+	// chain is seeded again with every minimizer below max_occ occurrences and chained again (with one segment per query that is the
+	// whole test; `rep_len > 0` only spares reads whose second pass would collect the same seeds).  Two passes over the query set: the
+	// first tells which reads found no chain, the second maps every read with ITS threshold -- the reads of a batch are independent,
+	// so the second pass's records are the reference's, in its order, whatever the mode of the call (records, hits, chains).
 	int64_t map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
 	            const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10 = nullptr,
-	            const Regs *regs = nullptr);
+	            const Regs *regs = nullptr)
+	{
+		if (o.max_occ <= mid) return map_once(o, mid, n_q, words, n_words, woff, lens, ids, out, out10, regs);
+		std::vector<uint32_t> chains;
+		struct Unset { Engine *e; ~Unset() { e->read_mid = nullptr, e->chains_per_read = nullptr; } } unset{this};
+		chains_per_read = &chains;
+		int64_t n = map_once(o, mid, n_q, words, n_words, woff, lens, ids, out, out10, regs);
+		chains_per_read = nullptr;
+		if (n < 0) return n;
+		chains.resize(n_q, 0u);
+		std::vector<int32_t> thr(n_q, mid);
+		uint64_t again = 0;
+		for (uint32_t i = 0; i < n_q; ++i)
+			if (!chains[i]) thr[i] = o.max_occ, ++again;
+		if (!again) return n;
+		st.rechained += again;
+		read_mid = thr.data();
+		return map_once(o, mid, n_q, words, n_words, woff, lens, ids, out, out10, regs);
+	}
 };
 
 static OvlParams to_params(const ndgpu_ovl_opt &o)
@@ -590,17 +621,16 @@ static OvlParams to_params(const ndgpu_ovl_opt &o)
 
 static const char *check_opt(const ndgpu_ovl_opt &o)
 {
-	if (o.k < 1 || (o.k > 28 && (o.k < 33 || o.k > 63 || !(o.k & 1))))
-		return "k must be in 1..28, or odd in 33..63 (the two-word k-mer sketch of ava-hifi)";
+	if (o.k < 1 || o.k > 127 || (o.k > 28 && !(o.k & 31)))
+		return "k must be in 1..127 and not 32, 64 or 96 (the reference's long k-mer mask is undefined there: sketch.c:286-287)";
 	if (o.w < 1 || o.w > 64) return "w must be in 1..64";
-	if (o.min_cnt < 2) return "min_cnt must be >= 2";
 	if (o.max_chain_iter < 1 || o.max_chain_iter >= 8192) return "max_chain_iter must be in 1..8191";
 	if (o.max_gap < 0 || o.bw < 0) return "negative max_gap / bw";
 	if (o.step == 2 && (o.mode < 0 || o.mode > 2)) return "--step 2 is built for --mode 0 (no re-alignment), 1 and 2 (the default)";
 	return nullptr;
 }
 
-int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
+int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
                     const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10, const Regs *regs)
 {
 	OvlParams Pm = to_params(o);
@@ -618,6 +648,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	if (++maps_served >= (getenv("NDGPU_OVL_HASH") ? 1u : 2u)) build_hash();
 	out.clear();
 	if (out10) out10->clear();
+	if (chains_per_read) chains_per_read->clear();
 	if ((P.step2 != 0) != (out10 != nullptr)) return -1; // the two record types have an entry point each
 	if (!n_q) return 0;
 
@@ -641,7 +672,12 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		d_want_off.upload(regs->want_off, n_q + 1, stream);
 		if (nw) d_want.upload(regs->want, nw, stream);
 	}
-	const QueryDev qd{Q.len.p, Q.id.p, qhash.p, Q.namekey.p, S.off.p, d_want_off.p, regs && regs->want_off ? d_want.p : nullptr};
+	DevBuf<int32_t> d_read_mid;
+	if (read_mid) {
+		d_read_mid.alloc(n_q);
+		d_read_mid.upload(read_mid, n_q, stream);
+	}
+	const QueryDev qd{Q.len.p, Q.id.p, qhash.p, Q.namekey.p, S.off.p, d_want_off.p, regs && regs->want_off ? d_want.p : nullptr, d_read_mid.p};
 
 	// K3a over every query minimizer
 	EvTimer tm(stream);
@@ -698,7 +734,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	struct BatchOut {
 		std::vector<OvlRec> recs;
 		std::vector<OvlRec10> recs10;
-		std::vector<uint32_t> counts;
+		std::vector<uint32_t> counts, chains;
 		std::vector<uint64_t> ca_x, ca_y, ca_off{0};   // (ca_off: relative to the batch)
 		ndgpu_ovl_stats st{};
 	};
@@ -728,6 +764,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 		EvTimer tm(stream);
 		size_t tb = 0;
 		const uint32_t r0 = ranges[bi].first, r1 = ranges[bi].second;
+		if (chains_per_read) BO.chains.assign(r1 - r0, 0u);
 		const uint32_t nb = r1 - r0;
 		const uint64_t a_base = h_raoff[r0], na = h_raoff[r1] - a_base;
 		++st.batches;
@@ -830,7 +867,8 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 
 		// K5 (keeps copies of f/p for the debug view first: K5 reuses v and t only)
 		const uint64_t rec_cap = na / (uint64_t)std::max(1, P.min_cnt) + nb + 1;
-		DevBuf<uint64_t> wx(na), wy(na);
+		const uint64_t n_w = P.min_cnt < 2 ? 2 * na : na;   // (K5's chain tables: see hits_kernel)
+		DevBuf<uint64_t> wx(n_w), wy(n_w);
 		DevBuf<uint32_t> tables((size_t)nb * 512), n_rec(nb + 1), n_chain(nb);
 		DevBuf<OvlRec> recs(rec_cap);
 		DevBuf<OvlRec10> recs10(P.step2 ? rec_cap : 0);
@@ -855,6 +893,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 			n_rec.download(regs->counts->data() + at, nb, stream);
 		}
 		HIP_OK(hipStreamSynchronize(stream));
+		if (chains_per_read) BO.chains = h_chain;
 		if (P.chains) {
 			DevBuf<uint64_t> ca_off(nb + 1);
 			tb = 0;
@@ -990,6 +1029,7 @@ int64_t Engine::map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uin
 	for (BatchOut &BO : outs) {
 		out.insert(out.end(), BO.recs.begin(), BO.recs.end());
 		if (out10) out10->insert(out10->end(), BO.recs10.begin(), BO.recs10.end());
+		if (chains_per_read) chains_per_read->insert(chains_per_read->end(), BO.chains.begin(), BO.chains.end());
 		if (regs) {
 			regs->counts->insert(regs->counts->end(), BO.counts.begin(), BO.counts.end());
 			if (regs->ca_x) {

@@ -68,7 +68,10 @@ struct BaseReader {
 	}
 };
 
-template <bool FILL>
+// LONG: k > 28 -- mm_sketch_nextdenovo_longkmer (sketch.c:283-356) with the k-mer in up to four words (b2kmer, b2kmer_rc, kmer_cmp,
+// hash256to64: sketch.c:219-281); the launcher sends here what the position-parallel kernels below do not take (even k, where a k-mer
+// can equal its reverse complement and the window stands still; k = 29..31 and k > 63).
+template <bool FILL, bool LONG>
 __global__ void __launch_bounds__(64) sketch_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ woff,
                                                      const uint32_t *__restrict__ len, const uint32_t *__restrict__ order,
                                                      uint32_t n_reads, int w, int k, int hpc, int rid_is_index,
@@ -90,8 +93,11 @@ __global__ void __launch_bounds__(64) sketch_kernel(const uint32_t *__restrict__
 	uint32_t cnt = 0;
 	if (n > 0) {
 		BaseReader rd(words + woff[r]);
-		const uint64_t mask = (1ULL << 2 * k) - 1, top = 2ULL * (k - 1);
+		const int k_idx = LONG ? (k - 1) / 32 : 0;
+		const uint64_t mask = LONG ? (1ULL << 2 * (((k - 1) & 31) + 1)) - 1 : (1ULL << 2 * k) - 1;
+		const uint64_t top = LONG ? (uint64_t)(((k - 1) & 31) << 1) : 2ULL * (k - 1);
 		uint64_t fw = 0, rv = 0, best_x = ~0ULL;
+		uint64_t F[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
 		uint32_t best_y = ~0u;
 		int good = 0, slot = 0, best_slot = 0, span = 0, rq_front = 0, rq_count = 0;
 		for (int j = 0; j < w; ++j) ring_x[j * 64 + lane] = ~0ULL, ring_y[j * 64 + lane] = ~0u;
@@ -112,13 +118,37 @@ __global__ void __launch_bounds__(64) sketch_kernel(const uint32_t *__restrict__
 				span += rc;
 				if (rq_count > k) { span -= runq[rq_front * 64 + lane]; rq_front = (rq_front + 1) & 31; --rq_count; }
 			} else span = good + 1 < k ? good + 1 : k;
-			fw = (fw << 2 | (uint64_t)c) & mask;
-			rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
-			if (fw == rv) continue;
-			const int strand = fw < rv ? 0 : 1;
+			int strand;
+			if (LONG) {
+				F[3] = F[3] << 2 | F[2] >> 62, F[2] = F[2] << 2 | F[1] >> 62, F[1] = F[1] << 2 | F[0] >> 62, F[0] = F[0] << 2 | (uint64_t)c;
+				R[0] = R[0] >> 2 | R[1] << 62, R[1] = R[1] >> 2 | R[2] << 62, R[2] = R[2] >> 2 | R[3] << 62, R[3] >>= 2;
+				int cmp = 0;
+#pragma unroll
+				for (int j = 3; j >= 0; --j) {
+					if (j == k_idx) F[j] &= mask, R[j] |= (uint64_t)(3 ^ c) << top;
+					if (!cmp) cmp = F[j] < R[j] ? -1 : F[j] > R[j] ? 1 : 0;
+				}
+				if (cmp == 0) continue;
+				strand = cmp < 0 ? 0 : 1;
+			} else {
+				fw = (fw << 2 | (uint64_t)c) & mask;
+				rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
+				if (fw == rv) continue;
+				strand = fw < rv ? 0 : 1;
+			}
 			++good;
 			if (good >= k && span < 256) {
-				cur_x = hash_masked(strand ? rv : fw, mask) << 8 | (uint64_t)span;
+				uint64_t h;
+				if (LONG) {
+					h = 0;
+#pragma unroll
+					for (int j = 3; j >= 0; --j) {
+						const uint64_t kj = strand ? R[j] : F[j];
+						if (j == k_idx) h = hash_masked(kj, mask);
+						else if (j < k_idx && kj) h += hash_full(kj);
+					}
+				} else h = hash_masked(strand ? rv : fw, mask);
+				cur_x = h << 8 | (uint64_t)span;
 				cur_y = (uint32_t)i << 1 | (uint32_t)strand;
 			}
 			ring_x[slot * 64 + lane] = cur_x, ring_y[slot * 64 + lane] = cur_y;
@@ -162,12 +192,11 @@ void launch_sketch(bool fill, const uint32_t *words, const uint64_t *woff, const
 	if (!n_reads) return;
 	dim3 grid((n_reads + 63) / 64), block(64);
 	size_t sm = sketch_smem(P.w);
-	if (fill)
-		ND_LAUNCH(sketch_kernel<true>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
-		                   out_off, out_x, out_y, out_read, out_cnt);
-	else
-		ND_LAUNCH(sketch_kernel<false>, grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index,
-		                   out_off, out_x, out_y, out_read, out_cnt);
+#define SK(F_, L_) ND_LAUNCH((sketch_kernel<F_, L_>), grid, block, sm, s, words, woff, len, order, n_reads, P.w, P.k, P.hpc, rid_is_index, \
+                             out_off, out_x, out_y, out_read, out_cnt)
+	if (P.k > 28) { if (fill) SK(true, true); else SK(false, true); }
+	else { if (fill) SK(true, false); else SK(false, false); }
+#undef SK
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -639,6 +668,7 @@ __global__ void seed_count_kernel(const uint64_t *__restrict__ mx, const uint64_
 	uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= n_m) return;
 	uint32_t start, cnt, surv = 0;
+	if (q.read_mid) mid_occ = q.read_mid[m_read[m]];
 	index_lookup(ix, mx[m] >> 8, start, cnt);
 	if (q.want) { // re-alignment: the index the reference looks this minimizer up in holds the wanted reads only
 		const uint32_t rd = m_read[m];
@@ -1477,7 +1507,9 @@ __global__ void __launch_bounds__(64) hits_kernel(const uint64_t *__restrict__ r
 	const uint64_t *X = ax + a0, *Y = ay + a0;
 	const int32_t *F = f + a0, *Pp = p + a0;
 	int32_t *T = t + a0;  // (v[] is K4's; the walks are not listed any more)
-	uint64_t *U = u + a0, *BX = bx + a0, *BY = by + a0, *WX = wx + a0, *WY = wy + a0;
+	// (wx / wy: one slot per anchor, or two when chains of ONE anchor pass -- min_cnt < 2 -- and a read can have as many chains as anchors)
+	const uint64_t w0 = P.min_cnt < 2 ? 2 * a0 : a0;
+	uint64_t *U = u + a0, *BX = bx + a0, *BY = by + a0, *WX = wx + w0, *WY = wy + w0;
 	uint32_t *head = tables + (size_t)rl * 512, *tail = head + 256;
 	SortJob *stack = stacks + a0 / 64 + 2 * (size_t)rl;
 
@@ -1591,7 +1623,7 @@ __global__ void __launch_bounds__(64) hits_kernel(const uint64_t *__restrict__ r
 	}
 	// hash-ordered hits: z.x = score<<32 | (cnt ^ h), z.y = first<<32 | cnt, over the re-ordered chains
 	const uint32_t qhash = q.hash[rd];
-	// (the host rejects min_cnt < 2, so n_u <= n / 2 and the upper halves of WX/WY are free)
+	// (a chain has min_cnt >= 2 anchors, so n_u <= n / 2 and the upper halves of WX/WY are free; with min_cnt < 2 the arrays are twice as long)
 	uint64_t *ZX = WX + n_u, *ZY = WY + n_u;
 	// The reference now copies the chains back in this order; the anchors are the same, so they are addressed
 	// in place through `first` (their offset in B).

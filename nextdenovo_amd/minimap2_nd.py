@@ -3,7 +3,7 @@
 
 Takes the command line nextDenovo writes for the raw-align subtasks (reference nextDenovo:436-466):
 
-    python -m nextdenovo_amd.minimap2_nd --step 1 [--dual=yes] [--mode 3] -t 8 -x ava-ont|ava-pb|ava-hifi [-f N] [-I 4G] target.2bit query.2bit -o out.ovl
+    python -m nextdenovo_amd.minimap2_nd --step 1 [--dual=yes] [--mode 3] -t 8 -x ava-ont|ava-pb|ava-hifi [-f N[,M]] [-I 4G] target.2bit query.2bit -o out.ovl
 
 and writes the byte-identical overlap file.  Mirrors minimap2/main.c for the options of this path (preset
 first, then the remaining options in order: main.c:140-366); the index is split into parts exactly as
@@ -19,6 +19,8 @@ filters, the dovetail / contained filter, the 10-field encoder and the `.bl` tab
 mm_chain_dp_nextdenovo, anchor thinning beyond 100,000 anchors included).
 `-c` (with --step 1, not --mode 3, not ava-hifi -- the compiled reference aborts there): base-level alignment through every chain
 (mm_align_skeleton, minimap2/align.c:857-913) before the writer's filter; -A -B -O -E -z -s as in minimap2/main.c:250-252,353-361.
+`-f FLOAT,INT` re-chains the reads that found no chain with the second threshold (map.c:553-575); `-n` may go down to 1; `-k` up to
+127 (not 32, 64, 96: the reference's own mask is undefined there).
 Options of other paths (-a, --step 3) are rejected, not approximated.
 """
 from __future__ import annotations
@@ -125,8 +127,8 @@ def build_opt(a: Args) -> overlap.Opt:
                 opt.mid_occ_frac, opt.mid_occ = x, 0
             else:
                 opt.mid_occ = int(x + .499)
-            if tail:
-                raise SystemExit("[ERROR] -f FLOAT,INT (max_occ re-chaining) is not supported")
+            if tail:   # main.c:343: a read that chained nothing is seeded again up to this many occurrences (map.c:553-575)
+                opt.max_occ = int(float(tail) + .499)
         elif name == "-I":
             a.batch_size = parse_num(val)
         elif name == "-K":

@@ -21,7 +21,7 @@ class Opt(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "no_diag", "no_dual", "min_cnt", "min_chain_score", "bw", "max_gap",
                                          "max_chain_skip", "max_chain_iter", "minlen", "seed", "dvt", "maxhan1", "maxhan2")] \
         + [("mid_occ_frac", C.c_float), ("mid_occ", C.c_int32), ("mode", C.c_int32), ("d_factor", C.c_float), ("step", C.c_int32),
-           ("minide", C.c_float), ("minmatch", C.c_int32)]
+           ("minide", C.c_float), ("minmatch", C.c_int32), ("max_occ", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -29,7 +29,7 @@ class Stats(C.Structure):
                                           "hits_ms")] \
         + [(n, C.c_uint64) for n in ("bases_sketched", "minimizers", "anchors", "tie_reads", "chain_cells", "chains",
                                      "overlaps", "map_calls", "batches", "ext_problems", "ext_launches")] \
-        + [("ext_ms", C.c_double)]
+        + [("ext_ms", C.c_double), ("rechained", C.c_uint64)]
 
 
 REC = np.dtype([(n, np.uint32) for n in ("rev", "qname", "qs", "qe", "tname", "ts", "te", "match")])

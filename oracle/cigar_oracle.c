@@ -601,6 +601,14 @@ static int64_t c_read(c_ctx *C, uint32_t qid, const uint8_t *qcodes, int qlen, i
 	n_a = nd_mm_seeds(C->ix, opt, qname, qlen, mid_occ, mv, n_mv, a, 1);
 	u = (uint64_t*)malloc(8 * (size_t)(n_a > 0 ? n_a : 1));
 	n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
+	if (n_u == 0 && nd_mm_rechain_wanted(C->ix, opt, mid_occ, mv, n_mv)) { /* map.c:553-575 */
+		free(a); free(u);
+		for (i = 0, n_a = 0; i < n_mv; ++i) { int n_occ; index_get(C->ix, mv[i].x >> 8, &n_occ); if (n_occ < opt->max_occ) n_a += n_occ; }
+		a = (nd_mm128*)malloc(sizeof(nd_mm128) * (size_t)(n_a > 0 ? n_a : 1));
+		n_a = nd_mm_seeds(C->ix, opt, qname, qlen, opt->max_occ, mv, n_mv, a, 1);
+		u = (uint64_t*)malloc(8 * (size_t)(n_a > 0 ? n_a : 1));
+		n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
+	}
 	free(mv);
 	if (n_u <= 0) { free(a); free(u); return 0; }
 	g = (nd_mm_reg*)malloc(sizeof(nd_mm_reg) * (size_t)n_u);

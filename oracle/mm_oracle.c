@@ -30,6 +30,7 @@ typedef struct {
 	int32_t min_cnt, min_sc, bw, max_gap, max_skip, max_iter;
 	int32_t minlen, seed;
 	int32_t dvt, maxhan1, maxhan2;
+	int32_t max_occ; /* -f FLOAT,INT (main.c:343); 0 = no re-chaining */
 } nd_mm_opt;
 
 typedef struct {
@@ -82,23 +83,25 @@ static uint64_t mix64_full(uint64_t key) /* hash64_no_mask, sketch.c:262-272; th
 }
 
 /* codes[i] in 0..3 (reads come from .2bit files: no ambiguous bases).  out needs room for len+1 entries.
- * k <= 28: mm_sketch_shortkmer (sketch.c:77-143); 33 <= k <= 63: mm_sketch_nextdenovo_longkmer (sketch.c:283-356, the
- * ava-hifi preset's k = 51) with the k-mer in two words (u[1] = the top 2(k-32) bits, u[0] = the low 64) -- the same window
- * automaton, another k-mer value: hash64(u[1], mask) + (u[0] ? hash64_no_mask(u[0]) : 0)  (hash256to64, sketch.c:274-281).
+ * k <= 28: mm_sketch_shortkmer (sketch.c:77-143); 29 <= k <= 127: mm_sketch_nextdenovo_longkmer (sketch.c:283-356, the
+ * ava-hifi preset's k = 51) with the k-mer in up to four words, u[k_idx] the top one of 2 (((k - 1) & 31) + 1) bits -- the same
+ * window automaton, another k-mer value: hash64(u[k_idx], mask) + the sum of hash64_no_mask(u[j]) over the non-zero lower words
+ * (hash256to64, sketch.c:274-281).  k = 32, 64, 96 and 128 are refused: the reference's mask is `(1ULL << 64) - 1` there.
  * The run-length queue keeps the reference's 32 slots (sketch.c:40-58): with k > 31 it wraps, and the span the reference
  * reports for a homopolymer-compressed long k-mer is what this ring leaves. */
 int64_t nd_mm_sketch(const uint8_t *codes, int len, int w, int k, uint32_t rid, int hpc, nd_mm128 *out)
 {
 	const int longk = k > 28;
-	const int kbits = longk ? 2 * (k - 32) : 2 * k;              /* bits of the top word */
-	const uint64_t mask = (1ULL << kbits) - 1;
-	const int top = longk ? 2 * (k - 1) - 64 : 2 * (k - 1);      /* where a new base enters the reverse strand's top word */
-	uint64_t fw = 0, rv = 0, fw_lo = 0, rv_lo = 0;
+	const int k_idx = longk ? (k - 1) / 32 : 0;                          /* the top word (sketch.c:286) */
+	const int kbits = longk ? 2 * (((k - 1) & 31) + 1) : 2 * k;         /* its bits */
+	const uint64_t mask = (1ULL << (kbits & 63)) - 1;
+	const int top = longk ? ((k - 1) & 31) << 1 : 2 * (k - 1);          /* where a new base enters the reverse strand's top word */
+	uint64_t fw = 0, rv = 0, F[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
 	nd_mm128 ring[256], best = { NONE64, NONE64 };
 	int runq[32], rq_front = 0, rq_count = 0; /* last k homopolymer run lengths (32 slots, as tiny_queue_t) */
 	int i, j, good = 0, slot = 0, best_slot = 0, span = 0;
 	int64_t n = 0;
-	if (len <= 0 || w <= 0 || w >= 256 || k <= 0 || (k > 28 && k < 33) || k > 63) return -1;
+	if (len <= 0 || w <= 0 || w >= 256 || k <= 0 || k > 127 || (longk && kbits == 64)) return -1;
 	memset(ring, 0xff, sizeof(nd_mm128) * w);
 	for (i = 0; i < len; ++i) {
 		int c = codes[i], strand;
@@ -114,13 +117,17 @@ int64_t nd_mm_sketch(const uint8_t *codes, int len, int w, int k, uint32_t rid, 
 			span += run;
 			if (rq_count > k) { span -= runq[rq_front]; rq_front = (rq_front + 1) & 31; --rq_count; }
 		} else span = good + 1 < k ? good + 1 : k;
-		if (longk) {
-			fw = (fw << 2 | fw_lo >> 62) & mask;
-			fw_lo = fw_lo << 2 | (uint64_t)c;
-			rv_lo = rv_lo >> 2 | rv << 62;
-			rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
-			if (fw == rv && fw_lo == rv_lo) continue;
-			strand = (fw < rv || (fw == rv && fw_lo < rv_lo)) ? 0 : 1;
+		if (longk) { /* b2kmer, b2kmer_rc, kmer_cmp (sketch.c:219-259) */
+			int cmp = 0;
+			for (j = 3; j > 0; --j) F[j] = F[j] << 2 | F[j - 1] >> 62;
+			F[0] = F[0] << 2 | (uint64_t)c;
+			F[k_idx] &= mask;
+			for (j = 0; j < 3; ++j) R[j] = R[j] >> 2 | R[j + 1] << 62;
+			R[3] >>= 2;
+			R[k_idx] |= (uint64_t)(3 ^ c) << top;
+			for (j = 3; j >= 0 && !cmp; --j) cmp = F[j] < R[j] ? -1 : F[j] > R[j] ? 1 : 0;
+			if (cmp == 0) continue;
+			strand = cmp < 0 ? 0 : 1;
 		} else {
 			fw = (fw << 2 | (uint64_t)c) & mask;
 			rv = rv >> 2 | (uint64_t)(3 ^ c) << top;
@@ -129,11 +136,12 @@ int64_t nd_mm_sketch(const uint8_t *codes, int len, int w, int k, uint32_t rid, 
 		}
 		++good;
 		if (good >= k && span < 256) {
-			uint64_t h = mix64(strand ? rv : fw, mask);
+			uint64_t h;
 			if (longk) {
-				const uint64_t lo = strand ? rv_lo : fw_lo;
-				if (lo) h += mix64_full(lo);
-			}
+				const uint64_t *K = strand ? R : F;
+				h = mix64(K[k_idx], mask);
+				for (j = k_idx - 1; j >= 0; --j) if (K[j]) h += mix64_full(K[j]);
+			} else h = mix64(strand ? rv : fw, mask);
 			cur.x = h << 8 | (uint64_t)span;
 			cur.y = (uint64_t)rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)strand;
 		}
@@ -615,6 +623,21 @@ static void trim_bad_chain_ends(nd_mm_reg *r, const nd_mm128 *a, int qlen, int b
 	}
 }
 
+/* The re-chaining test of mm_map_frag (minimap2/map.c:553-566) for a query of one segment whose chaining ended without a chain:
+ * max_occ above the threshold just used, and rep_len > 0 -- collect_matches (map.c:91-125) adds the span of every minimizer it
+ * skips for its occurrences, so rep_len > 0 says "one was skipped". */
+int nd_mm_rechain_wanted(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, const nd_mm128 *mv, int64_t n_mv)
+{
+	int64_t i;
+	if (opt->max_occ <= mid_occ) return 0;
+	for (i = 0; i < n_mv; ++i) {
+		int n_occ;
+		index_get(ix, mv[i].x >> 8, &n_occ);
+		if (n_occ >= mid_occ) return 1;
+	}
+	return 0;
+}
+
 static int map_read_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_occ, uint32_t qid, const uint8_t *qcodes, int qlen,
                          nd_mm_reg *regs, int reg_cap, int mode3);
 
@@ -660,6 +683,18 @@ static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_o
 	u = (uint64_t*)malloc(8 * (n_a > 0 ? n_a : 1));
 	g_chain_thin = g_count_big_maps;
 	n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
+	if (n_u == 0 && nd_mm_rechain_wanted(ix, opt, mid_occ, mv, n_mv)) { /* map.c:553-575, :678-700 */
+		free(a); free(u);
+		for (i = 0, n_a = 0; i < n_mv; ++i) {
+			int n_occ;
+			index_get(ix, mv[i].x >> 8, &n_occ);
+			if (n_occ < opt->max_occ) n_a += n_occ;
+		}
+		a = (nd_mm128*)malloc(sizeof(nd_mm128) * (n_a > 0 ? n_a : 1));
+		n_a = nd_mm_seeds(ix, opt, qname, qlen, opt->max_occ, mv, n_mv, a, 1);
+		u = (uint64_t*)malloc(8 * (n_a > 0 ? n_a : 1));
+		n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
+	}
 	g_chain_thin = 0;
 	n = n_u <= reg_cap ? n_u : -n_u;
 	if (n > 0) nd_mm_gen_regs(nd_mm_read_hash(qname, qlen, opt->seed), qlen, n_u, u, a, regs);

@@ -35,6 +35,8 @@ CASES_C = [  # (file tag, preset, target, query, dual, extra argv); sets "seed"/
     ("ont.sv.I150k.c", "ava-ont", "sv", "svq", True, ("-c", "-I", "150k")),   # a multi-part index: through the command line only
     # one gap piece: the reference aligns with ksw_extz2_sse (minimap2/align.c:313-331)
     ("ont.sv.O4E2.c", "ava-ont", "sv", "svq", True, ("-c", "-O", "4", "-E", "2")),
+    # -f FLOAT,INT: the reads that chained nothing below 6 occurrences are seeded and chained again below 300 (map.c:553-575)
+    ("ont.sxp.dual.f6r300.c", "ava-ont", "seed", "part", True, ("-c", "-f", "6,300")),
 ]
 
 

@@ -30,6 +30,15 @@ CASES = [  # (file tag, preset, target, query, dual, extra argv)
     ("hifi.sxs", "ava-hifi", "hseed", "hseed", False, ()),
     ("hifi.sxp.dual", "ava-hifi", "hseed", "hpart", True, ()),
     ("hifi.sxs.f40", "ava-hifi", "hseed", "hseed", False, ("-f", "40")),   # nextDenovo passes -f seed_depth*20 (config_parser.py:46-47)
+    # -f FLOAT,INT: a read that chained nothing below the first threshold is seeded and chained again below the second (map.c:553-575)
+    ("ont.sxp.dual.f6r300", "ava-ont", "seed", "part", True, ("-f", "6,300")),
+    ("pb.sxs.f4r60", "ava-pb", "seed", "seed", False, ("-f", "4,60")),
+    ("hifi.sxp.f3r50", "ava-hifi", "hseed", "hpart", False, ("-f", "3,50")),
+    # chains of ONE anchor pass (-n 1; the thresholds lowered so that they reach the output)
+    ("ont.sxp.dual.n1", "ava-ont", "seed", "part", True, ("-n", "1", "-m", "15", "--minlen", "14")),
+    # long k-mers outside ava-hifi's 51: even (a k-mer can equal its reverse complement), three words
+    ("hifi.sxp.dual.k40", "ava-hifi", "hseed", "hpart", True, ("-k", "40", "-w", "30")),
+    ("hifi.sxs.k70", "ava-hifi", "hseed", "hseed", False, ("-k", "70", "-w", "40")),
 ]
 # --mode 3: chain ends trimmed (nd_fix_bad_ends) and every hit extended into the unaligned read ends (nd_extend_ends,
 # minimap2/map.c:340-482) before the step-1 filter; with --dvt the extension is skipped for hits that are not near-dovetails

@@ -46,6 +46,12 @@ CASES_M1 = [("ont.m1", dict(CASES)["ont"]), ("deep.m1", dict(CASES_M2)["deep.m2"
 CASES_THIN = [("tandem.m1", ("--dual=yes", "-x", "ava-ont", "-k", "17", "-w", "17", "--minlen", "1000", "--maxhan1", "2000", "-f", "1000"))]
 
 
+# -f FLOAT,INT: reads that chained nothing below the first occurrence threshold are seeded and chained again below the second
+# (minimap2/map.c:553-575; in the re-alignment's mappings too, which get the same options: map.c:1045-1113)
+CASES_RECHAIN = [("ont.rechain", dict(CASES)["ont"] + ("-f", "5,200")), ("ont.rechain.m2", dict(CASES)["ont"] + ("-f", "5,200")),
+                 ("deep.rechain.m1", dict(CASES_M2)["deep.m2"] + ("-f", "60,2000"))]
+
+
 def files_of(tag):
     if tag.startswith("tandem"):
         return ["tandem.fa.gz", "tandem.fa.gz"]
@@ -71,10 +77,25 @@ def make_tandem():
         print(tag, ul, copies, len(rs.seqs), os.path.getsize(out), os.path.getsize(out + ".bl"))
 
 
+def make_rechain():
+    for tag, argv in CASES_RECHAIN:
+        mode = () if tag.endswith(".m2") else ("--mode", "1") if tag.endswith(".m1") else ("--mode", "0")
+        out = os.path.join(OUT, tag + ".ovl")
+        refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *mode, "-t", "3", *argv,
+                     *[os.path.join(OUT, f) for f in files_of(tag)], "-o", out])
+        first = argv[:-1] + (argv[-1].partition(",")[0],)   # (the first threshold alone: the fixture must differ from it)
+        refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *mode, "-t", "3", *first,
+                     *[os.path.join(OUT, f) for f in files_of(tag)], "-o", "/tmp/nd_first.ovl"])
+        same = open(out, "rb").read() == open("/tmp/nd_first.ovl", "rb").read()
+        print(tag, os.path.getsize(out), os.path.getsize(out + ".bl"), "same as without re-chaining" if same else "re-chaining changes it")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "tandem":   # (only the anchor-thinning fixture)
         return make_tandem()
+    if len(sys.argv) > 1 and sys.argv[1] == "rechain":  # (only the -f FLOAT,INT fixtures)
+        return make_rechain()
     g = synth.make_genome(26000, seed=61, n_repeats=2, repeat_len=1200)
     rs = synth.simulate_reads(g, 22, "hifi", seed=62, mu=8.3, sigma=0.35, min_len=2200)
     seqs = list(rs.seqs)
@@ -100,6 +121,7 @@ def main():
             refpipe.run([os.path.join(M.REFDIR, "minimap2-nd"), "--step", "2", *mode, "-t", "3", *argv,
                          *[os.path.join(OUT, f) for f in files_of(tag)], "-o", out])
             print(tag, os.path.getsize(out), os.path.getsize(out + ".bl"))
+    make_rechain()
     make_tandem()
 
 

@@ -15,7 +15,7 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 
 class MMOpt(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "no_diag", "no_dual", "min_cnt", "min_sc", "bw", "max_gap",
-                                         "max_skip", "max_iter", "minlen", "seed", "dvt", "maxhan1", "maxhan2")]
+                                         "max_skip", "max_iter", "minlen", "seed", "dvt", "maxhan1", "maxhan2", "max_occ")]
 
 
 class MMReg(C.Structure):

@@ -13,7 +13,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import mm_util as M  # noqa: E402
 from make_overlap_golden import CASES, SETS  # noqa: E402
-from test_overlap_oracle import case_kwargs  # noqa: E402
+from test_overlap_oracle import case_kwargs, max_occ_of, opt_overrides  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(HERE, "golden", "overlap")
@@ -48,6 +48,9 @@ def dev_opt(preset, dual, extra=()):
         o.mode = 3
     if "--dvt" in extra:
         o.dvt = 1
+    o.max_occ = max_occ_of(extra)
+    for name, v in opt_overrides(extra).items():
+        setattr(o, "min_chain_score" if name == "min_sc" else name, v)
     return o
 
 
@@ -108,6 +111,7 @@ def test_ovl_bytes_match_reference_golden(sets, case):
         st = ix.stats()
     assert got == want
     assert st["anchors"] > 0 and st["chains"] > 0
+    assert (st["rechained"] > 0) == (o.max_occ > 0)   # -f FLOAT,INT: some reads of those fixtures chain nothing at the first threshold
 
 
 @pytest.mark.parametrize("preset,dual,tq", [("ava-ont", True, ("seed", "part")), ("ava-ont", False, ("seed", "seed")),
@@ -216,11 +220,15 @@ def _adversarial_reads(seed=11):
 
 
 @pytest.mark.parametrize("k,w,hpc", [(15, 5, 0), (19, 5, 1), (5, 1, 0), (7, 8, 1), (11, 17, 0), (3, 2, 1), (27, 64, 0), (14, 5, 0), (6, 3, 1),
-                                     (51, 51, 1), (51, 51, 0), (33, 4, 1), (63, 7, 1), (35, 64, 0), (47, 1, 1)])
+                                     (51, 51, 1), (51, 51, 0), (33, 4, 1), (63, 7, 1), (35, 64, 0), (47, 1, 1),
+                                     (29, 5, 1), (30, 4, 0), (31, 9, 1), (34, 3, 0), (40, 6, 1), (36, 8, 0), (62, 2, 0), (65, 7, 1), (70, 5, 0),
+                                     (100, 11, 0), (127, 2, 1)])
 def test_sketch_adversarial_reads(olib, k, w, hpc):
     """Low-complexity / tandem / homopolymer-heavy / very short reads: the position-parallel K1 (odd k) and the
     sequential K1 (even k) both reproduce the window automaton, first-window quirks included; k > 32 is the two-word k-mer
-    of ava-hifi, whose homopolymer-compressed span comes out of the reference's wrapped 32-slot run queue."""
+    of ava-hifi, whose homopolymer-compressed span comes out of the reference's wrapped 32-slot run queue.  Every other k above 28
+    (even: the tandem reads hold k-mers that equal their reverse complement; 29..31; three and four words) is the sequential K1
+    with the k-mer in four words."""
     from nextdenovo_amd import overlap, synth
     reads = _adversarial_reads()
     lens = np.asarray([r.size for r in reads], dtype=np.uint32)

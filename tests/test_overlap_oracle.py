@@ -33,7 +33,7 @@ def case_kwargs(extra, preset=None):
     if preset == "ava-hifi":
         kw["mid_occ_frac"] = 1e-4  # options.c:108
     if "-f" in extra:
-        x = float(extra[extra.index("-f") + 1])
+        x = float(extra[extra.index("-f") + 1].partition(",")[0])
         if x < 1.0:
             kw["mid_occ_frac"] = x
         else:
@@ -46,12 +46,28 @@ def case_kwargs(extra, preset=None):
     return kw
 
 
+def opt_overrides(extra):
+    """-k / -w / -n / -m / --minlen of a case's argv as fields of the oracle's option struct."""
+    kw = {}
+    for flag, name in (("-k", "k"), ("-w", "w"), ("-n", "min_cnt"), ("-m", "min_sc"), ("--minlen", "minlen")):
+        if flag in extra:
+            kw[name] = int(extra[extra.index(flag) + 1])
+    return kw
+
+
+def max_occ_of(extra):
+    """-f FLOAT,INT (main.c:343): the re-chaining threshold, 0 when the option has no second number."""
+    tail = extra[extra.index("-f") + 1].partition(",")[2] if "-f" in extra else ""
+    return int(float(tail) + .499) if tail else 0
+
+
 @pytest.mark.parametrize("case", CASES + CASES_M3, ids=[c[0] for c in CASES + CASES_M3])
 def test_oracle_matches_golden_ovl(lib, sets, case):
     tag, preset, t, q, dual, extra = case
     with open(os.path.join(GOLD, tag + ".ovl"), "rb") as f:
         want = f.read()
-    got, _ = M.step1(lib, M.preset(preset, dual, dvt=1 if "--dvt" in extra else 0), sets[t], sets[q], **case_kwargs(extra, preset))
+    got, _ = M.step1(lib, M.preset(preset, dual, dvt=1 if "--dvt" in extra else 0, max_occ=max_occ_of(extra), **opt_overrides(extra)), sets[t], sets[q],
+                     **case_kwargs(extra, preset))
     assert got == want
 
 
@@ -185,14 +201,16 @@ def _fasta_set(path):
     return (np.asarray(ids, dtype=np.uint32), lens, np.concatenate(arrs).astype(np.uint8), off)
 
 
-@pytest.mark.parametrize("tag", ["ont", "pb", "ont.m2", "pb.m2", "deep.m2", "ont.m1", "deep.m1"])
+@pytest.mark.parametrize("tag", ["ont", "pb", "ont.m2", "pb.m2", "deep.m2", "ont.m1", "deep.m1", "ont.rechain", "ont.rechain.m2", "deep.rechain.m1"])
 def test_oracle_step2_matches_golden(lib, tag):
     """The step-2 oracle on the committed fixtures of the compiled reference (tests/golden/step2; `.m2`: the command without --mode,
     i.e. with the re-alignment): what the GPU tests of the device path compare with on a box that has no reference."""
     sys.path.insert(0, os.path.join(HERE, "golden"))
-    from make_step2_golden import CASES as S0, CASES_M1, CASES_M2, OUT
-    argv = dict(S0 + CASES_M2 + CASES_M1)[tag]
-    kw = {}
+    from make_step2_golden import CASES as S0, CASES_M1, CASES_M2, CASES_RECHAIN, OUT
+    argv = dict(S0 + CASES_M2 + CASES_M1 + CASES_RECHAIN)[tag]
+    kw, f_kw = {}, {}
+    if "-f" in argv:   # (-f INT,INT: the fixed threshold and the re-chaining one)
+        f_kw, kw["max_occ"] = {"mid_occ_fixed": int(argv[argv.index("-f") + 1].partition(",")[0])}, max_occ_of(argv)
     for k_, name in (("-k", "k"), ("-w", "w"), ("--minlen", "minlen"), ("--maxhan1", "maxhan1"), ("--maxhan2", "maxhan2")):
         if k_ in argv:
             kw[name] = int(argv[argv.index(k_) + 1])
@@ -203,7 +221,7 @@ def test_oracle_step2_matches_golden(lib, tag):
         a, b = _fasta_set(os.path.join(OUT, "a.fa.gz")), _fasta_set(os.path.join(OUT, "b.fa.gz"))
         qs = [b, a]
     mode = 2 if tag.endswith(".m2") else 1 if tag.endswith(".m1") else 0
-    got, got_bl = M.step2(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, qs, mode, cn=50 if mode == 1 else 20)
+    got, got_bl = M.step2(lib, M.preset(argv[argv.index("-x") + 1], True, **kw), a, qs, mode, cn=50 if mode == 1 else 20, **f_kw)
     lib.nd_mm_step2_big_maps.restype = C.c_int64
     assert lib.nd_mm_step2_big_maps() == 0   # (no mapping of these fixtures has the 100,000 anchors mm_chain_dp_nextdenovo thins: see below)
     assert got == open(os.path.join(OUT, tag + ".ovl"), "rb").read()

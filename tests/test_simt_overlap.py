@@ -68,7 +68,7 @@ def test_batches_side_by_side(interpreted, olib, monkeypatch, tmp_path):
     GO.test_live_set_many_batches(olib, "ont", "ava-ont", monkeypatch, tmp_path)
 
 
-_CLI_CASES = [c for c in GO.CASES + CASES_M3 if "-I" in c[5] or "--mode" in c[5]]
+_CLI_CASES = [c for c in GO.CASES + CASES_M3 if "-I" in c[5] or "--mode" in c[5] or "," in "".join(c[5])]   # (, : -f FLOAT,INT)
 
 
 @pytest.mark.parametrize("case", _CLI_CASES, ids=[c[0] for c in _CLI_CASES])
@@ -95,6 +95,14 @@ def test_step2_mode0_cli_and_abi(interpreted, tmp_path):
 def test_sketch_and_index_match_oracle(olib, sets):
     GO.test_sketch_matches_oracle(olib, sets, "ava-ont", True)
     GO.test_index_matches_oracle(olib, sets, "ava-pb")
+
+
+@pytest.mark.parametrize("k,w,hpc", [(30, 4, 0), (31, 9, 1), (40, 6, 1), (70, 5, 0), (127, 2, 1), (51, 51, 1)])
+def test_long_kmer_sketch(interpreted, olib, k, w, hpc, monkeypatch):
+    """k > 28 outside the position-parallel kernels' range (and k = 51 sent there by hand): the sequential K1 with the k-mer in up
+    to four words, on the low-complexity reads (palindromic even k-mers included)."""
+    monkeypatch.setenv("NDGPU_OVL_SEQ_SKETCH", "1")
+    GO.test_sketch_adversarial_reads(olib, k, w, hpc)
 
 
 def test_anchors_and_chain_arrays_match_oracle(olib, sets, monkeypatch):
@@ -143,16 +151,16 @@ def test_whole_stage_from_2bit_to_cns_fasta(interpreted, tmp_path):
     assert open(out + ".idx", "rb").read() == GS._golden("cns.default.fasta.idx", gz=True)
 
 
-@pytest.mark.parametrize("tag", ["ont.m2", "hifi.self.m2", "ont.m1"] + (["pb.m2", "ont.I.m2", "deep.m2", "tandem.m1"] if os.environ.get("NDGPU_SLOW_TESTS") else []))
+@pytest.mark.parametrize("tag", ["ont.m2", "hifi.self.m2", "ont.m1", "ont.rechain", "ont.rechain.m2"] + (["pb.m2", "ont.I.m2", "deep.m2", "deep.rechain.m1", "tandem.m1"] if os.environ.get("NDGPU_SLOW_TESTS") else []))
 def test_step2_with_the_realignment(interpreted, tmp_path, tag):
     """`--step 2` as nextDenovo writes it (no --mode: every marked candidate mapped again with the short k-mer sketch -- hits per
     read, wanted-target lists and nameless units through the seed kernels, provisional records out of K5, the bookkeeping on the
     host): the compiled reference's `.ovl` / `.bl` bytes through the command line."""
     import test_zz_gpu_step2 as S2
-    S2.run_case(tag, dict(S2.CASES_M2 + S2.CASES_M1 + S2.CASES_THIN)[tag], tmp_path)
+    S2.run_case(tag, dict(S2.CASES_M2 + S2.CASES_M1 + S2.CASES_RECHAIN + S2.CASES_THIN)[tag], tmp_path)
 
 
-_C_FAST = ("pb.sv.dvt.c",) + (("ont.sv.O4E2.c",) if os.environ.get("NDGPU_SLOW_TESTS") else ())   # (~70 s each under the interpreter; all ten golden runs run on the GPU; O4E2 = one gap piece)
+_C_FAST = ("pb.sv.dvt.c",) + (("ont.sv.O4E2.c", "ont.sxp.dual.f6r300.c") if os.environ.get("NDGPU_SLOW_TESTS") else ())   # (~70 s each under the interpreter; all ten golden runs run on the GPU; O4E2 = one gap piece)
 
 
 @pytest.mark.parametrize("tag", _C_FAST)

@@ -11,7 +11,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
-from make_step2_golden import CASES, CASES_M1, CASES_M2, CASES_THIN, OUT as GOLD, files_of  # noqa: E402
+from make_step2_golden import CASES, CASES_M1, CASES_M2, CASES_RECHAIN, CASES_THIN, OUT as GOLD, files_of  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,7 @@ def run_case(tag, argv, tmp_path):
         assert g.read() == f.read()
 
 
-_ALL = CASES + CASES_M2 + CASES_M1 + CASES_THIN   # (tandem.m1: mappings beyond 100,000 anchors -- the anchor thinning of mm_chain_dp_nextdenovo)
+_ALL = CASES + CASES_M2 + CASES_M1 + CASES_RECHAIN + CASES_THIN   # (tandem.m1: mappings beyond 100,000 anchors -- the anchor thinning of mm_chain_dp_nextdenovo)
 
 
 @pytest.mark.parametrize("tag,argv", _ALL, ids=[c[0] for c in _ALL])

@@ -41,6 +41,9 @@ def dev_opts(preset, dual, extra):
         ao.e, ao.e2 = int(v[0]), int(v[-1])
     if "--cap-sw-mem" in extra:
         ao.max_sw_mat = int(extra[extra.index("--cap-sw-mem") + 1])
+    if "-f" in extra:   # -f INT,INT: the occurrence threshold and the re-chaining one (main.c:337-343)
+        head, _, tail = extra[extra.index("-f") + 1].partition(",")
+        o.mid_occ, o.max_occ = int(float(head) + .499), int(float(tail) + .499) if tail else 0
     return o, ao
 
 
@@ -50,7 +53,7 @@ def run_case(case):
     o, ao = dev_opts(preset, dual, extra)
     T, Q = overlap.ReadSet.from_2bit(G.set_path(t)), overlap.ReadSet.from_2bit(G.set_path(q))
     with overlap.Index(o, T) as ix:
-        recs, st = ix.map_cigar(T, Q, ix.mid_occ(), ao, want_stats=True)
+        recs, st = ix.map_cigar(T, Q, o.mid_occ if o.mid_occ > 0 else ix.mid_occ(), ao, want_stats=True)
     return overlap.encode(recs, np.zeros(2, dtype=np.uint32)), st
 
 
@@ -68,7 +71,7 @@ def test_cigar_bytes_match_reference_golden(case):
         assert st["second_pass"] > 50 and st["splits"] > 50 and st["inversion_tests"] > 50, st
 
 
-@pytest.mark.parametrize("case", [G.CASES_C[0], G.CASES_C[7], G.CASES_C[8]], ids=[G.CASES_C[0][0], G.CASES_C[7][0], G.CASES_C[8][0]])
+@pytest.mark.parametrize("case", [G.CASES_C[0], G.CASES_C[7], G.CASES_C[8], G.CASES_C[10]], ids=[G.CASES_C[i][0] for i in (0, 7, 8, 10)])
 def test_cigar_cli_writes_reference_bytes(case, tmp_path):
     """`python -m nextdenovo_amd.minimap2_nd --step 1 -c ...` with the reference's own command line (-z, -s included)."""
     from nextdenovo_amd import minimap2_nd
@@ -151,7 +154,7 @@ def test_fresh_reads_against_the_reference_binary(tmp_path):
         T = overlap.ReadSet.from_2bit(seed)
         Q = overlap.ReadSet.from_2bit(part) if dual else T
         with overlap.Index(o, T) as ix:
-            recs, st = ix.map_cigar(T, Q, ix.mid_occ(), ao, want_stats=True)
+            recs, st = ix.map_cigar(T, Q, o.mid_occ if o.mid_occ > 0 else ix.mid_occ(), ao, want_stats=True)
         assert overlap.encode(recs, np.zeros(2, dtype=np.uint32)) == want
         assert st["splits"] > 0
 
