@@ -118,12 +118,22 @@ def committed_kernel_stats():
     return rows, os.path.relpath(files[-1], ROOT)
 
 
-def kernel_source_sha16():
-    """What a committed counter measurement is tied to: the consensus kernels' sources."""
+_KERNEL_SOURCES = {   # the files a kernel's code lives in (its counter measurement is tied to them)
+    "ond_forward_kernel": ("ond_kernels.hip", "nd_device.h"), "ond_traceback_kernel": ("ond_kernels.hip", "nd_device.h"),
+    "count_links_kernel": ("msa_kernels.hip", "nd_device.h"), "score_seg_kernel": ("msa_kernels.hip", "nd_device.h"),
+}
+
+
+def kernel_source_sha16(kernel=None, read=None):
+    """What a committed counter measurement of `kernel` is tied to: the sources its code lives in (every consensus kernel source for a
+    kernel that is not listed).  `read`: file name -> bytes (tools/make_pmc_json.py hashes the tree a pass was measured on)."""
     h = hashlib.sha256()
-    for f in ("ond_kernels.hip", "lq_kernels.hip", "msa_kernels.hip", "nd_device.h"):
-        with open(os.path.join(ROOT, "nextdenovo_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    for f in _KERNEL_SOURCES.get(kernel, ("ond_kernels.hip", "lq_kernels.hip", "msa_kernels.hip", "nd_device.h")):
+        if read:
+            h.update(read(f))
+        else:
+            with open(os.path.join(ROOT, "nextdenovo_amd", "csrc", f), "rb") as fh:
+                h.update(fh.read())
     return h.hexdigest()[:16]
 
 
@@ -135,9 +145,9 @@ def committed_traffic(kernel, launches_per_step, config):
             pm = json.load(f)
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
-    if pm.get("kernel_source_sha16") != kernel_source_sha16():
-        return None, "profiles/pmc_traffic.json was measured on other kernel sources (%s): not reported" % pm.get("kernel_source_sha16")
     k = pm.get("kernels", {}).get(kernel)
+    if k and k.get("source_sha16") != kernel_source_sha16(kernel):
+        return None, "profiles/pmc_traffic.json: %s was measured on other sources (%s): not reported" % (kernel, k.get("source_sha16"))
     if not k or pm.get("config") != config or abs(k["launches_per_step"] - launches_per_step) > 0.5:
         return None, "profiles/pmc_traffic.json holds no matching entry for this kernel / workload"
     # MI355X_MICROARCH.md (HBM / rocprofv3): KB units; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes for wide reads -> x2

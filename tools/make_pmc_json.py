@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/pmc_traffic.json from a tools/rocprof_pmc_summary.py table: per modelled kernel the FETCH_SIZE / WRITE_SIZE KB per
-launch, tied to the kernel sources they were measured on (bench.py refuses the figure once the sources change).
+launch, each tied to the sources its kernel lives in when the passes ran (bench.py refuses a figure once those sources change).
 usage: make_pmc_json.py <pmc_summary.txt> <bench steps the passes ran, warm-up included> <config> [source note]"""
 import json
 import os
@@ -23,9 +23,10 @@ def main():
             continue
         for k in keys:
             if mt.group(1).startswith(k):
-                kernels[k.split("<")[0]] = {"launches_per_step": int(mt.group(2)) / steps, "fetch_kb_per_launch": float(mt.group(3)),
-                                            "write_kb_per_launch": float(mt.group(4))}
-    out = {"config": config, "kernel_source_sha16": bench.kernel_source_sha16(), "source": note, "kernels": kernels}
+                name = k.split("<")[0]
+                kernels[name] = {"launches_per_step": int(mt.group(2)) / steps, "fetch_kb_per_launch": float(mt.group(3)),
+                                 "write_kb_per_launch": float(mt.group(4)), "source_sha16": bench.kernel_source_sha16(name)}
+    out = {"config": config, "source": note, "kernels": kernels}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
