@@ -109,6 +109,16 @@ int64_t ndgpu_fastx_read(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *o
 int64_t ndgpu_fastx_read_named(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *off, uint32_t *len, uint32_t *ids, int64_t max_recs);
 uint64_t ndgpu_fastx_pending(const ndgpu_fastx *h);
 void ndgpu_fastx_close(ndgpu_fastx *h);
+/* The byte stream under ndgpu_fastx, by itself: gzread() (zlib.h; what KSEQ_INIT(gzFile, gzread) reads through, lib/bseq.h:3) with the
+ * gzip file inflated by `threads` host threads (0 = NDGPU_INFLATE_THREADS, or the CPUs the process may use, at most 16) -- the same
+ * bytes: members concatenated, trailing garbage ignored, a truncated file hands out what it holds, -1 for corrupt data.  With 1
+ * thread, or for what is not a regular file starting with a gzip member, the reader IS zlib's.  ndgpu_gzin_stats: 1 and
+ * {rounds, chunks decoded, chunks accepted} when the threaded reader is in use, else 0. */
+typedef struct ndgpu_gzin ndgpu_gzin;
+ndgpu_gzin *ndgpu_gzin_open(const char *path, int threads);
+int64_t ndgpu_gzin_read(ndgpu_gzin *h, void *buf, uint32_t len);
+int ndgpu_gzin_stats(const ndgpu_gzin *h, uint64_t out[3]);
+void ndgpu_gzin_close(ndgpu_gzin *h);
 
 void ndgpu_ovl_free(void *p);
 /* Why an entry point of this library failed: 1 = out of device memory (release memory, e.g. ndgpu_ovl_trim() and the consensus

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libndgpu_nextcorrect.so")
 SOURCES = ["ond_kernels.hip", "msa_kernels.hip", "lq_kernels.hip", "ext_kernels.hip", "device_runtime.hip", "consensus.cpp", "poa.cpp", "readdb.cpp", "capi.cpp"]
 HEADERS = ["nd_device.h", "nd_host.h", "nd_runtime.h", os.path.join("..", "..", "include", "ndgpu_nextcorrect.h")]
 OVL_LIB = os.path.join(HERE, "libndgpu_overlap.so")
-OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip", "ovlsort_kernels.hip", "ovlsort_engine.hip", "fastx_reader.cpp", "ovl_step2.cpp", "ovl_cigar.cpp", "ksw2_kernels.hip"]
+OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip", "ovlsort_kernels.hip", "ovlsort_engine.hip", "fastx_reader.cpp", "pinflate.cpp", "ovl_step2.cpp", "ovl_cigar.cpp", "ksw2_kernels.hip"]
 OVL_HEADERS = ["ovl_device.h", os.path.join("..", "..", "include", "ndgpu_overlap.h")]
 
 

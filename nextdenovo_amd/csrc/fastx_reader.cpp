@@ -7,20 +7,68 @@
 //   * after '+': the rest of that line is skipped, quality lines are read until they cover the sequence; a quality string of another
 //     length ends the file (kseq_read returns -2 and seq_dump's loop stops); after a FASTQ record the next header is searched for.
 // The reader streams: the file is inflated through a 1 MB window, records are handed out in chunks the caller sizes, so a
-// multi-GB .fastq.gz never sits in memory (the Python parser this replaces read the whole file).
+// multi-GB .fastq.gz never sits in memory (the Python parser this replaces read the whole file).  A gzip file is inflated by
+// several threads (pinflate.cpp: NDGPU_INFLATE_THREADS, default = the CPUs the process may use, at most 16; 1 = zlib's gzread,
+// which also reads what is not a regular gzip file).
+#include <sched.h>
 #include <zlib.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <string>
 
 #include "../../include/ndgpu_overlap.h"
+#include "pinflate.h"
 
 namespace {
 
-struct Stream {
+// the CPUs this process may run on at once: its affinity mask and, in a container, the cgroup's quota (cpu.max / cfs_quota_us)
+int usable_cpus() {
+    int n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32];
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 100000;
+            fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) n = (int)std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+    return n < 1 ? 1 : n;
+}
+
+// gzread over one of two readers
+struct GzIn {
     gzFile f = nullptr;
+    ndovl::PInflate *par = nullptr;
+    bool open(const char *path, int threads) {
+        par = ndovl::pinflate_open(path, threads);
+        if (par) return true;
+        f = gzopen(path, "r");
+        if (!f) return false;
+        (void)gzbuffer(f, 1 << 20);
+        return true;
+    }
+    int read(void *buf, unsigned len) { return par ? (int)ndovl::pinflate_read(par, buf, len) : gzread(f, buf, len); }
+    void close() {
+        if (par) ndovl::pinflate_close(par);
+        if (f) gzclose(f);
+        par = nullptr, f = nullptr;
+    }
+};
+
+struct Stream {
+    GzIn f;
     unsigned char buf[1 << 20];
     int begin = 0, end = 0;
     bool eof = false, err = false;
@@ -30,7 +78,7 @@ struct Stream {
         if (begin >= end) {
             if (eof) return -1;
             begin = 0;
-            end = gzread(f, buf, sizeof(buf));
+            end = f.read(buf, sizeof(buf));
             if (end == 0) { eof = true; return -1; }
             if (end < 0) { eof = true; err = true; end = 0; return -3; }
         }
@@ -44,7 +92,7 @@ struct Stream {
             if (begin >= end) {
                 if (eof) break;
                 begin = 0;
-                end = gzread(f, buf, sizeof(buf));
+                end = f.read(buf, sizeof(buf));
                 if (end == 0) { eof = true; break; }
                 if (end < 0) { eof = true; err = true; end = 0; return -3; }
             }
@@ -69,7 +117,7 @@ struct Stream {
             if (begin >= end) {
                 if (eof) break;
                 begin = 0;
-                end = gzread(f, buf, sizeof(buf));
+                end = f.read(buf, sizeof(buf));
                 if (end == 0) { eof = true; break; }
                 if (end < 0) { eof = true; err = true; end = 0; return -3; }
             }
@@ -132,13 +180,45 @@ struct ndgpu_fastx {
 
 extern "C" {
 
+static int inflate_threads() {
+    if (const char *e = getenv("NDGPU_INFLATE_THREADS")) return std::max(1, atoi(e));
+    return std::min(16, usable_cpus());
+}
+
 ndgpu_fastx *ndgpu_fastx_open(const char *path) {
-    gzFile f = gzopen(path, "r");
-    if (!f) return nullptr;
-    (void)gzbuffer(f, 1 << 20);
     ndgpu_fastx *h = new ndgpu_fastx;
-    h->st.f = f;
+    if (!h->st.f.open(path, inflate_threads())) {
+        delete h;
+        return nullptr;
+    }
     return h;
+}
+
+/* gzread by several threads, by itself (what ndgpu_fastx_open reads through) */
+struct ndgpu_gzin { GzIn in; };
+
+ndgpu_gzin *ndgpu_gzin_open(const char *path, int threads) {
+    ndgpu_gzin *h = new ndgpu_gzin;
+    if (!h->in.open(path, threads > 0 ? threads : inflate_threads())) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+int64_t ndgpu_gzin_read(ndgpu_gzin *h, void *buf, uint32_t len) { return h->in.read(buf, len); }
+
+int ndgpu_gzin_stats(const ndgpu_gzin *h, uint64_t out[3]) {
+    out[0] = out[1] = out[2] = 0;
+    if (!h->in.par) return 0;
+    ndovl::pinflate_stats(h->in.par, out);
+    return 1;
+}
+
+void ndgpu_gzin_close(ndgpu_gzin *h) {
+    if (!h) return;
+    h->in.close();
+    delete h;
 }
 
 int64_t ndgpu_fastx_read(ndgpu_fastx *h, uint8_t *buf, uint64_t cap, uint64_t *off, uint32_t *len, int64_t max_recs) {
@@ -179,7 +259,7 @@ uint64_t ndgpu_fastx_pending(const ndgpu_fastx *h) { return h->have ? (uint64_t)
 
 void ndgpu_fastx_close(ndgpu_fastx *h) {
     if (!h) return;
-    if (h->st.f) gzclose(h->st.f);
+    h->st.f.close();
     delete h;
 }
 

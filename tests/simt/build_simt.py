@@ -16,7 +16,7 @@ LIB = os.path.join(OUT_DIR, "libnextcorrect_simt.so")
 OVL_LIB = os.path.join(OUT_DIR, "liboverlap_simt.so")
 SOURCES = ["ond_kernels.hip", "msa_kernels.hip", "lq_kernels.hip", "ext_kernels.hip", "device_runtime.hip", "consensus.cpp", "poa.cpp", "readdb.cpp",
            "capi.cpp"]
-OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip", "ovlsort_kernels.hip", "ovlsort_engine.hip", "fastx_reader.cpp", "ovl_step2.cpp", "ovl_cigar.cpp", "ksw2_kernels.hip"]
+OVL_SOURCES = ["ovl_kernels.hip", "ovl_engine.hip", "ovlsort_kernels.hip", "ovlsort_engine.hip", "fastx_reader.cpp", "pinflate.cpp", "ovl_step2.cpp", "ovl_cigar.cpp", "ksw2_kernels.hip"]
 
 
 def _stale(lib) -> bool:
