@@ -1,5 +1,6 @@
 // ovlsort_engine.hip -- host orchestration + C ABI of the overlap sort / filter stage (util/ovl_sort.c path).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,8 +84,32 @@ struct SortRun {
 
 using namespace ndovl;
 
+// the records of a call, in the malloc'd block the caller gets (grown by realloc when a call sorts in seed ranges): the download
+// goes straight into it -- through a std::vector the records were zero-filled, downloaded and copied once more, 5 ms per 18 MB
+struct RecOut {
+	OvlRec *p = nullptr;
+	size_t n = 0, cap = 0;
+	~RecOut() { free(p); }
+	RecOut() = default;
+	RecOut(const RecOut &) = delete;
+	RecOut &operator=(const RecOut &) = delete;
+	size_t size() const { return n; }
+	OvlRec *grow(size_t more) {   // room for `more` records at the end; returns where they go
+		if (n + more + 1 > cap) {
+			const size_t want = std::max(n + more + 1, cap + cap / 2);
+			OvlRec *q = (OvlRec*)realloc(p, want * sizeof(OvlRec));
+			if (!q) throw std::runtime_error("malloc");
+			p = q, cap = want;
+		}
+		OvlRec *at = p + n;
+		n += more;
+		return at;
+	}
+	OvlRec *release() { OvlRec *q = p ? p : (OvlRec*)malloc(sizeof(OvlRec)); p = nullptr, n = cap = 0; return q; }
+};
+
 struct SortOut {
-	std::vector<OvlRec> recs;
+	RecOut recs;
 	std::vector<uint32_t> bl_id;
 	std::vector<uint8_t> bl_kind;
 	uint64_t seeds = 0;
@@ -135,9 +160,8 @@ static void sort_and_filter(SortRun &R, const OvlRec *cand_p, const uint32_t *k_
 	launch_compact_seed_recs(sstart.p, (uint32_t)n_seeds, outrec.p, n_out.p, off.p, dense.p, R.st);
 	std::vector<uint32_t> h_id(n_seeds);
 	std::vector<uint8_t> h_kind(n_seeds);
-	const size_t at = o.recs.size();
-	o.recs.resize(at + total);
-	if (total) HIP_OK(hipMemcpyAsync(o.recs.data() + at, dense.p, total * sizeof(OvlRec), hipMemcpyDeviceToHost, R.st));
+	OvlRec *const dst = o.recs.grow(total);
+	if (total) HIP_OK(hipMemcpyAsync(dst, dense.p, total * sizeof(OvlRec), hipMemcpyDeviceToHost, R.st));
 	HIP_OK(hipMemcpyAsync(h_id.data(), d_bl_id.p, n_seeds * 4, hipMemcpyDeviceToHost, R.st));
 	HIP_OK(hipMemcpyAsync(h_kind.data(), d_bl_kind.p, n_seeds, hipMemcpyDeviceToHost, R.st));
 	HIP_OK(hipStreamSynchronize(R.st));
@@ -147,13 +171,14 @@ static void sort_and_filter(SortRun &R, const OvlRec *cand_p, const uint32_t *k_
 	o.seeds += n_seeds;
 }
 
-static void hand_out(const SortOut &so, ndgpu_ovl_rec **out, uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl)
+static void hand_out(SortOut &so, ndgpu_ovl_rec **out, uint32_t **bl_id, uint8_t **bl_kind, int64_t *n_bl)
 {
-	*out = (ndgpu_ovl_rec*)malloc(sizeof(ndgpu_ovl_rec) * (so.recs.size() + 1));
+	static_assert(sizeof(OvlRec) == sizeof(ndgpu_ovl_rec), "record layout");
 	*bl_id = (uint32_t*)malloc(4 * (so.bl_id.size() + 1));
 	*bl_kind = (uint8_t*)malloc(so.bl_kind.size() + 1);
-	if (!*out || !*bl_id || !*bl_kind) throw std::runtime_error("malloc");
-	if (!so.recs.empty()) memcpy(*out, so.recs.data(), so.recs.size() * sizeof(OvlRec));
+	if (!*bl_id || !*bl_kind) throw std::runtime_error("malloc");
+	*out = (ndgpu_ovl_rec*)so.recs.release();
+	if (!*out) throw std::runtime_error("malloc");
 	if (!so.bl_id.empty()) memcpy(*bl_id, so.bl_id.data(), so.bl_id.size() * 4), memcpy(*bl_kind, so.bl_kind.data(), so.bl_kind.size());
 	*n_bl = (int64_t)so.bl_id.size();
 }
@@ -248,6 +273,9 @@ static int64_t sort_impl(const ndgpu_ovl_rec *const *files, const int64_t *n_per
 {
 	*out = nullptr, *bl_id = nullptr, *bl_kind = nullptr, *n_bl = 0;
 	if (stats) memset(stats, 0, sizeof(*stats));
+	const bool prof = getenv("NDGPU_PROF") != nullptr;
+	const auto tp0 = std::chrono::steady_clock::now();
+	auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); };
 	try {
 		int n_dev = 0;
 		if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -263,6 +291,7 @@ static int64_t sort_impl(const ndgpu_ovl_rec *const *files, const int64_t *n_per
 		hipEvent_t ev0, ev1;
 		HIP_OK(hipEventCreate(&ev0)); HIP_OK(hipEventCreate(&ev1));
 		HIP_OK(hipEventRecord(ev0, R.st));
+		const double t_setup = since();
 
 		uint64_t n = 0;
 		std::vector<uint64_t> h_fstart((size_t)n_files + 1);
@@ -286,15 +315,16 @@ static int64_t sort_impl(const ndgpu_ovl_rec *const *files, const int64_t *n_per
 			                 &nc_total, &n_ranges);
 			HIP_OK(hipEventRecord(ev1, R.st));
 			HIP_OK(hipStreamSynchronize(R.st));
+			const uint64_t kept = so.recs.size();
 			hand_out(so, out, bl_id, bl_kind, n_bl);
 			if (stats) {
 				float ms = 0;
 				(void)hipEventElapsedTime(&ms, ev0, ev1);
-				stats->gpu_ms = ms, stats->raw_records = n, stats->candidates = nc_total, stats->seeds = so.seeds, stats->kept = so.recs.size();
+				stats->gpu_ms = ms, stats->raw_records = n, stats->candidates = nc_total, stats->seeds = so.seeds, stats->kept = kept;
 				stats->ranges = n_ranges;
 			}
 			(void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-			return (int64_t)so.recs.size();
+			return (int64_t)kept;
 		}
 		std::vector<uint32_t> h_file_of(n);
 		Buf<OvlRec> raw(n);
@@ -334,7 +364,10 @@ static int64_t sort_impl(const ndgpu_ovl_rec *const *files, const int64_t *n_per
 		HIP_OK(hipEventRecord(ev1, R.st));
 		HIP_OK(hipStreamSynchronize(R.st));
 		const uint64_t total = so.recs.size(), n_seeds = so.seeds;
+		const double t_dev = since();
 		hand_out(so, out, bl_id, bl_kind, n_bl);
+		if (prof) fprintf(stderr, "[ndgpu_ovl_sort] %llu records: set-up %.2f ms, uploads + kernels + downloads %.2f ms, hand-out %.2f ms\n",
+		                  (unsigned long long)n, t_setup, t_dev - t_setup, since() - t_dev);
 		if (stats) {
 			float ms = 0;
 			(void)hipEventElapsedTime(&ms, ev0, ev1);
