@@ -742,6 +742,7 @@ int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, cons
 	const Regs *const regs_all = regs;
 	const bool want10 = out10 != nullptr;
 	std::mutex dbg_mu;
+	const size_t n_lanes = std::min<size_t>((size_t)lanes, ranges.size());
 	auto run_batch = [&](size_t bi, hipStream_t stream, DevBuf<uint8_t> &lane_tmp) {
 		// (everything the batch touches by these names is its own: its stream, its scratch, its counters, its output)
 		BatchOut &BO = outs[bi];
@@ -992,7 +993,6 @@ int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, cons
 			dbg_ax = std::move(ax); dbg_ay = std::move(ay); dbg_f = std::move(f); dbg_p = std::move(p);
 		}
 	};
-	const size_t n_lanes = std::min<size_t>((size_t)lanes, ranges.size());
 	if (n_lanes <= 1) {
 		for (size_t bi = 0; bi < ranges.size(); ++bi) run_batch(bi, stream, tmp);
 	} else {
@@ -1027,8 +1027,12 @@ int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, cons
 	}
 	// the batches' outputs, in read order
 	for (BatchOut &BO : outs) {
-		out.insert(out.end(), BO.recs.begin(), BO.recs.end());
-		if (out10) out10->insert(out10->end(), BO.recs10.begin(), BO.recs10.end());
+		if (out.empty()) out = std::move(BO.recs);   // (the usual call is one batch: its vector is the result)
+		else out.insert(out.end(), BO.recs.begin(), BO.recs.end());
+		if (out10) {
+			if (out10->empty()) *out10 = std::move(BO.recs10);
+			else out10->insert(out10->end(), BO.recs10.begin(), BO.recs10.end());
+		}
 		if (chains_per_read) chains_per_read->insert(chains_per_read->end(), BO.chains.begin(), BO.chains.end());
 		if (regs) {
 			regs->counts->insert(regs->counts->end(), BO.counts.begin(), BO.counts.end());
