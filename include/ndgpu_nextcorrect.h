@@ -130,6 +130,16 @@ int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, uns
                         unsigned int min_cov, float min_error_corrected_ratio, unsigned int split, unsigned int fast,
                         int read_type, int host_threads, consensus_trimed **out);
 
+/* The output loop of lib/nextcorrect.py:236-260 (without -s) over finished records: for every ids[k] in order, a record with
+ * len >= min_len_seed, len > 4 and identity >= min_ratio is written to fd_out as ">NAME LEN IDENTITY\nBASES\n" (IDENTITY as Python's
+ * '%f') and, if fd_idx >= 0, "NAME\tOFFSET\tLEN\n" to fd_idx (OFFSET = where the bases start in the output file); any other record
+ * but an out-of-memory seed (len 3) gets "NAME\t0\t0\n" in the index.  names[i] = the number the reference prints for pile i;
+ * *pos = the output file's size before the call, updated.  lens / identities (may be NULL) receive every handed-over record's
+ * values at [ids[k]]; the records are freed (free_consensus_trimed) and their slots set to NULL.  What a caller's completion
+ * callback (ndgpu_piles_done_fn) does with its sub-batch.  Returns 0, or -1 when a write fails. */
+int ndgpu_write_records(consensus_trimed **recs, const uint32_t *ids, int n, const uint32_t *names, uint32_t min_len_seed,
+                        double min_ratio, int fd_out, int fd_idx, uint64_t *pos, uint32_t *lens, float *identities);
+
 /* Resident read database: the additive replacement for ovlseq.so's init_ovls + getseq
  * (reference lib/ovlseq.c:39-138, lib/nextcorrect.py:62-69,193).  `words` is the .2bit
  * payload layout of lib/bseq.c:114-139 (16 bases per uint32, first base in the top two

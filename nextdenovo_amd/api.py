@@ -74,6 +74,9 @@ def _bind(lib):
     lib.ndgpu_correct_piles.restype = C.c_int
     lib.ndgpu_correct_piles_stream.argtypes = lib.ndgpu_correct_piles.argtypes + [PILES_DONE_FN, C.c_void_p]
     lib.ndgpu_correct_piles_stream.restype = C.c_int
+    lib.ndgpu_write_records.argtypes = [C.POINTER(C.POINTER(ConsensusTrimed)), C.POINTER(C.c_uint32), C.c_int, C.c_void_p, C.c_uint32, C.c_double,
+                                        C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]
+    lib.ndgpu_write_records.restype = C.c_int
     lib.ndgpu_get_stats.argtypes = [C.POINTER(Stats)]
     lib.ndgpu_reset_stats.argtypes = []
     lib.ndgpu_device_count.restype = C.c_int
@@ -175,14 +178,35 @@ class ReadDB:
             OUT, IDX, names, min_len_seed, min_ratio = fasta
             res = [None] * n
             state = {"pos": OUT.tell(), "err": None, "t": 0.0}
+            # real files: the library formats and writes a sub-batch's records itself (ndgpu_write_records: one writev per 340
+            # records, the bases straight from where it holds them); anything else that has a write(): the loop below, record by record
+            try:
+                fd_out, fd_idx = OUT.fileno(), (IDX.fileno() if IDX is not None else -1)
+                OUT.flush()
+                if IDX is not None:
+                    IDX.flush()
+            except (AttributeError, OSError, ValueError):
+                fd_out = None
+            if fd_out is not None:
+                names32 = np.ascontiguousarray(names, dtype=np.uint32)
+                lens, ides = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.float32)
+                pos = C.c_uint64(state["pos"])
+                wr = self._lib.ndgpu_write_records
 
-            def done(_user, ids, cnt):
-                tw = time.perf_counter()
-                try:
-                    self._write_records(out, [ids[k] for k in range(cnt)], res, state, OUT, IDX, names, min_len_seed, min_ratio)
-                except BaseException as e:  # noqa: BLE001  (an exception must not unwind through the C caller)
-                    state["err"] = e
-                state["t"] += time.perf_counter() - tw
+                def done(_user, ids, cnt):
+                    tw = time.perf_counter()
+                    if wr(out, ids, cnt, names32.ctypes.data, int(min_len_seed), float(min_ratio), fd_out, fd_idx, C.byref(pos),
+                          lens.ctypes.data, ides.ctypes.data) != 0:
+                        state["err"] = OSError("writing the corrected records failed")
+                    state["t"] += time.perf_counter() - tw
+            else:
+                def done(_user, ids, cnt):
+                    tw = time.perf_counter()
+                    try:
+                        self._write_records(out, [ids[k] for k in range(cnt)], res, state, OUT, IDX, names, min_len_seed, min_ratio)
+                    except BaseException as e:  # noqa: BLE001  (an exception must not unwind through the C caller)
+                        state["err"] = e
+                    state["t"] += time.perf_counter() - tw
 
             cb = PILES_DONE_FN(done)
             rc = self._lib.ndgpu_correct_piles_stream(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
@@ -204,6 +228,11 @@ class ReadDB:
         if rc != 0:
             raise RuntimeError("ndgpu_correct_piles failed (%d)" % rc)
         if fasta is not None:
+            if fd_out is not None:
+                OUT.seek(0, 2)   # (the descriptor moved under the file objects)
+                if IDX is not None:
+                    IDX.seek(0, 2)
+                res = list(zip(lens.tolist(), ides.tolist()))
             return res
         if lengths_only:
             res = []

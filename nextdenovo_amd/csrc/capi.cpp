@@ -1,5 +1,7 @@
 // C ABI of the engine (include/ndgpu_nextcorrect.h).
 #include <hip/hip_runtime_api.h>
+#include <sys/uio.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -137,6 +139,70 @@ void free_consensus_trimed(consensus_trimed *c) {
     if (!c) return;
     free(c->seq);
     free(c);
+}
+
+// lib/nextcorrect.py:236-260 over the records of one hand-over: headers and index lines are formatted into two small buffers, the
+// bases go to the file from where the library holds them (writev: no copy of the 70 MB a config-2 step prints)
+int ndgpu_write_records(consensus_trimed **recs, const uint32_t *ids, int n, const uint32_t *names, uint32_t min_len_seed,
+                        double min_ratio, int fd_out, int fd_idx, uint64_t *pos, uint32_t *lens, float *identities) {
+    std::vector<char> heads;
+    std::string idx;
+    struct Piece { size_t head_at, head_len; const char *seq; size_t len; };
+    std::vector<Piece> pieces;
+    heads.reserve((size_t)n * 40);
+    uint64_t at = *pos;
+    char line[96];
+    for (int k = 0; k < n; k++) {
+        const uint32_t i = ids[k];
+        consensus_trimed *c = recs[i];
+        if (!c) continue;
+        const uint32_t ln = c->len;
+        const float ide = c->identity;
+        if (lens) lens[i] = ln;
+        if (identities) identities[i] = ide;
+        if (ln >= min_len_seed && ln > 4 && (double)ide >= min_ratio) {
+            const int hl = snprintf(line, sizeof(line), ">%u %u %f\n", names[i], ln, (double)ide);
+            pieces.push_back(Piece{heads.size(), (size_t)hl, c->seq, (size_t)ln});
+            heads.insert(heads.end(), line, line + hl);
+            at += (uint64_t)hl + ln + 1;
+            if (fd_idx >= 0) {
+                const int il = snprintf(line, sizeof(line), "%u\t%llu\t%u\n", names[i], (unsigned long long)(at - ln - 1), ln);
+                idx.append(line, (size_t)il);
+            }
+        } else if (ln != 3 && fd_idx >= 0) {
+            const int il = snprintf(line, sizeof(line), "%u\t0\t0\n", names[i]);
+            idx.append(line, (size_t)il);
+        }
+    }
+    auto write_all = [](int fd, struct iovec *iov, int cnt) {
+        while (cnt > 0) {
+            ssize_t w = writev(fd, iov, cnt > 1024 ? 1024 : cnt);
+            if (w < 0) return false;
+            while (cnt > 0 && (size_t)w >= iov->iov_len) w -= (ssize_t)iov->iov_len, ++iov, --cnt;
+            if (cnt > 0 && w > 0) iov->iov_base = (char *)iov->iov_base + w, iov->iov_len -= (size_t)w;
+        }
+        return true;
+    };
+    bool ok = true;
+    static const char nl = '\n';
+    std::vector<struct iovec> iov;
+    iov.reserve(pieces.size() * 3);
+    for (const Piece &p : pieces) {
+        iov.push_back({heads.data() + p.head_at, p.head_len});
+        iov.push_back({(void *)p.seq, p.len});
+        iov.push_back({(void *)&nl, 1});
+    }
+    if (!iov.empty()) ok = write_all(fd_out, iov.data(), (int)iov.size());
+    if (ok && fd_idx >= 0 && !idx.empty()) {
+        struct iovec one{(void *)idx.data(), idx.size()};
+        ok = write_all(fd_idx, &one, 1);
+    }
+    for (int k = 0; k < n; k++) {   // (after the write: the bases were the library's until here)
+        free_consensus_trimed(recs[ids[k]]);
+        recs[ids[k]] = nullptr;
+    }
+    if (ok) *pos = at;
+    return ok ? 0 : -1;
 }
 
 int ndgpu_correct_batch(int n_piles, char ***seqs, unsigned int **aln_start, unsigned int **aln_end,

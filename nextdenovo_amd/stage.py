@@ -316,10 +316,13 @@ class Shard:
             _live, cached, peak = overlap.pool_bytes()
             # (the margin scales with the device: 32 GB on a 288 GB MI355X, an eighth of the memory on a smaller part -- a fixed 32 GB
             # left the consensus stage its 4 GB floor on anything below ~50 GB)
-            try:
-                import torch
-                total = torch.cuda.mem_get_info()[1] if torch.cuda.is_available() else 288 << 30
-            except Exception:
-                total = 288 << 30
+            total = getattr(self, "_device_total", 0)
+            if not total:   # (asked once: the query goes through the runtime's device enumeration, 3 ms of every step)
+                try:
+                    import torch
+                    total = torch.cuda.mem_get_info()[1] if torch.cuda.is_available() else 288 << 30
+                except Exception:
+                    total = 288 << 30
+                self._device_total = total
             api.reserve_device_memory(max(0, peak - cached) + max(min(32 << 30, total // 8), peak // 4))
         return sub, off, seeds, len(bl)

@@ -302,12 +302,26 @@ def test_records_are_handed_over_as_their_sub_batches_finish(simt_api, tmp_path,
     plain = db.correct_piles(recs, poff, read_type=1, max_lq_length=10000, host_threads=4)
     fa = tmp_path / "cns.fasta"
     with open(fa, "wb") as OUT, open(str(fa) + ".idx", "wb") as IDX:
+        OUT.write(b">0 5 1.000000\nACGTA\n")      # (the files may hold records already: offsets count from the file's start)
         res = db.correct_piles(recs, poff, read_type=1, max_lq_length=10000, host_threads=4, fasta=(OUT, IDX, names, 500, 0.8))
+        assert OUT.tell() == os.path.getsize(fa) and IDX.tell() == os.path.getsize(str(fa) + ".idx")
+    # the same through objects that are not files (the record-by-record loop instead of ndgpu_write_records): the same records
+    import io
+    mem_out, mem_idx = io.BytesIO(), io.BytesIO()
+    mem_out.write(b">0 5 1.000000\nACGTA\n")
+    res2 = db.correct_piles(recs, poff, read_type=1, max_lq_length=10000, host_threads=4, fasta=(mem_out, mem_idx, names, 500, 0.8))
     db.close()
+    assert res2 == res
+
+    def records(b):
+        return sorted(b.split(b">")[1:])
+    assert records(mem_out.getvalue()) == records(open(fa, "rb").read())
+    assert sorted(ln.split()[0::2] for ln in mem_idx.getvalue().splitlines()) == sorted(ln.split()[0::2] for ln in open(str(fa) + ".idx", "rb").read().splitlines())
     assert [(ln, np.float32(ide)) for ln, ide in res] == [(ln, np.float32(ide)) for ln, ide, _ in plain]
     blob = open(fa, "rb").read()
     got = {}
-    at = 0
+    at = len(b">0 5 1.000000\nACGTA\n")
+    assert blob[:at] == b">0 5 1.000000\nACGTA\n"
     while at < len(blob):
         e1 = blob.index(b"\n", at)
         e2 = blob.index(b"\n", e1 + 1)
