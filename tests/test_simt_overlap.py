@@ -105,6 +105,16 @@ def test_long_kmer_sketch(interpreted, olib, k, w, hpc, monkeypatch):
     GO.test_sketch_adversarial_reads(olib, k, w, hpc)
 
 
+def test_options_drawn_at_random_match_oracle():
+    """tools/fuzz_overlap_options.py: preset, k, w, -n, -m, -f INT[,INT], --dual, --mode 3 and the batch size drawn at random on small
+    read sets with repeats and tandem arrays; the device library's `.ovl` bytes against the oracle's.  (A process of its own: the tool
+    binds nextdenovo_amd.overlap to the interpreted library for good.)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fuzz_overlap_options.py"), "5", "5"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "5 cases, 0 bad" in r.stdout
+
+
 def test_anchors_and_chain_arrays_match_oracle(olib, sets, monkeypatch):
     GO.test_anchors_and_chain_arrays_match_oracle(olib, sets, "ava-ont", True, ("seed", "part"), monkeypatch)
 
