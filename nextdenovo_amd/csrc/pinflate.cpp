@@ -38,6 +38,7 @@ namespace {
 
 constexpr int kWin = 32768;
 constexpr int kLitBits = 10, kDistBits = 9;
+constexpr uint64_t kMaxScanBytes = 512u << 10;
 constexpr uint64_t kMaxChunkOut = 512ull << 20;   // a chunk that inflates beyond this stops at its next block (the round ends there)
 
 struct BitIn {
@@ -349,6 +350,7 @@ struct PInflate {
     uint64_t run_len = 0;
     bool done = false, failed = false;
     int lone_rounds = 0;        // consecutive rounds in which no guessed chunk was accepted
+    unsigned lone_waited = 0;   // rounds since
     std::vector<uint8_t> out;   // the bytes of the round being decoded (the producer's)
     std::atomic<uint64_t> stat_rounds{0}, stat_chunks{0}, stat_accepted{0};
     // The rounds run ahead of the reader on a thread of their own (two finished rounds may wait): the parser that calls
@@ -389,7 +391,9 @@ bool PInflate::round() {
     if (done || failed) return false;
     ++stat_rounds;
     const uint64_t byte0 = bit >> 3;
-    int n_chunks = lone_rounds >= 2 ? 1 : threads;
+    // two rounds in a row in which no guessed chunk fitted: one chunk per round from here on, with another try every 32 rounds
+    // (a stretch of stored blocks inside a file that is compressible again after it)
+    int n_chunks = (lone_rounds >= 2 && (++lone_waited & 31)) ? 1 : threads;
     n_chunks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_chunks, (size - byte0 + chunk - 1) / chunk));
     if ((int)guess.size() < n_chunks - 1) guess.resize((size_t)n_chunks - 1);
     std::vector<uint8_t> tried((size_t)n_chunks, 0);
@@ -407,7 +411,9 @@ bool PInflate::round() {
         for (int i = 0; i < kWin; ++i) G.out[(size_t)i] = (uint16_t)(256 + i);
         G.stop = kStopError;
         uint64_t from = bound(j);
-        const uint64_t to = std::min<uint64_t>(bound(j + 1), size * 8);
+        // (a compressor starts a block every few tens of kilobytes; a chunk without a dynamic block in its first 512 KB -- stored
+        // or fixed-code data -- is not searched to its end: that would cost seconds for nothing)
+        const uint64_t to = std::min<uint64_t>(std::min<uint64_t>(bound(j + 1), from + 8 * kMaxScanBytes), size * 8);
         for (int attempt = 0; attempt < 8; ++attempt) {
             uint64_t s;
             if (!find_block_start(data, size, from, to, s)) return;
@@ -436,7 +442,7 @@ bool PInflate::round() {
         ++accepted, end_bit = G.end_bit, end_inm = G.end_in_member, last_stop = G.stop;
     }
     stat_accepted += (uint64_t)accepted;
-    lone_rounds = (n_chunks > 1 && accepted == 1) ? lone_rounds + 1 : 0;
+    if (n_chunks > 1) lone_rounds = accepted == 1 ? lone_rounds + 1 : 0;   // (a round of one chunk says nothing about the guesses)
     // sizes, windows, bytes
     std::vector<uint64_t> off((size_t)accepted + 1, 0);
     off[1] = first.n;
