@@ -30,17 +30,23 @@ from .correct_stage import _IndexCache, job_matrix
 
 class DeviceBackend:
     """The product path: indexes and maps on the device (libndgpu_overlap.so), sorts with ndgpu_ovl_sort."""
+    concurrent = True   # map calls against different indexes may run side by side (an index has its own stream)
 
     def __init__(self, opt):
-        self.opt, self.caches, self.last_stats = opt, {}, None
+        self.opt, self.caches, self.last_stats, self.calls = opt, {}, None, 0
+        self._lock = __import__("threading").Lock()   # (the cache dictionary; an index itself is used by one thread at a time)
 
     def map(self, key, target, query, batch_size, dual):
-        if key not in self.caches:
-            self.caches[key] = _IndexCache(self.opt, target)
-        return self.caches[key].map(query, batch_size, dual)
+        with self._lock:
+            if key not in self.caches:
+                self.caches[key] = _IndexCache(self.opt, target)
+            c = self.caches[key]
+            self.calls += 1
+        return c.map(query, batch_size, dual)
 
     def release(self, key, keep_stats=False):
-        c = self.caches.pop(key, None)
+        with self._lock:
+            c = self.caches.pop(key, None)
         if c is not None:
             if keep_stats:
                 st = [ix.stats() for ix in c.parts.values()]
@@ -251,11 +257,17 @@ class Shard:
                 return r
             got = {}
             # the jobs this rank owns first (the others wait for them), then what the others hand over
-            for k, tgt, kind, j, dual in jobs:
-                if ex is None or kind == "part" or owner_of(tgt, j) == i:
+            own = [job for job in jobs if ex is None or job[2] == "part" or owner_of(job[1], job[3]) == i]
+
+            def hand_over(k, tgt, kind, j):
+                if ex is not None and kind == "seed" and tgt != j:
+                    ex.put(k, got[k], i)
+            if getattr(be, "concurrent", False) and len(own) > 2 and not os.environ.get("NDGPU_STAGE_SERIAL"):
+                self._overlaps_grouped(i, own, got, hand_over)
+            else:
+                for k, tgt, kind, j, dual in own:
                     got[k] = compute(k, tgt, kind, j, dual)
-                    if ex is not None and kind == "seed" and tgt != j:
-                        ex.put(k, got[k], i)
+                    hand_over(k, tgt, kind, j)
             for k, tgt, kind, j, dual in jobs:
                 if k not in got:
                     r = ex.get(k, owner_of(tgt, j))
@@ -273,6 +285,59 @@ class Shard:
         self.stats["records"] += int(sum(r.size for r in out))
         self.stats["jobs"] += len(out)
         return out
+
+    def _overlaps_grouped(self, i, own, got, hand_over):
+        """The jobs a rank of many computes are small (1 / N^2 of the pair space each) and a map call has a floor -- the chain and the
+        replayed sort of its heaviest read, a dozen waits -- that does not shrink with the job: at N = 8 the five to nine calls of a
+        rank took 62 ms where the whole job's ONE call takes 86.  So (a) the jobs that map against the same index with the same options
+        go into ONE call -- their query files back to back; the reads of a query set are mapped independently of each other, so the
+        call's records are the jobs' records back to back, cut apart again at the file boundaries -- and (b) the calls against
+        DIFFERENT indexes (the mirror jobs: target = another rank's seed file) run side by side, a host thread and an index -- with
+        its stream -- each.  An index is never used by two threads at a time."""
+        import threading
+        be = self.backend
+        by_target = {}
+        for job in own:
+            k, tgt, kind, j, dual = job
+            batch = minimap2_nd.IDX_BATCH if kind == "part" else self.seed_batch
+            layout = tuple(minimap2_nd.index_parts(self.lens[self.seed_ids[tgt]], batch))   # (jobs of one call share the -I split)
+            by_target.setdefault(tgt, {}).setdefault((dual, layout), (batch, []))[1].append(job)   # (-I only matters through the split)
+        errors = []
+
+        def run_target(tgt, groups):
+            try:
+                target = self._set(self.seed_ids[tgt])
+                for (dual, _layout), (batch, members) in groups.items():
+                    ids = [self.part_ids[j] if kind == "part" else self.seed_ids[j] for _k, _t, kind, j, _d in members]
+                    if len(members) == 1:
+                        parts = [be.map(tgt, target, self._set(ids[0]), batch, dual)]
+                    else:
+                        recs = be.map(tgt, target, self._set(np.concatenate(ids)), batch, dual)
+                        # a record's query is its qname (lib/ovl.h:20-25): which file of the call it came from
+                        file_of = np.zeros(self.lens.size, dtype=np.int32)
+                        for f, x in enumerate(ids):
+                            file_of[x] = f
+                        rf = file_of[recs["qname"]] if recs.size else np.zeros(0, dtype=np.int32)
+                        if recs.size and np.any(np.diff(rf) < 0):
+                            raise RuntimeError("records of a fused map call are not in query-file order")
+                        cut = np.searchsorted(rf, np.arange(len(ids) + 1))
+                        parts = [recs[cut[f]:cut[f + 1]] for f in range(len(ids))]
+                    for (k, _t, kind, j, _d), r in zip(members, parts):
+                        got[k] = r
+                        hand_over(k, tgt, kind, j)
+                if tgt != i:   # that index is not needed again by this shard
+                    be.release(tgt)
+            except BaseException as e:   # noqa: BLE001  (re-raised by the caller's thread)
+                errors.append(e)
+        threads = [threading.Thread(target=run_target, args=(tgt, groups)) for tgt, groups in by_target.items() if tgt != i]
+        for th in threads:
+            th.start()
+        if i in by_target:
+            run_target(i, by_target[i])
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
 
     def piles(self, i, files=None):
         """(records [n, 8] uint32, pile_off, seed ids, blacklisted) of seed file i: what `nextcorrect.py -i sorted.ovl` corrects."""

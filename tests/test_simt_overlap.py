@@ -105,6 +105,35 @@ def test_long_kmer_sketch(interpreted, olib, k, w, hpc, monkeypatch):
     GO.test_sketch_adversarial_reads(olib, k, w, hpc)
 
 
+def test_jobs_of_a_rank_fused_and_side_by_side(interpreted, monkeypatch):
+    """stage.Shard.overlaps with 4 seed files, the rank of seed file 2 on its own (no hand-over: 2 mirror jobs against the indexes of
+    seed files 0 and 1, the part job and the jobs (2, 2), (2, 3) against its own): the jobs with one index and one set of options in ONE
+    map call cut apart at the file boundaries, the calls against different indexes on threads of their own -- the records of every
+    job equal to the job-by-job loop's."""
+    from nextdenovo_amd import stage, synth
+    g = synth.make_genome(60000, seed=5, n_repeats=3, repeat_len=1500)
+    rs = synth.simulate_reads(g, 14, "ont", seed=6, mu=7.9, sigma=0.5, min_len=500)
+    words, off, lens = synth.pack_db(rs)
+    outs = {}
+    for mode in ("serial", "grouped"):
+        if mode == "serial":
+            monkeypatch.setenv("NDGPU_STAGE_SERIAL", "1")
+        else:
+            monkeypatch.delenv("NDGPU_STAGE_SERIAL")
+        sh = stage.Shard(words, off, lens, preset="ava-ont", seed_cutoff=2500, read_cutoff=500, n_seed_files=4, sort_k=20)
+        try:
+            assert len(sh.part_ids) >= 1 and all(x.size > 5 for x in sh.seed_ids)
+            jobs = sh.jobs_of(2)
+            assert len(jobs) == 4 + len(sh.part_ids) and sum(1 for j in jobs if j[1] != 2) == 2
+            outs[mode] = sh.overlaps(2)
+            assert sh.backend.calls == (len(jobs) if mode == "serial" else 4)   # own index: {part jobs, (2, 3)} and (2, 2); two mirrors
+        finally:
+            sh.close()
+    assert len(outs["serial"]) == len(outs["grouped"]) and sum(r.size for r in outs["serial"]) > 200
+    for a, b in zip(outs["serial"], outs["grouped"]):
+        assert a.size == b.size and a.tobytes() == b.tobytes()
+
+
 def test_options_drawn_at_random_match_oracle():
     """tools/fuzz_overlap_options.py: preset, k, w, -n, -m, -f INT[,INT], --dual, --mode 3 and the batch size drawn at random on small
     read sets with repeats and tandem arrays; the device library's `.ovl` bytes against the oracle's.  (A process of its own: the tool
