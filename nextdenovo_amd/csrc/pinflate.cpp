@@ -278,8 +278,58 @@ void decode_run(const uint8_t *data, uint64_t size, uint64_t bit, bool in_member
         } else {
             if (type == 1) fixed_codes(C);
             else if (!read_dynamic(in, C, false)) return finish(in.over ? kStopInputEnd : kStopError, true);
+            const uint64_t back0 = R.member_out0 == UINT64_MAX ? (uint64_t)kWin : 0, base0 = R.member_out0 == UINT64_MAX ? 0 : R.member_out0;
             for (;;) {
                 grow(300);
+                // The common case, without the bookkeeping of the careful path below: with 48 bits in the buffer a whole symbol --
+                // a literal / length code (15), its extra bits (5), a distance code (15), its extra bits (13) -- needs no refill and
+                // cannot run past the input.  The bit state lives in locals for the run.
+                if (in.cnt < 48) in.refill();
+                if (in.cnt >= 48) {
+                    uint64_t buf = in.buf;
+                    int cnt = in.cnt;
+                    const uint8_t *p = in.p;
+                    bool leave = false;   // a symbol for the careful path: a long code, the end of the block, an error
+                    while (n + 300 <= cap) {
+                        if (cnt < 48) {
+                            if (p + 8 > in.end) break;
+                            uint64_t w;
+                            memcpy(&w, p, 8);
+                            buf |= w << cnt;
+                            p += (63 - cnt) >> 3;
+                            cnt |= 56;
+                        }
+                        const uint16_t e = C.lit.fast[buf & ((1u << kLitBits) - 1)];
+                        if (!e) { leave = true; break; }
+                        const int sym = e >> 4;
+                        if (sym < 256) {
+                            buf >>= (e & 15), cnt -= (e & 15);
+                            o[n++] = (T)sym;
+                            continue;
+                        }
+                        if (sym == 256 || sym >= 286 || C.dist_none) { leave = true; break; }
+                        uint64_t b2 = buf >> (e & 15);
+                        int used = e & 15;
+                        const int ls = sym - 257;
+                        const uint32_t len = kLenBase[ls] + (uint32_t)(b2 & ((1u << kLenExtra[ls]) - 1));
+                        b2 >>= kLenExtra[ls], used += kLenExtra[ls];
+                        const uint16_t de = C.dist.fast[b2 & ((1u << kDistBits) - 1)];
+                        if (!de || (de >> 4) >= 30) { leave = true; break; }
+                        b2 >>= (de & 15), used += (de & 15);
+                        const int ds = de >> 4;
+                        const uint32_t dist = kDistBase[ds] + (uint32_t)(b2 & ((1u << kDistExtra[ds]) - 1));
+                        used += kDistExtra[ds];
+                        if (dist > n - base0 + back0) { leave = true; break; }   // (the careful path reports it)
+                        buf >>= used, cnt -= used;
+                        const T *src = o + n - dist;
+                        T *dst = o + n;
+                        if (dist >= len) memcpy(dst, src, len * sizeof(T));
+                        else for (uint32_t i2 = 0; i2 < len; ++i2) dst[i2] = src[i2];
+                        n += len;
+                    }
+                    in.buf = buf, in.cnt = cnt, in.p = p;
+                    if (!leave) continue;   // (room or input to fetch: round again)
+                }
                 int s = C.lit.decode(in);
                 if (s < 0) return finish(in.over ? kStopInputEnd : kStopError, true);
                 if (in.over) return finish(kStopInputEnd, true);
