@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64) void lq_stitch_kernel(LqPileDev *__restrict__ p
                     if (rel) {
                         const int ld = __ffsll((long long)rel) - 1;
                         const long long mine = tp - (long long)ss[in ? i : 0];
-                        const long long d0 = ((long long)__shfl((int)(mine >> 32), ld, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)mine, ld, 64);
+                        const long long d0 = (long long)(((unsigned long long)(uint32_t)__shfl((int)(mine >> 32), ld, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)mine, ld, 64));
                         if (!have) dl = d0, have = true;
                         if (in && !s_abs && mine != dl) bad = true;
                     }

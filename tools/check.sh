@@ -16,7 +16,7 @@ for san in undefined address; do
   pre=/usr/lib/gcc/x86_64-linux-gnu/11/lib$([ $san = undefined ] && echo ubsan || echo asan).so
   SIMT_SANITIZE=$san UBSAN_OPTIONS=halt_on_error=1 ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$pre \
     python -m pytest tests/test_simt_kernels.py tests/test_simt_overlap.py tests/test_simt_ksw2.py -x -q \
-      -k "not forced and not out_of and not step2_mode0"   # (child processes and exception paths do not mix with a preloaded sanitizer)
+      -k "not forced and not out_of and not step2_mode0 and not drawn_at_random and not every_failed"   # (child processes and exception paths do not mix with a preloaded sanitizer)
 done
 # 4. optional (`tools/check.sh fuzz`, after `full`): short campaigns of the fuzzers against the compiled reference programs (oracle/_ref) --
 #    the oracles, then the device paths under the interpreter
