@@ -303,6 +303,7 @@ class Shard:
             layout = tuple(minimap2_nd.index_parts(self.lens[self.seed_ids[tgt]], batch))   # (jobs of one call share the -I split)
             by_target.setdefault(tgt, {}).setdefault((dual, layout), (batch, []))[1].append(job)   # (-I only matters through the split)
         errors = []
+        hand_lock = threading.Lock()   # (the hand-over keeps a list and counters: one thread at a time)
 
         def run_target(tgt, groups):
             try:
@@ -324,7 +325,8 @@ class Shard:
                         parts = [recs[cut[f]:cut[f + 1]] for f in range(len(ids))]
                     for (k, _t, kind, j, _d), r in zip(members, parts):
                         got[k] = r
-                        hand_over(k, tgt, kind, j)
+                        with hand_lock:
+                            hand_over(k, tgt, kind, j)
                 if tgt != i:   # that index is not needed again by this shard
                     be.release(tgt)
             except BaseException as e:   # noqa: BLE001  (re-raised by the caller's thread)

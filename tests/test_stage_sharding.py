@@ -73,3 +73,76 @@ def test_shard_jobs_and_piles_equal_reference_programs(tmp_path, oracle_lib):
             assert np.array_equal(sub[int(off[p]):int(off[p + 1])], w[5]), (i, p)
         n_piles += len(want)
     assert n_piles >= 6
+
+
+class _PairBackend:
+    """A stand-in for the device backend (no GPU, no oracle): one record per (query read, target read) pair whose ids add up to a
+    multiple of three, in query order -- enough to see which records a map call returns and in which order.  `concurrent` like the
+    device backend: `Shard.overlaps` groups the jobs of one index into one call and runs the other indexes' calls on threads."""
+    concurrent = True
+
+    def __init__(self):
+        import threading
+        self.calls, self.lock, self.released = [], threading.Lock(), []
+
+    def map(self, key, target, query, batch_size, dual):
+        from nextdenovo_amd import overlap
+        with self.lock:
+            self.calls.append((key, len(query), dual))
+        out = []
+        for q in query.ids.tolist():
+            for t in target.ids.tolist():
+                if (q + t) % 3 == 0 and (dual or q <= t):
+                    out.append((0, q, 1, 2, t, 3, 4, q * 1000 + t))
+        return np.asarray(out, dtype=np.uint32).reshape(-1, 8).view(overlap.REC).reshape(-1) if out else np.zeros(0, dtype=overlap.REC)
+
+    def release(self, key, keep_stats=False):
+        with self.lock:
+            self.released.append(key)
+
+
+def test_grouped_jobs_with_the_hand_over(tmp_path, monkeypatch):
+    """Three ranks of one node in one process (threads), each with the stand-in backend: job by job (NDGPU_STAGE_SERIAL) and
+    grouped + side by side give every rank the same records for every job, hand-over included, and the grouped form makes fewer
+    calls."""
+    import threading
+    from nextdenovo_amd import stage
+    rng = np.random.default_rng(4)
+    lens = rng.integers(600, 9000, 160).astype(np.uint32)
+    word_off = np.zeros(lens.size, dtype=np.uint64)
+    word_off[1:] = np.cumsum((lens.astype(np.uint64) + 15) // 16)[:-1]
+    words = np.zeros(int(((lens.astype(np.uint64) + 15) // 16).sum()) + 1, dtype=np.uint32)
+    results = {}
+    for mode in ("serial", "grouped"):
+        if mode == "serial":
+            monkeypatch.setenv("NDGPU_STAGE_SERIAL", "1")
+        else:
+            monkeypatch.delenv("NDGPU_STAGE_SERIAL")
+        xdir = tmp_path / mode
+        got, calls, errs = {}, {}, []
+
+        def rank(r):
+            try:
+                be = _PairBackend()
+                sh = stage.Shard(words, word_off, lens, seed_cutoff=3000, read_cutoff=500, n_seed_files=5, backend=be,
+                                 exchange=stage.Exchange(str(xdir), r, timeout_s=30.0))
+                assert len(sh.part_ids) == 1
+                got[r] = [x.copy() for x in sh.overlaps(r)]
+                calls[r] = list(be.calls)
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=rank, args=(r,)) for r in range(5)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        results[mode] = (got, calls)
+    for r in range(5):
+        a, b = results["serial"][0][r], results["grouped"][0][r]
+        assert len(a) == len(b) == 6 and sum(x.size for x in a) > 50          # part job + 5 seed x seed jobs per seed file
+        for x, y in zip(a, b):
+            assert x.tobytes() == y.tobytes()
+    n_serial = sum(len(c) for c in results["serial"][1].values())
+    n_grouped = sum(len(c) for c in results["grouped"][1].values())
+    assert n_serial == 5 + 15 and n_grouped < n_serial                          # every job once across the node; fewer, larger calls
