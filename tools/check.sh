@@ -24,3 +24,4 @@ done
 python tools/fuzz_overlap.py plain 1 10 && python tools/fuzz_overlap.py step2 1 6 && python tools/fuzz_overlap.py sort 1 6 && python tools/fuzz_cigar.py oracle 1 6
 NDGPU_SIMT=1 python tools/fuzz_overlap.py cli 1 6 && NDGPU_SIMT=1 python tools/fuzz_overlap.py dump 1 10 && NDGPU_SIMT=1 python tools/fuzz_cigar.py device 1 3
 NDGPU_SIMT=1 python tools/fuzz_consensus.py 1 8 && NDGPU_SIMT=1 python tools/fuzz_stage.py 1 2
+python tools/fuzz_inflate.py 1 60 && python tools/fuzz_overlap_options.py 1 8
