@@ -51,7 +51,7 @@ def sets(interpreted):
 
 from make_overlap_golden import CASES_M3  # noqa: E402
 
-_FAST_CASES = [c for c in GO.CASES + CASES_M3 if "-I" not in c[5]]
+_FAST_CASES = [c for c in GO.CASES + CASES_M3 if "-I" not in c[5] and (c[0] != "hifi.sxp.dual.k40" or os.environ.get("NDGPU_SLOW_TESTS"))]   # (k40: 24 s here; k70 covers the long k-mers, both run on the GPU)
 
 
 @pytest.mark.parametrize("case", _FAST_CASES, ids=[c[0] for c in _FAST_CASES])
@@ -139,9 +139,9 @@ def test_options_drawn_at_random_match_oracle():
     read sets with repeats and tandem arrays; the device library's `.ovl` bytes against the oracle's.  (A process of its own: the tool
     binds nextdenovo_amd.overlap to the interpreted library for good.)"""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fuzz_overlap_options.py"), "5", "5"], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fuzz_overlap_options.py"), "5", "3"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "5 cases, 0 bad" in r.stdout
+    assert "3 cases, 0 bad" in r.stdout
 
 
 def test_anchors_and_chain_arrays_match_oracle(olib, sets, monkeypatch):
