@@ -190,7 +190,7 @@ def test_whole_stage_from_2bit_to_cns_fasta(interpreted, tmp_path):
     assert open(out + ".idx", "rb").read() == GS._golden("cns.default.fasta.idx", gz=True)
 
 
-@pytest.mark.parametrize("tag", ["ont.m2", "hifi.self.m2", "ont.m1", "ont.rechain", "ont.rechain.m2"] + (["pb.m2", "ont.I.m2", "deep.m2", "deep.rechain.m1", "tandem.m1"] if os.environ.get("NDGPU_SLOW_TESTS") else []))
+@pytest.mark.parametrize("tag", ["ont.m2", "hifi.self.m2", "ont.m1", "ont.rechain"] + (["pb.m2", "ont.I.m2", "deep.m2", "ont.rechain.m2", "deep.rechain.m1", "tandem.m1"] if os.environ.get("NDGPU_SLOW_TESTS") else []))
 def test_step2_with_the_realignment(interpreted, tmp_path, tag):
     """`--step 2` as nextDenovo writes it (no --mode: every marked candidate mapped again with the short k-mer sketch -- hits per
     read, wanted-target lists and nameless units through the seed kernels, provisional records out of K5, the bookkeeping on the
