@@ -112,6 +112,7 @@ def fuzz_step2(seed, n_cases, lib):
         if mode and rng.random()<0.3:
             cn=int(rng.choice([5,20,40])); extra+=["--cn",str(cn)]; s2["cn"]=cn
         if mode==1: s2["minide"]=max(s2["minide"],0.01)
+        if mode==1 and s2["cn"]==20: s2["cn"]=50   # main.c:457 cannot tell `--cn 20` from the default and makes both 50 in --mode 1
         out=os.path.join(wd,"o.ovl")
         cmd=[os.path.join(M.REFDIR,"minimap2-nd"),"--step","2",*(("--mode",str(mode)) if mode!=2 else ()),"--dual=yes","-t","3","-x",preset,*extra,files[0],files[1],files[0],"-o",out]
         try: subprocess.run(cmd,check=True,stdout=subprocess.DEVNULL,stderr=subprocess.DEVNULL)
@@ -343,6 +344,7 @@ def fuzz_cli2(seed, n_cases, lib):
         if mode and rng.random()<0.3:
             cn=int(rng.choice([5,20,40])); extra+=["--cn",str(cn)]; s2["cn"]=cn
         if mode==1: s2["minide"]=max(s2["minide"],0.01)
+        if mode==1 and s2["cn"]==20: s2["cn"]=50   # main.c:457 cannot tell `--cn 20` from the default and makes both 50 in --mode 1
         out=os.path.join(wd,"o.ovl")
         cmd=[os.path.join(M.REFDIR,"minimap2-nd"),"--step","2",*(("--mode",str(mode)) if mode!=2 else ()),"--dual=yes","-t","3","-x",preset,*extra,files[0],files[1],files[0],"-o",out]
         try: subprocess.run(cmd,check=True,stdout=subprocess.DEVNULL,stderr=subprocess.DEVNULL)
