@@ -149,7 +149,8 @@ void launch_sort_init(const uint32_t *tie_reads, uint32_t n_tie, const uint64_t 
                       const KeyLayout &L, uint64_t *ax, uint64_t *ay, void *jobs, uint32_t *n_jobs, hipStream_t s);
 void launch_sort_pass(const void *jobs, uint32_t n_jobs, uint64_t *x, uint64_t *y, uint64_t *tx, uint64_t *ty, uint32_t *gs, void *next,
                       uint32_t *n_next, hipStream_t s);
-void launch_thin_anchors(const uint64_t *r_aoff, uint32_t n_reads, uint64_t *ax, int32_t *t, int32_t *v, hipStream_t s);
+void launch_thin_anchors(const uint64_t *r_aoff, uint32_t n_reads, uint64_t *ax, int32_t *t, int32_t *v, const int32_t *read_mid, uint32_t read_base,
+                         int32_t mid, hipStream_t s);
 void launch_chain(const uint64_t *slab_i0, const uint32_t *slab_read, uint32_t n_slabs, uint64_t n_anchors, const uint64_t *r_aoff,
                   const float *read_avg_span, const uint64_t *ax, const uint64_t *ay, const OvlParams &P, int32_t *f, int32_t *p, int32_t *v,
                   unsigned long long *cells, hipStream_t s);

@@ -858,7 +858,7 @@ int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, cons
 		cells.zero(stream);
 		t.zero(stream);
 		tm.start();
-		if (P.thin) launch_thin_anchors(r_aoff.p, nb, ax.p, t.p, v.p, stream);
+		if (P.thin) launch_thin_anchors(r_aoff.p, nb, ax.p, t.p, v.p, qd.read_mid, r0, mid, stream);
 		launch_chain(slab_i0.p, slab_read.p, (uint32_t)n_slabs, na, r_aoff.p, avg_span.p, ax.p, ay.p, P, f.p, p.p, v.p, cells.p, stream);
 		launch_chain_ends(r_aoff.p, nb, P, f.p, p.p, v.p, t.p, u.p, n_end.p, stream);
 		HIP_OK(hipGetLastError());

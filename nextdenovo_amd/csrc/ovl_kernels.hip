@@ -1367,10 +1367,13 @@ __global__ void __launch_bounds__(64) chain_ends_kernel(const uint64_t *__restri
 // x becomes all ones (the reference's a[i].x = -1).  Two sequential passes per read, one lane each: rare reads, ~10 ms.
 // (The reference's counters can step one slot past its arrays when every anchor is a group of its own; that slot is not written here.)
 __global__ void thin_anchors_kernel(const uint64_t *__restrict__ r_aoff, uint32_t n_reads, uint64_t *__restrict__ ax, int32_t *__restrict__ t,
-                                    int32_t *__restrict__ v)
+                                    int32_t *__restrict__ v, const int32_t *__restrict__ read_mid, uint32_t read_base, int32_t mid)
 {
 	const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rd >= n_reads) return;
+	// a read that is chained a second time (-f FLOAT,INT: its threshold was raised) is chained by mm_chain_dp there, without the
+	// thinning: the re-chaining branch of mm_map_frag_nextdenovo1 does not call the _nextdenovo form (minimap2/map.c:696-698)
+	if (read_mid && read_mid[read_base + rd] != mid) return;
 	const uint64_t a0 = r_aoff[rd];
 	const int64_t n = (int64_t)(r_aoff[rd + 1] - a0);
 	if (n <= 100000) return;
@@ -1403,9 +1406,10 @@ __global__ void thin_anchors_kernel(const uint64_t *__restrict__ r_aoff, uint32_
 	for (i = 0; i <= groups && i < n; ++i) T[i] = 0;
 }
 
-void launch_thin_anchors(const uint64_t *r_aoff, uint32_t n_reads, uint64_t *ax, int32_t *t, int32_t *v, hipStream_t s)
+void launch_thin_anchors(const uint64_t *r_aoff, uint32_t n_reads, uint64_t *ax, int32_t *t, int32_t *v, const int32_t *read_mid, uint32_t read_base,
+                         int32_t mid, hipStream_t s)
 {
-	if (n_reads) ND_LAUNCH(thin_anchors_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, ax, t, v);
+	if (n_reads) ND_LAUNCH(thin_anchors_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, r_aoff, n_reads, ax, t, v, read_mid, read_base, mid);
 }
 
 void launch_chain(const uint64_t *slab_i0, const uint32_t *slab_read, uint32_t n_slabs, uint64_t n_anchors, const uint64_t *r_aoff,

@@ -693,6 +693,7 @@ static int map_named_impl(const nd_mm_index *ix, const nd_mm_opt *opt, int mid_o
 		a = (nd_mm128*)malloc(sizeof(nd_mm128) * (n_a > 0 ? n_a : 1));
 		n_a = nd_mm_seeds(ix, opt, qname, qlen, opt->max_occ, mv, n_mv, a, 1);
 		u = (uint64_t*)malloc(8 * (n_a > 0 ? n_a : 1));
+		g_chain_thin = 0; /* the second chaining is mm_chain_dp in mm_map_frag_nextdenovo1 too (map.c:696-698) */
 		n_u = nd_mm_chain(opt, n_a, a, u, &n_b, 0, 0);
 	}
 	g_chain_thin = 0;
