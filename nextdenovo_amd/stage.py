@@ -319,8 +319,13 @@ class Shard:
                         for f, x in enumerate(ids):
                             file_of[x] = f
                         rf = file_of[recs["qname"]] if recs.size else np.zeros(0, dtype=np.int32)
+                        # a target that splits into several -I parts is mapped part by part, the whole query set each time
+                        # (minimap2/main.c:488-528): the call's records are part-major -- file 0..n of part 0, file 0..n of part
+                        # 1, ... -- and a job's own file is its records of part 0, part 1, ... in that order.  A stable sort by
+                        # file gives exactly that (the identity when the target is one part).
                         if recs.size and np.any(np.diff(rf) < 0):
-                            raise RuntimeError("records of a fused map call are not in query-file order")
+                            order = np.argsort(rf, kind="stable")
+                            recs, rf = recs[order], rf[order]
                         cut = np.searchsorted(rf, np.arange(len(ids) + 1))
                         parts = [recs[cut[f]:cut[f + 1]] for f in range(len(ids))]
                     for (k, _t, kind, j, _d), r in zip(members, parts):

@@ -146,3 +146,51 @@ def test_grouped_jobs_with_the_hand_over(tmp_path, monkeypatch):
     n_serial = sum(len(c) for c in results["serial"][1].values())
     n_grouped = sum(len(c) for c in results["grouped"][1].values())
     assert n_serial == 5 + 15 and n_grouped < n_serial                          # every job once across the node; fewer, larger calls
+
+
+class _SplitBackend(_PairBackend):
+    """The stand-in with a target that splits into -I parts as `minimap2_nd.index_parts` cuts it: the whole query set is mapped
+    against part 0, then against part 1, ... (`_IndexCache.map`, minimap2/main.c:488-528), so a fused call's records are part-major."""
+
+    def map(self, key, target, query, batch_size, dual):
+        from nextdenovo_amd import minimap2_nd, overlap
+        with self.lock:
+            self.calls.append((key, len(query), dual))
+        out = []
+        tids = target.ids.tolist()
+        for a, b in minimap2_nd.index_parts(target.lens, batch_size):
+            for q in query.ids.tolist():
+                for t in tids[a:b]:
+                    if (q + t) % 3 == 0 and (dual or q <= t):
+                        out.append((0, q, 1, 2, t, 3, 4, q * 1000 + t))
+        return np.asarray(out, dtype=np.uint32).reshape(-1, 8).view(overlap.REC).reshape(-1) if out else np.zeros(0, dtype=overlap.REC)
+
+
+def test_grouped_jobs_against_a_target_of_several_index_parts(monkeypatch):
+    """when the target seed file splits into more than one -I part and two jobs share the call, the fused
+    call's records come back part-major (file 0, 1, 0, 1); every job must still get its own records, part 0 then part 1, exactly
+    as its own call would have returned them."""
+    from nextdenovo_amd import minimap2_nd, stage
+    rng = np.random.default_rng(9)
+    lens = rng.integers(600, 9000, 200).astype(np.uint32)
+    word_off = np.zeros(lens.size, dtype=np.uint64)
+    word_off[1:] = np.cumsum((lens.astype(np.uint64) + 15) // 16)[:-1]
+    words = np.zeros(int(((lens.astype(np.uint64) + 15) // 16).sum()) + 1, dtype=np.uint32)
+    parts_of = minimap2_nd.index_parts
+    monkeypatch.setattr(minimap2_nd, "index_parts", lambda lens_, batch: parts_of(lens_, batch, 20000))
+    results = {}
+    for mode in ("serial", "grouped"):
+        if mode == "serial":
+            monkeypatch.setenv("NDGPU_STAGE_SERIAL", "1")
+        else:
+            monkeypatch.delenv("NDGPU_STAGE_SERIAL", raising=False)
+        be = _SplitBackend()
+        sh = stage.Shard(words, word_off, lens, seed_cutoff=3000, read_cutoff=500, n_seed_files=5, backend=be)
+        sh.seed_batch = 60000           # -I of the seed x seed jobs: every seed file is cut into several parts
+        assert len(minimap2_nd.index_parts(lens[sh.seed_ids[1]], sh.seed_batch)) > 1
+        results[mode] = ([x.copy() for x in sh.overlaps(1)], list(be.calls))
+    a, b = results["serial"][0], results["grouped"][0]
+    assert len(a) == len(b) and sum(x.size for x in a) > 50
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    assert len(results["grouped"][1]) < len(results["serial"][1])
