@@ -667,7 +667,7 @@ def main():
                 "other_kernels": others}),
             "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "trace_words", "lq_rounds", "lq_declined", "max_band", "piles", "tags",
                                             "cells_msa", "links", "path_items", "score_segments", "score_repairs", "score_slow_piles",
-                                            "lq_jobs", "lq_repairs", "lq_columns")},
+                                            "lq_jobs", "lq_repairs", "lq_columns", "tb_tasks", "tb_walkers", "tb_fallbacks")},
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms", "lq_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,

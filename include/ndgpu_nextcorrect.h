@@ -208,6 +208,9 @@ typedef struct {
     uint64_t lq_out;           /* consensus characters written */
     uint64_t lq_jobs;          /* K12 jobs (runs of regions scored from a speculative start) */
     uint64_t lq_repairs;       /* of which scored again after a failed boundary check */
+    uint64_t tb_tasks;         /* alignments whose traceback ran in segments (one lane per 2^k edit steps) */
+    uint64_t tb_walkers;       /* segments they were cut into */
+    uint64_t tb_fallbacks;     /* of the alignments: walked again in one piece (a segment boundary did not agree) */
 } ndgpu_stats;
 void ndgpu_get_stats(ndgpu_stats *out);
 void ndgpu_reset_stats(void);

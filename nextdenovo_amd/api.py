@@ -33,7 +33,8 @@ class Stats(C.Structure):
                 ("score_repairs", C.c_uint64), ("score_slow_piles", C.c_uint64), ("trace_words", C.c_uint64), ("lq_rounds", C.c_uint64), ("lq_declined", C.c_uint64),
                 ("lq_ms", C.c_double), ("allocs", C.c_uint64), ("alloc_ms", C.c_double), ("level_allocs", C.c_uint64), ("level_ms", C.c_double),
                 ("traceback_launches", C.c_uint64), ("lq_launches", C.c_uint64), ("lq_columns", C.c_uint64), ("lq_aln_columns", C.c_uint64),
-                ("lq_bases", C.c_uint64), ("lq_out", C.c_uint64), ("lq_jobs", C.c_uint64), ("lq_repairs", C.c_uint64)]
+                ("lq_bases", C.c_uint64), ("lq_out", C.c_uint64), ("lq_jobs", C.c_uint64), ("lq_repairs", C.c_uint64),
+                ("tb_tasks", C.c_uint64), ("tb_walkers", C.c_uint64), ("tb_fallbacks", C.c_uint64)]
 
 
 def lib_path() -> str:

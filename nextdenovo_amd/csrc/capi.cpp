@@ -784,6 +784,7 @@ void ndgpu_get_stats(ndgpu_stats *o) {
     o->traceback_launches = s.traceback_launches, o->lq_launches = s.lq_launches, o->lq_columns = s.lq_columns;
     o->lq_aln_columns = s.lq_aln_columns, o->lq_bases = s.lq_bases, o->lq_out = s.lq_out;
     o->lq_jobs = s.lq_jobs, o->lq_repairs = s.lq_repairs;
+    o->tb_tasks = s.tb_tasks, o->tb_walkers = s.tb_walkers, o->tb_fallbacks = s.tb_fallbacks;
 }
 
 void ndgpu_reset_stats(void) { DeviceAligner::reset_all_stats(); }

@@ -282,6 +282,11 @@ struct DeviceAligner::State {
     DevBuf<uint64_t> d_wtrace;  // wide-band alignments (K7w): trace rows and their min_k -- members, not locals of run_wide: a local
     DevBuf<int32_t> d_wmink;    // buffer was a hipMalloc + hipFree per call, and hipFree waits for every stream of the device
     DevBuf<int32_t> d_v, d_ids;
+    // segmented traceback (ond_kernels.hip): checkpoint cells / headers the forward kernel leaves, the walkers and what they report
+    DevBuf<uint32_t> d_ck_cells;
+    DevBuf<uint2> d_ck_hdr;
+    DevBuf<TbSeg> d_tbseg;
+    DevBuf<TbSegOut> d_tbout;
     std::vector<int32_t> order;
     std::vector<uint32_t> order_cls;
     // main-phase state (alive from run_main to end_batch)
@@ -435,6 +440,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec) NDGPU_NAME(d_lq_jobs) NDGPU_NAME(d_lq_hdr) NDGPU_NAME(d_lq_lnk)
     NDGPU_NAME(d_lq_out) NDGPU_NAME(d_lq_tmp) NDGPU_NAME(d_lq_bnd)
     NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v) NDGPU_NAME(d_wtrace) NDGPU_NAME(d_wmink)
+    NDGPU_NAME(d_ck_cells) NDGPU_NAME(d_ck_hdr) NDGPU_NAME(d_tbseg) NDGPU_NAME(d_tbout)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
     NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
     NDGPU_NAME(d_cell_start) NDGPU_NAME(d_cell_len) NDGPU_NAME(d_cell_bpp) NDGPU_NAME(d_cell_blink) NDGPU_NAME(d_ent_pp)
@@ -494,6 +500,7 @@ RuntimeStats DeviceAligner::total_stats() {
         t.score_segments += s.score_segments; t.score_repairs += s.score_repairs; t.score_slow_piles += s.score_slow_piles;
         t.traceback_launches += s.traceback_launches; t.lq_launches += s.lq_launches; t.lq_columns += s.lq_columns;
         t.lq_aln_columns += s.lq_aln_columns; t.lq_bases += s.lq_bases; t.lq_out += s.lq_out; t.lq_jobs += s.lq_jobs; t.lq_repairs += s.lq_repairs;
+        t.tb_tasks += s.tb_tasks; t.tb_walkers += s.tb_walkers; t.tb_fallbacks += s.tb_fallbacks;
     }
     t.allocs = g_alloc_calls.load(), t.alloc_ms = (double)g_alloc_ns.load() * 1e-6;
     t.level_allocs = g_level_calls.load(), t.level_ms = (double)g_level_ns.load() * 1e-6;
@@ -543,6 +550,7 @@ void DeviceAligner::release_memory() {
     NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec) NDGPU_REL(d_lq_jobs) NDGPU_REL(d_lq_hdr) NDGPU_REL(d_lq_lnk)
     NDGPU_REL(d_lq_out) NDGPU_REL(d_lq_tmp) NDGPU_REL(d_lq_bnd)
     NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v) NDGPU_REL(d_wtrace) NDGPU_REL(d_wmink)
+    NDGPU_REL(d_ck_cells) NDGPU_REL(d_ck_hdr) NDGPU_REL(d_tbseg) NDGPU_REL(d_tbout)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
     NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
     NDGPU_REL(d_cell_start) NDGPU_REL(d_cell_len) NDGPU_REL(d_cell_bpp) NDGPU_REL(d_cell_blink) NDGPU_REL(d_ent_pp)
@@ -587,6 +595,7 @@ void DeviceAligner::level_buffers(int drivers) {
 #define NDGPU_LVL(x) lvl(S.x, #x[0] == 'd');
             NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_jobs) NDGPU_LVL(d_lq_hdr) NDGPU_LVL(d_lq_lnk) NDGPU_LVL(d_lq_out) NDGPU_LVL(d_lq_tmp) NDGPU_LVL(d_lq_bnd)
             NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v) NDGPU_LVL(d_wtrace) NDGPU_LVL(d_wmink)
+            NDGPU_LVL(d_ck_cells) NDGPU_LVL(d_ck_hdr) NDGPU_LVL(d_tbseg) NDGPU_LVL(d_tbout)
             NDGPU_LVL(d_ids) NDGPU_LVL(d_reads) NDGPU_LVL(d_piles) NDGPU_LVL(d_read_pile) NDGPU_LVL(d_acc) NDGPU_LVL(d_tags)
             NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
             NDGPU_LVL(d_cell_start) NDGPU_LVL(d_cell_len) NDGPU_LVL(d_cell_bpp) NDGPU_LVL(d_cell_blink) NDGPU_LVL(d_ent_pp)
@@ -656,6 +665,63 @@ static void limits_for(int total, int hq, int *max_d, int *band) {
     }
 }
 
+// ---- the traceback in segments (ond_kernels.hip: tb_chase / tb_walk / tb_stitch) ----
+// NDGPU_K8_SEG = rows per walker (a power of two; 0: the one-lane kernel everywhere), NDGPU_K8_WARM = rows a walker walks before the rows
+// it owns, NDGPU_K8_MINLEN = a launch takes the segmented path when its longest pair has at least that many bases (q + t).  Test hooks
+// and A/B knobs; the defaults are what the bench was measured with.
+struct TbConfig {
+    int cshift = 8, warm = 32;
+    bool on = true;
+    uint32_t minlen = 8192;
+    TbConfig() {
+        if (const char *e = getenv("NDGPU_K8_SEG")) {
+            const int c = atoi(e);
+            on = c >= 4;
+            cshift = 2;
+            while ((2 << cshift) <= c) cshift++;
+        }
+        if (const char *e = getenv("NDGPU_K8_WARM")) warm = atoi(e);
+        if (warm < 1) warm = 1;
+        if (warm > (1 << cshift)) warm = 1 << cshift;
+        if (const char *e = getenv("NDGPU_K8_MINLEN")) minlen = (uint32_t)atoll(e);
+    }
+};
+static const TbConfig &tb_config() {
+    static const TbConfig c;
+    return c;
+}
+static inline uint32_t tb_ck_slots(int max_d) { return max_d > 0 ? (uint32_t)(max_d - 1) >> tb_config().cshift : 0u; }
+// device bytes a task adds to its launch when the launch is walked in segments
+static inline uint64_t tb_bytes(int max_d) {
+    if (!tb_config().on) return 0;
+    const uint64_t k = tb_ck_slots(max_d);
+    return k * (kCkptCells * sizeof(uint32_t) + sizeof(uint2)) + (k + 1) * (sizeof(TbSeg) + sizeof(TbSegOut));
+}
+// tasks [a, b) of one launch: their checkpoint / walker slots (AlnTask::mink_off, seg_off); false: the launch keeps the one-lane kernel
+static bool tb_assign(AlnTask *tasks, size_t a, size_t b, uint64_t *ck_slots, uint64_t *seg_slots) {
+    const TbConfig &c = tb_config();
+    *ck_slots = *seg_slots = 0;
+    if (!c.on) return false;
+    uint32_t longest = 0;
+    for (size_t i = a; i < b; i++) {
+        if ((uint32_t)tasks[i].q_len >= (1u << 24)) return false;  // (a checkpoint cell holds x in 24 bits)
+        longest = std::max(longest, (uint32_t)tasks[i].q_len + (uint32_t)tasks[i].t_len);
+    }
+    if (longest < c.minlen) return false;
+    uint64_t ck = 0, sg = 0;
+    for (size_t i = a; i < b; i++) {
+        const uint32_t k = tb_ck_slots(tasks[i].max_d);
+        tasks[i].mink_off = ck;
+        tasks[i].seg_off = (uint32_t)sg;
+        ck += k;
+        sg += k + 1;
+    }
+    if (sg >= (1ull << 31)) return false;
+    *ck_slots = ck;
+    *seg_slots = sg;
+    return true;
+}
+
 void DeviceAligner::align_batch(AlnJob **jobs, size_t n) {
     if (n == 0) return;
     std::unique_lock<std::mutex> dbg_lock;
@@ -670,7 +736,7 @@ void DeviceAligner::align_batch(AlnJob **jobs, size_t n) {
             const AlnJob &j = *jobs[done + take];
             int md, bd;
             limits_for(j.q_len + j.t_len, j.hq, &md, &bd);
-            const size_t b = (size_t)md * (kFastRowWords * 8);
+            const size_t b = (size_t)md * (kFastRowWords * 8) + (size_t)tb_bytes(md);
             if (take && bytes + b > s_->trace_budget_bytes) break;
             bytes += b;
             take++;
@@ -789,6 +855,16 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.d_ops.reserve(ops_words + 2);
     S.h_ops.reserve(ops_words + 2);
     S.h_outs.reserve(n);
+    uint64_t ck_slots = 0, seg_slots = 0;
+    const bool seg = tb_assign(tasks.data(), 0, n, &ck_slots, &seg_slots);
+    TbArgs tb{};
+    if (seg) {
+        S.d_ck_cells.reserve(ck_slots * kCkptCells + 1);
+        S.d_ck_hdr.reserve(ck_slots + 1);
+        S.d_tbseg.reserve(seg_slots);
+        S.d_tbout.reserve(seg_slots);
+        tb = TbArgs{S.d_ck_cells.p, S.d_ck_hdr.p, S.d_tbseg.p, S.d_tbout.p, (int)seg_slots, tb_config().cshift, tb_config().warm};
+    }
 
     hipStream_t st = S.stream;
     const uint64_t tc1 = wall_ns();
@@ -796,10 +872,12 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.h2d(S.d_tasks.p, tasks.data(), n * sizeof(AlnTask), st);
     HIP_CHECK(hipEventRecord(S.ev0, st));
     NDGPU_DBG(st, "chunk: forward %zu tasks", n);
-    launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, (int)n, st);
+    if (seg) launch_ond_forward_ckpt(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_ops.p, tb, (int)n, st, nullptr);
+    else launch_ond_forward(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, (int)n, st);
     HIP_CHECK(hipEventRecord(S.ev1, st));
     NDGPU_DBG(st, "chunk: traceback");
-    launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr, S.d_ops.p, nullptr, (int)n, st);
+    if (seg) launch_ond_traceback_seg(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_ops.p, tb, (int)n, st);
+    else launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr, S.d_ops.p, nullptr, (int)n, st);
     NDGPU_DBG(st, "chunk: done");
     HIP_CHECK(hipMemcpyAsync(S.h_outs.p, S.d_outs.p, n * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(S.h_ops.p, S.d_ops.p, ops_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -823,6 +901,11 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
         S.stats.cells += (uint64_t)o.cells;
         S.stats.d_steps += (uint64_t)o.d_steps;
         S.stats.trace_words += (uint64_t)o.trace_end;
+        if (o.fin_idx & kTbSeen) {
+            S.stats.tb_tasks++;
+            S.stats.tb_walkers += (uint64_t)(o.d_final > 0 ? (o.d_final - 1) >> tb_config().cshift : 0) + 1;
+            if (o.fin_idx & kTbRefused) S.stats.tb_fallbacks++;
+        }
         if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
         if (o.status == ST_ALIGNED) {
             S.stats.trace_bits += (uint64_t)o.cells;
@@ -1119,21 +1202,43 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     std::vector<size_t> chunk_end;
     uint64_t max_tw = 0;
     {
-        uint64_t tw = 0;
+        uint64_t tw = 0, extra = 0;
         for (size_t i = 0; i < nt; i++) {
-            const uint64_t need = (uint64_t)tasks[i].max_d * kFastRowWords;
-            if (i && (tw + need) * 8 > S.trace_budget_bytes) {
+            const uint64_t need = (uint64_t)tasks[i].max_d * kFastRowWords, tbb = tb_bytes(tasks[i].max_d);
+            if (i && (tw + need) * 8 + extra + tbb > S.trace_budget_bytes) {
                 chunk_end.push_back(i);
                 max_tw = std::max(max_tw, tw);
-                tw = 0;
+                tw = extra = 0;
             }
             tasks[i].trace_off = tw;
             tw += need;
+            extra += tbb;
         }
         chunk_end.push_back(nt);
         max_tw = std::max(max_tw, tw);
     }
     S.d_trace.reserve(max_tw + 2);
+    // the traceback in segments where a launch holds long pairs (regions of several kb): slots per launch
+    struct ChunkTb { bool seg; uint64_t slots; };
+    std::vector<ChunkTb> chunk_tb;
+    {
+        uint64_t max_ck = 0, max_sg = 0;
+        size_t a = 0;
+        for (size_t b : chunk_end) {
+            uint64_t ck = 0, sg = 0;
+            const bool seg = b > a && tb_assign(tasks.data(), a, b, &ck, &sg);
+            max_ck = std::max(max_ck, ck);
+            max_sg = std::max(max_sg, sg);
+            chunk_tb.push_back(ChunkTb{seg, sg});
+            a = b;
+        }
+        if (max_sg) {
+            S.d_ck_cells.reserve(max_ck * kCkptCells + 1);
+            S.d_ck_hdr.reserve(max_ck + 1);
+            S.d_tbseg.reserve(max_sg);
+            S.d_tbout.reserve(max_sg);
+        }
+    }
 
     const uint64_t tc1 = wall_ns();
     S.h2d(S.d_pool.p, pool.data(), pool.size() * sizeof(uint32_t), st);
@@ -1152,10 +1257,17 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         size_t a = 0, c = 0;
         for (size_t b : chunk_end) {
             NDGPU_DBG(st, "lq: forward / traceback %zu..%zu of %zu tasks", a, b, nt);
-            launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st);
+            const ChunkTb ctb = chunk_tb[c];
+            const TbArgs tb{S.d_ck_cells.p, S.d_ck_hdr.p, S.d_tbseg.p, S.d_tbout.p, (int)ctb.slots, tb_config().cshift, tb_config().warm};
+            if (ctb.seg)
+                launch_ond_forward_ckpt(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_ops.p, tb, (int)(b - a), st, nullptr);
+            else launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st);
             HIP_CHECK(hipEventRecord(S.lq_evs[2 * c + 1], st));
-            launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr, S.d_ops.p, nullptr,
-                                 (int)(b - a), st);
+            if (ctb.seg)
+                launch_ond_traceback_seg(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_ops.p, tb, (int)(b - a), st);
+            else
+                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr, S.d_ops.p, nullptr,
+                                     (int)(b - a), st);
             HIP_CHECK(hipEventRecord(S.lq_evs[2 * c + 2], st));
             a = b;
             c++;
@@ -1197,6 +1309,11 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         S.stats.cells += (uint64_t)o.cells;
         S.stats.d_steps += (uint64_t)o.d_steps;
         S.stats.trace_words += (uint64_t)o.trace_end;
+        if (o.fin_idx & kTbSeen) {
+            S.stats.tb_tasks++;
+            S.stats.tb_walkers += (uint64_t)(o.d_final > 0 ? (o.d_final - 1) >> tb_config().cshift : 0) + 1;
+            if (o.fin_idx & kTbRefused) S.stats.tb_fallbacks++;
+        }
         if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
         if (o.status == ST_ALIGNED) {
             S.stats.trace_bits += (uint64_t)o.cells;
@@ -1339,28 +1456,45 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     // forward/traceback chunks bounded by the trace budget
     std::vector<size_t> chunk_end;
     {
-        uint64_t tw = 0;
+        uint64_t tw = 0, extra = 0;
         for (size_t i = 0; i < nt; i++) {
-            const uint64_t need = (uint64_t)tasks[i].max_d * (kFastRowWords * 8);
-            if (i && (tw * 8 + need) > S.trace_budget_bytes) {
+            const uint64_t need = (uint64_t)tasks[i].max_d * (kFastRowWords * 8), tbb = tb_bytes(tasks[i].max_d);
+            if (i && (tw * 8 + extra + need + tbb) > S.trace_budget_bytes) {
                 chunk_end.push_back(i);
-                tw = 0;
+                tw = extra = 0;
             }
             tasks[i].trace_off = tw;
             tw += (uint64_t)tasks[i].max_d * kFastRowWords;
+            extra += tbb;
         }
         chunk_end.push_back(nt);
     }
     uint64_t max_tw = 0;
+    // the traceback in segments: checkpoint and walker slots per launch
+    struct ChunkTb { bool seg; uint64_t slots; };
+    std::vector<ChunkTb> chunk_tb;
+    uint64_t max_ck = 0, max_sg = 0;
     {
         size_t a = 0;
         for (size_t b : chunk_end) {
+            uint64_t ck = 0, sg = 0;
+            bool seg = false;
             if (b > a) {
                 const AlnTask &l = tasks[b - 1];
                 max_tw = std::max<uint64_t>(max_tw, l.trace_off + (uint64_t)l.max_d * kFastRowWords);
+                seg = tb_assign(tasks.data(), a, b, &ck, &sg);
+                max_ck = std::max(max_ck, ck);
+                max_sg = std::max(max_sg, sg);
             }
+            chunk_tb.push_back(ChunkTb{seg, sg});
             a = b;
         }
+    }
+    if (max_sg) {
+        S.d_ck_cells.reserve(max_ck * kCkptCells + 1);
+        S.d_ck_hdr.reserve(max_ck + 1);
+        S.d_tbseg.reserve(max_sg);
+        S.d_tbout.reserve(max_sg);
     }
 
     S.d_pool.reserve(pool.size());
@@ -1392,8 +1526,9 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     HIP_CHECK(hipMemsetAsync(S.d_err.p, 0, 4 * sizeof(uint32_t), st));
 
     {
-        size_t a = 0;
+        size_t a = 0, ci = 0;
         for (size_t b : chunk_end) {
+            const ChunkTb ctb = chunk_tb[ci++];
             if (b > a) {
                 NDGPU_DBG(st, "main: forward %zu..%zu of %zu tasks, %zu piles", a, b, nt, np);
                 const int32_t *order = nullptr;
@@ -1417,16 +1552,22 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
                     S.h2d(S.d_ids.p, ord.data(), m * sizeof(int32_t), st);
                     order = S.d_ids.p;
                 }
+                const TbArgs tb{S.d_ck_cells.p, S.d_ck_hdr.p, S.d_tbseg.p, S.d_tbout.p, (int)ctb.slots, tb_config().cshift, tb_config().warm};
                 HIP_CHECK(hipEventRecord(S.evs[0], st));
-                launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st, order);
+                if (ctb.seg)
+                    launch_ond_forward_ckpt(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_ops.p, tb, (int)(b - a), st, order);
+                else launch_ond_forward(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, (int)(b - a), st, order);
                 HIP_CHECK(hipEventRecord(S.evs[1], st));
                 NDGPU_DBG(st, "main: traceback");
                 // (K8a stays in table order: measured in round 5, the 64 walks of a wavefront ordered longest first like K7's --
                 // equal lengths, long walks first -- cost 605 ms of traceback per step against 496: the lanes of a wavefront in pile
                 // order walk neighbouring windows of one seed and share its cache lines; NDGPU_K8_ORDER=1 switches the order on)
                 static const bool k8_order = getenv("NDGPU_K8_ORDER") != nullptr;
-                launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr,
-                                     S.d_ops.p, nullptr, (int)(b - a), st, k8_order ? order : nullptr);
+                if (ctb.seg)
+                    launch_ond_traceback_seg(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, S.d_ops.p, tb, (int)(b - a), st);
+                else
+                    launch_ond_traceback(S.d_tasks.p + a, S.d_outs.p + a, S.d_pool.p, S.db_pool, S.d_trace.p, nullptr,
+                                         S.d_ops.p, nullptr, (int)(b - a), st, k8_order ? order : nullptr);
                 NDGPU_DBG(st, "main: traceback done");
                 HIP_CHECK(hipEventRecord(S.evs[2], st));
                 HIP_CHECK(hipEventSynchronize(S.evs[2]));
@@ -1450,6 +1591,11 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
             S.stats.cells += (uint64_t)o.cells;
             S.stats.d_steps += (uint64_t)o.d_steps;
             S.stats.trace_words += (uint64_t)o.trace_end;
+        if (o.fin_idx & kTbSeen) {
+            S.stats.tb_tasks++;
+            S.stats.tb_walkers += (uint64_t)(o.d_final > 0 ? (o.d_final - 1) >> tb_config().cshift : 0) + 1;
+            if (o.fin_idx & kTbRefused) S.stats.tb_fallbacks++;
+        }
             if ((uint32_t)o.max_band > S.stats.max_band) S.stats.max_band = (uint32_t)o.max_band;
             if (o.status == ST_NEED_WIDE) wide.push_back((int32_t)i);
             if (o.status == ST_ALIGNED) {   // (K8a's output: 2-bit column kinds -- the term bench.py's roofline prices it with)

@@ -20,13 +20,14 @@ struct AlnTask {
     int32_t band;        // band cap     (lib/align.c:568,576)
     uint64_t trace_off;  // uint64-word offset of the task's trace (register path: a stream of <= 2 * max_d words;
                          // wide path: row d at trace_off + d*row_words)
-    uint64_t mink_off;   // wide path only: index of row 0 in the per-row min_k array
+    uint64_t mink_off;   // wide path: index of row 0 in the per-row min_k array; register path with checkpoints (segmented
+                         // traceback): the task's first checkpoint slot
     uint64_t ops_off;    // first ops word of this task (uint32 units)
     uint32_t ops_cap;    // capacity in columns (= q_len + t_len)
     uint32_t row_words;  // wide path only: uint64 words per trace row
     uint64_t v_off;      // wide path only: first int of this task's global V scratch
     uint32_t v_mask;     // wide path only: V ring size - 1 (power of two - 1)
-    uint32_t pad_;
+    uint32_t seg_off;    // segmented traceback: the task's first walker slot (TbSeg / TbSegOut)
 };
 
 enum : int32_t {
@@ -48,8 +49,43 @@ struct AlnOut {
     int32_t max_band;
     int64_t cells;
     uint32_t trace_end;  // register path: words of trace stream written (the finishing step's record ends here)
-    int32_t fin_idx;     // register path: cell index of k_final in the finishing step
+    int32_t fin_idx;     // register path: bits [7:0] cell index of k_final in the finishing step; bits [15:8] (checkpointing
+                         // forward kernel) cell index, in the last checkpoint row, of the cell the finishing cell descends from
 };
+
+// ---- segmented traceback (K8a in pieces; ond_kernels.hip) ----
+// The forward kernel leaves a checkpoint every 2^cshift edit steps: per cell of that row its furthest-reaching x and the cell of
+// the checkpoint row before that its move bits lead back to (packed: x in [23:0], cell in [31:24]; 128 cells a slot), per row the
+// trace position behind its record and its min_k.  A chase along those cells names, for every checkpoint row under the finishing
+// step, the cell the traceback passes through; one WALKER per checkpoint then walks its stretch of rows on a lane of its own.
+struct TbSeg {            // a walker: starts at the top of row d_top, owns (emits) rows d_own .. d_end
+    int32_t task;         // index into the launch's task table; -1: unused slot
+    int32_t d_top;        // first row walked (a checkpoint row, or the finishing step for a task's first walker)
+    int32_t d_own;        // first row owned: d_top for the first walker, d_top - warm otherwise (the rows above it are walked
+                          // without output: the walk's x falls in with the true walk's within a few rows, see tb_walk_kernel)
+    int32_t d_end;        // last row owned
+    int32_t x;            // the state at the top of row d_top: query position, cell index, the row's min_k, trace position
+    int32_t idx;
+    int32_t min_k;
+    uint32_t pos;
+};
+struct TbSegOut {
+    int32_t x_own, k_own; // the walk's state at the top of row d_own ...
+    int32_t x_end, k_end; // ... and at the top of row d_end - 1 (what the next walker's x_own / k_own must equal)
+    int32_t lead, trail;  // gap columns before the first match run of the owned rows / behind the last (lib/align.c:542-545 counts
+                          // across walkers: the stitch carries them)
+    uint32_t rows;        // owned rows walked
+    uint32_t flags;       // kTbReset | kTbAbort | kTbTerminal | kTbBad
+};
+enum : uint32_t {
+    kTbReset = 1,         // a match run inside the owned rows (the gap counter restarted)
+    kTbAbort = 2,         // more than 250 gap columns in a row inside the owned rows
+    kTbTerminal = 4,      // reached the alignment's start
+    kTbBad = 8,           // the walk ended where it must not (in the warm-up rows): the task is walked again in one piece
+};
+constexpr int kCkptCells = 128;
+constexpr int32_t kTbRefused = 1 << 16;   // AlnOut::fin_idx: the stitch refused the task (host statistics) ...
+constexpr int32_t kTbSeen = 1 << 17;      // ... of the tasks it saw
 
 // ---- main-phase consensus on the device (msa_kernels.hip) ---------------------------------
 // Packed alignment tag (reference: align_tag, lib/nextcorrect.h:28-32): t_pos+1 in bits
@@ -255,6 +291,21 @@ constexpr int kFastMaxBand = 238;      // register path: at most 120 same-parity
 // launchers (ond_kernels.hip)
 void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                         uint64_t *trace, int n_tasks, void *stream, const int32_t *order = nullptr);  // order: device, n_tasks ids, longest first
+// The forward kernel with checkpoints + the traceback in segments (chase, walkers, stitch, and the one-lane walk for what the stitch
+// refuses).  ck_cells: kCkptCells words per checkpoint slot, ck_hdr: one uint2 per slot (AlnTask::mink_off = a task's first slot,
+// ((max_d - 1) >> cshift) slots each); segs / seg_outs: AlnTask::seg_off = a task's first walker slot, slots + 1 each; n_slots = all of them.
+struct TbArgs {
+    uint32_t *ck_cells;
+    void *ck_hdr;
+    TbSeg *segs;
+    TbSegOut *seg_outs;
+    int n_slots;
+    int cshift, warm;
+};
+void launch_ond_forward_ckpt(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, uint64_t *trace,
+                             uint32_t *ops, const TbArgs &tb, int n_tasks, void *stream, const int32_t *order);
+void launch_ond_traceback_seg(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, const uint64_t *trace,
+                              uint32_t *ops, const TbArgs &tb, int n_tasks, void *stream);
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace, int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream);
 // task_ids == nullptr: tasks [0, n), traces in the register path's stream format, walked in the order `order` lists them

@@ -56,6 +56,9 @@ struct RuntimeStats {
     uint64_t lq_out = 0;              // consensus characters K12 wrote
     uint64_t lq_jobs = 0;             // K12 jobs (runs of regions scored from a speculative start)
     uint64_t lq_repairs = 0;          // of which the stitch kernel scored again (failed boundary check)
+    uint64_t tb_tasks = 0;            // alignments whose traceback ran in segments
+    uint64_t tb_walkers = 0;          // walkers (segments) of those
+    uint64_t tb_fallbacks = 0;        // of the alignments: refused by the stitch, walked again by the one-lane kernel
 };
 
 // Thrown when a device (or pinned host) allocation fails for lack of memory.  The C ABI catches it, releases the

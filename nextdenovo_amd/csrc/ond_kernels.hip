@@ -116,10 +116,17 @@ __device__ __forceinline__ int snake64(const uint32_t *__restrict__ qp, const ui
     return x;
 }
 
+// CKPT: the kernel also leaves what the segmented traceback starts from (nd_device.h: TbSeg).  Every cell carries `org`, the cell of
+// the last checkpoint row its move bits lead back to: it rides the moves V takes (one more permute, one more DPP shift, one select per
+// step); every 2^cshift steps the cells store (x, org) and start again from their own index.  The kernel also zeroes the task's column
+// words: walkers that share a word OR their columns into it.
+template <bool CKPT>
 __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
                                                           const uint32_t *__restrict__ pool,
                                                           const uint32_t *__restrict__ db_pool,
-                                                          uint64_t *__restrict__ trace, const int32_t *__restrict__ order) {
+                                                          uint64_t *__restrict__ trace, const int32_t *__restrict__ order,
+                                                          uint32_t *__restrict__ ck_cells, uint2 *__restrict__ ck_hdr,
+                                                          uint32_t *__restrict__ ops, int cshift) {
     // `order` lists the launch's tasks longest first: workgroups are dispatched in index order, so the long dependent chains
     // start first and the short ones fill in behind them
     const int tid = order ? order[blockIdx.x] : (int)blockIdx.x;
@@ -148,6 +155,14 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
     const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
     uint64_t *__restrict__ S = trace + T.trace_off;
     uint32_t pos = 0;
+    if (CKPT) {
+        uint32_t *__restrict__ W = ops + T.ops_off;
+        const uint32_t nw = (T.ops_cap + 15u) / 16u + 1u;
+        for (uint32_t i = (uint32_t)lane; i < nw; i += 64u) W[i] = 0u;
+    }
+    const int cmask = CKPT ? (1 << cshift) - 1 : 0;
+    int porg0 = 0, porg1 = 0;  // the step before: org of cell `lane` / of cell 64 + `lane`
+    int fin_org = 0;
 
     int px0 = 0, px1 = 0;  // the step before: x of cell `lane` / of cell 64 + `lane` (the reference memsets V: all zero)
     int pj = 0;            // its j
@@ -168,36 +183,46 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         // ---- cells 0..63
         const int src = pj + lane;
         int vp = __shfl(px0, src & 63, 64);
+        int op = CKPT ? __shfl(porg0, src & 63, 64) : 0;
         if (pwide) {
             const int hi = __shfl(px1, src & 63, 64);
             vp = src >= 64 ? hi : vp;
+            if (CKPT) {
+                const int ohi = __shfl(porg1, src & 63, 64);
+                op = src >= 64 ? ohi : op;
+            }
         }
         const int vm = wave_shr1(0, vp);
+        const int om = CKPT ? wave_shr1(0, op) : 0;
         const int k0 = min_k + 2 * lane;
         const bool act0 = k0 <= max_k;
-        int x0 = 0;
+        int x0 = 0, org0 = 0;
         bool left0 = false;
         if (act0) {
             const bool down = (k0 == min_k) || (k0 != max_k && vm < vp);  // lib/align.c:443
             left0 = !down;
+            if (CKPT) org0 = down ? op : om;
             x0 = snake64(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp : vm + 1, k0);
         }
         const unsigned long long lb0 = __ballot(act0 && left0);
         const unsigned long long fb0 = __ballot(act0 && x0 >= q_len && x0 - k0 >= t_len);
         int row_best = act0 ? 2 * x0 - k0 : -1;
         // ---- cells 64..127 (only the steps whose band is wider than 126 diagonals)
-        int x1 = 0, k1 = 0;
+        int x1 = 0, k1 = 0, org1 = 0;
         bool act1 = false;
         unsigned long long lb1 = 0, fb1 = 0;
         if (two && !fb0) {
             const int vp1 = __shfl(px1, src & 63, 64);       // cell 64 + pj + lane of the step before
             const int vm1 = wave_shr1(__builtin_amdgcn_readlane(vp, 63), vp1);
+            const int op1 = CKPT ? __shfl(porg1, src & 63, 64) : 0;
+            const int om1 = CKPT ? wave_shr1(__builtin_amdgcn_readlane(op, 63), op1) : 0;
             k1 = k0 + 128;
             act1 = k1 <= max_k;
             bool left1 = false;
             if (act1) {
                 const bool down = k1 != max_k && vm1 < vp1;
                 left1 = !down;
+                if (CKPT) org1 = down ? op1 : om1;
                 x1 = snake64(qp, tp, q_sh, t_sh, q_len, t_len, down ? vp1 : vm1 + 1, k1);
                 const int m1 = 2 * x1 - k1;
                 row_best = m1 > row_best ? m1 : row_best;
@@ -214,6 +239,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
             fin_idx = fb0 ? fl : 64 + fl;
             fin_k = min_k + 2 * fin_idx;
             fin_x = fb0 ? __shfl(x0, fl, 64) : __shfl(x1, fl, 64);
+            if (CKPT) fin_org = fb0 ? __shfl(org0, fl, 64) : __shfl(org1, fl, 64);
             fin_d = d;
             status = ST_FINISHED;
             if (lane == 0) {
@@ -248,10 +274,21 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         }
         pos += wide_rec ? 2u : 1u;
 
+        if (CKPT && d && (d & cmask) == 0) {  // a checkpoint row: what a walker that starts at the top of this row needs
+            const uint64_t slot = T.mink_off + (uint64_t)((d >> cshift) - 1);
+            if (act0) ck_cells[slot * kCkptCells + (uint32_t)lane] = (uint32_t)x0 | ((uint32_t)org0 << 24);
+            if (act1) ck_cells[slot * kCkptCells + 64u + (uint32_t)lane] = (uint32_t)x1 | ((uint32_t)org1 << 24);
+            if (lane == 0) ck_hdr[slot] = make_uint2(pos, (uint32_t)min_k);
+            org0 = lane;
+            org1 = 64 + lane;
+        }
+
         max_k = min_k + 2 * jmax + 1;
         min_k = min_k + 2 * j - 1;
         px0 = x0;
         px1 = x1;
+        porg0 = org0;
+        porg1 = org1;
         pj = j;
         pwide = two;
     }
@@ -268,7 +305,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         o.max_band = max_band;
         o.cells = cells;
         o.trace_end = pos;
-        o.fin_idx = fin_idx;
+        o.fin_idx = fin_idx | (fin_org << 8);
         outs[tid] = o;
     }
 }
@@ -437,7 +474,7 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
     bool aborted = false;
     const uint64_t *__restrict__ S = trace + T.trace_off;
     uint32_t pos = STREAM ? (uint32_t)outs[gid].trace_end : 0u;  // one past the record of step d
-    int idx = outs[gid].fin_idx;                                  // cell index of diagonal k in step d
+    int idx = outs[gid].fin_idx & 0xff;                           // cell index of diagonal k in step d
     uint64_t hdr = (STREAM && pos) ? S[pos - 1] : 0ull;
     // the two words before the header: the second word of this record if it has one, and -- whichever length it has -- the header of the
     // record before it.  Loaded a step ahead of their use, so that the walk never waits for the record it steps into.
@@ -530,13 +567,302 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
 }
 
 
+// ---- K8a in segments -----------------------------------------------------------------------------------------------------------
+// The one-lane walk above is a chain of d dependent steps (5 x 10^4 for a 200 kb pair) on a device with half a million lanes.  Cut
+// it: the forward kernel left a checkpoint every C = 2^cshift steps (see K7, CKPT), the chase below names the cell the walk passes
+// through at every checkpoint row, and one lane per checkpoint -- a WALKER -- walks C rows.
+//
+// What a walker cannot know is its x: the reference's traceback extends a match run as far back as the bases agree
+// (lib/align.c:502-507), which may be further than the forward snake of that cell began, so at the top of a row the walk stands at
+// V[d][k] - 1 - o with an overshoot o >= 0 that depends on the rows above.  But o is forgotten quickly: wherever o(d) does not exceed
+// the length of cell (d, k)'s snake, o(d - 1) is a property of that cell alone.  So a walker starts `warm` rows ABOVE the rows it
+// owns with o = 0, walks them without output, and owns the rows from there on.  Nothing of that is assumed: every walker reports the
+// state (x, k) it reached at the top of its first owned row and the one it left behind its last, the stitch compares neighbours, and
+// a task with a boundary that does not agree (or with any other irregularity) is walked again by the one-lane kernel, which
+// overwrites every column word of the task.  The forced moves of lib/align.c:512 (x < k) leave the move bits' path; they are caught
+// by the same comparison (k is compared too).
+//
+// Where a column goes needs no count of the columns above it: from the finishing cell (x_f, y_f, d_f) to the top of row d at (x, y)
+// the walk has emitted ((x_f - 1 - x) + (y_f - 1 - y) + (d_f - d)) / 2 columns -- a match column consumes a base of both sequences,
+// a gap column one base and one row.  Walkers that share a 16-column word OR their part into it (the forward kernel zeroed the words).
+// The > 250-gap-columns abort (lib/align.c:542-545) counts across walkers: each reports the gap columns before its first match run
+// and behind its last, the stitch carries the count.
+
+__global__ __launch_bounds__(64) void tb_chase_kernel(const AlnTask *__restrict__ tasks, const AlnOut *__restrict__ outs,
+                                                       const uint32_t *__restrict__ ck_cells, const uint2 *__restrict__ ck_hdr,
+                                                       TbSeg *__restrict__ segs, int n_tasks, int cshift, int warm) {
+    const int gid = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (gid >= n_tasks) return;
+    const AlnTask T = tasks[gid];
+    const AlnOut O = outs[gid];
+    TbSeg *__restrict__ G = segs + T.seg_off;
+    const int cap = (T.max_d > 0 ? (T.max_d - 1) >> cshift : 0) + 1;  // walker slots of the task
+    int live = 0;
+    if (O.status == ST_FINISHED) {
+        const int n = O.d_final > 0 ? (O.d_final - 1) >> cshift : 0;  // checkpoint rows under the finishing step: C, 2C, ..., nC
+        const int C = 1 << cshift;
+        live = n + 1;
+        TbSeg g;
+        g.task = gid;
+        g.d_top = g.d_own = O.d_final;
+        g.d_end = n ? n * C - warm + 1 : 0;
+        g.x = O.x_final - 1;  // 0-based last query base (lib/align.c:492)
+        g.idx = O.fin_idx & 0xff;
+        g.min_k = O.k_final - 2 * g.idx;
+        g.pos = O.trace_end;
+        G[0] = g;
+        uint32_t cell = ((uint32_t)O.fin_idx >> 8) & 0xffu;
+        for (int i = n; i >= 1; --i) {
+            const uint64_t slot = T.mink_off + (uint64_t)(i - 1);
+            const uint32_t c = ck_cells[slot * kCkptCells + cell];
+            const uint2 h = ck_hdr[slot];
+            g.d_top = i * C;
+            g.d_own = i * C - warm;
+            g.d_end = i > 1 ? (i - 1) * C - warm + 1 : 0;
+            g.x = (int)(c & 0xffffffu) - 1;
+            g.idx = (int)cell;
+            g.min_k = (int)h.y;
+            g.pos = h.x;
+            G[n - i + 1] = g;
+            cell = c >> 24;
+        }
+    }
+    for (int w = live; w < cap; w++) G[w].task = -1;
+}
+
+// the record stream read back to front (see the one-lane kernel): header of the current row, the two words before it
+struct TbCursor {
+    uint32_t pos;
+    uint64_t hdr, c1, c2;
+};
+
+template <bool EMIT>
+__device__ __forceinline__ int tb_match_run(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint64_t q_off, uint64_t t_off,
+                                            int &x, int k, uint32_t &col, uint32_t &acc, uint32_t *__restrict__ W, bool &head) {
+    int total = 0;
+    for (;;) {
+        const int yy = x - k;
+        const int avail = (x < yy ? x : yy) + 1;
+        if (avail <= 0) break;
+        const int n = avail < 64 ? avail : 64;
+        const Bases64 a = fetch64_abs(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
+        const Bases64 b = fetch64_abs(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
+        int m = n;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            const int nb = n - 16 * i;
+            if (nb <= 0) continue;
+            uint32_t diff = a.w[i] ^ b.w[i];
+            if (nb < 16) diff &= (1u << (2 * nb)) - 1u;
+            if (diff) {
+                m = n - 1 - (16 * i + ((31 - __builtin_clz(diff)) >> 1));
+                break;
+            }
+        }
+        if (m) {
+            if (EMIT) {
+                int left_to_emit = m;  // match columns are code 0: only the cursor moves
+                while (left_to_emit > 0) {
+                    const uint32_t room = ((col - 1u) & 15u) + 1u;
+                    const uint32_t take = (uint32_t)left_to_emit < room ? (uint32_t)left_to_emit : room;
+                    col -= take;
+                    left_to_emit -= (int)take;
+                    if ((col & 15u) == 0) {
+                        if (head) atomicOr(&W[col >> 4], acc);  // the walker's first word: the walker above may hold its upper columns
+                        else W[col >> 4] = acc;
+                        head = false;
+                        acc = 0;
+                    }
+                }
+            }
+            x -= m;
+            total += m;
+        }
+        if (m < n) break;
+    }
+    return total;
+}
+
+__global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ segs, TbSegOut *__restrict__ seg_outs,
+                                                      const AlnTask *__restrict__ tasks, const AlnOut *__restrict__ outs,
+                                                      const uint32_t *__restrict__ pool, const uint32_t *__restrict__ db_pool,
+                                                      const uint64_t *__restrict__ trace, uint32_t *__restrict__ ops, int n_slots) {
+    const int slot = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (slot >= n_slots) return;
+    const TbSeg G = segs[slot];
+    if (G.task < 0) return;
+    const AlnTask T = tasks[G.task];
+    const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
+    const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
+    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
+    const uint64_t *__restrict__ S = trace + T.trace_off;
+    uint32_t *__restrict__ W = ops + T.ops_off;
+
+    int x = G.x, k = G.min_k + 2 * G.idx, d = G.d_top, idx = G.idx;
+    uint32_t pos = G.pos;
+    uint64_t hdr = pos ? S[pos - 1] : 0ull;
+    uint64_t c1 = pos >= 2 ? S[pos - 2] : 0ull, c2 = pos >= 3 ? S[pos - 3] : 0ull;
+    uint32_t col = 0, acc = 0;
+    bool head = false;
+    TbSegOut R;
+    R.x_own = R.k_own = R.x_end = R.k_end = 0;
+    R.lead = R.trail = 0;
+    R.rows = 0;
+    R.flags = 0;
+
+    // one row: the move (lib/align.c:509-541) and the step into the record of the row below
+    auto move = [&](bool &left) {
+        if (x < k) left = true;  // lib/align.c:512: forced query-consuming move
+        else if (x >= 0) {
+            const bool second = idx >= kStreamBits && pos >= 2;
+            const uint64_t w = second ? c1 : hdr;
+            left = (w >> ((second ? idx - kStreamBits : idx) & 63)) & 1ull;
+        } else left = false;
+    };
+    auto step_down = [&](bool left) {
+        d--;
+        if (left) { k--; x--; } else k++;
+        const uint32_t len = 1u + (uint32_t)((hdr >> kStreamBits) & 1ull);
+        pos = pos > len ? pos - len : 0u;
+        hdr = pos ? (len == 1u ? c1 : c2) : 0ull;
+        idx += (int)(hdr >> (kStreamBits + 1)) - (left ? 1 : 0);
+        c1 = pos >= 2 ? S[pos - 2] : 0ull;
+        c2 = pos >= 3 ? S[pos - 3] : 0ull;
+    };
+
+    // the rows above the owned ones: the walk only (no columns, no gap count)
+    while (d > G.d_own) {
+        (void)tb_match_run<false>(qp, tp, q_off, t_off, x, k, col, acc, W, head);
+        if (x < 0 && x - k < 0) {
+            R.flags = kTbBad;
+            break;
+        }
+        bool left;
+        move(left);
+        step_down(left);
+    }
+    if (R.flags) {
+        seg_outs[slot] = R;
+        return;
+    }
+
+    R.x_own = x;
+    R.k_own = k;
+    {
+        const AlnOut O = outs[G.task];
+        const int done = ((O.x_final - 1 - x) + (O.y_final - 1 - (x - k)) + (O.d_final - d)) >> 1;  // columns the walk has emitted above
+        col = T.ops_cap - (uint32_t)(done < 0 ? 0 : done);
+    }
+    head = (col & 15u) != 0;
+    int gap = 0;
+    bool reset = false;
+    for (;;) {
+        if (tb_match_run<true>(qp, tp, q_off, t_off, x, k, col, acc, W, head)) {
+            gap = 0;
+            reset = true;
+        }
+        if (x < 0 && x - k < 0) {
+            R.flags |= d == 0 ? kTbTerminal : kTbBad;  // (the start of the alignment above row 0: the column count is not the closed form's)
+            break;
+        }
+        bool left;
+        move(left);
+        uint32_t code;
+        if (left) { code = 1u; if (x < 0) gap = 260; }
+        else { code = 2u; if (x - k < 0) gap = 260; }
+        if (gap < 260) {
+            col--;
+            acc |= code << ((col & 15u) * 2u);
+            if ((col & 15u) == 0) {
+                if (head) atomicOr(&W[col >> 4], acc);
+                else W[col >> 4] = acc;
+                head = false;
+                acc = 0;
+            }
+        }
+        if (!reset) R.lead++;
+        R.rows++;
+        if (gap++ > 250) {  // lib/align.c:542-545 (with the gap columns of this walker alone; the stitch adds what came before)
+            R.flags |= kTbAbort;
+            break;
+        }
+        step_down(left);
+        if (d < G.d_end) break;
+    }
+    if ((col & 15u) != 0 && acc) atomicOr(&W[col >> 4], acc);  // the last word: the walker below may hold its lower columns
+    R.x_end = x;
+    R.k_end = k;
+    R.trail = gap;
+    if (reset) R.flags |= kTbReset;
+    seg_outs[slot] = R;
+}
+
+// one lane per task: the walkers' boundaries, the gap count across them, the verdict.  A task it refuses keeps ST_FINISHED and is
+// walked by the one-lane kernel, launched behind this one over the same tasks (it skips every task that has its verdict).
+__global__ __launch_bounds__(64) void tb_stitch_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
+                                                        const TbSegOut *__restrict__ seg_outs, int n_tasks, int cshift) {
+    const int gid = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (gid >= n_tasks) return;
+    const AlnOut O = outs[gid];
+    if (O.status != ST_FINISHED) return;
+    const TbSegOut *__restrict__ R = seg_outs + tasks[gid].seg_off;
+    const int n = O.d_final > 0 ? (O.d_final - 1) >> cshift : 0;
+    bool bad = false, aborted = false, ended = false;
+    int gap = 0, px = 0, pk = 0;
+    for (int w = 0; w <= n && !bad && !aborted && !ended; w++) {
+        const TbSegOut r = R[w];
+        if (r.flags & kTbBad) bad = true;
+        else if (w && (r.x_own != px || r.k_own != pk)) bad = true;
+        else {
+            // gap columns in a row: a walker's first run continues the run the walker above ended with
+            if (r.lead && gap + r.lead - 1 > 250) aborted = true;
+            else if (r.flags & kTbAbort) aborted = true;
+            else {
+                gap = (r.flags & kTbReset) ? r.trail : gap + (int)r.rows;
+                px = r.x_end;
+                pk = r.k_end;
+                if (r.flags & kTbTerminal) {
+                    ended = true;
+                    if (w != n) bad = true;   // the alignment's start above the last walker's rows: not this kernel's case
+                } else if (w == n) bad = true;  // the last walker left row 0 without reaching the start: neither
+            }
+        }
+    }
+    outs[gid].fin_idx = O.fin_idx | kTbSeen | (bad ? kTbRefused : 0);  // (for the host's counts)
+    if (bad) return;
+    outs[gid].n_cols = aborted ? 2 : (O.x_final + O.y_final + O.d_final) >> 1;
+    outs[gid].status = aborted ? ST_GAP_ABORT : ST_ALIGNED;
+}
+
+
 }  // namespace
 
 void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, uint64_t *trace,
                         int n_tasks, void *stream, const int32_t *order) {
     if (n_tasks <= 0) return;
-    hipLaunchKernelGGL(ond_forward_kernel, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
-                       order);
+    hipLaunchKernelGGL(ond_forward_kernel<false>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
+                       order, (uint32_t *)nullptr, (uint2 *)nullptr, (uint32_t *)nullptr, 0);
+}
+
+void launch_ond_forward_ckpt(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, uint64_t *trace,
+                             uint32_t *ops, const TbArgs &tb, int n_tasks, void *stream, const int32_t *order) {
+    if (n_tasks <= 0) return;
+    hipLaunchKernelGGL(ond_forward_kernel<true>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
+                       order, tb.ck_cells, (uint2 *)tb.ck_hdr, ops, tb.cshift);
+}
+
+void launch_ond_traceback_seg(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, const uint64_t *trace,
+                              uint32_t *ops, const TbArgs &tb, int n_tasks, void *stream) {
+    if (n_tasks <= 0) return;
+    const dim3 per_task((unsigned)((n_tasks + 63) / 64)), per_slot((unsigned)((tb.n_slots + 63) / 64));
+    hipLaunchKernelGGL(tb_chase_kernel, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, tb.ck_cells, (const uint2 *)tb.ck_hdr, tb.segs,
+                       n_tasks, tb.cshift, tb.warm);
+    hipLaunchKernelGGL(tb_walk_kernel, per_slot, dim3(64), 0, (hipStream_t)stream, tb.segs, tb.seg_outs, tasks, outs, pool, db_pool, trace, ops,
+                       tb.n_slots);
+    hipLaunchKernelGGL(tb_stitch_kernel, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, tb.seg_outs, n_tasks, tb.cshift);
+    // what the stitch refused (still ST_FINISHED) in one piece
+    hipLaunchKernelGGL(ond_traceback_kernel<true>, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
+                       (const int32_t *)nullptr, ops, (const int32_t *)nullptr, n_tasks);
 }
 
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,

@@ -67,4 +67,4 @@ if __name__ == "__main__":
     rs, sub, off, seeds, res, st = run(gs, depth, max_piles=max_piles)
     print(json.dumps({"seeds": [int(s) for s in seeds], "digests": [digest(r) for r in res],
                       "stats": {k: st[k] for k in ("piles", "score_segments", "score_repairs", "score_slow_piles", "cells_msa", "links", "forward_ms",
-                                                    "traceback_ms", "lq_rounds", "lq_declined", "lq_ms")}}))
+                                                    "traceback_ms", "lq_rounds", "lq_declined", "lq_ms", "tb_tasks", "tb_walkers", "tb_fallbacks")}}))

@@ -88,6 +88,24 @@ def test_scoring_paths_agree(default_run, env, check):
     assert check(got["stats"]), got["stats"]
 
 
+@pytest.mark.parametrize("env,check", [
+    ({"NDGPU_K8_SEG": "0"}, lambda s: s["tb_tasks"] == 0),                                              # the one-lane kernel everywhere
+    ({"NDGPU_K8_MINLEN": "0"}, lambda s: s["tb_fallbacks"] * 1000 <= s["tb_tasks"]),                    # the rounds' short alignments in segments too
+    ({"NDGPU_K8_SEG": "64", "NDGPU_K8_WARM": "2"}, lambda s: s["tb_fallbacks"] > 100),                  # warm-up too short: the stitch refuses, the one-lane walk takes over
+    ({"NDGPU_K8_SEG": "1024", "NDGPU_K8_WARM": "64"}, lambda s: s["tb_fallbacks"] * 1000 <= s["tb_tasks"]),
+], ids=["one-lane", "every-launch", "short-warmup", "long-segments"])
+def test_traceback_forms_agree(default_run, env, check):
+    """K8a in segments (the default: 256 rows a walker, 32 rows of warm-up) against the one-lane walk and against other cuts, on every
+    config-2 pile; the default run itself is held against the compiled reference above."""
+    st = default_run["stats"]
+    assert st["tb_tasks"] > 100000 and st["tb_walkers"] > 5 * st["tb_tasks"] and st["tb_fallbacks"] * 1000 <= st["tb_tasks"], st
+    got = _driver(env)
+    assert got["seeds"] == default_run["seeds"]
+    bad = [i for i, (a, b) in enumerate(zip(got["digests"], default_run["digests"])) if a != b]
+    assert not bad, (len(bad), bad[:5])
+    assert check(got["stats"]), got["stats"]
+
+
 def test_lq_rounds_host_path_agrees(default_run):
     """The low-quality-region rounds on the device (K12: every round of the config-2 piles, a handful declined at most) against
     the host path of the same rounds (NDGPU_LQ_HOST: alignments as a batch, second MSA in the engine)."""

@@ -148,7 +148,8 @@ st = api.Stats()
 lib.ndgpu_get_stats(C.byref(st))
 print(json.dumps(dict(bad=bad, segments=int(st.score_segments), repairs=int(st.score_repairs), slow=int(st.score_slow_piles),
                       lq_rounds=int(st.lq_rounds), lq_declined=int(st.lq_declined), lq_jobs=int(st.lq_jobs),
-                      lq_repairs=int(st.lq_repairs))))
+                      lq_repairs=int(st.lq_repairs), tb_tasks=int(st.tb_tasks), tb_walkers=int(st.tb_walkers),
+                      tb_fallbacks=int(st.tb_fallbacks))))
 """
 
 
@@ -205,6 +206,89 @@ def test_lq_rounds_cut_into_speculative_jobs(simt_lib, env, repairs):
         assert r["lq_repairs"] > 0, r
     elif repairs is False:
         assert r["lq_repairs"] == 0, r
+
+
+@pytest.mark.parametrize("env,fallbacks", [
+    ({"NDGPU_K8_SEG": "16", "NDGPU_K8_WARM": "8", "NDGPU_K8_MINLEN": "0"}, None),     # ~60 walkers per kb of alignment, main phase and rounds alike
+    ({"NDGPU_K8_SEG": "16", "NDGPU_K8_WARM": "1", "NDGPU_K8_MINLEN": "0", "SIMT_SCHEDULE": "1"}, True),   # one warm-up row: boundaries disagree, the one-lane walk takes over
+    ({"NDGPU_K8_SEG": "64", "NDGPU_K8_WARM": "64", "NDGPU_K8_MINLEN": "0", "SIMT_LANES_DESCENDING": "1"}, None),
+    ({"NDGPU_K8_MINLEN": "0"}, False),                                                  # the product's segment length and warm-up on every launch
+    ({"NDGPU_K8_SEG": "0"}, "off"),                                                     # the one-lane kernel everywhere
+])
+def test_traceback_in_segments(simt_lib, env, fallbacks):
+    """K8a cut into walkers (checkpoints of the forward kernel, chase, one lane per 2^k edit steps from a speculative x, stitch, the
+    one-lane walk for what the stitch refuses): whatever the segment length and the warm-up, the records are the reference's."""
+    r = _forced(env, stride=1)
+    assert r["bad"] == [], r
+    if fallbacks == "off":
+        assert r["tb_tasks"] == 0, r
+        return
+    assert r["tb_tasks"] > 100 and r["tb_walkers"] > r["tb_tasks"], r
+    if fallbacks is True:
+        assert r["tb_fallbacks"] > 0, r
+    elif fallbacks is False:
+        assert r["tb_fallbacks"] == 0, r
+
+
+_CHILD_ALIGN = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, util, build_simt
+from nextdenovo_amd import api, synth
+lib = C.CDLL(build_simt.build())
+api._LIB = api._bind(lib)
+ora = C.CDLL(%r)
+rng = np.random.default_rng(11)
+bad, n_ok = [], 0
+for p in util.load_pairs():
+    n, tu, qu, ts, qs = util.gpu_align(lib, p["q"], p["t"], p["hq"])
+    if n != p["aln_len"] or (n > 2 and (not np.array_equal(util.strings_to_ops(ts, qs), p["ops"]) or (tu, qu) != (p["t_used"], p["q_used"]))):
+        bad.append("golden")
+for it in range(60):
+    L = int(rng.integers(50, 5000))
+    kind = it %% 6
+    base = rng.integers(0, 4 if kind else 2, L, dtype=np.uint8)
+    if kind == 3 and L > 200:                       # homopolymers and tandem repeats: the walk's overshoot can outlast many rows
+        for _ in range(20):
+            unit = rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8)
+            at = int(rng.integers(0, L - 90))
+            base[at:at + 80] = np.resize(unit, 80)
+    prof = ("ont", "clr", "hifi")[it %% 3]
+    q = synth.mutate(base, np.random.default_rng(3 * it + 100), prof)[0]
+    t = synth.mutate(base, np.random.default_rng(3 * it + 101), prof)[0]
+    if kind == 4:                                   # a query prefix the target lacks: the walk runs along the edge (forced moves, lib/align.c:512)
+        q = np.concatenate([rng.integers(0, 4, int(rng.integers(5, 150)), dtype=np.uint8), q])
+    if kind == 5:
+        t = np.concatenate([rng.integers(0, 4, int(rng.integers(5, 150)), dtype=np.uint8), t])
+    hq = int(it %% 7 == 0)
+    qa, ta = util.ASC[q].tobytes(), util.ASC[t].tobytes()
+    o, ots, oqs, _ = util.oracle_align(ora, qa, ta, hq)
+    n, tu, qu, ts, qs = util.gpu_align(lib, qa, ta, hq)
+    if n != o.aln_len or (o.status == 1 and (ts != ots or qs != oqs or (tu, qu) != (o.t_used, o.q_used))):
+        bad.append(it)
+    n_ok += o.status == 1
+st = api.stats()
+print(json.dumps(dict(bad=bad, ok=int(n_ok), tb_tasks=st["tb_tasks"], tb_walkers=st["tb_walkers"], tb_fallbacks=st["tb_fallbacks"])))
+"""
+
+
+@pytest.mark.parametrize("env", [
+    {"NDGPU_K8_SEG": "16", "NDGPU_K8_WARM": "4", "NDGPU_K8_MINLEN": "0"},
+    {"NDGPU_K8_SEG": "32", "NDGPU_K8_WARM": "32", "NDGPU_K8_MINLEN": "0", "SIMT_LANES_DESCENDING": "1"},
+    {"NDGPU_K8_SEG": "256", "NDGPU_K8_WARM": "32", "NDGPU_K8_MINLEN": "0"},
+])
+def test_align_in_segments_vs_oracle(simt_lib, oracle_lib, env):
+    """The C-ABI `align` with the traceback in segments: the reference's golden pairs (failures, the > 250-gap marker, wide bands) and 60
+    fuzzed pairs -- low-complexity sequence, one-sided overhangs -- against the oracle, with boundaries that do and do not agree."""
+    e = dict(os.environ, NDGPU_CONTEXTS="1", **env)
+    out = subprocess.run([sys.executable, "-c", _CHILD_ALIGN % (os.path.dirname(HERE), HERE, os.path.join(HERE, "simt"), oracle_lib._name)], env=e,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["bad"] == [] and r["ok"] > 40, r
+    assert r["tb_tasks"] > 60 and r["tb_walkers"] > r["tb_tasks"], r
+    if env["NDGPU_K8_WARM"] == "4":
+        assert r["tb_fallbacks"] > 0, r
 
 
 def _synth_set(gsize, mu, sigma, seed, depth=30, profile="ont"):

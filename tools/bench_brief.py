@@ -16,6 +16,7 @@ for p in sys.argv[1:]:
     print("   steps %s" % sm.get("list"))
     print("   kernel_ms/step %s" % {k: round(v / d["steps"], 1) for k, v in d["kernel_ms"].items()})
     c = d["counters"]
+    print("   traceback in segments: tasks %s walkers %s fallbacks %s" % (c.get("tb_tasks"), c.get("tb_walkers"), c.get("tb_fallbacks")))
     print("   lq rounds %s declined %s jobs %s repairs %s | host %s" % (c.get("lq_rounds"), c.get("lq_declined"), c.get("lq_jobs"), c.get("lq_repairs"),
                                                                         {k: d.get("host", {}).get(k) for k in ("cpu_model", "cpu_count", "host_threads", "before", "after")}))
     if "cpu_baseline" in d and d["cpu_baseline"]:
