@@ -60,6 +60,9 @@ def parse(argv=None):
                          "the output is part of the stage)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="consensus stage only, on analytically derived piles")
+    ap.add_argument("--consensus-depth", type=int, default=2, help="consensus calls in flight (1: a step's consensus ends before the next begins)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not start the overlap / sort / pile-admission stage of the next step while the consensus of this one runs")
     ap.add_argument("--no-exchange", action="store_true",
                     help="N > 1: every rank computes the mirror jobs it needs itself instead of taking them from the rank that owns them "
                          "(nextdenovo_amd/stage.py: Exchange)")
@@ -502,35 +505,81 @@ def main():
     fasta_bytes = [0]
     last_res = []
 
-    def step():
+    # The stage of the NEXT seed file begins while this one's consensus runs (a node has more seed files than GPUs: nextDenovo:344-354
+    # runs sort_align / seed_cns once per seed file, and the raw_align jobs of the next one are independent of this one's consensus):
+    # its overlap, sort and pile-admission kernels fill what the consensus kernels leave of the device, its host work what the
+    # contexts' host phases leave of the CPUs.  Every timed step still runs BOTH halves inside the timed region: the first timed step
+    # computes its own piles (nothing is prefetched across the start of the clock), the last one prefetches nothing.
+    import threading
+    pipeline = {"on": not (args.no_pipeline or args.no_overlap), "thread": None, "result": None, "error": None, "hidden_s": 0.0, "wait_s": 0.0}
+
+    def prefetch_piles():
+        try:
+            pipeline["result"] = sh.piles(my_file)
+        except BaseException as e:   # noqa: BLE001  (taken up by the step that wanted the piles)
+            pipeline["error"] = e
+
+    def get_piles(prefetch_next=False):
+        """(records, pile offsets, names) of this step: computed here, or taken from the thread that was started during the step before."""
         if args.no_overlap:
-            r_, o_, names = a_recs, a_off, a_names
+            return a_recs, a_off, a_names
+        th = pipeline["thread"]
+        if th is not None:
+            t_j = time.perf_counter()
+            th.join()
+            pipeline["wait_s"] += time.perf_counter() - t_j
+            pipeline["thread"] = None
+            err, res_p = pipeline["error"], pipeline["result"]
+            pipeline["error"] = pipeline["result"] = None
+            if isinstance(err, MemoryError):   # the two stages do not fit the device side by side: one after the other from here on
+                sys.stderr.write("[bench] overlap stage out of device memory beside the consensus: pipelining off\n")
+                pipeline["on"] = False
+                res_p = sh.piles(my_file)
+            elif err is not None:
+                raise err
+            sub, off, seeds, n_bl = res_p
         else:
             sub, off, seeds, n_bl = sh.piles(my_file)
-            last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
-            r_, o_, names = (a_recs, a_off, a_names) if analytic else (sub, off, seeds)
+        last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
+        if prefetch_next and pipeline["on"]:
+            pipeline["thread"] = threading.Thread(target=prefetch_piles)
+            pipeline["thread"].start()
+        return (a_recs, a_off, a_names) if analytic else (sub, off, seeds)
+
+    acc_lock = threading.Lock()
+
+    def consensus(r_, o_, names, path):
+        """The consensus half of a step: every admitted pile through the library, cns.fasta + .idx written as the sub-batches finish."""
         t_c = time.perf_counter()
         n_ok = b_ok = 0
         if args.lengths_only:
             res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads, lengths_only=True)
             t_w = time.perf_counter()
-            cns_wall[0] += t_w - t_c
+            with acc_lock:
+                cns_wall[0] += t_w - t_c
         else:
-            with open(fa_path, "wb") as OUT, open(fa_path + ".idx", "wb") as IDX:
+            with open(path, "wb") as OUT, open(path + ".idx", "wb") as IDX:
                 t_lib = [0.0, 0.0]
                 res = db.correct_piles(r_, o_, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads,
                                        fasta=(OUT, IDX, names, 500, 0.8), lib_wall=t_lib)
                 t_w = t_c + t_lib[0]
-                cns_wall[0] += t_lib[0]
-                stream_wall[0] += t_lib[1]
-                fasta_bytes[0] = OUT.tell()
-        last_res[:] = [res]
+                with acc_lock:
+                    cns_wall[0] += t_lib[0]
+                    stream_wall[0] += t_lib[1]
+                    fasta_bytes[0] = OUT.tell()
         # accepted records exactly as lib/nextcorrect.py:236 (len >= min_len_seed(=seed_cutoff/2), identity >= ratio)
         for ln, ide in res:
             if ln >= 500 and ln > 4 and ide >= 0.8:
                 n_ok += 1
                 b_ok += ln
-        write_wall[0] += time.perf_counter() - t_w
+        with acc_lock:
+            write_wall[0] += time.perf_counter() - t_w
+        return b_ok, n_ok, res, path
+
+    def step(prefetch_next=False):
+        r_, o_, names = get_piles(prefetch_next)
+        b_ok, n_ok, res, _ = consensus(r_, o_, names, fa_path)
+        last_res[:] = [res]
         return b_ok, n_ok
 
     for _ in range(args.warmup):
@@ -549,12 +598,40 @@ def main():
     t0 = time.perf_counter()
     bases = n_ok = 0
     step_s = []
-    for _ in range(args.steps):
-        t_s = time.perf_counter()
-        b, n = step()
-        step_s.append(time.perf_counter() - t_s)
-        bases += b
-        n_ok += n
+    # Two consensus calls in flight (--consensus-depth 2, with pipelining on): a call ends with its last sub-batches' low-quality-region
+    # stages -- host ranking and POA, two rounds of small launches -- and little else on the device; the next call's main phases fill
+    # that.  The contexts serve both calls: a context takes a sub-batch of the newer call when the older one has none left for it.
+    depth = 2 if (pipeline["on"] and args.consensus_depth >= 2 and args.steps > 1) else 1
+    pipeline["depth"] = depth
+    if depth == 1:
+        for k_step in range(args.steps):
+            t_s = time.perf_counter()
+            b, n = step(prefetch_next=k_step + 1 < args.steps)
+            step_s.append(time.perf_counter() - t_s)
+            bases += b
+            n_ok += n
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        inflight = []
+        t_last = t0
+        with ThreadPoolExecutor(max_workers=depth) as pool_x:
+            def finish(fut):
+                nonlocal bases, n_ok, t_last
+                b, n, res, path = fut.result()
+                now = time.perf_counter()
+                step_s.append(now - t_last)   # (completion to completion)
+                t_last = now
+                bases += b
+                n_ok += n
+                last_res[:] = [res]
+                last["fa_path"] = path
+            for k_step in range(args.steps):
+                r_, o_, names = get_piles(prefetch_next=k_step + 1 < args.steps)
+                inflight.append(pool_x.submit(consensus, r_, o_, names, fa_path + (".%d" % (k_step % depth))))
+                while len(inflight) >= depth:
+                    finish(inflight.pop(0))
+            while inflight:
+                finish(inflight.pop(0))
     sync()
     dt = time.perf_counter() - t0
     host1 = host_snapshot()
@@ -671,6 +748,12 @@ def main():
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms", "lq_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
+            "pipeline": {"next_stage_begins_during_consensus": bool(pipeline["on"]), "consensus_calls_in_flight": pipeline.get("depth", 1),
+                         "wait_for_prefetched_piles_ms_per_step": pipeline["wait_s"] / args.steps * 1e3,
+                         "note": "with pipelining the overlap / sort / pile-admission stage of step k + 1 runs on its own host thread and "
+                                 "streams while the consensus of step k holds the device; the first timed step computes its piles itself and "
+                                 "the last one prefetches nothing, so K overlap stages and K consensus stages lie inside the timed region; "
+                                 "the per-stage times then add up to more than ms_per_step (--no-pipeline: one stage after the other)"},
             "fasta_write": {"ms_per_step": (write_wall[0] + stream_wall[0]) / args.steps * 1e3, "bytes_per_step": fasta_bytes[0],
                             "of_which_after_the_last_sub_batch_ms": write_wall[0] / args.steps * 1e3,
                             "how": "records written sub-batch by sub-batch from the library's completion callback while later sub-batches "
@@ -721,6 +804,7 @@ def main():
         parity_fail = False
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             out["cpu_baseline"], ref = cpu_baseline(rs, piles, read_type, args.cpu_sample, max_lq)
+            fa_path = last.get("fa_path", fa_path)   # (the file of the step that ended last)
             if ref and not args.lengths_only and last_res and os.path.exists(fa_path):
                 # what the LAST TIMED STEP wrote: (len, identity) of every pile from the library's records, the bases from the
                 # step's cns.fasta (a record the output filter dropped has no bases there: length and identity only)

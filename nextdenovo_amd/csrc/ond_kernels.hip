@@ -636,9 +636,9 @@ struct TbCursor {
     uint64_t hdr, c1, c2;
 };
 
-template <bool EMIT>
+// the match run behind (x, x - k), back to front (lib/align.c:502-507), 64 bases per compare; returns its length, x moves
 __device__ __forceinline__ int tb_match_run(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint64_t q_off, uint64_t t_off,
-                                            int &x, int k, uint32_t &col, uint32_t &acc, uint32_t *__restrict__ W, bool &head) {
+                                            int &x, int k) {
     int total = 0;
     for (;;) {
         const int yy = x - k;
@@ -659,25 +659,8 @@ __device__ __forceinline__ int tb_match_run(const uint32_t *__restrict__ qp, con
                 break;
             }
         }
-        if (m) {
-            if (EMIT) {
-                int left_to_emit = m;  // match columns are code 0: only the cursor moves
-                while (left_to_emit > 0) {
-                    const uint32_t room = ((col - 1u) & 15u) + 1u;
-                    const uint32_t take = (uint32_t)left_to_emit < room ? (uint32_t)left_to_emit : room;
-                    col -= take;
-                    left_to_emit -= (int)take;
-                    if ((col & 15u) == 0) {
-                        if (head) atomicOr(&W[col >> 4], acc);  // the walker's first word: the walker above may hold its upper columns
-                        else W[col >> 4] = acc;
-                        head = false;
-                        acc = 0;
-                    }
-                }
-            }
-            x -= m;
-            total += m;
-        }
+        x -= m;
+        total += m;
         if (m < n) break;
     }
     return total;
@@ -702,8 +685,6 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
     uint32_t pos = G.pos;
     uint64_t hdr = pos ? S[pos - 1] : 0ull;
     uint64_t c1 = pos >= 2 ? S[pos - 2] : 0ull, c2 = pos >= 3 ? S[pos - 3] : 0ull;
-    uint32_t col = 0, acc = 0;
-    bool head = false;
     TbSegOut R;
     R.x_own = R.k_own = R.x_end = R.k_end = 0;
     R.lead = R.trail = 0;
@@ -732,7 +713,7 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
 
     // the rows above the owned ones: the walk only (no columns, no gap count)
     while (d > G.d_own) {
-        (void)tb_match_run<false>(qp, tp, q_off, t_off, x, k, col, acc, W, head);
+        (void)tb_match_run(qp, tp, q_off, t_off, x, k);
         if (x < 0 && x - k < 0) {
             R.flags = kTbBad;
             break;
@@ -748,16 +729,23 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
 
     R.x_own = x;
     R.k_own = k;
+    uint32_t col;
     {
         const AlnOut O = outs[G.task];
         const int done = ((O.x_final - 1 - x) + (O.y_final - 1 - (x - k)) + (O.d_final - d)) >> 1;  // columns the walk has emitted above
         col = T.ops_cap - (uint32_t)(done < 0 ? 0 : done);
     }
-    head = (col & 15u) != 0;
+    // Column words: a match column is code 0 and the words were zeroed by the forward kernel, so a match run only moves the cursor;
+    // gap columns collect in `acc` until the cursor leaves their word.  The walker's first word may hold columns of the walker above
+    // and its last one columns of the walker below: those two are OR-ed into place, every word between them is this walker's alone.
+    const uint32_t head_w = (col & 15u) ? (col >> 4) : 0xffffffffu;
+    uint32_t cur_w = col >> 4, acc = 0;
     int gap = 0;
     bool reset = false;
     for (;;) {
-        if (tb_match_run<true>(qp, tp, q_off, t_off, x, k, col, acc, W, head)) {
+        const int m = tb_match_run(qp, tp, q_off, t_off, x, k);
+        if (m) {
+            col -= (uint32_t)m;
             gap = 0;
             reset = true;
         }
@@ -772,13 +760,16 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
         else { code = 2u; if (x - k < 0) gap = 260; }
         if (gap < 260) {
             col--;
-            acc |= code << ((col & 15u) * 2u);
-            if ((col & 15u) == 0) {
-                if (head) atomicOr(&W[col >> 4], acc);
-                else W[col >> 4] = acc;
-                head = false;
+            const uint32_t wi = col >> 4;
+            if (wi != cur_w) {
+                if (acc) {
+                    if (cur_w == head_w) atomicOr(&W[cur_w], acc);
+                    else W[cur_w] = acc;
+                }
                 acc = 0;
+                cur_w = wi;
             }
+            acc |= code << ((col & 15u) * 2u);
         }
         if (!reset) R.lead++;
         R.rows++;
@@ -789,7 +780,7 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
         step_down(left);
         if (d < G.d_end) break;
     }
-    if ((col & 15u) != 0 && acc) atomicOr(&W[col >> 4], acc);  // the last word: the walker below may hold its lower columns
+    if (acc) atomicOr(&W[cur_w], acc);
     R.x_end = x;
     R.k_end = k;
     R.trail = gap;
