@@ -574,11 +574,11 @@ def main():
                 b_ok += ln
         with acc_lock:
             write_wall[0] += time.perf_counter() - t_w
-        return b_ok, n_ok, res, path
+        return b_ok, n_ok, res, path, time.perf_counter()
 
     def step(prefetch_next=False):
         r_, o_, names = get_piles(prefetch_next)
-        b_ok, n_ok, res, _ = consensus(r_, o_, names, fa_path)
+        b_ok, n_ok, res, _, _ = consensus(r_, o_, names, fa_path)
         last_res[:] = [res]
         return b_ok, n_ok
 
@@ -615,16 +615,17 @@ def main():
         inflight = []
         t_last = t0
         with ThreadPoolExecutor(max_workers=depth) as pool_x:
+            ends = []
+
             def finish(fut):
-                nonlocal bases, n_ok, t_last
-                b, n, res, path = fut.result()
-                now = time.perf_counter()
-                step_s.append(now - t_last)   # (completion to completion)
-                t_last = now
+                nonlocal bases, n_ok
+                b, n, res, path, t_end = fut.result()
+                ends.append(t_end)
                 bases += b
                 n_ok += n
-                last_res[:] = [res]
-                last["fa_path"] = path
+                if t_end >= max(ends):   # (the parity block reads the file of the call that ended last)
+                    last_res[:] = [res]
+                    last["fa_path"] = path
             for k_step in range(args.steps):
                 r_, o_, names = get_piles(prefetch_next=k_step + 1 < args.steps)
                 inflight.append(pool_x.submit(consensus, r_, o_, names, fa_path + (".%d" % (k_step % depth))))
@@ -632,6 +633,10 @@ def main():
                     finish(inflight.pop(0))
             while inflight:
                 finish(inflight.pop(0))
+            # a step's time = from the end of the call before it to its own end, in the order the calls ended (two are in flight)
+            for t_end in sorted(ends):
+                step_s.append(t_end - t_last)
+                t_last = t_end
     sync()
     dt = time.perf_counter() - t0
     host1 = host_snapshot()

@@ -391,6 +391,7 @@ int ndgpu_correct_piles_stream(ndgpu_db *h, int n_piles, const uint32_t *recs, c
         }
     }
     join_reapers();  // the previous call's teardown
+    const uint64_t call_order = DeviceAligner::next_order();  // (an older call in flight goes first on every context)
     const auto t_call0 = std::chrono::steady_clock::now();
     std::atomic<uint64_t> build_ns{0}, take_ns{0};
     // piles per sub-batch at most (the cost target below normally cuts earlier)
@@ -531,7 +532,7 @@ int ndgpu_correct_piles_stream(ndgpu_db *h, int n_piles, const uint32_t *recs, c
         build_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_b0).count();
         bool oom = false;
         try {
-            HipBackend be(ctx, threads_each, h->dev_pool);
+            HipBackend be(ctx, threads_each, h->dev_pool, call_order);
             run_engines(eng.data(), cnt, be, threads_each);
         } catch (const DeviceOom &e) {
             oom = true;

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <set>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -290,7 +291,34 @@ struct DeviceAligner::State {
     std::vector<int32_t> order;
     std::vector<uint32_t> order_cls;
     // main-phase state (alive from run_main to end_batch)
-    std::mutex batch_mu;
+    // Held from begin_batch to end_batch.  Not a plain mutex: with two batch calls in flight (the caller's pipeline: the tail of one
+    // call under the main phases of the next) the context must serve the OLDER call's sub-batches first, whichever thread asked first.
+    struct OrderedLock {
+        std::mutex m;
+        std::condition_variable cv;
+        bool held = false;
+        std::multiset<uint64_t> waiting;
+        void lock(uint64_t order = 0) {
+            std::unique_lock<std::mutex> l(m);
+            auto it = waiting.insert(order);
+            cv.wait(l, [&] { return !held && *waiting.begin() == order; });
+            waiting.erase(it);
+            held = true;
+        }
+        void unlock() {
+            {
+                std::lock_guard<std::mutex> l(m);
+                held = false;
+            }
+            cv.notify_all();
+        }
+        bool try_lock() {
+            std::lock_guard<std::mutex> l(m);
+            if (held || !waiting.empty()) return false;
+            held = true;
+            return true;
+        }
+    } batch_mu;
     DevBuf<ReadDev> d_reads;
     DevBuf<PileDev> d_piles;
     DevBuf<uint32_t> d_read_pile, d_acc, d_tags, d_colidx, d_cov /* coverage | insertion counts | longest insertion: one block, one fill */, d_cellbase, d_entbase;
@@ -572,7 +600,7 @@ void DeviceAligner::level_buffers(int drivers) {
         State &S = *d->s_;
         // a context with a batch open (another caller's thread) keeps its main-phase buffers alive between run_main and end_batch:
         // growing them here would free live device state.  It is skipped, like release_memory_if_idle skips it.
-        std::unique_lock<std::mutex> batch(S.batch_mu, std::try_to_lock);
+        std::unique_lock<State::OrderedLock> batch(S.batch_mu, std::try_to_lock);
         if (!batch.owns_lock()) continue;
         std::lock_guard<std::mutex> lock(S.mu);
         (void)hipSetDevice(S.device);
@@ -1354,7 +1382,11 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     g_prof.c_pack += tc1 - tc0, g_prof.c_dev += tc2 - tc1, g_prof.c_decode += wall_ns() - tc2, g_prof.c_jobs += nt;
 }
 
-void DeviceAligner::begin_batch() { s_->batch_mu.lock(); }
+void DeviceAligner::begin_batch(uint64_t order) { s_->batch_mu.lock(order); }
+uint64_t DeviceAligner::next_order() {
+    static std::atomic<uint64_t> n{1};
+    return n.fetch_add(1);
+}
 void DeviceAligner::end_batch() { s_->batch_mu.unlock(); }
 
 // Main phase of a batch of piles, entirely on the device:

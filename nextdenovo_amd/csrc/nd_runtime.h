@@ -83,7 +83,10 @@ class DeviceAligner {
     void align_batch(AlnJob **jobs, size_t n);
     // device main phase / candidate extraction of a batch of piles (see Backend in nd_host.h);
     // begin_batch()/end_batch() bracket one batch and serialise batches of one process
-    void begin_batch();
+    // order: who goes first when several callers wait for this context (lower first; equal: any) -- the calls of a process take a
+    // number each (next_order), so that a context serves the older of two batch calls in flight before the newer one
+    void begin_batch(uint64_t order = 0);
+    static uint64_t next_order();
     void run_main(MainPile **piles, size_t n);
     void run_extract(ExtractPile **piles, size_t n);
     void run_lq(LqRound **rounds, size_t n);
@@ -119,8 +122,9 @@ class DeviceAligner {
 // The product's only Backend: every request runs in HIP kernels on the device.
 class HipBackend : public Backend {
   public:
-    explicit HipBackend(int ctx = 0, int host_threads = 1, const uint32_t *db_pool = nullptr) : dev_(DeviceAligner::context(ctx)) {
-        dev_.begin_batch();
+    explicit HipBackend(int ctx = 0, int host_threads = 1, const uint32_t *db_pool = nullptr, uint64_t order = ~0ull)
+        : dev_(DeviceAligner::context(ctx)) {
+        dev_.begin_batch(order == ~0ull ? DeviceAligner::next_order() : order);
         dev_.set_host_threads(host_threads);
         dev_.use_db(db_pool);
     }
