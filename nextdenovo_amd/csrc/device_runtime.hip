@@ -282,6 +282,7 @@ struct DeviceAligner::State {
     DevBuf<uint64_t> d_trace;
     DevBuf<uint64_t> d_wtrace;  // wide-band alignments (K7w): trace rows and their min_k -- members, not locals of run_wide: a local
     DevBuf<int32_t> d_wmink;    // buffer was a hipMalloc + hipFree per call, and hipFree waits for every stream of the device
+    DevBuf<AlnTask> d_wtasks;   // the wide tasks' records of one group, in list order (one upload, not one per task)
     DevBuf<int32_t> d_v, d_ids;
     // segmented traceback (ond_kernels.hip): checkpoint cells / headers the forward kernel leaves, the walkers and what they report
     DevBuf<uint32_t> d_ck_cells;
@@ -467,7 +468,7 @@ DeviceAligner::DeviceAligner() : s_(new State) {
     NDGPU_NAME(h_ops) NDGPU_NAME(h_outs) NDGPU_NAME(up) NDGPU_NAME(down)
     NDGPU_NAME(d_lq_piles) NDGPU_NAME(d_lq_pieces) NDGPU_NAME(d_lq_rec) NDGPU_NAME(d_lq_jobs) NDGPU_NAME(d_lq_hdr) NDGPU_NAME(d_lq_lnk)
     NDGPU_NAME(d_lq_out) NDGPU_NAME(d_lq_tmp) NDGPU_NAME(d_lq_bnd)
-    NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v) NDGPU_NAME(d_wtrace) NDGPU_NAME(d_wmink)
+    NDGPU_NAME(d_pool) NDGPU_NAME(d_ops) NDGPU_NAME(d_tasks) NDGPU_NAME(d_outs) NDGPU_NAME(d_trace) NDGPU_NAME(d_v) NDGPU_NAME(d_wtrace) NDGPU_NAME(d_wmink) NDGPU_NAME(d_wtasks)
     NDGPU_NAME(d_ck_cells) NDGPU_NAME(d_ck_hdr) NDGPU_NAME(d_tbseg) NDGPU_NAME(d_tbout)
     NDGPU_NAME(d_ids) NDGPU_NAME(d_reads) NDGPU_NAME(d_piles) NDGPU_NAME(d_read_pile) NDGPU_NAME(d_acc) NDGPU_NAME(d_tags)
     NDGPU_NAME(d_colidx) NDGPU_NAME(d_cov) NDGPU_NAME(d_cellbase) NDGPU_NAME(d_entbase)
@@ -577,7 +578,7 @@ void DeviceAligner::release_memory() {
 #define NDGPU_REL(x) S.x.release();
     NDGPU_REL(d_lq_piles) NDGPU_REL(d_lq_pieces) NDGPU_REL(d_lq_rec) NDGPU_REL(d_lq_jobs) NDGPU_REL(d_lq_hdr) NDGPU_REL(d_lq_lnk)
     NDGPU_REL(d_lq_out) NDGPU_REL(d_lq_tmp) NDGPU_REL(d_lq_bnd)
-    NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v) NDGPU_REL(d_wtrace) NDGPU_REL(d_wmink)
+    NDGPU_REL(d_pool) NDGPU_REL(d_ops) NDGPU_REL(d_tasks) NDGPU_REL(d_outs) NDGPU_REL(d_trace) NDGPU_REL(d_v) NDGPU_REL(d_wtrace) NDGPU_REL(d_wmink) NDGPU_REL(d_wtasks)
     NDGPU_REL(d_ck_cells) NDGPU_REL(d_ck_hdr) NDGPU_REL(d_tbseg) NDGPU_REL(d_tbout)
     NDGPU_REL(d_ids) NDGPU_REL(d_reads) NDGPU_REL(d_piles) NDGPU_REL(d_read_pile) NDGPU_REL(d_acc) NDGPU_REL(d_tags)
     NDGPU_REL(d_colidx) NDGPU_REL(d_cov) NDGPU_REL(d_cellbase) NDGPU_REL(d_entbase)
@@ -622,7 +623,7 @@ void DeviceAligner::level_buffers(int drivers) {
         try {
 #define NDGPU_LVL(x) lvl(S.x, #x[0] == 'd');
             NDGPU_LVL(d_lq_piles) NDGPU_LVL(d_lq_pieces) NDGPU_LVL(d_lq_rec) NDGPU_LVL(d_lq_jobs) NDGPU_LVL(d_lq_hdr) NDGPU_LVL(d_lq_lnk) NDGPU_LVL(d_lq_out) NDGPU_LVL(d_lq_tmp) NDGPU_LVL(d_lq_bnd)
-            NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v) NDGPU_LVL(d_wtrace) NDGPU_LVL(d_wmink)
+            NDGPU_LVL(d_pool) NDGPU_LVL(d_ops) NDGPU_LVL(d_tasks) NDGPU_LVL(d_outs) NDGPU_LVL(d_trace) NDGPU_LVL(d_v) NDGPU_LVL(d_wtrace) NDGPU_LVL(d_wmink) NDGPU_LVL(d_wtasks)
             NDGPU_LVL(d_ck_cells) NDGPU_LVL(d_ck_hdr) NDGPU_LVL(d_tbseg) NDGPU_LVL(d_tbout)
             NDGPU_LVL(d_ids) NDGPU_LVL(d_reads) NDGPU_LVL(d_piles) NDGPU_LVL(d_read_pile) NDGPU_LVL(d_acc) NDGPU_LVL(d_tags)
             NDGPU_LVL(d_colidx) NDGPU_LVL(d_cov) NDGPU_LVL(d_cellbase) NDGPU_LVL(d_entbase)
@@ -1016,15 +1017,23 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
         mink.reserve(mr + 2);
         S.d_v.reserve(vw + 2);
         S.d_ids.reserve(take);
+        S.d_wtasks.reserve(take);
         hipStream_t st = S.stream;
+        // the group's records go up as ONE table in list order (the kernels of this path read it; the main table keeps the register
+        // path's fields, which nobody reads again) and the whole span of results comes back in ONE copy: a task at a time was 2 x 8,307
+        // blit kernels per step of the ultra-long read set
+        int32_t lo = ids[at], hi = ids[at];
         for (size_t i = 0; i < take; i++) {
             S.tasks[ids[at + i]] = patch[i];
-            S.h2d(S.d_tasks.p + ids[at + i], &S.tasks[ids[at + i]], sizeof(AlnTask), st);
+            lo = std::min(lo, ids[at + i]);
+            hi = std::max(hi, ids[at + i]);
         }
+        S.h2d(S.d_wtasks.p, patch.data(), take * sizeof(AlnTask), st);
         S.h2d(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), st);
-        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st);
-        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st);
-        for (size_t i = 0; i < take; i++) S.d2h(&S.h_outs.p[ids[at + i]], S.d_outs.p + ids[at + i], sizeof(AlnOut), st);
+        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st, S.d_wtasks.p);
+        launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st, nullptr,
+                             S.d_wtasks.p);
+        HIP_CHECK(hipMemcpyAsync(S.h_outs.p + lo, S.d_outs.p + lo, (size_t)(hi - lo + 1) * sizeof(AlnOut), hipMemcpyDeviceToHost, st));
         S.sync_drain(st);
         for (size_t i = 0; i < take; i++) {
             const int32_t id = ids[at + i];

@@ -319,9 +319,11 @@ __global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__r
                                                           uint64_t *__restrict__ trace,
                                                           int32_t *__restrict__ trace_mink,
                                                           int32_t *__restrict__ vscratch,
-                                                          const int32_t *__restrict__ ids) {
+                                                          const int32_t *__restrict__ ids, const AlnTask *__restrict__ wtasks) {
+    // (wtasks: the listed tasks' records with the wide path's fields -- rows, min_k, V ring -- in list order; the table itself keeps the
+    // register path's: one upload instead of one per task)
     const int tid = ids[blockIdx.x];
-    const AlnTask T = tasks[tid];
+    const AlnTask T = wtasks ? wtasks[blockIdx.x] : tasks[tid];
     const int lane = (int)threadIdx.x;
     int32_t *V = vscratch + T.v_off;
     const uint32_t vmask = T.v_mask;
@@ -449,7 +451,8 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
                                                             const uint64_t *__restrict__ trace,
                                                             const int32_t *__restrict__ trace_mink,
                                                             uint32_t *__restrict__ ops,
-                                                            const int32_t *__restrict__ ids, int n_tasks) {
+                                                            const int32_t *__restrict__ ids, int n_tasks,
+                                                            const AlnTask *__restrict__ wtasks = nullptr) {
     const int slot = (int)(blockIdx.x * 64 + threadIdx.x);
     if (slot >= n_tasks) return;
     const int gid = ids ? ids[slot] : slot;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(64) void ond_traceback_kernel(const AlnTask *__rest
         else if (total > 40000) __builtin_amdgcn_s_setprio(1);
     }
     if (outs[gid].status != ST_FINISHED) return;
-    const AlnTask T = tasks[gid];
+    const AlnTask T = (!STREAM && wtasks) ? wtasks[slot] : tasks[gid];
     const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
     const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
     const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
@@ -853,15 +856,16 @@ void launch_ond_traceback_seg(const AlnTask *tasks, AlnOut *outs, const uint32_t
     hipLaunchKernelGGL(tb_stitch_kernel, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, tb.seg_outs, n_tasks, tb.cshift);
     // what the stitch refused (still ST_FINISHED) in one piece
     hipLaunchKernelGGL(ond_traceback_kernel<true>, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
-                       (const int32_t *)nullptr, ops, (const int32_t *)nullptr, n_tasks);
+                       (const int32_t *)nullptr, ops, (const int32_t *)nullptr, n_tasks, (const AlnTask *)nullptr);
 }
 
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace,
-                             int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream) {
+                             int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream,
+                             const AlnTask *wtasks) {
     if (n_ids <= 0) return;
     hipLaunchKernelGGL(ond_forward_wide_kernel, dim3((unsigned)n_ids), dim3(64), 0, (hipStream_t)stream, tasks, outs,
-                       pool, db_pool, trace, trace_mink, vscratch, task_ids);
+                       pool, db_pool, trace, trace_mink, vscratch, task_ids, wtasks);
 }
 
 // task_ids == nullptr: every task of the table, traces in the register path's stream format -- in the order `order` lists them
@@ -870,14 +874,14 @@ void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t 
 void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                           const uint64_t *trace,
                           const int32_t *trace_mink, uint32_t *ops, const int32_t *task_ids, int n_tasks, void *stream,
-                          const int32_t *order) {
+                          const int32_t *order, const AlnTask *wtasks) {
     if (n_tasks <= 0) return;
     if (task_ids)
         hipLaunchKernelGGL(ond_traceback_kernel<false>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                           tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks);
+                           tasks, outs, pool, db_pool, trace, trace_mink, ops, task_ids, n_tasks, wtasks);
     else
         hipLaunchKernelGGL(ond_traceback_kernel<true>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                           tasks, outs, pool, db_pool, trace, (const int32_t *)nullptr, ops, order, n_tasks);
+                           tasks, outs, pool, db_pool, trace, (const int32_t *)nullptr, ops, order, n_tasks, (const AlnTask *)nullptr);
 }
 
 }  // namespace ndgpu
