@@ -508,42 +508,19 @@ def main():
     # The stage of the NEXT seed file begins while this one's consensus runs (a node has more seed files than GPUs: nextDenovo:344-354
     # runs sort_align / seed_cns once per seed file, and the raw_align jobs of the next one are independent of this one's consensus):
     # its overlap, sort and pile-admission kernels fill what the consensus kernels leave of the device, its host work what the
-    # contexts' host phases leave of the CPUs.  Every timed step still runs BOTH halves inside the timed region: the first timed step
-    # computes its own piles (nothing is prefetched across the start of the clock), the last one prefetches nothing.
+    # contexts' host phases leave of the CPUs; and two consensus calls are in flight, the tail of one under the main phases of the
+    # next (stage.StagePipeline -- the product's `correct_stage` command runs its seed files through the same class).  Every timed
+    # step still runs BOTH halves inside the timed region: the first timed step computes its own piles (nothing is prefetched across
+    # the start of the clock), the last one prefetches nothing.
     import threading
-    pipeline = {"on": not (args.no_pipeline or args.no_overlap), "thread": None, "result": None, "error": None, "hidden_s": 0.0, "wait_s": 0.0}
+    pipeline = {"on": not (args.no_pipeline or args.no_overlap), "depth": 1, "wait_s": 0.0}
 
-    def prefetch_piles():
-        try:
-            pipeline["result"] = sh.piles(my_file)
-        except BaseException as e:   # noqa: BLE001  (taken up by the step that wanted the piles)
-            pipeline["error"] = e
-
-    def get_piles(prefetch_next=False):
-        """(records, pile offsets, names) of this step: computed here, or taken from the thread that was started during the step before."""
+    def get_piles(_k=None):
+        """(records, pile offsets, names) of a step."""
         if args.no_overlap:
             return a_recs, a_off, a_names
-        th = pipeline["thread"]
-        if th is not None:
-            t_j = time.perf_counter()
-            th.join()
-            pipeline["wait_s"] += time.perf_counter() - t_j
-            pipeline["thread"] = None
-            err, res_p = pipeline["error"], pipeline["result"]
-            pipeline["error"] = pipeline["result"] = None
-            if isinstance(err, MemoryError):   # the two stages do not fit the device side by side: one after the other from here on
-                sys.stderr.write("[bench] overlap stage out of device memory beside the consensus: pipelining off\n")
-                pipeline["on"] = False
-                res_p = sh.piles(my_file)
-            elif err is not None:
-                raise err
-            sub, off, seeds, n_bl = res_p
-        else:
-            sub, off, seeds, n_bl = sh.piles(my_file)
+        sub, off, seeds, n_bl = sh.piles(my_file)
         last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
-        if prefetch_next and pipeline["on"]:
-            pipeline["thread"] = threading.Thread(target=prefetch_piles)
-            pipeline["thread"].start()
         return (a_recs, a_off, a_names) if analytic else (sub, off, seeds)
 
     acc_lock = threading.Lock()
@@ -576,8 +553,8 @@ def main():
             write_wall[0] += time.perf_counter() - t_w
         return b_ok, n_ok, res, path, time.perf_counter()
 
-    def step(prefetch_next=False):
-        r_, o_, names = get_piles(prefetch_next)
+    def step():
+        r_, o_, names = get_piles()
         b_ok, n_ok, res, _, _ = consensus(r_, o_, names, fa_path)
         last_res[:] = [res]
         return b_ok, n_ok
@@ -598,45 +575,31 @@ def main():
     t0 = time.perf_counter()
     bases = n_ok = 0
     step_s = []
-    # Two consensus calls in flight (--consensus-depth 2, with pipelining on): a call ends with its last sub-batches' low-quality-region
-    # stages -- host ranking and POA, two rounds of small launches -- and little else on the device; the next call's main phases fill
-    # that.  The contexts serve both calls: a context takes a sub-batch of the newer call when the older one has none left for it.
     depth = 2 if (pipeline["on"] and args.consensus_depth >= 2 and args.steps > 1) else 1
-    pipeline["depth"] = depth
-    if depth == 1:
+    if not pipeline["on"]:
         for k_step in range(args.steps):
             t_s = time.perf_counter()
-            b, n = step(prefetch_next=k_step + 1 < args.steps)
+            b, n = step()
             step_s.append(time.perf_counter() - t_s)
             bases += b
             n_ok += n
     else:
-        from concurrent.futures import ThreadPoolExecutor
-        inflight = []
+        line = stage.StagePipeline(get_piles, lambda k, piles: consensus(piles[0], piles[1], piles[2], fa_path + (".%d" % (k % 2))),
+                                   depth=depth, prefetch=True)
+        ends = []
+        for _k, (b, n, res, path, _t), t_end in line.run(range(args.steps)):
+            ends.append(t_end)
+            bases += b
+            n_ok += n
+            if t_end >= max(ends):   # (the parity block reads the file of the call that ended last)
+                last_res[:] = [res]
+                last["fa_path"] = path
+        # a step's time = from the end of the call before it to its own end, in the order the calls ended (two are in flight)
         t_last = t0
-        with ThreadPoolExecutor(max_workers=depth) as pool_x:
-            ends = []
-
-            def finish(fut):
-                nonlocal bases, n_ok
-                b, n, res, path, t_end = fut.result()
-                ends.append(t_end)
-                bases += b
-                n_ok += n
-                if t_end >= max(ends):   # (the parity block reads the file of the call that ended last)
-                    last_res[:] = [res]
-                    last["fa_path"] = path
-            for k_step in range(args.steps):
-                r_, o_, names = get_piles(prefetch_next=k_step + 1 < args.steps)
-                inflight.append(pool_x.submit(consensus, r_, o_, names, fa_path + (".%d" % (k_step % depth))))
-                while len(inflight) >= depth:
-                    finish(inflight.pop(0))
-            while inflight:
-                finish(inflight.pop(0))
-            # a step's time = from the end of the call before it to its own end, in the order the calls ended (two are in flight)
-            for t_end in sorted(ends):
-                step_s.append(t_end - t_last)
-                t_last = t_end
+        for t_end in sorted(ends):
+            step_s.append(t_end - t_last)
+            t_last = t_end
+        pipeline.update(on=line.prefetch, depth=line.depth, wait_s=line.wait_s)
     sync()
     dt = time.perf_counter() - t0
     host1 = host_snapshot()

@@ -178,32 +178,48 @@ def run(argv) -> int:
     db = api.ReadDB(words, word_off, lens)
     fail = 0
     totals = [0, 0]  # corrected bases, corrected records of this rank
+    # The seed files run through the stage like parts through a line (stage.StagePipeline): the sort + pile admission of the next one on a
+    # thread of its own while this one's consensus holds the device, and two consensus calls in flight -- the tail of one (host ranking,
+    # POA, two rounds of small launches) under the main phases of the next.  NDGPU_STAGE_SERIAL=1: one seed file after the other.
+    def make_piles(i):
+        s = seeds[i]
+        seed_len = np.zeros(int(lens.size), dtype=np.uint32)
+        seed_len[s.ids] = s.lens
+        files = [r for _, r in sorted(per_seed_files[i], key=lambda kr: kr[0])]
+        srt, bl, _ = overlap.sort_overlaps(files, seed_len, int(s.lens.min()) if len(s) else 0, a.sort_k, a.flank)
+        tag = os.path.basename(seed_paths[i])[len("input.seed."):-len(".2bit")]
+        if a.keep:
+            so = os.path.join(a.keep, "input.seed.%s.sorted.ovl" % tag)
+            with open(so, "wb") as f:
+                f.write(overlap.encode(srt, np.zeros(2, dtype=np.uint32)))
+            with open(so + ".bl", "w") as f:
+                for rid, kind in bl:
+                    f.write("%d %s\n" % (rid, kind))
+        skip = [rid for rid, _ in bl] if a.blacklist else []
+        dec, off, names = overlap.assemble_piles(srt, int(lens.size), a.min_len_seed, a.min_len_aln, a.max_cov_aln, a.min_cov_seed, skip)
+        return tag, dec, off, names
+
+    def correct(i, made):
+        tag, dec, off, names = made
+        piles = [(int(names[p]), np.arange(int(off[p]), int(off[p + 1]))) for p in range(names.size)]
+        out = "%s.%s.fasta" % (a.out, tag)
+        with open(out, "w") as OUT, open(out + ".idx", "w") as IDX:
+            failed = nextcorrect.correct_and_write(db, dec, piles, a, OUT, IDX)
+        n_bases = n_recs = 0
+        for line in open(out + ".idx"):
+            ln = int(line.split("\t")[2])
+            if ln > 0:
+                n_bases += ln
+                n_recs += 1
+        return failed, n_bases, n_recs
+
     try:
-        for i in sorted(want):
-            s = seeds[i]
-            seed_len = np.zeros(int(lens.size), dtype=np.uint32)
-            seed_len[s.ids] = s.lens
-            files = [r for _, r in sorted(per_seed_files[i], key=lambda kr: kr[0])]
-            srt, bl, _ = overlap.sort_overlaps(files, seed_len, int(s.lens.min()) if len(s) else 0, a.sort_k, a.flank)
-            tag = os.path.basename(seed_paths[i])[len("input.seed."):-len(".2bit")]
-            if a.keep:
-                so = os.path.join(a.keep, "input.seed.%s.sorted.ovl" % tag)
-                with open(so, "wb") as f:
-                    f.write(overlap.encode(srt, np.zeros(2, dtype=np.uint32)))
-                with open(so + ".bl", "w") as f:
-                    for rid, kind in bl:
-                        f.write("%d %s\n" % (rid, kind))
-            skip = [rid for rid, _ in bl] if a.blacklist else []
-            dec, off, names = overlap.assemble_piles(srt, int(lens.size), a.min_len_seed, a.min_len_aln, a.max_cov_aln, a.min_cov_seed, skip)
-            piles = [(int(names[p]), np.arange(int(off[p]), int(off[p + 1]))) for p in range(names.size)]
-            out = "%s.%s.fasta" % (a.out, tag)
-            with open(out, "w") as OUT, open(out + ".idx", "w") as IDX:
-                fail += nextcorrect.correct_and_write(db, dec, piles, a, OUT, IDX)
-            for line in open(out + ".idx"):
-                ln = int(line.split("\t")[2])
-                if ln > 0:
-                    totals[0] += ln
-                    totals[1] += 1
+        from .stage import StagePipeline
+        serial = bool(os.environ.get("NDGPU_STAGE_SERIAL"))
+        for _i, (failed, n_bases, n_recs), _t in StagePipeline(make_piles, correct, depth=1 if serial else 2, prefetch=not serial).run(sorted(want)):
+            fail += failed
+            totals[0] += n_bases
+            totals[1] += n_recs
     finally:
         db.close()
     if world > 1:  # the stage's only collective: the final counts (RCCL over xGMI on a GPU node, gloo without one)

@@ -178,6 +178,79 @@ class Exchange:
         return recs
 
 
+class StagePipeline:
+    """Seed files through the stage like parts through a line: while the consensus of seed file k holds the device, the piles of seed
+    file k + 1 -- overlap jobs, sort, pile admission, whatever `make_piles` does -- are computed on a thread of their own, and up to
+    `depth` consensus calls are in flight: a call ends with its last sub-batches' low-quality-region stages (host ranking and POA, two
+    rounds of small launches) and little else on the device, which the next call's main phases fill.  The library's contexts serve the
+    older call first (DeviceAligner::begin_batch(order)).  The reference runs the same stage seed file by seed file, several at a time
+    (nextDenovo:344-354 with `pa_correction` subtasks side by side); one GPU takes them one behind the other.
+
+    make_piles(item) -> piles;  correct(item, piles) -> result.  `run` yields (item, result, t_end) in the order the items were given.
+    A `make_piles` that runs out of device memory beside the consensus (MemoryError) is run again when its turn comes, alone, and
+    prefetching stays off from there on (genome-scale read sets whose two stages do not fit the device side by side)."""
+
+    def __init__(self, make_piles, correct, depth=2, prefetch=True):
+        self.make_piles, self.correct = make_piles, correct
+        self.depth = max(1, int(depth)) if prefetch else 1
+        self.prefetch = bool(prefetch)
+        self.wait_s = 0.0            # time the line stood still waiting for prefetched piles
+
+    def run(self, items):
+        import sys
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        items = list(items)
+        box = {}
+
+        def fetch(it):
+            try:
+                box["piles"] = self.make_piles(it)
+            except BaseException as e:   # noqa: BLE001  (taken up by the turn that wants the piles)
+                box["error"] = e
+
+        def timed(it, piles):
+            r = self.correct(it, piles)
+            return r, time.perf_counter()
+
+        th = None
+        inflight = []
+        with ThreadPoolExecutor(max_workers=self.depth) as pool:
+            for n, it in enumerate(items):
+                if th is not None:
+                    t0 = time.perf_counter()
+                    th.join()
+                    self.wait_s += time.perf_counter() - t0
+                    th = None
+                    err, piles = box.pop("error", None), box.pop("piles", None)
+                    if isinstance(err, MemoryError):
+                        sys.stderr.write("[ndgpu stage] the next seed file's overlap stage ran out of device memory beside the consensus: "
+                                         "one stage after the other from here on\n")
+                        self.prefetch = False
+                        self.depth = 1
+                        while inflight:            # (its turn has come: alone on the device)
+                            i0, f0 = inflight.pop(0)
+                            r0, te0 = f0.result()
+                            yield i0, r0, te0
+                        piles = self.make_piles(it)
+                    elif err is not None:
+                        raise err
+                else:
+                    piles = self.make_piles(it)
+                if self.prefetch and n + 1 < len(items):
+                    th = threading.Thread(target=fetch, args=(items[n + 1],))
+                    th.start()
+                inflight.append((it, pool.submit(timed, it, piles)))
+                while len(inflight) >= self.depth:
+                    i0, f0 = inflight.pop(0)
+                    r0, te0 = f0.result()
+                    yield i0, r0, te0
+            while inflight:
+                i0, f0 = inflight.pop(0)
+                r0, te0 = f0.result()
+                yield i0, r0, te0
+
+
 class Shard:
     """One read set (2-bit words as in a .2bit file, read i at words[word_off[i]], lens[i] bases; read id = index) and
     the parameters of the stage."""

@@ -217,6 +217,35 @@ def test_chains_of_the_base_level_alignment_match_oracle(interpreted, olib):
     GC.check_chains_against_oracle(olib, "ava-ont", True, "seed", "part")
 
 
+def test_seed_files_through_the_stage_pipeline(interpreted, tmp_path, monkeypatch):
+    """`correct_stage` over three seed files: the next seed file's sort + pile admission during this one's consensus and two consensus
+    calls in flight (stage.StagePipeline; the contexts serve the older call first) give the files that one seed file after the other
+    (NDGPU_STAGE_SERIAL=1) gives."""
+    from nextdenovo_amd import correct_stage, synth
+    import refpipe
+    g = synth.make_genome(45000, seed=51, n_repeats=2, repeat_len=1200)
+    rs = synth.simulate_reads(g, 26, "ont", seed=52, mu=8.5, sigma=0.4, min_len=900)
+    fa = os.path.join(str(tmp_path), "reads.fa")
+    refpipe.write_fasta(fa, [synth.codes_to_ascii(x) for x in rs.seqs])
+    fofn = os.path.join(str(tmp_path), "input.fofn")
+    with open(fofn, "w") as f:
+        f.write(fa + "\n")
+    outs = {}
+    for mode in ("line", "serial"):
+        if mode == "serial":
+            monkeypatch.setenv("NDGPU_STAGE_SERIAL", "1")
+        else:
+            monkeypatch.delenv("NDGPU_STAGE_SERIAL", raising=False)
+        d = os.path.join(str(tmp_path), "db_" + mode)
+        out = os.path.join(str(tmp_path), "cns_" + mode)
+        assert correct_stage.run(["--fofn", fofn, "--read-cutoff", "500", "--seed-cutoff", "4k", "--seed-cutfiles", "3", "-d", d, "-x", "ava-ont",
+                                  "-k", "24", "-r", "ont", "-min_len_seed", "2000", "-p", "4", "-o", out]) == 0
+        outs[mode] = {n[len("cns_" + mode):]: open(os.path.join(str(tmp_path), n), "rb").read()
+                      for n in sorted(os.listdir(str(tmp_path))) if n.startswith("cns_" + mode + ".")}
+    assert len(outs["line"]) == 6 and outs["line"] == outs["serial"]          # three .fasta + three .idx
+    assert sum(len(v) for k, v in outs["line"].items() if k.endswith(".fasta")) > 100000
+
+
 def test_sort_in_seed_ranges_equals_the_sort_at_once(interpreted, monkeypatch):
     """The out-of-core form of the overlap sort (tests/test_gpu_ovlsort.py) under the interpreter."""
     GS.check_sort_in_seed_ranges_equals_the_sort_at_once(monkeypatch, False)

@@ -194,3 +194,68 @@ def test_grouped_jobs_against_a_target_of_several_index_parts(monkeypatch):
     for x, y in zip(a, b):
         assert x.tobytes() == y.tobytes()
     assert len(results["grouped"][1]) < len(results["serial"][1])
+
+
+def test_stage_pipeline_order_depth_and_the_memory_fallback():
+    """stage.StagePipeline by itself: results come back in the order the items were given; the piles of item k + 1 are made while
+    item k is being corrected; at most `depth` corrections are in flight; a `make_piles` that runs out of device memory beside a
+    correction is run again alone when its turn comes, and the line goes on one stage after the other."""
+    import threading
+    import time
+    from nextdenovo_amd import stage
+    lock = threading.Lock()
+    state = {"correcting": 0, "max_correcting": 0, "made_during_correct": 0, "log": []}
+
+    def make(i):
+        with lock:
+            if state["correcting"]:
+                state["made_during_correct"] += 1
+            state["log"].append(("make", i))
+        time.sleep(0.02)
+        return i * 10
+
+    def correct(i, piles):
+        with lock:
+            state["correcting"] += 1
+            state["max_correcting"] = max(state["max_correcting"], state["correcting"])
+        time.sleep(0.05)
+        with lock:
+            state["correcting"] -= 1
+        return piles + 1
+
+    line = stage.StagePipeline(make, correct, depth=2)
+    got = list(line.run(range(6)))
+    assert [g[0] for g in got] == list(range(6)) and [g[1] for g in got] == [i * 10 + 1 for i in range(6)]
+    assert all(a[2] <= b[2] + 1.0 for a, b in zip(got, got[1:]))
+    assert state["max_correcting"] == 2 and state["made_during_correct"] >= 3
+    assert [x for x in state["log"] if x[0] == "make"] == [("make", i) for i in range(6)]   # every item's piles made once, in order
+    # one stage after the other
+    state.update(correcting=0, max_correcting=0, made_during_correct=0, log=[])
+    got = list(stage.StagePipeline(make, correct, depth=1, prefetch=False).run(range(3)))
+    assert [g[1] for g in got] == [1, 11, 21] and state["max_correcting"] == 1 and state["made_during_correct"] == 0
+    # out of device memory beside the consensus: made again alone, prefetching off from there on
+    state.update(correcting=0, max_correcting=0, made_during_correct=0, log=[])
+    failed = []
+
+    def make_oom(i):
+        with lock:
+            busy = state["correcting"] > 0
+        if i == 2 and busy and not failed:
+            failed.append(i)
+            raise MemoryError("no room beside the consensus")
+        with lock:
+            state["log"].append(("make", i, busy))
+        return i * 10
+
+    line = stage.StagePipeline(make_oom, correct, depth=2)
+    got = list(line.run(range(5)))
+    assert [g[1] for g in got] == [i * 10 + 1 for i in range(5)] and failed == [2]
+    assert line.prefetch is False and line.depth == 1
+    assert ("make", 2, False) in state["log"] and ("make", 3, False) in state["log"]   # item 2 again with nothing else running; 3 not prefetched
+    # any other failure of make_piles is the caller's
+    def make_bad(i):
+        if i == 1:
+            raise ValueError("a bad option")
+        return i
+    with pytest.raises(ValueError):
+        list(stage.StagePipeline(make_bad, correct, depth=2).run(range(3)))
