@@ -102,7 +102,7 @@ def _rank_main(rank, port, q):
     from nextdenovo_amd import api, overlap
     overlap._lib = overlap._bind(C.CDLL(build_simt.build_overlap()))
     api._LIB = api._bind(C.CDLL(build_simt.build()))
-    sys.argv = ["bench.py", "--gpus", "2", "--genome-size", "30000", "--depth", "14", "--steps", "1", "--warmup", "1"]
+    sys.argv = ["bench.py", "--gpus", "2", "--genome-size", "30000", "--depth", "14", "--steps", "2", "--warmup", "1"]   # (two steps: the second one's piles are prefetched, hand-over included, and two consensus calls are in flight)
     import bench
     buf = io.StringIO()
     with redirect_stdout(buf):
@@ -143,6 +143,6 @@ def test_bench_line_of_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["seed_files"] == 2
     assert len(d["per_rank"]) == 2 and all(r["piles"] > 0 for r in d["per_rank"])
     ra = d["config"]["raw_align_jobs"]
-    assert ra["exchange"] is True and ra["per_rank_jobs_computed"] == [2, 1] and ra["rank0_exchange"]["sent"] == 2   # (warm-up + 1 step)
+    assert ra["exchange"] is True and ra["per_rank_jobs_computed"] == [2, 1] and ra["rank0_exchange"]["sent"] == 3   # (warm-up + 2 steps)
     assert ra["rank0_exchange"]["recomputed"] == 0
     assert not os.path.exists(xdir)   # (removed by rank 0 once every rank is past its last read)
