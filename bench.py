@@ -86,6 +86,13 @@ def kernel_models(st):
         "alg_bytes": st["seq_bases"] / 4.0 + st["d_steps"] / 8.0 + st["columns"] / 4.0,
         "formula": "seq_bases / 4 (operands) + d_steps / 8 (the path's move bit of every edit step) + columns / 4 (2-bit column kinds out)",
         "ms": st["traceback_ms"], "launches": st["traceback_launches"]}
+    m["tb_walk_kernel"] = {
+        "label": "K8a in segments: tb_walk (one lane per 256 edit steps of a traceback) -- the HIP-event bracket holds its chase, stitch and "
+                 "the one-lane walk of refused alignments too; the walkers are > 95 % of it",
+        "alg_bytes": st["seq_bases"] / 4.0 + st["d_steps"] / 8.0 + st["columns"] / 4.0,
+        "formula": "seq_bases / 4 (operands) + d_steps / 8 (the path's move bit of every edit step) + columns / 4 (2-bit column kinds out); "
+                   "the walkers' warm-up rows (32 per 256) are not algorithmic",
+        "ms": st["traceback_ms"], "launches": st["traceback_launches"]}
     m["lq_score_kernel"] = {
         "label": "K12 lq_links + lq_score (low-quality-region rounds: links per run of regions, then scores / best links / walk per pile; "
                  "one HIP-event bracket over both, lq_score is ~85 % of it)",
@@ -102,6 +109,8 @@ def kernel_models(st):
         "alg_bytes": 20.0 * st["cells_msa"] + 12.0 * st["links"] + 20.0 * st["path_items"],
         "formula": "20 B per MSA cell (8 in, 12 out) + 12 B per link in + 20 B of column metadata",
         "ms": st["score_ms"], "launches": st["score_launches"]}
+    # (one HIP-event bracket, two forms of the traceback: the one the run used is modelled)
+    m.pop("ond_traceback_kernel" if st.get("tb_tasks", 0) > 0 else "tb_walk_kernel")
     return m
 
 
@@ -123,6 +132,7 @@ def committed_kernel_stats():
 
 _KERNEL_SOURCES = {   # the files a kernel's code lives in (its counter measurement is tied to them)
     "ond_forward_kernel": ("ond_kernels.hip", "nd_device.h"), "ond_traceback_kernel": ("ond_kernels.hip", "nd_device.h"),
+    "tb_walk_kernel": ("ond_kernels.hip", "nd_device.h"),
     "count_links_kernel": ("msa_kernels.hip", "nd_device.h"), "score_seg_kernel": ("msa_kernels.hip", "nd_device.h"),
 }
 

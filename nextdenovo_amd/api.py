@@ -213,6 +213,12 @@ class ReadDB:
             rc = self._lib.ndgpu_correct_piles_stream(self._h, n, recs.ctypes.data, pile_off.ctypes.data, min_len_aln, max_cov_aln,
                                                       min_cov_base, max_lq_length, min_error_corrected_ratio, split, fast, read_type,
                                                       host_threads, out, cb, None)
+            if state["err"] is not None or rc != 0:
+                # records that were never handed over (the call failed, or a hand-over did): they are the caller's to free
+                for i in range(n):
+                    if out[i]:
+                        self._lib.free_consensus_trimed(out[i])
+                        out[i] = None
             if state["err"] is not None:
                 raise state["err"]
         else:
@@ -264,6 +270,7 @@ class ReadDB:
                 IDX.write(b"%d\t0\t0\n" % name)
             res[i] = (ln, ide)
             free(out[i])
+            out[i] = None   # (handed over: nobody frees it again)
         state["pos"] = pos
 
 

@@ -1,5 +1,6 @@
 // C ABI of the engine (include/ndgpu_nextcorrect.h).
 #include <hip/hip_runtime_api.h>
+#include <cerrno>
 #include <sys/uio.h>
 #include <unistd.h>
 
@@ -177,6 +178,7 @@ int ndgpu_write_records(consensus_trimed **recs, const uint32_t *ids, int n, con
     auto write_all = [](int fd, struct iovec *iov, int cnt) {
         while (cnt > 0) {
             ssize_t w = writev(fd, iov, cnt > 1024 ? 1024 : cnt);
+            if (w < 0 && errno == EINTR) continue;   // (a signal, not a failure)
             if (w < 0) return false;
             while (cnt > 0 && (size_t)w >= iov->iov_len) w -= (ssize_t)iov->iov_len, ++iov, --cnt;
             if (cnt > 0 && w > 0) iov->iov_base = (char *)iov->iov_base + w, iov->iov_len -= (size_t)w;
@@ -192,6 +194,7 @@ int ndgpu_write_records(consensus_trimed **recs, const uint32_t *ids, int n, con
         iov.push_back({(void *)p.seq, p.len});
         iov.push_back({(void *)&nl, 1});
     }
+    const off_t idx0 = fd_idx >= 0 ? lseek(fd_idx, 0, SEEK_CUR) : (off_t)-1;   // (where the index stood before this hand-over)
     if (!iov.empty()) ok = write_all(fd_out, iov.data(), (int)iov.size());
     if (ok && fd_idx >= 0 && !idx.empty()) {
         struct iovec one{(void *)idx.data(), idx.size()};
@@ -202,6 +205,12 @@ int ndgpu_write_records(consensus_trimed **recs, const uint32_t *ids, int n, con
         recs[ids[k]] = nullptr;
     }
     if (ok) *pos = at;
+    else {
+        // part of the hand-over may be on disk and its index lines not: cut both files back to where they stood before this call, so
+        // that what a resumed run reads (lib/nextcorrect.py:205-226: the .idx decides where the .fasta is cut) belongs together
+        if (ftruncate(fd_out, (off_t)*pos) == 0) (void)lseek(fd_out, (off_t)*pos, SEEK_SET);
+        if (idx0 >= 0 && ftruncate(fd_idx, idx0) == 0) (void)lseek(fd_idx, idx0, SEEK_SET);
+    }
     return ok ? 0 : -1;
 }
 

@@ -363,6 +363,7 @@ struct Engine {
 	DevBuf<HashSlot> htab;   // the lookup table (build_hash: from the index's second map call on)
 	uint64_t hsize = 0;
 	uint32_t maps_served = 0;
+	double query_minimizers_seen = 0;   // estimate (2 / (w + 1) per base) over the map calls of this index: what decides the lookup table
 	ndgpu_ovl_stats st{};
 	// debug view of the last map batch
 	std::vector<uint64_t> dbg_aoff;
@@ -532,25 +533,35 @@ struct Engine {
 		launch_build_buckets(ukey.p, n_keys, bucket_shift, bucket.p, stream);
 		HIP_OK(hipGetLastError());
 		htab.release();
-		hsize = 0, maps_served = 0;
+		hsize = 0, maps_served = 0, hash_skipped = false, query_minimizers_seen = 0;
 		st.index_sort_ms += tm.stop();
 	}
 
 	// The lookup table over the distinct keys: two thirds full, 16 bytes a slot.  Measured on config 2 (r5_10): the seed pass of a map
-	// call 13.5 -> 9.6 ms, the table's build 6.7 ms (a power-of-two table at most half full; smaller since) -- so an index builds
-	// it when its SECOND map call arrives (one index serves the 1-8 raw_align jobs of its seed file, nextDenovo:426-467; the index of
-	// a one-job layout never pays for it).  NDGPU_OVL_HASH=1: with the index; NDGPU_OVL_NO_HASH: never.  Skipped when it would take
-	// more than a sixteenth of the device; an allocation that fails is reported like any other.
+	// call 13.5 -> 9.6 ms, the table's build 6.7 ms (a power-of-two table at most half full; smaller since) -- built when the query
+	// minimizers it serves outweigh that (map_once: by cost, not by call count).  Skipped when it would take
+	// more than a sixteenth of the device -- a decision taken once per index (the memory query goes through the runtime's device
+	// enumeration: milliseconds) -- and when its block cannot be had: the table is a short cut, the bucket search answers the same
+	// lookups, so a map call that would succeed without it must not fail for it.
+	bool hash_skipped = false;
 	void build_hash()
 	{
-		if (htab.p || !n_keys || getenv("NDGPU_OVL_NO_HASH")) return;
+		if (htab.p || hash_skipped || !n_keys || getenv("NDGPU_OVL_NO_HASH")) return;
 		const uint64_t slots = n_keys + n_keys / 2 + 64;
-		if (slots >= (1ull << 32)) return;
 		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && slots * sizeof(HashSlot) > total_b / 16) return;
+		if (slots >= (1ull << 32) || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && slots * sizeof(HashSlot) > total_b / 16)) {
+			hash_skipped = true;
+			return;
+		}
 		EvTimer tm(stream);
 		tm.start();
-		htab.alloc(slots);
+		try {
+			htab.alloc(slots);
+		} catch (const std::runtime_error &) {   // out of device memory (or an injected failure): no table
+			(void)ndovl::last_error_take();
+			hash_skipped = true;
+			return;
+		}
 		htab.zero(stream);
 		hsize = slots;
 		launch_build_hash(ukey.p, ustart.p, n_keys, htab.p, hsize, stream);
@@ -645,7 +656,17 @@ int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, cons
 	P = Pm;
 	struct Restore { Engine *e; OvlParams p; ~Restore() { e->P = p; } } restore{this, Pi};
 	++st.map_calls;
-	if (++maps_served >= (getenv("NDGPU_OVL_HASH") ? 1u : 2u)) build_hash();
+	// The lookup table is built when it pays, by cost and not by the number of calls (one fused call may carry the query files of eight
+	// jobs): config 2 measured 25 ps saved per query minimizer looked up (seed pass 13.5 -> 9.6 ms for 156 M) against 86 ps per distinct
+	// key to build (6.7 ms for 78 M) -- so once the minimizers this index has been, and is about to be, asked for exceed ~3.4 x its keys.
+	// NDGPU_OVL_HASH=1: with the first call; NDGPU_OVL_NO_HASH: never.
+	{
+		++maps_served;
+		uint64_t bases = 0;
+		for (uint32_t i = 0; i < n_q; ++i) bases += lens[i];
+		query_minimizers_seen += 2.0 * (double)bases / (double)(P.w + 1);
+		if (getenv("NDGPU_OVL_HASH") || query_minimizers_seen * 25.0 > (double)n_keys * 86.0) build_hash();
+	}
 	out.clear();
 	if (out10) out10->clear();
 	if (chains_per_read) chains_per_read->clear();
