@@ -212,7 +212,7 @@ def _ref_worker(i):
     return key, ln, bits, digest, ide, cpu_s
 
 
-def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16):
+def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16, n_runs=3):
     """Reference CPU path on a bounded sample of the same workload: the compiled reference's nextCorrect() over a fork pool of
     `cores` workers that STREAMS the piles (imap_unordered, one pile per task, longest seeds first), as lib/nextcorrect.py:232-235
     streams all of them -- with >= 16 piles per worker the pool's tail (its longest pile) amortises.  Every pile's CPU time is
@@ -241,14 +241,16 @@ def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16):
     _CPU_CTX = (rs, piles, max_lq, read_type)
     ctx = get_context("fork")
     got = {}
+    runs = []   # three runs, the median -- (wall, CPU-seconds) of each
     with ctx.Pool(cores) as pool:
         pool.map(_ref_worker, idx[-cores:], chunksize=1)  # warm: dlopen + page in, on the shortest piles
-        t0 = time.perf_counter()
-        for key, ln, bits, digest, ide, cpu_s in pool.imap_unordered(_ref_worker, idx, chunksize=1):
-            got[key] = (ln, bits, digest, ide, cpu_s)
-        dt = time.perf_counter() - t0
+        for _run in range(max(1, n_runs)):
+            t0 = time.perf_counter()
+            for key, ln, bits, digest, ide, cpu_s in pool.imap_unordered(_ref_worker, idx, chunksize=1):
+                got[key] = (ln, bits, digest, ide, cpu_s)
+            runs.append((time.perf_counter() - t0, float(sum(g[4] for g in got.values()))))
+    dt, cpu_s = sorted(runs)[len(runs) // 2]
     bases = int(sum(ln for ln, _b, _d, ide, _c in got.values() if ln > 4 and ide >= 0.8))
-    cpu_s = float(sum(g[4] for g in got.values()))
     slowest = max(g[4] for g in got.values())
     ref = {i: got[i][:3] for i in idx}
     _CPU_CTX = None
@@ -256,6 +258,8 @@ def cpu_baseline(rs, piles, read_type, n_sample, max_lq, n_longest=16):
     return {"value": bases / dt, "unit": "corrected bases/s", "cores": cores, "kind": "reference",
             "cores_note": "min(64, the CPUs this process can have: hardware threads %s, cgroup quota %s)" % (os.cpu_count(), hostinfo.cgroup_cpu_quota()),
             "wall_s": dt, "cpu_seconds": cpu_s, "per_core_measured": per_core, "per_core_measured_x_cores": per_core * cores,
+            "runs": [{"wall_s": round(w, 3), "cpu_seconds": round(c, 2), "value": bases / w} for w, c in runs],
+            "runs_note": "%d runs of the same sample on the same pool, `value` / `wall_s` / `cpu_seconds` = the median run (SURVEY.md section 8d)" % len(runs),
             "slowest_pile_cpu_s": slowest, "piles_per_worker": len(idx) / cores,
             "sample": "%d of %d piles (every %d-th + the %d longest seeds), %d corrected bases; compiled reference nextcorrect.so, fork pool "
                       "of %d workers streaming one pile per task, longest first (lib/nextcorrect.py:232-235): %.2f s wall, %.1f CPU-seconds "
@@ -296,7 +300,7 @@ def parity_block(ref, gpu_full, piles):
             "device_out_of_memory_seeds": sum(1 for i in ref if gpu_full[i][0] == 3), "mismatches": bad[:8]}
 
 
-def cpu_baseline_overlap(rs_dev, preset, device_records=None):
+def cpu_baseline_overlap(rs_dev, preset, device_records=None, sort_k=0):
     """Reference overlapper (oracle/_ref/minimap2-nd --step 1 -I 3G -t cores, the seed x seed job of nextDenovo:456-464) on the
     same read set: the whole all-vs-all job, wall time including its index build; with `device_records` (what the device's stage
     produced for the same job) also whether the two `.ovl` byte streams are the same."""
@@ -331,8 +335,39 @@ def cpu_baseline_overlap(rs_dev, preset, device_records=None):
         mine = overlap.encode(device_records, np.zeros(2, dtype=np.uint32))
         res["device_ovl_bytes"] = len(mine)
         res["device_ovl_identical"] = len(mine) == nbytes and hashlib.md5(mine).hexdigest() == h.hexdigest()
-    for f in (p, out):
-        os.remove(f)
+    # sort_align on the CPU (the wall of raw_align + sort_align + seed_cns): the compiled reference's ovl_sort on
+    # the .ovl the reference overlapper just wrote, as nextDenovo:344-354 runs it (-k as lib/config_parser.py:44)
+    srt_exe = os.path.join(ROOT, "oracle", "_ref", "ovl_sort")
+    if sort_k and os.path.exists(srt_exe):
+        try:
+            ids = np.asarray(rs_dev.ids, dtype=np.int64)
+            ln = np.asarray(rs_dev.lens, dtype=np.int64)
+            cnt = (ln + 15) >> 4
+            start = np.zeros(ids.size + 1, dtype=np.int64)
+            np.cumsum(cnt + 2, out=start[1:])
+            with open(os.path.join(wd, ".reads.idx"), "w") as f:   # id, byte offset of the read's first word, length (util/seq_dump.c:39)
+                f.write("".join("%d\t%d\t%d\n" % (i, 2 + 4 * (st + 2), l_) for i, st, l_ in zip(ids.tolist(), start[:-1].tolist(), ln.tolist())))
+            with open(os.path.join(wd, "in.fofn"), "w") as f:
+                f.write(out + "\n")
+            t0 = time.perf_counter()
+            subprocess.run([srt_exe, "-m", "40g", "-t", str(max(2, cores)), "-k", str(sort_k), "-i", os.path.join(wd, ".reads.idx"), "-o", "ref.sorted.ovl",
+                            "in.fofn"], check=True, cwd=wd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            res["ovl_sort"] = {"wall_s": time.perf_counter() - t0, "threads": max(2, cores), "kind": "reference",
+                               "sorted_ovl_bytes": os.path.getsize(os.path.join(wd, "ref.sorted.ovl")),
+                               "command": "oracle/_ref/ovl_sort -m 40g -t %d -k %d -i .reads.idx -o ref.sorted.ovl in.fofn" % (max(2, cores), sort_k)}
+            if device_records is not None:   # the device's sort of the device's records against the reference chain's bytes
+                seed_len = np.zeros(int(ids.max()) + 1 if ids.size else 0, dtype=np.uint32)
+                seed_len[ids] = ln
+                srt, bl, _ = overlap.sort_overlaps([device_records], seed_len, int(ln.min()) if ln.size else 0, sort_k, 300)
+                mine = overlap.encode(srt, np.zeros(2, dtype=np.uint32))
+                with open(os.path.join(wd, "ref.sorted.ovl"), "rb") as f:
+                    theirs = f.read()
+                res["ovl_sort"]["device_sorted_ovl_identical"] = mine == theirs
+                res["ovl_sort"]["blacklisted_reads"] = len(bl)
+        except (OSError, subprocess.CalledProcessError) as e_:
+            res["ovl_sort"] = {"error": repr(e_)}
+    import shutil
+    shutil.rmtree(wd, ignore_errors=True)
     return res
 
 
@@ -807,7 +842,20 @@ def main():
                 from nextdenovo_amd import overlap
                 files = sh.overlaps(my_file)   # (untimed) the records of the one raw_align job of this layout: seed file x itself
                 out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(
-                    overlap.ReadSet(np.arange(len(rs), dtype=np.uint32), lens, words, word_off), preset, files[0] if len(files) == 1 else None)
+                    overlap.ReadSet(np.arange(len(rs), dtype=np.uint32), lens, words, word_off), preset, files[0] if len(files) == 1 else None, sort_k=sort_k)
+                osrt = (out["overlap"]["cpu_baseline"] or {}).get("ovl_sort") or {}
+                if osrt.get("device_sorted_ovl_identical") is False:
+                    parity_fail = True
+                # the three stages of the reference on this box's CPUs, one after the other
+                cb = out.get("cpu_baseline")
+                if cb and out["overlap"]["cpu_baseline"] and "wall_s" in osrt:
+                    whole_cns_s = (total_bases / args.steps / world) / cb["value"] if cb["value"] else 0.0
+                    out["cpu_baseline"]["stage_chain"] = {
+                        "raw_align_s": out["overlap"]["cpu_baseline"]["wall_s"], "sort_align_s": osrt["wall_s"], "seed_cns_s_extrapolated": whole_cns_s,
+                        "corrected_bases_per_s": (total_bases / args.steps / world) / (out["overlap"]["cpu_baseline"]["wall_s"] + osrt["wall_s"] + whole_cns_s),
+                        "note": "minimap2-nd and ovl_sort of the compiled reference timed whole on %d threads; seed_cns = this step's corrected bases / "
+                                "the sample's rate (the sample is every k-th pile + the longest seeds); the metric over the three stages"
+                                % out["overlap"]["cpu_baseline"]["cores"]}
                 if out["overlap"]["cpu_baseline"] and out["overlap"]["cpu_baseline"].get("device_ovl_identical") is False:
                     parity_fail = True
         print(json.dumps(out))

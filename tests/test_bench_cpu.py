@@ -48,6 +48,12 @@ def test_bench_line_on_a_tiny_genome(monkeypatch):
     assert d["parity"]["piles"] > 5 and d["parity"]["mismatch"] == 0
     assert d["parity"]["fasta_records"] > 5 and "cns.fasta" in d["parity"]["compared"]   # the bytes compared are the ones the step wrote
     assert d["overlap"]["cpu_baseline"]["device_ovl_identical"] is True
+    # SURVEY 8(d)'s CPU protocol: three runs and their median; the reference's ovl_sort timed on the reference overlapper's file, the
+    # device's sort of the device's records byte for byte the same; the metric over raw_align + sort_align + seed_cns
+    assert len(cb["runs"]) == 3 and sorted(r["wall_s"] for r in cb["runs"])[1] == round(cb["wall_s"], 3)
+    osrt = d["overlap"]["cpu_baseline"]["ovl_sort"]
+    assert osrt["wall_s"] > 0 and osrt["sorted_ovl_bytes"] > 100 and osrt["device_sorted_ovl_identical"] is True
+    assert cb["stage_chain"]["corrected_bases_per_s"] > 0 and cb["stage_chain"]["corrected_bases_per_s"] < cb["value"] * 1.0001
     # every timed step by itself, the box the host phases ran on, and the stage's output inside the timed region
     assert len(d["step_ms"]["list"]) == d["steps"] and d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
     assert d["host"]["cpu_count"] >= 1 and d["host"]["host_threads"] >= 1
