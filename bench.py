@@ -61,6 +61,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="consensus stage only, on analytically derived piles")
     ap.add_argument("--consensus-depth", type=int, default=2, help="consensus calls in flight (1: a step's consensus ends before the next begins)")
+    ap.add_argument("--producers", type=int, default=0,
+                    help="threads (a Shard each) that compute the piles of later steps side by side (default 1: measured on config 2, a second one "
+                         "takes the line's waits for piles from 160 to 70 ms per step and leaves the step where it was -- the device is the bound)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not start the overlap / sort / pile-admission stage of the next step while the consensus of this one runs")
     ap.add_argument("--no-exchange", action="store_true",
@@ -526,6 +529,17 @@ def main():
         exchange = stage.Exchange(xdir, rank)
     sh = stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k,
                      exchange=exchange)
+    # --producers 2: a second Shard for a second producer of piles (stage.StagePipeline).  Under the consensus kernels a stage's many
+    # short kernels wait in line -- one stage takes ~0.45 s where it takes 0.09 s alone -- and the line waits ~160 ms per step for piles;
+    # with two stages side by side it waits 70 ms and the step is the same 560-570 ms (profiles/r06_pipeline_ab.txt): the device is
+    # the bound, so one producer is the default.  One GPU only (the ranks of a node step their hand-over together).
+    n_prod = max(1, args.producers)
+    if world > 1 or args.no_pipeline or args.no_overlap:
+        n_prod = 1
+    shards = [sh]
+    for _ in range(n_prod - 1):
+        shards.append(stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k))
+    last_lock = __import__("threading").Lock()
     a_piles = a_recs = a_off = a_names = None
     if analytic:  # piles from the true read positions, for the seeds of this rank's seed file
         a_piles = synth.build_piles(rs, seed_cutoff=1000, seed_ids=[int(i) for i in sh.seed_ids[my_file]])
@@ -564,8 +578,9 @@ def main():
         """(records, pile offsets, names) of a step."""
         if args.no_overlap:
             return a_recs, a_off, a_names
-        sub, off, seeds, n_bl = sh.piles(my_file)
-        last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
+        sub, off, seeds, n_bl = shards[(_k or 0) % len(shards)].piles(my_file)
+        with last_lock:
+            last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
         return (a_recs, a_off, a_names) if analytic else (sub, off, seeds)
 
     acc_lock = threading.Lock()
@@ -613,8 +628,9 @@ def main():
     if not args.no_overlap:
         from nextdenovo_amd import overlap as _ovl
         _ovl.pool_calls(reset=True)
-    for k in sh.stats:
-        sh.stats[k] = 0
+    for sh_ in shards:
+        for k in sh_.stats:
+            sh_.stats[k] = 0
     host0 = host_snapshot()
     sync()
     t0 = time.perf_counter()
@@ -630,7 +646,7 @@ def main():
             n_ok += n
     else:
         line = stage.StagePipeline(get_piles, lambda k, piles: consensus(piles[0], piles[1], piles[2], fa_path + (".%d" % (k % 2))),
-                                   depth=depth, prefetch=True)
+                                   depth=depth, prefetch=True, producers=len(shards))
         ends = []
         for _k, (b, n, res, path, _t), t_end in line.run(range(args.steps)):
             ends.append(t_end)
@@ -645,6 +661,11 @@ def main():
             step_s.append(t_end - t_last)
             t_last = t_end
         pipeline.update(on=line.prefetch, depth=line.depth, wait_s=line.wait_s)
+    for sh_ in shards[1:]:   # (the stage times of every producer's Shard, summed)
+        for k in sh_.stats:
+            sh.stats[k] += sh_.stats[k]
+        if sh.ovl_stats is None:
+            sh.ovl_stats = sh_.ovl_stats
     sync()
     dt = time.perf_counter() - t0
     host1 = host_snapshot()
@@ -761,7 +782,7 @@ def main():
             "kernel_ms": {k: round(st[k], 2) for k in ("forward_ms", "traceback_ms", "tags_ms", "links_ms", "score_ms",
                                                        "backtrack_ms", "extract_ms", "lq_ms")},
             "consensus_ms_per_step": cns_wall[0] / args.steps * 1e3,
-            "pipeline": {"next_stage_begins_during_consensus": bool(pipeline["on"]), "consensus_calls_in_flight": pipeline.get("depth", 1),
+            "pipeline": {"next_stage_begins_during_consensus": bool(pipeline["on"]), "consensus_calls_in_flight": pipeline.get("depth", 1), "piles_producers": len(shards),
                          "wait_for_prefetched_piles_ms_per_step": pipeline["wait_s"] / args.steps * 1e3,
                          "note": "with pipelining the overlap / sort / pile-admission stage of step k + 1 runs on its own host thread and "
                                  "streams while the consensus of step k holds the device; the first timed step computes its piles itself and "

@@ -541,7 +541,7 @@ int ndgpu_correct_piles_stream(ndgpu_db *h, int n_piles, const uint32_t *recs, c
         build_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_b0).count();
         bool oom = false;
         try {
-            HipBackend be(ctx, threads_each, h->dev_pool, call_order);
+            HipBackend be(ctx, threads_each, h->dev_pool, call_order, true);
             run_engines(eng.data(), cnt, be, threads_each);
         } catch (const DeviceOom &e) {
             oom = true;
@@ -585,6 +585,11 @@ int ndgpu_correct_piles_stream(ndgpu_db *h, int n_piles, const uint32_t *recs, c
     };
     std::atomic<size_t> next_sub{0};
     auto drive = [&](int ctx) {
+        // (the context serves this call's sub-batches one behind the other before a newer call's: the place in its line is kept
+        // between them)
+        DeviceAligner &dev = DeviceAligner::context(ctx);
+        dev.reserve_batches(call_order);
+        struct Unreserve { DeviceAligner &d; uint64_t o; ~Unreserve() { d.unreserve_batches(o); } } unreserve{dev, call_order};
         for (;;) {
             const size_t sb = next_sub.fetch_add(1);
             if (sb >= n_sub) break;

@@ -299,12 +299,26 @@ struct DeviceAligner::State {
         std::condition_variable cv;
         bool held = false;
         std::multiset<uint64_t> waiting;
-        void lock(uint64_t order = 0) {
+        // reserved: the caller holds a reservation of this order (reserve()): its place in the line stays taken between its batches, so
+        // a newer call's thread that is already waiting does not slip in while the older call's thread fetches its next sub-batch
+        void lock(uint64_t order = 0, bool reserved = false) {
             std::unique_lock<std::mutex> l(m);
-            auto it = waiting.insert(order);
+            auto it = reserved ? waiting.end() : waiting.insert(order);
             cv.wait(l, [&] { return !held && *waiting.begin() == order; });
-            waiting.erase(it);
+            if (!reserved) waiting.erase(it);
             held = true;
+        }
+        void reserve(uint64_t order) {
+            std::lock_guard<std::mutex> l(m);
+            waiting.insert(order);
+        }
+        void unreserve(uint64_t order) {
+            {
+                std::lock_guard<std::mutex> l(m);
+                auto it = waiting.find(order);
+                if (it != waiting.end()) waiting.erase(it);
+            }
+            cv.notify_all();
         }
         void unlock() {
             {
@@ -1391,7 +1405,9 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
     g_prof.c_pack += tc1 - tc0, g_prof.c_dev += tc2 - tc1, g_prof.c_decode += wall_ns() - tc2, g_prof.c_jobs += nt;
 }
 
-void DeviceAligner::begin_batch(uint64_t order) { s_->batch_mu.lock(order); }
+void DeviceAligner::begin_batch(uint64_t order, bool reserved) { s_->batch_mu.lock(order, reserved); }
+void DeviceAligner::reserve_batches(uint64_t order) { s_->batch_mu.reserve(order); }
+void DeviceAligner::unreserve_batches(uint64_t order) { s_->batch_mu.unreserve(order); }
 uint64_t DeviceAligner::next_order() {
     static std::atomic<uint64_t> n{1};
     return n.fetch_add(1);

@@ -85,7 +85,10 @@ class DeviceAligner {
     // begin_batch()/end_batch() bracket one batch and serialise batches of one process
     // order: who goes first when several callers wait for this context (lower first; equal: any) -- the calls of a process take a
     // number each (next_order), so that a context serves the older of two batch calls in flight before the newer one
-    void begin_batch(uint64_t order = 0);
+    void begin_batch(uint64_t order = 0, bool reserved = false);
+    // a thread that will bring this context several batches of one call keeps its place in the line between them
+    void reserve_batches(uint64_t order);
+    void unreserve_batches(uint64_t order);
     static uint64_t next_order();
     void run_main(MainPile **piles, size_t n);
     void run_extract(ExtractPile **piles, size_t n);
@@ -122,9 +125,9 @@ class DeviceAligner {
 // The product's only Backend: every request runs in HIP kernels on the device.
 class HipBackend : public Backend {
   public:
-    explicit HipBackend(int ctx = 0, int host_threads = 1, const uint32_t *db_pool = nullptr, uint64_t order = ~0ull)
+    explicit HipBackend(int ctx = 0, int host_threads = 1, const uint32_t *db_pool = nullptr, uint64_t order = ~0ull, bool reserved = false)
         : dev_(DeviceAligner::context(ctx)) {
-        dev_.begin_batch(order == ~0ull ? DeviceAligner::next_order() : order);
+        dev_.begin_batch(order == ~0ull ? DeviceAligner::next_order() : order, reserved);
         dev_.set_host_threads(host_threads);
         dev_.use_db(db_pool);
     }

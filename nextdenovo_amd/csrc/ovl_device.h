@@ -4,11 +4,24 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "nd_lockstep.h"
 
 namespace ndovl {
+
+// The stage's streams run at the device's highest priority: when the stage of the next seed file shares the device with the consensus of
+// this one (stage.StagePipeline), its kernels are the short ones -- 65 ms of device time against 580 -- and the consensus of the seed
+// file after next waits for their result.  NDGPU_OVL_PRIO=0: the runtime's default priority (the A/B knob).
+inline hipError_t create_stage_stream(hipStream_t *s)
+{
+	static const bool plain = getenv("NDGPU_OVL_PRIO") && atoi(getenv("NDGPU_OVL_PRIO")) == 0;
+	int least = 0, greatest = 0;
+	if (plain || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreate(s);
+	return hipStreamCreateWithPriority(s, hipStreamDefault, greatest);
+}
+
 
 // Every device operation of the overlap library reports its failure by throwing (defined in ovl_engine.hip): a rocPRIM primitive
 // that returns an error, a kernel launch the runtime refuses.  Until round 4 the primitives' return values were dropped -- and a

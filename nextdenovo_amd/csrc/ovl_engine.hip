@@ -1124,7 +1124,7 @@ ndgpu_ovl_index *ndgpu_ovl_index_create(const ndgpu_ovl_opt *opt, uint32_t n_rea
 		if (!getenv("NDGPU_SPIN_SYNC")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);  // (a waiting host thread sleeps: see device_runtime.hip)
 		h = new ndgpu_ovl_index();
 		h->e.device = dev;
-		HIP_OK(hipStreamCreate(&h->e.stream));
+		HIP_OK(ndovl::create_stage_stream(&h->e.stream));
 		h->e.P = to_params(*opt);
 		h->e.T.upload(n_reads, words, n_words, word_off, lens, ids, h->e.stream);
 		h->e.build_index();
@@ -1437,7 +1437,7 @@ int64_t ndgpu_ovl_sketch(const ndgpu_ovl_opt *opt, uint32_t n_reads, const uint3
 		Engine e;
 		if (const char *d = getenv("NDGPU_DEVICE")) e.device = atoi(d);
 		HIP_OK(hipSetDevice(e.device));
-		HIP_OK(hipStreamCreate(&e.stream));
+		HIP_OK(ndovl::create_stage_stream(&e.stream));
 		e.P = to_params(*opt);
 		std::vector<uint32_t> ids(n_reads, 0);
 		ReadSetDev R;

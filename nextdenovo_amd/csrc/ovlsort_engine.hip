@@ -286,7 +286,7 @@ static int64_t sort_impl(const ndgpu_ovl_rec *const *files, const int64_t *n_per
 		if (const char *e = getenv("NDGPU_DEVICE")) dev = atoi(e);
 		HIP_OK(hipSetDevice(dev % n_dev));
 		SortRun R;
-		HIP_OK(hipStreamCreate(&R.st));
+		HIP_OK(ndovl::create_stage_stream(&R.st));
 		struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } guard{R.st};
 		hipEvent_t ev0, ev1;
 		HIP_OK(hipEventCreate(&ev0)); HIP_OK(hipEventCreate(&ev1));

@@ -190,10 +190,12 @@ class StagePipeline:
     A `make_piles` that runs out of device memory beside the consensus (MemoryError) is run again when its turn comes, alone, and
     prefetching stays off from there on (genome-scale read sets whose two stages do not fit the device side by side)."""
 
-    def __init__(self, make_piles, correct, depth=2, prefetch=True):
+    def __init__(self, make_piles, correct, depth=2, prefetch=True, producers=1, ahead=2):
         self.make_piles, self.correct = make_piles, correct
         self.depth = max(1, int(depth)) if prefetch else 1
         self.prefetch = bool(prefetch)
+        self.producers = max(1, int(producers))   # threads that make piles side by side (make_piles(item) must then be safe to call from two threads
+        self.ahead = max(1, int(ahead))           # for DIFFERENT items: e.g. a Shard per thread); sets of piles made ahead of the line at most
         self.wait_s = 0.0            # time the line stood still waiting for prefetched piles
 
     def run(self, items):
@@ -201,54 +203,99 @@ class StagePipeline:
         import threading
         from concurrent.futures import ThreadPoolExecutor
         items = list(items)
-        box = {}
-
-        def fetch(it):
-            try:
-                box["piles"] = self.make_piles(it)
-            except BaseException as e:   # noqa: BLE001  (taken up by the turn that wants the piles)
-                box["error"] = e
 
         def timed(it, piles):
             r = self.correct(it, piles)
             return r, time.perf_counter()
 
-        th = None
+        # the producers run ahead of the line on their own: the piles of a later item are begun when a producer is free (not when the line
+        # comes to take them), at most `ahead` sets beyond the item the line is at -- so the line never stands still for a stage that could
+        # have begun earlier.  (Calls that share the device end in pairs as often as one by one, and the line then asks for two sets in
+        # quick succession.)
+        cond = threading.Condition()
+        state = {"taken": 0, "next": 1, "made": {}, "stop": False}
+
+        def produce():
+            while True:
+                with cond:
+                    while not state["stop"] and (state["next"] >= len(items) or state["next"] > state["taken"] + self.ahead):
+                        if state["next"] >= len(items):
+                            return
+                        cond.wait(0.05)
+                    if state["stop"]:
+                        return
+                    n = state["next"]
+                    state["next"] += 1
+                try:
+                    res = ("ok", self.make_piles(items[n]))
+                except BaseException as e:   # noqa: BLE001  (taken up by the turn that wants the piles)
+                    res = ("error", e)
+                with cond:
+                    state["made"][n] = res
+                    if res[0] == "error":
+                        state["stop"] = True
+                    cond.notify_all()
+                if res[0] == "error":
+                    return
+
+        threads = []
         inflight = []
-        with ThreadPoolExecutor(max_workers=self.depth) as pool:
-            for n, it in enumerate(items):
-                if th is not None:
-                    t0 = time.perf_counter()
-                    th.join()
-                    self.wait_s += time.perf_counter() - t0
-                    th = None
-                    err, piles = box.pop("error", None), box.pop("piles", None)
-                    if isinstance(err, MemoryError):
-                        sys.stderr.write("[ndgpu stage] the next seed file's overlap stage ran out of device memory beside the consensus: "
-                                         "one stage after the other from here on\n")
-                        self.prefetch = False
-                        self.depth = 1
-                        while inflight:            # (its turn has come: alone on the device)
-                            i0, f0 = inflight.pop(0)
-                            r0, te0 = f0.result()
-                            yield i0, r0, te0
+        try:
+            with ThreadPoolExecutor(max_workers=self.depth) as pool:
+                for n, it in enumerate(items):
+                    if threads and n >= 1:
+                        t0 = time.perf_counter()
+                        with cond:
+                            while n not in state["made"]:
+                                if state["stop"] and n >= state["next"]:   # (a producer failed on an earlier item and nobody will make this one)
+                                    break
+                                cond.wait(0.05)
+                            kind, val = state["made"].pop(n, ("missing", None))
+                            state["taken"] = n
+                            cond.notify_all()
+                        self.wait_s += time.perf_counter() - t0
+                        if kind == "error" and isinstance(val, MemoryError):
+                            sys.stderr.write("[ndgpu stage] the next seed file's overlap stage ran out of device memory beside the consensus: "
+                                             "one stage after the other from here on\n")
+                            self.prefetch = False
+                            self.depth = 1
+                            for th in threads:
+                                th.join()
+                            threads = []
+                            with cond:
+                                state["made"].clear()      # (sets made ahead are dropped: each is made again at its turn, alone)
+                            while inflight:            # (its turn has come: alone on the device)
+                                i0, f0 = inflight.pop(0)
+                                r0, te0 = f0.result()
+                                yield i0, r0, te0
+                            piles = self.make_piles(it)
+                        elif kind == "error":
+                            raise val
+                        elif kind == "missing":
+                            piles = self.make_piles(it)
+                        else:
+                            piles = val
+                    else:
                         piles = self.make_piles(it)
-                    elif err is not None:
-                        raise err
-                else:
-                    piles = self.make_piles(it)
-                if self.prefetch and n + 1 < len(items):
-                    th = threading.Thread(target=fetch, args=(items[n + 1],))
-                    th.start()
-                inflight.append((it, pool.submit(timed, it, piles)))
-                while len(inflight) >= self.depth:
+                        if self.prefetch and len(items) > 1 and n == 0:   # (the first item's piles are the line's own: nothing runs before the line does)
+                            threads = [threading.Thread(target=produce) for _ in range(self.producers)]
+                            for th in threads:
+                                th.start()
+                    inflight.append((it, pool.submit(timed, it, piles)))
+                    while len(inflight) >= self.depth:
+                        i0, f0 = inflight.pop(0)
+                        r0, te0 = f0.result()
+                        yield i0, r0, te0
+                while inflight:
                     i0, f0 = inflight.pop(0)
                     r0, te0 = f0.result()
                     yield i0, r0, te0
-            while inflight:
-                i0, f0 = inflight.pop(0)
-                r0, te0 = f0.result()
-                yield i0, r0, te0
+        finally:
+            with cond:
+                state["stop"] = True
+                cond.notify_all()
+            for th in threads:
+                th.join()
 
 
 class Shard:
