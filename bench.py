@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--profile", default="")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-baseline", action="store_true",
+                    help="skip the reference overlapper / ovl_sort leg of the CPU baseline (minutes on a genome-scale read set); the consensus leg and the parity block stay")
     ap.add_argument("--lengths-only", action="store_true",
                     help="the timed steps skip the hand-over of the corrected sequences and the cns.fasta / .idx write (A/B runs only: "
                          "the output is part of the stage)")
@@ -859,7 +861,7 @@ def main():
                 full = db.correct_piles(recs, off, read_type=read_type, max_lq_length=max_lq, host_threads=args.host_threads)
                 out["parity"] = parity_block(ref, full, piles)
                 parity_fail = out["parity"]["mismatch"] != 0
-            if not args.no_overlap and n_files == 1 and args.config in (2, 3):
+            if not args.no_overlap and n_files == 1 and args.config in (2, 3) and not args.no_overlap_baseline:
                 from nextdenovo_amd import overlap
                 files = sh.overlaps(my_file)   # (untimed) the records of the one raw_align job of this layout: seed file x itself
                 out["overlap"]["cpu_baseline"] = cpu_baseline_overlap(

@@ -851,7 +851,10 @@ void launch_ond_traceback_seg(const AlnTask *tasks, AlnOut *outs, const uint32_t
     const dim3 per_task((unsigned)((n_tasks + 63) / 64)), per_slot((unsigned)((tb.n_slots + 63) / 64));
     hipLaunchKernelGGL(tb_chase_kernel, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, tb.ck_cells, (const uint2 *)tb.ck_hdr, tb.segs,
                        n_tasks, tb.cshift, tb.warm);
-    hipLaunchKernelGGL(tb_walk_kernel, per_slot, dim3(64), 0, (hipStream_t)stream, tb.segs, tb.seg_outs, tasks, outs, pool, db_pool, trace, ops,
+    // (NDGPU_TB_LDS_KB: dynamic LDS a walker wavefront asks for and never touches -- an occupancy knob: every lane walks a trace and two
+    // sequences of its own, so the lines a compute unit's resident walkers hold open outgrow the caches with their number)
+    static const size_t walk_lds = getenv("NDGPU_TB_LDS_KB") ? (size_t)atoi(getenv("NDGPU_TB_LDS_KB")) << 10 : 0;
+    hipLaunchKernelGGL(tb_walk_kernel, per_slot, dim3(64), walk_lds, (hipStream_t)stream, tb.segs, tb.seg_outs, tasks, outs, pool, db_pool, trace, ops,
                        tb.n_slots);
     hipLaunchKernelGGL(tb_stitch_kernel, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, tb.seg_outs, n_tasks, tb.cshift);
     // what the stitch refused (still ST_FINISHED) in one piece

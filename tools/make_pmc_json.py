@@ -15,8 +15,9 @@ import bench  # noqa: E402
 def main():
     table, steps, config = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
     note = sys.argv[4] if len(sys.argv) > 4 else os.path.relpath(table, ROOT)
-    keys = ("ond_forward_kernel", "ond_traceback_kernel", "count_links_kernel", "score_seg_kernel<96")
+    keys = ("ond_forward_kernel", "ond_traceback_kernel", "tb_walk_kernel", "count_links_kernel", "score_seg_kernel<96")
     kernels = {}
+    acc = {}   # a kernel's instantiations together (K7 with and without checkpoints share one HIP-event bracket and one model in bench.py)
     for ln in open(table):
         mt = re.match(r"^(\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+([\d.]+)\s*$", ln)
         if not mt:
@@ -24,8 +25,14 @@ def main():
         for k in keys:
             if mt.group(1).startswith(k):
                 name = k.split("<")[0]
-                kernels[name] = {"launches_per_step": int(mt.group(2)) / steps, "fetch_kb_per_launch": float(mt.group(3)),
-                                 "write_kb_per_launch": float(mt.group(4)), "source_sha16": bench.kernel_source_sha16(name)}
+                a = acc.setdefault(name, [0, 0.0, 0.0])
+                calls = int(mt.group(2))
+                a[0] += calls
+                a[1] += calls * float(mt.group(3))
+                a[2] += calls * float(mt.group(4))
+    for name, (calls, fkb, wkb) in acc.items():
+        kernels[name] = {"launches_per_step": calls / steps, "fetch_kb_per_launch": fkb / calls, "write_kb_per_launch": wkb / calls,
+                         "source_sha16": bench.kernel_source_sha16(name)}
     out = {"config": config, "source": note, "kernels": kernels}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -36,7 +36,7 @@ def main():
         calls = max(f[k][0], w[k][0], 1)
         fk, wk = f[k][1] / calls, w[k][1] / calls
         rows.append(((fk + wk) * calls, short(k), calls, fk, wk))
-    for _, k, calls, fk, wk in sorted(rows, reverse=True)[:16]:
+    for _, k, calls, fk, wk in sorted(rows, reverse=True)[:40]:
         print("%-46s %6d %16.0f %16.0f %14.3f" % (k, calls, fk, wk, (fk + wk) * 1024 / 1e9))
 
 
