@@ -841,7 +841,10 @@ void launch_ond_forward(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool
 void launch_ond_forward_ckpt(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool, uint64_t *trace,
                              uint32_t *ops, const TbArgs &tb, int n_tasks, void *stream, const int32_t *order) {
     if (n_tasks <= 0) return;
-    hipLaunchKernelGGL(ond_forward_kernel<true>, dim3((unsigned)n_tasks), dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
+    // (NDGPU_K7_LDS_KB: dynamic LDS a forward wavefront asks for and never touches -- an occupancy knob for A/B runs: fewer resident K7
+    // wavefronts leave wavefront slots and issue cycles to the kernels of the other contexts)
+    static const size_t k7_lds = getenv("NDGPU_K7_LDS_KB") ? (size_t)atoi(getenv("NDGPU_K7_LDS_KB")) << 10 : 0;
+    hipLaunchKernelGGL(ond_forward_kernel<true>, dim3((unsigned)n_tasks), dim3(64), k7_lds, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,
                        order, tb.ck_cells, (uint2 *)tb.ck_hdr, ops, tb.cshift);
 }
 
