@@ -697,10 +697,19 @@ def main():
         models = kernel_models(st)
         stat_rows, stat_file = committed_kernel_stats()
         dom = None
+        # (a modelled kernel may appear as several instantiations -- K7 with and without checkpoints -- that share one HIP-event bracket
+        # and one model: their rows are taken together, calls-weighted)
+        agg = {}
+        for kname, calls, avg_us in stat_rows:
+            for key in models:
+                if kname.startswith(key):
+                    a_ = agg.setdefault(key, [0, 0.0])
+                    a_[0] += calls
+                    a_[1] += calls * avg_us
         for kname, calls, avg_us in stat_rows:   # (rows in order of GPU time)
             for key in models:
                 if kname.startswith(key):
-                    dom = (key, kname, calls, avg_us)
+                    dom = (key, kname, agg[key][0], agg[key][1] / max(1, agg[key][0]))
                     break
             if dom:
                 break
@@ -727,11 +736,7 @@ def main():
         if not analytic and world == 1 and n_files == 1:
             traffic, traffic_note = committed_traffic(dom[0], dom_entry["launches_per_step"], args.config)
         others = {}
-        rp = {}
-        for kname, calls, avg_us in stat_rows:
-            for key in models:
-                if kname.startswith(key) and key not in rp:
-                    rp[key] = avg_us
+        rp = {key: v[1] / max(1, v[0]) for key, v in agg.items()}
         for key in models:
             if key != dom[0]:
                 others[key] = entry(key, rp.get(key) if same_workload else None)

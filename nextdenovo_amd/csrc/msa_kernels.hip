@@ -270,18 +270,30 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
     const ColBlock B = blocks[blockIdx.x];
     const PileDev P = piles[B.pile];
     const int lane = (int)threadIdx.x;
-    const uint32_t *ms = max_size + P.col_off;
-    const uint32_t *cb = cell_base + P.col_off;
-    const uint32_t *eb = ent_base + P.col_off;
-    const uint32_t *acc = acc_list + P.acc_off;
+    // (the pile's offsets are the same in every lane: said out loud, they live in scalar registers -- as vector registers four of these
+    // 64-bit values were what the 72-register budget spilled around every column: 32 bytes of scratch written and read back per column
+    // and lane, 8.9 GB of the kernel's 10.5 GB of writes per launch by the counters)
+    auto uni64 = [](uint64_t v) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    const uint64_t p_col_off = uni64(P.col_off), p_acc_off = uni64(P.acc_off), p_cell_off = uni64(P.cell_off), p_ent_off = uni64(P.ent_off);
+    const uint32_t *ms = max_size + p_col_off;
+    const uint32_t *cb = cell_base + p_col_off;
+    const uint32_t *eb = ent_base + p_col_off;
+    const uint32_t *acc = acc_list + p_acc_off;
     const uint32_t t_end = B.col0 + kColBlock < P.seed_len ? B.col0 + kColBlock : P.seed_len;
 
     // Per-lane read descriptors of the first kRegChunks x 64 accepted reads stay in registers for
     // the whole column block; deeper piles reload the rest from HBM.
     constexpr int kRegChunks = 2;
+    constexpr int kWinChunks = 1;   // of which keep a 32-byte window of their tag stream in registers
     uint32_t g_ts[kRegChunks], g_te[kRegChunks], g_len[kRegChunks];
     const uint32_t *g_ci[kRegChunks];
-    const uint32_t *g_tg[kRegChunks];
+    uint32_t g_tg[kRegChunks];  // first tag slot of the read (an index into `tags`: the table of a sub-batch holds < 2^32 slots; a
+                                // 64-bit pointer per chunk was two of the registers the 72-register budget spilled -- 32 bytes of
+                                // scratch written and read back per cell row and lane: 8.9 GB of the kernel's 10.5 GB of writes)
 #pragma unroll
     for (int ch = 0; ch < kRegChunks; ch++) {
         const uint32_t rank = (uint32_t)ch * 64u + (uint32_t)lane;
@@ -289,14 +301,14 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
         g_te[ch] = 0;  // empty interval: never covers a column
         g_len[ch] = 0;
         g_ci[ch] = nullptr;
-        g_tg[ch] = nullptr;
+        g_tg[ch] = 0;
         if (rank < P.n_acc) {
             const ReadDev *R = &reads[acc[rank]];
             g_ts[ch] = R->t_s;
             g_te[ch] = R->t_e;
             g_len[ch] = R->aln_len;
             g_ci[ch] = colidx + R->colidx_off;
-            g_tg[ch] = tags + R->tag_off;
+            g_tg[ch] = (uint32_t)R->tag_off;
         }
     }
     const uint32_t n_chunks = (P.n_acc + 63u) / 64u;
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
 
     for (uint32_t t = B.col0; t < t_end; t++) {
         const uint32_t width = ms[t];
-        uint64_t e = P.ent_off + eb[t];
+        uint64_t e = p_ent_off + eb[t];
         for (uint32_t d = 0; d < width; d++) {
             uint32_t n_cell[6] = {0, 0, 0, 0, 0, 0};  // links collected so far in the six cells of (t, d): the same in every lane
             for (uint32_t chn = 0; chn < n_chunks; chn++) {
@@ -335,20 +347,30 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
                         if ((uint32_t)ch == chn) {
                             const uint32_t i = w_pos[ch];
                             if (i < g_len[ch]) {
-                                const uint32_t *tp = g_tg[ch];
+                                const uint32_t *tp = tags + g_tg[ch];
                                 if (w_i[ch] == 0xffffffffu) {  // first tag of this read inside the column block
                                     if (i > 0) w_p1[ch] = tp[i - 1];
                                     if (i > 1) w_p2[ch] = tp[i - 2];
                                 }
-                                if (w_i[ch] == 0xffffffffu || i - w_i[ch] >= 8u) {
-                                    w_lo[ch] = *reinterpret_cast<const uint4 *>(tp + i);
-                                    w_hi[ch] = *reinterpret_cast<const uint4 *>(tp + i + 4);
+                                uint32_t c;
+                                if (ch < kWinChunks) {
+                                    if (w_i[ch] == 0xffffffffu || i - w_i[ch] >= 8u) {
+                                        w_lo[ch] = *reinterpret_cast<const uint4 *>(tp + i);
+                                        w_hi[ch] = *reinterpret_cast<const uint4 *>(tp + i + 4);
+                                        w_i[ch] = i;
+                                    }
+                                    const uint32_t k = i - w_i[ch];
+                                    const uint4 w = k < 4u ? w_lo[ch] : w_hi[ch];
+                                    const uint32_t k4 = k & 3u;
+                                    c = k4 == 0 ? w.x : k4 == 1 ? w.y : k4 == 2 ? w.z : w.w;
+                                } else {
+                                    // the second 64 reads of a deep pile: the next tag straight from the stream (it sits in the line the tag
+                                    // before it came from).  A 32-byte window for this chunk too was 8 registers more than the kernel's 72
+                                    // hold: the compiler spilled it around every column -- 32 bytes of scratch per lane and column written
+                                    // and read back, 8.9 GB of the kernel's 10.5 GB of writes per launch by the counters.
                                     w_i[ch] = i;
+                                    c = tp[i];
                                 }
-                                const uint32_t k = i - w_i[ch];
-                                const uint4 w = k < 4u ? w_lo[ch] : w_hi[ch];
-                                const uint32_t k4 = k & 3u;
-                                const uint32_t c = k4 == 0 ? w.x : k4 == 1 ? w.y : k4 == 2 ? w.z : w.w;
                                 if ((c >> 3) == key) {  // the read's next tag sits in this cell row: consume it
                                     cur = c;
                                     pp = w_p1[ch];
@@ -421,12 +443,12 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
                 }
             }
             // flush the six cells of (t, d), links contiguous per cell in first-seen order
-            const uint64_t cell0 = P.cell_off + cb[t] + (uint64_t)d * 6u;
+            const uint64_t cell0 = p_cell_off + cb[t] + (uint64_t)d * 6u;
 #pragma unroll
             for (uint32_t bb = 0; bb < 6; bb++) {
                 const uint32_t n = n_cell[bb];
                 if (lane == 0) {
-                    cell_start[cell0 + bb] = (uint32_t)(e - P.ent_off);
+                    cell_start[cell0 + bb] = (uint32_t)(e - p_ent_off);
                     cell_len[cell0 + bb] = n;
                 }
                 for (uint32_t j = (uint32_t)lane; j < n; j += 64) {
