@@ -638,7 +638,7 @@ def main():
     t0 = time.perf_counter()
     bases = n_ok = 0
     step_s = []
-    depth = 2 if (pipeline["on"] and args.consensus_depth >= 2 and args.steps > 1) else 1
+    depth = min(max(1, args.consensus_depth), 4) if (pipeline["on"] and args.steps > 1) else 1
     if not pipeline["on"]:
         for k_step in range(args.steps):
             t_s = time.perf_counter()
@@ -647,7 +647,7 @@ def main():
             bases += b
             n_ok += n
     else:
-        line = stage.StagePipeline(get_piles, lambda k, piles: consensus(piles[0], piles[1], piles[2], fa_path + (".%d" % (k % 2))),
+        line = stage.StagePipeline(get_piles, lambda k, piles: consensus(piles[0], piles[1], piles[2], fa_path + (".%d" % (k % 4))),
                                    depth=depth, prefetch=True, producers=len(shards))
         ends = []
         for _k, (b, n, res, path, _t), t_end in line.run(range(args.steps)):
