@@ -270,19 +270,10 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
     const ColBlock B = blocks[blockIdx.x];
     const PileDev P = piles[B.pile];
     const int lane = (int)threadIdx.x;
-    // (the pile's offsets are the same in every lane: said out loud, they live in scalar registers -- as vector registers four of these
-    // 64-bit values were what the 72-register budget spilled around every column: 32 bytes of scratch written and read back per column
-    // and lane, 8.9 GB of the kernel's 10.5 GB of writes per launch by the counters)
-    auto uni64 = [](uint64_t v) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        return ((uint64_t)hi << 32) | lo;
-    };
-    const uint64_t p_col_off = uni64(P.col_off), p_acc_off = uni64(P.acc_off), p_cell_off = uni64(P.cell_off), p_ent_off = uni64(P.ent_off);
-    const uint32_t *ms = max_size + p_col_off;
-    const uint32_t *cb = cell_base + p_col_off;
-    const uint32_t *eb = ent_base + p_col_off;
-    const uint32_t *acc = acc_list + p_acc_off;
+    const uint32_t *ms = max_size + P.col_off;
+    const uint32_t *cb = cell_base + P.col_off;
+    const uint32_t *eb = ent_base + P.col_off;
+    const uint32_t *acc = acc_list + P.acc_off;
     const uint32_t t_end = B.col0 + kColBlock < P.seed_len ? B.col0 + kColBlock : P.seed_len;
 
     // Per-lane read descriptors of the first kRegChunks x 64 accepted reads stay in registers for
@@ -291,9 +282,7 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
     constexpr int kWinChunks = 1;   // of which keep a 32-byte window of their tag stream in registers
     uint32_t g_ts[kRegChunks], g_te[kRegChunks], g_len[kRegChunks];
     const uint32_t *g_ci[kRegChunks];
-    uint32_t g_tg[kRegChunks];  // first tag slot of the read (an index into `tags`: the table of a sub-batch holds < 2^32 slots; a
-                                // 64-bit pointer per chunk was two of the registers the 72-register budget spilled -- 32 bytes of
-                                // scratch written and read back per cell row and lane: 8.9 GB of the kernel's 10.5 GB of writes)
+    uint32_t g_tg[kRegChunks];  // first tag slot of the read (an index into `tags`: the table of a sub-batch holds < 2^32 slots)
 #pragma unroll
     for (int ch = 0; ch < kRegChunks; ch++) {
         const uint32_t rank = (uint32_t)ch * 64u + (uint32_t)lane;
@@ -332,7 +321,7 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
 
     for (uint32_t t = B.col0; t < t_end; t++) {
         const uint32_t width = ms[t];
-        uint64_t e = p_ent_off + eb[t];
+        uint64_t e = P.ent_off + eb[t];
         for (uint32_t d = 0; d < width; d++) {
             uint32_t n_cell[6] = {0, 0, 0, 0, 0, 0};  // links collected so far in the six cells of (t, d): the same in every lane
             for (uint32_t chn = 0; chn < n_chunks; chn++) {
@@ -443,12 +432,12 @@ __global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(cons
                 }
             }
             // flush the six cells of (t, d), links contiguous per cell in first-seen order
-            const uint64_t cell0 = p_cell_off + cb[t] + (uint64_t)d * 6u;
+            const uint64_t cell0 = P.cell_off + cb[t] + (uint64_t)d * 6u;
 #pragma unroll
             for (uint32_t bb = 0; bb < 6; bb++) {
                 const uint32_t n = n_cell[bb];
                 if (lane == 0) {
-                    cell_start[cell0 + bb] = (uint32_t)(e - p_ent_off);
+                    cell_start[cell0 + bb] = (uint32_t)(e - P.ent_off);
                     cell_len[cell0 + bb] = n;
                 }
                 for (uint32_t j = (uint32_t)lane; j < n; j += 64) {

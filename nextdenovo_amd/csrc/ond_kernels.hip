@@ -687,7 +687,8 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
     int x = G.x, k = G.min_k + 2 * G.idx, d = G.d_top, idx = G.idx;
     uint32_t pos = G.pos;
     uint64_t hdr = pos ? S[pos - 1] : 0ull;
-    uint64_t c1 = pos >= 2 ? S[pos - 2] : 0ull, c2 = pos >= 3 ? S[pos - 3] : 0ull;
+    uint64_t c1 = pos >= 2 ? S[pos - 2] : 0ull;   // the word before the header, loaded a row ahead: the header of the row below, or -- for the
+                                                  // few rows of more than 56 cells -- this record's second word
     TbSegOut R;
     R.x_own = R.k_own = R.x_end = R.k_end = 0;
     R.lead = R.trail = 0;
@@ -708,10 +709,9 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
         if (left) { k--; x--; } else k++;
         const uint32_t len = 1u + (uint32_t)((hdr >> kStreamBits) & 1ull);
         pos = pos > len ? pos - len : 0u;
-        hdr = pos ? (len == 1u ? c1 : c2) : 0ull;
+        hdr = pos ? (len == 1u ? c1 : S[pos - 1]) : 0ull;   // (behind a two-word record the header is not in hand: one load the row waits for)
         idx += (int)(hdr >> (kStreamBits + 1)) - (left ? 1 : 0);
         c1 = pos >= 2 ? S[pos - 2] : 0ull;
-        c2 = pos >= 3 ? S[pos - 3] : 0ull;
     };
 
     // the rows above the owned ones: the walk only (no columns, no gap count)
