@@ -1002,6 +1002,7 @@ __global__ void __launch_bounds__(64) sort_pass_kernel(const SortJob *__restrict
 	__shared__ uint32_t cnt[256], head[256], tail[256];
 	__shared__ int nz, dA, dB;
 	if (blockIdx.x >= n_jobs) return;
+	__builtin_amdgcn_s_setprio(3);   // (see chain_kernel)
 	const SortJob job = jobs[blockIdx.x];
 	const int lane = threadIdx.x, sh = job.shift;
 	const uint32_t beg = job.beg, end = job.end;
@@ -1195,6 +1196,10 @@ __global__ void __launch_bounds__(64) chain_kernel(const uint64_t *__restrict__ 
 	__shared__ uint16_t ring[kRing];
 	const uint32_t sb = blockIdx.x;
 	if (sb >= n_slabs) return;
+	// (the stage's chain kernels ask the SIMD's arbiter for priority: when the stage runs beside the consensus of another seed file
+	// -- stage.StagePipeline -- a wavefront of theirs shares its SIMD with seven of K7's, and a chain that gets an eighth of the issue
+	// slots is eight times as long; they are few wavefronts, what they take nobody misses)
+	__builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
 	// one slab = whole segments [i0, n) of one read (indices relative to the read: p[] holds read-relative indices)
 	const uint32_t rd = slab_read[sb];
@@ -1328,6 +1333,7 @@ __global__ void __launch_bounds__(64) chain_ends_kernel(const uint64_t *__restri
 {
 	const uint32_t rd = blockIdx.x;
 	if (rd >= n_reads) return;
+	__builtin_amdgcn_s_setprio(3);   // (see chain_kernel)
 	const int lane = threadIdx.x;
 	const uint64_t a0 = r_aoff[rd];
 	const int32_t n = (int32_t)(r_aoff[rd + 1] - a0);
@@ -1485,6 +1491,7 @@ __global__ void __launch_bounds__(64) hits_kernel(const uint64_t *__restrict__ r
                             OvlRec10 *__restrict__ recs10, uint64_t *__restrict__ cx, uint64_t *__restrict__ cy, uint32_t *__restrict__ n_ca,
                             unsigned long long *__restrict__ prof)
 {
+	__builtin_amdgcn_s_setprio(3);   // (see chain_kernel)
 	// (NDGPU_K5_PROF: per phase the sum over reads and the longest single read, in 10 ns ticks of the constant clock)
 #ifdef SIMT_EMULATION
 #define K5_TICK(ph) ((void)0)
