@@ -933,9 +933,10 @@ __device__ void score_range(K10Smem<CELLS, ENTS> &S, const K10Args &A, const Pil
     }
 }
 
-// Phase A: one workgroup per (pile, segment) of this table tier.
+// Phase A: one workgroup per (pile, segment) of this table tier.  (Five wavefronts per SIMD asked for: the small tier then takes 96 registers
+// instead of 101 -- no scratch -- and six workgroups fit a compute unit where five did; the kernel is parked half its cycles.)
 template <int CELLS, int ENTS>
-__global__ __launch_bounds__(192) void score_seg_kernel(const K10Args A, const SegItem *__restrict__ items) {
+__global__ __launch_bounds__(192, 5) void score_seg_kernel(const K10Args A, const SegItem *__restrict__ items) {
     __shared__ K10Smem<CELLS, ENTS> S;
     const SegItem it = items[blockIdx.x];
     const PileDev &P = A.piles[it.pile];
