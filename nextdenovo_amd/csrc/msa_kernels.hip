@@ -252,8 +252,10 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
 // of 13.8 KB: the kernel is latency-bound and lives on resident wavefronts); a cell that overflows raises err[0] and the
 // host repeats the sub-batch with kLinkCap.  Seven wavefronts per SIMD for the small capacity (72 VGPRs, 36 B of scratch per lane):
 // 148 -> 127 ms per config-2 step with the kernel alone on the device; at 6 (80 VGPRs) 133 ms, at 8 (64 VGPRs, 76 B of scratch) 134 ms.
+// Round 6: the second chunk of reads lost its register window (it was what spilled), and at EIGHT wavefronts per SIMD the kernel now takes
+// 63 registers with 12 bytes of scratch per lane and column: 124.2 (seven, no scratch) -> 118.8 ms.
 template <int CAP>
-__global__ __launch_bounds__(64, CAP <= 64 ? 7 : 3) void count_links_kernel(const PileDev *__restrict__ piles,
+__global__ __launch_bounds__(64, CAP <= 64 ? 8 : 3) void count_links_kernel(const PileDev *__restrict__ piles,
                                                           const ReadDev *__restrict__ reads,
                                                           const uint32_t *__restrict__ acc_list,
                                                           const ColBlock *__restrict__ blocks,
