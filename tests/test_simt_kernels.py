@@ -349,6 +349,23 @@ def _oom_child(env, twice=0):
     return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
 
 
+def test_deep_pile_through_every_read_chunk_of_the_link_counter(simt_api, host_harness):
+    """A pile of > 128 accepted reads: K9's first 64 reads keep a 32-byte window of their tag stream in registers, the second 64 take their
+    next tag straight from the stream (round 6: that window was what the register budget spilled), the rest go through the column index
+    -- all three against the host engine + oracle."""
+    from nextdenovo_amd import synth
+    rs, piles = _synth_set(6000, 7.6, 0.25, 83, depth=150)
+    p = max(piles, key=lambda q: len(q["recs"]))
+    assert len(p["recs"]) > 135, len(p["recs"])
+    seqs, st, en, mal = synth.pile_sequences(rs, p)
+    mlq = min(en[0] // 2, 10000)
+    fn, fr = util.bind_correct(host_harness, "ndtest_correct", "ndtest_free")
+    c = util.call_correct(fn, fr, dict(seqs=seqs, aln_start=st, aln_end=en, max_aln=mal, max_lq=mlq, read_type=1, fast=0, split=0))
+    a = simt_api.correct(seqs, st, en, mal, max_lq_length=mlq)
+    assert a[0] == c[0] and a[2] == c[2] and a[0] > 1000
+    assert np.float32(a[1]) == np.float32(c[1])
+
+
 def test_out_of_device_memory_halves_the_sub_batch(simt_lib):
     """lib/nextcorrect.c:2254-2261, lib/nextcorrect.py:255-257: a seed whose working memory cannot be had is a `len == 3` seed and
     nothing else is lost.  Here: a sub-batch that does not fit is halved until its pieces fit -- the records of the pieces are the
