@@ -64,8 +64,9 @@ def parse(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="consensus stage only, on analytically derived piles")
     ap.add_argument("--consensus-depth", type=int, default=2, help="consensus calls in flight (1: a step's consensus ends before the next begins)")
     ap.add_argument("--producers", type=int, default=0,
-                    help="threads (a Shard each) that compute the piles of later steps side by side (default 1: measured on config 2, a second one "
-                         "takes the line's waits for piles from 160 to 70 ms per step and leaves the step where it was -- the device is the bound)")
+                    help="threads (a Shard each) that compute the piles of later steps side by side (default: 1 on one GPU -- measured on config 2, a "
+                         "second one takes the line's waits for piles from 160 to 70 ms per step and leaves the step where it was: the device is the "
+                         "bound --, 2 per rank of several when the rank has six CPUs or more: a rank's step is bound by its stage)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not start the overlap / sort / pile-admission stage of the next step while the consensus of this one runs")
     ap.add_argument("--no-exchange", action="store_true",
@@ -535,12 +536,22 @@ def main():
     # short kernels wait in line -- one stage takes ~0.45 s where it takes 0.09 s alone -- and the line waits ~160 ms per step for piles;
     # with two stages side by side it waits 70 ms and the step is the same 560-570 ms (profiles/r06_pipeline_ab.txt): the device is
     # the bound, so one producer is the default.  One GPU only (the ranks of a node step their hand-over together).
+    # N > 1: a rank's stage takes two to three times as long beside its consensus as alone (80 -> 280 ms for a rank of 2, 40 -> 110 for a
+    # rank of 8) and is what the rank's line waits for; two producers -- each Shard with an Exchange object of its own on the node's
+    # directory, the steps numbered here -- keep it fed.  Only where the rank has CPUs for them.
     n_prod = max(1, args.producers)
-    if world > 1 or args.no_pipeline or args.no_overlap:
+    if args.producers <= 0 and world > 1:
+        from nextdenovo_amd import hostinfo as _hi
+        n_prod = 2 if _hi.effective_cpus() // world >= 6 else 1
+    if args.no_pipeline or args.no_overlap:
         n_prod = 1
     shards = [sh]
+    if n_prod > 1 and exchange is not None:
+        exchange.lookahead, exchange.KEEP_STEPS = 2, 7   # (StagePipeline.ahead; see Exchange.__init__)
     for _ in range(n_prod - 1):
-        shards.append(stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k))
+        ex_b = stage.Exchange(exchange.dir, rank, lookahead=2) if exchange is not None else None
+        shards.append(stage.Shard(words, word_off, lens, preset=preset, seed_cutoff=1000, read_cutoff=500, n_seed_files=n_files, sort_k=sort_k,
+                                  exchange=ex_b))
     last_lock = __import__("threading").Lock()
     a_piles = a_recs = a_off = a_names = None
     if analytic:  # piles from the true read positions, for the seeds of this rank's seed file
@@ -580,7 +591,7 @@ def main():
         """(records, pile offsets, names) of a step."""
         if args.no_overlap:
             return a_recs, a_off, a_names
-        sub, off, seeds, n_bl = shards[(_k or 0) % len(shards)].piles(my_file)
+        sub, off, seeds, n_bl = shards[(_k or 0) % len(shards)].piles(my_file, step=None if _k is None else step_base[0] + 1 + _k)
         with last_lock:
             last.update(sub=sub, off=off, seeds=seeds, n_bl=n_bl)
         return (a_recs, a_off, a_names) if analytic else (sub, off, seeds)
@@ -621,8 +632,10 @@ def main():
         last_res[:] = [res]
         return b_ok, n_ok
 
+    step_base = [0]   # the hand-over's step number of the last warm-up step: timed step k is step_base + 1 + k on every Shard of the rank
     for _ in range(args.warmup):
         step()
+    step_base[0] = args.warmup
     cns_wall[0] = 0.0
     write_wall[0] = 0.0
     stream_wall[0] = 0.0
@@ -822,7 +835,9 @@ def main():
                 "exchange": exchange is not None,
                 "per_rank_jobs_computed": [r_["jobs_computed_with_exchange" if exchange is not None else "jobs_computed_alone"] for r_ in pl],
                 "per_rank_index_builds": [r_["index_builds_with_exchange" if exchange is not None else "index_builds_alone"] for r_ in pl],
-                "rank0_exchange": dict(exchange.stats) if exchange is not None else None,
+                "rank0_exchange": ({k_: sum(sh_.exchange.stats[k_] for sh_ in shards if sh_.exchange is not None) for k_ in exchange.stats}
+                                   if exchange is not None else None),
+                "rank0_piles_producers": len(shards),
                 "note": "a seed x seed pair is mapped once per node and handed over through /dev/shm (nextDenovo:455-459 does it with "
                         "`ln -sf`); --no-exchange: every rank maps the mirrors it needs itself"}
         if not args.no_overlap:

@@ -104,8 +104,13 @@ def plan(n_seed_files: int, n_part_files: int = 0):
 class Exchange:
     """Node-local hand-over of seed x seed job records between the ranks of one node (one directory, one file per job and step)."""
 
-    def __init__(self, directory: str, rank: int, timeout_s: float = 120.0):
+    def __init__(self, directory: str, rank: int, timeout_s: float = 120.0, lookahead: int = 0):
+        """lookahead: how many steps beyond the one a reader waits for its owner may have written files of WITHOUT being through with that
+        step -- 0 for an owner that makes its steps one after the other; `StagePipeline.ahead` for an owner whose steps are made by
+        several producers side by side (each with an Exchange object of its own on the same directory, steps numbered by the caller)."""
         self.dir, self.rank, self.timeout_s, self.step = directory, rank, timeout_s, 0
+        self.lookahead = max(0, int(lookahead))
+        self.KEEP_STEPS = 3 + 2 * self.lookahead
         os.makedirs(directory, exist_ok=True)
         self.stats = {"sent": 0, "received": 0, "recomputed": 0, "wait_s": 0.0}
         self._mine = []   # (step, path) of the files this rank wrote and nobody is known to have read
@@ -148,7 +153,7 @@ class Exchange:
         import glob
         for path in glob.glob(os.path.join(self.dir, "step*.job%05d.r%d.npy" % (k, owner))):
             try:
-                if int(os.path.basename(path)[4:10]) > self.step:
+                if int(os.path.basename(path)[4:10]) > self.step + self.lookahead:
                     return True
             except ValueError:
                 pass
@@ -466,15 +471,17 @@ class Shard:
         if errors:
             raise errors[0]
 
-    def piles(self, i, files=None):
-        """(records [n, 8] uint32, pile_off, seed ids, blacklisted) of seed file i: what `nextcorrect.py -i sorted.ovl` corrects."""
+    def piles(self, i, files=None, step=None):
+        """(records [n, 8] uint32, pile_off, seed ids, blacklisted) of seed file i: what `nextcorrect.py -i sorted.ovl` corrects.
+        step: the hand-over's number of this logical step (default: one more than this Shard's last) -- given by a caller that has the
+        steps of one rank made by several Shards side by side."""
         import time
         if files is None:
             from . import api
             if getattr(self, "_release_first", False):
                 api.release_device_memory()   # learned below: on this device the two stages do not fit side by side
             if self.exchange is not None:
-                self.exchange.begin_step()   # once per logical step, whatever happens below
+                self.exchange.begin_step(step)   # once per logical step, whatever happens below
             try:
                 files = self.overlaps(i, own_step=True)
             except MemoryError:

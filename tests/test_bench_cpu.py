@@ -96,7 +96,7 @@ def test_bench_steps_in_a_pipeline(monkeypatch):
     assert a["fasta_write"]["bytes_per_step"] == b["fasta_write"]["bytes_per_step"] > 0
 
 
-def _rank_main(rank, port, q):
+def _rank_main(rank, port, q, extra=()):
     """bench.main() of one rank of two, libraries = the interpreted builds, collectives over gloo."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       NDGPU_BENCH_DIST_BACKEND="gloo", NDGPU_DEVICE="0", NDGPU_CONTEXTS="1")
@@ -107,7 +107,7 @@ def _rank_main(rank, port, q):
     from nextdenovo_amd import api, overlap
     overlap._lib = overlap._bind(C.CDLL(build_simt.build_overlap()))
     api._LIB = api._bind(C.CDLL(build_simt.build()))
-    sys.argv = ["bench.py", "--gpus", "2", "--genome-size", "30000", "--depth", "14", "--steps", "2", "--warmup", "1"]   # (two steps: the second one's piles are prefetched, hand-over included, and two consensus calls are in flight)
+    sys.argv = ["bench.py", "--gpus", "2", "--genome-size", "30000", "--depth", "14", "--steps", "2", "--warmup", "1"] + list(extra)   # (two steps: the second one's piles are prefetched, hand-over included, and two consensus calls are in flight)
     import bench
     buf = io.StringIO()
     with redirect_stdout(buf):
@@ -115,8 +115,11 @@ def _rank_main(rank, port, q):
     q.put((rank, [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]))
 
 
-def test_bench_line_of_two_ranks(tmp_path):
-    """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), on
+@pytest.mark.parametrize("producers", [1, 2])
+def test_bench_line_of_two_ranks(tmp_path, producers):
+    """(producers = 2: every rank's later steps are made by two Shards side by side, each with an Exchange object of its own on the
+    node's directory and the steps numbered by bench.py -- three timed steps, so that both are at work.)
+    `bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), on
     the CPU: rank 0 prints the ONE line, whole-job value, strong scaling, per-rank stage times; the seed x seed pair of the two seed
     files is mapped by its owner only and handed over."""
     import socket
@@ -136,7 +139,8 @@ def test_bench_line_of_two_ranks(tmp_path):
             f.write(b"not the records of this job")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, port, q)) for r in range(2)]
+    extra = ("--producers", "2", "--steps", "3") if producers == 2 else ()   # (a later --steps wins)
+    procs = [ctx.Process(target=_rank_main, args=(r, port, q, extra)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=1200) for _ in procs)
@@ -148,6 +152,8 @@ def test_bench_line_of_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["seed_files"] == 2
     assert len(d["per_rank"]) == 2 and all(r["piles"] > 0 for r in d["per_rank"])
     ra = d["config"]["raw_align_jobs"]
-    assert ra["exchange"] is True and ra["per_rank_jobs_computed"] == [2, 1] and ra["rank0_exchange"]["sent"] == 3   # (warm-up + 2 steps)
+    n_steps = 3 if producers == 2 else 2
+    assert d["steps"] == n_steps and ra["rank0_piles_producers"] == producers
+    assert ra["exchange"] is True and ra["per_rank_jobs_computed"] == [2, 1] and ra["rank0_exchange"]["sent"] == 1 + n_steps   # (warm-up + the steps)
     assert ra["rank0_exchange"]["recomputed"] == 0
     assert not os.path.exists(xdir)   # (removed by rank 0 once every rank is past its last read)
