@@ -423,13 +423,13 @@ void PInflate::produce() {
     for (;;) {
         const bool more = round();
         std::unique_lock<std::mutex> lk(mu);
-        if (failed) { prod_failed = prod_over = true; cv.notify_all(); return; }
-        if (!out.empty()) {
+        if (!out.empty()) {   // (also of a round that failed: what it decoded in front of the error is the reader's, as gzread's is)
             cv.wait(lk, [&] { return stop || ready.size() < 2; });
             if (stop) return;
             ready.emplace_back(std::move(out));
             out = std::vector<uint8_t>();
         }
+        if (failed) { prod_failed = prod_over = true; cv.notify_all(); return; }
         if (!more || done) { prod_over = true; cv.notify_all(); return; }
         cv.notify_all();
         if (stop) return;
@@ -481,7 +481,14 @@ bool PInflate::round() {
     }
     stat_chunks += (uint64_t)n_chunks;
     // in order: which guessed chunks continue the one before
-    if (first.stop == kStopError) { failed = true; return false; }
+    if (first.stop == kStopError) {
+        // what was decoded in front of the bad code / the failed CRC-32 is handed out first, as zlib's gzread hands out everything it
+        // decoded before it reports the error; the NEXT call then fails
+        failed = true;
+        if (!first.n) return false;
+        out.assign(first.out.data() + kWin, first.out.data() + kWin + first.n);
+        return true;
+    }
     int accepted = 1;
     uint64_t end_bit = first.end_bit;
     bool end_inm = first.end_in_member;
@@ -555,7 +562,12 @@ bool PInflate::round() {
             if (!run_len && !len) run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
             run_len += len;
             if (segs[k].ends_member) {
-                if (run_crc != segs[k].crc || (uint32_t)run_len != segs[k].isize) { failed = true; out.clear(); return false; }
+                if (run_crc != segs[k].crc || (uint32_t)run_len != segs[k].isize) {
+                    // a member whose check values do not hold: its bytes are handed out (zlib checks at the member's end too), nothing behind it
+                    failed = true;
+                    out.resize((size_t)(off[(size_t)j] + segs[k].end));
+                    return false;
+                }
                 run_crc = 0, run_len = 0;
             }
         }

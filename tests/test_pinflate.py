@@ -98,6 +98,12 @@ def test_same_bytes_as_gzread(lib, tmp_path, monkeypatch, chunk):
             assert threaded and gerr == werr, (name, th)
             if not werr:
                 assert got == want, (name, th, len(got), len(want))
+            else:
+                # in front of the error gzread hands out what it decoded; so does the threaded reader (one of the two may see the error a
+                # block earlier than the other: what both hand out is the same stream)
+                k = min(len(got), len(want))
+                assert got[:k] == want[:k], (name, th)
+                assert len(got) * 2 >= len(want), (name, th, len(got), len(want))
             speculative += st[2] - st[0]                        # accepted chunks beyond every round's first
     if chunk < (2 << 20):
         assert speculative > 20                                  # (the guessed chunks do carry the decoding)
