@@ -100,6 +100,9 @@ struct QueryDev {
 	const uint32_t *want;
 	// -f FLOAT,INT (re-chaining, minimap2/map.c:553-575): the occurrence threshold of every query read; nullptr: the launch's one
 	const int32_t *read_mid;
+	// ... and, in the pass that tells which reads are seeded again: rep[i] != 0 once a minimizer of query read i was dropped for its
+	// occurrences (the reference's `rep_len > 0`, collect_matches, map.c:101-113); nullptr: nobody asks
+	uint32_t *rep;
 };
 
 // sort key of an anchor: | read (batch local) | strand | target read | target position |

@@ -588,12 +588,15 @@ struct Engine {
 	// belong to map_rechain() below.
 	const int32_t *read_mid = nullptr;
 	std::vector<uint32_t> *chains_per_read = nullptr;
+	std::vector<uint32_t> *rep_per_read = nullptr;   // (with chains_per_read) != 0: a minimizer of the read was dropped for its occurrences
 	int64_t map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
 	                 const uint32_t *lens, const uint32_t *ids, std::vector<OvlRec> &out, std::vector<OvlRec10> *out10 = nullptr,
 	                 const Regs *regs = nullptr);
 	// -f FLOAT,INT (mm_mapopt_t::max_occ > mid_occ; minimap2/map.c:553-575 and :678-700): a query read that ends its chaining without a
 	// chain is seeded again with every minimizer below max_occ occurrences and chained again (with one segment per query that is the
-	// whole test; `rep_len > 0` only spares reads whose second pass would collect the same seeds).  Two passes over the query set: the
+	// test together with `rep_len > 0`: a read none of whose minimizers was dropped would collect the same seeds again -- and in the
+	// one-read-index mappings of --step 2 --mode 1, whose second chaining skips the anchor thinning, must not be chained again at all:
+	// ADVICE round 5).  Two passes over the query set: the
 	// first tells which reads found no chain, the second maps every read with ITS threshold -- the reads of a batch are independent,
 	// so the second pass's records are the reference's, in its order, whatever the mode of the call (records, hits, chains).
 	int64_t map(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, const uint32_t *words, uint64_t n_words, const uint64_t *woff,
@@ -601,17 +604,20 @@ struct Engine {
 	            const Regs *regs = nullptr)
 	{
 		if (o.max_occ <= mid) return map_once(o, mid, n_q, words, n_words, woff, lens, ids, out, out10, regs);
-		std::vector<uint32_t> chains;
-		struct Unset { Engine *e; ~Unset() { e->read_mid = nullptr, e->chains_per_read = nullptr; } } unset{this};
+		std::vector<uint32_t> chains, rep;
+		struct Unset { Engine *e; ~Unset() { e->read_mid = nullptr, e->chains_per_read = nullptr, e->rep_per_read = nullptr; } } unset{this};
 		chains_per_read = &chains;
+		rep_per_read = &rep;
 		int64_t n = map_once(o, mid, n_q, words, n_words, woff, lens, ids, out, out10, regs);
 		chains_per_read = nullptr;
+		rep_per_read = nullptr;
 		if (n < 0) return n;
 		chains.resize(n_q, 0u);
+		rep.resize(n_q, 0u);
 		std::vector<int32_t> thr(n_q, mid);
 		uint64_t again = 0;
 		for (uint32_t i = 0; i < n_q; ++i)
-			if (!chains[i]) thr[i] = o.max_occ, ++again;
+			if (!chains[i] && rep[i]) thr[i] = o.max_occ, ++again;   // map.c:553 / :678: no chain AND rep_len > 0
 		if (!again) return n;
 		st.rechained += again;
 		read_mid = thr.data();
@@ -698,7 +704,12 @@ int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, cons
 		d_read_mid.alloc(n_q);
 		d_read_mid.upload(read_mid, n_q, stream);
 	}
-	const QueryDev qd{Q.len.p, Q.id.p, qhash.p, Q.namekey.p, S.off.p, d_want_off.p, regs && regs->want_off ? d_want.p : nullptr, d_read_mid.p};
+	DevBuf<uint32_t> d_rep;
+	if (rep_per_read) {
+		d_rep.alloc(n_q);
+		d_rep.zero(stream);
+	}
+	const QueryDev qd{Q.len.p, Q.id.p, qhash.p, Q.namekey.p, S.off.p, d_want_off.p, regs && regs->want_off ? d_want.p : nullptr, d_read_mid.p, d_rep.p};
 
 	// K3a over every query minimizer
 	EvTimer tm(stream);
@@ -1068,6 +1079,11 @@ int64_t Engine::map_once(const ndgpu_ovl_opt &o, int32_t mid, uint32_t n_q, cons
 		st.seed_ms += b.seed_ms, st.sort_ms += b.sort_ms, st.exact_sort_ms += b.exact_sort_ms, st.chain_ms += b.chain_ms, st.hits_ms += b.hits_ms;
 		st.ext_ms += b.ext_ms, st.tie_reads += b.tie_reads, st.chain_cells += b.chain_cells, st.chains += b.chains, st.overlaps += b.overlaps;
 		st.batches += b.batches, st.ext_problems += b.ext_problems, st.ext_launches += b.ext_launches;
+	}
+	if (rep_per_read) {   // (K3a ran over every query minimizer before the first batch: the flags are whole)
+		rep_per_read->assign(n_q, 0u);
+		d_rep.download(rep_per_read->data(), n_q, stream);
+		HIP_OK(hipStreamSynchronize(stream));
 	}
 	return out10 ? (int64_t)out10->size() : (int64_t)out.size();
 }

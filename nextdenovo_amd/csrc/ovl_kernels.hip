@@ -679,11 +679,17 @@ __global__ void seed_count_kernel(const uint64_t *__restrict__ mx, const uint64_
 				occ_run(ix.pos, start, cnt, q.want[i], lo, hi);
 				n_in += hi - lo;
 			}
-		if ((int64_t)n_in >= (int64_t)mid_occ) n_in = 0;
+		if ((int64_t)n_in >= (int64_t)mid_occ) {
+			n_in = 0;
+			if (q.rep) q.rep[rd] = 1u;
+		}
 		m_start[m] = start, m_cnt[m] = n_in ? cnt : 0, m_surv[m] = n_in;
 		return;
 	}
-	if ((int64_t)cnt >= (int64_t)mid_occ) cnt = 0; // repetitive minimizer: contributes nothing
+	if ((int64_t)cnt >= (int64_t)mid_occ) { // repetitive minimizer: contributes nothing
+		cnt = 0;
+		if (q.rep) q.rep[m_read[m]] = 1u;
+	}
 	if (cnt) {
 		const uint32_t rd = m_read[m], q_pos = (uint32_t)my[m];
 		const uint64_t qk = q.namekey[rd];
