@@ -136,6 +136,26 @@ def committed_kernel_stats():
     return rows, os.path.relpath(files[-1], ROOT)
 
 
+def committed_sq_ranking(top=6):
+    """Whose the device is by the SQ counters: the first rows of the newest profiles/rNN_sq_wave_cycles_per_kernel.txt (one --pmc pass over
+    SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY ..., tools/rocprof_sq_summary.py: every kernel alone on the device)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_sq_wave_cycles_per_kernel.txt")))
+    if not files:
+        return None
+    rows = []
+    for ln in open(files[-1]):
+        mt = re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s+(\d+)\s*$", ln)
+        if mt:
+            rows.append({"kernel": mt.group(1).strip(), "launches": int(mt.group(2)), "wave_Mcycles": float(mt.group(3)),
+                         "parked_pct": float(mt.group(4)), "stalled_at_issue_pct": float(mt.group(5)), "issuing_pct": float(mt.group(6))})
+    rows.sort(key=lambda r_: -r_["wave_Mcycles"])
+    return {"source": os.path.relpath(files[-1], ROOT), "by_wave_cycles": rows[:top],
+            "note": "wave cycles of a kernel's wavefronts summed over its launches (quad-cycle counters), and where they go: parked on a wait "
+                    "counter, stalled at instruction issue, issuing; the kernel the HBM roofline entry names is the one that leads this list too"}
+
+
 _KERNEL_SOURCES = {   # the files a kernel's code lives in (its counter measurement is tied to them)
     "ond_forward_kernel": ("ond_kernels.hip", "nd_device.h"), "ond_traceback_kernel": ("ond_kernels.hip", "nd_device.h"),
     "tb_walk_kernel": ("ond_kernels.hip", "nd_device.h"),
@@ -795,6 +815,7 @@ def main():
                                     "cns.fasta write are skipped" if args.lengths_only else
                                     "every step takes the corrected sequences from the library and writes cns.fasta + cns.fasta.idx "
                                     "(lib/nextcorrect.py:236-260) inside the timed region"),
+                "device_load_by_sq_counters": committed_sq_ranking(),
                 "other_kernels": others}),
             "counters": {k: st[k] for k in ("tasks", "wide_tasks", "cells", "d_steps", "trace_words", "lq_rounds", "lq_declined", "max_band", "piles", "tags",
                                             "cells_msa", "links", "path_items", "score_segments", "score_repairs", "score_slow_piles",
