@@ -894,7 +894,7 @@ void DeviceAligner::run_chunk(AlnJob **jobs, size_t n) {
     S.d_pool.reserve(pool.size());
     S.d_tasks.reserve(n);
     S.d_outs.reserve(n);
-    S.d_trace.reserve(trace_words + 2);
+    S.d_trace.reserve(trace_words + kTracePadWords);
     S.d_ops.reserve(ops_words + 2);
     S.h_ops.reserve(ops_words + 2);
     S.h_outs.reserve(n);
@@ -1268,7 +1268,7 @@ void DeviceAligner::run_lq(LqRound **rounds, size_t n) {
         chunk_end.push_back(nt);
         max_tw = std::max(max_tw, tw);
     }
-    S.d_trace.reserve(max_tw + 2);
+    S.d_trace.reserve(max_tw + kTracePadWords);
     // the traceback in segments where a launch holds long pairs (regions of several kb): slots per launch
     struct ChunkTb { bool seg; uint64_t slots; };
     std::vector<ChunkTb> chunk_tb;
@@ -1558,7 +1558,7 @@ void DeviceAligner::run_main(MainPile **mp, size_t np) {
     S.d_tasks.reserve(nt + 1);
     S.d_outs.reserve(nt + 1);
     S.h_outs.reserve(nt + 1);
-    S.d_trace.reserve(max_tw + 2);
+    S.d_trace.reserve(max_tw + kTracePadWords);
     S.d_ops.reserve(ops_words + 2);
     S.d_reads.reserve(nr);
     S.d_piles.reserve(np);

@@ -283,8 +283,10 @@ constexpr uint64_t kOffDb = 1ull << 63;   // offset flag: sequence lives in the 
 constexpr uint64_t kOffMask = kOffDb - 1;
 
 // Words of zeros behind the last sequence of every 2-bit pool (per-batch pools, the resident read DB): the forward kernel fetches 64
-// bases -- five words -- at a time, starting anywhere up to the last base (csrc/ond_kernels.hip: fetch64_rel)
-constexpr uint32_t kPoolPadWords = 8;
+// bases -- five words -- at a time, starting anywhere up to the last base (csrc/ond_kernels.hip: fetch64_rel), and a walker of the
+// traceback fills its window with the 16 words from a sequence's first on, however short the sequence (fetch64_win)
+constexpr uint32_t kPoolPadWords = 24;
+constexpr uint32_t kTracePadWords = 16;  // words behind the last task's trace: a walker's window holds 16 record words from the task's first on
 constexpr int kFastRowWords = 2;       // register path: at most two 64-bit trace words per edit step (one up to 56 cells)
 constexpr int kFastMaxBand = 238;      // register path: at most 120 same-parity diagonals per edit step (two per lane, 7-bit offsets)
 

@@ -639,17 +639,84 @@ struct TbCursor {
     uint64_t hdr, c1, c2;
 };
 
+// A walker's windows in LDS.  Every lane of a walker wavefront reads a trace and two sequences of its own, back to front, a few
+// bytes per row: as loads from memory that is six instructions per row with 64 different cache lines each -- the address path
+// serves one line per cycle, and the lines a compute unit's 32 resident wavefronts hold open (6000) outgrow its caches, so most
+// of them come from HBM again and again (profiles/pmc_traffic.json: 30 x the algorithmic bytes).  Here a lane copies the next
+// kWinSeqWords words of each sequence and kWinTraceWords trace records behind its cursor into a column of LDS ([word][lane]: the
+// lanes of a read fall on different banks) with full-line loads, once per 20-odd rows, and reads its rows from there.
+// (Sizes from a sweep on the device, profiles/r06_tb_walk_windows.txt: 10 KB of LDS per wavefront; larger windows are refilled less often
+// but leave room for fewer wavefronts, and the wavefronts are what hides a refill.)
+constexpr int kWinSeqWords = 12;    // 192 bases of a sequence: the five words of a fetch and seven more behind them
+constexpr int kWinTraceWords = 8;   // 8 record words
+static_assert(kWinSeqWords % 4 == 0 && kWinSeqWords >= 8 && kWinTraceWords % 2 == 0, "filled four / two words at a time");
+static_assert(kPoolPadWords >= (uint32_t)kWinSeqWords && kTracePadWords >= (uint32_t)kWinTraceWords, "a window is filled from word 0 on");
+struct TbWin {
+    uint32_t *q, *t;        // the lane's column of each window
+    uint64_t *s;
+    uint32_t qb, tb, sb;    // the first word each holds (of the sequence / of the task's trace); ~0: nothing yet
+};
+
+// 64 bases from base `pos` of the sequence that starts at `seq` (pos counts from seq's first word), through the lane's window
+__device__ __forceinline__ Bases64 fetch64_win(const uint32_t *__restrict__ seq, uint32_t pos, uint32_t *__restrict__ win, uint32_t &base) {
+    const uint32_t ws = pos >> 4;
+    // (when one lane of the wavefront is out of its window every lane at this fetch moves its window: the lanes use theirs up at
+    // different rates, and a row in which any of them waits for memory costs the wavefront that wait -- together they wait once
+    // in a dozen rows instead of in nearly every one)
+    if (__ballot(ws < base || ws + 4u >= base + (uint32_t)kWinSeqWords)) {   // the five words ws .. ws + 4 end the new window
+        base = ws + 5u > (uint32_t)kWinSeqWords ? ws + 5u - (uint32_t)kWinSeqWords : 0u;
+        const uint32_t *__restrict__ src = seq + base;
+#pragma unroll
+        for (int i = 0; i < kWinSeqWords; i += 4) {
+            struct W4 { uint32_t x, y, z, w; } v;
+            v.x = src[i], v.y = src[i + 1], v.z = src[i + 2], v.w = src[i + 3];
+            win[(i + 0) * 64] = v.x, win[(i + 1) * 64] = v.y, win[(i + 2) * 64] = v.z, win[(i + 3) * 64] = v.w;
+        }
+    }
+    const uint32_t *__restrict__ p = win + (ws - base) * 64u;
+    const uint32_t v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192], v4 = p[256];
+    const uint32_t s = (pos & 15u) * 2u;
+    Bases64 r;
+    r.w[0] = __builtin_amdgcn_alignbit(v1, v0, s);
+    r.w[1] = __builtin_amdgcn_alignbit(v2, v1, s);
+    r.w[2] = __builtin_amdgcn_alignbit(v3, v2, s);
+    r.w[3] = __builtin_amdgcn_alignbit(v4, v3, s);
+    return r;
+}
+
+// record word p of the task's trace through the lane's window
+__device__ __forceinline__ uint64_t trace_win(const uint64_t *__restrict__ S, uint32_t p, uint64_t *__restrict__ win, uint32_t &base) {
+    if (__ballot(p < base || p >= base + (uint32_t)kWinTraceWords)) {   // word p ends the new window
+        base = p + 1u > (uint32_t)kWinTraceWords ? p + 1u - (uint32_t)kWinTraceWords : 0u;
+        const uint64_t *__restrict__ src = S + base;
+#pragma unroll
+        for (int i = 0; i < kWinTraceWords; i += 2) {
+            const uint64_t a = src[i], b = src[i + 1];
+            win[(i + 0) * 64] = a, win[(i + 1) * 64] = b;
+        }
+    }
+    return win[(p - base) * 64u];
+}
+
 // the match run behind (x, x - k), back to front (lib/align.c:502-507), 64 bases per compare; returns its length, x moves
+// (WIN: q_off / t_off are the sequences' first bases within the words qp / tp point at, and the bases come through `win`)
+template <bool WIN>
 __device__ __forceinline__ int tb_match_run(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp, uint64_t q_off, uint64_t t_off,
-                                            int &x, int k) {
+                                            int &x, int k, TbWin &win) {
     int total = 0;
     for (;;) {
         const int yy = x - k;
         const int avail = (x < yy ? x : yy) + 1;
         if (avail <= 0) break;
         const int n = avail < 64 ? avail : 64;
-        const Bases64 a = fetch64_abs(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
-        const Bases64 b = fetch64_abs(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
+        Bases64 a, b;
+        if (WIN) {
+            a = fetch64_win(qp, (uint32_t)q_off + (uint32_t)(x - n + 1), win.q, win.qb);
+            b = fetch64_win(tp, (uint32_t)t_off + (uint32_t)(yy - n + 1), win.t, win.tb);
+        } else {
+            a = fetch64_abs(qp, q_off + (uint64_t)(uint32_t)(x - n + 1));
+            b = fetch64_abs(tp, t_off + (uint64_t)(uint32_t)(yy - n + 1));
+        }
         int m = n;
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
@@ -669,6 +736,7 @@ __device__ __forceinline__ int tb_match_run(const uint32_t *__restrict__ qp, con
     return total;
 }
 
+template <bool WIN>
 __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ segs, TbSegOut *__restrict__ seg_outs,
                                                       const AlnTask *__restrict__ tasks, const AlnOut *__restrict__ outs,
                                                       const uint32_t *__restrict__ pool, const uint32_t *__restrict__ db_pool,
@@ -680,15 +748,26 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
     const AlnTask T = tasks[G.task];
     const uint32_t *__restrict__ qp = (T.q_off >> 63) ? db_pool : pool;
     const uint32_t *__restrict__ tp = (T.t_off >> 63) ? db_pool : pool;
-    const uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
+    uint64_t q_off = T.q_off & kOffMask, t_off = T.t_off & kOffMask;
     const uint64_t *__restrict__ S = trace + T.trace_off;
     uint32_t *__restrict__ W = ops + T.ops_off;
 
+    __shared__ uint32_t l_q[WIN ? kWinSeqWords * 64 : 1], l_t[WIN ? kWinSeqWords * 64 : 1];
+    __shared__ uint64_t l_s[WIN ? kWinTraceWords * 64 : 1];
+    TbWin win;
+    win.q = l_q + (WIN ? threadIdx.x : 0), win.t = l_t + (WIN ? threadIdx.x : 0), win.s = l_s + (WIN ? threadIdx.x : 0);
+    win.qb = win.tb = win.sb = 0xffffffffu;
+    if (WIN) {   // the windows count words from the sequence's first
+        qp += q_off >> 4, tp += t_off >> 4;
+        q_off &= 15u, t_off &= 15u;
+    }
+    auto rec = [&](uint32_t p) -> uint64_t { return WIN ? trace_win(S, p, win.s, win.sb) : S[p]; };
+
     int x = G.x, k = G.min_k + 2 * G.idx, d = G.d_top, idx = G.idx;
     uint32_t pos = G.pos;
-    uint64_t hdr = pos ? S[pos - 1] : 0ull;
-    uint64_t c1 = pos >= 2 ? S[pos - 2] : 0ull;   // the word before the header, loaded a row ahead: the header of the row below, or -- for the
-                                                  // few rows of more than 56 cells -- this record's second word
+    uint64_t hdr = pos ? rec(pos - 1) : 0ull;
+    uint64_t c1 = pos >= 2 ? rec(pos - 2) : 0ull;   // the word before the header, loaded a row ahead: the header of the row below, or -- for
+                                                    // the few rows of more than 56 cells -- this record's second word
     TbSegOut R;
     R.x_own = R.k_own = R.x_end = R.k_end = 0;
     R.lead = R.trail = 0;
@@ -709,14 +788,14 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
         if (left) { k--; x--; } else k++;
         const uint32_t len = 1u + (uint32_t)((hdr >> kStreamBits) & 1ull);
         pos = pos > len ? pos - len : 0u;
-        hdr = pos ? (len == 1u ? c1 : S[pos - 1]) : 0ull;   // (behind a two-word record the header is not in hand: one load the row waits for)
+        hdr = pos ? (len == 1u ? c1 : rec(pos - 1)) : 0ull;   // (behind a two-word record the header is not in hand: one load the row waits for)
         idx += (int)(hdr >> (kStreamBits + 1)) - (left ? 1 : 0);
-        c1 = pos >= 2 ? S[pos - 2] : 0ull;
+        c1 = pos >= 2 ? rec(pos - 2) : 0ull;
     };
 
     // the rows above the owned ones: the walk only (no columns, no gap count)
     while (d > G.d_own) {
-        (void)tb_match_run(qp, tp, q_off, t_off, x, k);
+        (void)tb_match_run<WIN>(qp, tp, q_off, t_off, x, k, win);
         if (x < 0 && x - k < 0) {
             R.flags = kTbBad;
             break;
@@ -746,7 +825,7 @@ __global__ __launch_bounds__(64) void tb_walk_kernel(const TbSeg *__restrict__ s
     int gap = 0;
     bool reset = false;
     for (;;) {
-        const int m = tb_match_run(qp, tp, q_off, t_off, x, k);
+        const int m = tb_match_run<WIN>(qp, tp, q_off, t_off, x, k, win);
         if (m) {
             col -= (uint32_t)m;
             gap = 0;
@@ -857,8 +936,14 @@ void launch_ond_traceback_seg(const AlnTask *tasks, AlnOut *outs, const uint32_t
     // (NDGPU_TB_LDS_KB: dynamic LDS a walker wavefront asks for and never touches -- an occupancy knob: every lane walks a trace and two
     // sequences of its own, so the lines a compute unit's resident walkers hold open outgrow the caches with their number)
     static const size_t walk_lds = getenv("NDGPU_TB_LDS_KB") ? (size_t)atoi(getenv("NDGPU_TB_LDS_KB")) << 10 : 0;
-    hipLaunchKernelGGL(tb_walk_kernel, per_slot, dim3(64), walk_lds, (hipStream_t)stream, tb.segs, tb.seg_outs, tasks, outs, pool, db_pool, trace, ops,
-                       tb.n_slots);
+    // (NDGPU_TB_WIN=0: the walkers read memory directly, for A/B runs)
+    static const bool walk_win = !getenv("NDGPU_TB_WIN") || atoi(getenv("NDGPU_TB_WIN")) != 0;
+    if (walk_win)
+        hipLaunchKernelGGL(tb_walk_kernel<true>, per_slot, dim3(64), walk_lds, (hipStream_t)stream, tb.segs, tb.seg_outs, tasks, outs, pool, db_pool,
+                           trace, ops, tb.n_slots);
+    else
+        hipLaunchKernelGGL(tb_walk_kernel<false>, per_slot, dim3(64), walk_lds, (hipStream_t)stream, tb.segs, tb.seg_outs, tasks, outs, pool, db_pool,
+                           trace, ops, tb.n_slots);
     hipLaunchKernelGGL(tb_stitch_kernel, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, tb.seg_outs, n_tasks, tb.cshift);
     // what the stitch refused (still ST_FINISHED) in one piece
     hipLaunchKernelGGL(ond_traceback_kernel<true>, per_task, dim3(64), 0, (hipStream_t)stream, tasks, outs, pool, db_pool, trace,

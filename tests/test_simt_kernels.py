@@ -214,6 +214,7 @@ def test_lq_rounds_cut_into_speculative_jobs(simt_lib, env, repairs):
     ({"NDGPU_K8_SEG": "64", "NDGPU_K8_WARM": "64", "NDGPU_K8_MINLEN": "0", "SIMT_LANES_DESCENDING": "1"}, None),
     ({"NDGPU_K8_MINLEN": "0"}, False),                                                  # the product's segment length and warm-up on every launch
     ({"NDGPU_K8_SEG": "0"}, "off"),                                                     # the one-lane kernel everywhere
+    ({"NDGPU_K8_SEG": "16", "NDGPU_K8_WARM": "8", "NDGPU_K8_MINLEN": "0", "NDGPU_TB_WIN": "0"}, None),   # walkers that read memory directly
 ])
 def test_traceback_in_segments(simt_lib, env, fallbacks):
     """K8a cut into walkers (checkpoints of the forward kernel, chase, one lane per 2^k edit steps from a speculative x, stitch, the
