@@ -94,7 +94,7 @@ def test_scoring_paths_agree(default_run, env, check):
     ({"NDGPU_K8_SEG": "64", "NDGPU_K8_WARM": "2"}, lambda s: s["tb_fallbacks"] > 100),                  # warm-up too short: the stitch refuses, the one-lane walk takes over
     ({"NDGPU_K8_SEG": "1024", "NDGPU_K8_WARM": "64"}, lambda s: s["tb_fallbacks"] * 1000 <= s["tb_tasks"]),
     ({"NDGPU_TB_WIN": "0"}, lambda s: s["tb_fallbacks"] * 1000 <= s["tb_tasks"]),                      # walkers without their LDS windows
-], ids=["one-lane", "every-launch", "short-warmup", "long-segments"])
+], ids=["one-lane", "every-launch", "short-warmup", "long-segments", "no-windows"])
 def test_traceback_forms_agree(default_run, env, check):
     """K8a in segments (the default: 256 rows a walker, 32 rows of warm-up) against the one-lane walk and against other cuts, on every
     config-2 pile; the default run itself is held against the compiled reference above."""
