@@ -159,10 +159,27 @@ __global__ __launch_bounds__(64) void make_tags_kernel(const PileDev *__restrict
     uint32_t *imax = ins_max + P.col_off;
     int32_t carry_t = (int32_t)R.t_s - 1;
     uint32_t carry_delta = 0, carry_q = R.q_start;
+    // The column words and the query's bases come 64 words at a time -- one word per lane, 1,024 columns or bases, handed to the
+    // lane that needs them by a shuffle.  Loaded per 64 columns they put two loads into every round of the loop, and a load's
+    // s_waitcnt also waits for every store and atomic issued before it (one counter, in order): each round then waited for the
+    // atomics of the round before it to come back from memory.
+    const uint32_t w_last = (R.shift + R.aln_len - 1u) >> 4;
+    const uint64_t q_last = (qo + (uint64_t)(uint32_t)T.q_len - 1u) >> 4;
+    uint32_t w_base = 0, opw = 0, qw = 0;
+    uint64_t q_base = 0;
+    bool have_w = false, have_q = false;
     for (uint32_t c0 = 0; c0 < R.aln_len; c0 += 64) {
         const uint32_t c = c0 + (uint32_t)lane;
         const bool valid = c < R.aln_len;
-        const uint32_t op = valid ? op_at(W, R.shift + c) : 0u;
+        if (!have_w || ((R.shift + c0 + 63u) >> 4) > w_base + 63u) {
+            w_base = (R.shift + c0) >> 4;
+            opw = w_base + (uint32_t)lane <= w_last ? W[w_base + (uint32_t)lane] : 0u;
+            ND_LOADED(opw);
+            have_w = true;
+        }
+        const uint32_t col = R.shift + c;
+        const uint32_t word = (uint32_t)__shfl((int)opw, (int)((col >> 4) - w_base), 64);
+        const uint32_t op = valid ? (word >> ((col & 15u) * 2u)) & 3u : 0u;
         const bool is_t = valid && op != 1u, is_q = valid && op != 2u;
         const unsigned long long mt = __ballot(is_t), mq = __ballot(is_q);
         const unsigned long long le = lanes_le(lane);
@@ -170,12 +187,22 @@ __global__ __launch_bounds__(64) void make_tags_kernel(const PileDev *__restrict
         const unsigned long long mm = mt & le;
         const uint32_t delta = mm ? (uint32_t)(lane - (63 - __clzll((long long)mm))) : carry_delta + (uint32_t)lane + 1u;
         const uint32_t qidx = carry_q + (uint32_t)__popcll(mq & (le >> 1));
+        if (!have_q || ((qo + carry_q + 63u) >> 4) > q_base + 63u) {
+            q_base = (qo + carry_q) >> 4;
+            qw = q_base + (uint64_t)lane <= q_last ? qp[q_base + (uint64_t)lane] : 0u;
+            ND_LOADED(qw);
+            have_q = true;
+        }
+        const uint64_t q_at = qo + qidx;
+        const uint32_t qword = (uint32_t)__shfl((int)qw, (int)((q_at >> 4) - q_base), 64);
         if (valid) {
-            const uint32_t base = is_q ? cns_code(code_at(qp, qo + qidx)) : 4u;
+            const uint32_t base = is_q ? cns_code((qword >> ((uint32_t)(q_at & 15u) * 2u)) & 3u) : 4u;
             tg[c] = tag_pack(t_pos, delta, base);
             if (delta == 0) ci[(uint32_t)t_pos - R.t_s] = c;
-            else {
-                atomicAdd(&icnt[t_pos], 1u);
+            else if (lane == 63 || c + 1u == R.aln_len || ((mt >> (lane + 1)) & 1ull)) {
+                // An insertion run is counted once, by its last column (of these 64): device-scope atomics are served behind the
+                // L2s, one memory transaction each.  (Looking at the maximum first to skip its atomic would be a load again.)
+                atomicAdd(&icnt[t_pos], mm ? delta : (uint32_t)lane + 1u);
                 atomicMax(&imax[t_pos], delta + 1u);
             }
         }

@@ -9,3 +9,12 @@
 #else
 #define ND_LOCKSTEP() ((void)0)
 #endif
+
+// ND_LOADED(x): the value of x is in its register from here on.  The compiler waits for a load at the first use of its result; when
+// the load sits in a branch of a loop and the use behind the branch, that wait (s_waitcnt vmcnt(0): every store and atomic issued
+// before it, too) is paid by every round of the loop.  The mark is a use inside the branch.
+#ifdef SIMT_EMULATION
+#define ND_LOADED(x) ((void)(x))
+#else
+#define ND_LOADED(x) asm volatile("" : "+v"(x))
+#endif
