@@ -23,6 +23,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "nd_device.h"
 
@@ -230,10 +231,31 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
     uint32_t *eb = ent_base + P.col_off;
     uint32_t run_cov = 0, run_cells = 0, run_ents = 0;
     uint32_t big = 0;  // a column of this lane needs the large scoring tables
-    for (uint32_t t0 = 0; t0 < L; t0 += 64) {
+    // The three inputs of the next 64 columns are asked for before this round's stores and waited for behind them (ND_LOADED at the
+    // end of the round: s_waitcnt vmcnt(4), the four stores stay in flight).  A load's wait covers everything issued before it, so
+    // with the loads at the top every round waited for its predecessor's stores to be acknowledged.  The rounds of 64 whole columns
+    // store without a condition (the compiler can count them); the seed's last columns are a round of their own.
+    // (Columns past the seed's end read its last column instead -- a load under a condition meets its default at a join, and the
+    // join waits; what such a lane computes is never stored, and no lane above it in a prefix sum is.)
+    const uint32_t t_last = L ? L - 1u : 0u;
+    uint32_t n_cov, n_ms, n_ic;
+    {
+        const uint32_t tn = (uint32_t)lane < t_last ? (uint32_t)lane : t_last;
+        n_cov = cov[tn], n_ms = ms[tn], n_ic = icnt[tn];
+        ND_LOADED(n_cov);
+        ND_LOADED(n_ms);
+        ND_LOADED(n_ic);
+    }
+    auto round = [&](uint32_t t0, auto whole) {
+        constexpr bool kWhole = decltype(whole)::value;
         const uint32_t t = t0 + (uint32_t)lane;
-        const bool v = t < L;
-        uint32_t c = v ? cov[t] : 0u;
+        const bool v = kWhole || t < L;
+        uint32_t c = n_cov;
+        const uint32_t ms_in = n_ms, ic_in = n_ic;
+        if (kWhole) {
+            const uint32_t tn = t + 64u < t_last ? t + 64u : t_last;
+            n_cov = cov[tn], n_ms = ms[tn], n_ic = icnt[tn];
+        }
         // inclusive wave prefix sums
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t u = (uint32_t)__shfl_up((int)c, o, 64);
@@ -242,8 +264,8 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
         c += run_cov;
         uint32_t m = 0, e = 0;
         if (v) {
-            m = c ? (ms[t] > 1u ? ms[t] : 1u) : 0u;
-            e = c + icnt[t];
+            m = c ? (ms_in > 1u ? ms_in : 1u) : 0u;
+            e = c + ic_in;
         }
         if (m * 6u > (uint32_t)kColCellsSmall || e > (uint32_t)kColEntsSmall) big = 1;
         uint32_t pc = m * 6u, pe = e;
@@ -264,7 +286,15 @@ __global__ __launch_bounds__(64) void col_scan_kernel(PileDev *__restrict__ pile
         run_cov = (uint32_t)__shfl((int)c, 63, 64);
         run_cells += (uint32_t)__shfl((int)pc, 63, 64);
         run_ents += (uint32_t)__shfl((int)pe, 63, 64);
-    }
+        if (kWhole) {
+            ND_LOADED(n_cov);
+            ND_LOADED(n_ms);
+            ND_LOADED(n_ic);
+        }
+    };
+    uint32_t t0 = 0;
+    for (; t0 + 64u <= L; t0 += 64) round(t0, std::true_type{});
+    if (t0 < L) round(t0, std::false_type{});
     const bool any_big = __ballot(big != 0) != 0ull;
     if (lane == 0) {
         cb[L] = run_cells;

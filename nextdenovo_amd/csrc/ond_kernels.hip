@@ -154,7 +154,25 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
     const uint32_t *__restrict__ tp = ((T.t_off >> 63) ? db_pool : pool) + (t_off >> 4);
     const uint32_t q_sh = (uint32_t)(q_off & 15u), t_sh = (uint32_t)(t_off & 15u);
     uint64_t *__restrict__ S = trace + T.trace_off;
-    uint32_t pos = 0;
+    // The record words wait in a register of the lanes -- lane l holds the l-th word not yet written -- and go out 63 or 64 at a
+    // time, one 512-byte store.  Written step by step (8 bytes from lane 0) the store sat in front of the next step's loads, and a
+    // load's s_waitcnt waits for every memory operation issued before it: each step waited for its predecessor's store as well.
+    uint64_t rec = 0;
+    uint32_t pos_base = 0, fill = 0;   // words written, words waiting (the same in every lane); the stream's length is their sum
+    auto flush = [&]() {
+        if ((uint32_t)lane < fill) S[pos_base + (uint32_t)lane] = rec;
+        pos_base += fill;
+        fill = 0;
+    };
+    auto put = [&](bool wide, uint64_t hi, uint64_t lo) {
+        if (wide) {
+            if ((uint32_t)lane == fill) rec = hi;
+            fill++;
+        }
+        if ((uint32_t)lane == fill) rec = lo;
+        fill++;
+        if (fill >= 63u) flush();   // (room for a two-word record is kept)
+    };
     if (CKPT) {
         uint32_t *__restrict__ W = ops + T.ops_off;
         const uint32_t nw = (T.ops_cap + 15u) / 16u + 1u;
@@ -242,11 +260,7 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
             if (CKPT) fin_org = fb0 ? __shfl(org0, fl, 64) : __shfl(org1, fl, 64);
             fin_d = d;
             status = ST_FINISHED;
-            if (lane == 0) {
-                if (wide_rec) S[pos] = bits_hi;
-                S[pos + (wide_rec ? 1u : 0u)] = ((uint64_t)wide_rec << kStreamBits) | bits_lo;
-            }
-            pos += wide_rec ? 2u : 1u;
+            put(wide_rec, bits_hi, ((uint64_t)wide_rec << kStreamBits) | bits_lo);
             break;
         }
 
@@ -268,17 +282,13 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         if (qhi1) jmax = 64 + 63 - __clzll((long long)qhi1);
         else if (qhi0) jmax = 63 - __clzll((long long)qhi0);
 
-        if (lane == 0) {
-            if (wide_rec) S[pos] = bits_hi;
-            S[pos + (wide_rec ? 1u : 0u)] = ((uint64_t)j << (kStreamBits + 1)) | ((uint64_t)wide_rec << kStreamBits) | bits_lo;
-        }
-        pos += wide_rec ? 2u : 1u;
+        put(wide_rec, bits_hi, ((uint64_t)j << (kStreamBits + 1)) | ((uint64_t)wide_rec << kStreamBits) | bits_lo);
 
         if (CKPT && d && (d & cmask) == 0) {  // a checkpoint row: what a walker that starts at the top of this row needs
             const uint64_t slot = T.mink_off + (uint64_t)((d >> cshift) - 1);
             if (act0) ck_cells[slot * kCkptCells + (uint32_t)lane] = (uint32_t)x0 | ((uint32_t)org0 << 24);
             if (act1) ck_cells[slot * kCkptCells + 64u + (uint32_t)lane] = (uint32_t)x1 | ((uint32_t)org1 << 24);
-            if (lane == 0) ck_hdr[slot] = make_uint2(pos, (uint32_t)min_k);
+            if (lane == 0) ck_hdr[slot] = make_uint2(pos_base + fill, (uint32_t)min_k);
             org0 = lane;
             org1 = 64 + lane;
         }
@@ -293,6 +303,8 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
         pwide = two;
     }
 
+    const uint32_t pos = pos_base + fill;
+    flush();
     if (lane == 0) {
         AlnOut o;
         o.status = status;
