@@ -45,8 +45,10 @@ sys.path.insert(0, ROOT)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 8 after 2 warm-up steps for config 2 -- the line of two calls in flight needs a few steps to "
+                         "show its rate; 2 after 1 for the genome-scale configs, whose steps take seconds)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[N-1]")
     ap.add_argument("--seed-files", type=int, default=0, help="seed_cutfiles (default: the number of GPUs)")
     ap.add_argument("--shard", type=int, default=0, help="with one GPU and --seed-files M: which seed file to correct")
@@ -74,7 +76,13 @@ def parse(argv=None):
                          "(nextdenovo_amd/stage.py: Exchange)")
     ap.add_argument("--analytic-piles", action="store_true",
                     help="run the overlap stage but feed the consensus stage with piles derived from the true read positions")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    small = args.config == 2
+    if args.steps is None:
+        args.steps = 8 if small else 2
+    if args.warmup is None:
+        args.warmup = 2 if small else 1
+    return args
 
 
 # ---- roofline bookkeeping -----------------------------------------------------------------------
