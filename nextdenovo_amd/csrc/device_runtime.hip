@@ -1008,6 +1008,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
     while (at < ids.size()) {
         size_t take = 0;
         uint64_t tw = 0, mr = 0, vw = 0;
+        uint32_t max_ring = 0;
         std::vector<AlnTask> patch;
         while (at + take < ids.size()) {
             AlnTask t = S.tasks[ids[at + take]];
@@ -1024,6 +1025,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
             tw += (uint64_t)t.max_d * rw;
             mr += (uint64_t)t.max_d;
             vw += ring;
+            max_ring = std::max(max_ring, ring);
             patch.push_back(t);
             take++;
         }
@@ -1044,7 +1046,7 @@ void DeviceAligner::run_wide(AlnJob **jobs, size_t n, const std::vector<int32_t>
         }
         S.h2d(S.d_wtasks.p, patch.data(), take * sizeof(AlnTask), st);
         S.h2d(S.d_ids.p, ids.data() + at, take * sizeof(int32_t), st);
-        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st, S.d_wtasks.p);
+        launch_ond_forward_wide(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_v.p, S.d_ids.p, (int)take, st, S.d_wtasks.p, max_ring);
         launch_ond_traceback(S.d_tasks.p, S.d_outs.p, S.d_pool.p, S.db_pool, trace.p, mink.p, S.d_ops.p, S.d_ids.p, (int)take, st, nullptr,
                              S.d_wtasks.p);
         HIP_CHECK(hipMemcpyAsync(S.h_outs.p + lo, S.d_outs.p + lo, (size_t)(hi - lo + 1) * sizeof(AlnOut), hipMemcpyDeviceToHost, st));

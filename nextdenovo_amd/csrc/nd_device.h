@@ -310,7 +310,8 @@ void launch_ond_traceback_seg(const AlnTask *tasks, AlnOut *outs, const uint32_t
                               uint32_t *ops, const TbArgs &tb, int n_tasks, void *stream);
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace, int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream,
-                             const AlnTask *wtasks = nullptr);  // wtasks: the listed tasks' records (wide-path fields), in list order
+                             const AlnTask *wtasks = nullptr, uint32_t max_ring = 0);
+constexpr size_t kWideLdsBytes = 64u << 10;   // the wide path keeps V rings up to this size in LDS (a workgroup's default limit)  // wtasks: the listed tasks' records (wide-path fields), in list order
 // task_ids == nullptr: tasks [0, n), traces in the register path's stream format, walked in the order `order` lists them
 // (device, n ids; nullptr = table order); otherwise the listed (wide-band) tasks, traces in the wide kernel's row format
 void launch_ond_traceback(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,

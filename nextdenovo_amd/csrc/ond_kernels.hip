@@ -325,6 +325,11 @@ __global__ __launch_bounds__(64) void ond_forward_kernel(const AlnTask *__restri
 // K7w: the same sweep with V[] in a global scratch ring and trace rows as wide as the band cap, for the rare alignments whose
 // live band exceeds the register path (exactness of the band-cap / edit-budget failure semantics).  Trace: row d = row_words
 // 64-bit words of move bits (bit c = diagonal min_k + 2c) + min_k in a side array.
+// LDSV: the V ring in the LDS of the compute unit (the launch's largest ring is at most 64 KB).  A launch of this path is a few dozen
+// wavefronts, each with a compute unit to itself, and lasts as long as its longest alignment: with the ring in global memory every
+// edit step read V[k - 1], V[k + 1] from and wrote V[k] to the caches and waited for the stores before the next step read them.
+constexpr int kWidePasses = 4;   // passes of a wide step whose snakes share a round of loads
+template <bool LDSV>
 __global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__restrict__ tasks, AlnOut *__restrict__ outs,
                                                           const uint32_t *__restrict__ pool,
                                                           const uint32_t *__restrict__ db_pool,
@@ -337,7 +342,8 @@ __global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__r
     const int tid = ids[blockIdx.x];
     const AlnTask T = wtasks ? wtasks[blockIdx.x] : tasks[tid];
     const int lane = (int)threadIdx.x;
-    int32_t *V = vscratch + T.v_off;
+    extern __shared__ int32_t wide_v[];
+    int32_t *V = LDSV ? wide_v : vscratch + T.v_off;
     const uint32_t vmask = T.v_mask;
 
     for (uint32_t i = (uint32_t)lane; i <= vmask; i += 64) V[i] = 0;  // the reference memsets V per alignment
@@ -369,39 +375,72 @@ __global__ __launch_bounds__(64) void ond_forward_wide_kernel(const AlnTask *__r
         int row_best = -1;
         bool done = false;
         int x_keep = 0;
-        for (int ps = 0; ps < npass; ps++) {
-            const int k = min_k + 2 * (ps * 64 + lane);
-            const bool act = k <= max_k;
-            int x = 0;
-            bool left = false;
-            if (act) {
-                const int vm = V[(uint32_t)(k - 1) & vmask];
-                const int vp = V[(uint32_t)(k + 1) & vmask];
-                // lib/align.c:443
-                const bool down = (k == min_k) || (k != max_k && vm < vp);
-                x = down ? vp : vm + 1;
-                left = !down;
-                x = snake64(qp, tp, q_sh, t_sh, q_len, t_len, x, k);  // (lib/align.c:452-455)
+        // The passes of a step are independent (every cell reads the step before: the other parity of V[]), so kWidePasses of them
+        // go side by side: their starts, then the first 64 bases of all their snakes in ONE round of loads -- every lane loads, a
+        // lane without a snake loads its sequence's first words: a load under a condition meets its default at a join and the join
+        // waits -- and then, pass by pass in order, what has an order: move bits, V[], the finish (smallest k first).
+        for (int ps0 = 0; ps0 < npass && !done; ps0 += kWidePasses) {
+            int xs[kWidePasses], rems[kWidePasses];
+            bool lefts[kWidePasses], acts[kWidePasses];
+            Bases64 qa[kWidePasses], tb[kWidePasses];
+#pragma unroll
+            for (int u = 0; u < kWidePasses; u++) {
+                const int k = min_k + 2 * ((ps0 + u) * 64 + lane);
+                const bool act = ps0 + u < npass && k <= max_k;
+                int x = 0;
+                bool left = false;
+                if (act) {
+                    const int vm = V[(uint32_t)(k - 1) & vmask];
+                    const int vp = V[(uint32_t)(k + 1) & vmask];
+                    // lib/align.c:443
+                    const bool down = (k == min_k) || (k != max_k && vm < vp);
+                    x = down ? vp : vm + 1;
+                    left = !down;
+                }
+                int rem = q_len - x;
+                const int rt = t_len - (x - k);
+                rem = rt < rem ? rt : rem;
+                if (!act) rem = 0;
+                xs[u] = x, lefts[u] = left, acts[u] = act, rems[u] = rem;
+                qa[u] = fetch64_rel(qp, q_sh + (uint32_t)(rem > 0 ? x : 0));
+                tb[u] = fetch64_rel(tp, t_sh + (uint32_t)(rem > 0 ? x - k : 0));
             }
-            const unsigned long long lb = __ballot(act && left);
-            if (lane == 0) trace[row0 + (uint64_t)d * row_words + (uint32_t)ps] = lb;
-            const int y = x - k;
-            const unsigned long long fb = __ballot(act && x >= q_len && y >= t_len);
-            if (act) {
-                V[(uint32_t)k & vmask] = x;
-                const int m = x + y;
-                row_best = m > row_best ? m : row_best;
+#pragma unroll
+            for (int u = 0; u < kWidePasses; u++) {
+                if (rems[u] > 0) {  // (lib/align.c:452-455)
+                    const uint32_t d0 = qa[u].w[0] ^ tb[u].w[0], d1 = qa[u].w[1] ^ tb[u].w[1], d2 = qa[u].w[2] ^ tb[u].w[2], d3 = qa[u].w[3] ^ tb[u].w[3];
+                    int m = d0 ? (__builtin_ctz(d0) >> 1) : d1 ? 16 + (__builtin_ctz(d1) >> 1) : d2 ? 32 + (__builtin_ctz(d2) >> 1) : d3 ? 48 + (__builtin_ctz(d3) >> 1) : 64;
+                    m = m < rems[u] ? m : rems[u];
+                    xs[u] += m;
+                    if (m == 64) xs[u] = snake64(qp, tp, q_sh, t_sh, q_len, t_len, xs[u], min_k + 2 * ((ps0 + u) * 64 + lane));
+                }
             }
-            x_keep = x;
-            if (fb) {
-                // several diagonals may finish in one step: the smallest k wins (lib/align.c:467-470)
-                const int fl = __ffsll((long long)fb) - 1;
-                fin_k = min_k + 2 * (ps * 64 + fl);
-                fin_x = __shfl(x, fl, 64);
-                fin_d = d;
-                status = ST_FINISHED;
-                done = true;
-                break;
+#pragma unroll
+            for (int u = 0; u < kWidePasses; u++) {
+                const int ps = ps0 + u;
+                if (ps >= npass || done) continue;
+                const int k = min_k + 2 * (ps * 64 + lane);
+                const bool act = acts[u];
+                const int x = xs[u];
+                const unsigned long long lb = __ballot(act && lefts[u]);
+                if (lane == 0) trace[row0 + (uint64_t)d * row_words + (uint32_t)ps] = lb;
+                const int y = x - k;
+                const unsigned long long fb = __ballot(act && x >= q_len && y >= t_len);
+                if (act) {
+                    V[(uint32_t)k & vmask] = x;
+                    const int m = x + y;
+                    row_best = m > row_best ? m : row_best;
+                }
+                x_keep = x;
+                if (fb) {
+                    // several diagonals may finish in one step: the smallest k wins (lib/align.c:467-470)
+                    const int fl = __ffsll((long long)fb) - 1;
+                    fin_k = min_k + 2 * (ps * 64 + fl);
+                    fin_x = __shfl(x, fl, 64);
+                    fin_d = d;
+                    status = ST_FINISHED;
+                    done = true;
+                }
             }
         }
         if (done) break;
@@ -965,10 +1004,16 @@ void launch_ond_traceback_seg(const AlnTask *tasks, AlnOut *outs, const uint32_t
 void launch_ond_forward_wide(const AlnTask *tasks, AlnOut *outs, const uint32_t *pool, const uint32_t *db_pool,
                              uint64_t *trace,
                              int32_t *trace_mink, int32_t *vscratch, const int32_t *task_ids, int n_ids, void *stream,
-                             const AlnTask *wtasks) {
+                             const AlnTask *wtasks, uint32_t max_ring) {
     if (n_ids <= 0) return;
-    hipLaunchKernelGGL(ond_forward_wide_kernel, dim3((unsigned)n_ids), dim3(64), 0, (hipStream_t)stream, tasks, outs,
-                       pool, db_pool, trace, trace_mink, vscratch, task_ids, wtasks);
+    // (max_ring: the largest V ring among the listed tasks, in ints; 0: unknown -- the rings stay in `vscratch`.  NDGPU_WIDE_LDS=0: A/B)
+    static const bool lds_ok = !getenv("NDGPU_WIDE_LDS") || atoi(getenv("NDGPU_WIDE_LDS")) != 0;
+    if (lds_ok && max_ring && (size_t)max_ring * sizeof(int32_t) <= kWideLdsBytes)
+        hipLaunchKernelGGL(ond_forward_wide_kernel<true>, dim3((unsigned)n_ids), dim3(64), (size_t)max_ring * sizeof(int32_t), (hipStream_t)stream,
+                           tasks, outs, pool, db_pool, trace, trace_mink, vscratch, task_ids, wtasks);
+    else
+        hipLaunchKernelGGL(ond_forward_wide_kernel<false>, dim3((unsigned)n_ids), dim3(64), 0, (hipStream_t)stream, tasks, outs,
+                           pool, db_pool, trace, trace_mink, vscratch, task_ids, wtasks);
 }
 
 // task_ids == nullptr: every task of the table, traces in the register path's stream format -- in the order `order` lists them
